@@ -1,0 +1,96 @@
+"""Pin the oracle (oracle/proxytta_oracle.py) to the golden vectors produced by the real
+reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import proxytta_oracle as O
+from proxytta import synth
+
+CASES = [('msgchn_1layer_32x48', 'meta_selfsup_seq_1layer_ema'),
+         ('msgchn_1layer_64x96', 'meta_selfsup_seq_1layer_ema'),
+         ('msgchn_1layer_36x52_pad', 'meta_selfsup_seq_1layer_ema'),
+         ('msgchn_1layer_32x48_n2', 'meta_selfsup_seq_1layer_ema'),
+         ('msgchn_1layer_32x48_wcos1', 'meta_selfsup_seq_1layer_ema'),
+         ('msgchn_2layers_32x48', 'meta_selfsup_seq_2layers_ema')]
+
+
+def rel_mae(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    # gradients that are analytically zero (a conv bias feeding a BatchNorm) are pure rounding
+    # noise ~1e-9 on both sides: floor the denominator so they compare as equal
+    return float(np.abs(a - b).mean() / max(np.abs(b).mean(), 1e-4))
+
+
+@pytest.mark.parametrize('name,mode', CASES)
+def test_oracle_matches_reference(golden_dir, name, mode):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid, gain = [float(x) for x in g['hp']]
+    torch.set_num_threads(4)
+    o = O.MsgChnOracle(synth.formula_state_dict(mode, gain), mode, max_input_depth=mid, lr=lr,
+                       betas=(b1, b2), eps=eps, weight_decay=wd, w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
+    # 2layers: the noise-driven bias (see below) leaks into the next BN's running mean and into
+    # the eval forward, which uses running statistics
+    buf_tol, eval_tol = (2e-3, 2e-4) if '2layers' in mode else (1e-5, 1e-5)
+    for s in range(steps):
+        image, sparse = [torch.from_numpy(x) for x in synth.synthetic_frame(s, h, w, n)]
+        r = o.step(image, sparse)
+        p = 's%d/' % s
+        assert rel_mae(r['depth'], g[p + 'depth_train']) < 1e-5
+        idx = g[p + 'row_idx']
+        assert tuple(r['emb'].shape) == tuple(g[p + 'emb_shape'])
+        assert rel_mae(r['emb'][idx], g[p + 'emb_rows']) < 1e-4
+        assert rel_mae(r['ref'][idx], g[p + 'ref_rows']) < 1e-4
+        li = r['loss_info']
+        got = [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']]
+        np.testing.assert_allclose(got, g[p + 'loss_info'], rtol=2e-5)
+        for k in o.names:
+            assert rel_mae(r['grads'][k], g[p + 'grad/' + k]) < 2e-4, k
+            if np.abs(g[p + 'grad/' + k]).max() < 1e-6:
+                # analytically-zero gradient (conv bias in front of a BatchNorm): Adam turns the
+                # ~1e-9 rounding noise into +-lr moves, in the reference too; bound, don't match
+                assert np.abs(o.P[k].detach().numpy() - g[p + 'param/' + k]).max() <= 2.5 * lr * (s + 1)
+                continue
+            assert rel_mae(o.P[k].detach(), g[p + 'param/' + k]) < 1e-5, k
+        for i, k in enumerate(o.names):
+            assert rel_mae(o.opt.m[i], g[p + 'exp_avg/' + k]) < 2e-4
+            assert rel_mae(o.opt.v[i], g[p + 'exp_avg_sq/' + k]) < 4e-4
+        for k in g.files:
+            if k.startswith(p + 'buf/'):
+                assert rel_mae(o.P[k[len(p) + 4:]], g[k]) < buf_tol, k
+        d_eval = o.forward_eval(image, sparse)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < eval_tol
+
+
+def test_adapt_loss_gate(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'adapt_loss_gate.npz'))
+    h, w, n, rows, dim = [int(x) for x in g['meta']]
+    image, sparse = [torch.from_numpy(x) for x in synth.synthetic_frame(11, h, w, n, density=0.1)]
+    validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+    u = lambda tag, *shape: torch.from_numpy(
+        (synth.hash_uniform(tag, int(np.prod(shape))) * 2 - 1).reshape(shape).astype(np.float32))
+    for tag in ('near', 'far'):
+        depth = (20 + 10 * u('gate/depth', n, 1, h, w)).requires_grad_(True)
+        emb = u('gate/emb', rows, dim)
+        ref = (emb + float(g[tag + '/noise']) * u('gate/noise' + tag, rows, dim)).requires_grad_(True)
+        loss, info = O.adapt_loss(image, depth, sparse, validity, emb, ref, 1.0, 2.0, 0.1, 80.0)
+        loss.backward()
+        got = [float(info[k]) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')]
+        np.testing.assert_allclose(got, g[tag + '/loss_info'], rtol=1e-5)
+        np.testing.assert_allclose(depth.grad.numpy(), g[tag + '/grad_depth'], rtol=1e-5, atol=1e-9)
+        gr = ref.grad.numpy() if ref.grad is not None else np.zeros((rows, dim), np.float32)
+        np.testing.assert_allclose(gr, g[tag + '/grad_ref'], rtol=1e-4, atol=1e-9)
+    assert g['near/loss_info'][3] < 0.3 < g['far/loss_info'][3]   # both sides of the gate
+
+
+def test_outlier_removal(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'outlier_removal.npz'))
+    _, sparse = synth.synthetic_frame(7, 40, 56, 2, density=0.2, dmin=1.0, dmax=20.0)
+    sparse = torch.from_numpy(sparse)
+    validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+    sd, vm = O.remove_outliers(sparse, validity, 7, 1.5)
+    np.testing.assert_array_equal(sd.numpy(), g['sparse_out'])
+    np.testing.assert_array_equal(vm.numpy(), g['validity_out'])

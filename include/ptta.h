@@ -1,0 +1,115 @@
+/* libptta_hip — C ABI of the MI355X-native ProxyTTA test-time-adaptation step (MSG_CHN backbone).
+ *
+ * This is the drop-in boundary for the hot path of seobbro/TTA-depth-completion.  The reference
+ * has no FFI for this path (it is Python calling ATen); each entry point below names the Python
+ * call(s) it replaces, file:line relative to the reference root.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; tensors are the reference's
+ *     own layouts: images (N,3,H,W), depth maps (N,1,H,W), embeddings (rows,512), all fp32,
+ *     contiguous.  Weights are passed as the reference's state_dict tensors (fp32, NCHW) and are
+ *     re-packed internally.
+ *   - all work is enqueued on the hipStream_t argument (pass torch.cuda.current_stream()); no
+ *     call synchronises the device or allocates after ptta_create.
+ *   - return value 0 = ok, <0 = error; ptta_last_error() returns a message.  Nothing is printed.
+ *   - one handle per (process, GPU); a handle is not thread-safe.
+ */
+#ifndef PTTA_H
+#define PTTA_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ptta_ctx* ptta_handle;
+typedef void* ptta_stream;              /* hipStream_t */
+
+enum { PTTA_BACKBONE_MSG_CHN = 0 };
+enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
+enum { PTTA_META_1LAYER = 0 };
+
+/* Hyper-parameters of the step.  Reference: src/tta.py:10-160 flags learning_rates,
+ * optimizer_betas, optimizer_epsilon, w_weight_decay, w_loss_sparse_depth, w_loss_smoothness,
+ * w_loss_cos, max_input_depth (forwarded positionally to src/tta_main.py:23-100). */
+typedef struct {
+    float lr, beta1, beta2, eps, weight_decay;
+    float w_sparse_depth, w_smoothness, w_cos;
+    float max_input_depth;              /* < 0: no clamp (max_input_depth=None) */
+} ptta_hparams;
+
+/* ExternalModel_Adapt(model_name='msg_chn', ...) + _prepare_head(prepare_mode)
+ * (src/external_model_adapt.py:46-80, :561; network_exp_msg_chn_adapt.py:1022-1087).
+ * n, height, width: batch and frame size of every later call.  Shapes not divisible by 16 run
+ * the reference's dual-corner padding (src/msg_chn_model_adapt.py:60-123) internally. */
+int ptta_create(ptta_handle* out, int backbone, int meta_mode, int n, int height, int width, int dtype,
+                const ptta_hparams* hp_host);
+void ptta_destroy(ptta_handle h);
+const char* ptta_last_error(ptta_handle h);
+
+/* optimizer.param_groups[i]['lr'] = ... (src/tta_main.py:507-512) and the loss weights. */
+int ptta_set_hparams(ptta_handle h, const ptta_hparams* hp_host, ptta_stream s);
+
+/* restore_model -> load_state_dict(checkpoint['net']) (src/msg_chn_model_adapt.py:482-501), one
+ * call per state_dict key.  Frozen tensors are copied and re-packed; BatchNorm buffers
+ * (*.running_mean / *.running_var / *.num_batches_tracked) are BOUND: the pointer is kept and
+ * updated in place by every training-mode forward, as nn.BatchNorm1d does.  Unknown keys: error. */
+int ptta_load_weights(ptta_handle h, const char* name, const void* tensor, const int64_t* shape, int ndim,
+                      ptta_stream s);
+
+/* adapt_parameters(mode='meta') + torch.optim.Adam state (src/msg_chn_model_adapt.py:392-396,
+ * src/tta_main.py:339-346).  The caller keeps ownership of the parameter and of the Adam moments
+ * exp_avg / exp_avg_sq (fp32, same shape); the library reads the parameter on every forward and
+ * ptta_step / ptta_adam_step update all three in place.  name: "conv1_rgb_meta.weight" | ".bias". */
+int ptta_bind_adapted(ptta_handle h, const char* name, float* param, float* exp_avg, float* exp_avg_sq);
+int ptta_set_adam_step(ptta_handle h, int step, ptta_stream s);      /* optimizer.state[p]['step'] */
+int ptta_get_adam_step(ptta_handle h, int* step_host, ptta_stream s); /* synchronises s */
+
+/* model.train(); model.forward(image, sparse_depth, loss_type='adapt_meta_selfsup_seq_ema_reverse')
+ * (src/tta_main.py:610 -> external_model_adapt.py:82-114 -> msg_chn_model_adapt.py:54-125 ->
+ * network_exp_msg_chn_adapt.py:463-557).  Outputs: depth (N,1,H,W), emb/ref (rows,512) with
+ * rows = ptta_embedding_rows(h).  Activations needed by ptta_backward stay in the handle. */
+int ptta_forward_train(ptta_handle h, const float* image, const float* sparse_depth,
+                       float* depth_out, float* emb_out, float* ref_out, ptta_stream s);
+int64_t ptta_embedding_rows(ptta_handle h);
+
+/* model.eval(); with no_grad: model.forward(...) (src/tta_main.py:729-736). */
+int ptta_forward_eval(ptta_handle h, const float* image, const float* sparse_depth, float* depth_out, ptta_stream s);
+
+/* model.compute_loss(..., loss_type='adapt') (src/external_model_adapt.py:119-203, :371-441).
+ * loss_info_out[4] (device) = {loss, loss_smooth, loss_sparse_depth, loss_cos}.  emb/ref may be
+ * NULL (loss_cos = 0).  The backward half writes dL/d(depth) (N,1,H,W) and dL/d(ref) (rows,512). */
+int ptta_loss_forward(ptta_handle h, const float* loss_image, const float* depth, const float* sparse_depth,
+                      const float* validity, const float* emb, const float* ref, int64_t rows,
+                      float w_sparse_depth, float w_smoothness, float w_cos, float* loss_info_out, ptta_stream s);
+int ptta_loss_backward(ptta_handle h, const float* loss_image, const float* depth, const float* sparse_depth,
+                       const float* validity, const float* emb, const float* ref, int64_t rows,
+                       float* grad_depth_out, float* grad_ref_out, ptta_stream s);
+
+/* loss.backward() restricted to the adapted parameters (src/tta_main.py:632): consumes
+ * dL/d(depth) and dL/d(ref) of the last ptta_forward_train and writes the gradients of
+ * conv1_rgb_meta.{weight (32,32,3,3), bias (32)}. */
+int ptta_backward(ptta_handle h, const float* grad_depth, const float* grad_ref,
+                  float* grad_meta_weight_out, float* grad_meta_bias_out, ptta_stream s);
+
+/* optimizer.step() for the bound parameters with explicit gradients (src/tta_main.py:633). */
+int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* grad_meta_bias, ptta_stream s);
+
+/* One whole TTA step = src/tta_main.py:610-633: forward_train + compute_loss + zero_grad +
+ * backward + optimizer.step, in one enqueue.  `image` feeds the network, `loss_image` the
+ * smoothness weights (tta_main.py:610 vs :620; may be the same pointer).  validity NULL =>
+ * where(sparse>0,1,sparse) (tta_main.py:583-586).  Optional outputs may be NULL. */
+int ptta_step(ptta_handle h, const float* image, const float* loss_image, const float* sparse_depth,
+              const float* validity, float* depth_out, float* loss_info_out, ptta_stream s);
+
+/* Test / debug hooks (not on the hot path). */
+int ptta_debug_tensor(ptta_handle h, const char* name, float* dst, int64_t capacity, int64_t* numel_host, ptta_stream s);
+int ptta_op_conv32(const float* in_nhwc, const float* weight, const float* bias, float* out_nhwc,
+                   int b, int hin, int win, int mode, int relu_in, int in_major, int flip, int dtype, int naive,
+                   ptta_stream s);
+int ptta_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,224 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the golden vectors produced by the
+real reference and against the oracle on the same seeded inputs.  Tolerances are the ones of
+BASELINE.json's north_star: float32, relative MAE <= 1e-3 on depth maps (we hold fp32 mode to
+1e-4 or better); bf16 mode is reported separately in test_gpu_bf16.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from proxytta import synth
+from tests.util import ONE, golden_hp, make_engine, rel_mae
+
+pytestmark = pytest.mark.gpu
+
+CASES = ['msgchn_1layer_32x48', 'msgchn_1layer_64x96', 'msgchn_1layer_36x52_pad', 'msgchn_1layer_32x48_n2',
+         'msgchn_1layer_32x48_wcos1']
+
+
+def _torch_conv(x_nhwc, w, b, mode, relu):
+    import torch.nn.functional as F
+    x = x_nhwc.permute(0, 3, 1, 2)
+    if relu:
+        x = F.relu(x)
+    if mode == 0:
+        y = F.conv2d(x, w, b, padding=1)
+    elif mode == 1:
+        y = F.conv2d(x, w, b, stride=2, padding=1)
+    else:
+        y = F.conv_transpose2d(x, w, b, stride=2, padding=1, output_padding=1)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('naive', [True, False])
+@pytest.mark.parametrize('mode', [0, 1, 2])
+@pytest.mark.parametrize('relu', [False, True])
+def test_op_conv32_forward(mode, relu, naive):
+    from proxytta.engine import op_conv32
+    g = torch.Generator().manual_seed(mode * 7 + relu)
+    x = torch.randn(2, 12, 44, 32, generator=g)            # W=44: one full and one ragged 32-pixel tile
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.1        # asymmetric in (out, in, ky, kx)
+    b = torch.randn(32, generator=g)
+    ref = _torch_conv(x, w, b, mode, relu)
+    got = op_conv32(x.cuda(), w.cuda(), b.cuda(), mode, relu_in=relu, in_major=(mode == 2), naive=naive).cpu()
+    assert got.shape == ref.shape
+    assert rel_mae(got, ref) < 2e-6
+
+
+@pytest.mark.parametrize('naive', [True, False])
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_op_conv32_input_gradient(mode, naive):
+    """The backward re-packings (in_major / flip) reproduce autograd's conv backward-data."""
+    from proxytta.engine import op_conv32
+    g = torch.Generator().manual_seed(100 + mode)
+    x = torch.randn(1, 8, 36, 32, generator=g, requires_grad=True)
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.1
+    y = _torch_conv(x, w, None, mode, False)
+    gy = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, x, gy)
+    # S1 -> S1 (transposed+flipped); S2 -> T2 (in-major); T2 -> S2 (as stored)
+    bmode, in_major, flip = {0: (0, True, True), 1: (2, True, False), 2: (1, False, False)}[mode]
+    got = op_conv32(gy.cuda(), w.cuda(), None, bmode, in_major=in_major, flip=flip, naive=naive).cpu()
+    assert rel_mae(got, gx) < 2e-6
+
+
+def test_op_conv32_bf16():
+    from proxytta.engine import op_conv32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 8, 64, 32, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.1
+    b = torch.randn(32, generator=g)
+    for mode in (0, 1, 2):
+        xr = x.bfloat16().float()
+        wr = w.bfloat16().float()
+        ref = _torch_conv(xr, wr, b, mode, True)
+        got = op_conv32(x.cuda(), w.cuda(), b.cuda(), mode, relu_in=True, in_major=(mode == 2), dtype='bf16').cpu()
+        assert rel_mae(got, ref) < 4e-3        # output rounded to bf16
+
+
+def _run_golden(name, impl, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, impl)
+    for s in range(steps):
+        image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)]
+        p = 's%d/' % s
+        bufs = {k: v.clone() for k, v in sd.items() if k.endswith(('running_mean', 'running_var'))}
+        # split call first, fused step second
+        depth, emb, ref = eng.forward_train(image, sparse)
+        assert rel_mae(depth, g[p + 'depth_train']) < 1e-4, (name, s)
+        idx = g[p + 'row_idx']
+        assert tuple(emb.shape) == tuple(g[p + 'emb_shape'])
+        assert rel_mae(emb.cpu()[idx], g[p + 'emb_rows']) < 2e-4
+        assert rel_mae(ref.cpu()[idx], g[p + 'ref_rows']) < 2e-4
+        # forward_train just updated the BatchNorm1d running stats: put them back so that the fused
+        # step below starts from the state the reference saw
+        for k, v in bufs.items():
+            sd[k].copy_(v)
+        info, depth2 = eng.step(image, sparse, want_depth=True)
+        torch.cuda.synchronize()
+        assert rel_mae(depth2, g[p + 'depth_train']) < 1e-4
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=1e-4)
+        gw, gb = eng.debug_tensor('gW').view(32, 32, 3, 3), eng.debug_tensor('gB')
+        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < 1e-3, (name, s)
+        assert rel_mae(gb, g[p + 'grad/conv1_rgb_meta.bias']) < 1e-3
+        for k, (prm, m, v) in adapted.items():
+            assert rel_mae(prm, g[p + 'param/' + k]) < 2e-5, k
+            assert rel_mae(m, g[p + 'exp_avg/' + k]) < 1e-3
+            assert rel_mae(v, g[p + 'exp_avg_sq/' + k]) < 2e-3
+        for k in g.files:
+            if k.startswith(p + 'buf/'):
+                key = k[len(p) + 4:]
+                if key.startswith('proj_t'):
+                    continue
+                assert rel_mae(sd[key], g[k]) < 1e-4, k
+        d_eval = eng.forward_eval(image, sparse)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-4
+    assert eng.adam_step_count() == steps
+    eng.close()
+
+
+@pytest.mark.parametrize('impl', ['naive', None])
+@pytest.mark.parametrize('name', CASES)
+def test_step_matches_reference_golden(golden_dir, name, impl):
+    _run_golden(name, impl, golden_dir)
+
+
+def test_loss_gate(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'adapt_loss_gate.npz'))
+    h, w, n, rows, dim = [int(x) for x in g['meta']]
+    eng, _, _ = make_engine(n, h, w, 'fp32', dict(max_input_depth=80.0))
+    image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(11, h, w, n, density=0.1)]
+    validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+    u = lambda tag, *shape: torch.from_numpy(
+        (synth.hash_uniform(tag, int(np.prod(shape))) * 2 - 1).reshape(shape).astype(np.float32)).cuda()
+    for tag in ('near', 'far'):
+        depth = 20 + 10 * u('gate/depth', n, 1, h, w)
+        emb = u('gate/emb', rows, dim)
+        ref = emb + float(g[tag + '/noise']) * u('gate/noise' + tag, rows, dim)
+        info = eng.loss_forward(image, depth, sparse, validity, emb, ref, 1.0, 2.0, 0.1)
+        gd, gr = eng.loss_backward(image, depth, sparse, validity, emb, ref)
+        np.testing.assert_allclose(info.cpu().numpy(), g[tag + '/loss_info'], rtol=2e-5)
+        np.testing.assert_allclose(gd.cpu().numpy(), g[tag + '/grad_depth'], rtol=1e-4, atol=1e-8)
+        np.testing.assert_allclose(gr.cpu().numpy(), g[tag + '/grad_ref'], rtol=2e-4, atol=1e-9)
+    eng.close()
+
+
+def test_against_oracle_midsize():
+    """128x256 (not in the golden set): fused step and eval forward against the oracle."""
+    from oracle import proxytta_oracle as O
+    n, h, w = 1, 128, 256
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, w_sparse_depth=1.0, w_smoothness=2.0,
+              w_cos=0.1, max_input_depth=80.0)
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', hp)
+    o = O.MsgChnOracle(synth.formula_state_dict(ONE), ONE, max_input_depth=80.0, lr=1e-3, weight_decay=1e-4,
+                       w_sd=1.0, w_sm=2.0, w_cos=0.1)
+    for s in range(2):
+        image, sparse = synth.synthetic_frame(40 + s, h, w, n)
+        r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+        info, depth = eng.step(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda(), want_depth=True)
+        assert rel_mae(depth, r['depth']) < 1e-4
+        li = r['loss_info']
+        np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=1e-4)
+        for k, (prm, m, v) in adapted.items():
+            assert rel_mae(prm, o.P[k].detach()) < 2e-5
+        d_eval = eng.forward_eval(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())
+        assert rel_mae(d_eval, o.forward_eval(torch.from_numpy(image), torch.from_numpy(sparse))) < 1e-4
+    eng.close()
+
+
+def test_facade_reference_style_driver(golden_dir):
+    """tta_main-style loop (forward / compute_loss / zero_grad / backward / optimizer.step) through the
+    ExternalModel_Adapt mirror gives the same numbers as the golden run."""
+    from proxytta.model import CANONICAL_LOSS_TYPE, ExternalModel_Adapt
+    g = np.load(os.path.join(golden_dir, 'msgchn_1layer_32x48.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    model = ExternalModel_Adapt('msg_chn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], device=torch.device('cuda'))
+    model._prepare_head(ONE)
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict(ONE, gain).items()})
+    params = model.adapt_parameters(mode='meta')
+    opt = torch.optim.Adam(params, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'])
+    for s in range(steps):
+        image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)]
+        validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+        model.train()
+        depth, emb, ref = model.forward(image=image, sparse_depth=sparse, loss_type=CANONICAL_LOSS_TYPE)
+        loss, info = model.compute_loss(input_rgb=image, output_depth=depth, sparse_depth=sparse, validity_map=validity,
+                                        embedding=emb, reference=ref, w_loss_sparse_depth=hp['w_sparse_depth'],
+                                        w_loss_smoothness=hp['w_smoothness'], w_loss_cos=hp['w_cos'], loss_type='adapt')
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        p = 's%d/' % s
+        assert abs(float(loss) - g[p + 'loss_info'][0]) < 1e-4 * abs(g[p + 'loss_info'][0])
+        for k, prm in zip(('conv1_rgb_meta.weight', 'conv1_rgb_meta.bias'), params):
+            assert rel_mae(prm.grad, g[p + 'grad/' + k]) < 1e-3
+            assert rel_mae(prm, g[p + 'param/' + k]) < 2e-5
+        model.eval()
+        with torch.no_grad():
+            d_eval = model.forward(image=image, sparse_depth=sparse, loss_type=CANONICAL_LOSS_TYPE)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-4
+
+
+def test_full_size_properties():
+    """352x1216 (BASELINE config): finite, deterministic bit-for-bit across two handles, Adam moves
+    the parameters, and the eval depth after the step differs from before."""
+    n, h, w = 1, 352, 1216
+    hp = dict(w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
+    image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(0, h, w, n)]
+    outs = []
+    for _ in range(2):
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp)
+        before = eng.forward_eval(image, sparse).clone()
+        info, depth = eng.step(image, sparse, want_depth=True)
+        after = eng.forward_eval(image, sparse)
+        torch.cuda.synchronize()
+        assert torch.isfinite(info).all() and torch.isfinite(depth).all() and torch.isfinite(after).all()
+        assert (after - before).abs().max() > 0
+        outs.append((info.cpu(), depth.cpu(), after.cpu(), adapted['conv1_rgb_meta.weight'][0].cpu().clone()))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

@@ -1,0 +1,41 @@
+"""Shared helpers for the GPU parity tests."""
+import os
+
+import numpy as np
+import torch
+
+from proxytta import synth
+
+ONE = 'meta_selfsup_seq_1layer_ema'
+
+
+def rel_mae(a, b, floor=1e-4):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, np.float64)
+    return float(np.abs(a - b).mean() / max(np.abs(b).mean(), floor))
+
+
+def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None):
+    """Engine with formula weights; returns (engine, state dict on device, adapted dict)."""
+    from proxytta.engine import ADAPTED, Engine
+    if impl is None:
+        os.environ.pop('PTTA_CONV_IMPL', None)
+    else:
+        os.environ['PTTA_CONV_IMPL'] = impl
+    hp = dict(hp or {})
+    eng = Engine(n, h, w, dtype=dtype, **hp)
+    os.environ.pop('PTTA_CONV_IMPL', None)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(ONE, gain).items()}
+    eng.load_state_dict(sd)
+    adapted = {}
+    for name in ADAPTED:
+        p = sd[name]
+        adapted[name] = (p, torch.zeros_like(p), torch.zeros_like(p))
+        eng.bind_adapted(name, *adapted[name])
+    return eng, sd, adapted
+
+
+def golden_hp(g):
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid, gain = [float(x) for x in g['hp']]
+    return dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm,
+                w_cos=w_cos, max_input_depth=mid), gain

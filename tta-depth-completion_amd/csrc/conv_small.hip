@@ -1,0 +1,233 @@
+// First-layer and prediction convolutions of the MSG_CHN cascade: the ones that are NOT dense
+// 32x32 contractions (network_exp_msg_chn_adapt.py: RGBEncoder.init[0] 3->32 :218, DepthEncoder
+// .init[0] {1,2}->32 :172, DepthDecoder.prdct[3] 32->1 :291) and their input gradients.
+//
+//  * conv_in  : planar fp32 inputs with 1..3 channels -> 32-channel NHWC.  K = 9*cin <= 27 is
+//               padded to an even number and run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32)
+//               so that the output fragment, and therefore the fused epilogue and the full-line
+//               NHWC stores, are identical to conv32.  Inputs stay fp32 in both precision modes.
+//               Also used as the input gradient of the 32->1 prediction conv (1 -> 32, flipped).
+//  * conv_out1: 32-channel NHWC -> 1 planar fp32 channel, one lane per output pixel, HBM-bound
+//               (reads each 128-B pixel line once from HBM, 8 more times from L1/L2).
+//               Also the input gradient of conv_in w.r.t. one of its input planes.
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+template <typename T>
+struct ConvInP {
+    Plane pl[3]; int zero_from_b;
+    const float* w;
+    Epi<T> epi;
+    int B, H, W;
+};
+
+template <typename T, int CIN>
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(ConvInP<T> p) {
+    constexpr int K = 9 * CIN;
+    constexpr int NS = (K + 1) / 2;
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float w[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) w[s] = p.w[s * 64 + lane];
+
+    const int nseg = (p.W + 31) >> 5;
+    const long nitems = (long)p.B * nseg * p.H;
+    const float sy = up_scale(p.H >> 1, p.H), sx = up_scale(p.W >> 1, p.W);
+    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+        long t_ = item;
+        const int y = (int)(t_ % p.H); t_ /= p.H;
+        const int seg = (int)(t_ % nseg);
+        const int b = (int)(t_ / nseg);
+        const int x0 = seg << 5;
+        const bool live = (x0 + i) < p.W && b < p.zero_from_b;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // lane half h contributes k = 2s + h -> (tap, ci); both candidates are compile-time
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            const int c0 = k0 % CIN, c1 = (k1 < K) ? (k1 % CIN) : 0;
+            const int tap = h ? (k1 / CIN) : (k0 / CIN);
+            const bool kval = h ? (k1 < K) : true;
+            const int yi = y + tap / 3 - 1, xi = x0 + i + tap % 3 - 1;
+            const float* pp = h ? p.pl[c1].p : p.pl[c0].p;          // static plane indices
+            const int pnb = h ? p.pl[c1].nb : p.pl[c0].nb;
+            const long pbs = h ? p.pl[c1].bstride : p.pl[c0].bstride;
+            float a = 0.f;
+            if (live && kval && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W)
+                a = pp[(size_t)(b % pnb) * pbs + (size_t)yi * p.W + xi];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[s], acc, 0, 0, 0);
+        }
+        Lerp ly = {0, 0, 0.f, 0.f};
+        if (p.epi.up) ly = lerp_coef(y, p.H >> 1, sy);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = x0 + acc_row(r, h);
+            if (px >= p.W) continue;
+            Lerp lx = {0, 0, 0.f, 0.f};
+            if (p.epi.up) lx = lerp_coef(px, p.W >> 1, sx);
+            epi_store<T>(p.epi, b, y, px, p.H, p.W, i, acc[r], ly, lx);
+        }
+    }
+}
+
+template <typename T>
+__global__ void conv_in_naive_kernel(ConvInP<T> p, int cin) {
+    const long total = (long)p.B * p.H * p.W * 32;
+    const float sy = up_scale(p.H >> 1, p.H), sx = up_scale(p.W >> 1, p.W);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx & 31);
+        long t_ = idx >> 5;
+        const int x = (int)(t_ % p.W); t_ /= p.W;
+        const int y = (int)(t_ % p.H);
+        const int b = (int)(t_ / p.H);
+        float acc = 0.f;
+        if (b < p.zero_from_b)
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yi = y + tap / 3 - 1, xi = x + tap % 3 - 1;
+                if (yi < 0 || yi >= p.H || xi < 0 || xi >= p.W) continue;
+                for (int ci = 0; ci < cin; ++ci) {
+                    const Plane& pl = p.pl[ci];
+                    acc = fmaf(pl.p[(size_t)(b % pl.nb) * pl.bstride + (size_t)yi * p.W + xi],
+                               p.w[(tap * cin + ci) * 32 + co], acc);
+                }
+            }
+        Lerp ly = {0, 0, 0.f, 0.f}, lx = {0, 0, 0.f, 0.f};
+        if (p.epi.up) { ly = lerp_coef(y, p.H >> 1, sy); lx = lerp_coef(x, p.W >> 1, sx); }
+        epi_store<T>(p.epi, b, y, x, p.H, p.W, co, acc, ly, lx);
+    }
+}
+
+__global__ void pack_conv_in_kernel(const float* __restrict__ src, int cin_total, int cin_first, int cin,
+                                    int transpose_flip, float* wfrag, float* wcanon) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over 14*64 fragment slots
+    if (idx >= 14 * 64) return;
+    const int lane = idx & 63, s = idx >> 6;
+    const int co = lane & 31, h = lane >> 5;
+    const int k = 2 * s + h;
+    float v = 0.f;
+    if (k < 9 * cin) {
+        const int tap = k / cin, ci = k % cin;
+        v = transpose_flip ? src[(size_t)co * 9 + (8 - tap)]
+                           : src[((size_t)co * cin_total + cin_first + ci) * 9 + tap];
+        wcanon[(tap * cin + ci) * 32 + co] = v;
+    }
+    wfrag[idx] = v;
+}
+
+void ptta_pack_conv_in(const float* src, int cin_total, int cin_first, int cin, int transpose_flip,
+                       float* wfrag, float* wcanon, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_in_kernel, dim3(4), dim3(256), 0, s, src, cin_total, cin_first, cin,
+                       transpose_flip, wfrag, wcanon);
+}
+
+template <typename T>
+static int launch_conv_in_t(const ConvInArgs& a, hipStream_t s) {
+    ConvInP<T> p;
+    for (int c = 0; c < 3; ++c) { p.pl[c] = a.pl[c]; if (p.pl[c].nb < 1) p.pl[c].nb = 1; }
+    p.zero_from_b = a.zero_from_b;
+    p.epi.bias = a.bias;
+    p.epi.up = (const T*)a.up; p.epi.up_nb = a.up_nb > 0 ? a.up_nb : 1;
+    p.epi.mask = (const T*)a.mask; p.epi.mask_nb = a.mask_nb > 0 ? a.mask_nb : 1;
+    p.epi.add1 = (const T*)a.add1; p.epi.add1_nb = a.add1_nb > 0 ? a.add1_nb : 1;
+    p.epi.add2 = nullptr; p.epi.add2_nb = 1;
+    p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = (T*)a.out_sum;
+    p.B = a.B; p.H = a.H; p.W = a.W;
+    if (a.naive) {
+        p.w = a.wcanon;
+        const long total = (long)p.B * p.H * p.W * 32;
+        int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL((conv_in_naive_kernel<T>), dim3(blocks), dim3(256), 0, s, p, a.cin);
+    } else {
+        p.w = a.wfrag;
+        const long items = (long)p.B * ((p.W + 31) / 32) * p.H;
+        long blocks = (items + 3) / 4; if (blocks > 2048) blocks = 2048;
+        if (a.cin == 1) hipLaunchKernelGGL((conv_in_mfma_kernel<T, 1>), dim3((int)blocks), dim3(256), 0, s, p);
+        else if (a.cin == 2) hipLaunchKernelGGL((conv_in_mfma_kernel<T, 2>), dim3((int)blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_in_mfma_kernel<T, 3>), dim3((int)blocks), dim3(256), 0, s, p);
+    }
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+int ptta_launch_conv_in(const ConvInArgs& a, hipStream_t s) {
+    if (a.cin < 1 || a.cin > 3) return -22;
+    return a.bf16 ? launch_conv_in_t<bf16_t>(a, s) : launch_conv_in_t<float>(a, s);
+}
+
+// ---- 32 -> 1 ------------------------------------------------------------------------------------
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void conv_out1_kernel(const T* __restrict__ in, int in_nb, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, const float* __restrict__ add,
+                                                        int add_nb, float* __restrict__ out, int B, int H, int W) {
+    __shared__ float ws[288];
+    for (int k = threadIdx.x; k < 288; k += blockDim.x) ws[k] = w[k];
+    __syncthreads();
+    const long total = (long)B * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        long t_ = idx / W;
+        const int y = (int)(t_ % H);
+        const int b = (int)(t_ / H);
+        const T* inb = in + (size_t)(b % in_nb) * H * W * 32;
+        float acc = bias ? bias[0] : 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yi = y + tap / 3 - 1, xi = x + tap % 3 - 1;
+            if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
+            const T* src = inb + ((size_t)yi * W + xi) * 32;
+            if (sizeof(T) == 4) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float4 v = *(const float4*)((const float*)src + 4 * q);
+                    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    const float* wq = ws + tap * 32 + 4 * q;
+                    acc = fmaf(v.x, wq[0], acc); acc = fmaf(v.y, wq[1], acc);
+                    acc = fmaf(v.z, wq[2], acc); acc = fmaf(v.w, wq[3], acc);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint4 u = *(const uint4*)((const bf16_t*)src + 8 * q);
+                    const unsigned uu[4] = {u.x, u.y, u.z, u.w};
+                    const float* wq = ws + tap * 32 + 8 * q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float lo = __uint_as_float(uu[e] << 16), hi = __uint_as_float(uu[e] & 0xffff0000u);
+                        if (RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                        acc = fmaf(lo, wq[2 * e], acc); acc = fmaf(hi, wq[2 * e + 1], acc);
+                    }
+                }
+            }
+        }
+        if (add) acc += add[(size_t)(b % add_nb) * H * W + (size_t)y * W + x];
+        out[idx] = acc;
+    }
+}
+
+__global__ void pack_conv_out1_kernel(const float* __restrict__ src, int cin_total, int cin_index, int from_conv_in, float* w) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 288) return;
+    const int c = idx & 31, tap = idx >> 5;
+    w[idx] = from_conv_in ? src[((size_t)c * cin_total + cin_index) * 9 + (8 - tap)] : src[(size_t)c * 9 + tap];
+}
+
+void ptta_pack_conv_out1(const float* src, int src_cin_total, int src_cin_index, int from_conv_in, float* w, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv_out1_kernel, dim3(2), dim3(256), 0, s, src, src_cin_total, src_cin_index, from_conv_in, w);
+}
+
+int ptta_launch_conv_out1(const ConvOut1Args& a, hipStream_t s) {
+    const long total = (long)a.B * a.H * a.W;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    const int add_nb = a.add_nb > 0 ? a.add_nb : 1;
+#define LAUNCH_(T, R) hipLaunchKernelGGL((conv_out1_kernel<T, R>), dim3(blocks), dim3(256), 0, s, (const T*)a.in, a.in_nb, \
+                                         a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W)
+    if (a.bf16) { if (a.relu_in) LAUNCH_(bf16_t, true); else LAUNCH_(bf16_t, false); }
+    else { if (a.relu_in) LAUNCH_(float, true); else LAUNCH_(float, false); }
+#undef LAUNCH_
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

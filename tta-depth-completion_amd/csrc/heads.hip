@@ -1,0 +1,228 @@
+// Projection / prediction MLP heads of ProxyTTA (network_exp_msg_chn_adapt.py:1031-1036,1089-1098:
+// Linear - BatchNorm1d(train) - ReLU - Linear, 32 -> 512 -> 512 and 512 -> 512 -> 512) and the
+// backward through the one `proj` application that carries gradient (:554).
+//
+// These are the true dense contractions of the step (37 % of forward MACs), so
+// they run on the matrix cores: C[R][N] = op(A)[R][K] * W[N][K]^T, 128x64 block tiles, K staged
+// through LDS in 32-deep slices (row stride padded to 36 floats => conflict-free ds_read_b128),
+// fp32 in / fp32 accumulate (v_mfma_f32_32x32x2_f32, exact fp32).
+// Fusions: BatchNorm+ReLU of the previous layer is applied while the A tile is staged (never
+// materialised), the train-mode batch statistics of the produced layer come out of the epilogue
+// as per-row-block partial column sums (deterministic two-stage reduction, no atomics), and in
+// the backward the ReLU mask / BatchNorm-backward reductions are fused the same way.
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+#define GEMM_BM 128
+#define GEMM_BK 32
+#define GEMM_LDS_STRIDE 36
+
+struct GemmP {
+    const void* A; const float* A2; const float* W; const float* bias; float* C;
+    int R, K, N;
+    const float* pscale; const float* pshift; const float* pmean; const float* pinv; const float* pc1; const float* pc2;
+    const float* eH; const float* escale; const float* eshift; const float* emean; const float* einv;
+    float* part;
+};
+
+template <int NT, int PRO, int EPI, bool ABF16>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
+    constexpr int BN = 32 * NT;
+    __shared__ __attribute__((aligned(16))) float As[GEMM_BM * GEMM_LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * GEMM_LDS_STRIDE];
+    __shared__ float red[4][2][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * BN;
+    const long row0 = (long)blockIdx.y * GEMM_BM;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int k0 = 0; k0 < p.K; k0 += GEMM_BK) {
+        // ---- stage A (with the fused prologue) and B -----------------------------------------
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            const int row = idx >> 3, kq = idx & 7;
+            const long gr = row0 + row;
+            const int k = k0 + 4 * kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gr < p.R) {
+                if (ABF16) {
+                    const uint2 u = *(const uint2*)((const bf16_t*)p.A + gr * p.K + k);
+                    v.x = __uint_as_float(u.x << 16); v.y = __uint_as_float(u.x & 0xffff0000u);
+                    v.z = __uint_as_float(u.y << 16); v.w = __uint_as_float(u.y & 0xffff0000u);
+                } else {
+                    v = *(const float4*)((const float*)p.A + gr * p.K + k);
+                }
+                if (PRO == 1) {
+                    const float4 sc = *(const float4*)(p.pscale + k), sh = *(const float4*)(p.pshift + k);
+                    v.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                    v.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+                } else if (PRO == 2) {
+                    // BatchNorm1d backward: dh = gamma*invstd * (g - mean(g) - xhat * mean(g*xhat))
+                    const float4 hh = *(const float4*)(p.A2 + gr * p.K + k);
+                    const float4 mu = *(const float4*)(p.pmean + k), iv = *(const float4*)(p.pinv + k);
+                    const float4 gs = *(const float4*)(p.pscale + k);
+                    const float4 c1 = *(const float4*)(p.pc1 + k), c2 = *(const float4*)(p.pc2 + k);
+                    v.x = gs.x * (v.x - c1.x - (hh.x - mu.x) * iv.x * c2.x);
+                    v.y = gs.y * (v.y - c1.y - (hh.y - mu.y) * iv.y * c2.y);
+                    v.z = gs.z * (v.z - c1.z - (hh.z - mu.z) * iv.z * c2.z);
+                    v.w = gs.w * (v.w - c1.w - (hh.w - mu.w) * iv.w * c2.w);
+                }
+            }
+            *(float4*)(As + row * GEMM_LDS_STRIDE + 4 * kq) = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            const int idx = tid + 256 * q;
+            const int row = idx >> 3, kq = idx & 7;
+            *(float4*)(Bs + row * GEMM_LDS_STRIDE + 4 * kq) =
+                *(const float4*)(p.W + (long)(n0 + row) * p.K + k0 + 4 * kq);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 a = *(const float4*)(As + (32 * wave + i) * GEMM_LDS_STRIDE + 8 * c + 4 * h);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float4 b = *(const float4*)(Bs + (32 * t + i) * GEMM_LDS_STRIDE + 8 * c + 4 * h);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = n0 + 32 * t + i;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+        float esc = 0.f, esh = 0.f, emu = 0.f, eiv = 0.f;
+        if (EPI == 2) { esc = p.escale[col]; esh = p.eshift[col]; emu = p.emean[col]; eiv = p.einv[col]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long row = row0 + 32 * wave + acc_row(r, h);
+            if (row >= p.R) continue;
+            float v = acc[t][r] + bias;
+            if (EPI == 1) { s1 += v; s2 += v * v; }
+            if (EPI == 2) {
+                const float hh = p.eH[row * p.N + col];
+                v = (fmaf(hh, esc, esh) > 0.f) ? v : 0.f;
+                s1 += v; s2 += v * (hh - emu) * eiv;
+            }
+            p.C[row * p.N + col] = v;
+        }
+        if (EPI != 0) {
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (h == 0) { red[wave][0][32 * t + i] = s1; red[wave][1][32 * t + i] = s2; }
+        }
+    }
+    if (EPI != 0) {
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            const float v = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+            p.part[((long)blockIdx.y * 2 + which) * p.N + n0 + c] = v;
+        }
+    }
+}
+
+int ptta_gemm_row_blocks(int R) { return (R + GEMM_BM - 1) / GEMM_BM; }
+
+int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
+    if (a.K % GEMM_BK || a.N % 32) return -22;
+    GemmP p;
+    p.A = a.A; p.A2 = a.A2; p.W = a.W; p.bias = a.bias; p.C = a.C; p.R = a.R; p.K = a.K; p.N = a.N;
+    p.pscale = a.pscale; p.pshift = a.pshift; p.pmean = a.pmean; p.pinv = a.pinv; p.pc1 = a.pc1; p.pc2 = a.pc2;
+    p.eH = a.eH; p.escale = a.escale; p.eshift = a.eshift; p.emean = a.emean; p.einv = a.einv; p.part = a.part;
+    const int nt = (a.N % 64 == 0) ? 2 : 1;
+    dim3 grid(a.N / (32 * nt), ptta_gemm_row_blocks(a.R));
+#define GL_(NT, PRO, EPI, BF) hipLaunchKernelGGL((gemm_mfma_kernel<NT, PRO, EPI, BF>), grid, dim3(256), 0, s, p)
+    const int key = a.pro * 100 + a.epi * 10 + (a.a_bf16 ? 1 : 0);
+    if (nt == 2) {
+        switch (key) {
+            case 0: GL_(2, 0, 0, false); break;
+            case 10: GL_(2, 0, 1, false); break;
+            case 11: GL_(2, 0, 1, true); break;
+            case 100: GL_(2, 1, 0, false); break;
+            case 110: GL_(2, 1, 1, false); break;
+            case 20: GL_(2, 0, 2, false); break;
+            default: return -22;
+        }
+    } else {
+        switch (key) {
+            case 0: GL_(1, 0, 0, false); break;
+            case 200: GL_(1, 2, 0, false); break;
+            default: return -22;
+        }
+    }
+#undef GL_
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int row_blocks, int R, int N,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, long long* nbt,
+                                   float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int rb = 0; rb < row_blocks; ++rb) {
+        s1 += (double)part[((long)rb * 2 + 0) * N + c];
+        s2 += (double)part[((long)rb * 2 + 1) * N + c];
+    }
+    const double mu = s1 / R;
+    double var = s2 / R - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float iv = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)mu; invstd[c] = iv;
+    const float sc = gamma[c] * iv;
+    scale[c] = sc; shift[c] = beta[c] - (float)mu * sc;
+    if (running_mean) {
+        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
+                            float* mean, float* invstd, float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, part, row_blocks, R, N, gamma, beta,
+                       eps, momentum, running_mean, running_var, nbt, mean, invstd, scale, shift);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int row_blocks, int R, int N,
+                                       const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                       float* gscale, float* c1, float* c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int rb = 0; rb < row_blocks; ++rb) {
+        s1 += (double)part[((long)rb * 2 + 0) * N + c];
+        s2 += (double)part[((long)rb * 2 + 1) * N + c];
+    }
+    c1[c] = (float)(s1 / R); c2[c] = (float)(s2 / R);
+    gscale[c] = gamma[c] * invstd[c];
+}
+
+int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
+                                float* gscale, float* c1, float* c2, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, part, row_blocks, R, N, gamma,
+                       invstd, gscale, c1, c2);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

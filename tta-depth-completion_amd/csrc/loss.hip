@@ -1,0 +1,204 @@
+// ProxyTTA adaptation loss and its analytic gradients.
+//
+// Follows ExternalModel_Adapt.adapt_loss (src/external_model_adapt.py:371-441):
+//   L = w_sd * sparse_depth_consistency (src/loss_utils.py:116-137)
+//     + w_sm * edge-aware smoothness     (src/loss_utils.py:139-169, gradient_yx :624-638)
+//     + w_cos * mean_rows(2 - 2 <e/|e|, r/|r|>)   (F.normalize eps 1e-12, :421-423)
+//   with the data-dependent gate  L_cos < 0.3  =>  w_cos = 0  (:424-425) evaluated ON DEVICE
+//   (the reference pays a device->host sync for it).
+// Reductions are wave-shuffle + LDS per block, then a fixed-order second stage (bitwise
+// reproducible, no float atomics).  Gradients w.r.t. the depth map and w.r.t. `reference`
+// replace autograd's backward through these ops (src/tta_main.py:632).
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+#define LOSS_PB 128          // depth-reduction blocks per sample
+#define LOSS_CB 1024         // cosine-reduction blocks
+#define WS_SCAL 0            // [0] coef_cos [1] coef_smx [2] coef_smy
+#define WS_SD 16             // per-sample w_sd / (N * sum_w)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+static __host__ __device__ inline long ws_depth_off(int N) { return WS_SD + ((N + 15) / 16) * 16; }
+static __host__ __device__ inline long ws_cos_off(int N) { return ws_depth_off(N) + (long)N * LOSS_PB * 4; }
+static __host__ __device__ inline long ws_rows_off(int N) { return ws_cos_off(N) + LOSS_CB; }
+
+int ptta_loss_ws_floats(int N, int H, int W, long R) { return (int)(ws_rows_off(N) + 3 * R + 64); }
+
+__device__ __forceinline__ float clampd(float d, float max_d) { return max_d >= 0.f ? fminf(fmaxf(d, 0.f), max_d) : d; }
+__device__ __forceinline__ float edge_w(const float* img, size_t plane, size_t a, size_t b) {
+    const float m = (fabsf(img[a] - img[b]) + fabsf(img[plane + a] - img[plane + b]) +
+                     fabsf(img[2 * plane + a] - img[2 * plane + b])) / 3.0f;
+    return expf(-m);
+}
+
+__global__ __launch_bounds__(256) void loss_depth_reduce_kernel(const float* __restrict__ depth, const float* __restrict__ image,
+                                                                const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                                float max_d, int H, int W, float* __restrict__ part) {
+    __shared__ float red[4][4];
+    const int n = blockIdx.y;
+    const size_t plane = (size_t)H * W;
+    const float* D = depth + n * plane;
+    const float* S = sparse + n * plane;
+    const float* V = validity + n * plane;
+    const float* I = image + (size_t)n * 3 * plane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)(idx / W);
+        const float d = D[idx], w = V[idx];
+        a0 += w * fabsf(clampd(S[idx], max_d) - d);
+        a1 += w;
+        if (x < W - 1) a2 += edge_w(I, plane, idx, idx + 1) * fabsf(d - D[idx + 1]);
+        if (y < H - 1) a3 += edge_w(I, plane, idx, idx + W) * fabsf(d - D[idx + W]);
+    }
+    a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; red[wave][3] = a3; }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        part[((size_t)n * LOSS_PB + blockIdx.x) * 4 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// one wave per row of `emb`/`ref` (D = 512: 8 values per lane)
+__global__ __launch_bounds__(256) void cos_rows_kernel(const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+                                                       float* __restrict__ rowstats, float* __restrict__ part) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
+        const float* e = emb + row * D;
+        const float* r = ref + row * D;
+        float ee = 0.f, rr = 0.f, er = 0.f;
+        for (int k = 4 * lane; k < D; k += 256) {
+            const float4 a = *(const float4*)(e + k), b = *(const float4*)(r + k);
+            ee += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+            rr += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+            er += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        ee = wave_sum(ee); rr = wave_sum(rr); er = wave_sum(er);
+        const float ne = fmaxf(sqrtf(ee), 1e-12f), nr = fmaxf(sqrtf(rr), 1e-12f);
+        const float c = er / (ne * nr);
+        if (lane == 0) { rowstats[3 * row] = ne; rowstats[3 * row + 1] = nr; rowstats[3 * row + 2] = c; }
+        acc += 2.f - 2.f * c;
+    }
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void loss_finalize_kernel(float* __restrict__ ws, int N, int H, int W, long R, int has_cos,
+                                     const float* __restrict__ w3, float* __restrict__ loss_info) {
+    // single thread: a few hundred adds in fixed order
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float w_sd = w3[0], w_sm = w3[1], w_cos = w3[2];
+    const float* dp = ws + ws_depth_off(N);
+    double l_sd = 0.0, smx = 0.0, smy = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double num = 0.0, den = 0.0;
+        for (int b = 0; b < LOSS_PB; ++b) {
+            const float* q = dp + ((size_t)n * LOSS_PB + b) * 4;
+            num += q[0]; den += q[1]; smx += q[2]; smy += q[3];
+        }
+        l_sd += num / den;                                   // NaN if a sample has no valid point, as the reference
+        ws[WS_SD + n] = (float)((double)w_sd / ((double)N * den));
+    }
+    l_sd /= N;
+    const double cntx = (double)N * H * (W - 1), cnty = (double)N * (H - 1) * W;
+    const double l_sm = smx / cntx + smy / cnty;
+    double l_cos = 0.0;
+    float wc = w_cos;
+    if (has_cos) {
+        const float* cp = ws + ws_cos_off(N);
+        for (int b = 0; b < LOSS_CB; ++b) l_cos += cp[b];
+        l_cos /= (double)R;
+        if ((float)l_cos < 0.3f) wc = 0.f;                   // external_model_adapt.py:424-425
+    }
+    ws[WS_SCAL + 0] = has_cos ? (float)(-2.0 * wc / (double)R) : 0.f;
+    ws[WS_SCAL + 1] = (float)(w_sm / cntx);
+    ws[WS_SCAL + 2] = (float)(w_sm / cnty);
+    loss_info[0] = (float)(w_sd * l_sd + w_sm * l_sm + (double)wc * l_cos);
+    loss_info[1] = (float)l_sm;
+    loss_info[2] = (float)l_sd;
+    loss_info[3] = (float)l_cos;
+}
+
+int ptta_launch_loss_forward(const float* depth, const float* image, const float* sparse, const float* validity,
+                             float max_input_depth, const float* emb, const float* ref, long R, int D,
+                             const float* w3_dev, int N, int H, int W,
+                             float* ws, float* loss_info, hipStream_t s) {
+    hipLaunchKernelGGL(loss_depth_reduce_kernel, dim3(LOSS_PB, N), dim3(256), 0, s, depth, image, sparse, validity,
+                       max_input_depth, H, W, ws + ws_depth_off(N));
+    const int has_cos = (emb && ref) ? 1 : 0;
+    if (has_cos)
+        hipLaunchKernelGGL(cos_rows_kernel, dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, ws, N, H, W, R, has_cos, w3_dev, loss_info);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void loss_depth_grad_kernel(const float* __restrict__ depth, const float* __restrict__ image,
+                                                              const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                              float max_d, int N, int H, int W, const float* __restrict__ ws,
+                                                              float* __restrict__ g) {
+    const size_t plane = (size_t)H * W;
+    const size_t total = (size_t)N * plane;
+    const float cx = ws[WS_SCAL + 1], cy = ws[WS_SCAL + 2];
+    for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(gi / plane);
+        const size_t idx = gi % plane;
+        const int x = (int)(idx % W), y = (int)(idx / W);
+        const float* D = depth + n * plane;
+        const float* I = image + (size_t)n * 3 * plane;
+        const float d = D[idx];
+        float v = ws[WS_SD + n] * validity[gi] * sgn(d - clampd(sparse[gi], max_d));
+        float tx = 0.f, ty = 0.f;
+        if (x < W - 1) tx += edge_w(I, plane, idx, idx + 1) * sgn(d - D[idx + 1]);
+        if (x > 0) tx -= edge_w(I, plane, idx - 1, idx) * sgn(D[idx - 1] - d);
+        if (y < H - 1) ty += edge_w(I, plane, idx, idx + W) * sgn(d - D[idx + W]);
+        if (y > 0) ty -= edge_w(I, plane, idx - W, idx) * sgn(D[idx - W] - d);
+        g[gi] = v + cx * tx + cy * ty;
+    }
+}
+
+__global__ __launch_bounds__(256) void cos_grad_kernel(const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+                                                       const float* __restrict__ ws, const float* __restrict__ rowstats,
+                                                       float* __restrict__ gref) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float coef = ws[WS_SCAL + 0];
+    for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
+        const float ne = rowstats[3 * row], nr = rowstats[3 * row + 1], c = rowstats[3 * row + 2];
+        const float ie = 1.f / ne, ir = 1.f / nr;
+        // d(r/max(|r|,eps))/dr = (I - rhat rhat^T)/|r| above eps, I/eps below it
+        const float proj = (nr > 1e-12f) ? c : 0.f;
+        for (int k = 4 * lane; k < D; k += 256) {
+            const float4 a = *(const float4*)(emb + row * D + k), b = *(const float4*)(ref + row * D + k);
+            float4 o;
+            o.x = coef * (a.x * ie - proj * b.x * ir) * ir;
+            o.y = coef * (a.y * ie - proj * b.y * ir) * ir;
+            o.z = coef * (a.z * ie - proj * b.z * ir) * ir;
+            o.w = coef * (a.w * ie - proj * b.w * ir) * ir;
+            *(float4*)(gref + row * D + k) = o;
+        }
+    }
+}
+
+int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
+                              float max_input_depth, const float* emb, const float* ref, long R, int D,
+                              int N, int H, int W, const float* ws, float* gdepth, float* gref, hipStream_t s) {
+    const size_t total = (size_t)N * H * W;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(loss_depth_grad_kernel, dim3(blocks), dim3(256), 0, s, depth, image, sparse, validity,
+                       max_input_depth, N, H, W, ws, gdepth);
+    if (emb && ref && gref) {
+        long cb = (R + 3) / 4; if (cb > 2048) cb = 2048;
+        hipLaunchKernelGGL(cos_grad_kernel, dim3((int)cb), dim3(256), 0, s, emb, ref, R, D, ws, ws + ws_rows_off(N), gref);
+    }
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

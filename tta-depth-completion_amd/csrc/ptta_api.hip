@@ -1,0 +1,826 @@
+// libptta_hip: handle, workspace, weight registry and the launch schedule of one ProxyTTA step
+// for the MSG_CHN backbone (C-ABI in include/ptta.h).
+//
+// Schedule = the dataflow of network_adapt._rgbd_meta_contrast
+// (external_src/MSG_CHN/workspace/exp_msg_chn/network_exp_msg_chn_adapt.py:463-557) with
+//   * the grad pass and the no-grad proxy (zero image) pass batched into ONE launch per layer
+//     (batch = [real frames | proxy frames]); the depth-only encoder of stage 1 is shared,
+//   * every elementwise op of the graph (pre-activation ReLU, bias, decoder skip additions,
+//     bilinear x2 skip, final residual) fused into the producing/consuming conv,
+//   * the minimal backward: data gradients only along paths that reach conv1_rgb_meta, weight
+//     gradient only for conv1_rgb_meta, then Adam on device.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ptta.h"
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+#define PTTA_VERSION 1
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return c->fail(std::string(#x) + ": " + hipGetErrorString(e_), -100 - (int)e_); } while (0)
+#define RUN(x) do { int r_ = (x); if (r_ != 0) return c->fail(std::string(#x) + " failed", r_ < 0 ? r_ : -r_); } while (0)
+
+namespace {
+
+struct L32 { ConvW f{}, b{}; float* bias = nullptr; int transposed = 0; };
+struct LIn { float *wfrag = nullptr, *wcanon = nullptr, *bias = nullptr, *bw = nullptr; int cin = 1; };
+struct LOut { float *w = nullptr, *bias = nullptr, *bfrag = nullptr, *bcanon = nullptr; };
+struct Lin { float *W = nullptr, *Wt = nullptr, *bias = nullptr; int N = 0, K = 0; };
+struct BNorm { float *gamma = nullptr, *beta = nullptr, *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
+               float *mean = nullptr, *inv = nullptr, *scale = nullptr, *shift = nullptr; };
+struct Dbg { const void* p; long numel; int is_act; };
+
+}  // namespace
+
+struct ptta_ctx {
+    int N = 1, H = 0, W = 0, Hp = 0, Wp = 0, pt = 0, pr = 0, dual = 0, Nn = 1;
+    int bf16 = 0, naive = 0, es = 4;
+    ptta_hparams hp{};
+    std::string err;
+    std::vector<void*> allocs;
+    std::map<std::string, L32> l32;
+    std::map<std::string, LIn> lin_in;
+    std::map<std::string, LOut> lout;
+    std::map<std::string, Lin> fc;
+    std::map<std::string, BNorm> bn;
+    std::map<std::string, Dbg> dbg;
+    // adapted parameters (bound, caller-owned)
+    float *meta_w = nullptr, *meta_b = nullptr, *meta_w_m = nullptr, *meta_w_v = nullptr, *meta_b_m = nullptr, *meta_b_v = nullptr;
+    float *gW = nullptr, *gB = nullptr;
+    float* hyper = nullptr;      // device: lr b1 b2 eps wd | w_sd w_sm w_cos
+    float* w3_tmp = nullptr;     // device: loss weights of the standalone loss call
+    int* step_dev = nullptr;
+    bool fwd_valid = false;
+
+    int fail(const std::string& m, int code) { err = m; return code; }
+
+    bool oom = false;
+    void* dalloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { oom = true; return nullptr; }
+        hipMemset(p, 0, bytes ? bytes : 16);
+        allocs.push_back(p);
+        return p;
+    }
+    float* falloc(size_t n) { return (float*)dalloc(n * sizeof(float)); }
+    void* act(const char* name, int nb, int h, int w) {
+        void* p = dalloc((size_t)nb * h * w * 32 * es);
+        dbg[name] = Dbg{p, (long)nb * h * w * 32, 1};
+        return p;
+    }
+    float* map1(const char* name, int nb, int h, int w) {
+        float* p = falloc((size_t)nb * h * w);
+        dbg[name] = Dbg{p, (long)nb * h * w, 0};
+        return p;
+    }
+
+    // ---- workspace (see build_workspace) ----
+    int H2, W2, H4, W4, H8, W8, H16, W16;
+    long Rg = 0;                 // embedding rows = Nn * H4 * W4
+    float *img_pad = nullptr, *sp_pad = nullptr, *zero_plane = nullptr;
+    float *dclamp, *d12, *d14, *out1, *p12, *q, *p11, *depth_net, *depth_final, *validity_tmp;
+    void *c0a, *c0, *c1a, *c1, *c2a, *c2, *m, *c3a, *c3, *c4a, *c4;
+    void *e1_0a, *e1_0, *e1_1a, *e1_1, *e1_2a, *y1, *y2, *t1, *y3, *s1_1, *u1, *y4, *s0_1, *v1;
+    void *e2_0a, *e2_0, *e2_1a, *e2_1, *e2_2a, *z2, *t2, *z3, *s1_2, *u2, *z4, *s0_2, *v2;
+    void *e3_0a, *e3_0, *e3_1a, *e3_1, *e3_2a, *feat, *w2, *t3, *s1_3, *u3, *s0_3, *v3;
+    float *h1z, *pz, *h2, *emb, *h1, *ref, *gref_buf, *gmask, *bn_part;
+    float *bnb_gscale, *bnb_c1, *bnb_c2;
+    float *loss_ws, *loss_info, *g_final, *g_net;
+    // backward
+    void *dv3, *ds0_3, *du3, *ds1_3, *dt3, *dw2, *dfeat_tot, *dz2_up, *de3_2a, *de3_1, *de3_1a, *de3_0, *de3_0a;
+    void *dv2, *ds0_2, *dz4, *du2, *ds1_2, *dz3, *dt2, *dz2, *de2_2a, *de2_1, *de2_1a, *de2_0, *de2_0a, *dv1, *dm_total, *g_feat;
+    float *dp11, *dq, *dp12, *dout1, *g_feat_f32;
+    float* wgrad_part;
+};
+
+namespace {
+
+// ---- small utility kernels ---------------------------------------------------------------------
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows * cols) return;
+    const int r = (int)(idx / cols), cc = (int)(idx % cols);
+    dst[(long)cc * rows + r] = src[idx];
+}
+// dual-corner zero padding (src/msg_chn_model_adapt.py:75-103): item k=0 pads top/right, k=1 bottom/left
+__global__ void pad_dual_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
+                                int Hp, int Wp, int pt, int pr) {
+    const long total = (long)2 * N * C * Hp * Wp;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Wp); long t_ = idx / Wp;
+        const int y = (int)(t_ % Hp); t_ /= Hp;
+        const int ch = (int)(t_ % C); t_ /= C;
+        const int n = (int)(t_ % N); const int k = (int)(t_ / N);
+        const int sy = k == 0 ? y - pt : y, sx = k == 0 ? x : x - pr;
+        float v = 0.f;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = src[(((long)n * C + ch) * H + sy) * W + sx];
+        dst[idx] = v;
+    }
+}
+// crop both paddings and average (src/msg_chn_model_adapt.py:107-123)
+__global__ void crop_avg_kernel(const float* __restrict__ net, float* __restrict__ out, int N, int H, int W, int Hp, int Wp,
+                                int pt, int pr) {
+    const long total = (long)N * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W); long t_ = idx / W;
+        const int y = (int)(t_ % H); const int n = (int)(t_ / H);
+        const float a = net[((long)n * Hp + y + pt) * Wp + x];
+        const float b = net[((long)(N + n) * Hp + y) * Wp + x + pr];
+        out[idx] = (a + b) / 2.0f;
+    }
+}
+__global__ void scatter_dual_grad_kernel(const float* __restrict__ g, float* __restrict__ gnet, int N, int H, int W, int Hp,
+                                         int Wp, int pt, int pr) {
+    const long total = (long)2 * N * Hp * Wp;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Wp); long t_ = idx / Wp;
+        const int y = (int)(t_ % Hp); t_ /= Hp;
+        const int n = (int)(t_ % N); const int k = (int)(t_ / N);
+        const int sy = k == 0 ? y - pt : y, sx = k == 0 ? x : x - pr;
+        float v = 0.f;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = 0.5f * g[((long)n * H + sy) * W + sx];
+        gnet[idx] = v;
+    }
+}
+__global__ void validity_kernel(const float* __restrict__ sparse, float* __restrict__ v, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float s = sparse[i];
+        v[i] = s > 0.f ? 1.f : s;              // torch.where(sd > 0, 1, sd), src/tta_main.py:583-586
+    }
+}
+template <typename T>
+__global__ void to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = ld(src + i);
+}
+template <typename T>
+__global__ void from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) st(dst + i, src[i]);
+}
+inline int nblk(long n, int cap = 4096) { long b = (n + 255) / 256; return (int)(b > cap ? cap : (b < 1 ? 1 : b)); }
+
+int pad16(int n) { return n % 16 == 0 ? 0 : (n / 16 + 1) * 16 - n; }
+
+ConvW alloc_convw(ptta_ctx* c) {
+    ConvW w;
+    w.mf32 = c->falloc(9 * 4 * 64 * 4);
+    w.mbf16 = (bf16_t*)c->dalloc(9 * 2 * 64 * 8 * sizeof(bf16_t));
+    w.canon = c->falloc(9 * 32 * 32);
+    return w;
+}
+
+const char* kRgb32[] = {"rgb_encoder.init.2", "rgb_encoder.enc1.1", "rgb_encoder.enc1.3", "rgb_encoder.enc2.1", "rgb_encoder.enc2.3",
+                        "rgb_encoder.enc3.1", "rgb_encoder.enc3.3", "rgb_encoder.enc4.1", "rgb_encoder.enc4.3"};
+
+void build_registry(ptta_ctx* c) {
+    auto add32 = [&](const std::string& n, int transposed, bool need_bwd) {
+        L32 l; l.f = alloc_convw(c); if (need_bwd) l.b = alloc_convw(c);
+        l.bias = c->falloc(32); l.transposed = transposed;
+        c->l32[n] = l;
+    };
+    for (const char* n : kRgb32) add32(n, 0, false);
+    for (int s = 1; s <= 3; ++s) {
+        const std::string e = "depth_encoder" + std::to_string(s), d = "depth_decoder" + std::to_string(s);
+        const bool bw = s >= 2;
+        add32(e + ".init.2", 0, bw);
+        for (const char* k : {".enc1.1", ".enc1.3", ".enc2.1", ".enc2.3"}) add32(e + k, 0, bw);
+        add32(d + ".dec2.1", 1, bw); add32(d + ".dec2.3", 0, bw);
+        add32(d + ".dec1.1", 1, bw); add32(d + ".dec1.3", 0, bw);
+        add32(d + ".prdct.1", 0, true);
+        LIn li; li.cin = (s == 1) ? 1 : 2;
+        li.wfrag = c->falloc(14 * 64); li.wcanon = c->falloc(9 * 3 * 32); li.bias = c->falloc(32); li.bw = c->falloc(288);
+        c->lin_in[e + ".init.0"] = li;
+        LOut lo; lo.w = c->falloc(288); lo.bias = c->falloc(1); lo.bfrag = c->falloc(14 * 64); lo.bcanon = c->falloc(9 * 3 * 32);
+        c->lout[d + ".prdct.3"] = lo;
+    }
+    {
+        LIn li; li.cin = 3;
+        li.wfrag = c->falloc(14 * 64); li.wcanon = c->falloc(9 * 3 * 32); li.bias = c->falloc(32); li.bw = c->falloc(288);
+        c->lin_in["rgb_encoder.init.0"] = li;
+    }
+    {   // the adapted layer: forward fragments are re-packed from the bound parameter every forward
+        L32 l; l.f = alloc_convw(c); l.bias = nullptr; c->l32["conv1_rgb_meta"] = l;
+    }
+    for (const char* p : {"proj", "pred"}) {
+        const int din = std::string(p) == "proj" ? 32 : 512;
+        Lin a; a.N = 512; a.K = din; a.W = c->falloc((size_t)512 * din); a.Wt = c->falloc((size_t)512 * din); a.bias = c->falloc(512);
+        Lin b; b.N = 512; b.K = 512; b.W = c->falloc(512 * 512); b.Wt = c->falloc(512 * 512); b.bias = c->falloc(512);
+        c->fc[std::string(p) + ".0"] = a; c->fc[std::string(p) + ".3"] = b;
+        BNorm n; n.gamma = c->falloc(512); n.beta = c->falloc(512);
+        n.mean = c->falloc(512); n.inv = c->falloc(512); n.scale = c->falloc(512); n.shift = c->falloc(512);
+        c->bn[std::string(p) + ".1"] = n;
+    }
+}
+
+void build_workspace(ptta_ctx* c) {
+    const int Nn = c->Nn, B2 = 2 * Nn;
+    const int H1 = c->Hp, W1 = c->Wp;
+    c->H2 = H1 / 2; c->W2 = W1 / 2; c->H4 = H1 / 4; c->W4 = W1 / 4; c->H8 = H1 / 8; c->W8 = W1 / 8; c->H16 = H1 / 16; c->W16 = W1 / 16;
+    const int H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
+    c->Rg = (long)Nn * H4 * W4;
+    if (c->dual) { c->img_pad = c->falloc((size_t)Nn * 3 * H1 * W1); c->sp_pad = c->falloc((size_t)Nn * H1 * W1); }
+#define A_(name, nb, h, w) c->name = c->act(#name, nb, h, w)
+#define M_(name, nb, h, w) c->name = c->map1(#name, nb, h, w)
+    M_(dclamp, Nn, H1, W1); M_(d12, Nn, H2, W2); M_(d14, Nn, H4, W4);
+    M_(out1, B2, H4, W4); M_(p12, B2, H2, W2); M_(q, B2, H2, W2); M_(p11, B2, H1, W1);
+    M_(depth_net, Nn, H1, W1); M_(depth_final, c->N, c->H, c->W); M_(validity_tmp, c->N, c->H, c->W);
+    A_(c0a, B2, H1, W1); A_(c0, B2, H1, W1); A_(c1a, B2, H2, W2); A_(c1, B2, H2, W2);
+    A_(c2a, B2, H4, W4); A_(c2, B2, H4, W4); A_(m, B2, H4, W4);
+    A_(c3a, B2, H8, W8); A_(c3, B2, H8, W8); A_(c4a, B2, H16, W16); A_(c4, B2, H16, W16);
+    A_(e1_0a, Nn, H4, W4); A_(e1_0, Nn, H4, W4); A_(e1_1a, Nn, H8, W8); A_(e1_1, B2, H8, W8); A_(e1_2a, Nn, H16, W16);
+    A_(y1, B2, H8, W8); A_(y2, B2, H16, W16); A_(t1, B2, H8, W8); A_(y3, B2, H8, W8); A_(s1_1, B2, H8, W8);
+    A_(u1, B2, H4, W4); A_(y4, B2, H4, W4); A_(s0_1, B2, H4, W4); A_(v1, B2, H4, W4);
+    A_(e2_0a, B2, H2, W2); A_(e2_0, B2, H2, W2); A_(e2_1a, B2, H4, W4); A_(e2_1, B2, H4, W4); A_(e2_2a, B2, H8, W8);
+    A_(z2, B2, H8, W8); A_(t2, B2, H4, W4); A_(z3, B2, H4, W4); A_(s1_2, B2, H4, W4); A_(u2, B2, H2, W2);
+    A_(z4, B2, H2, W2); A_(s0_2, B2, H2, W2); A_(v2, B2, H2, W2);
+    A_(e3_0a, B2, H1, W1); A_(e3_0, B2, H1, W1); A_(e3_1a, B2, H2, W2); A_(e3_1, B2, H2, W2); A_(e3_2a, B2, H4, W4);
+    A_(feat, B2, H4, W4); A_(w2, B2, H4, W4);
+    A_(t3, Nn, H2, W2); A_(s1_3, Nn, H2, W2); A_(u3, Nn, H1, W1); A_(s0_3, Nn, H1, W1); A_(v3, Nn, H1, W1);
+    // heads
+    const size_t RD = (size_t)c->Rg * 512;
+    c->h1z = c->falloc(RD); c->pz = c->falloc(RD); c->h2 = c->falloc(RD); c->emb = c->falloc(RD);
+    c->h1 = c->falloc(RD); c->ref = c->falloc(RD); c->gref_buf = c->falloc(RD); c->gmask = c->falloc(RD);
+    c->dbg["emb"] = Dbg{c->emb, (long)RD, 0}; c->dbg["ref"] = Dbg{c->ref, (long)RD, 0};
+    c->dbg["h1"] = Dbg{c->h1, (long)RD, 0}; c->dbg["gmask"] = Dbg{c->gmask, (long)RD, 0}; c->dbg["gref"] = Dbg{c->gref_buf, (long)RD, 0};
+    c->bn_part = c->falloc((size_t)ptta_gemm_row_blocks((int)c->Rg) * 2 * 512);
+    c->bnb_gscale = c->falloc(512); c->bnb_c1 = c->falloc(512); c->bnb_c2 = c->falloc(512);
+    c->loss_ws = c->falloc((size_t)ptta_loss_ws_floats(c->N, c->H, c->W, c->Rg));
+    c->loss_info = c->falloc(4);
+    M_(g_final, c->N, c->H, c->W); M_(g_net, Nn, H1, W1);
+    // backward
+    A_(dv3, Nn, H1, W1); A_(ds0_3, Nn, H1, W1); A_(du3, Nn, H1, W1); A_(ds1_3, Nn, H2, W2); A_(dt3, Nn, H2, W2);
+    A_(dw2, Nn, H4, W4); A_(dfeat_tot, Nn, H4, W4); A_(dz2_up, Nn, H8, W8); A_(de3_2a, Nn, H4, W4);
+    A_(de3_1, Nn, H2, W2); A_(de3_1a, Nn, H2, W2); A_(de3_0, Nn, H1, W1); A_(de3_0a, Nn, H1, W1);
+    A_(dv2, Nn, H2, W2); A_(ds0_2, Nn, H2, W2); A_(dz4, Nn, H2, W2); A_(du2, Nn, H2, W2); A_(ds1_2, Nn, H4, W4);
+    A_(dz3, Nn, H4, W4); A_(dt2, Nn, H4, W4); A_(dz2, Nn, H8, W8); A_(de2_2a, Nn, H8, W8); A_(de2_1, Nn, H4, W4);
+    A_(de2_1a, Nn, H4, W4); A_(de2_0, Nn, H2, W2); A_(de2_0a, Nn, H2, W2); A_(dv1, Nn, H4, W4); A_(dm_total, Nn, H4, W4);
+    A_(g_feat, Nn, H4, W4);
+    M_(dp11, Nn, H1, W1); M_(dq, Nn, H2, W2); M_(dp12, Nn, H2, W2); M_(dout1, Nn, H4, W4);
+    c->g_feat_f32 = c->falloc((size_t)c->Rg * 32);
+    c->dbg["g_feat_f32"] = Dbg{c->g_feat_f32, c->Rg * 32, 0};
+    c->wgrad_part = c->falloc((size_t)ptta_wgrad_chunks(c->Rg) * 10 * 1024);
+    c->gW = c->falloc(32 * 32 * 9); c->gB = c->falloc(32);
+    c->dbg["gW"] = Dbg{c->gW, 9216, 0}; c->dbg["gB"] = Dbg{c->gB, 32, 0};
+    c->hyper = c->falloc(16); c->w3_tmp = c->falloc(4);
+    c->step_dev = (int*)c->dalloc(16);
+#undef A_
+#undef M_
+}
+
+struct E { const void* up = nullptr; int up_nb = 1; const void* mask = nullptr; int mask_nb = 1;
+           const void* add1 = nullptr; int add1_nb = 1; const void* add2 = nullptr; int add2_nb = 1;
+           void* raw = nullptr; void* sum = nullptr; };
+
+int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int mode, const void* in, int in_nb,
+           int B, int Hin, int Win, bool relu, const E& e) {
+    auto it = c->l32.find(layer);
+    if (it == c->l32.end()) return c->fail("unknown 32->32 layer " + layer, -2);
+    Conv32Args a;
+    a.in = in; a.in_nb = in_nb; a.w = bwd ? &it->second.b : &it->second.f;
+    a.bias = bwd ? nullptr : (layer == "conv1_rgb_meta" ? c->meta_b : it->second.bias);
+    a.up = e.up; a.up_nb = e.up_nb; a.mask = e.mask; a.mask_nb = e.mask_nb;
+    a.add1 = e.add1; a.add1_nb = e.add1_nb; a.add2 = e.add2; a.add2_nb = e.add2_nb;
+    a.out_raw = e.raw; a.out_sum = e.sum;
+    a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = c->bf16; a.naive = c->naive;
+    return ptta_launch_conv32(a, s);
+}
+
+// One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half.
+int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
+    const int Nn = c->Nn, B2 = train ? 2 * Nn : Nn;
+    const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
+#define CV(...) RUN(conv32(c, s, __VA_ARGS__))
+    auto e_raw = [](void* raw) { E e; e.raw = raw; return e; };
+    // ---- RGB encoder (RGBEncoder.forward :252-264) + meta layer (:481-482) ----
+    {
+        const LIn& li = c->lin_in["rgb_encoder.init.0"];
+        ConvInArgs a; a.cin = 3; a.zero_from_b = Nn;
+        for (int ch = 0; ch < 3; ++ch) { a.pl[ch].p = image + (size_t)ch * H1 * W1; a.pl[ch].nb = Nn; a.pl[ch].bstride = 3L * H1 * W1; }
+        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->c0a;
+        a.B = B2; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
+        RUN(ptta_launch_conv_in(a, s));
+    }
+    CV("rgb_encoder.init.2", false, CONV_S1, c->c0a, B2, B2, H1, W1, true, e_raw(c->c0));
+    CV("rgb_encoder.enc1.1", false, CONV_S2, c->c0, B2, B2, H1, W1, true, e_raw(c->c1a));
+    CV("rgb_encoder.enc1.3", false, CONV_S1, c->c1a, B2, B2, H2, W2, true, e_raw(c->c1));
+    CV("rgb_encoder.enc2.1", false, CONV_S2, c->c1, B2, B2, H2, W2, true, e_raw(c->c2a));
+    CV("rgb_encoder.enc2.3", false, CONV_S1, c->c2a, B2, B2, H4, W4, true, e_raw(c->c2));
+    CV("rgb_encoder.enc3.1", false, CONV_S2, c->c2, B2, B2, H4, W4, true, e_raw(c->c3a));
+    CV("rgb_encoder.enc3.3", false, CONV_S1, c->c3a, B2, B2, H8, W8, true, e_raw(c->c3));
+    CV("rgb_encoder.enc4.1", false, CONV_S2, c->c3, B2, B2, H8, W8, true, e_raw(c->c4a));
+    CV("rgb_encoder.enc4.3", false, CONV_S1, c->c4a, B2, B2, H16, W16, true, e_raw(c->c4));
+    CV("conv1_rgb_meta", false, CONV_S1, c->c2, B2, B2, H4, W4, false, e_raw(c->m));
+
+    // ---- stage 1/4 (:487-489): depth-only encoder shared by both passes ----
+    {
+        const LIn& li = c->lin_in["depth_encoder1.init.0"];
+        ConvInArgs a; a.cin = 1; a.pl[0].p = c->d14; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H4 * W4;
+        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e1_0a;
+        a.B = Nn; a.H = H4; a.W = W4; a.bf16 = c->bf16; a.naive = c->naive;
+        RUN(ptta_launch_conv_in(a, s));
+    }
+    CV("depth_encoder1.init.2", false, CONV_S1, c->e1_0a, Nn, Nn, H4, W4, true, e_raw(c->e1_0));
+    CV("depth_encoder1.enc1.1", false, CONV_S2, c->e1_0, Nn, Nn, H4, W4, true, e_raw(c->e1_1a));
+    { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
+      CV("depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, B2, H8, W8, true, e); }
+    CV("depth_encoder1.enc2.1", false, CONV_S2, c->e1_1, B2, Nn, H8, W8, true, e_raw(c->e1_2a));
+    { E e; e.sum = c->y2; e.add1 = c->c4; e.add1_nb = B2;                                         // y2 = e1_2 + c4
+      CV("depth_encoder1.enc2.3", false, CONV_S1, c->e1_2a, Nn, B2, H16, W16, true, e); }
+    // decoder 1 (DepthDecoder.forward :296-311)
+    CV("depth_decoder1.dec2.1", false, CONV_T2, c->y2, B2, B2, H16, W16, true, e_raw(c->t1));
+    { E e; e.raw = c->y3; e.sum = c->s1_1; e.add1 = c->y1; e.add1_nb = B2;
+      CV("depth_decoder1.dec2.3", false, CONV_S1, c->t1, B2, B2, H8, W8, true, e); }
+    CV("depth_decoder1.dec1.1", false, CONV_T2, c->s1_1, B2, B2, H8, W8, true, e_raw(c->u1));
+    { E e; e.raw = c->y4; e.sum = c->s0_1; e.add1 = c->e1_0; e.add1_nb = Nn; e.add2 = c->m; e.add2_nb = B2;
+      CV("depth_decoder1.dec1.3", false, CONV_S1, c->u1, B2, B2, H4, W4, true, e); }
+    CV("depth_decoder1.prdct.1", false, CONV_S1, c->s0_1, B2, B2, H4, W4, true, e_raw(c->v1));
+    {
+        const LOut& lo = c->lout["depth_decoder1.prdct.3"];
+        ConvOut1Args a; a.in = c->v1; a.in_nb = B2; a.w = lo.w; a.bias = lo.bias; a.out = c->out1;
+        a.B = B2; a.H = H4; a.W = W4; a.relu_in = 1; a.bf16 = c->bf16;
+        RUN(ptta_launch_conv_out1(a, s));
+    }
+    // ---- stage 1/2 (:491-498) ----
+    RUN(ptta_launch_up2_1ch(c->out1, c->p12, B2, H4, W4, s));
+    {
+        const LIn& li = c->lin_in["depth_encoder2.init.0"];
+        ConvInArgs a; a.cin = 2;
+        a.pl[0].p = c->d12; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H2 * W2;
+        a.pl[1].p = c->p12; a.pl[1].nb = B2; a.pl[1].bstride = (long)H2 * W2;
+        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e2_0a;
+        a.B = B2; a.H = H2; a.W = W2; a.bf16 = c->bf16; a.naive = c->naive;
+        RUN(ptta_launch_conv_in(a, s));
+    }
+    { E e; e.raw = c->e2_0; e.up = c->y4; e.up_nb = B2; CV("depth_encoder2.init.2", false, CONV_S1, c->e2_0a, B2, B2, H2, W2, true, e); }
+    CV("depth_encoder2.enc1.1", false, CONV_S2, c->e2_0, B2, B2, H2, W2, true, e_raw(c->e2_1a));
+    { E e; e.raw = c->e2_1; e.up = c->y3; e.up_nb = B2; CV("depth_encoder2.enc1.3", false, CONV_S1, c->e2_1a, B2, B2, H4, W4, true, e); }
+    CV("depth_encoder2.enc2.1", false, CONV_S2, c->e2_1, B2, B2, H4, W4, true, e_raw(c->e2_2a));
+    { E e; e.sum = c->z2; e.up = c->y2; e.up_nb = B2; e.add1 = c->c3; e.add1_nb = B2;            // z2 = e2_2 + c3
+      CV("depth_encoder2.enc2.3", false, CONV_S1, c->e2_2a, B2, B2, H8, W8, true, e); }
+    CV("depth_decoder2.dec2.1", false, CONV_T2, c->z2, B2, B2, H8, W8, true, e_raw(c->t2));
+    { E e; e.raw = c->z3; e.sum = c->s1_2; e.add1 = c->e2_1; e.add1_nb = B2; e.add2 = c->m; e.add2_nb = B2;
+      CV("depth_decoder2.dec2.3", false, CONV_S1, c->t2, B2, B2, H4, W4, true, e); }
+    CV("depth_decoder2.dec1.1", false, CONV_T2, c->s1_2, B2, B2, H4, W4, true, e_raw(c->u2));
+    { E e; e.raw = c->z4; e.sum = c->s0_2; e.add1 = c->e2_0; e.add1_nb = B2; e.add2 = c->c1; e.add2_nb = B2;
+      CV("depth_decoder2.dec1.3", false, CONV_S1, c->u2, B2, B2, H2, W2, true, e); }
+    CV("depth_decoder2.prdct.1", false, CONV_S1, c->s0_2, B2, B2, H2, W2, true, e_raw(c->v2));
+    {
+        const LOut& lo = c->lout["depth_decoder2.prdct.3"];
+        ConvOut1Args a; a.in = c->v2; a.in_nb = B2; a.w = lo.w; a.bias = lo.bias; a.add = c->p12; a.add_nb = B2; a.out = c->q;
+        a.B = B2; a.H = H2; a.W = W2; a.relu_in = 1; a.bf16 = c->bf16;                           // q = out2 + p12
+        RUN(ptta_launch_conv_out1(a, s));
+    }
+    // ---- stage 1/1 (:500-506) ----
+    RUN(ptta_launch_up2_1ch(c->q, c->p11, B2, H2, W2, s));
+    {
+        const LIn& li = c->lin_in["depth_encoder3.init.0"];
+        ConvInArgs a; a.cin = 2;
+        a.pl[0].p = c->dclamp; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H1 * W1;
+        a.pl[1].p = c->p11; a.pl[1].nb = B2; a.pl[1].bstride = (long)H1 * W1;
+        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e3_0a;
+        a.B = B2; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
+        RUN(ptta_launch_conv_in(a, s));
+    }
+    { E e; e.raw = c->e3_0; e.up = c->z4; e.up_nb = B2; CV("depth_encoder3.init.2", false, CONV_S1, c->e3_0a, B2, B2, H1, W1, true, e); }
+    CV("depth_encoder3.enc1.1", false, CONV_S2, c->e3_0, B2, B2, H1, W1, true, e_raw(c->e3_1a));
+    { E e; e.raw = c->e3_1; e.up = c->z3; e.up_nb = B2; CV("depth_encoder3.enc1.3", false, CONV_S1, c->e3_1a, B2, B2, H2, W2, true, e); }
+    CV("depth_encoder3.enc2.1", false, CONV_S2, c->e3_1, B2, B2, H2, W2, true, e_raw(c->e3_2a));
+    { E e; e.raw = c->feat; e.sum = c->w2; e.up = c->z2; e.up_nb = B2; e.add1 = c->m; e.add1_nb = B2;   // w2 = feat + m
+      CV("depth_encoder3.enc2.3", false, CONV_S1, c->e3_2a, B2, B2, H4, W4, true, e); }
+    // decoder 3: real frames only (the proxy pass stops at depth_encoder3, :509-532)
+    CV("depth_decoder3.dec2.1", false, CONV_T2, c->w2, B2, Nn, H4, W4, true, e_raw(c->t3));
+    { E e; e.sum = c->s1_3; e.add1 = c->e3_1; e.add1_nb = B2; e.add2 = c->c1; e.add2_nb = B2;
+      CV("depth_decoder3.dec2.3", false, CONV_S1, c->t3, Nn, Nn, H2, W2, true, e); }
+    CV("depth_decoder3.dec1.1", false, CONV_T2, c->s1_3, Nn, Nn, H2, W2, true, e_raw(c->u3));
+    { E e; e.sum = c->s0_3; e.add1 = c->e3_0; e.add1_nb = B2; e.add2 = c->c0; e.add2_nb = B2;
+      CV("depth_decoder3.dec1.3", false, CONV_S1, c->u3, Nn, Nn, H1, W1, true, e); }
+    CV("depth_decoder3.prdct.1", false, CONV_S1, c->s0_3, Nn, Nn, H1, W1, true, e_raw(c->v3));
+    {
+        const LOut& lo = c->lout["depth_decoder3.prdct.3"];
+        ConvOut1Args a; a.in = c->v3; a.in_nb = Nn; a.w = lo.w; a.bias = lo.bias; a.add = c->p11; a.add_nb = B2; a.out = c->depth_net;
+        a.B = Nn; a.H = H1; a.W = W1; a.relu_in = 1; a.bf16 = c->bf16;                           // output = out3 + p11 (:506)
+        RUN(ptta_launch_conv_out1(a, s));
+    }
+#undef CV
+    return 0;
+}
+
+// proj / pred heads (:551-554): emb = pred(proj(feat_zero)), ref = proj(feat); BN1d in train mode.
+int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16, int K, float* hidden, float* out, hipStream_t s) {
+    const Lin& l0 = c->fc[name + ".0"]; const Lin& l3 = c->fc[name + ".3"]; BNorm& bn = c->bn[name + ".1"];
+    const int R = (int)c->Rg;
+    GemmArgs g; g.A = A; g.a_bf16 = a_bf16; g.W = l0.W; g.bias = l0.bias; g.C = hidden; g.R = R; g.K = K; g.N = 512; g.epi = 1; g.part = c->bn_part;
+    RUN(ptta_launch_gemm(g, s));
+    RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_row_blocks(R), R, 512, bn.gamma, bn.beta, 1e-5f, 0.1f, bn.rm, bn.rv, bn.nbt,
+                                bn.mean, bn.inv, bn.scale, bn.shift, s));
+    GemmArgs g2; g2.A = hidden; g2.W = l3.W; g2.bias = l3.bias; g2.C = out; g2.R = R; g2.K = 512; g2.N = 512; g2.pro = 1;
+    g2.pscale = bn.scale; g2.pshift = bn.shift;
+    RUN(ptta_launch_gemm(g2, s));
+    return 0;
+}
+
+int heads_forward(ptta_ctx* c, hipStream_t s) {
+    const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
+    const void* feat_zero = (const char*)c->feat + half;
+    RUN(mlp_forward(c, "proj", feat_zero, c->bf16, 32, c->h1z, c->pz, s));
+    RUN(mlp_forward(c, "pred", c->pz, 0, 512, c->h2, c->emb, s));
+    RUN(mlp_forward(c, "proj", c->feat, c->bf16, 32, c->h1, c->ref, s));     // last: its BN statistics are kept for backward
+    return 0;
+}
+
+// d ref -> d feat through proj = Linear(32,512) - BN1d - ReLU - Linear(512,512)
+int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
+    const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
+    const int R = (int)c->Rg;
+    GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;
+    g.eH = c->h1; g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part;
+    RUN(ptta_launch_gemm(g, s));
+    RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_row_blocks(R), R, 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
+    GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = c->g_feat_f32; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;
+    g2.pscale = c->bnb_gscale; g2.pmean = bn.mean; g2.pinv = bn.inv; g2.pc1 = c->bnb_c1; g2.pc2 = c->bnb_c2;
+    RUN(ptta_launch_gemm(g2, s));
+    if (c->bf16) hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(c->Rg * 32)), dim3(256), 0, s, c->g_feat_f32, (bf16_t*)c->g_feat, c->Rg * 32);
+    else HIPCHK(hipMemcpyAsync(c->g_feat, c->g_feat_f32, (size_t)c->Rg * 32 * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// data gradients from d(depth_net) [Nn,1,Hp,Wp] and d(feat) down to conv1_rgb_meta, then its wgrad
+int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s) {
+    const int Nn = c->Nn, B2 = 2 * Nn;
+    const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
+#define CV(...) RUN(conv32(c, s, __VA_ARGS__))
+    auto dgrad_out1 = [&](const std::string& layer, const float* g, const void* mask, void* out, int H, int W) -> int {
+        const LOut& lo = c->lout[layer];
+        ConvInArgs a; a.cin = 1; a.pl[0].p = g; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H * W;
+        a.wfrag = lo.bfrag; a.wcanon = lo.bcanon; a.mask = mask; a.mask_nb = B2; a.out_raw = out;
+        a.B = Nn; a.H = H; a.W = W; a.bf16 = c->bf16; a.naive = c->naive;
+        return ptta_launch_conv_in(a, s);
+    };
+    auto dgrad_in_ch1 = [&](const std::string& layer, const void* g, const float* add, float* out, int H, int W) -> int {
+        const LIn& li = c->lin_in[layer];
+        ConvOut1Args a; a.in = g; a.in_nb = Nn; a.w = li.bw; a.add = add; a.add_nb = Nn; a.out = out;
+        a.B = Nn; a.H = H; a.W = W; a.relu_in = 0; a.bf16 = c->bf16;
+        return ptta_launch_conv_out1(a, s);
+    };
+    auto em = [](void* raw, const void* mask, int mask_nb) { E e; e.raw = raw; e.mask = mask; e.mask_nb = mask_nb; return e; };
+    // ---- decoder 3 ----
+    RUN(dgrad_out1("depth_decoder3.prdct.3", g_net, c->v3, c->dv3, H1, W1));
+    CV("depth_decoder3.prdct.1", true, CONV_S1, c->dv3, Nn, Nn, H1, W1, false, em(c->ds0_3, c->s0_3, Nn));
+    CV("depth_decoder3.dec1.3", true, CONV_S1, c->ds0_3, Nn, Nn, H1, W1, false, em(c->du3, c->u3, Nn));
+    CV("depth_decoder3.dec1.1", true, CONV_S2, c->du3, Nn, Nn, H1, W1, false, em(c->ds1_3, c->s1_3, Nn));
+    CV("depth_decoder3.dec2.3", true, CONV_S1, c->ds1_3, Nn, Nn, H2, W2, false, em(c->dt3, c->t3, Nn));
+    { E e; e.raw = c->dw2; e.mask = c->w2; e.mask_nb = B2; e.sum = c->dfeat_tot; e.add1 = c->g_feat; e.add1_nb = Nn;
+      CV("depth_decoder3.dec2.1", true, CONV_S2, c->dt3, Nn, Nn, H2, W2, false, e); }
+    // ---- encoder 3 ----
+    RUN(ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, c->bf16, s));
+    CV("depth_encoder3.enc2.3", true, CONV_S1, c->dfeat_tot, Nn, Nn, H4, W4, false, em(c->de3_2a, c->e3_2a, B2));
+    { E e; e.sum = c->de3_1; e.mask = c->e3_1; e.mask_nb = B2; e.add1 = c->ds1_3; e.add1_nb = Nn;
+      CV("depth_encoder3.enc2.1", true, CONV_T2, c->de3_2a, Nn, Nn, H4, W4, false, e); }
+    CV("depth_encoder3.enc1.3", true, CONV_S1, c->de3_1, Nn, Nn, H2, W2, false, em(c->de3_1a, c->e3_1a, B2));
+    { E e; e.sum = c->de3_0; e.mask = c->e3_0; e.mask_nb = B2; e.add1 = c->ds0_3; e.add1_nb = Nn;
+      CV("depth_encoder3.enc1.1", true, CONV_T2, c->de3_1a, Nn, Nn, H2, W2, false, e); }
+    CV("depth_encoder3.init.2", true, CONV_S1, c->de3_0, Nn, Nn, H1, W1, false, em(c->de3_0a, c->e3_0a, B2));
+    RUN(dgrad_in_ch1("depth_encoder3.init.0", c->de3_0a, g_net, c->dp11, H1, W1));       // d p11 = conv^T + d output
+    RUN(ptta_launch_up2T_1ch(c->dp11, c->dq, Nn, H2, W2, s));                              // d(out2 + p12)
+    // ---- decoder 2 ----
+    RUN(dgrad_out1("depth_decoder2.prdct.3", c->dq, c->v2, c->dv2, H2, W2));
+    CV("depth_decoder2.prdct.1", true, CONV_S1, c->dv2, Nn, Nn, H2, W2, false, em(c->ds0_2, c->s0_2, B2));
+    RUN(ptta_launch_up2T_32(c->de3_0, c->ds0_2, c->dz4, Nn, H2, W2, c->bf16, s));         // d z4 = d s0_2 + up2^T(d e3_0)
+    CV("depth_decoder2.dec1.3", true, CONV_S1, c->dz4, Nn, Nn, H2, W2, false, em(c->du2, c->u2, B2));
+    CV("depth_decoder2.dec1.1", true, CONV_S2, c->du2, Nn, Nn, H2, W2, false, em(c->ds1_2, c->s1_2, B2));
+    RUN(ptta_launch_up2T_32(c->de3_1, c->ds1_2, c->dz3, Nn, H4, W4, c->bf16, s));         // d z3 = d s1_2 + up2^T(d e3_1)
+    CV("depth_decoder2.dec2.3", true, CONV_S1, c->dz3, Nn, Nn, H4, W4, false, em(c->dt2, c->t2, B2));
+    { E e; e.sum = c->dz2; e.mask = c->z2; e.mask_nb = B2; e.add1 = c->dz2_up; e.add1_nb = Nn;
+      CV("depth_decoder2.dec2.1", true, CONV_S2, c->dt2, Nn, Nn, H4, W4, false, e); }
+    // ---- encoder 2 ----
+    CV("depth_encoder2.enc2.3", true, CONV_S1, c->dz2, Nn, Nn, H8, W8, false, em(c->de2_2a, c->e2_2a, B2));
+    { E e; e.sum = c->de2_1; e.mask = c->e2_1; e.mask_nb = B2; e.add1 = c->ds1_2; e.add1_nb = Nn;
+      CV("depth_encoder2.enc2.1", true, CONV_T2, c->de2_2a, Nn, Nn, H8, W8, false, e); }
+    CV("depth_encoder2.enc1.3", true, CONV_S1, c->de2_1, Nn, Nn, H4, W4, false, em(c->de2_1a, c->e2_1a, B2));
+    { E e; e.sum = c->de2_0; e.mask = c->e2_0; e.mask_nb = B2; e.add1 = c->ds0_2; e.add1_nb = Nn;
+      CV("depth_encoder2.enc1.1", true, CONV_T2, c->de2_1a, Nn, Nn, H4, W4, false, e); }
+    CV("depth_encoder2.init.2", true, CONV_S1, c->de2_0, Nn, Nn, H2, W2, false, em(c->de2_0a, c->e2_0a, B2));
+    RUN(dgrad_in_ch1("depth_encoder2.init.0", c->de2_0a, c->dq, c->dp12, H2, W2));       // d p12 = conv^T + d q
+    RUN(ptta_launch_up2T_1ch(c->dp12, c->dout1, Nn, H4, W4, s));
+    // ---- decoder 1: only the prediction head reaches the meta layer (y0 = e1_0 + m) ----
+    RUN(dgrad_out1("depth_decoder1.prdct.3", c->dout1, c->v1, c->dv1, H4, W4));
+    { E e; e.sum = c->dm_total; e.mask = c->s0_1; e.mask_nb = B2; e.add1 = c->dw2; e.add1_nb = Nn; e.add2 = c->ds1_2; e.add2_nb = Nn;
+      CV("depth_decoder1.prdct.1", true, CONV_S1, c->dv1, Nn, Nn, H4, W4, false, e); }
+#undef CV
+    // ---- weight gradient of the meta layer: input = c2 of the real frames ----
+    RUN(ptta_launch_wgrad32(c->c2, c->dm_total, c->bf16, Nn, H4, W4, c->wgrad_part, c->gW, c->gB, s));
+    return 0;
+}
+
+int push_hparams(ptta_ctx* c, hipStream_t s) {
+    const float h[8] = {c->hp.lr, c->hp.beta1, c->hp.beta2, c->hp.eps, c->hp.weight_decay,
+                        c->hp.w_sparse_depth, c->hp.w_smoothness, c->hp.w_cos};
+    HIPCHK(hipMemcpyAsync(c->hyper, h, sizeof(h), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));     // h is on the stack
+    return 0;
+}
+
+int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool train, hipStream_t s) {
+    if (!c->meta_w || !c->meta_b) return c->fail("adapted parameters not bound (ptta_bind_adapted)", -3);
+    const float* img = image; const float* sp = sparse;
+    if (c->dual) {
+        hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * 3 * c->Hp * c->Wp)), dim3(256), 0, s, image, c->img_pad, c->N, 3, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
+        hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * c->Hp * c->Wp)), dim3(256), 0, s, sparse, c->sp_pad, c->N, 1, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
+        img = c->img_pad; sp = c->sp_pad;
+    }
+    RUN(ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
+    const L32& ml = c->l32["conv1_rgb_meta"];
+    ptta_pack_conv32(c->meta_w, ml.f.mf32, ml.f.mbf16, ml.f.canon, 0, 0, s);
+    RUN(backbone(c, img, train, s));
+    if (c->dual)
+        hipLaunchKernelGGL(crop_avg_kernel, dim3(nblk((long)c->N * c->H * c->W)), dim3(256), 0, s, c->depth_net, c->depth_final, c->N, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
+    return 0;
+}
+
+const float* final_depth(ptta_ctx* c) { return c->dual ? c->depth_final : c->depth_net; }
+
+}  // namespace
+
+extern "C" {
+
+int ptta_version(void) { return PTTA_VERSION; }
+
+const char* ptta_last_error(ptta_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int height, int width, int dtype, const ptta_hparams* hp) {
+    if (!out) return -1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -19;          // no HIP device: fail loudly
+    if (backbone_id != PTTA_BACKBONE_MSG_CHN || meta_mode != PTTA_META_1LAYER) return -38;
+    if (n < 1 || height < 16 || width < 16 || (dtype != PTTA_DTYPE_F32 && dtype != PTTA_DTYPE_BF16) || !hp) return -22;
+    ptta_ctx* c = new ptta_ctx();
+    c->N = n; c->H = height; c->W = width; c->pt = pad16(height); c->pr = pad16(width);
+    c->Hp = height + c->pt; c->Wp = width + c->pr; c->dual = (c->pt || c->pr) ? 1 : 0; c->Nn = c->dual ? 2 * n : n;
+    c->bf16 = dtype == PTTA_DTYPE_BF16; c->es = c->bf16 ? 2 : 4;
+    const char* impl = getenv("PTTA_CONV_IMPL");
+    c->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
+    c->hp = *hp;
+    build_registry(c);
+    build_workspace(c);
+    if (c->oom || !c->step_dev) { ptta_destroy(c); return -12; }
+    const float h8[8] = {hp->lr, hp->beta1, hp->beta2, hp->eps, hp->weight_decay, hp->w_sparse_depth, hp->w_smoothness, hp->w_cos};
+    if (hipMemcpy(c->hyper, h8, sizeof(h8), hipMemcpyHostToDevice) != hipSuccess) { ptta_destroy(c); return -5; }
+    *out = c;
+    return 0;
+}
+
+void ptta_destroy(ptta_handle h) {
+    if (!h) return;
+    for (void* p : h->allocs) if (p) hipFree(p);
+    delete h;
+}
+
+int ptta_set_hparams(ptta_handle c, const ptta_hparams* hp, ptta_stream s) {
+    if (!c || !hp) return -1;
+    c->hp = *hp;
+    return push_hparams(c, (hipStream_t)s);
+}
+
+static long shape_numel(const int64_t* shape, int ndim) { long n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
+
+int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, const int64_t* shape, int ndim, ptta_stream s_) {
+    if (!c || !name_ || !tensor) return -1;
+    hipStream_t s = (hipStream_t)s_;
+    const std::string name(name_);
+    const long numel = shape_numel(shape, ndim);
+    auto ends = [&](const char* suf) { const size_t n = strlen(suf); return name.size() >= n && name.compare(name.size() - n, n, suf) == 0; };
+    if (name.rfind("proj_t.", 0) == 0) return 0;                     // EMA target head: unused in stage 3 (:551-554)
+    if (name.rfind("conv1_rgb_meta", 0) == 0) return c->fail("adapted parameter " + name + " must be bound with ptta_bind_adapted", -4);
+    const std::string base = name.substr(0, name.rfind('.'));
+    const bool is_w = ends(".weight"), is_b = ends(".bias");
+    const float* src = (const float*)tensor;
+    if (c->l32.count(base)) {
+        L32& l = c->l32[base];
+        if (is_w) {
+            if (numel != 9216) return c->fail("bad shape for " + name, -22);
+            if (!l.transposed) {          // Conv2d weight [out][in][3][3]
+                ptta_pack_conv32(src, l.f.mf32, l.f.mbf16, l.f.canon, 0, 0, s);
+                // backward: stride-1 conv -> stride-1 conv (transposed + flipped); stride-2 conv -> transposed conv
+                const bool s2 = base.find("enc1.1") != std::string::npos || base.find("enc2.1") != std::string::npos ||
+                                base.find("enc3.1") != std::string::npos || base.find("enc4.1") != std::string::npos;
+                if (l.b.mf32) ptta_pack_conv32(src, l.b.mf32, l.b.mbf16, l.b.canon, 1, s2 ? 0 : 1, s);
+            } else {                      // ConvTranspose2d weight [in][out][3][3]
+                ptta_pack_conv32(src, l.f.mf32, l.f.mbf16, l.f.canon, 1, 0, s);
+                if (l.b.mf32) ptta_pack_conv32(src, l.b.mf32, l.b.mbf16, l.b.canon, 0, 0, s);   // backward = stride-2 conv
+            }
+        } else if (is_b) {
+            if (numel != 32) return c->fail("bad shape for " + name, -22);
+            HIPCHK(hipMemcpyAsync(l.bias, src, 32 * 4, hipMemcpyDeviceToDevice, s));
+        } else return c->fail("unknown key " + name, -2);
+        return 0;
+    }
+    if (c->lin_in.count(base)) {
+        LIn& l = c->lin_in[base];
+        if (is_w) {
+            if (numel != 32L * l.cin * 9) return c->fail("bad shape for " + name, -22);
+            ptta_pack_conv_in(src, l.cin, 0, l.cin, 0, l.wfrag, l.wcanon, s);
+            if (l.cin == 2) ptta_pack_conv_out1(src, 2, 1, 1, l.bw, s);      // gradient w.r.t. the predicted-depth plane
+        } else if (is_b) { HIPCHK(hipMemcpyAsync(l.bias, src, 32 * 4, hipMemcpyDeviceToDevice, s)); }
+        else return c->fail("unknown key " + name, -2);
+        return 0;
+    }
+    if (c->lout.count(base)) {
+        LOut& l = c->lout[base];
+        if (is_w) {
+            if (numel != 288) return c->fail("bad shape for " + name, -22);
+            ptta_pack_conv_out1(src, 0, 0, 0, l.w, s);
+            ptta_pack_conv_in(src, 1, 0, 1, 1, l.bfrag, l.bcanon, s);
+        } else if (is_b) { HIPCHK(hipMemcpyAsync(l.bias, src, 4, hipMemcpyDeviceToDevice, s)); }
+        else return c->fail("unknown key " + name, -2);
+        return 0;
+    }
+    if (c->fc.count(base)) {
+        Lin& l = c->fc[base];
+        if (is_w) {
+            if (numel != (long)l.N * l.K) return c->fail("bad shape for " + name, -22);
+            HIPCHK(hipMemcpyAsync(l.W, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(transpose_kernel, dim3(nblk(numel)), dim3(256), 0, s, src, l.Wt, l.N, l.K);
+        } else if (is_b) { HIPCHK(hipMemcpyAsync(l.bias, src, (size_t)l.N * 4, hipMemcpyDeviceToDevice, s)); }
+        else return c->fail("unknown key " + name, -2);
+        return 0;
+    }
+    if (c->bn.count(base)) {
+        BNorm& b = c->bn[base];
+        if (is_w) { HIPCHK(hipMemcpyAsync(b.gamma, src, 512 * 4, hipMemcpyDeviceToDevice, s)); }
+        else if (is_b) { HIPCHK(hipMemcpyAsync(b.beta, src, 512 * 4, hipMemcpyDeviceToDevice, s)); }
+        else if (ends(".running_mean")) b.rm = (float*)tensor;               // bound, updated in place
+        else if (ends(".running_var")) b.rv = (float*)tensor;
+        else if (ends(".num_batches_tracked")) b.nbt = (long long*)tensor;
+        else return c->fail("unknown key " + name, -2);
+        return 0;
+    }
+    return c->fail("unknown key " + name, -2);
+}
+
+int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp_avg, float* exp_avg_sq) {
+    if (!c || !name_ || !param) return -1;
+    const std::string name(name_);
+    if (name == "conv1_rgb_meta.weight") { c->meta_w = param; c->meta_w_m = exp_avg; c->meta_w_v = exp_avg_sq; return 0; }
+    if (name == "conv1_rgb_meta.bias") { c->meta_b = param; c->meta_b_m = exp_avg; c->meta_b_v = exp_avg_sq; return 0; }
+    return c->fail("not an adapted parameter: " + name, -2);
+}
+
+int ptta_set_adam_step(ptta_handle c, int step, ptta_stream s) {
+    if (!c) return -1;
+    HIPCHK(hipMemcpyAsync(c->step_dev, &step, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)s));
+    HIPCHK(hipStreamSynchronize((hipStream_t)s));
+    return 0;
+}
+int ptta_get_adam_step(ptta_handle c, int* step, ptta_stream s) {
+    if (!c || !step) return -1;
+    HIPCHK(hipMemcpyAsync(step, c->step_dev, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)s));
+    HIPCHK(hipStreamSynchronize((hipStream_t)s));
+    return 0;
+}
+
+int64_t ptta_embedding_rows(ptta_handle c) { return c ? c->Rg : 0; }
+
+int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, float* depth_out, float* emb_out, float* ref_out, ptta_stream s_) {
+    if (!c || !image || !sparse) return -1;
+    hipStream_t s = (hipStream_t)s_;
+    c->fwd_valid = false;
+    RUN(forward_common(c, image, sparse, true, s));
+    RUN(heads_forward(c, s));
+    const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
+    if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), dbytes, hipMemcpyDeviceToDevice, s));
+    if (emb_out) HIPCHK(hipMemcpyAsync(emb_out, c->emb, ebytes, hipMemcpyDeviceToDevice, s));
+    if (ref_out) HIPCHK(hipMemcpyAsync(ref_out, c->ref, ebytes, hipMemcpyDeviceToDevice, s));
+    c->fwd_valid = true;
+    return 0;
+}
+
+int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, float* depth_out, ptta_stream s_) {
+    if (!c || !image || !sparse || !depth_out) return -1;
+    hipStream_t s = (hipStream_t)s_;
+    c->fwd_valid = false;                      // the eval pass overwrites the saved activations
+    RUN(forward_common(c, image, sparse, false, s));
+    HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
+                      const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos,
+                      float* loss_info_out, ptta_stream s_) {
+    if (!c || !loss_image || !depth || !sparse || !validity || !loss_info_out) return -1;
+    if (rows > c->Rg) return c->fail("rows exceeds the handle's embedding rows", -22);
+    hipStream_t s = (hipStream_t)s_;
+    const float w3[3] = {w_sd, w_sm, w_cos};
+    HIPCHK(hipMemcpyAsync(c->w3_tmp, w3, sizeof(w3), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    RUN(ptta_launch_loss_forward(depth, loss_image, sparse, validity, c->hp.max_input_depth, emb, ref, rows, 512, c->w3_tmp,
+                                 c->N, c->H, c->W, c->loss_ws, loss_info_out, s));
+    return 0;
+}
+
+int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
+                       const float* emb, const float* ref, int64_t rows, float* gdepth, float* gref, ptta_stream s_) {
+    if (!c || !loss_image || !depth || !sparse || !validity || !gdepth) return -1;
+    RUN(ptta_launch_loss_backward(depth, loss_image, sparse, validity, c->hp.max_input_depth, emb, ref, rows, 512,
+                                  c->N, c->H, c->W, c->loss_ws, gdepth, gref, (hipStream_t)s_));
+    return 0;
+}
+
+int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref, float* gw_out, float* gb_out, ptta_stream s_) {
+    if (!c || !grad_depth) return -1;
+    if (!c->fwd_valid) return c->fail("ptta_backward without a preceding ptta_forward_train", -3);
+    hipStream_t s = (hipStream_t)s_;
+    const float* g_net = grad_depth;
+    if (c->dual) {
+        hipLaunchKernelGGL(scatter_dual_grad_kernel, dim3(nblk((long)c->Nn * c->Hp * c->Wp)), dim3(256), 0, s, grad_depth, c->g_net,
+                           c->N, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
+        g_net = c->g_net;
+    }
+    if (grad_ref) { RUN(heads_backward(c, grad_ref, s)); }
+    else HIPCHK(hipMemsetAsync(c->g_feat, 0, (size_t)c->Rg * 32 * c->es, s));
+    RUN(backbone_backward(c, g_net, s));
+    if (gw_out) HIPCHK(hipMemcpyAsync(gw_out, c->gW, 9216 * 4, hipMemcpyDeviceToDevice, s));
+    if (gb_out) HIPCHK(hipMemcpyAsync(gb_out, c->gB, 32 * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream s_) {
+    if (!c) return -1;
+    if (!c->meta_w_m || !c->meta_w_v || !c->meta_b_m || !c->meta_b_v) return c->fail("Adam moments not bound", -3);
+    hipStream_t s = (hipStream_t)s_;
+    RUN(ptta_launch_step_inc(c->step_dev, s));
+    RUN(ptta_launch_adam(c->meta_w, c->meta_w_m, c->meta_w_v, gw ? gw : c->gW, 9216, c->hyper, c->step_dev, s));
+    RUN(ptta_launch_adam(c->meta_b, c->meta_b_m, c->meta_b_v, gb ? gb : c->gB, 32, c->hyper, c->step_dev, s));
+    return 0;
+}
+
+int ptta_step(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
+              float* depth_out, float* loss_info_out, ptta_stream s_) {
+    if (!c || !image || !sparse) return -1;
+    hipStream_t s = (hipStream_t)s_;
+    if (!loss_image) loss_image = image;
+    RUN(ptta_forward_train(c, image, sparse, depth_out, nullptr, nullptr, s_));
+    const long npx = (long)c->N * c->H * c->W;
+    if (!validity) {
+        hipLaunchKernelGGL(validity_kernel, dim3(nblk(npx)), dim3(256), 0, s, sparse, c->validity_tmp, npx);
+        validity = c->validity_tmp;
+    }
+    RUN(ptta_launch_loss_forward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
+                                 c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info, s));
+    RUN(ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
+                                  c->N, c->H, c->W, c->loss_ws, c->g_final, c->gref_buf, s));
+    RUN(ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_));
+    RUN(ptta_adam_step(c, nullptr, nullptr, s_));
+    if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int ptta_debug_tensor(ptta_handle c, const char* name, float* dst, int64_t capacity, int64_t* numel_host, ptta_stream s_) {
+    if (!c || !name) return -1;
+    auto it = c->dbg.find(name);
+    if (it == c->dbg.end()) return c->fail(std::string("no debug tensor ") + name, -2);
+    if (numel_host) *numel_host = it->second.numel;
+    if (!dst) return 0;
+    if (capacity < it->second.numel) return c->fail("capacity too small", -22);
+    hipStream_t s = (hipStream_t)s_;
+    const long n = it->second.numel;
+    if (it->second.is_act && c->bf16) hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(nblk(n)), dim3(256), 0, s, (const bf16_t*)it->second.p, dst, n);
+    else HIPCHK(hipMemcpyAsync(dst, it->second.p, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// Stand-alone 32->32 3x3 convolution on fp32 NHWC buffers (tests only): packs `weight`, converts
+// to the requested storage type, runs the hot-path kernel and converts back.
+int ptta_op_conv32(const float* in, const float* weight, const float* bias, float* out, int b, int hin, int win, int mode,
+                   int relu_in, int in_major, int flip, int dtype, int naive, ptta_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    ConvW w{};
+    void *tin = nullptr, *tout = nullptr;
+    const int ho = mode == CONV_S1 ? hin : (mode == CONV_S2 ? hin / 2 : hin * 2), wo = mode == CONV_S1 ? win : (mode == CONV_S2 ? win / 2 : win * 2);
+    const long nin = (long)b * hin * win * 32, nout = (long)b * ho * wo * 32;
+    int rc = 0;
+    if (hipMalloc((void**)&w.mf32, 9 * 4 * 64 * 4 * 4) != hipSuccess || hipMalloc((void**)&w.mbf16, 9 * 2 * 64 * 8 * 2) != hipSuccess ||
+        hipMalloc((void**)&w.canon, 9216 * 4) != hipSuccess || hipMalloc(&tin, nin * 2) != hipSuccess || hipMalloc(&tout, nout * 2) != hipSuccess)
+        rc = -12;
+    if (rc == 0) {
+        ptta_pack_conv32(weight, w.mf32, w.mbf16, w.canon, in_major, flip, s);
+        Conv32Args a; a.w = &w; a.bias = bias; a.B = b; a.Hin = hin; a.Win = win; a.mode = mode; a.relu_in = relu_in; a.naive = naive;
+        if (dtype == PTTA_DTYPE_BF16) {
+            hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(nin)), dim3(256), 0, s, in, (bf16_t*)tin, nin);
+            a.in = tin; a.in_nb = b; a.out_raw = tout; a.bf16 = 1;
+            rc = ptta_launch_conv32(a, s);
+            hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(nblk(nout)), dim3(256), 0, s, (const bf16_t*)tout, out, nout);
+        } else {
+            a.in = in; a.in_nb = b; a.out_raw = out; a.bf16 = 0;
+            rc = ptta_launch_conv32(a, s);
+        }
+        hipStreamSynchronize(s);
+    }
+    hipFree(w.mf32); hipFree(w.mbf16); hipFree(w.canon); hipFree(tin); hipFree(tout);
+    return rc;
+}
+
+}  // extern "C"

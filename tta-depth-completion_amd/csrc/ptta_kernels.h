@@ -1,0 +1,106 @@
+// Host-side launch interface of the kernel translation units (internal; the public C-ABI is
+// include/ptta.h).  All pointers are device pointers; every launcher only enqueues on `s`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ptta_common.h"
+
+// ---- conv32.hip ------------------------------------------------------------------------------
+struct ConvW {           // one packed 3x3 32->32 filter, three formats (device memory)
+    float* mf32;         // fp32 MFMA fragments  [9][4][64][4]
+    bf16_t* mbf16;       // bf16 MFMA fragments  [9][2][64][8]
+    float* canon;        // [tap][cin][cout] for the direct kernel / wgrad checks
+};
+struct Conv32Args {
+    const void* in = nullptr; int in_nb = 1;
+    const ConvW* w = nullptr;
+    const float* bias = nullptr;
+    const void* up = nullptr; int up_nb = 1;
+    const void* mask = nullptr; int mask_nb = 1;
+    const void* add1 = nullptr; int add1_nb = 1;
+    const void* add2 = nullptr; int add2_nb = 1;
+    void* out_raw = nullptr; void* out_sum = nullptr;
+    int B = 1, Hin = 0, Win = 0;    // input spatial size; output size follows from mode
+    int mode = CONV_S1; int relu_in = 0; int bf16 = 0; int naive = 0;
+};
+void ptta_pack_conv32(const float* src, float* mf32, bf16_t* mbf16, float* canon, int in_major, int flip, hipStream_t s);
+int ptta_launch_conv32(const Conv32Args& a, hipStream_t s);
+
+// ---- conv_small.hip ---------------------------------------------------------------------------
+struct Plane { const float* p = nullptr; int nb = 1; long bstride = 0; };
+struct ConvInArgs {      // planar fp32 (cin = 1..3) -> 32-channel NHWC
+    Plane pl[3]; int cin = 1; int zero_from_b = 1 << 30;
+    const float* wfrag = nullptr;   // [14][64] fp32 MFMA fragments
+    const float* wcanon = nullptr;  // [tap][cin][32]
+    const float* bias = nullptr;
+    const void* up = nullptr; int up_nb = 1;
+    const void* mask = nullptr; int mask_nb = 1;
+    const void* add1 = nullptr; int add1_nb = 1;
+    void* out_raw = nullptr; void* out_sum = nullptr;
+    int B = 1, H = 0, W = 0; int bf16 = 0; int naive = 0;
+};
+void ptta_pack_conv_in(const float* src, int cin_total, int cin_first, int cin, int transpose_flip,
+                       float* wfrag, float* wcanon, hipStream_t s);
+int ptta_launch_conv_in(const ConvInArgs& a, hipStream_t s);
+
+struct ConvOut1Args {    // 32-channel NHWC -> planar fp32, 1 channel
+    const void* in = nullptr; int in_nb = 1;
+    const float* w = nullptr;       // [tap][32]
+    const float* bias = nullptr;    // [1] or null
+    const float* add = nullptr; int add_nb = 1;
+    float* out = nullptr;
+    int B = 1, H = 0, W = 0; int relu_in = 0; int bf16 = 0;
+};
+void ptta_pack_conv_out1(const float* src, int src_cin_total, int src_cin_index, int from_conv_in, float* w, hipStream_t s);
+int ptta_launch_conv_out1(const ConvOut1Args& a, hipStream_t s);
+
+// ---- resample.hip -----------------------------------------------------------------------------
+int ptta_launch_prep(const float* sparse, float max_input_depth, float* dclamp, float* d12, float* d14,
+                     int N, int H, int W, hipStream_t s);
+int ptta_launch_up2_1ch(const float* in, float* out, int B, int Hin, int Win, hipStream_t s);
+int ptta_launch_up2T_1ch(const float* gout, float* gin, int B, int Hin, int Win, hipStream_t s);
+int ptta_launch_up2T_32(const void* gout, const void* add, void* gin, int B, int Hin, int Win, int bf16, hipStream_t s);
+
+// ---- heads.hip --------------------------------------------------------------------------------
+struct GemmArgs {
+    const void* A = nullptr; int a_bf16 = 0;   // [R][K] (fp32, or bf16 NHWC features when a_bf16)
+    const float* A2 = nullptr;                 // second A tensor (h1) for the BN-backward prologue
+    const float* W = nullptr;                  // [N][K] row-major
+    const float* bias = nullptr;               // [N] or null
+    float* C = nullptr;                        // [R][N]
+    int R = 0, K = 0, N = 0;
+    int pro = 0;                               // 0 none, 1 relu(a*scale[k]+shift[k]), 2 BN-backward
+    const float* pscale = nullptr; const float* pshift = nullptr;    // [K]
+    const float* pmean = nullptr; const float* pinv = nullptr;       // [K] (pro 2)
+    const float* pc1 = nullptr; const float* pc2 = nullptr;          // [K] (pro 2)
+    int epi = 0;                               // 0 none, 1 column sum/sumsq, 2 relu-mask + sum g, sum g*xhat
+    const float* eH = nullptr;                 // [R][N] pre-BN activations (epi 2)
+    const float* escale = nullptr; const float* eshift = nullptr; const float* emean = nullptr; const float* einv = nullptr;
+    float* part = nullptr;                     // [row_blocks][2][N] partial column statistics
+};
+int ptta_gemm_row_blocks(int R);
+int ptta_launch_gemm(const GemmArgs& a, hipStream_t s);
+// BatchNorm1d (train) statistics from partials; also updates running stats (momentum 0.1, unbiased var)
+int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* beta,
+                            float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
+                            float* mean, float* invstd, float* scale, float* shift, hipStream_t s);
+int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
+                                float* gscale, float* c1, float* c2, hipStream_t s);
+
+// ---- loss.hip ---------------------------------------------------------------------------------
+struct LossScalars;      // device-resident scalars, see loss.hip
+int ptta_loss_ws_floats(int N, int H, int W, long R);
+int ptta_launch_loss_forward(const float* depth, const float* image, const float* sparse, const float* validity,
+                             float max_input_depth, const float* emb, const float* ref, long R, int D,
+                             const float* w3_dev /* w_sd, w_sm, w_cos */, int N, int H, int W,
+                             float* ws, float* loss_info, hipStream_t s);
+int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
+                              float max_input_depth, const float* emb, const float* ref, long R, int D,
+                              int N, int H, int W, const float* ws, float* gdepth, float* gref, hipStream_t s);
+
+// ---- wgrad_adam.hip ---------------------------------------------------------------------------
+int ptta_wgrad_chunks(long pixels);
+int ptta_launch_wgrad32(const void* x, const void* gy, int bf16, int B, int H, int W, float* part,
+                        float* gw, float* gb, hipStream_t s);
+int ptta_launch_adam(float* p, float* m, float* v, const float* g, long n, const float* hyper /*lr,b1,b2,eps,wd*/,
+                     const int* step_dev, hipStream_t s);
+int ptta_launch_step_inc(int* step_dev, hipStream_t s);

@@ -1,0 +1,183 @@
+// Resolution changes of the MSG_CHN cascade that are not convolutions
+// (network_exp_msg_chn_adapt.py:487-501): sparse-aware average pooling of the depth input,
+// bilinear x2 (align_corners=True) of the 1-channel predictions, and the transposes of the
+// bilinear x2 used by the backward pass (1-channel planar and 32-channel NHWC).  The forward
+// bilinear x2 of 32-channel maps is fused into the producing conv's epilogue (ptta_common.h).
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+// One thread per 4x4 input block: clamp (external_model_adapt.py:108), 1/2 and 1/4 pooled maps
+// d_s = avg_pool(d, k) / (avg_pool(d > 0, k) + 1e-4)  (network_exp_msg_chn_adapt.py:487,492).
+__global__ void prep_kernel(const float* __restrict__ sparse, float max_d, float* __restrict__ dclamp,
+                            float* __restrict__ d12, float* __restrict__ d14, int N, int H, int W) {
+    const int H4 = H >> 2, W4 = W >> 2;
+    const long total = (long)N * H4 * W4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x4 = (int)(idx % W4);
+        long t_ = idx / W4;
+        const int y4 = (int)(t_ % H4);
+        const int n = (int)(t_ / H4);
+        const float* src = sparse + (size_t)n * H * W;
+        float* dc = dclamp + (size_t)n * H * W;
+        float s4 = 0.f, c4 = 0.f;
+        float s2[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            const int y = 4 * y4 + dy;
+            float4 v = *(const float4*)(src + (size_t)y * W + 4 * x4);
+            float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int dx = 0; dx < 4; ++dx) {
+                float d = a[dx];
+                if (max_d >= 0.f) d = fminf(fmaxf(d, 0.f), max_d);
+                a[dx] = d;
+                const float c = d > 0.f ? 1.f : 0.f;
+                s4 += d; c4 += c;
+                const int q = (dy >> 1) * 2 + (dx >> 1);
+                s2[q] += d; c2[q] += c;
+            }
+            *(float4*)(dc + (size_t)y * W + 4 * x4) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+        d14[idx] = (s4 / 16.f) / (c4 / 16.f + 0.0001f);
+        const int H2 = H >> 1, W2 = W >> 1;
+        float* o2 = d12 + (size_t)n * H2 * W2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            o2[(size_t)(2 * y4 + (q >> 1)) * W2 + 2 * x4 + (q & 1)] = (s2[q] / 4.f) / (c2[q] / 4.f + 0.0001f);
+    }
+}
+
+int ptta_launch_prep(const float* sparse, float max_input_depth, float* dclamp, float* d12, float* d14,
+                     int N, int H, int W, hipStream_t s) {
+    const long total = (long)N * (H / 4) * (W / 4);
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(prep_kernel, dim3(blocks), dim3(256), 0, s, sparse, max_input_depth, dclamp, d12, d14, N, H, W);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void up2_1ch_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int Hin, int Win) {
+    const int Ho = 2 * Hin, Wo = 2 * Win;
+    const float sy = up_scale(Hin, Ho), sx = up_scale(Win, Wo);
+    const long total = (long)B * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Wo);
+        long t_ = idx / Wo;
+        const int y = (int)(t_ % Ho);
+        const int b = (int)(t_ / Ho);
+        const Lerp ly = lerp_coef(y, Hin, sy), lx = lerp_coef(x, Win, sx);
+        const float* p = in + (size_t)b * Hin * Win;
+        out[idx] = ly.l0 * (lx.l0 * p[(size_t)ly.i0 * Win + lx.i0] + lx.l1 * p[(size_t)ly.i0 * Win + lx.i1]) +
+                   ly.l1 * (lx.l0 * p[(size_t)ly.i1 * Win + lx.i0] + lx.l1 * p[(size_t)ly.i1 * Win + lx.i1]);
+    }
+}
+
+int ptta_launch_up2_1ch(const float* in, float* out, int B, int Hin, int Win, hipStream_t s) {
+    const long total = (long)B * Hin * Win * 4;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(up2_1ch_kernel, dim3(blocks), dim3(256), 0, s, in, out, B, Hin, Win);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+// Transposed bilinear x2 as a GATHER (deterministic, no atomics): the gradient of source index i
+// collects every destination d in [2i-3, 2i+3] whose lerp taps touch i.
+__device__ __forceinline__ void up2T_weights(int i, int in_size, float scale, int& d0, float w[7]) {
+    d0 = 2 * i - 3;
+    const int out_size = 2 * in_size;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int d = d0 + k;
+        float ww = 0.f;
+        if (d >= 0 && d < out_size) {
+            const Lerp l = lerp_coef(d, in_size, scale);
+            if (l.i0 == i) ww += l.l0;
+            if (l.i1 == i) ww += l.l1;
+        }
+        w[k] = ww;
+    }
+}
+
+__global__ void up2T_1ch_kernel(const float* __restrict__ gout, float* __restrict__ gin, int B, int Hin, int Win) {
+    const int Wo = 2 * Win, Ho = 2 * Hin;
+    const float sy = up_scale(Hin, Ho), sx = up_scale(Win, Wo);
+    const long total = (long)B * Hin * Win;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % Win);
+        long t_ = idx / Win;
+        const int y = (int)(t_ % Hin);
+        const int b = (int)(t_ / Hin);
+        int dy0, dx0; float wy[7], wx[7];
+        up2T_weights(y, Hin, sy, dy0, wy);
+        up2T_weights(x, Win, sx, dx0, wx);
+        const float* g = gout + (size_t)b * Ho * Wo;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            if (wy[ky] == 0.f) continue;
+            float row = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx)
+                if (wx[kx] != 0.f) row += wx[kx] * g[(size_t)(dy0 + ky) * Wo + dx0 + kx];
+            acc += wy[ky] * row;
+        }
+        gin[idx] = acc;
+    }
+}
+
+int ptta_launch_up2T_1ch(const float* gout, float* gin, int B, int Hin, int Win, hipStream_t s) {
+    const long total = (long)B * Hin * Win;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(up2T_1ch_kernel, dim3(blocks), dim3(256), 0, s, gout, gin, B, Hin, Win);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+// 32-channel NHWC version: one thread per (pixel, 4 channels); gin = add + up2^T(gout).
+template <typename T>
+__global__ void up2T_32_kernel(const T* __restrict__ gout, const T* __restrict__ add, T* __restrict__ gin,
+                               int B, int Hin, int Win) {
+    const int Wo = 2 * Win, Ho = 2 * Hin;
+    const float sy = up_scale(Hin, Ho), sx = up_scale(Win, Wo);
+    const long total = (long)B * Hin * Win * 8;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(idx & 7);
+        long t_ = idx >> 3;
+        const int x = (int)(t_ % Win); t_ /= Win;
+        const int y = (int)(t_ % Hin);
+        const int b = (int)(t_ / Hin);
+        int dy0, dx0; float wy[7], wx[7];
+        up2T_weights(y, Hin, sy, dy0, wy);
+        up2T_weights(x, Win, sx, dx0, wx);
+        const T* g = gout + (size_t)b * Ho * Wo * 32 + 4 * cq;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            if (wy[ky] == 0.f) continue;
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                if (wx[kx] == 0.f) continue;
+                const float wgt = wy[ky] * wx[kx];
+                const T* q = g + ((size_t)(dy0 + ky) * Wo + dx0 + kx) * 32;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += wgt * ld(q + c);
+            }
+        }
+        const size_t o = (((size_t)b * Hin + y) * Win + x) * 32 + 4 * cq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = acc[c];
+            if (add) v += ld(add + o + c);
+            st(gin + o + c, v);
+        }
+    }
+}
+
+int ptta_launch_up2T_32(const void* gout, const void* add, void* gin, int B, int Hin, int Win, int bf16, hipStream_t s) {
+    const long total = (long)B * Hin * Win * 8;
+    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+    if (bf16) hipLaunchKernelGGL((up2T_32_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)gout, (const bf16_t*)add, (bf16_t*)gin, B, Hin, Win);
+    else hipLaunchKernelGGL((up2T_32_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)gout, (const float*)add, (float*)gin, B, Hin, Win);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,119 @@
+// Weight gradient of the adapted meta layer conv1_rgb_meta = Conv2d(32,32,3,1,1)
+// (network_exp_msg_chn_adapt.py:1065-1071) and the fused Adam update (torch.optim.Adam,
+// src/tta_main.py:341-346,633).  Only the adapted parameters get a weight gradient: the reference's
+// autograd computes (and DDP all-reduces) weight gradients for all 1.46 M parameters and throws
+// them away.
+//
+// wgrad: dW[co][ci][tap] = sum_pixels gy[pix][co] * x[pix+tap][ci]  ->  per wave nine 32x32 fp32
+// MFMA accumulators (one per tap) + one for the bias, K = pixels, two pixels per MFMA; each wave
+// reduces a contiguous chunk of pixels and a second, fixed-order pass sums the chunk partials.
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+#define WGRAD_MAX_CHUNKS 512
+#define WGRAD_PART (10 * 1024)       // floats per chunk: 9 taps * 32 * 32 + 32 bias (padded)
+
+int ptta_wgrad_chunks(long pixels) {
+    long c = (pixels + 63) / 64;
+    return (int)(c > WGRAD_MAX_CHUNKS ? WGRAD_MAX_CHUNKS : (c < 1 ? 1 : c));
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void wgrad32_kernel(const T* __restrict__ x, const T* __restrict__ gy, int B, int H, int W,
+                                                     int nchunks, float* __restrict__ part) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const long P = (long)B * H * W;
+    const long per = ((P + nchunks - 1) / nchunks + 1) & ~1L;          // even number of pixels per chunk
+    const long p0 = (long)blockIdx.x * per;
+    long p1 = p0 + per; if (p1 > P) p1 = P;
+    f32x16 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (long pp = p0; pp < p1; pp += 2) {
+        const long pix = pp + h;
+        const bool pv = pix < p1;
+        int px = 0, py = 0, pb = 0;
+        float a = 0.f;
+        if (pv) {
+            px = (int)(pix % W); const long t_ = pix / W; py = (int)(t_ % H); pb = (int)(t_ / H);
+            a = ld(gy + pix * 32 + i);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+            float b = 0.f;
+            if (pv && yy >= 0 && yy < H && xx >= 0 && xx < W) b = ld(x + (((long)pb * H + yy) * W + xx) * 32 + i);
+            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
+        }
+        acc[9] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pv ? 1.f : 0.f, acc[9], 0, 0, 0);
+    }
+    float* out = part + (long)blockIdx.x * WGRAD_PART;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(tap * 32 + acc_row(r, h)) * 32 + i] = acc[tap][r];
+    if (i == 0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[9 * 1024 + acc_row(r, h)] = acc[9][r];
+}
+
+__global__ void wgrad32_reduce_kernel(const float* __restrict__ part, int nchunks, float* __restrict__ gw, float* __restrict__ gb) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= 9 * 1024 + 32) return;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += part[(long)c * WGRAD_PART + o];
+    if (o < 9 * 1024) {
+        const int ci = o & 31, co = (o >> 5) & 31, tap = o >> 10;
+        gw[(co * 32 + ci) * 9 + tap] = s;
+    } else {
+        gb[o - 9 * 1024] = s;
+    }
+}
+
+int ptta_launch_wgrad32(const void* x, const void* gy, int bf16, int B, int H, int W, float* part,
+                        float* gw, float* gb, hipStream_t s) {
+    const int nchunks = ptta_wgrad_chunks((long)B * H * W);
+    if (bf16) hipLaunchKernelGGL((wgrad32_kernel<bf16_t>), dim3(nchunks), dim3(64), 0, s, (const bf16_t*)x, (const bf16_t*)gy, B, H, W, nchunks, part);
+    else hipLaunchKernelGGL((wgrad32_kernel<float>), dim3(nchunks), dim3(64), 0, s, (const float*)x, (const float*)gy, B, H, W, nchunks, part);
+    hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((9 * 1024 + 32 + 255) / 256), dim3(256), 0, s, part, nchunks, gw, gb);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+// torch.optim.Adam single-tensor update: g += wd*p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  The step count lives on the device so the
+// whole TTA step can be replayed from a hipGraph.
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                            long n, const float* __restrict__ hyper, const int* __restrict__ step) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+    const int t = *step;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2s = (float)sqrt(bc2);
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        float gg = g[k];
+        const float pk = p[k];
+        if (wd != 0.f) gg = fmaf(wd, pk, gg);
+        const float mk = b1 * m[k] + (1.f - b1) * gg;
+        const float vk = b2 * v[k] + (1.f - b2) * gg * gg;
+        m[k] = mk; v[k] = vk;
+        p[k] = pk - step_size * (mk / (sqrtf(vk) / bc2s + eps));
+    }
+}
+
+__global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+
+int ptta_launch_step_inc(int* step_dev, hipStream_t s) {
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, step_dev);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+int ptta_launch_adam(float* p, float* m, float* v, const float* g, long n, const float* hyper, const int* step_dev, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256); if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, m, v, g, n, hyper, step_dev);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

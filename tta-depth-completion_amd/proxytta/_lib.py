@@ -1,0 +1,84 @@
+"""ctypes binding of libptta_hip.so (C-ABI: include/ptta.h).
+
+The product path has no CPU fallback: if the shared library is missing or cannot be loaded this
+module raises, and every call that needs a GPU raises when no HIP device is present.
+"""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libptta_hip.so')
+
+PTTA_BACKBONE_MSG_CHN = 0
+PTTA_META_1LAYER = 0
+PTTA_DTYPE_F32 = 0
+PTTA_DTYPE_BF16 = 1
+CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
+
+
+class Hparams(ctypes.Structure):
+    _fields_ = [('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
+                ('weight_decay', c_float), ('w_sparse_depth', c_float), ('w_smoothness', c_float),
+                ('w_cos', c_float), ('max_input_depth', c_float)]
+
+
+# every symbol include/ptta.h declares: (name, restype, argtypes)
+_P = c_void_p
+SIGNATURES = [
+    ('ptta_create', c_int, [POINTER(c_void_p), c_int, c_int, c_int, c_int, c_int, c_int, POINTER(Hparams)]),
+    ('ptta_destroy', None, [_P]),
+    ('ptta_last_error', c_char_p, [_P]),
+    ('ptta_set_hparams', c_int, [_P, POINTER(Hparams), _P]),
+    ('ptta_load_weights', c_int, [_P, c_char_p, _P, POINTER(c_int64), c_int, _P]),
+    ('ptta_bind_adapted', c_int, [_P, c_char_p, _P, _P, _P]),
+    ('ptta_set_adam_step', c_int, [_P, c_int, _P]),
+    ('ptta_get_adam_step', c_int, [_P, POINTER(c_int), _P]),
+    ('ptta_forward_train', c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    ('ptta_embedding_rows', c_int64, [_P]),
+    ('ptta_forward_eval', c_int, [_P, _P, _P, _P, _P]),
+    ('ptta_loss_forward', c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, _P, _P]),
+    ('ptta_loss_backward', c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    ('ptta_backward', c_int, [_P, _P, _P, _P, _P, _P]),
+    ('ptta_adam_step', c_int, [_P, _P, _P, _P]),
+    ('ptta_step', c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    ('ptta_debug_tensor', c_int, [_P, c_char_p, _P, c_int64, POINTER(c_int64), _P]),
+    ('ptta_op_conv32', c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    ('ptta_version', c_int, []),
+]
+
+_lib = None
+
+
+def load():
+    """Load libptta_hip.so (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('libptta_hip.so not found at %s: build it with `python -c "import '
+                           '__graft_entry__ as g; g.build()"` — there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(lib, handle, rc, what):
+    if rc != 0:
+        msg = lib.ptta_last_error(handle).decode() if handle else ''
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous()
+    return c_void_p(t.data_ptr())
+
+
+__all__ = ['load', 'check', 'ptr', 'Hparams', 'SIGNATURES', 'LIB_PATH', 'byref']

@@ -1,0 +1,187 @@
+"""Thin Python owner of one libptta_hip handle: device memory, streams and tensors come from
+PyTorch-ROCm, all arithmetic of the step runs inside the HIP library."""
+import ctypes
+from ctypes import byref, c_int, c_int64, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import Hparams, check, ptr
+
+ADAPTED = ('conv1_rgb_meta.weight', 'conv1_rgb_meta.bias')
+_BOUND_SUFFIX = ('running_mean', 'running_var', 'num_batches_tracked')
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One (batch, height, width, dtype) instance of the MSG_CHN ProxyTTA step on the current GPU."""
+
+    def __init__(self, n, height, width, dtype='fp32', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0,
+                 max_input_depth=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('proxytta needs a HIP device (torch.cuda.is_available() is False); '
+                               'there is no CPU fallback')
+        self.lib = _lib.load()
+        self.n, self.h, self.w = int(n), int(height), int(width)
+        self.dtype = dtype
+        self.hp = Hparams(lr, betas[0], betas[1], eps, weight_decay, w_sparse_depth, w_smoothness,
+                          w_cos, -1.0 if max_input_depth is None else float(max_input_depth))
+        self.handle = c_void_p()
+        code = {'fp32': _lib.PTTA_DTYPE_F32, 'bf16': _lib.PTTA_DTYPE_BF16}[dtype]
+        rc = self.lib.ptta_create(byref(self.handle), _lib.PTTA_BACKBONE_MSG_CHN, _lib.PTTA_META_1LAYER,
+                                  self.n, self.h, self.w, code, byref(self.hp))
+        if rc != 0:
+            raise RuntimeError('ptta_create failed (%d)' % rc)
+        self.rows = int(self.lib.ptta_embedding_rows(self.handle))
+        self._keep = {}           # tensors whose storage the library borrows
+        self.device = torch.device('cuda', torch.cuda.current_device())
+
+    def close(self):
+        if getattr(self, 'handle', None) and self.handle.value:
+            torch.cuda.synchronize()
+            self.lib.ptta_destroy(self.handle)
+            self.handle = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        check(self.lib, self.handle, rc, what)
+
+    # ---- weights ---------------------------------------------------------------------------
+    def load_state_dict(self, state):
+        """state: {reference state_dict key: cuda tensor}.  Adapted parameters are skipped (bind
+        them with bind_adapted); BatchNorm buffers are bound by pointer and updated in place."""
+        for k, t in state.items():
+            if k in ADAPTED:
+                continue
+            assert t.is_cuda and t.is_contiguous(), k
+            if k.endswith(_BOUND_SUFFIX):
+                self._keep[k] = t
+            shape = (c_int64 * max(t.dim(), 1))(*([int(x) for x in t.shape] or [1]))
+            self._chk(self.lib.ptta_load_weights(self.handle, k.encode(), ptr(t), shape, max(t.dim(), 1),
+                                                 _stream()), 'ptta_load_weights(%s)' % k)
+
+    def bind_adapted(self, name, param, exp_avg, exp_avg_sq):
+        for t in (param, exp_avg, exp_avg_sq):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+        self._keep['adapt/' + name] = (param, exp_avg, exp_avg_sq)
+        self._chk(self.lib.ptta_bind_adapted(self.handle, name.encode(), ptr(param), ptr(exp_avg),
+                                             ptr(exp_avg_sq)), 'ptta_bind_adapted')
+
+    def set_hparams(self, **kw):
+        for k, v in kw.items():
+            if k == 'betas':
+                self.hp.beta1, self.hp.beta2 = v
+            elif k == 'max_input_depth':
+                self.hp.max_input_depth = -1.0 if v is None else float(v)
+            else:
+                setattr(self.hp, k, v)
+        self._chk(self.lib.ptta_set_hparams(self.handle, byref(self.hp), _stream()), 'ptta_set_hparams')
+
+    def set_adam_step(self, step):
+        self._chk(self.lib.ptta_set_adam_step(self.handle, int(step), _stream()), 'ptta_set_adam_step')
+
+    def adam_step_count(self):
+        out = c_int(0)
+        self._chk(self.lib.ptta_get_adam_step(self.handle, byref(out), _stream()), 'ptta_get_adam_step')
+        return out.value
+
+    # ---- the path ----------------------------------------------------------------------------
+    def _f32(self, t, shape):
+        assert t.is_cuda and t.dtype == torch.float32 and tuple(t.shape) == tuple(shape), (t.shape, shape)
+        return t.contiguous()
+
+    def forward_train(self, image, sparse, want_emb=True):
+        image = self._f32(image, (self.n, 3, self.h, self.w))
+        sparse = self._f32(sparse, (self.n, 1, self.h, self.w))
+        depth = torch.empty((self.n, 1, self.h, self.w), device=image.device, dtype=torch.float32)
+        emb = ref = None
+        if want_emb:
+            emb = torch.empty((self.rows, 512), device=image.device, dtype=torch.float32)
+            ref = torch.empty_like(emb)
+        self._chk(self.lib.ptta_forward_train(self.handle, ptr(image), ptr(sparse), ptr(depth), ptr(emb),
+                                              ptr(ref), _stream()), 'ptta_forward_train')
+        return depth, emb, ref
+
+    def forward_eval(self, image, sparse):
+        image = self._f32(image, (self.n, 3, self.h, self.w))
+        sparse = self._f32(sparse, (self.n, 1, self.h, self.w))
+        depth = torch.empty((self.n, 1, self.h, self.w), device=image.device, dtype=torch.float32)
+        self._chk(self.lib.ptta_forward_eval(self.handle, ptr(image), ptr(sparse), ptr(depth), _stream()),
+                  'ptta_forward_eval')
+        return depth
+
+    def loss_forward(self, loss_image, depth, sparse, validity, emb, ref, w_sd, w_sm, w_cos):
+        info = torch.empty(4, device=depth.device, dtype=torch.float32)
+        rows = 0 if emb is None else emb.shape[0]
+        self._chk(self.lib.ptta_loss_forward(self.handle, ptr(loss_image.contiguous()), ptr(depth.contiguous()),
+                                             ptr(sparse.contiguous()), ptr(validity.contiguous()),
+                                             ptr(None if emb is None else emb.contiguous()),
+                                             ptr(None if ref is None else ref.contiguous()), rows,
+                                             float(w_sd), float(w_sm), float(w_cos), ptr(info), _stream()),
+                  'ptta_loss_forward')
+        return info
+
+    def loss_backward(self, loss_image, depth, sparse, validity, emb, ref):
+        """Gradients of the LAST loss_forward w.r.t. depth and ref (same inputs must be passed)."""
+        gd = torch.empty_like(depth)
+        gr = None if ref is None else torch.empty_like(ref)
+        rows = 0 if emb is None else emb.shape[0]
+        self._chk(self.lib.ptta_loss_backward(self.handle, ptr(loss_image.contiguous()), ptr(depth.contiguous()),
+                                              ptr(sparse.contiguous()), ptr(validity.contiguous()),
+                                              ptr(None if emb is None else emb.contiguous()),
+                                              ptr(None if ref is None else ref.contiguous()), rows,
+                                              ptr(gd), ptr(gr), _stream()), 'ptta_loss_backward')
+        return gd, gr
+
+    def backward(self, grad_depth, grad_ref):
+        gw = torch.empty((32, 32, 3, 3), device=grad_depth.device, dtype=torch.float32)
+        gb = torch.empty((32,), device=grad_depth.device, dtype=torch.float32)
+        self._chk(self.lib.ptta_backward(self.handle, ptr(grad_depth.contiguous()),
+                                         ptr(None if grad_ref is None else grad_ref.contiguous()),
+                                         ptr(gw), ptr(gb), _stream()), 'ptta_backward')
+        return gw, gb
+
+    def adam_step(self, gw=None, gb=None):
+        self._chk(self.lib.ptta_adam_step(self.handle, ptr(gw), ptr(gb), _stream()), 'ptta_adam_step')
+
+    def step(self, image, sparse, validity=None, loss_image=None, want_depth=False):
+        """forward + loss + backward + Adam in one enqueue (src/tta_main.py:610-633).
+        Returns (loss_info[4] device tensor, depth or None)."""
+        image = self._f32(image, (self.n, 3, self.h, self.w))
+        sparse = self._f32(sparse, (self.n, 1, self.h, self.w))
+        info = torch.empty(4, device=image.device, dtype=torch.float32)
+        depth = torch.empty((self.n, 1, self.h, self.w), device=image.device, dtype=torch.float32) if want_depth else None
+        self._chk(self.lib.ptta_step(self.handle, ptr(image), ptr(None if loss_image is None else loss_image.contiguous()),
+                                     ptr(sparse), ptr(None if validity is None else validity.contiguous()),
+                                     ptr(depth), ptr(info), _stream()), 'ptta_step')
+        return info, depth
+
+    def debug_tensor(self, name):
+        n = c_int64(0)
+        self._chk(self.lib.ptta_debug_tensor(self.handle, name.encode(), None, 0, byref(n), _stream()), 'ptta_debug_tensor')
+        out = torch.empty(n.value, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.ptta_debug_tensor(self.handle, name.encode(), ptr(out), n.value, byref(n), _stream()),
+                  'ptta_debug_tensor')
+        return out
+
+
+def op_conv32(x_nhwc, weight, bias, mode, relu_in=False, in_major=False, flip=False, dtype='fp32', naive=False):
+    """Test hook: run the hot-path 32->32 3x3 kernel on an fp32 NHWC tensor."""
+    lib = _lib.load()
+    b, h, w, _ = x_nhwc.shape
+    ho, wo = {0: (h, w), 1: (h // 2, w // 2), 2: (2 * h, 2 * w)}[mode]
+    out = torch.empty((b, ho, wo, 32), device=x_nhwc.device, dtype=torch.float32)
+    rc = lib.ptta_op_conv32(ptr(x_nhwc.contiguous()), ptr(weight.contiguous()), ptr(bias), ptr(out), b, h, w, mode,
+                            int(relu_in), int(in_major), int(flip), 1 if dtype == 'bf16' else 0, int(naive), _stream())
+    if rc != 0:
+        raise RuntimeError('ptta_op_conv32 failed (%d)' % rc)
+    return out

@@ -1,0 +1,355 @@
+"""Host-side mirror of the reference's plugin surface for the ProxyTTA hot path.
+
+``ExternalModel_Adapt`` keeps the method names, argument meaning and return values of
+src/external_model_adapt.py:29-660 and of the per-backbone adapter src/msg_chn_model_adapt.py
+(forward / compute_loss / _prepare_head / adapt_parameters / parameters / train / eval / to /
+restore_model / save_model / convert_syncbn / distributed_data_parallel), so a tta_main-style
+driver runs unchanged; underneath, forward, loss, backward and Adam are libptta_hip kernels.
+``step()`` and ``adapt()`` are the fused entry points the reference only has inline
+(src/tta_main.py:579-636 and :504-804).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import synth
+from .engine import ADAPTED, Engine
+
+CANONICAL_LOSS_TYPE = 'adapt_meta_selfsup_seq_ema_reverse'
+
+
+class _Tree(nn.Module):
+    """Parameter container with the reference's state_dict keys (no forward of its own)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def _leaf(self, dotted, tensor, is_param):
+        mod = self
+        parts = dotted.split('.')
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, _Tree())
+            mod = getattr(mod, p)
+        if is_param:
+            mod.register_parameter(parts[-1], nn.Parameter(tensor))
+        else:
+            mod.register_buffer(parts[-1], tensor)
+
+
+def _init_tensor(name, shape):
+    """Shape-faithful default init (xavier for the backbone convs with bias 0.01, kaiming fan_out
+    for the meta conv, PyTorch defaults for Linear/BatchNorm); real runs restore a checkpoint."""
+    if name.endswith('num_batches_tracked'):
+        return torch.zeros((), dtype=torch.int64)
+    if name.endswith('running_mean'):
+        return torch.zeros(shape)
+    if name.endswith('running_var'):
+        return torch.ones(shape)
+    t = torch.empty(shape)
+    if len(shape) == 4:
+        if 'meta' in name:
+            nn.init.kaiming_normal_(t, mode='fan_out', nonlinearity='relu')
+        else:
+            nn.init.xavier_normal_(t)
+    elif len(shape) == 2:
+        nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+    elif name.endswith('bias'):
+        if '.1.' in name and ('proj' in name or 'pred' in name):
+            t.zero_()
+        elif 'proj' in name or 'pred' in name:
+            t.uniform_(-0.04, 0.04)
+        else:
+            t.fill_(0.01)
+    else:
+        t.fill_(1.0)
+    return t
+
+
+class _ForwardFn(torch.autograd.Function):
+    """(depth, emb, ref) = network(image, sparse); backward -> grads of the adapted parameters."""
+
+    @staticmethod
+    def forward(ctx, adapter, image, sparse, weight, bias):
+        eng = adapter._engine(image)
+        depth, emb, ref = eng.forward_train(image, sparse)
+        ctx.eng = eng
+        ctx.mark_non_differentiable(emb)
+        return depth, emb, ref
+
+    @staticmethod
+    def backward(ctx, g_depth, g_emb, g_ref):
+        if g_depth is None:
+            g_depth = torch.zeros((ctx.eng.n, 1, ctx.eng.h, ctx.eng.w), device=ctx.eng.device)
+        gw, gb = ctx.eng.backward(g_depth, g_ref)
+        return None, None, None, gw, gb
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, image, depth, sparse, validity, emb, ref, w_sd, w_sm, w_cos):
+        info = eng.loss_forward(image, depth, sparse, validity, emb, ref, w_sd, w_sm, w_cos)
+        # the gate and the gradient scalars live on the device until the next loss call
+        ctx.eng, ctx.args = eng, (image, depth.detach(), sparse, validity, None if emb is None else emb.detach(),
+                                  None if ref is None else ref.detach())
+        return info[0].clone(), info
+
+    @staticmethod
+    def backward(ctx, g_loss, g_info):
+        gd, gr = ctx.eng.loss_backward(*ctx.args)
+        gd = gd * g_loss
+        if gr is not None:
+            gr = gr * g_loss
+        return None, None, gd, None, None, None, gr, None, None, None
+
+
+class MsgChnModel_Adapt(object):
+    """Counterpart of src/msg_chn_model_adapt.py:11-556 on libptta_hip."""
+
+    def __init__(self, max_predict_depth=5.0, inpainting=False, device=torch.device('cuda'), dtype='fp32',
+                 max_input_depth=None):
+        self.max_predict_depth = max_predict_depth
+        self.max_input_depth = max_input_depth
+        self.device = device
+        self.dtype = dtype
+        self.training = True
+        self.prepare_mode = None
+        self.model = _Tree()
+        for k, s in synth.msg_chn_keys():                     # heads + meta layer come with _prepare_head
+            if not k.startswith(('rgb_encoder', 'depth_')):
+                continue
+            self.model._leaf(k, _init_tensor(k, s), not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+        self._engines = {}
+        self._opt_state = {}
+        self.hparams = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                            w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0)
+        self.total_time = self.train_time = self.eval_time = 0.0
+        self.to(device)
+
+    # ---- reference surface -----------------------------------------------------------------
+    def _prepare_head(self, mode=''):
+        """network_adapt._prepare_head (network_exp_msg_chn_adapt.py:1022-1087)."""
+        if 'meta' not in mode or 'selfsup' not in mode or 'ema' not in mode or 'seq' not in mode:
+            raise NotImplementedError('hot path covers prepare_mode meta_selfsup_seq_{1layer}_ema, got %r' % mode)
+        if '1layer' not in mode:
+            raise NotImplementedError('only the 1layer meta layer is built in this round (got %r)' % mode)
+        self.prepare_mode = mode
+        for k, s in synth.msg_chn_keys(mode):
+            if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
+                self.model._leaf(k, _init_tensor(k, s).to(self.device),
+                                 not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
+        self._engines.clear()
+
+    def parameters(self):
+        return list(self.model.parameters())
+
+    def adapt_parameters(self, mode=None):
+        """mode 'meta': every parameter whose name contains 'meta' (msg_chn_model_adapt.py:392-396)."""
+        if mode != 'meta':
+            raise NotImplementedError("adapt_mode %r: only 'meta' is on the accelerated path" % mode)
+        return nn.ParameterList([p for n, p in self.model.named_parameters() if 'meta' in n])
+
+    def train(self):
+        self.training = True
+        self.model.train()
+
+    train_prepare = train
+    train_meta = train
+
+    def eval(self):
+        self.training = False
+        self.model.eval()
+
+    def to(self, device):
+        self.device = device
+        self.model.to(device)
+        self._engines.clear()
+
+    def data_parallel(self):
+        raise NotImplementedError('one process per GPU; use proxytta.distributed')
+
+    def distributed_data_parallel(self, rank):
+        """The reference wraps in DDP (msg_chn_model_adapt.py:476-480) and all-reduces every
+        gradient; here only the adapted-parameter gradients are reduced (proxytta.distributed)."""
+        self.ddp_rank = rank
+
+    def convert_syncbn(self, apex=False):
+        self.sync_bn = True        # statistics exchange is handled by proxytta.distributed
+
+    def restore_model(self, restore_path, optimizer=None):
+        ckpt = torch.load(restore_path, map_location=self.device)
+        self.load_state_dict(ckpt['net'])
+        if optimizer is not None and 'optimizer' in ckpt:
+            optimizer.load_state_dict(ckpt['optimizer'])
+        return optimizer, ckpt.get('train_step', 0)
+
+    def save_model(self, checkpoint_path, step, optimizer, meanvar=None):
+        torch.save({'net': self.model.state_dict(), 'optimizer': optimizer.state_dict() if optimizer else {},
+                    'train_step': step}, checkpoint_path)
+
+    def load_state_dict(self, state):
+        with torch.no_grad():
+            own = self.model.state_dict()
+            missing = [k for k in own if k not in state]
+            if missing:
+                raise KeyError('missing keys: %s' % missing[:5])
+            for k, v in own.items():
+                v.copy_(torch.as_tensor(state[k]).to(v.device))
+        for eng in self._engines.values():
+            eng.load_state_dict(self.model.state_dict())
+
+    # ---- engine plumbing --------------------------------------------------------------------
+    def _engine(self, image):
+        n, _, h, w = image.shape
+        key = (n, h, w)
+        eng = self._engines.get(key)
+        if eng is None:
+            if self.prepare_mode is None:
+                raise RuntimeError('_prepare_head(mode) must be called before forward (tta_main.py:322)')
+            eng = Engine(n, h, w, dtype=self.dtype, max_input_depth=self.max_input_depth, **self.hparams)
+            eng.load_state_dict(self.model.state_dict())
+            params = dict(self.model.named_parameters())
+            for name in ADAPTED:
+                p = params[name]
+                st = self._opt_state.setdefault(name, {'exp_avg': torch.zeros_like(p.data), 'exp_avg_sq': torch.zeros_like(p.data)})
+                eng.bind_adapted(name, p.data, st['exp_avg'], st['exp_avg_sq'])
+            self._engines[key] = eng
+        return eng
+
+    def set_hparams(self, **kw):
+        self.hparams.update({k: v for k, v in kw.items() if k in self.hparams})
+        if 'max_input_depth' in kw:
+            self.max_input_depth = kw['max_input_depth']
+        for eng in self._engines.values():
+            eng.set_hparams(**kw)
+
+    def bind_optimizer(self, optimizer):
+        """Share Adam state with a torch.optim.Adam built on adapt_parameters(): its exp_avg /
+        exp_avg_sq tensors become the buffers the fused step updates, so optimizer.state_dict()
+        (save_model) stays meaningful."""
+        params = dict(self.model.named_parameters())
+        g = optimizer.param_groups[0]
+        self.set_hparams(lr=g['lr'], betas=tuple(g['betas']), eps=g['eps'], weight_decay=g['weight_decay'])
+        for name in ADAPTED:
+            p = params[name]
+            st = optimizer.state[p]
+            if 'exp_avg' not in st:
+                st['step'] = torch.tensor(0.0)
+                st['exp_avg'] = torch.zeros_like(p.data)
+                st['exp_avg_sq'] = torch.zeros_like(p.data)
+            self._opt_state[name] = st
+        self._engines.clear()
+        self._optimizer = optimizer
+
+    # ---- forward / loss -----------------------------------------------------------------------
+    def forward(self, image, sparse_depth, intrinsics=None, crop_mask=None, loss_type='pretrain'):
+        if not ('meta' in loss_type and 'selfsup' in loss_type):
+            raise NotImplementedError('loss_type %r is not on the accelerated path' % loss_type)
+        if self.training and 'adapt' in loss_type:
+            params = dict(self.model.named_parameters())
+            return _ForwardFn.apply(self, image, sparse_depth, params[ADAPTED[0]], params[ADAPTED[1]])
+        with torch.no_grad():
+            return self._engine(image).forward_eval(image, sparse_depth)
+
+    def step(self, image, sparse_depth, validity_map=None, loss_image=None, want_depth=False):
+        eng = self._engine(image)
+        info, depth = eng.step(image, sparse_depth, validity_map, loss_image, want_depth)
+        opt = getattr(self, '_optimizer', None)
+        if opt is not None:
+            for p in opt.param_groups[0]['params']:
+                if 'step' in opt.state[p]:
+                    opt.state[p]['step'] += 1
+        return info, depth
+
+
+class ExternalModel_Adapt(object):
+    """Counterpart of src/external_model_adapt.py:29 for model_name='msg_chn'."""
+
+    def __init__(self, model_name, min_predict_depth, max_predict_depth, max_input_depth=None, offset=False,
+                 from_scratch=False, dataset_name=None, device=torch.device('cuda'), dtype='fp32'):
+        self.model_name = model_name
+        self.dataset_name = dataset_name
+        self.device = device
+        self.max_predict_depth = max_predict_depth
+        self.max_input_depth = max_input_depth
+        if model_name == 'msg_chn':
+            self.model = MsgChnModel_Adapt(device=device, max_predict_depth=max_predict_depth, dtype=dtype,
+                                           max_input_depth=max_input_depth)
+        elif model_name == 'nlspn' or 'costdcnet' in model_name:
+            raise NotImplementedError('%s is not on the MI355X hot path yet (SURVEY.md §8 rows a16/a17)' % model_name)
+        else:
+            raise ValueError('Unsupported depth completion model: {}'.format(model_name))
+
+    def forward(self, image, sparse_depth, crop_mask=None, intrinsics=None, loss_type='pretrain'):
+        if loss_type == 'get_time':
+            m = self.model
+            return [m.total_time, m.train_time, m.eval_time]
+        # the clamp of external_model_adapt.py:108 happens inside the library (prep kernel)
+        return self.model.forward(image=image, sparse_depth=sparse_depth, intrinsics=intrinsics,
+                                  crop_mask=crop_mask, loss_type=loss_type)
+
+    def compute_loss(self, input_rgb=None, output_depth=None, sparse_depth=None, validity_map=None,
+                     embedding=None, reference=None, w_loss_sparse_depth=1.0, w_loss_smoothness=1.0,
+                     w_loss_cos=1.0, loss_type='adapt', **unused):
+        if 'adapt' not in loss_type:
+            raise NotImplementedError('loss_type %r is not on the accelerated path' % loss_type)
+        eng = self.model._engine(input_rgb)
+        loss, info = _LossFn.apply(eng, input_rgb, output_depth, sparse_depth, validity_map, embedding, reference,
+                                   w_loss_sparse_depth, w_loss_smoothness, w_loss_cos)
+        info = info.detach()
+        return loss, {'loss': loss, 'loss_smooth': info[1], 'loss_sparse_depth': info[2], 'loss_cos': info[3]}
+
+    def _prepare_head(self, mode=''):
+        self.model._prepare_head(mode=mode)
+
+    def parameters(self):
+        return self.model.parameters()
+
+    def adapt_parameters(self, mode=''):
+        return self.model.adapt_parameters(mode=mode)
+
+    def train(self, meta=False, prepare=False):
+        self.model.train()
+
+    def eval(self):
+        self.model.eval()
+
+    def to(self, device):
+        self.device = device
+        self.model.to(device)
+
+    def data_parallel(self):
+        self.model.data_parallel()
+
+    def distributed_data_parallel(self, rank):
+        self.model.distributed_data_parallel(rank)
+
+    def restore_model(self, restore_path, optimizer=None, learning_schedule=None, learning_rates=None,
+                      n_step_per_epoch=None):
+        return self.model.restore_model(restore_path=restore_path, optimizer=optimizer)
+
+    def save_model(self, checkpoint_path, step, optimizer, meanvar=None):
+        self.model.save_model(checkpoint_path, step, optimizer, meanvar)
+
+    def convert_syncbn(self, apex=False):
+        self.model.convert_syncbn(apex)
+
+    # ---- fused entry points -----------------------------------------------------------------
+    def step(self, image, sparse_depth, validity_map=None, loss_image=None, want_depth=False):
+        """One TTA step (src/tta_main.py:610-633) in one library call; returns (loss_info[4], depth)."""
+        return self.model.step(image, sparse_depth, validity_map, loss_image, want_depth)
+
+    def adapt(self, image, sparse_depth, inner_iter=1, validity_map=None, loss_image=None):
+        """Per-frame adaptation = inner_iter steps then the scored eval forward
+        (src/tta_main.py:579-636 and :729-736).  Returns (depth, loss_info of the last step)."""
+        info = None
+        self.model.train()
+        for _ in range(inner_iter):
+            info, _ = self.model.step(image, sparse_depth, validity_map, loss_image)
+        self.model.eval()
+        depth = self.model.forward(image, sparse_depth, loss_type=CANONICAL_LOSS_TYPE)
+        return depth, info
+
+
+ExternalModelAdapt = ExternalModel_Adapt

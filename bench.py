@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py — ProxyTTA step throughput on MI355X (metric of BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W [--dtype fp32|bf16]
+
+One "step" = one pass of the hot path (forward [grad + proxy pass + heads] + loss + backward +
+Adam, src/tta_main.py:610-633) over one synthetic 352x1216 KITTI-shaped frame, MSG_CHN backbone,
+prepare_mode meta_selfsup_seq_1layer_ema, batch 1 per GPU, inputs resident in HBM.
+N > 1: one process per GPU (torch.distributed.run), independent frame streams sharded over the
+ranks, no data-path collective ("weak" scaling); barrier + max-over-ranks timing.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     dominant kernel = conv32_mfma_kernel<S1, relu> (stride-1 3x3 32->32 conv):
+               algorithmic bytes/MACs of its launches (SURVEY.md §8d counting rule: input + output +
+               weight elements per layer) / their duration measured with hipEvents on the launch
+               stream inside the timed region (ptta_profile).
+  cpu_baseline the oracle (PyTorch CPU restatement, oracle/proxytta_oracle.py) timed on this
+               box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tta-depth-completion_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MODE = 'meta_selfsup_seq_1layer_ema'
+H, W = 352, 1216
+# SURVEY.md §8d / BASELINE.md §3 (measured with hooks on the reference): 905.0 M layer-I/O elements
+# and 107.2 GMAC per step for MSG_CHN 1layer at 352x1216, batch 1
+ALG_ELEMENTS_PER_STEP = 905.0e6
+ALG_FLOP_PER_STEP = 214.5e9
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK = 157.3e12   # fp32 matrix peak
+MFMA_BF16_PEAK = 2.5e15    # dense bf16
+HP = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0,
+          w_cos=0.1, max_input_depth=80.0)
+
+
+def cpu_baseline(steps=3):
+    from oracle import proxytta_oracle as O
+    from proxytta import synth
+    # PyTorch's CPU convolutions at batch 1 stop scaling (and then regress badly) past a few dozen
+    # threads; 16 is where the oracle is fastest on the GPU box's host (99 s/step with all 256)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    o = O.MsgChnOracle(synth.formula_state_dict(MODE), MODE, max_input_depth=80.0, lr=1e-3, w_sd=1.0, w_sm=2.0, w_cos=0.1)
+    frames = [[torch.from_numpy(x) for x in synth.synthetic_frame(i, H, W, 1)] for i in range(2)]
+    o.step(*frames[0])                                   # warm-up
+    t0 = time.time()
+    for i in range(steps):
+        o.step(*frames[i % 2])
+    dt = (time.time() - t0) / steps
+    return {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d steps of the same 352x1216 workload after 1 warm-up (PyTorch-CPU oracle, fp32, %.2f s/step)' % (steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'bf16'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    from proxytta import synth
+    from proxytta.engine import ADAPTED, Engine
+    eng = Engine(1, H, W, dtype=args.dtype, **HP)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
+    eng.load_state_dict(sd)
+    for name in ADAPTED:
+        eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+    nframes = 4     # this rank's slice of the frame stream, resident in HBM before the timed region
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(rank * 1000 + i, H, W, 1)] for i in range(nframes)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.step(*frames[i % nframes])
+    eng.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    info = None
+    for i in range(args.steps):
+        info, _ = eng.step(*frames[i % nframes])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms, abytes, macs, launches = eng.profile_read(1)      # class 1 = stride-1, relu-in
+    eng.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(info).all().item())
+
+    if rank == 0:
+        es = 4 if args.dtype == 'fp32' else 2
+        steps_per_s = world * args.steps / elapsed
+        if args.dtype == 'fp32':
+            # fp32: arithmetic intensity 59 FLOP/B > ridge 19.7 -> the fp32 matrix pipe is the roof
+            achieved = 2.0 * macs / (ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': achieved, 'peak': MFMA_F32_PEAK / 1e12, 'unit': 'TFLOP/s',
+                    'frac': achieved / (MFMA_F32_PEAK / 1e12)}
+        else:
+            achieved = abytes / (ms * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                    'frac': achieved / (HBM_PEAK / 1e9)}
+        roof.update({'kernel': 'conv32_mfma_kernel<%s, CONV_S1, relu>' % ('float' if es == 4 else 'bf16'),
+                     'launches': launches, 'avg_launch_us': 1e3 * ms / max(launches, 1),
+                     'alg_bytes_per_launch': abytes / max(launches, 1), 'traffic': None})
+        tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.dtype)
+        if os.path.exists(tpath):       # HBM bytes per launch from the separate rocprofv3 --pmc passes
+            roof['traffic'] = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        out = {
+            'metric': 'TTA frames/sec (fwd+loss+bwd+Adam) at 352x1216', 'value': steps_per_s, 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if es == 4 else 'bf16',
+            'data': 'synthetic',
+            'config': {'workload': 'MSG_CHN 1layer meta, 352x1216 KITTI-shaped synthetic, 1 TTA step/frame, batch 1 per GPU',
+                       'parallelism': 'independent frame streams, dp%d, no collectives' % world, 'finite': finite},
+            'step_roofline': {'alg_bytes_per_step': ALG_ELEMENTS_PER_STEP * es, 'alg_flop_per_step': ALG_FLOP_PER_STEP,
+                              'hbm_frac_per_gpu': ALG_ELEMENTS_PER_STEP * es * (steps_per_s / world) / HBM_PEAK,
+                              'mfma_frac_per_gpu': ALG_FLOP_PER_STEP * (steps_per_s / world) /
+                              (MFMA_F32_PEAK if es == 4 else MFMA_BF16_PEAK)},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

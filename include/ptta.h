@@ -102,6 +102,14 @@ int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* gr
 int ptta_step(ptta_handle h, const float* image, const float* loss_image, const float* sparse_depth,
               const float* validity, float* depth_out, float* loss_info_out, ptta_stream s);
 
+/* Measurement hook for bench.py: while enabled, every launch of the 3x3 32->32 convolution kernel
+ * is bracketed by hipEvents on its own stream.  klass = geometry*2 + relu_in (geometry 0 = stride 1,
+ * 1 = stride 2, 2 = transposed); read returns the summed duration (ms), the algorithmic bytes and
+ * MACs (SURVEY.md 8d counting rule) and the launch count since enable, after synchronising s. */
+int ptta_profile(ptta_handle h, int enable);
+int ptta_profile_read(ptta_handle h, int klass, double* ms_total_host, double* alg_bytes_host, double* macs_host,
+                      int64_t* launches_host, ptta_stream s);
+
 /* Test / debug hooks (not on the hot path). */
 int ptta_debug_tensor(ptta_handle h, const char* name, float* dst, int64_t capacity, int64_t* numel_host, ptta_stream s);
 int ptta_op_conv32(const float* in_nhwc, const float* weight, const float* bias, float* out_nhwc,

@@ -55,6 +55,10 @@ struct ptta_ctx {
     float* w3_tmp = nullptr;     // device: loss weights of the standalone loss call
     int* step_dev = nullptr;
     bool fwd_valid = false;
+    // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
+    struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double bytes = 0, macs = 0; };
+    bool prof_on = false;
+    ProfClass prof[6];
 
     int fail(const std::string& m, int code) { err = m; return code; }
 
@@ -285,7 +289,24 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     a.add1 = e.add1; a.add1_nb = e.add1_nb; a.add2 = e.add2; a.add2_nb = e.add2_nb;
     a.out_raw = e.raw; a.out_sum = e.sum;
     a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = c->bf16; a.naive = c->naive;
-    return ptta_launch_conv32(a, s);
+    if (!c->prof_on) return ptta_launch_conv32(a, s);
+    // bracket this launch with events on ITS stream; algorithmic bytes = input + output + weight
+    // elements x element size, MACs = output pixels x 9 x 32 x 32 (SURVEY.md 8d counting rule)
+    ptta_ctx::ProfClass& pc = c->prof[mode * 2 + (relu ? 1 : 0)];
+    if (pc.used == pc.ev.size()) {
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -12;
+        pc.ev.push_back({e0, e1});
+    }
+    const long pin = (long)B * Hin * Win;
+    const long pout = mode == CONV_S1 ? pin : (mode == CONV_S2 ? pin / 4 : pin * 4);
+    pc.bytes += (double)((pin + pout) * 32 + 9216) * c->es;
+    pc.macs += (double)(mode == CONV_T2 ? pin : pout) * 9.0 * 32.0 * 32.0;
+    hipEventRecord(pc.ev[pc.used].first, s);
+    const int rc = ptta_launch_conv32(a, s);
+    hipEventRecord(pc.ev[pc.used].second, s);
+    pc.used++;
+    return rc;
 }
 
 // One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half.
@@ -576,6 +597,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
 void ptta_destroy(ptta_handle h) {
     if (!h) return;
     for (void* p : h->allocs) if (p) hipFree(p);
+    for (auto& pc : h->prof) for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete h;
 }
 
@@ -775,6 +797,30 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
     RUN(ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_));
     RUN(ptta_adam_step(c, nullptr, nullptr, s_));
     if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int ptta_profile(ptta_handle c, int enable) {
+    if (!c) return -1;
+    c->prof_on = enable != 0;
+    for (auto& pc : c->prof) { pc.used = 0; pc.bytes = 0; pc.macs = 0; }
+    return 0;
+}
+
+int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_bytes, double* macs, int64_t* launches, ptta_stream s_) {
+    if (!c || klass < 0 || klass >= 6) return -1;
+    HIPCHK(hipStreamSynchronize((hipStream_t)s_));
+    ptta_ctx::ProfClass& pc = c->prof[klass];
+    double ms = 0;
+    for (size_t k = 0; k < pc.used; ++k) {
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, pc.ev[k].first, pc.ev[k].second));
+        ms += t;
+    }
+    if (ms_total) *ms_total = ms;
+    if (alg_bytes) *alg_bytes = pc.bytes;
+    if (macs) *macs = pc.macs;
+    if (launches) *launches = (int64_t)pc.used;
     return 0;
 }
 

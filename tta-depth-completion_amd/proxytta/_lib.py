@@ -42,6 +42,9 @@ SIGNATURES = [
     ('ptta_backward', c_int, [_P, _P, _P, _P, _P, _P]),
     ('ptta_adam_step', c_int, [_P, _P, _P, _P]),
     ('ptta_step', c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    ('ptta_profile', c_int, [_P, c_int]),
+    ('ptta_profile_read', c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
+                                  POINTER(c_int64), _P]),
     ('ptta_debug_tensor', c_int, [_P, c_char_p, _P, c_int64, POINTER(c_int64), _P]),
     ('ptta_op_conv32', c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     ('ptta_version', c_int, []),

@@ -165,6 +165,16 @@ class Engine:
                                      ptr(depth), ptr(info), _stream()), 'ptta_step')
         return info, depth
 
+    def profile(self, enable):
+        self._chk(self.lib.ptta_profile(self.handle, int(bool(enable))), 'ptta_profile')
+
+    def profile_read(self, klass):
+        """(ms_total, algorithmic_bytes, macs, launches) of conv32 kernel class `klass` since profile(True)."""
+        ms, by, mc, n = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0), c_int64(0)
+        self._chk(self.lib.ptta_profile_read(self.handle, int(klass), byref(ms), byref(by), byref(mc), byref(n), _stream()),
+                  'ptta_profile_read')
+        return ms.value, by.value, mc.value, n.value
+
     def debug_tensor(self, name):
         n = c_int64(0)
         self._chk(self.lib.ptta_debug_tensor(self.handle, name.encode(), None, 0, byref(n), _stream()), 'ptta_debug_tensor')

@@ -63,6 +63,28 @@ def test_op_conv32_input_gradient(mode, naive):
     assert rel_mae(got, gx) < 2e-6
 
 
+@pytest.mark.parametrize('relu', [False, True])
+@pytest.mark.parametrize('shape', [(2, 12, 44), (1, 8, 32), (1, 19, 70)])
+def test_op_conv32_bf16x3(shape, relu):
+    """fp32 storage, three bf16 MFMAs per product (LDS-staged stride-1 kernel): fp32-faithful to ~1e-5."""
+    from proxytta.engine import op_conv32
+    b, h, w = shape
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.randn(b, h, w, 32, generator=g) * 3.0
+    wt = torch.randn(32, 32, 3, 3, generator=g) * 0.1
+    bias = torch.randn(32, generator=g)
+    ref = _torch_conv(x, wt, bias, 0, relu)
+    got = op_conv32(x.cuda(), wt.cuda(), bias.cuda(), 0, relu_in=relu, x3=True).cpu()
+    assert rel_mae(got, ref) < 2e-5
+    # and the backward re-packing through the same kernel
+    xr = x.clone().requires_grad_(True)
+    y = _torch_conv(xr, wt, None, 0, False)
+    gy = torch.randn(y.shape, generator=g)
+    (gx,) = torch.autograd.grad(y, xr, gy)
+    got = op_conv32(gy.cuda(), wt.cuda(), None, 0, in_major=True, flip=True, x3=True).cpu()
+    assert rel_mae(got, gx) < 2e-5
+
+
 def test_op_conv32_bf16():
     from proxytta.engine import op_conv32
     g = torch.Generator().manual_seed(5)
@@ -78,6 +100,10 @@ def test_op_conv32_bf16():
 
 
 def _run_golden(name, impl, golden_dir):
+    # gradients of the L1 / total-variation terms are sums of sign() functions: a 1e-5 perturbation
+    # of the depth map (bf16x3 arithmetic, different summation order) flips a few signs, so the
+    # gradient tolerance is looser than the depth tolerance; exact-fp32 modes hold 1e-3
+    gtol, ptol = (1e-3, 2e-5) if impl in ('naive', 'exact') else (1e-2, 2e-4)
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
@@ -102,12 +128,12 @@ def _run_golden(name, impl, golden_dir):
         assert rel_mae(depth2, g[p + 'depth_train']) < 1e-4
         np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=1e-4)
         gw, gb = eng.debug_tensor('gW').view(32, 32, 3, 3), eng.debug_tensor('gB')
-        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < 1e-3, (name, s)
-        assert rel_mae(gb, g[p + 'grad/conv1_rgb_meta.bias']) < 1e-3
+        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < gtol, (name, s)
+        assert rel_mae(gb, g[p + 'grad/conv1_rgb_meta.bias']) < gtol
         for k, (prm, m, v) in adapted.items():
-            assert rel_mae(prm, g[p + 'param/' + k]) < 2e-5, k
-            assert rel_mae(m, g[p + 'exp_avg/' + k]) < 1e-3
-            assert rel_mae(v, g[p + 'exp_avg_sq/' + k]) < 2e-3
+            assert rel_mae(prm, g[p + 'param/' + k]) < ptol, k
+            assert rel_mae(m, g[p + 'exp_avg/' + k]) < gtol
+            assert rel_mae(v, g[p + 'exp_avg_sq/' + k]) < 2 * gtol
         for k in g.files:
             if k.startswith(p + 'buf/'):
                 key = k[len(p) + 4:]
@@ -120,9 +146,11 @@ def _run_golden(name, impl, golden_dir):
     eng.close()
 
 
-@pytest.mark.parametrize('impl', ['naive', None])
+@pytest.mark.parametrize('impl', ['naive', 'exact', None])
 @pytest.mark.parametrize('name', CASES)
 def test_step_matches_reference_golden(golden_dir, name, impl):
+    """impl: naive = direct kernels, exact = fp32 MFMA everywhere, None = shipped default (bf16x3
+    arithmetic on fp32 storage for the stride-1 convs)."""
     _run_golden(name, impl, golden_dir)
 
 
@@ -163,7 +191,7 @@ def test_against_oracle_midsize():
         li = r['loss_info']
         np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=1e-4)
         for k, (prm, m, v) in adapted.items():
-            assert rel_mae(prm, o.P[k].detach()) < 2e-5
+            assert rel_mae(prm, o.P[k].detach()) < 2e-4
         d_eval = eng.forward_eval(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())
         assert rel_mae(d_eval, o.forward_eval(torch.from_numpy(image), torch.from_numpy(sparse))) < 1e-4
     eng.close()
@@ -195,8 +223,8 @@ def test_facade_reference_style_driver(golden_dir):
         p = 's%d/' % s
         assert abs(float(loss) - g[p + 'loss_info'][0]) < 1e-4 * abs(g[p + 'loss_info'][0])
         for k, prm in zip(('conv1_rgb_meta.weight', 'conv1_rgb_meta.bias'), params):
-            assert rel_mae(prm.grad, g[p + 'grad/' + k]) < 1e-3
-            assert rel_mae(prm, g[p + "param/" + k]) < 1e-4
+            assert rel_mae(prm.grad, g[p + 'grad/' + k]) < 1e-2
+            assert rel_mae(prm, g[p + "param/" + k]) < 2e-4
         model.eval()
         with torch.no_grad():
             d_eval = model.forward(image=image, sparse_depth=sparse, loss_type=CANONICAL_LOSS_TYPE)

@@ -18,13 +18,16 @@ def rel_mae(a, b, floor=1e-4):
 def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None):
     """Engine with formula weights; returns (engine, state dict on device, adapted dict)."""
     from proxytta.engine import ADAPTED, Engine
-    if impl is None:
-        os.environ.pop('PTTA_CONV_IMPL', None)
-    else:
-        os.environ['PTTA_CONV_IMPL'] = impl
+    os.environ.pop('PTTA_CONV_IMPL', None)
+    os.environ.pop('PTTA_ARITH', None)
+    if impl == 'naive':
+        os.environ['PTTA_CONV_IMPL'] = 'naive'
+    elif impl == 'exact':
+        os.environ['PTTA_ARITH'] = 'exact'
     hp = dict(hp or {})
     eng = Engine(n, h, w, dtype=dtype, **hp)
     os.environ.pop('PTTA_CONV_IMPL', None)
+    os.environ.pop('PTTA_ARITH', None)
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(ONE, gain).items()}
     eng.load_state_dict(sd)
     adapted = {}

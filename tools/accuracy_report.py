@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Accuracy of a libptta_hip precision mode against the oracle (PyTorch-CPU fp32 restatement):
+relative MAE of the training-mode depth, the post-update eval depth (the tensor the reference
+scores, src/tta_main.py:729-736), gradients and updated parameters over a few TTA steps.
+  python tools/accuracy_report.py --dtype bf16 --size 352x1216 --steps 3
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tta-depth-completion_amd')):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from oracle import proxytta_oracle as O  # noqa: E402
+from proxytta import synth  # noqa: E402
+from proxytta.engine import ADAPTED, Engine  # noqa: E402
+
+MODE = 'meta_selfsup_seq_1layer_ema'
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().mean() / b.abs().mean())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--size', default='128x256')
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--threads', type=int, default=16)
+    a = ap.parse_args()
+    h, w = [int(x) for x in a.size.split('x')]
+    torch.set_num_threads(a.threads)
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1,
+              max_input_depth=80.0)
+    eng = Engine(1, h, w, dtype=a.dtype, **hp)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
+    eng.load_state_dict(sd)
+    for name in ADAPTED:
+        eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+    o = O.MsgChnOracle(synth.formula_state_dict(MODE), MODE, max_input_depth=80.0, lr=1e-3, w_sd=1.0, w_sm=2.0, w_cos=0.1)
+    rows = []
+    for s in range(a.steps):
+        image, sparse = synth.synthetic_frame(s, h, w, 1)
+        ic, sc = torch.from_numpy(image), torch.from_numpy(sparse)
+        r = o.step(ic, sc)
+        info, depth = eng.step(ic.cuda(), sc.cuda(), want_depth=True)
+        d_eval = eng.forward_eval(ic.cuda(), sc.cuda())
+        ref_eval = o.forward_eval(ic, sc)
+        gw = eng.debug_tensor('gW').view(32, 32, 3, 3)
+        row = {'step': s, 'depth_train': rel(depth, r['depth']), 'depth_eval': rel(d_eval, ref_eval),
+               'grad_w': rel(gw, r['grads'][ADAPTED[0]]), 'param_w': rel(sd[ADAPTED[0]], o.P[ADAPTED[0]]),
+               'loss_info': [float(x) for x in info.cpu()],
+               'loss_info_ref': [r['loss_info'][k] for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')]}
+        rows.append(row)
+        print(json.dumps(row))
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -25,6 +25,7 @@ template <typename T>
 struct Conv32P {
     const T* in; int in_nb;
     const void* wpack;
+    const void* wpack2;          // lo fragments (bf16x3 arithmetic)
     Epi<T> epi;
     int B, Hin, Win, Hout, Wout;
 };
@@ -46,7 +47,7 @@ __device__ __forceinline__ uint4 relu8(uint4 v) {
     return v;
 }
 
-template <typename T, int MODE, bool RELU>
+template <typename T, int MODE, bool RELU, bool UP, bool MASK, bool ADD>
 __global__ __launch_bounds__(256) void conv32_mfma_kernel(Conv32P<T> p) {
     constexpr bool F32 = sizeof(T) == 4;
     constexpr int NA = F32 ? 4 : 2;                  // 16-byte A fragments per tap
@@ -135,17 +136,127 @@ __global__ __launch_bounds__(256) void conv32_mfma_kernel(Conv32P<T> p) {
         }
 
         // ---- epilogue: lane = channel (lane&31), registers = 16 pixels of the tile --------------
-        Lerp ly = {0, 0, 0.f, 0.f};
-        if (p.epi.up) ly = lerp_coef(y, p.Hout >> 1, sy);
+        epi_tile<T, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx);
+    }
+}
+
+
+// ---- stride-1, fp32 storage, "bf16x3" arithmetic, LDS-staged -----------------------------------
+// fp32-faithful products on the bf16 matrix cores: x = xh + xl, w = wh + wl (each half a bf16),
+// x*w ~= xh*wh + xl*wh + xh*wl (the dropped xl*wl term is 2^-16 relative), accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16: 3 MFMAs instead of the 16x slower fp32 MFMA.  Measured end-to-end
+// error vs the fp32 oracle: see DESIGN.md §6.
+// A block owns an 8x32 output tile: the (8+2)x(32+2) input halo is read from HBM once (full 128-B
+// NHWC lines), ReLU'd and split ONCE while it is staged into LDS as [pixel][hi 64 B | lo 64 B]
+// with a 144-B pixel stride (conflict-free ds_read_b128: bank = 4*(9*pixel mod 16) + const).
+// Each wave computes two 32-pixel rows; weights (hi and lo fragments, 144 VGPRs) stay in
+// registers across the persistent tile loop.
+#define X3_TH 8
+#define X3_PW 34
+#define X3_PH 10
+#define X3_STRIDE 144
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    float2_t v = {a, b};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);          // v_cvt_pk_bf16_f32 (RNE)
+    hi = __builtin_bit_cast(unsigned, h);
+    float2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+}
+
+template <bool RELU, bool UP, bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) {
+    // one LDS array: [halo tile | lo weight fragments]
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * X3_STRIDE + 18 * 64 * 16];
+    unsigned char* const wl_lds = lds + X3_PH * X3_PW * X3_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // hi weight fragments stay in registers (72 VGPRs), lo fragments in LDS (read once per use)
+    uint4 wh[9][2];
+    {
+        const uint4* ph = (const uint4*)p.wpack;
+        const uint4* pl = (const uint4*)p.wpack2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int px = x0 + acc_row(r, h);
-            if (px >= Wt) continue;
-            const int xo = (MODE == CONV_T2) ? 2 * px + xpar : px;
-            Lerp lx = {0, 0, 0.f, 0.f};
-            if (p.epi.up) lx = lerp_coef(xo, p.Wout >> 1, sx);
-            epi_store<T>(p.epi, b, y, xo, p.Hout, p.Wout, i, acc[r], ly, lx);
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+    }
+    const int H = p.Hout, W = p.Wout;
+    const int ntx = (W + 31) >> 5, nty = (H + X3_TH - 1) / X3_TH;
+    const long ntiles = (long)p.B * ntx * nty;
+    const float sy = up_scale(H >> 1, H), sx = up_scale(W >> 1, W);
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        long t_ = tile;
+        const int ty = (int)(t_ % nty); t_ /= nty;          // y fastest: neighbouring blocks share halo rows in L2
+        const int tx = (int)(t_ % ntx);
+        const int b = (int)(t_ / ntx);
+        const int y0 = ty * X3_TH, x0 = tx << 5;
+        const float* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
+        // ---- stage the halo tile: (pixel, 8-channel group) items, 6 per thread; all global loads
+        //      of the tile are issued before the first one is consumed -------------------------------
+        constexpr int NIT = (X3_PH * X3_PW * 4 + 255) / 256;
+        float4 v0[NIT], v1[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int g = idx & 3, pix = idx >> 2;
+            const int py = pix / X3_PW, px = pix - py * X3_PW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
+            if (idx < X3_PH * X3_PW * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float* src = inb + ((size_t)gy * W + gx) * 32 + 8 * g;
+                v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
+            }
         }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            if (idx < X3_PH * X3_PW * 4) {
+                float4 a0 = v0[it], a1 = v1[it];
+                if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
+                uint4 hi, lo;
+                split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);
+                split2(a1.x, a1.y, hi.z, lo.z); split2(a1.z, a1.w, hi.w, lo.w);
+                unsigned char* dst = lds + (idx >> 2) * X3_STRIDE + 16 * (idx & 3);
+                *(uint4*)dst = hi;
+                *(uint4*)(dst + 64) = lo;
+            }
+        }
+        __syncthreads();
+        // ---- two output rows per wave ------------------------------------------------------------
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+            const int y = y0 + row;
+            if (y >= H) break;                                      // wave-uniform
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * X3_STRIDE + 16 * h;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+                if (kx == 2) __builtin_amdgcn_sched_barrier(0);      // bound the ds_read prefetch depth (VGPR pressure)
+            }
+            epi_tile<float, UP, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+        }
+        __syncthreads();
     }
 }
 
@@ -193,7 +304,7 @@ __global__ void conv32_naive_kernel(Conv32P<T> p) {
 // src: a Conv2d weight [out][in][3][3] or ConvTranspose2d weight [in][out][3][3] (fp32, NCHW).
 // in_major: src is indexed [cin_eff][cout_eff]; flip: use tap (2-ky, 2-kx).  See DESIGN.md §4 for
 // which (in_major, flip) pair each forward/backward use needs.
-__global__ void pack_conv32_kernel(const float* __restrict__ src, float* mf32, bf16_t* mbf16, float* canon,
+__global__ void pack_conv32_kernel(const float* __restrict__ src, float* mf32, bf16_t* mbf16, bf16_t* mlo, float* canon,
                                    int in_major, int flip) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // over tap*32*32
     if (idx >= 9 * 32 * 32) return;
@@ -207,13 +318,38 @@ __global__ void pack_conv32_kernel(const float* __restrict__ src, float* mf32, b
     }
     {   // bf16 fragments: [tap][kk][lane][e], cin = 16kk + 8h + e
         const int kk = ci >> 4, hh = (ci >> 3) & 1, e = ci & 7;
-        mbf16[((tap * 2 + kk) * 64 + hh * 32 + co) * 8 + e] = f2bf(v);
+        const bf16_t hi = f2bf(v);
+        mbf16[((tap * 2 + kk) * 64 + hh * 32 + co) * 8 + e] = hi;
+        mlo[((tap * 2 + kk) * 64 + hh * 32 + co) * 8 + e] = f2bf(v - bf2f(hi));     // bf16x3 split: v ~= hi + lo
     }
 }
 
-void ptta_pack_conv32(const float* src, float* mf32, bf16_t* mbf16, float* canon, int in_major, int flip,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv32_kernel, dim3(36), dim3(256), 0, s, src, mf32, mbf16, canon, in_major, flip);
+void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, hipStream_t s) {
+    hipLaunchKernelGGL(pack_conv32_kernel, dim3(36), dim3(256), 0, s, src, w.mf32, w.mbf16, w.mlo, w.canon, in_major, flip);
+}
+
+// compile-time epilogue flags -> kernel instance
+template <typename T, int MODE, bool RELU>
+static void launch_mfma(const Conv32P<T>& p, int flags, int blocks, hipStream_t s) {
+#define K_(U, M, A) hipLaunchKernelGGL((conv32_mfma_kernel<T, MODE, RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
+    switch (flags) {
+        case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;
+        case 2: K_(false, true, false); break;  case 3: K_(true, true, false); break;
+        case 4: K_(false, false, true); break;  case 5: K_(true, false, true); break;
+        case 6: K_(false, true, true); break;   default: K_(true, true, true); break;
+    }
+#undef K_
+}
+template <bool RELU>
+static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_t s) {
+#define K_(U, M, A) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
+    switch (flags) {
+        case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;
+        case 2: K_(false, true, false); break;  case 3: K_(true, true, false); break;
+        case 4: K_(false, false, true); break;  case 5: K_(true, false, true); break;
+        case 6: K_(false, true, true); break;   default: K_(true, true, true); break;
+    }
+#undef K_
 }
 
 template <typename T, int MODE>
@@ -230,6 +366,18 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     if (MODE == CONV_S1) { p.Hout = a.Hin; p.Wout = a.Win; }
     else if (MODE == CONV_S2) { p.Hout = a.Hin / 2; p.Wout = a.Win / 2; }
     else { p.Hout = a.Hin * 2; p.Wout = a.Win * 2; }
+    if (a.add2 && !a.add1) return -22;
+    const int flags = (a.up ? 1 : 0) | (a.mask ? 2 : 0) | (a.add1 ? 4 : 0);
+    p.wpack2 = nullptr;
+    if (!a.naive && sizeof(T) == 4 && MODE == CONV_S1 && a.x3) {
+        p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
+        const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
+        const int blocks = (int)(tiles > 512 ? 512 : tiles);     // 2 resident blocks per CU, persistent
+        const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
+        if (a.relu_in) launch_x3<true>(pf, flags, blocks, s); else launch_x3<false>(pf, flags, blocks, s);
+        PTTA_CHECK_LAUNCH();
+        return 0;
+    }
     if (a.naive) {
         p.wpack = a.w->canon;
         const long total = (long)p.B * p.Hout * p.Wout * 32;
@@ -243,8 +391,7 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         long blocks = (items + 3) / 4;
         const long cap = sizeof(T) == 4 ? 512 : 1024;     // persistent waves: 2 (fp32) / 4 (bf16) blocks per CU
         if (blocks > cap) blocks = cap;
-        if (a.relu_in) hipLaunchKernelGGL((conv32_mfma_kernel<T, MODE, true>), dim3((int)blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv32_mfma_kernel<T, MODE, false>), dim3((int)blocks), dim3(256), 0, s, p);
+        if (a.relu_in) launch_mfma<T, MODE, true>(p, flags, (int)blocks, s); else launch_mfma<T, MODE, false>(p, flags, (int)blocks, s);
     }
     PTTA_CHECK_LAUNCH();
     return 0;

@@ -136,6 +136,180 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmP p) {
     }
 }
 
+// ---- bf16x3 variant: fp32-faithful products on the bf16 matrix cores -------------------------------
+// a = ah + al (split while the A tile is staged, after the fused prologue), w = wh + wl (split once
+// at load time); a*w ~= al*wh + ah*wl + ah*wh, fp32 accumulate (v_mfma_f32_32x32x16_bf16).
+// Block tile (WGM*TM*32) x (WGN*TN*32), 4 waves, K slices of 32 staged through LDS as separate
+// hi / lo bf16 planes with an 80-byte row stride (conflict-free ds_read_b128).
+#define X3_ROW 80            // bytes per LDS row: 32 bf16 + 16 pad
+
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hfloat2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hsplit2(float a, float b, unsigned& hi, unsigned& lo) {
+    hfloat2 v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, hbf16x2));
+    hfloat2 r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, hbf16x2));
+}
+
+struct GemmX3P {
+    GemmP g;
+    const bf16_t* Whi; const bf16_t* Wlo;
+};
+
+template <int WGM, int WGN, int TM, int TN, int PRO, int EPI>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    static_assert(BM == 128, "row-block partials assume 128-row blocks");
+    const GemmP& p = q.g;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[(2 * BM + 2 * BN) * X3_ROW + 4 * 2 * BN * 4];
+    unsigned char* Ahi = sm; unsigned char* Alo = Ahi + BM * X3_ROW;
+    unsigned char* Bhi = Alo + BM * X3_ROW; unsigned char* Blo = Bhi + BN * X3_ROW;
+    float* red = (float*)(Blo + BN * X3_ROW);                 // [WGM][2][BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int n0 = blockIdx.x * BN;
+    const long row0 = (long)blockIdx.y * BM;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int k0 = 0; k0 < p.K; k0 += 32) {
+        // ---- A: 128 rows x 32 k fp32 -> prologue -> split -> LDS (8 k per thread-item) -----------
+#pragma unroll
+        for (int it = 0; it < BM * 4 / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int row = idx >> 2, kq = idx & 3;
+            const long gr = row0 + row;
+            const int k = k0 + 8 * kq;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (gr < p.R) {
+                const float4 x0 = *(const float4*)((const float*)p.A + gr * p.K + k);
+                const float4 x1 = *(const float4*)((const float*)p.A + gr * p.K + k + 4);
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                if (PRO == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], p.pscale[k + e], p.pshift[k + e]), 0.f);
+                } else if (PRO == 2) {
+                    const float4 h0 = *(const float4*)(p.A2 + gr * p.K + k), h1 = *(const float4*)(p.A2 + gr * p.K + k + 4);
+                    const float hh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[e] = p.pscale[k + e] * (v[e] - p.pc1[k + e] - (hh[e] - p.pmean[k + e]) * p.pinv[k + e] * p.pc2[k + e]);
+                }
+            }
+            uint4 hi, lo;
+            hsplit2(v[0], v[1], hi.x, lo.x); hsplit2(v[2], v[3], hi.y, lo.y);
+            hsplit2(v[4], v[5], hi.z, lo.z); hsplit2(v[6], v[7], hi.w, lo.w);
+            *(uint4*)(Ahi + row * X3_ROW + 16 * kq) = hi;
+            *(uint4*)(Alo + row * X3_ROW + 16 * kq) = lo;
+        }
+        // ---- B: BN rows x 32 k, pre-split bf16 planes ---------------------------------------------
+#pragma unroll
+        for (int it = 0; it < (BN * 4 + 255) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            if (idx < BN * 4) {
+                const int row = idx >> 2, kq = idx & 3;
+                const long off = (long)(n0 + row) * p.K + k0 + 8 * kq;
+                *(uint4*)(Bhi + row * X3_ROW + 16 * kq) = *(const uint4*)(q.Whi + off);
+                *(uint4*)(Blo + row * X3_ROW + 16 * kq) = *(const uint4*)(q.Wlo + off);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int off = ((wm * TM + a) * 32 + i) * X3_ROW + 32 * ks + 16 * h;
+                ah[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Ahi + off));
+                al[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Alo + off));
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int off = ((wn * TN + b) * 32 + i) * X3_ROW + 32 * ks + 16 * h;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)(Bhi + off));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(Blo + off));
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue (same fusions as the exact kernel) ----------------------------------------------
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int cl = (wn * TN + b) * 32 + i;          // column within the block tile
+        const int col = n0 + cl;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+        float esc = 0.f, esh = 0.f, emu = 0.f, eiv = 0.f;
+        if (EPI == 2) { esc = p.escale[col]; esh = p.eshift[col]; emu = p.emean[col]; eiv = p.einv[col]; }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            float hh[16];
+            if (EPI == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    long row = row0 + (wm * TM + a) * 32 + acc_row(r, h);
+                    if (row >= p.R) row = p.R - 1;
+                    hh[r] = p.eH[row * p.N + col];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + (wm * TM + a) * 32 + acc_row(r, h);
+                if (row >= p.R) continue;
+                float v = acc[a][b][r] + bias;
+                if (EPI == 1) { s1 += v; s2 += v * v; }
+                if (EPI == 2) {
+                    v = (fmaf(hh[r], esc, esh) > 0.f) ? v : 0.f;
+                    s1 += v; s2 += v * (hh[r] - emu) * eiv;
+                }
+                p.C[row * p.N + col] = v;
+            }
+        }
+        if (EPI != 0) {
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (h == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
+        }
+    }
+    if (EPI != 0) {
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 256) {
+            const int which = t / BN, c = t % BN;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) v += red[(w * 2 + which) * BN + c];
+            p.part[((long)blockIdx.y * 2 + which) * p.N + n0 + c] = v;
+        }
+    }
+}
+
+// split an fp32 [N][K] weight into bf16 hi / lo planes
+__global__ void split_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n) {
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        const float v = w[k];
+        const bf16_t hh = f2bf(v);
+        hi[k] = hh; lo[k] = f2bf(v - bf2f(hh));
+    }
+}
+void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, long n, hipStream_t s) {
+    long b = (n + 255) / 256; if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(split_weight_kernel, dim3((int)b), dim3(256), 0, s, w, hi, lo, n);
+}
+
 int ptta_gemm_row_blocks(int R) { return (R + GEMM_BM - 1) / GEMM_BM; }
 
 int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
@@ -144,6 +318,30 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     p.A = a.A; p.A2 = a.A2; p.W = a.W; p.bias = a.bias; p.C = a.C; p.R = a.R; p.K = a.K; p.N = a.N;
     p.pscale = a.pscale; p.pshift = a.pshift; p.pmean = a.pmean; p.pinv = a.pinv; p.pc1 = a.pc1; p.pc2 = a.pc2;
     p.eH = a.eH; p.escale = a.escale; p.eshift = a.eshift; p.emean = a.emean; p.einv = a.einv; p.part = a.part;
+    if (a.x3 && !a.a_bf16) {
+        GemmX3P q; q.g = p; q.Whi = a.Whi; q.Wlo = a.Wlo;
+        const int key3 = a.pro * 10 + a.epi;
+        if (a.N % 128 == 0) {
+            dim3 grid(a.N / 128, ptta_gemm_row_blocks(a.R));
+#define GX_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 2, 2, PRO, EPI>), grid, dim3(256), 0, s, q)
+            switch (key3) {
+                case 0: GX_(0, 0); break; case 1: GX_(0, 1); break; case 2: GX_(0, 2); break;
+                case 10: GX_(1, 0); break; case 11: GX_(1, 1); break;
+                default: return -22;
+            }
+#undef GX_
+        } else {
+            dim3 grid(a.N / 32, ptta_gemm_row_blocks(a.R));
+#define GX_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_kernel<4, 1, 1, 1, PRO, EPI>), grid, dim3(256), 0, s, q)
+            switch (key3) {
+                case 0: GX_(0, 0); break; case 20: GX_(2, 0); break;
+                default: return -22;
+            }
+#undef GX_
+        }
+        PTTA_CHECK_LAUNCH();
+        return 0;
+    }
     const int nt = (a.N % 64 == 0) ? 2 : 1;
     dim3 grid(a.N / (32 * nt), ptta_gemm_row_blocks(a.R));
 #define GL_(NT, PRO, EPI, BF) hipLaunchKernelGGL((gemm_mfma_kernel<NT, PRO, EPI, BF>), grid, dim3(256), 0, s, p)
@@ -170,18 +368,29 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int row_blocks, int R, int N,
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one wave per column: lanes stride over the row-block partials (fixed order per lane, then a
+// butterfly: deterministic)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int row_blocks, int R, int N,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* running_mean, float* running_var, long long* nbt,
                                    float* mean, float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c == 0 && lane == 0 && nbt) *nbt += 1;
     if (c >= N) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int rb = 0; rb < row_blocks; ++rb) {
+    for (int rb = lane; rb < row_blocks; rb += 64) {
         s1 += (double)part[((long)rb * 2 + 0) * N + c];
         s2 += (double)part[((long)rb * 2 + 1) * N + c];
     }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     const double mu = s1 / R;
     double var = s2 / R - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -199,29 +408,32 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int row_block
 int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* beta,
                             float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
                             float* mean, float* invstd, float* scale, float* shift, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, part, row_blocks, R, N, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 3) / 4), dim3(256), 0, s, part, row_blocks, R, N, gamma, beta,
                        eps, momentum, running_mean, running_var, nbt, mean, invstd, scale, shift);
     PTTA_CHECK_LAUNCH();
     return 0;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int row_blocks, int R, int N,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int row_blocks, int R, int N,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
                                        float* gscale, float* c1, float* c2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= N) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int rb = 0; rb < row_blocks; ++rb) {
+    for (int rb = lane; rb < row_blocks; rb += 64) {
         s1 += (double)part[((long)rb * 2 + 0) * N + c];
         s2 += (double)part[((long)rb * 2 + 1) * N + c];
     }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     c1[c] = (float)(s1 / R); c2[c] = (float)(s2 / R);
     gscale[c] = gamma[c] * invstd[c];
 }
 
 int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
                                 float* gscale, float* c1, float* c2, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, s, part, row_blocks, R, N, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + 3) / 4), dim3(256), 0, s, part, row_blocks, R, N, gamma,
                        invstd, gscale, c1, c2);
     PTTA_CHECK_LAUNCH();
     return 0;

@@ -29,7 +29,7 @@ namespace {
 struct L32 { ConvW f{}, b{}; float* bias = nullptr; int transposed = 0; };
 struct LIn { float *wfrag = nullptr, *wcanon = nullptr, *bias = nullptr, *bw = nullptr; int cin = 1; };
 struct LOut { float *w = nullptr, *bias = nullptr, *bfrag = nullptr, *bcanon = nullptr; };
-struct Lin { float *W = nullptr, *Wt = nullptr, *bias = nullptr; int N = 0, K = 0; };
+struct Lin { float *W = nullptr, *Wt = nullptr, *bias = nullptr; bf16_t *Whi = nullptr, *Wlo = nullptr, *Wthi = nullptr, *Wtlo = nullptr; int N = 0, K = 0; };
 struct BNorm { float *gamma = nullptr, *beta = nullptr, *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
                float *mean = nullptr, *inv = nullptr, *scale = nullptr, *shift = nullptr; };
 struct Dbg { const void* p; long numel; int is_act; };
@@ -38,7 +38,7 @@ struct Dbg { const void* p; long numel; int is_act; };
 
 struct ptta_ctx {
     int N = 1, H = 0, W = 0, Hp = 0, Wp = 0, pt = 0, pr = 0, dual = 0, Nn = 1;
-    int bf16 = 0, naive = 0, es = 4;
+    int bf16 = 0, naive = 0, es = 4, x3 = 1;
     ptta_hparams hp{};
     std::string err;
     std::vector<void*> allocs;
@@ -172,6 +172,7 @@ ConvW alloc_convw(ptta_ctx* c) {
     ConvW w;
     w.mf32 = c->falloc(9 * 4 * 64 * 4);
     w.mbf16 = (bf16_t*)c->dalloc(9 * 2 * 64 * 8 * sizeof(bf16_t));
+    w.mlo = (bf16_t*)c->dalloc(9 * 2 * 64 * 8 * sizeof(bf16_t));
     w.canon = c->falloc(9 * 32 * 32);
     return w;
 }
@@ -212,6 +213,11 @@ void build_registry(ptta_ctx* c) {
         const int din = std::string(p) == "proj" ? 32 : 512;
         Lin a; a.N = 512; a.K = din; a.W = c->falloc((size_t)512 * din); a.Wt = c->falloc((size_t)512 * din); a.bias = c->falloc(512);
         Lin b; b.N = 512; b.K = 512; b.W = c->falloc(512 * 512); b.Wt = c->falloc(512 * 512); b.bias = c->falloc(512);
+        for (Lin* l : {&a, &b}) {
+            const size_t ne = (size_t)l->N * l->K;
+            l->Whi = (bf16_t*)c->dalloc(ne * 2); l->Wlo = (bf16_t*)c->dalloc(ne * 2);
+            l->Wthi = (bf16_t*)c->dalloc(ne * 2); l->Wtlo = (bf16_t*)c->dalloc(ne * 2);
+        }
         c->fc[std::string(p) + ".0"] = a; c->fc[std::string(p) + ".3"] = b;
         BNorm n; n.gamma = c->falloc(512); n.beta = c->falloc(512);
         n.mean = c->falloc(512); n.inv = c->falloc(512); n.scale = c->falloc(512); n.shift = c->falloc(512);
@@ -288,7 +294,7 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     a.up = e.up; a.up_nb = e.up_nb; a.mask = e.mask; a.mask_nb = e.mask_nb;
     a.add1 = e.add1; a.add1_nb = e.add1_nb; a.add2 = e.add2; a.add2_nb = e.add2_nb;
     a.out_raw = e.raw; a.out_sum = e.sum;
-    a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = c->bf16; a.naive = c->naive;
+    a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = c->bf16; a.naive = c->naive; a.x3 = c->x3;
     if (!c->prof_on) return ptta_launch_conv32(a, s);
     // bracket this launch with events on ITS stream; algorithmic bytes = input + output + weight
     // elements x element size, MACs = output pixels x 9 x 32 x 32 (SURVEY.md 8d counting rule)
@@ -434,11 +440,13 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
     const Lin& l0 = c->fc[name + ".0"]; const Lin& l3 = c->fc[name + ".3"]; BNorm& bn = c->bn[name + ".1"];
     const int R = (int)c->Rg;
     GemmArgs g; g.A = A; g.a_bf16 = a_bf16; g.W = l0.W; g.bias = l0.bias; g.C = hidden; g.R = R; g.K = K; g.N = 512; g.epi = 1; g.part = c->bn_part;
+    g.x3 = c->x3; g.Whi = l0.Whi; g.Wlo = l0.Wlo;
     RUN(ptta_launch_gemm(g, s));
     RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_row_blocks(R), R, 512, bn.gamma, bn.beta, 1e-5f, 0.1f, bn.rm, bn.rv, bn.nbt,
                                 bn.mean, bn.inv, bn.scale, bn.shift, s));
     GemmArgs g2; g2.A = hidden; g2.W = l3.W; g2.bias = l3.bias; g2.C = out; g2.R = R; g2.K = 512; g2.N = 512; g2.pro = 1;
     g2.pscale = bn.scale; g2.pshift = bn.shift;
+    g2.x3 = c->x3; g2.Whi = l3.Whi; g2.Wlo = l3.Wlo;
     RUN(ptta_launch_gemm(g2, s));
     return 0;
 }
@@ -458,10 +466,12 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     const int R = (int)c->Rg;
     GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;
     g.eH = c->h1; g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part;
+    g.x3 = c->x3; g.Whi = l3.Wthi; g.Wlo = l3.Wtlo;
     RUN(ptta_launch_gemm(g, s));
     RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_row_blocks(R), R, 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
     GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = c->g_feat_f32; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;
     g2.pscale = c->bnb_gscale; g2.pmean = bn.mean; g2.pinv = bn.inv; g2.pc1 = c->bnb_c1; g2.pc2 = c->bnb_c2;
+    g2.x3 = c->x3; g2.Whi = l0.Wthi; g2.Wlo = l0.Wtlo;
     RUN(ptta_launch_gemm(g2, s));
     if (c->bf16) hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(c->Rg * 32)), dim3(256), 0, s, c->g_feat_f32, (bf16_t*)c->g_feat, c->Rg * 32);
     else HIPCHK(hipMemcpyAsync(c->g_feat, c->g_feat_f32, (size_t)c->Rg * 32 * 4, hipMemcpyDeviceToDevice, s));
@@ -554,7 +564,7 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
     }
     RUN(ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
     const L32& ml = c->l32["conv1_rgb_meta"];
-    ptta_pack_conv32(c->meta_w, ml.f.mf32, ml.f.mbf16, ml.f.canon, 0, 0, s);
+    ptta_pack_conv32(c->meta_w, ml.f, 0, 0, s);
     RUN(backbone(c, img, train, s));
     if (c->dual)
         hipLaunchKernelGGL(crop_avg_kernel, dim3(nblk((long)c->N * c->H * c->W)), dim3(256), 0, s, c->depth_net, c->depth_final, c->N, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
@@ -584,6 +594,8 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     c->bf16 = dtype == PTTA_DTYPE_BF16; c->es = c->bf16 ? 2 : 4;
     const char* impl = getenv("PTTA_CONV_IMPL");
     c->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
+    const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
+    c->x3 = (arith && strcmp(arith, "exact") == 0) ? 0 : 1;
     c->hp = *hp;
     build_registry(c);
     build_workspace(c);
@@ -625,14 +637,14 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
         if (is_w) {
             if (numel != 9216) return c->fail("bad shape for " + name, -22);
             if (!l.transposed) {          // Conv2d weight [out][in][3][3]
-                ptta_pack_conv32(src, l.f.mf32, l.f.mbf16, l.f.canon, 0, 0, s);
+                ptta_pack_conv32(src, l.f, 0, 0, s);
                 // backward: stride-1 conv -> stride-1 conv (transposed + flipped); stride-2 conv -> transposed conv
                 const bool s2 = base.find("enc1.1") != std::string::npos || base.find("enc2.1") != std::string::npos ||
                                 base.find("enc3.1") != std::string::npos || base.find("enc4.1") != std::string::npos;
-                if (l.b.mf32) ptta_pack_conv32(src, l.b.mf32, l.b.mbf16, l.b.canon, 1, s2 ? 0 : 1, s);
+                if (l.b.mf32) ptta_pack_conv32(src, l.b, 1, s2 ? 0 : 1, s);
             } else {                      // ConvTranspose2d weight [in][out][3][3]
-                ptta_pack_conv32(src, l.f.mf32, l.f.mbf16, l.f.canon, 1, 0, s);
-                if (l.b.mf32) ptta_pack_conv32(src, l.b.mf32, l.b.mbf16, l.b.canon, 0, 0, s);   // backward = stride-2 conv
+                ptta_pack_conv32(src, l.f, 1, 0, s);
+                if (l.b.mf32) ptta_pack_conv32(src, l.b, 0, 0, s);   // backward = stride-2 conv
             }
         } else if (is_b) {
             if (numel != 32) return c->fail("bad shape for " + name, -22);
@@ -666,6 +678,8 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
             if (numel != (long)l.N * l.K) return c->fail("bad shape for " + name, -22);
             HIPCHK(hipMemcpyAsync(l.W, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s));
             hipLaunchKernelGGL(transpose_kernel, dim3(nblk(numel)), dim3(256), 0, s, src, l.Wt, l.N, l.K);
+            ptta_split_weight(l.W, l.Whi, l.Wlo, numel, s);
+            ptta_split_weight(l.Wt, l.Wthi, l.Wtlo, numel, s);
         } else if (is_b) { HIPCHK(hipMemcpyAsync(l.bias, src, (size_t)l.N * 4, hipMemcpyDeviceToDevice, s)); }
         else return c->fail("unknown key " + name, -2);
         return 0;
@@ -849,11 +863,11 @@ int ptta_op_conv32(const float* in, const float* weight, const float* bias, floa
     const long nin = (long)b * hin * win * 32, nout = (long)b * ho * wo * 32;
     int rc = 0;
     if (hipMalloc((void**)&w.mf32, 9 * 4 * 64 * 4 * 4) != hipSuccess || hipMalloc((void**)&w.mbf16, 9 * 2 * 64 * 8 * 2) != hipSuccess ||
-        hipMalloc((void**)&w.canon, 9216 * 4) != hipSuccess || hipMalloc(&tin, nin * 2) != hipSuccess || hipMalloc(&tout, nout * 2) != hipSuccess)
+        hipMalloc((void**)&w.canon, 9216 * 4) != hipSuccess || hipMalloc((void**)&w.mlo, 9 * 2 * 64 * 8 * 2) != hipSuccess || hipMalloc(&tin, nin * 2) != hipSuccess || hipMalloc(&tout, nout * 2) != hipSuccess)
         rc = -12;
     if (rc == 0) {
-        ptta_pack_conv32(weight, w.mf32, w.mbf16, w.canon, in_major, flip, s);
-        Conv32Args a; a.w = &w; a.bias = bias; a.B = b; a.Hin = hin; a.Win = win; a.mode = mode; a.relu_in = relu_in; a.naive = naive;
+        ptta_pack_conv32(weight, w, in_major, flip, s);
+        Conv32Args a; a.w = &w; a.bias = bias; a.B = b; a.Hin = hin; a.Win = win; a.mode = mode; a.relu_in = relu_in; a.naive = naive & 1; a.x3 = (naive >> 1) & 1;
         if (dtype == PTTA_DTYPE_BF16) {
             hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(nin)), dim3(256), 0, s, in, (bf16_t*)tin, nin);
             a.in = tin; a.in_nb = b; a.out_raw = tout; a.bf16 = 1;
@@ -865,7 +879,7 @@ int ptta_op_conv32(const float* in, const float* weight, const float* bias, floa
         }
         hipStreamSynchronize(s);
     }
-    hipFree(w.mf32); hipFree(w.mbf16); hipFree(w.canon); hipFree(tin); hipFree(tout);
+    hipFree(w.mf32); hipFree(w.mbf16); hipFree(w.mlo); hipFree(w.canon); hipFree(tin); hipFree(tout);
     return rc;
 }
 

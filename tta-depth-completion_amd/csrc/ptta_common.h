@@ -92,6 +92,81 @@ __device__ __forceinline__ void epi_store(const Epi<T>& e, int b, int y, int x, 
     }
 }
 
+__device__ const float kZeroBias[32] = {0.f};
+
+// Tile form of the epilogue for the MFMA kernels: lane = channel `ch`, the 16 accumulator registers
+// are 16 pixels of one output row.  UP / MASK / ADD are compile-time so that every auxiliary load
+// of the tile is unconditional and can be issued back to back (a runtime "pointer or nothing" test
+// per element makes hipcc branch around each load and wait vmcnt(0) 100+ times per tile:
+// cdna_hip_programming.md §5 "Three .s-level traps" (c)).  Out-of-range pixels load from a
+// clamped address and are simply not stored.
+template <typename T, bool UP, bool MASK, bool ADD>
+__device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, int W, int ch, const f32x16& acc,
+                                         int x0, int h, int Wt, int xstep, int xoff, float sy, float sx) {
+    const float* bp = e.bias ? e.bias : kZeroBias;       // pointer select, not a branch around the load
+    const float bias = bp[ch];
+    float v[16];
+    int xo[16];
+    bool ok[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int px = x0 + ((r & 3) + 8 * (r >> 2) + 4 * h);
+        ok[r] = px < Wt;
+        xo[r] = (ok[r] ? px : Wt - 1) * xstep + xoff;
+        v[r] = acc[r] + bias;
+    }
+    if (UP) {
+        const int Hu = H >> 1, Wu = W >> 1;
+        const Lerp ly = lerp_coef(y, Hu, sy);
+        const T* u0 = e.up + ((size_t)(b % e.up_nb) * Hu + ly.i0) * Wu * 32 + ch;
+        const T* u1 = e.up + ((size_t)(b % e.up_nb) * Hu + ly.i1) * Wu * 32 + ch;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const Lerp lx = lerp_coef(xo[r], Wu, sx);
+            const float v00 = ld(u0 + (size_t)lx.i0 * 32), v01 = ld(u0 + (size_t)lx.i1 * 32);
+            const float v10 = ld(u1 + (size_t)lx.i0 * 32), v11 = ld(u1 + (size_t)lx.i1 * 32);
+            v[r] += ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // 16 gathers in flight at a time (VGPR budget)
+        }
+    }
+    const size_t rowoff = (size_t)y * W;
+    if (MASK) {
+        const T* mrow = e.mask + ((size_t)(b % e.mask_nb) * H * W + rowoff) * 32 + ch;
+        float m[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = ld(mrow + (size_t)xo[r] * 32);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = m[r] > 0.0f ? v[r] : 0.0f;
+    }
+    const size_t obase = ((size_t)b * H * W + rowoff) * 32 + ch;
+    if (e.out_raw) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) st(e.out_raw + obase + (size_t)xo[r] * 32, v[r]);
+    }
+    if (ADD) {
+        const T* a1 = e.add1 + ((size_t)(b % e.add1_nb) * H * W + rowoff) * 32 + ch;
+        float t1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t1[r] = ld(a1 + (size_t)xo[r] * 32);
+        if (e.add2) {
+            const T* a2 = e.add2 + ((size_t)(b % e.add2_nb) * H * W + rowoff) * 32 + ch;
+            float t2[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t2[r] = ld(a2 + (size_t)xo[r] * 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t1[r] += t2[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += t1[r];
+    }
+    if (e.out_sum) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok[r]) st(e.out_sum + obase + (size_t)xo[r] * 32, v[r]);
+    }
+}
+
 // MFMA 32x32 accumulator row of register r for lane half h (cdna_hip_programming.md §3):
 // row = (r&3) + 8*(r>>2) + 4*h, col = lane&31.
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -7,7 +7,8 @@
 // ---- conv32.hip ------------------------------------------------------------------------------
 struct ConvW {           // one packed 3x3 32->32 filter, three formats (device memory)
     float* mf32;         // fp32 MFMA fragments  [9][4][64][4]
-    bf16_t* mbf16;       // bf16 MFMA fragments  [9][2][64][8]
+    bf16_t* mbf16;       // bf16 MFMA fragments  [9][2][64][8] (= hi half of the bf16x3 split)
+    bf16_t* mlo;         // lo half of the bf16x3 split, same layout
     float* canon;        // [tap][cin][cout] for the direct kernel / wgrad checks
 };
 struct Conv32Args {
@@ -21,8 +22,9 @@ struct Conv32Args {
     void* out_raw = nullptr; void* out_sum = nullptr;
     int B = 1, Hin = 0, Win = 0;    // input spatial size; output size follows from mode
     int mode = CONV_S1; int relu_in = 0; int bf16 = 0; int naive = 0;
+    int x3 = 0;          // fp32 storage: bf16x3 arithmetic on the bf16 matrix cores (stride-1 only)
 };
-void ptta_pack_conv32(const float* src, float* mf32, bf16_t* mbf16, float* canon, int in_major, int flip, hipStream_t s);
+void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, hipStream_t s);
 int ptta_launch_conv32(const Conv32Args& a, hipStream_t s);
 
 // ---- conv_small.hip ---------------------------------------------------------------------------
@@ -76,7 +78,9 @@ struct GemmArgs {
     const float* eH = nullptr;                 // [R][N] pre-BN activations (epi 2)
     const float* escale = nullptr; const float* eshift = nullptr; const float* emean = nullptr; const float* einv = nullptr;
     float* part = nullptr;                     // [row_blocks][2][N] partial column statistics
+    int x3 = 0; const bf16_t* Whi = nullptr; const bf16_t* Wlo = nullptr;   // bf16x3 arithmetic: pre-split [N][K] weight
 };
+void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, long n, hipStream_t s);
 int ptta_gemm_row_blocks(int R);
 int ptta_launch_gemm(const GemmArgs& a, hipStream_t s);
 // BatchNorm1d (train) statistics from partials; also updates running stats (momentum 0.1, unbiased var)

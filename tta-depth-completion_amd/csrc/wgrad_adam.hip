@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void wgrad32_kernel(const T* __restrict__ x, co
                                                      int nchunks, float* __restrict__ part) {
     const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
     const long P = (long)B * H * W;
-    const long per = ((P + nchunks - 1) / nchunks + 1) & ~1L;          // even number of pixels per chunk
+    const long per = ((P + nchunks - 1) / nchunks + 7) & ~7L;          // multiple of 8 pixels per chunk
     const long p0 = (long)blockIdx.x * per;
     long p1 = p0 + per; if (p1 > P) p1 = P;
     f32x16 acc[10];
@@ -31,23 +31,33 @@ __global__ __launch_bounds__(64) void wgrad32_kernel(const T* __restrict__ x, co
     for (int t = 0; t < 10; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (long pp = p0; pp < p1; pp += 2) {
-        const long pix = pp + h;
-        const bool pv = pix < p1;
-        int px = 0, py = 0, pb = 0;
-        float a = 0.f;
-        if (pv) {
-            px = (int)(pix % W); const long t_ = pix / W; py = (int)(t_ % H); pb = (int)(t_ / H);
-            a = ld(gy + pix * 32 + i);
+    for (long pp = p0; pp < p1; pp += 8) {
+        // four pixel pairs per iteration, all 40 loads issued before the first MFMA
+        float a[4], bv[4][9];
+        bool pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long pix = pp + 2 * u + h;
+            pv[u] = pix < p1;
+            int px = 0, py = 0, pb = 0;
+            a[u] = 0.f;
+            if (pv[u]) {
+                px = (int)(pix % W); const long t_ = pix / W; py = (int)(t_ % H); pb = (int)(t_ / H);
+                a[u] = ld(gy + pix * 32 + i);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+                bv[u][tap] = 0.f;
+                if (pv[u] && yy >= 0 && yy < H && xx >= 0 && xx < W) bv[u][tap] = ld(x + (((long)pb * H + yy) * W + xx) * 32 + i);
+            }
         }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
-            float b = 0.f;
-            if (pv && yy >= 0 && yy < H && xx >= 0 && xx < W) b = ld(x + (((long)pb * H + yy) * W + xx) * 32 + i);
-            acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u][tap], acc[tap], 0, 0, 0);
+            acc[9] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], pv[u] ? 1.f : 0.f, acc[9], 0, 0, 0);
         }
-        acc[9] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pv ? 1.f : 0.f, acc[9], 0, 0, 0);
     }
     float* out = part + (long)blockIdx.x * WGRAD_PART;
 #pragma unroll
@@ -59,11 +69,18 @@ __global__ __launch_bounds__(64) void wgrad32_kernel(const T* __restrict__ x, co
         for (int r = 0; r < 16; ++r) out[9 * 1024 + acc_row(r, h)] = acc[9][r];
 }
 
-__global__ void wgrad32_reduce_kernel(const float* __restrict__ part, int nchunks, float* __restrict__ gw, float* __restrict__ gb) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= 9 * 1024 + 32) return;
+// 64 outputs per block, 8 chunk groups summed in parallel then combined through LDS (fixed order)
+__global__ __launch_bounds__(512) void wgrad32_reduce_kernel(const float* __restrict__ part, int nchunks, float* __restrict__ gw, float* __restrict__ gb) {
+    __shared__ float red[8][64];
+    const int ol = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + ol;
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += part[(long)c * WGRAD_PART + o];
+    if (o < 9 * 1024 + 32)
+        for (int c = cg; c < nchunks; c += 8) s += part[(long)c * WGRAD_PART + o];
+    red[cg][ol] = s;
+    __syncthreads();
+    if (cg != 0 || o >= 9 * 1024 + 32) return;
+    s = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
     if (o < 9 * 1024) {
         const int ci = o & 31, co = (o >> 5) & 31, tap = o >> 10;
         gw[(co * 32 + ci) * 9 + tap] = s;
@@ -77,7 +94,7 @@ int ptta_launch_wgrad32(const void* x, const void* gy, int bf16, int B, int H, i
     const int nchunks = ptta_wgrad_chunks((long)B * H * W);
     if (bf16) hipLaunchKernelGGL((wgrad32_kernel<bf16_t>), dim3(nchunks), dim3(64), 0, s, (const bf16_t*)x, (const bf16_t*)gy, B, H, W, nchunks, part);
     else hipLaunchKernelGGL((wgrad32_kernel<float>), dim3(nchunks), dim3(64), 0, s, (const float*)x, (const float*)gy, B, H, W, nchunks, part);
-    hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((9 * 1024 + 32 + 255) / 256), dim3(256), 0, s, part, nchunks, gw, gb);
+    hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((9 * 1024 + 32 + 63) / 64), dim3(512), 0, s, part, nchunks, gw, gb);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

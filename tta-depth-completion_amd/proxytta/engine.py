@@ -184,14 +184,14 @@ class Engine:
         return out
 
 
-def op_conv32(x_nhwc, weight, bias, mode, relu_in=False, in_major=False, flip=False, dtype='fp32', naive=False):
+def op_conv32(x_nhwc, weight, bias, mode, relu_in=False, in_major=False, flip=False, dtype='fp32', naive=False, x3=False):
     """Test hook: run the hot-path 32->32 3x3 kernel on an fp32 NHWC tensor."""
     lib = _lib.load()
     b, h, w, _ = x_nhwc.shape
     ho, wo = {0: (h, w), 1: (h // 2, w // 2), 2: (2 * h, 2 * w)}[mode]
     out = torch.empty((b, ho, wo, 32), device=x_nhwc.device, dtype=torch.float32)
     rc = lib.ptta_op_conv32(ptr(x_nhwc.contiguous()), ptr(weight.contiguous()), ptr(bias), ptr(out), b, h, w, mode,
-                            int(relu_in), int(in_major), int(flip), 1 if dtype == 'bf16' else 0, int(naive), _stream())
+                            int(relu_in), int(in_major), int(flip), 1 if dtype == 'bf16' else 0, int(bool(naive)) | (2 if x3 else 0), _stream())
     if rc != 0:
         raise RuntimeError('ptta_op_conv32 failed (%d)' % rc)
     return out

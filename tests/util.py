@@ -22,6 +22,7 @@ def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None):
     os.environ.pop('PTTA_ARITH', None)
     if impl == 'naive':
         os.environ['PTTA_CONV_IMPL'] = 'naive'
+        os.environ['PTTA_ARITH'] = 'exact'
     elif impl == 'exact':
         os.environ['PTTA_ARITH'] = 'exact'
     hp = dict(hp or {})

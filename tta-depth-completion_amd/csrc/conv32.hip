@@ -260,6 +260,88 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     }
 }
 
+// ---- stride-2 / transposed geometries, fp32 storage, bf16x3 arithmetic, direct loads ----------
+// Same per-wave tiling as conv32_mfma_kernel (32 outputs of one row / one x-parity), but each A
+// fragment (8 fp32 channels of one input pixel) is split into bf16 hi/lo in registers and fed to
+// three bf16 MFMAs.  The hi weight fragments are wave-stationary in VGPRs, the lo fragments sit
+// in LDS (loaded once per block).  Input lines are re-read from L1/L2 by neighbouring taps
+// (2.25x for stride 2), which is cheaper here than an 84 KB halo tile in LDS.
+template <int MODE, bool RELU, bool UP, bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float> p) {
+    __shared__ __attribute__((aligned(16))) unsigned char wl_lds[18 * 64 * 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint4 wh[9][2];
+    {
+        const uint4* ph = (const uint4*)p.wpack;
+        const uint4* pl = (const uint4*)p.wpack2;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+    }
+    __syncthreads();
+    const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
+    const int nseg = (Wt + 31) >> 5;
+    const int npar = (MODE == CONV_T2) ? 2 : 1;
+    const long nitems = (long)p.B * nseg * npar * p.Hout;
+    const float sy = up_scale(p.Hout >> 1, p.Hout), sx = up_scale(p.Wout >> 1, p.Wout);
+
+    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+        long t_ = item;
+        const int y = (int)(t_ % p.Hout); t_ /= p.Hout;
+        int xpar = 0;
+        if (MODE == CONV_T2) { xpar = (int)(t_ & 1); t_ >>= 1; }
+        const int seg = (int)(t_ % nseg);
+        const int b = (int)(t_ / nseg);
+        const int x0 = seg << 5;
+        const bool lane_in = (x0 + i) < Wt;
+        const float* inb = p.in + (size_t)(b % p.in_nb) * p.Hin * p.Win * 32;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            bool active = true;
+            int yi, xi;
+            if (MODE == CONV_S1) { yi = y + ky - 1; xi = x0 + i + kx - 1; }
+            else if (MODE == CONV_S2) { yi = 2 * y + ky - 1; xi = 2 * (x0 + i) + kx - 1; }
+            else {
+                const int ty = y + 1 - ky, tx = xpar + 1 - kx;
+                active = ((ty & 1) == 0) && ((tx & 1) == 0);
+                yi = ty >> 1; xi = x0 + i + (tx >> 1);
+            }
+            active = active && (yi >= 0) && (yi < p.Hin);
+            if (!active) continue;                                    // wave-uniform
+            const bool ok = lane_in && (xi >= 0) && (xi < p.Win);
+            const float* src = inb + ((size_t)yi * p.Win + (ok ? xi : 0)) * 32 + 8 * h;
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                              // q = 2*kstep + half-of-8
+                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok) v[q] = *(const float4*)(src + 16 * (q >> 1) + 4 * (q & 1));
+                if (RELU) v[q] = relu4(v[q]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                uint4 hi, lo;
+                split2(v[2 * k].x, v[2 * k].y, hi.x, lo.x); split2(v[2 * k].z, v[2 * k].w, hi.y, lo.y);
+                split2(v[2 * k + 1].x, v[2 * k + 1].y, hi.z, lo.z); split2(v[2 * k + 1].z, v[2 * k + 1].w, hi.w, lo.w);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, hi), al = __builtin_bit_cast(bf16x8, lo);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+        }
+        epi_tile<float, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx);
+    }
+}
+
 // ---- reference-style direct kernel (one thread per output element), same epilogue ------------
 // Selected with PTTA_CONV_IMPL=naive: keeps the whole pipeline testable independently of the MFMA
 // fragment packing.  Weights in canonical float layout Wc[tap][cin][cout].
@@ -352,6 +434,18 @@ static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_
 #undef K_
 }
 
+template <int MODE, bool RELU>
+static void launch_direct_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_t s) {
+#define K_(U, M, A) hipLaunchKernelGGL((conv32_direct_x3_kernel<MODE, RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
+    switch (flags) {
+        case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;
+        case 2: K_(false, true, false); break;  case 3: K_(true, true, false); break;
+        case 4: K_(false, false, true); break;  case 5: K_(true, false, true); break;
+        case 6: K_(false, true, true); break;   default: K_(true, true, true); break;
+    }
+#undef K_
+}
+
 template <typename T, int MODE>
 static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     Conv32P<T> p;
@@ -369,12 +463,22 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     if (a.add2 && !a.add1) return -22;
     const int flags = (a.up ? 1 : 0) | (a.mask ? 2 : 0) | (a.add1 ? 4 : 0);
     p.wpack2 = nullptr;
-    if (!a.naive && sizeof(T) == 4 && MODE == CONV_S1 && a.x3) {
+    if constexpr (sizeof(T) == 4 && MODE == CONV_S1) if (!a.naive && a.x3) {
         p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
         const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
         const int blocks = (int)(tiles > 512 ? 512 : tiles);     // 2 resident blocks per CU, persistent
         const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
         if (a.relu_in) launch_x3<true>(pf, flags, blocks, s); else launch_x3<false>(pf, flags, blocks, s);
+        PTTA_CHECK_LAUNCH();
+        return 0;
+    }
+    if constexpr (sizeof(T) == 4 && MODE != CONV_S1) if (!a.naive && a.x3) {
+        p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
+        const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
+        const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
+        long blocks = (items + 3) / 4; if (blocks > 512) blocks = 512;
+        const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
+        if (a.relu_in) launch_direct_x3<MODE, true>(pf, flags, (int)blocks, s); else launch_direct_x3<MODE, false>(pf, flags, (int)blocks, s);
         PTTA_CHECK_LAUNCH();
         return 0;
     }

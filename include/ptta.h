@@ -102,6 +102,10 @@ int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* gr
 int ptta_step(ptta_handle h, const float* image, const float* loss_image, const float* sparse_depth,
               const float* validity, float* depth_out, float* loss_info_out, ptta_stream s);
 
+/* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
+ * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
+int ptta_set_graph(ptta_handle h, int enable);
+
 /* Measurement hook for bench.py: while enabled, every launch of the 3x3 32->32 convolution kernel
  * is bracketed by hipEvents on its own stream.  klass = geometry*2 + relu_in (geometry 0 = stride 1,
  * 1 = stride 2, 2 = transposed); read returns the summed duration (ms), the algorithmic bytes and

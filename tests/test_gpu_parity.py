@@ -244,10 +244,12 @@ def test_full_size_properties():
     hp = dict(w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
     image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(0, h, w, n)]
     outs = []
-    for _ in range(2):
+    for use_graph in (True, False):         # hipGraph replay and kernel-by-kernel launches: same bits
         eng, sd, adapted = make_engine(n, h, w, 'fp32', hp)
+        eng.set_graph(use_graph)
         before = eng.forward_eval(image, sparse).clone()
         info, depth = eng.step(image, sparse, want_depth=True)
+        info, depth = eng.step(image, sparse, want_depth=True)      # second step = first graph REPLAY
         after = eng.forward_eval(image, sparse)
         torch.cuda.synchronize()
         assert torch.isfinite(info).all() and torch.isfinite(depth).all() and torch.isfinite(after).all()

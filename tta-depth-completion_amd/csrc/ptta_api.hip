@@ -59,6 +59,19 @@ struct ptta_ctx {
     struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double bytes = 0, macs = 0; };
     bool prof_on = false;
     ProfClass prof[6];
+    // hipGraph replay of the whole step (inputs are first copied to fixed staging buffers so that
+    // the captured pointers never change); one graph per (validity given, separate loss image)
+    int use_graph = 1;
+    hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t cap_stream = nullptr;    // private stream to capture on (the caller's may be the un-capturable null stream)
+    float *in_image = nullptr, *in_loss_image = nullptr, *in_sparse = nullptr, *in_validity = nullptr;
+    void drop_graphs() {
+        for (int k = 0; k < 4; ++k) {
+            if (gexec[k]) { hipGraphExecDestroy(gexec[k]); gexec[k] = nullptr; }
+            if (graph[k]) { hipGraphDestroy(graph[k]); graph[k] = nullptr; }
+        }
+    }
 
     int fail(const std::string& m, int code) { err = m; return code; }
 
@@ -274,6 +287,8 @@ void build_workspace(ptta_ctx* c) {
     c->wgrad_part = c->falloc((size_t)ptta_wgrad_chunks(c->Rg) * 10 * 1024);
     c->gW = c->falloc(32 * 32 * 9); c->gB = c->falloc(32);
     c->dbg["gW"] = Dbg{c->gW, 9216, 0}; c->dbg["gB"] = Dbg{c->gB, 32, 0};
+    c->in_image = c->falloc((size_t)c->N * 3 * c->H * c->W); c->in_loss_image = c->falloc((size_t)c->N * 3 * c->H * c->W);
+    c->in_sparse = c->falloc((size_t)c->N * c->H * c->W); c->in_validity = c->falloc((size_t)c->N * c->H * c->W);
     c->hyper = c->falloc(16); c->w3_tmp = c->falloc(4);
     c->step_dev = (int*)c->dalloc(16);
 #undef A_
@@ -594,6 +609,8 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     c->bf16 = dtype == PTTA_DTYPE_BF16; c->es = c->bf16 ? 2 : 4;
     const char* impl = getenv("PTTA_CONV_IMPL");
     c->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
+    const char* gr = getenv("PTTA_GRAPH");
+    c->use_graph = (gr && strcmp(gr, "0") == 0) ? 0 : 1;
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
     c->x3 = (arith && strcmp(arith, "exact") == 0) ? 0 : 1;
     c->hp = *hp;
@@ -608,6 +625,8 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
 
 void ptta_destroy(ptta_handle h) {
     if (!h) return;
+    h->drop_graphs();
+    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     for (void* p : h->allocs) if (p) hipFree(p);
     for (auto& pc : h->prof) for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete h;
@@ -615,6 +634,7 @@ void ptta_destroy(ptta_handle h) {
 
 int ptta_set_hparams(ptta_handle c, const ptta_hparams* hp, ptta_stream s) {
     if (!c || !hp) return -1;
+    if (hp->max_input_depth != c->hp.max_input_depth) c->drop_graphs();     // baked into kernel arguments
     c->hp = *hp;
     return push_hparams(c, (hipStream_t)s);
 }
@@ -623,6 +643,7 @@ static long shape_numel(const int64_t* shape, int ndim) { long n = 1; for (int i
 
 int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, const int64_t* shape, int ndim, ptta_stream s_) {
     if (!c || !name_ || !tensor) return -1;
+    c->drop_graphs();
     hipStream_t s = (hipStream_t)s_;
     const std::string name(name_);
     const long numel = shape_numel(shape, ndim);
@@ -699,6 +720,7 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
 
 int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp_avg, float* exp_avg_sq) {
     if (!c || !name_ || !param) return -1;
+    c->drop_graphs();
     const std::string name(name_);
     if (name == "conv1_rgb_meta.weight") { c->meta_w = param; c->meta_w_m = exp_avg; c->meta_w_v = exp_avg_sq; return 0; }
     if (name == "conv1_rgb_meta.bias") { c->meta_b = param; c->meta_b_m = exp_avg; c->meta_b_v = exp_avg_sq; return 0; }
@@ -793,12 +815,10 @@ int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream 
     return 0;
 }
 
-int ptta_step(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
-              float* depth_out, float* loss_info_out, ptta_stream s_) {
-    if (!c || !image || !sparse) return -1;
+static int step_body(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
+                     ptta_stream s_) {
     hipStream_t s = (hipStream_t)s_;
-    if (!loss_image) loss_image = image;
-    RUN(ptta_forward_train(c, image, sparse, depth_out, nullptr, nullptr, s_));
+    RUN(ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_));
     const long npx = (long)c->N * c->H * c->W;
     if (!validity) {
         hipLaunchKernelGGL(validity_kernel, dim3(nblk(npx)), dim3(256), 0, s, sparse, c->validity_tmp, npx);
@@ -810,7 +830,48 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
                                   c->N, c->H, c->W, c->loss_ws, c->g_final, c->gref_buf, s));
     RUN(ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_));
     RUN(ptta_adam_step(c, nullptr, nullptr, s_));
+    return 0;
+}
+
+int ptta_step(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
+              float* depth_out, float* loss_info_out, ptta_stream s_) {
+    if (!c || !image || !sparse) return -1;
+    hipStream_t s = (hipStream_t)s_;
+    if (!loss_image) loss_image = image;
+    const size_t ibytes = (size_t)c->N * 3 * c->H * c->W * 4, pbytes = (size_t)c->N * c->H * c->W * 4;
+    if (c->use_graph && !c->prof_on) {
+        // replay path: stage the inputs at fixed addresses, then one hipGraphLaunch
+        const int key = (validity ? 2 : 0) | (loss_image != image ? 1 : 0);
+        HIPCHK(hipMemcpyAsync(c->in_image, image, ibytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->in_sparse, sparse, pbytes, hipMemcpyDeviceToDevice, s));
+        if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
+        if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
+        if (!c->gexec[key]) {
+            if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+            HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+            const int rc = step_body(c, c->in_image, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse,
+                                     (key & 2) ? c->in_validity : nullptr, (ptta_stream)c->cap_stream);
+            hipGraph_t g = nullptr;
+            const hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+            if (rc != 0) { if (g) hipGraphDestroy(g); return rc; }
+            if (e != hipSuccess || !g) return c->fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e), -100 - (int)e);
+            c->graph[key] = g;
+            HIPCHK(hipGraphInstantiate(&c->gexec[key], g, nullptr, nullptr, 0));
+        }
+        HIPCHK(hipGraphLaunch(c->gexec[key], s));
+        c->fwd_valid = true;
+    } else {
+        RUN(step_body(c, image, loss_image, sparse, validity, s_));
+    }
+    if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
     if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int ptta_set_graph(ptta_handle c, int enable) {
+    if (!c) return -1;
+    c->use_graph = enable ? 1 : 0;
+    if (!enable) c->drop_graphs();
     return 0;
 }
 

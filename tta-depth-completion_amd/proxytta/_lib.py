@@ -42,6 +42,7 @@ SIGNATURES = [
     ('ptta_backward', c_int, [_P, _P, _P, _P, _P, _P]),
     ('ptta_adam_step', c_int, [_P, _P, _P, _P]),
     ('ptta_step', c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    ('ptta_set_graph', c_int, [_P, c_int]),
     ('ptta_profile', c_int, [_P, c_int]),
     ('ptta_profile_read', c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                   POINTER(c_int64), _P]),

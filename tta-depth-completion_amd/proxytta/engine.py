@@ -165,6 +165,9 @@ class Engine:
                                      ptr(depth), ptr(info), _stream()), 'ptta_step')
         return info, depth
 
+    def set_graph(self, enable):
+        self._chk(self.lib.ptta_set_graph(self.handle, int(bool(enable))), 'ptta_set_graph')
+
     def profile(self, enable):
         self._chk(self.lib.ptta_profile(self.handle, int(bool(enable))), 'ptta_profile')
 

@@ -1,0 +1,64 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol (no compute calls),
+include/ptta.h and the ctypes table agree, the host mirror keeps the reference's surface."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from proxytta import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libptta_hip.so not built (run __graft_entry__.build())')
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'ptta.h')).read()
+    declared = set(re.findall(r'\b(ptta_[a-z0-9_]+)\s*\(', header))
+    bound = {name for name, _, _ in _lib.SIGNATURES}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ptta_version() >= 1
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from proxytta.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine(1, 32, 48)
+
+
+def test_mirror_surface_and_state_dict_keys():
+    from proxytta import synth
+    from proxytta.model import ExternalModel_Adapt, MsgChnModel_Adapt
+    for name in ('forward', 'compute_loss', '_prepare_head', 'adapt_parameters', 'parameters', 'train', 'eval', 'to',
+                 'data_parallel', 'distributed_data_parallel', 'restore_model', 'save_model', 'convert_syncbn',
+                 'step', 'adapt'):
+        assert hasattr(ExternalModel_Adapt, name), name
+    m = MsgChnModel_Adapt(device=torch.device('cpu'))
+    m._prepare_head('meta_selfsup_seq_1layer_ema')
+    assert sorted(m.model.state_dict().keys()) == sorted(k for k, _ in synth.msg_chn_keys())
+    params = m.adapt_parameters('meta')
+    assert [tuple(p.shape) for p in params] == [(32, 32, 3, 3), (32,)]
+    with pytest.raises(ValueError):
+        ExternalModel_Adapt('unknown', 0, 1, device=torch.device('cpu'))
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    from proxytta.model import MsgChnModel_Adapt
+    m = MsgChnModel_Adapt(device=torch.device('cpu'))
+    m._prepare_head('meta_selfsup_seq_1layer_ema')
+    opt = torch.optim.Adam(m.adapt_parameters('meta'), lr=1e-3)
+    path = str(tmp_path / 'ckpt.pth')
+    m.save_model(path, 7, opt)
+    ck = torch.load(path)
+    assert set(ck) == {'net', 'optimizer', 'train_step'} and ck['train_step'] == 7    # msg_chn_model_adapt.py:513-545
+    m2 = MsgChnModel_Adapt(device=torch.device('cpu'))
+    m2._prepare_head('meta_selfsup_seq_1layer_ema')
+    _, step = m2.restore_model(path)
+    assert step == 7
+    for k, v in m.model.state_dict().items():
+        assert torch.equal(v, m2.model.state_dict()[k])

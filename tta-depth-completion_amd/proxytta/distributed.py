@@ -1,0 +1,53 @@
+"""Multi-GPU plumbing for the ProxyTTA step: one process per GPU, torch.distributed
+(backend 'nccl' = RCCL over xGMI on ROCm, 'gloo' in the CPU tests).
+
+Two modes:
+  * independent frame streams (BASELINE config 4): frame i of the stream goes to rank i % world;
+    every rank adapts its own copy of the adapted parameters on its sub-stream.  No collective on
+    the data path.
+  * shared-parameter batched TTA (what the reference's DDP does, src/msg_chn_model_adapt.py:476-480,
+    src/tta_main.py:354): every rank runs forward+loss+backward on its slice of the batch, then ONE
+    collective: mean all-reduce of the adapted-parameter gradients only (37 KB for the MSG_CHN 1layer
+    meta conv; the reference all-reduces all 5.8 MB of gradients and discards most of them), then
+    the same Adam update everywhere.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_frames(n_frames, rank, world):
+    """Indices of the frames this rank owns (round-robin, as a streaming source would deal them)."""
+    return list(range(rank, n_frames, world))
+
+
+def allreduce_adapted_grads(grads, group=None):
+    """Mean all-reduce of a list of gradient tensors as ONE flat message (latency-bound payload:
+    a single small collective beats one per tensor).  Returns the reduced tensors (in place)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return grads
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+    return grads
+
+
+def shared_parameter_step(engine, image, sparse, validity=None, loss_image=None, group=None,
+                          w=(1.0, 1.0, 1.0)):
+    """Batched TTA across ranks with shared adapted parameters: local forward / loss / backward
+    through the library, one gradient all-reduce, fused Adam with the reduced gradients."""
+    depth, emb, ref = engine.forward_train(image, sparse)
+    if validity is None:
+        validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+    if loss_image is None:
+        loss_image = image
+    info = engine.loss_forward(loss_image, depth, sparse, validity, emb, ref, *w)
+    gd, gr = engine.loss_backward(loss_image, depth, sparse, validity, emb, ref)
+    gw, gb = engine.backward(gd, gr)
+    allreduce_adapted_grads([gw, gb], group)
+    engine.adam_step(gw, gb)
+    return info, depth

@@ -109,7 +109,7 @@ def _run_golden(name, impl, golden_dir):
     # gradients of the L1 / total-variation terms are sums of sign() functions: a 1e-5 perturbation
     # of the depth map (bf16x3 arithmetic, different summation order) flips a few signs, so the
     # gradient tolerance is looser than the depth tolerance; exact-fp32 modes hold 1e-3
-    gtol, ptol = (1e-3, 2e-5) if impl in ('naive', 'exact') else (3e-2, 1e-3)
+    gtol, ptol = (1e-3, 5e-5) if impl in ('naive', 'exact') else (3e-2, 1e-3)
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)

@@ -159,52 +159,70 @@ int ptta_launch_conv_in(const ConvInArgs& a, hipStream_t s) {
 }
 
 // ---- 32 -> 1 ------------------------------------------------------------------------------------
+// 8 lanes per pixel (each lane 4 channels = 16 B of the pixel's 128-B line, 8 B in bf16 mode), 8
+// consecutive pixels per wave-instruction: every load instruction reads 8 whole NHWC lines (1 KiB
+// contiguous).  A wave walks DOWN a strip of 8 columns so the rows shared by consecutive outputs
+// stay in L1; the 288 weights live in 36 VGPRs; the 8 partial sums of a pixel are combined with
+// three xor-shuffles.
 template <typename T, bool RELU>
 __global__ __launch_bounds__(256) void conv_out1_kernel(const T* __restrict__ in, int in_nb, const float* __restrict__ w,
                                                         const float* __restrict__ bias, const float* __restrict__ add,
                                                         int add_nb, float* __restrict__ out, int B, int H, int W) {
-    __shared__ float ws[288];
-    for (int k = threadIdx.x; k < 288; k += blockDim.x) ws[k] = w[k];
-    __syncthreads();
-    const long total = (long)B * H * W;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % W);
-        long t_ = idx / W;
-        const int y = (int)(t_ % H);
-        const int b = (int)(t_ / H);
-        const T* inb = in + (size_t)(b % in_nb) * H * W * 32;
-        float acc = bias ? bias[0] : 0.f;
+    const int lane = threadIdx.x & 63, pl = lane >> 3, cq = lane & 7;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    float4 wt[9];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yi = y + tap / 3 - 1, xi = x + tap % 3 - 1;
-            if (yi < 0 || yi >= H || xi < 0 || xi >= W) continue;
-            const T* src = inb + ((size_t)yi * W + xi) * 32;
-            if (sizeof(T) == 4) {
+    for (int t = 0; t < 9; ++t) wt[t] = *(const float4*)(w + t * 32 + 4 * cq);
+    const float b0 = bias ? bias[0] : 0.f;
+    constexpr int RC = 4;                                    // output rows per work item
+    const int nsx = (W + 7) >> 3, nsy = (H + RC - 1) / RC;
+    const long nitems = (long)B * nsx * nsy;
+    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+        long t_ = item;
+        const int sx = (int)(t_ % nsx); t_ /= nsx;
+        const int sy = (int)(t_ % nsy);
+        const int b = (int)(t_ / nsy);
+        const int x = sx * 8 + pl;
+        const int ya = sy * RC;
+        const T* inb = in + (size_t)(b % in_nb) * H * W * 32 + 4 * cq;
+        // (RC+2) x 3 input window of this lane's channel quad: all 18 loads issued back to back
+        float4 v[RC + 2][3];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float4 v = *(const float4*)((const float*)src + 4 * q);
-                    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    const float* wq = ws + tap * 32 + 4 * q;
-                    acc = fmaf(v.x, wq[0], acc); acc = fmaf(v.y, wq[1], acc);
-                    acc = fmaf(v.z, wq[2], acc); acc = fmaf(v.w, wq[3], acc);
-                }
-            } else {
+        for (int r = 0; r < RC + 2; ++r)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint4 u = *(const uint4*)((const bf16_t*)src + 8 * q);
-                    const unsigned uu[4] = {u.x, u.y, u.z, u.w};
-                    const float* wq = ws + tap * 32 + 8 * q;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float lo = __uint_as_float(uu[e] << 16), hi = __uint_as_float(uu[e] & 0xffff0000u);
-                        if (RELU) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
-                        acc = fmaf(lo, wq[2 * e], acc); acc = fmaf(hi, wq[2 * e + 1], acc);
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yi = ya + r - 1, xi = x + kx - 1;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yi >= 0 && yi < H && xi >= 0 && xi < W) {
+                    const T* src = inb + ((size_t)yi * W + xi) * 32;
+                    if (sizeof(T) == 4) t = *(const float4*)src;
+                    else {
+                        const uint2 u = *(const uint2*)src;
+                        t.x = __uint_as_float(u.x << 16); t.y = __uint_as_float(u.x & 0xffff0000u);
+                        t.z = __uint_as_float(u.y << 16); t.w = __uint_as_float(u.y & 0xffff0000u);
                     }
                 }
+                if (RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+                v[r][kx] = t;
+            }
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const float4 t = v[r + tap / 3][tap % 3];
+                acc = fmaf(t.x, wt[tap].x, acc); acc = fmaf(t.y, wt[tap].y, acc);
+                acc = fmaf(t.z, wt[tap].z, acc); acc = fmaf(t.w, wt[tap].w, acc);
+            }
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+            const int y = ya + r;
+            if (cq == 0 && x < W && y < H) {
+                const size_t o = (size_t)y * W + x;
+                float res = acc + b0;
+                if (add) res += add[(size_t)(b % add_nb) * H * W + o];
+                out[(size_t)b * H * W + o] = res;
             }
         }
-        if (add) acc += add[(size_t)(b % add_nb) * H * W + (size_t)y * W + x];
-        out[idx] = acc;
     }
 }
 
@@ -220,8 +238,8 @@ void ptta_pack_conv_out1(const float* src, int src_cin_total, int src_cin_index,
 }
 
 int ptta_launch_conv_out1(const ConvOut1Args& a, hipStream_t s) {
-    const long total = (long)a.B * a.H * a.W;
-    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    const long items = (long)a.B * ((a.W + 7) / 8) * ((a.H + 3) / 4);
+    int blocks = (int)((items + 3) / 4); if (blocks > 8192) blocks = 8192;
     const int add_nb = a.add_nb > 0 ? a.add_nb : 1;
 #define LAUNCH_(T, R) hipLaunchKernelGGL((conv_out1_kernel<T, R>), dim3(blocks), dim3(256), 0, s, (const T*)a.in, a.in_nb, \
                                          a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W)

@@ -167,6 +167,10 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
 
+// staging item -> halo pixel: the 8 lanes of one ds_write_b128 group take pixels p and p+4 (not p, p+1):
+// at the 144-B stride their hi/lo footprints then fall on disjoint banks
+__device__ __forceinline__ int x3_stage_pix(int idx) { return ((idx >> 5) << 3) + (((idx >> 2) & 1) << 2) + ((idx >> 3) & 3); }
+
 template <bool RELU, bool UP, bool MASK, bool ADD>
 __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) {
     // one LDS array: [halo tile | lo weight fragments]
@@ -200,16 +204,16 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
         const float* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
         // ---- stage the halo tile: (pixel, 8-channel group) items, 6 per thread; all global loads
         //      of the tile are issued before the first one is consumed -------------------------------
-        constexpr int NIT = (X3_PH * X3_PW * 4 + 255) / 256;
+        constexpr int NIT = (((X3_PH * X3_PW + 7) / 8) * 32 + 255) / 256;
         float4 v0[NIT], v1[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
-            const int g = idx & 3, pix = idx >> 2;
+            const int g = idx & 3, pix = x3_stage_pix(idx);
             const int py = pix / X3_PW, px = pix - py * X3_PW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
-            if (idx < X3_PH * X3_PW * 4 && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (pix < X3_PH * X3_PW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
                 const float* src = inb + ((size_t)gy * W + gx) * 32 + 8 * g;
                 v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
             }
@@ -217,13 +221,14 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
-            if (idx < X3_PH * X3_PW * 4) {
+            const int pix = x3_stage_pix(idx);
+            if (pix < X3_PH * X3_PW) {
                 float4 a0 = v0[it], a1 = v1[it];
                 if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
                 uint4 hi, lo;
                 split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);
                 split2(a1.x, a1.y, hi.z, lo.z); split2(a1.z, a1.w, hi.w, lo.w);
-                unsigned char* dst = lds + (idx >> 2) * X3_STRIDE + 16 * (idx & 3);
+                unsigned char* dst = lds + pix * X3_STRIDE + 16 * (idx & 3);
                 *(uint4*)dst = hi;
                 *(uint4*)(dst + 64) = lo;
             }

@@ -152,6 +152,11 @@ __device__ __forceinline__ void hsplit2(float a, float b, unsigned& hi, unsigned
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, hbf16x2));
 }
 
+// staging item -> (row, 8-k chunk): the 8 lanes of one ds_write_b128 group take rows r and r+4 (not r and
+// r+1), whose 64-B footprints do not share banks at the 80-B row stride; each row's 128 B of global
+// memory is still fetched by 4 adjacent lanes
+__device__ __forceinline__ int stage_row(int idx) { return ((idx >> 5) << 3) + (((idx >> 2) & 1) << 2) + ((idx >> 3) & 3); }
+
 struct GemmX3P {
     GemmP g;
     const bf16_t* Whi; const bf16_t* Wlo;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
 #pragma unroll
         for (int it = 0; it < BM * 4 / 256; ++it) {
             const int idx = tid + 256 * it;
-            const int row = idx >> 2, kq = idx & 3;
+            const int row = stage_row(idx), kq = idx & 3;
             const long gr = row0 + row;
             const int k = k0 + 8 * kq;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
         for (int it = 0; it < (BN * 4 + 255) / 256; ++it) {
             const int idx = tid + 256 * it;
             if (idx < BN * 4) {
-                const int row = idx >> 2, kq = idx & 3;
+                const int row = stage_row(idx), kq = idx & 3;
                 const long off = (long)(n0 + row) * p.K + k0 + 8 * kq;
                 *(uint4*)(Bhi + row * X3_ROW + 16 * kq) = *(const uint4*)(q.Whi + off);
                 *(uint4*)(Blo + row * X3_ROW + 16 * kq) = *(const uint4*)(q.Wlo + off);
@@ -297,6 +302,162 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
     }
 }
 
+// ---- large-tile variant for N = 512: block = 256 rows x 256 columns, 8 waves (4 x 2), each wave
+// 64 x 128 outputs (2 x 4 MFMA tiles, 128 accumulator VGPRs).  Two LDS stages (2 x 80 KB = the whole
+// 160 KB of a CU): slice k is computed from stage k&1 while slice k+1 (already in registers) is
+// transformed (fused BN+ReLU / BN-backward), split and written to the other stage and slice k+2 is
+// being fetched from HBM/L2: one barrier per K slice, 48 MFMAs per wave between barriers.
+template <int PRO, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_x3_wide_kernel(GemmX3P q) {
+    constexpr int BM = 256, BN = 256, TM = 2, TN = 4;
+    const GemmP& p = q.g;
+    constexpr int STAGE = (2 * BM + 2 * BN) * X3_ROW;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[2 * STAGE];
+    float* red = (float*)sm;                                  // [4][2][BN], used after the K loop
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BN;
+    const long row0 = (long)blockIdx.y * BM;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    float4 ra[2][2], rh[2][2];
+    uint4 rbh[2], rbl[2];
+    auto load_slice = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 512 * it;
+            const long gr = row0 + stage_row(idx);
+            const int k = k0 + 8 * (idx & 3);
+            ra[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); ra[it][1] = ra[it][0];
+            if (PRO == 2) { rh[it][0] = ra[it][0]; rh[it][1] = ra[it][0]; }
+            if (gr < p.R) {
+                ra[it][0] = *(const float4*)((const float*)p.A + gr * p.K + k);
+                ra[it][1] = *(const float4*)((const float*)p.A + gr * p.K + k + 4);
+                if (PRO == 2) {
+                    rh[it][0] = *(const float4*)(p.A2 + gr * p.K + k);
+                    rh[it][1] = *(const float4*)(p.A2 + gr * p.K + k + 4);
+                }
+            }
+            const long off = (long)(n0 + stage_row(idx)) * p.K + k0 + 8 * (idx & 3);
+            rbh[it] = *(const uint4*)(q.Whi + off);
+            rbl[it] = *(const uint4*)(q.Wlo + off);
+        }
+    };
+    auto store_slice = [&](int k0, int stage) {
+        unsigned char* Ahi = sm + stage * STAGE; unsigned char* Alo = Ahi + BM * X3_ROW;
+        unsigned char* Bhi = Alo + BM * X3_ROW; unsigned char* Blo = Bhi + BN * X3_ROW;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 512 * it;
+            const int row = stage_row(idx), kq = idx & 3;
+            const long gr = row0 + row;
+            const int k = k0 + 8 * kq;
+            float v[8] = {ra[it][0].x, ra[it][0].y, ra[it][0].z, ra[it][0].w, ra[it][1].x, ra[it][1].y, ra[it][1].z, ra[it][1].w};
+            if (gr < p.R) {
+                if (PRO == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], p.pscale[k + e], p.pshift[k + e]), 0.f);
+                } else if (PRO == 2) {
+                    const float hh[8] = {rh[it][0].x, rh[it][0].y, rh[it][0].z, rh[it][0].w, rh[it][1].x, rh[it][1].y, rh[it][1].z, rh[it][1].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        v[e] = p.pscale[k + e] * (v[e] - p.pc1[k + e] - (hh[e] - p.pmean[k + e]) * p.pinv[k + e] * p.pc2[k + e]);
+                }
+            }
+            uint4 hi, lo;
+            hsplit2(v[0], v[1], hi.x, lo.x); hsplit2(v[2], v[3], hi.y, lo.y);
+            hsplit2(v[4], v[5], hi.z, lo.z); hsplit2(v[6], v[7], hi.w, lo.w);
+            *(uint4*)(Ahi + row * X3_ROW + 16 * kq) = hi;
+            *(uint4*)(Alo + row * X3_ROW + 16 * kq) = lo;
+            *(uint4*)(Bhi + row * X3_ROW + 16 * kq) = rbh[it];
+            *(uint4*)(Blo + row * X3_ROW + 16 * kq) = rbl[it];
+        }
+    };
+
+    load_slice(0);
+    store_slice(0, 0);
+    if (32 < p.K) load_slice(32);
+    __syncthreads();
+    for (int k0 = 0, stage = 0; k0 < p.K; k0 += 32, stage ^= 1) {
+        const unsigned char* Ahi = sm + stage * STAGE; const unsigned char* Alo = Ahi + BM * X3_ROW;
+        const unsigned char* Bhi = Alo + BM * X3_ROW; const unsigned char* Blo = Bhi + BN * X3_ROW;
+        if (k0 + 32 < p.K) {
+            store_slice(k0 + 32, stage ^ 1);          // registers hold slice k+1 (landed during slice k-1's MFMAs)
+            if (k0 + 64 < p.K) load_slice(k0 + 64);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int off = ((wm * TM + a) * 32 + i) * X3_ROW + 32 * ks + 16 * h;
+                ah[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Ahi + off));
+                al[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Alo + off));
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int off = ((wn * TN + b) * 32 + i) * X3_ROW + 32 * ks + 16 * h;
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)(Bhi + off));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(Blo + off));
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int cl = (wn * TN + b) * 32 + i;
+        const int col = n0 + cl;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+        float esc = 0.f, esh = 0.f, emu = 0.f, eiv = 0.f;
+        if (EPI == 2) { esc = p.escale[col]; esh = p.eshift[col]; emu = p.emean[col]; eiv = p.einv[col]; }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + (wm * TM + a) * 32 + acc_row(r, h);
+                if (row >= p.R) continue;
+                float v = acc[a][b][r] + bias;
+                if (EPI == 1) { s1 += v; s2 += v * v; }
+                if (EPI == 2) {
+                    const float hh = p.eH[row * p.N + col];
+                    v = (fmaf(hh, esc, esh) > 0.f) ? v : 0.f;
+                    s1 += v; s2 += v * (hh - emu) * eiv;
+                }
+                p.C[row * p.N + col] = v;
+            }
+        }
+        if (EPI != 0) {
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            if (h == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
+        }
+    }
+    if (EPI != 0) {
+        __syncthreads();
+        for (int t = tid; t < 2 * BN; t += 512) {
+            const int which = t / BN, c = t % BN;
+            const float v = (red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c]) +
+                            (red[(2 * 2 + which) * BN + c] + red[(3 * 2 + which) * BN + c]);
+            p.part[((long)blockIdx.y * 2 + which) * p.N + n0 + c] = v;
+        }
+    }
+}
+
 // split an fp32 [N][K] weight into bf16 hi / lo planes
 __global__ void split_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n) {
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
@@ -311,6 +472,8 @@ void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, long n, hipStream
 }
 
 int ptta_gemm_row_blocks(int R) { return (R + GEMM_BM - 1) / GEMM_BM; }
+// number of row-block partials the launch of `a` writes (the wide bf16x3 kernel uses 256-row blocks)
+int ptta_gemm_part_blocks(const GemmArgs& a) { return (a.x3 && !a.a_bf16 && a.N == 512) ? (a.R + 255) / 256 : ptta_gemm_row_blocks(a.R); }
 
 int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.K % GEMM_BK || a.N % 32) return -22;
@@ -321,7 +484,16 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.x3 && !a.a_bf16) {
         GemmX3P q; q.g = p; q.Whi = a.Whi; q.Wlo = a.Wlo;
         const int key3 = a.pro * 10 + a.epi;
-        if (a.N % 128 == 0) {
+        if (a.N == 512) {
+            dim3 grid(2, (a.R + 255) / 256);
+#define GW_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_wide_kernel<PRO, EPI>), grid, dim3(512), 0, s, q)
+            switch (key3) {
+                case 0: GW_(0, 0); break; case 1: GW_(0, 1); break; case 2: GW_(0, 2); break;
+                case 10: GW_(1, 0); break; case 11: GW_(1, 1); break;
+                default: return -22;
+            }
+#undef GW_
+        } else if (a.N % 128 == 0) {
             dim3 grid(a.N / 128, ptta_gemm_row_blocks(a.R));
 #define GX_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 2, 2, PRO, EPI>), grid, dim3(256), 0, s, q)
             switch (key3) {

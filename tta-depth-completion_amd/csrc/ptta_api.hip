@@ -457,7 +457,7 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
     GemmArgs g; g.A = A; g.a_bf16 = a_bf16; g.W = l0.W; g.bias = l0.bias; g.C = hidden; g.R = R; g.K = K; g.N = 512; g.epi = 1; g.part = c->bn_part;
     g.x3 = c->x3; g.Whi = l0.Whi; g.Wlo = l0.Wlo;
     RUN(ptta_launch_gemm(g, s));
-    RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_row_blocks(R), R, 512, bn.gamma, bn.beta, 1e-5f, 0.1f, bn.rm, bn.rv, bn.nbt,
+    RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(g), R, 512, bn.gamma, bn.beta, 1e-5f, 0.1f, bn.rm, bn.rv, bn.nbt,
                                 bn.mean, bn.inv, bn.scale, bn.shift, s));
     GemmArgs g2; g2.A = hidden; g2.W = l3.W; g2.bias = l3.bias; g2.C = out; g2.R = R; g2.K = 512; g2.N = 512; g2.pro = 1;
     g2.pscale = bn.scale; g2.pshift = bn.shift;
@@ -483,7 +483,7 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     g.eH = c->h1; g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part;
     g.x3 = c->x3; g.Whi = l3.Wthi; g.Wlo = l3.Wtlo;
     RUN(ptta_launch_gemm(g, s));
-    RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_row_blocks(R), R, 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
+    RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R, 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
     GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = c->g_feat_f32; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;
     g2.pscale = c->bnb_gscale; g2.pmean = bn.mean; g2.pinv = bn.inv; g2.pc1 = c->bnb_c1; g2.pc2 = c->bnb_c2;
     g2.x3 = c->x3; g2.Whi = l0.Wthi; g2.Wlo = l0.Wtlo;

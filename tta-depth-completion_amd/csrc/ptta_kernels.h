@@ -82,6 +82,7 @@ struct GemmArgs {
 };
 void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, long n, hipStream_t s);
 int ptta_gemm_row_blocks(int R);
+int ptta_gemm_part_blocks(const GemmArgs& a);
 int ptta_launch_gemm(const GemmArgs& a, hipStream_t s);
 // BatchNorm1d (train) statistics from partials; also updates running stats (momentum 0.1, unbiased var)
 int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* beta,

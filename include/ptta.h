@@ -27,7 +27,7 @@ typedef void* ptta_stream;              /* hipStream_t */
 
 enum { PTTA_BACKBONE_MSG_CHN = 0 };
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
-enum { PTTA_META_1LAYER = 0 };
+enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
 
 /* Hyper-parameters of the step.  Reference: src/tta.py:10-160 flags learning_rates,
  * optimizer_betas, optimizer_epsilon, w_weight_decay, w_loss_sparse_depth, w_loss_smoothness,
@@ -60,7 +60,7 @@ int ptta_load_weights(ptta_handle h, const char* name, const void* tensor, const
 /* adapt_parameters(mode='meta') + torch.optim.Adam state (src/msg_chn_model_adapt.py:392-396,
  * src/tta_main.py:339-346).  The caller keeps ownership of the parameter and of the Adam moments
  * exp_avg / exp_avg_sq (fp32, same shape); the library reads the parameter on every forward and
- * ptta_step / ptta_adam_step update all three in place.  name: "conv1_rgb_meta.weight" | ".bias". */
+ * ptta_step / ptta_adam_step update all three in place.  name: one of ptta_adapted_name(). */
 int ptta_bind_adapted(ptta_handle h, const char* name, float* param, float* exp_avg, float* exp_avg_sq);
 int ptta_set_adam_step(ptta_handle h, int step, ptta_stream s);      /* optimizer.state[p]['step'] */
 int ptta_get_adam_step(ptta_handle h, int* step_host, ptta_stream s); /* synchronises s */
@@ -91,6 +91,13 @@ int ptta_loss_backward(ptta_handle h, const float* loss_image, const float* dept
  * conv1_rgb_meta.{weight (32,32,3,3), bias (32)}. */
 int ptta_backward(ptta_handle h, const float* grad_depth, const float* grad_ref,
                   float* grad_meta_weight_out, float* grad_meta_bias_out, ptta_stream s);
+
+/* Gradient of one adapted parameter after ptta_backward / ptta_step, by state_dict key (the
+ * 2layers meta layer has seven adapted tensors: two conv weights, one conv bias, two BatchNorm
+ * gamma/beta pairs).  ptta_adapted_count/name enumerate them in state_dict order. */
+int ptta_get_grad(ptta_handle h, const char* name, float* dst, int64_t capacity, ptta_stream s);
+int ptta_adapted_count(ptta_handle h);
+const char* ptta_adapted_name(ptta_handle h, int index, int64_t* numel_host);
 
 /* optimizer.step() for the bound parameters with explicit gradients (src/tta_main.py:633). */
 int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* grad_meta_bias, ptta_stream s);

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from proxytta import synth
-from tests.util import ONE, golden_hp, make_engine, rel_mae
+from tests.util import ONE, TWO, golden_hp, make_engine, rel_mae
 
 pytestmark = pytest.mark.gpu
 
@@ -203,17 +203,19 @@ def test_against_oracle_midsize():
     eng.close()
 
 
-def test_facade_reference_style_driver(golden_dir):
+@pytest.mark.parametrize('mode,fixture', [(ONE, 'msgchn_1layer_32x48'), (TWO, 'msgchn_2layers_32x48')])
+def test_facade_reference_style_driver(golden_dir, mode, fixture):
     """tta_main-style loop (forward / compute_loss / zero_grad / backward / optimizer.step) through the
-    ExternalModel_Adapt mirror gives the same numbers as the golden run."""
+    ExternalModel_Adapt mirror gives the same numbers as the golden run (both meta layers)."""
     from proxytta.model import CANONICAL_LOSS_TYPE, ExternalModel_Adapt
-    g = np.load(os.path.join(golden_dir, 'msgchn_1layer_32x48.npz'))
+    g = np.load(os.path.join(golden_dir, fixture + '.npz'))
     h, w, n, steps = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
     model = ExternalModel_Adapt('msg_chn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], device=torch.device('cuda'))
-    model._prepare_head(ONE)
-    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict(ONE, gain).items()})
+    model._prepare_head(mode)
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict(mode, gain).items()})
     params = model.adapt_parameters(mode='meta')
+    names = [k for k, _ in model.model.model.named_parameters() if 'meta' in k]
     opt = torch.optim.Adam(params, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'])
     for s in range(steps):
         image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)]
@@ -227,14 +229,16 @@ def test_facade_reference_style_driver(golden_dir):
         loss.backward()
         opt.step()
         p = 's%d/' % s
-        assert abs(float(loss) - g[p + 'loss_info'][0]) < 1e-4 * abs(g[p + 'loss_info'][0])
-        for k, prm in zip(('conv1_rgb_meta.weight', 'conv1_rgb_meta.bias'), params):
-            assert rel_mae(prm.grad, g[p + 'grad/' + k]) < 3e-2
-            assert rel_mae(prm, g[p + "param/" + k]) < 1e-3
+        assert abs(float(loss.detach()) - g[p + 'loss_info'][0]) < 2e-4 * abs(g[p + 'loss_info'][0])
+        for k, prm in zip(names, params):
+            if np.abs(g[p + 'grad/' + k]).max() < 1e-6:
+                continue                          # analytically-zero gradient, see test_2layers_...
+            assert rel_mae(prm.grad, g[p + 'grad/' + k]) < 5e-2, k
+            assert rel_mae(prm, g[p + "param/" + k]) < 2e-3, k
         model.eval()
         with torch.no_grad():
             d_eval = model.forward(image=image, sparse_depth=sparse, loss_type=CANONICAL_LOSS_TYPE)
-        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-4
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 3e-4
 
 
 def test_full_size_properties():
@@ -258,3 +262,39 @@ def test_full_size_properties():
         eng.close()
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('impl', ['exact', None])
+def test_2layers_meta_layer_matches_reference_golden(golden_dir, impl):
+    """prepare_mode meta_selfsup_seq_2layers_ema (Res_Conv(32,128) with train-mode BatchNorm2d): the
+    recipe of bash/adapt/adapt_msgchn_vkitti.sh.  Seven adapted tensors, BN running statistics."""
+    g = np.load(os.path.join(golden_dir, 'msgchn_2layers_32x48.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, impl, meta='2layers')
+    gtol = 2e-3 if impl == 'exact' else 5e-2
+    for s in range(steps):
+        image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)]
+        p = 's%d/' % s
+        info, depth = eng.step(image, sparse, want_depth=True)
+        torch.cuda.synchronize()
+        assert rel_mae(depth, g[p + 'depth_train']) < 1e-4
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2e-4)
+        for k, (prm, m, v) in adapted.items():
+            gref = g[p + 'grad/' + k]
+            got = eng.grad(k, prm)
+            if np.abs(gref).max() < 1e-6:           # conv bias in front of a BatchNorm: analytically zero
+                assert float(got.abs().max()) < 1e-5
+                assert np.abs(prm.cpu().numpy() - g[p + 'param/' + k]).max() <= 2.5 * hp['lr'] * (s + 1)
+                continue
+            assert rel_mae(got, gref) < gtol, (k, s)
+            assert rel_mae(prm, g[p + 'param/' + k]) < (1e-4 if impl == 'exact' else 2e-3), k
+        for k in g.files:
+            if k.startswith(p + 'buf/'):
+                key = k[len(p) + 4:]
+                if key.startswith('proj_t'):
+                    continue
+                assert rel_mae(sd[key], g[k]) < 2e-3, k
+        d_eval = eng.forward_eval(image, sparse)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 3e-4
+    eng.close()

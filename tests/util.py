@@ -15,9 +15,12 @@ def rel_mae(a, b, floor=1e-4):
     return float(np.abs(a - b).mean() / max(np.abs(b).mean(), floor))
 
 
-def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None):
+TWO = 'meta_selfsup_seq_2layers_ema'
+
+
+def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None, meta='1layer'):
     """Engine with formula weights; returns (engine, state dict on device, adapted dict)."""
-    from proxytta.engine import ADAPTED, Engine
+    from proxytta.engine import Engine, adapted_names
     os.environ.pop('PTTA_CONV_IMPL', None)
     os.environ.pop('PTTA_ARITH', None)
     if impl == 'naive':
@@ -26,13 +29,13 @@ def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None):
     elif impl == 'exact':
         os.environ['PTTA_ARITH'] = 'exact'
     hp = dict(hp or {})
-    eng = Engine(n, h, w, dtype=dtype, **hp)
+    eng = Engine(n, h, w, dtype=dtype, meta=meta, **hp)
     os.environ.pop('PTTA_CONV_IMPL', None)
     os.environ.pop('PTTA_ARITH', None)
-    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(ONE, gain).items()}
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(TWO if meta == '2layers' else ONE, gain).items()}
     eng.load_state_dict(sd)
     adapted = {}
-    for name in ADAPTED:
+    for name in adapted_names(meta):
         p = sd[name]
         adapted[name] = (p, torch.zeros_like(p), torch.zeros_like(p))
         eng.bind_adapted(name, *adapted[name])

@@ -195,17 +195,22 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     const long ntiles = (long)p.B * ntx * nty;
     const float sy = up_scale(H >> 1, H), sx = up_scale(W >> 1, W);
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // (pixel, 8-channel group) staging items, 6 per thread.  Without the bilinear epilogue there are
+    // registers to spare, so the NEXT tile's global loads are issued before this tile's MFMAs and
+    // land while the matrix cores work (software prefetch across the persistent tile loop).
+    constexpr int NIT = (((X3_PH * X3_PW + 7) / 8) * 32 + 255) / 256;
+    constexpr bool PREFETCH = !UP;
+    float4 v0[NIT], v1[NIT];
+    auto tile_coords = [&](long tile, int& b, int& y0, int& x0) {
         long t_ = tile;
         const int ty = (int)(t_ % nty); t_ /= nty;          // y fastest: neighbouring blocks share halo rows in L2
         const int tx = (int)(t_ % ntx);
-        const int b = (int)(t_ / ntx);
-        const int y0 = ty * X3_TH, x0 = tx << 5;
+        b = (int)(t_ / ntx); y0 = ty * X3_TH; x0 = tx << 5;
+    };
+    auto issue_loads = [&](long tile) {
+        int b, y0, x0;
+        tile_coords(tile, b, y0, x0);
         const float* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
-        // ---- stage the halo tile: (pixel, 8-channel group) items, 6 per thread; all global loads
-        //      of the tile are issued before the first one is consumed -------------------------------
-        constexpr int NIT = (((X3_PH * X3_PW + 7) / 8) * 32 + 255) / 256;
-        float4 v0[NIT], v1[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
@@ -218,6 +223,13 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
                 v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
             }
         }
+    };
+    if (PREFETCH && blockIdx.x < ntiles) issue_loads(blockIdx.x);
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b, y0, x0;
+        tile_coords(tile, b, y0, x0);
+        if (!PREFETCH) issue_loads(tile);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
@@ -233,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
                 *(uint4*)(dst + 64) = lo;
             }
         }
+        if (PREFETCH && tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x);
         __syncthreads();
         // ---- two output rows per wave ------------------------------------------------------------
 #pragma unroll 1
@@ -392,12 +405,13 @@ __global__ void conv32_naive_kernel(Conv32P<T> p) {
 // in_major: src is indexed [cin_eff][cout_eff]; flip: use tap (2-ky, 2-kx).  See DESIGN.md §4 for
 // which (in_major, flip) pair each forward/backward use needs.
 __global__ void pack_conv32_kernel(const float* __restrict__ src, float* mf32, bf16_t* mbf16, bf16_t* mlo, float* canon,
-                                   int in_major, int flip) {
+                                   int in_major, int flip, int row_stride, int col_off) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;          // over tap*32*32
     if (idx >= 9 * 32 * 32) return;
     const int co = idx & 31, ci = (idx >> 5) & 31, tap = idx >> 10;
     const int st = flip ? 8 - tap : tap;
-    const float v = in_major ? src[(ci * 32 + co) * 9 + st] : src[(co * 32 + ci) * 9 + st];
+    // row_stride / col_off select a 32x32 block out of a wider weight (the 32->128->32 meta layer)
+    const float v = in_major ? src[((size_t)ci * row_stride + col_off + co) * 9 + st] : src[((size_t)co * row_stride + col_off + ci) * 9 + st];
     canon[(tap * 32 + ci) * 32 + co] = v;
     {   // fp32 fragments: [tap][g][lane][s], lane = h*32 + cout, cin = 8g + 4h + s
         const int g = ci >> 3, hh = (ci >> 2) & 1, s = ci & 3;
@@ -411,8 +425,8 @@ __global__ void pack_conv32_kernel(const float* __restrict__ src, float* mf32, b
     }
 }
 
-void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, hipStream_t s) {
-    hipLaunchKernelGGL(pack_conv32_kernel, dim3(36), dim3(256), 0, s, src, w.mf32, w.mbf16, w.mlo, w.canon, in_major, flip);
+void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, hipStream_t s, int row_stride, int col_off) {
+    hipLaunchKernelGGL(pack_conv32_kernel, dim3(36), dim3(256), 0, s, src, w.mf32, w.mbf16, w.mlo, w.canon, in_major, flip, row_stride, col_off);
 }
 
 // compile-time epilogue flags -> kernel instance

@@ -48,9 +48,20 @@ struct ptta_ctx {
     std::map<std::string, Lin> fc;
     std::map<std::string, BNorm> bn;
     std::map<std::string, Dbg> dbg;
-    // adapted parameters (bound, caller-owned)
-    float *meta_w = nullptr, *meta_b = nullptr, *meta_w_m = nullptr, *meta_w_v = nullptr, *meta_b_m = nullptr, *meta_b_v = nullptr;
+    // adapted parameters (bound, caller-owned) in state_dict order; g = internal gradient buffer
+    int meta_mode = 0;
+    struct Adapted { std::string name; long n = 0; float *p = nullptr, *m = nullptr, *v = nullptr, *g = nullptr; };
+    std::vector<Adapted> adapted;
+    float *meta_w = nullptr, *meta_b = nullptr;      // 1layer aliases of adapted[0].p / adapted[1].p
     float *gW = nullptr, *gB = nullptr;
+    // 2layers meta layer (Res_Conv(32,128)): four 32-channel groups
+    struct Meta2 {
+        ConvW w1f[4], w2f[4], w2b[4];
+        void *h[4] = {}, *a1[4] = {}, *t = nullptr, *dt = nullptr, *da1 = nullptr, *dh = nullptr;
+        float *st1 = nullptr, *st2 = nullptr;          // [pass 2][mean, inv, scale, shift][C]
+        float *rm1 = nullptr, *rv1 = nullptr, *rm2 = nullptr, *rv2 = nullptr; long long *nbt1 = nullptr, *nbt2 = nullptr;
+        float *cs_part = nullptr, *bw = nullptr;       // statistics partials; [gscale, c1, c2, scratch] x 32
+    } m2;
     float* hyper = nullptr;      // device: lr b1 b2 eps wd | w_sd w_sm w_cos
     float* w3_tmp = nullptr;     // device: loss weights of the standalone loss call
     int* step_dev = nullptr;
@@ -285,7 +296,29 @@ void build_workspace(ptta_ctx* c) {
     c->g_feat_f32 = c->falloc((size_t)c->Rg * 32);
     c->dbg["g_feat_f32"] = Dbg{c->g_feat_f32, c->Rg * 32, 0};
     c->wgrad_part = c->falloc((size_t)ptta_wgrad_chunks(c->Rg) * 10 * 1024);
-    c->gW = c->falloc(32 * 32 * 9); c->gB = c->falloc(32);
+    {
+        const char* p2 = "conv1_rgb_meta.conv1_meta.";
+        std::vector<std::pair<std::string, long>> names;
+        if (c->meta_mode == PTTA_META_2LAYERS)
+            names = {{std::string(p2) + "0.0.weight", 128L * 32 * 9}, {std::string(p2) + "0.1.weight", 128}, {std::string(p2) + "0.1.bias", 128},
+                     {std::string(p2) + "1.weight", 32L * 128 * 9}, {std::string(p2) + "1.bias", 32}, {std::string(p2) + "2.weight", 32},
+                     {std::string(p2) + "2.bias", 32}};
+        else names = {{"conv1_rgb_meta.weight", 9216}, {"conv1_rgb_meta.bias", 32}};
+        for (auto& nm : names) { ptta_ctx::Adapted ad; ad.name = nm.first; ad.n = nm.second; ad.g = c->falloc(nm.second); c->adapted.push_back(ad); }
+        if (c->meta_mode == PTTA_META_2LAYERS) {
+            auto& m2 = c->m2;
+            for (int g = 0; g < 4; ++g) {
+                m2.w1f[g] = alloc_convw(c); m2.w2f[g] = alloc_convw(c); m2.w2b[g] = alloc_convw(c);
+                m2.h[g] = c->act(("meta_h" + std::to_string(g)).c_str(), B2, H4, W4);
+                m2.a1[g] = c->act(("meta_a" + std::to_string(g)).c_str(), B2, H4, W4);
+            }
+            m2.t = c->act("meta_t", B2, H4, W4); m2.dt = c->act("meta_dt", Nn, H4, W4);
+            m2.da1 = c->act("meta_da1", Nn, H4, W4); m2.dh = c->act("meta_dh", Nn, H4, W4);
+            m2.st1 = c->falloc(2 * 4 * 128); m2.st2 = c->falloc(2 * 4 * 32);
+            m2.cs_part = c->falloc((size_t)ptta_chan_stats_blocks() * 2 * 32); m2.bw = c->falloc(4 * 32);
+        }
+    }
+    c->gW = c->adapted[0].g; c->gB = c->adapted[1].g;
     c->dbg["gW"] = Dbg{c->gW, 9216, 0}; c->dbg["gB"] = Dbg{c->gB, 32, 0};
     c->in_image = c->falloc((size_t)c->N * 3 * c->H * c->W); c->in_loss_image = c->falloc((size_t)c->N * 3 * c->H * c->W);
     c->in_sparse = c->falloc((size_t)c->N * c->H * c->W); c->in_validity = c->falloc((size_t)c->N * c->H * c->W);
@@ -330,6 +363,97 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     return rc;
 }
 
+int conv32w(ptta_ctx* c, hipStream_t s, const ConvW* w, const float* bias, const void* in, int in_nb, int B, int H, int W, const E& e) {
+    Conv32Args a;
+    a.in = in; a.in_nb = in_nb; a.w = w; a.bias = bias;
+    a.add1 = e.add1; a.add1_nb = e.add1_nb; a.out_raw = e.raw; a.out_sum = e.sum;
+    a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 0; a.bf16 = c->bf16; a.naive = c->naive; a.x3 = c->x3;
+    return ptta_launch_conv32(a, s);
+}
+
+inline float* st_ptr(float* base, int C, int pass, int kind) { return base + ((size_t)pass * 4 + kind) * C; }   // kind: 0 mean 1 inv 2 scale 3 shift
+
+// conv1_rgb_meta forward.  1layer: one conv (:1065-1071).  2layers: Res_Conv(32,128) (:28-36); in training
+// mode each pass (real frames, proxy frames) is a separate forward call in the reference, so BatchNorm
+// statistics are per pass and the running statistics are updated once per pass, real frames first.
+int meta_forward(ptta_ctx* c, bool train, int B, hipStream_t s) {
+    const int H4 = c->H4, W4 = c->W4, Nn = c->Nn;
+    if (c->meta_mode == PTTA_META_1LAYER) {
+        E e; e.raw = c->m;
+        return conv32(c, s, "conv1_rgb_meta", false, CONV_S1, c->c2, B, B, H4, W4, false, e);
+    }
+    auto& m2 = c->m2;
+    const ptta_ctx::Adapted* A = c->adapted.data();          // 0 W1, 1 g1, 2 b1, 3 W2, 4 bias2, 5 g2, 6 b2
+    const long P = (long)Nn * H4 * W4;                         // pixels per pass
+    const int npass = train ? B / Nn : 1;
+    const int nblk = ptta_chan_stats_blocks();
+    for (int g = 0; g < 4; ++g) { E e; e.raw = m2.h[g]; RUN(conv32w(c, s, &m2.w1f[g], nullptr, c->c2, B, B, H4, W4, e)); }
+    if (train) {
+        for (int pass = 0; pass < npass; ++pass)
+            for (int g = 0; g < 4; ++g) {
+                RUN(ptta_launch_chan_stats32(m2.h[g], nullptr, c->bf16, pass * P, P, nullptr, nullptr, nullptr, nullptr, -1.f, m2.cs_part, s));
+                RUN(ptta_launch_bn_finalize(m2.cs_part, nblk, (int)P, 32, A[1].p + 32 * g, A[2].p + 32 * g, 1e-5f, 0.1f,
+                                            m2.rm1 ? m2.rm1 + 32 * g : nullptr, m2.rv1 ? m2.rv1 + 32 * g : nullptr, g == 0 ? m2.nbt1 : nullptr,
+                                            st_ptr(m2.st1, 128, pass, 0) + 32 * g, st_ptr(m2.st1, 128, pass, 1) + 32 * g,
+                                            st_ptr(m2.st1, 128, pass, 2) + 32 * g, st_ptr(m2.st1, 128, pass, 3) + 32 * g, s));
+            }
+    } else {
+        if (!m2.rm1 || !m2.rv1 || !m2.rm2 || !m2.rv2) return c->fail("meta BatchNorm running statistics not loaded", -3);
+        RUN(ptta_launch_bn_eval_affine(A[1].p, A[2].p, m2.rm1, m2.rv1, 1e-5f, st_ptr(m2.st1, 128, 0, 2), st_ptr(m2.st1, 128, 0, 3), 128, s));
+    }
+    for (int g = 0; g < 4; ++g)
+        RUN(ptta_launch_bn_apply32(m2.h[g], nullptr, m2.a1[g], c->bf16, (long)B * H4 * W4, train ? P : (long)B * H4 * W4,
+                                   st_ptr(m2.st1, 128, 0, 2) + 32 * g, st_ptr(m2.st1, 128, 0, 3) + 32 * g, 4 * 128, 0.2f, s));
+    for (int g = 0; g < 4; ++g) {
+        E e;
+        if (g == 0) e.raw = m2.t; else { e.add1 = m2.t; e.add1_nb = B; e.sum = m2.t; }
+        RUN(conv32w(c, s, &m2.w2f[g], g == 0 ? A[4].p : nullptr, m2.a1[g], B, B, H4, W4, e));
+    }
+    if (train) {
+        for (int pass = 0; pass < npass; ++pass) {
+            RUN(ptta_launch_chan_stats32(m2.t, nullptr, c->bf16, pass * P, P, nullptr, nullptr, nullptr, nullptr, -1.f, m2.cs_part, s));
+            RUN(ptta_launch_bn_finalize(m2.cs_part, nblk, (int)P, 32, A[5].p, A[6].p, 1e-5f, 0.1f, m2.rm2, m2.rv2, m2.nbt2,
+                                        st_ptr(m2.st2, 32, pass, 0), st_ptr(m2.st2, 32, pass, 1), st_ptr(m2.st2, 32, pass, 2), st_ptr(m2.st2, 32, pass, 3), s));
+        }
+    } else {
+        RUN(ptta_launch_bn_eval_affine(A[5].p, A[6].p, m2.rm2, m2.rv2, 1e-5f, st_ptr(m2.st2, 32, 0, 2), st_ptr(m2.st2, 32, 0, 3), 32, s));
+    }
+    RUN(ptta_launch_bn_apply32(m2.t, c->c2, c->m, c->bf16, (long)B * H4 * W4, train ? P : (long)B * H4 * W4,
+                               st_ptr(m2.st2, 32, 0, 2), st_ptr(m2.st2, 32, 0, 3), 4 * 32, -1.f, s));
+    return 0;
+}
+
+// gradients of the seven 2layers parameters from d m (= c->dm_total, real frames, pass 0 statistics)
+int meta2_backward(ptta_ctx* c, hipStream_t s) {
+    auto& m2 = c->m2;
+    ptta_ctx::Adapted* A = c->adapted.data();
+    const int H4 = c->H4, W4 = c->W4, Nn = c->Nn;
+    const long P = (long)Nn * H4 * W4;
+    const int nblk = ptta_chan_stats_blocks();
+    float *gsc = m2.bw, *c1 = m2.bw + 32, *c2 = m2.bw + 64, *scr = m2.bw + 96;
+    // BatchNorm2d(32) backward: d gamma2, d beta2, d t
+    RUN(ptta_launch_chan_stats32(m2.t, c->dm_total, c->bf16, 0, P, nullptr, nullptr, st_ptr(m2.st2, 32, 0, 0), st_ptr(m2.st2, 32, 0, 1), -1.f, m2.cs_part, s));
+    RUN(ptta_launch_bn2d_bwd_finalize(m2.cs_part, nblk, P, A[5].p, st_ptr(m2.st2, 32, 0, 1), A[5].g, A[6].g, gsc, c1, c2, s));
+    RUN(ptta_launch_bn_bwd_apply32(m2.t, c->dm_total, m2.dt, c->bf16, P, nullptr, nullptr, st_ptr(m2.st2, 32, 0, 0), st_ptr(m2.st2, 32, 0, 1), gsc, c1, c2, -1.f, s));
+    // conv2 bias gradient = per-channel sum of d t (analytically 0: the bias feeds a BatchNorm)
+    RUN(ptta_launch_chan_stats32(m2.dt, nullptr, c->bf16, 0, P, nullptr, nullptr, nullptr, nullptr, -1.f, m2.cs_part, s));
+    RUN(ptta_launch_bn2d_bwd_finalize(m2.cs_part, nblk, P, A[5].p, st_ptr(m2.st2, 32, 0, 1), nullptr, A[4].g, scr, scr, scr, s));
+    for (int g = 0; g < 4; ++g) {
+        // conv2 weight gradient, input-channel group g
+        RUN(ptta_launch_wgrad32(m2.a1[g], m2.dt, c->bf16, Nn, H4, W4, c->wgrad_part, A[3].g + (size_t)32 * g * 9, nullptr, s, 128 * 9));
+        // d a1_g, then LeakyReLU + BatchNorm2d(128) backward for this group
+        { E e; e.raw = m2.da1; RUN(conv32w(c, s, &m2.w2b[g], nullptr, m2.dt, Nn, Nn, H4, W4, e)); }
+        const float* sc1 = st_ptr(m2.st1, 128, 0, 2) + 32 * g; const float* sh1 = st_ptr(m2.st1, 128, 0, 3) + 32 * g;
+        const float* mu1 = st_ptr(m2.st1, 128, 0, 0) + 32 * g; const float* iv1 = st_ptr(m2.st1, 128, 0, 1) + 32 * g;
+        RUN(ptta_launch_chan_stats32(m2.h[g], m2.da1, c->bf16, 0, P, sc1, sh1, mu1, iv1, 0.2f, m2.cs_part, s));
+        RUN(ptta_launch_bn2d_bwd_finalize(m2.cs_part, nblk, P, A[1].p + 32 * g, iv1, A[1].g + 32 * g, A[2].g + 32 * g, gsc, c1, c2, s));
+        RUN(ptta_launch_bn_bwd_apply32(m2.h[g], m2.da1, m2.dh, c->bf16, P, sc1, sh1, mu1, iv1, gsc, c1, c2, 0.2f, s));
+        // conv1 weight gradient, output-channel group g
+        RUN(ptta_launch_wgrad32(c->c2, m2.dh, c->bf16, Nn, H4, W4, c->wgrad_part, A[0].g + (size_t)g * 9216, nullptr, s, 32 * 9));
+    }
+    return 0;
+}
+
 // One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half.
 int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     const int Nn = c->Nn, B2 = train ? 2 * Nn : Nn;
@@ -354,7 +478,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     CV("rgb_encoder.enc3.3", false, CONV_S1, c->c3a, B2, B2, H8, W8, true, e_raw(c->c3));
     CV("rgb_encoder.enc4.1", false, CONV_S2, c->c3, B2, B2, H8, W8, true, e_raw(c->c4a));
     CV("rgb_encoder.enc4.3", false, CONV_S1, c->c4a, B2, B2, H16, W16, true, e_raw(c->c4));
-    CV("conv1_rgb_meta", false, CONV_S1, c->c2, B2, B2, H4, W4, false, e_raw(c->m));
+    RUN(meta_forward(c, train, B2, s));
 
     // ---- stage 1/4 (:487-489): depth-only encoder shared by both passes ----
     {
@@ -557,6 +681,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s) {
       CV("depth_decoder1.prdct.1", true, CONV_S1, c->dv1, Nn, Nn, H4, W4, false, e); }
 #undef CV
     // ---- weight gradient of the meta layer: input = c2 of the real frames ----
+    if (c->meta_mode == PTTA_META_2LAYERS) return meta2_backward(c, s);
     RUN(ptta_launch_wgrad32(c->c2, c->dm_total, c->bf16, Nn, H4, W4, c->wgrad_part, c->gW, c->gB, s));
     return 0;
 }
@@ -570,7 +695,7 @@ int push_hparams(ptta_ctx* c, hipStream_t s) {
 }
 
 int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool train, hipStream_t s) {
-    if (!c->meta_w || !c->meta_b) return c->fail("adapted parameters not bound (ptta_bind_adapted)", -3);
+    for (auto& ad : c->adapted) if (!ad.p) return c->fail("adapted parameter " + ad.name + " not bound (ptta_bind_adapted)", -3);
     const float* img = image; const float* sp = sparse;
     if (c->dual) {
         hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * 3 * c->Hp * c->Wp)), dim3(256), 0, s, image, c->img_pad, c->N, 3, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
@@ -578,8 +703,16 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
         img = c->img_pad; sp = c->sp_pad;
     }
     RUN(ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
-    const L32& ml = c->l32["conv1_rgb_meta"];
-    ptta_pack_conv32(c->meta_w, ml.f, 0, 0, s);
+    if (c->meta_mode == PTTA_META_2LAYERS) {
+        for (int g = 0; g < 4; ++g) {
+            ptta_pack_conv32(c->adapted[0].p + (size_t)g * 9216, c->m2.w1f[g], 0, 0, s);            // W1 rows 32g..32g+31
+            ptta_pack_conv32(c->adapted[3].p, c->m2.w2f[g], 0, 0, s, 128, 32 * g);                 // W2 columns 32g..
+            ptta_pack_conv32(c->adapted[3].p, c->m2.w2b[g], 1, 1, s, 128, 32 * g);                 // its input gradient
+        }
+    } else {
+        const L32& ml = c->l32["conv1_rgb_meta"];
+        ptta_pack_conv32(c->meta_w, ml.f, 0, 0, s);
+    }
     RUN(backbone(c, img, train, s));
     if (c->dual)
         hipLaunchKernelGGL(crop_avg_kernel, dim3(nblk((long)c->N * c->H * c->W)), dim3(256), 0, s, c->depth_net, c->depth_final, c->N, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
@@ -601,9 +734,10 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -19;          // no HIP device: fail loudly
-    if (backbone_id != PTTA_BACKBONE_MSG_CHN || meta_mode != PTTA_META_1LAYER) return -38;
+    if (backbone_id != PTTA_BACKBONE_MSG_CHN || (meta_mode != PTTA_META_1LAYER && meta_mode != PTTA_META_2LAYERS)) return -38;
     if (n < 1 || height < 16 || width < 16 || (dtype != PTTA_DTYPE_F32 && dtype != PTTA_DTYPE_BF16) || !hp) return -22;
     ptta_ctx* c = new ptta_ctx();
+    c->meta_mode = meta_mode;
     c->N = n; c->H = height; c->W = width; c->pt = pad16(height); c->pr = pad16(width);
     c->Hp = height + c->pt; c->Wp = width + c->pr; c->dual = (c->pt || c->pr) ? 1 : 0; c->Nn = c->dual ? 2 * n : n;
     c->bf16 = dtype == PTTA_DTYPE_BF16; c->es = c->bf16 ? 2 : 4;
@@ -649,7 +783,16 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
     const long numel = shape_numel(shape, ndim);
     auto ends = [&](const char* suf) { const size_t n = strlen(suf); return name.size() >= n && name.compare(name.size() - n, n, suf) == 0; };
     if (name.rfind("proj_t.", 0) == 0) return 0;                     // EMA target head: unused in stage 3 (:551-554)
-    if (name.rfind("conv1_rgb_meta", 0) == 0) return c->fail("adapted parameter " + name + " must be bound with ptta_bind_adapted", -4);
+    if (name.rfind("conv1_rgb_meta", 0) == 0) {
+        auto ends2 = [&](const char* suf) { const size_t n = strlen(suf); return name.size() >= n && name.compare(name.size() - n, n, suf) == 0; };
+        if (c->meta_mode == PTTA_META_2LAYERS) {           // BatchNorm2d buffers of Res_Conv: bound, updated in place
+            const bool first = name.find("conv1_meta.0.1.") != std::string::npos, second = name.find("conv1_meta.2.") != std::string::npos;
+            if ((first || second) && ends2(".running_mean")) { (first ? c->m2.rm1 : c->m2.rm2) = (float*)tensor; return 0; }
+            if ((first || second) && ends2(".running_var")) { (first ? c->m2.rv1 : c->m2.rv2) = (float*)tensor; return 0; }
+            if ((first || second) && ends2(".num_batches_tracked")) { (first ? c->m2.nbt1 : c->m2.nbt2) = (long long*)tensor; return 0; }
+        }
+        return c->fail("adapted parameter " + name + " must be bound with ptta_bind_adapted", -4);
+    }
     const std::string base = name.substr(0, name.rfind('.'));
     const bool is_w = ends(".weight"), is_b = ends(".bias");
     const float* src = (const float*)tensor;
@@ -722,9 +865,30 @@ int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp
     if (!c || !name_ || !param) return -1;
     c->drop_graphs();
     const std::string name(name_);
-    if (name == "conv1_rgb_meta.weight") { c->meta_w = param; c->meta_w_m = exp_avg; c->meta_w_v = exp_avg_sq; return 0; }
-    if (name == "conv1_rgb_meta.bias") { c->meta_b = param; c->meta_b_m = exp_avg; c->meta_b_v = exp_avg_sq; return 0; }
+    for (size_t k = 0; k < c->adapted.size(); ++k)
+        if (c->adapted[k].name == name) {
+            c->adapted[k].p = param; c->adapted[k].m = exp_avg; c->adapted[k].v = exp_avg_sq;
+            if (c->meta_mode == PTTA_META_1LAYER) { if (k == 0) c->meta_w = param; else c->meta_b = param; }
+            return 0;
+        }
     return c->fail("not an adapted parameter: " + name, -2);
+}
+
+int ptta_adapted_count(ptta_handle c) { return c ? (int)c->adapted.size() : 0; }
+const char* ptta_adapted_name(ptta_handle c, int index, int64_t* numel) {
+    if (!c || index < 0 || index >= (int)c->adapted.size()) return nullptr;
+    if (numel) *numel = c->adapted[index].n;
+    return c->adapted[index].name.c_str();
+}
+int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity, ptta_stream s) {
+    if (!c || !name || !dst) return -1;
+    for (auto& ad : c->adapted)
+        if (ad.name == name) {
+            if (capacity < ad.n) return c->fail("capacity too small", -22);
+            HIPCHK(hipMemcpyAsync(dst, ad.g, (size_t)ad.n * 4, hipMemcpyDeviceToDevice, (hipStream_t)s));
+            return 0;
+        }
+    return c->fail(std::string("not an adapted parameter: ") + name, -2);
 }
 
 int ptta_set_adam_step(ptta_handle c, int step, ptta_stream s) {
@@ -800,18 +964,25 @@ int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref,
     if (grad_ref) { RUN(heads_backward(c, grad_ref, s)); }
     else HIPCHK(hipMemsetAsync(c->g_feat, 0, (size_t)c->Rg * 32 * c->es, s));
     RUN(backbone_backward(c, g_net, s));
-    if (gw_out) HIPCHK(hipMemcpyAsync(gw_out, c->gW, 9216 * 4, hipMemcpyDeviceToDevice, s));
-    if (gb_out) HIPCHK(hipMemcpyAsync(gb_out, c->gB, 32 * 4, hipMemcpyDeviceToDevice, s));
+    if (c->meta_mode == PTTA_META_1LAYER) {
+        if (gw_out) HIPCHK(hipMemcpyAsync(gw_out, c->gW, 9216 * 4, hipMemcpyDeviceToDevice, s));
+        if (gb_out) HIPCHK(hipMemcpyAsync(gb_out, c->gB, 32 * 4, hipMemcpyDeviceToDevice, s));
+    }
     return 0;
 }
 
 int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream s_) {
     if (!c) return -1;
-    if (!c->meta_w_m || !c->meta_w_v || !c->meta_b_m || !c->meta_b_v) return c->fail("Adam moments not bound", -3);
+    for (auto& ad : c->adapted) if (!ad.p || !ad.m || !ad.v) return c->fail("Adam state of " + ad.name + " not bound", -3);
+    if ((gw || gb) && c->meta_mode != PTTA_META_1LAYER) return c->fail("explicit gradients are a 1layer convenience; use the internal ones", -22);
     hipStream_t s = (hipStream_t)s_;
     RUN(ptta_launch_step_inc(c->step_dev, s));
-    RUN(ptta_launch_adam(c->meta_w, c->meta_w_m, c->meta_w_v, gw ? gw : c->gW, 9216, c->hyper, c->step_dev, s));
-    RUN(ptta_launch_adam(c->meta_b, c->meta_b_m, c->meta_b_v, gb ? gb : c->gB, 32, c->hyper, c->step_dev, s));
+    for (size_t k = 0; k < c->adapted.size(); ++k) {
+        auto& ad = c->adapted[k];
+        const float* g = ad.g;
+        if (c->meta_mode == PTTA_META_1LAYER) { if (k == 0 && gw) g = gw; if (k == 1 && gb) g = gb; }
+        RUN(ptta_launch_adam(ad.p, ad.m, ad.v, g, ad.n, c->hyper, c->step_dev, s));
+    }
     return 0;
 }
 

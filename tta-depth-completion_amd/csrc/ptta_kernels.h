@@ -24,7 +24,7 @@ struct Conv32Args {
     int mode = CONV_S1; int relu_in = 0; int bf16 = 0; int naive = 0;
     int x3 = 0;          // fp32 storage: bf16x3 arithmetic on the bf16 matrix cores (stride-1 only)
 };
-void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, hipStream_t s);
+void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, hipStream_t s, int row_stride = 32, int col_off = 0);
 int ptta_launch_conv32(const Conv32Args& a, hipStream_t s);
 
 // ---- conv_small.hip ---------------------------------------------------------------------------
@@ -105,7 +105,21 @@ int ptta_launch_loss_backward(const float* depth, const float* image, const floa
 // ---- wgrad_adam.hip ---------------------------------------------------------------------------
 int ptta_wgrad_chunks(long pixels);
 int ptta_launch_wgrad32(const void* x, const void* gy, int bf16, int B, int H, int W, float* part,
-                        float* gw, float* gb, hipStream_t s);
+                        float* gw, float* gb, hipStream_t s, int co_stride = 288);
+
+// ---- meta2.hip (2layers meta layer: BatchNorm2d / LeakyReLU pieces) ----------------------------
+int ptta_chan_stats_blocks();
+int ptta_launch_chan_stats32(const void* x, const void* g, int bf16, long pix0, long npix, const float* fscale,
+                             const float* fshift, const float* mean, const float* inv, float slope, float* part, hipStream_t s);
+int ptta_launch_bn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift, int C, hipStream_t s);
+int ptta_launch_bn_apply32(const void* x, const void* res, void* y, int bf16, long npix, long pix_per_pass, const float* scale,
+                           const float* shift, int stat_stride, float slope, hipStream_t s);
+int ptta_launch_bn_bwd_apply32(const void* x, const void* g, void* dx, int bf16, long npix, const float* fscale, const float* fshift,
+                               const float* mean, const float* inv, const float* gscale, const float* c1, const float* c2,
+                               float slope, hipStream_t s);
+int ptta_launch_bn2d_bwd_finalize(const float* part, int nblocks, long R, const float* gamma, const float* inv, float* dgamma,
+                                  float* dbeta, float* gscale, float* c1, float* c2, hipStream_t s);
 int ptta_launch_adam(float* p, float* m, float* v, const float* g, long n, const float* hyper /*lr,b1,b2,eps,wd*/,
                      const int* step_dev, hipStream_t s);
 int ptta_launch_step_inc(int* step_dev, hipStream_t s);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void wgrad32_kernel(const T* __restrict__ x, co
 }
 
 // 64 outputs per block, 8 chunk groups summed in parallel then combined through LDS (fixed order)
-__global__ __launch_bounds__(512) void wgrad32_reduce_kernel(const float* __restrict__ part, int nchunks, float* __restrict__ gw, float* __restrict__ gb) {
+__global__ __launch_bounds__(512) void wgrad32_reduce_kernel(const float* __restrict__ part, int nchunks, float* __restrict__ gw, float* __restrict__ gb, int co_stride) {
     __shared__ float red[8][64];
     const int ol = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + ol;
@@ -83,18 +83,18 @@ __global__ __launch_bounds__(512) void wgrad32_reduce_kernel(const float* __rest
     s = ((red[0][ol] + red[1][ol]) + (red[2][ol] + red[3][ol])) + ((red[4][ol] + red[5][ol]) + (red[6][ol] + red[7][ol]));
     if (o < 9 * 1024) {
         const int ci = o & 31, co = (o >> 5) & 31, tap = o >> 10;
-        gw[(co * 32 + ci) * 9 + tap] = s;
-    } else {
+        gw[(size_t)co * co_stride + ci * 9 + tap] = s;        // co_stride = 9 * (input channels of the full weight)
+    } else if (gb) {
         gb[o - 9 * 1024] = s;
     }
 }
 
 int ptta_launch_wgrad32(const void* x, const void* gy, int bf16, int B, int H, int W, float* part,
-                        float* gw, float* gb, hipStream_t s) {
+                        float* gw, float* gb, hipStream_t s, int co_stride) {
     const int nchunks = ptta_wgrad_chunks((long)B * H * W);
     if (bf16) hipLaunchKernelGGL((wgrad32_kernel<bf16_t>), dim3(nchunks), dim3(64), 0, s, (const bf16_t*)x, (const bf16_t*)gy, B, H, W, nchunks, part);
     else hipLaunchKernelGGL((wgrad32_kernel<float>), dim3(nchunks), dim3(64), 0, s, (const float*)x, (const float*)gy, B, H, W, nchunks, part);
-    hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((9 * 1024 + 32 + 63) / 64), dim3(512), 0, s, part, nchunks, gw, gb);
+    hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((9 * 1024 + 32 + 63) / 64), dim3(512), 0, s, part, nchunks, gw, gb, co_stride);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

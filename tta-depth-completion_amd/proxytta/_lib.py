@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libptta_hip.so')
 
 PTTA_BACKBONE_MSG_CHN = 0
 PTTA_META_1LAYER = 0
+PTTA_META_2LAYERS = 1
 PTTA_DTYPE_F32 = 0
 PTTA_DTYPE_BF16 = 1
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
@@ -40,6 +41,9 @@ SIGNATURES = [
     ('ptta_loss_forward', c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, _P, _P]),
     ('ptta_loss_backward', c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     ('ptta_backward', c_int, [_P, _P, _P, _P, _P, _P]),
+    ('ptta_get_grad', c_int, [_P, c_char_p, _P, c_int64, _P]),
+    ('ptta_adapted_count', c_int, [_P]),
+    ('ptta_adapted_name', c_char_p, [_P, c_int, POINTER(c_int64)]),
     ('ptta_adam_step', c_int, [_P, _P, _P, _P]),
     ('ptta_step', c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     ('ptta_set_graph', c_int, [_P, c_int]),

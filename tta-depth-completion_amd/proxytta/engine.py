@@ -8,7 +8,14 @@ import torch
 from . import _lib
 from ._lib import Hparams, check, ptr
 
-ADAPTED = ('conv1_rgb_meta.weight', 'conv1_rgb_meta.bias')
+ADAPTED = ('conv1_rgb_meta.weight', 'conv1_rgb_meta.bias')          # 1layer meta layer
+_P2 = 'conv1_rgb_meta.conv1_meta.'
+ADAPTED_2LAYERS = (_P2 + '0.0.weight', _P2 + '0.1.weight', _P2 + '0.1.bias', _P2 + '1.weight', _P2 + '1.bias',
+                   _P2 + '2.weight', _P2 + '2.bias')
+
+
+def adapted_names(meta='1layer'):
+    return ADAPTED_2LAYERS if meta == '2layers' else ADAPTED
 _BOUND_SUFFIX = ('running_mean', 'running_var', 'num_batches_tracked')
 
 
@@ -21,18 +28,21 @@ class Engine:
 
     def __init__(self, n, height, width, dtype='fp32', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0,
-                 max_input_depth=None):
+                 max_input_depth=None, meta='1layer'):
         if not torch.cuda.is_available():
             raise RuntimeError('proxytta needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
         self.lib = _lib.load()
         self.n, self.h, self.w = int(n), int(height), int(width)
         self.dtype = dtype
+        self.meta = meta
+        self.adapted = adapted_names(meta)
         self.hp = Hparams(lr, betas[0], betas[1], eps, weight_decay, w_sparse_depth, w_smoothness,
                           w_cos, -1.0 if max_input_depth is None else float(max_input_depth))
         self.handle = c_void_p()
         code = {'fp32': _lib.PTTA_DTYPE_F32, 'bf16': _lib.PTTA_DTYPE_BF16}[dtype]
-        rc = self.lib.ptta_create(byref(self.handle), _lib.PTTA_BACKBONE_MSG_CHN, _lib.PTTA_META_1LAYER,
+        rc = self.lib.ptta_create(byref(self.handle), _lib.PTTA_BACKBONE_MSG_CHN,
+                                  _lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER,
                                   self.n, self.h, self.w, code, byref(self.hp))
         if rc != 0:
             raise RuntimeError('ptta_create failed (%d)' % rc)
@@ -60,7 +70,7 @@ class Engine:
         """state: {reference state_dict key: cuda tensor}.  Adapted parameters are skipped (bind
         them with bind_adapted); BatchNorm buffers are bound by pointer and updated in place."""
         for k, t in state.items():
-            if k in ADAPTED:
+            if k in self.adapted:
                 continue
             assert t.is_cuda and t.is_contiguous(), k
             if k.endswith(_BOUND_SUFFIX):
@@ -141,6 +151,19 @@ class Engine:
                                               ptr(None if ref is None else ref.contiguous()), rows,
                                               ptr(gd), ptr(gr), _stream()), 'ptta_loss_backward')
         return gd, gr
+
+    def grad(self, name, like):
+        """Gradient of an adapted parameter after backward()/step(), shaped like `like`."""
+        out = torch.empty_like(like)
+        self._chk(self.lib.ptta_get_grad(self.handle, name.encode(), ptr(out), out.numel(), _stream()), 'ptta_get_grad')
+        return out
+
+    def backward_all(self, grad_depth, grad_ref, params):
+        """loss.backward() for any meta layer: returns the gradients of `params` ({name: tensor})."""
+        self._chk(self.lib.ptta_backward(self.handle, ptr(grad_depth.contiguous()),
+                                         ptr(None if grad_ref is None else grad_ref.contiguous()), None, None, _stream()),
+                  'ptta_backward')
+        return [self.grad(k, params[k]) for k in self.adapted]
 
     def backward(self, grad_depth, grad_ref):
         gw = torch.empty((32, 32, 3, 3), device=grad_depth.device, dtype=torch.float32)

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import synth
-from .engine import ADAPTED, Engine
+from .engine import ADAPTED, Engine, adapted_names
 
 CANONICAL_LOSS_TYPE = 'adapt_meta_selfsup_seq_ema_reverse'
 
@@ -71,10 +71,11 @@ class _ForwardFn(torch.autograd.Function):
     """(depth, emb, ref) = network(image, sparse); backward -> grads of the adapted parameters."""
 
     @staticmethod
-    def forward(ctx, adapter, image, sparse, weight, bias):
+    def forward(ctx, adapter, image, sparse, *adapted):
         eng = adapter._engine(image)
         depth, emb, ref = eng.forward_train(image, sparse)
         ctx.eng = eng
+        ctx.params = dict(zip(eng.adapted, adapted))
         ctx.mark_non_differentiable(emb)
         return depth, emb, ref
 
@@ -82,8 +83,8 @@ class _ForwardFn(torch.autograd.Function):
     def backward(ctx, g_depth, g_emb, g_ref):
         if g_depth is None:
             g_depth = torch.zeros((ctx.eng.n, 1, ctx.eng.h, ctx.eng.w), device=ctx.eng.device)
-        gw, gb = ctx.eng.backward(g_depth, g_ref)
-        return None, None, None, gw, gb
+        grads = ctx.eng.backward_all(g_depth, g_ref, ctx.params)
+        return (None, None, None) + tuple(grads)
 
 
 class _LossFn(torch.autograd.Function):
@@ -132,9 +133,11 @@ class MsgChnModel_Adapt(object):
         """network_adapt._prepare_head (network_exp_msg_chn_adapt.py:1022-1087)."""
         if 'meta' not in mode or 'selfsup' not in mode or 'ema' not in mode or 'seq' not in mode:
             raise NotImplementedError('hot path covers prepare_mode meta_selfsup_seq_{1layer}_ema, got %r' % mode)
-        if '1layer' not in mode:
-            raise NotImplementedError('only the 1layer meta layer is built in this round (got %r)' % mode)
+        if '1layer' not in mode and '2layers' not in mode:
+            raise NotImplementedError('meta layer of %r is not on the accelerated path (1layer / 2layers are)' % mode)
         self.prepare_mode = mode
+        self.meta = '2layers' if '2layers' in mode else '1layer'
+        self.adapted = adapted_names(self.meta)
         for k, s in synth.msg_chn_keys(mode):
             if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
                 self.model._leaf(k, _init_tensor(k, s).to(self.device),
@@ -207,10 +210,10 @@ class MsgChnModel_Adapt(object):
         if eng is None:
             if self.prepare_mode is None:
                 raise RuntimeError('_prepare_head(mode) must be called before forward (tta_main.py:322)')
-            eng = Engine(n, h, w, dtype=self.dtype, max_input_depth=self.max_input_depth, **self.hparams)
+            eng = Engine(n, h, w, dtype=self.dtype, max_input_depth=self.max_input_depth, meta=self.meta, **self.hparams)
             eng.load_state_dict(self.model.state_dict())
             params = dict(self.model.named_parameters())
-            for name in ADAPTED:
+            for name in self.adapted:
                 p = params[name]
                 st = self._opt_state.setdefault(name, {'exp_avg': torch.zeros_like(p.data), 'exp_avg_sq': torch.zeros_like(p.data)})
                 eng.bind_adapted(name, p.data, st['exp_avg'], st['exp_avg_sq'])
@@ -231,7 +234,7 @@ class MsgChnModel_Adapt(object):
         params = dict(self.model.named_parameters())
         g = optimizer.param_groups[0]
         self.set_hparams(lr=g['lr'], betas=tuple(g['betas']), eps=g['eps'], weight_decay=g['weight_decay'])
-        for name in ADAPTED:
+        for name in self.adapted:
             p = params[name]
             st = optimizer.state[p]
             if 'exp_avg' not in st:
@@ -248,7 +251,7 @@ class MsgChnModel_Adapt(object):
             raise NotImplementedError('loss_type %r is not on the accelerated path' % loss_type)
         if self.training and 'adapt' in loss_type:
             params = dict(self.model.named_parameters())
-            return _ForwardFn.apply(self, image, sparse_depth, params[ADAPTED[0]], params[ADAPTED[1]])
+            return _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted])
         with torch.no_grad():
             return self._engine(image).forward_eval(image, sparse_depth)
 

@@ -109,6 +109,12 @@ int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* gr
 int ptta_step(ptta_handle h, const float* image, const float* loss_image, const float* sparse_depth,
               const float* validity, float* depth_out, float* loss_info_out, ptta_stream s);
 
+/* OutlierRemoval(kernel_size, threshold).remove_outliers(sparse_depth, validity_map) (src/net_utils.py:750-811),
+ * the on-device filter src/tta_main.py:590 applies before every forward.  Handle-free; scratch = 4 KiB of
+ * device memory (1024 floats).  Outputs may not alias the inputs. */
+int ptta_outlier_removal(const float* sparse_depth, const float* validity, float* sparse_out, float* validity_out,
+                         int n, int height, int width, int kernel_size, float threshold, float* scratch, ptta_stream s);
+
 /* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
  * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
 int ptta_set_graph(ptta_handle h, int enable);

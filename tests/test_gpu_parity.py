@@ -298,3 +298,24 @@ def test_2layers_meta_layer_matches_reference_golden(golden_dir, impl):
         d_eval = eng.forward_eval(image, sparse)
         assert rel_mae(d_eval, g[p + 'depth_eval']) < 3e-4
     eng.close()
+
+
+def test_outlier_removal_matches_reference_golden(golden_dir):
+    """OutlierRemoval(7, 1.5) fused HIP stencil vs the reference's output (bit-exact: selection only)."""
+    from proxytta.model import OutlierRemoval
+    g = np.load(os.path.join(golden_dir, 'outlier_removal.npz'))
+    _, sparse = synth.synthetic_frame(7, 40, 56, 2, density=0.2, dmin=1.0, dmax=20.0)
+    sparse = torch.from_numpy(sparse).cuda()
+    validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+    sd, vm = OutlierRemoval(7, 1.5).remove_outliers(sparse, validity)
+    np.testing.assert_array_equal(sd.cpu().numpy(), g['sparse_out'])
+    np.testing.assert_array_equal(vm.cpu().numpy(), g['validity_out'])
+    # full size (352x1216) against the oracle, bit-exact
+    from oracle import proxytta_oracle as O
+    _, big = synth.synthetic_frame(3, 352, 1216, 1, density=0.05, dmin=1.0, dmax=80.0)
+    big = torch.from_numpy(big).cuda()
+    vbig = (big > 0).float()
+    sd2, vm2 = OutlierRemoval(7, 1.5).remove_outliers(big, vbig)
+    rs, rv = O.remove_outliers(big.cpu(), vbig.cpu(), 7, 1.5)
+    assert torch.equal(sd2.cpu(), rs) and torch.equal(vm2.cpu(), rv)
+    assert 0 < float(vm2.sum()) < float(vbig.sum())          # some points were removed, not all

@@ -1046,6 +1046,14 @@ int ptta_set_graph(ptta_handle c, int enable) {
     return 0;
 }
 
+int ptta_outlier_removal(const float* sparse, const float* validity, float* sparse_out, float* validity_out, int n, int height,
+                         int width, int kernel_size, float threshold, float* scratch, ptta_stream s) {
+    if (!sparse || !validity || !sparse_out || !validity_out || !scratch || n < 1 || height < 1 || width < 1 || kernel_size < 1 ||
+        (kernel_size & 1) == 0) return -22;
+    return ptta_launch_outlier_removal(sparse, validity, sparse_out, validity_out, n, height, width, kernel_size, threshold, scratch,
+                                       (hipStream_t)s);
+}
+
 int ptta_profile(ptta_handle c, int enable) {
     if (!c) return -1;
     c->prof_on = enable != 0;

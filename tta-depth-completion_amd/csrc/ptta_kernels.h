@@ -62,6 +62,9 @@ int ptta_launch_up2_1ch(const float* in, float* out, int B, int Hin, int Win, hi
 int ptta_launch_up2T_1ch(const float* gout, float* gin, int B, int Hin, int Win, hipStream_t s);
 int ptta_launch_up2T_32(const void* gout, const void* add, void* gin, int B, int Hin, int Win, int bf16, hipStream_t s);
 
+int ptta_launch_outlier_removal(const float* sparse, const float* validity, float* sparse_out, float* validity_out,
+                                int N, int H, int W, int ksize, float threshold, float* scratch, hipStream_t s);
+
 // ---- heads.hip --------------------------------------------------------------------------------
 struct GemmArgs {
     const void* A = nullptr; int a_bf16 = 0;   // [R][K] (fp32, or bf16 NHWC features when a_bf16)

@@ -181,3 +181,77 @@ int ptta_launch_up2T_32(const void* gout, const void* add, void* gin, int B, int
     PTTA_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- OutlierRemoval.remove_outliers (src/net_utils.py:766-811), the sparse-depth filter that runs
+// on-device before every forward (src/tta_main.py:590,:703) ---------------------------------------
+//   max_value = 10 * max(sparse);  filled = validity <= 0 ? max_value : sparse  (padded with max_value)
+//   min_k x k(filled) < sparse - threshold  =>  point removed
+// One fused stencil replaces the reference's 6 ATen kernels (where, pad, neg, max_pool2d, where, 2 muls);
+// the global max is a two-stage reduction (block partials, then every block re-reduces the <=1024
+// partials, which is cheaper than a third launch).
+__global__ __launch_bounds__(256) void outlier_max_kernel(const float* __restrict__ sparse, long n, float* __restrict__ part) {
+    __shared__ float red[4];
+    float m = -INFINITY;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, sparse[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void outlier_removal_kernel(const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                              const float* __restrict__ part, int nparts, float* __restrict__ sparse_out,
+                                                              float* __restrict__ validity_out, int N, int H, int W, int ksize, float threshold) {
+    __shared__ float smax;
+    {
+        float m = -INFINITY;
+        for (int k = threadIdx.x; k < nparts; k += blockDim.x) m = fmaxf(m, part[k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) smax = 10.0f * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+    }
+    const float max_value = smax;
+    const int pad = ksize / 2;
+    const long total = (long)N * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const long t_ = idx / W;
+        const int y = (int)(t_ % H);
+        const long base = (t_ / H) * (long)H * W;
+        float mn = INFINITY;
+        for (int dy = -pad; dy <= pad; ++dy) {
+            const int yy = y + dy;
+            for (int dx = -pad; dx <= pad; ++dx) {
+                const int xx = x + dx;
+                float f = max_value;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const long q = base + (long)yy * W + xx;
+                    f = validity[q] <= 0.f ? max_value : sparse[q];
+                }
+                mn = fminf(mn, f);
+            }
+        }
+        const float sd = sparse[idx], v = validity[idx];
+        const float clean = (mn < sd - threshold) ? 0.f : 1.f;
+        const float vo = v * clean;
+        validity_out[idx] = vo;
+        sparse_out[idx] = sd * vo;
+    }
+}
+
+int ptta_launch_outlier_removal(const float* sparse, const float* validity, float* sparse_out, float* validity_out,
+                                int N, int H, int W, int ksize, float threshold, float* scratch, hipStream_t s) {
+    const long total = (long)N * H * W;
+    int nparts = (int)((total + 255) / 256); if (nparts > 1024) nparts = 1024;
+    hipLaunchKernelGGL(outlier_max_kernel, dim3(nparts), dim3(256), 0, s, sparse, total, scratch);
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(outlier_removal_kernel, dim3(blocks), dim3(256), 0, s, sparse, validity, scratch, nparts, sparse_out,
+                       validity_out, N, H, W, ksize, threshold);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

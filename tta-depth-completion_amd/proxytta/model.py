@@ -356,3 +356,29 @@ class ExternalModel_Adapt(object):
 
 
 ExternalModelAdapt = ExternalModel_Adapt
+
+
+class OutlierRemoval(object):
+    """Counterpart of src/net_utils.py:750-811 on libptta_hip (one fused stencil instead of 6 ATen kernels)."""
+
+    def __init__(self, kernel_size=7, threshold=1.5):
+        self.kernel_size = kernel_size
+        self.threshold = threshold
+        self._scratch = None
+
+    def remove_outliers(self, sparse_depth, validity_map):
+        from . import _lib
+        from .engine import _stream
+        from ._lib import ptr
+        lib = _lib.load()
+        assert sparse_depth.is_cuda and sparse_depth.dtype == torch.float32 and sparse_depth.shape == validity_map.shape
+        n, _, h, w = sparse_depth.shape
+        if self._scratch is None or self._scratch.device != sparse_depth.device:
+            self._scratch = torch.empty(1024, device=sparse_depth.device, dtype=torch.float32)
+        sd, vm = sparse_depth.contiguous(), validity_map.contiguous()
+        sd_out, vm_out = torch.empty_like(sd), torch.empty_like(vm)
+        rc = lib.ptta_outlier_removal(ptr(sd), ptr(vm), ptr(sd_out), ptr(vm_out), n, h, w, int(self.kernel_size),
+                                      float(self.threshold), ptr(self._scratch), _stream())
+        if rc != 0:
+            raise RuntimeError('ptta_outlier_removal failed (%d)' % rc)
+        return sd_out, vm_out

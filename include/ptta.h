@@ -115,6 +115,12 @@ int ptta_step(ptta_handle h, const float* image, const float* loss_image, const 
 int ptta_outlier_removal(const float* sparse_depth, const float* validity, float* sparse_out, float* validity_out,
                          int n, int height, int width, int kernel_size, float threshold, float* scratch, ptta_stream s);
 
+/* Validation metrics of src/tta_main.py:779-798 (eval_utils.py:117-174) reduced on device:
+ * metrics_out[4] (device) = {MAE mm, RMSE mm, iMAE 1/km, iRMSE 1/km} over pixels with ground_truth > 0 and
+ * min <= ground_truth <= max.  scratch: 16 KiB of device memory.  Handle-free. */
+int ptta_eval_metrics(const float* depth, const float* ground_truth, int64_t numel, float min_evaluate_depth,
+                      float max_evaluate_depth, void* scratch, float* metrics_out, ptta_stream s);
+
 /* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
  * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
 int ptta_set_graph(ptta_handle h, int enable);

@@ -295,3 +295,19 @@ class MsgChnOracle:
         return {'depth': depth.detach(), 'emb': emb.detach(), 'ref': ref.detach(),
                 'loss_info': {k: float(v.detach()) for k, v in info.items()},
                 'grads': {k: g for k, g in zip(self.names, grads)}}
+
+
+def eval_metrics(output_depth, ground_truth, min_evaluate_depth, max_evaluate_depth):
+    """src/tta_main.py:779-798 with src/eval_utils.py:117-174 (eps = 1e-9, eval_utils.py:24):
+    MAE / RMSE on 1000x (mm), iMAE / iRMSE on 0.001x (1/km), over the validity mask."""
+    eps = 1e-9
+    mask = torch.where(ground_truth > 0, torch.ones_like(ground_truth), torch.zeros_like(ground_truth))
+    mask[ground_truth < min_evaluate_depth] = 0.0
+    mask[ground_truth > max_evaluate_depth] = 0.0
+    idx = mask.nonzero(as_tuple=True)
+    o, g = output_depth[idx], ground_truth[idx]
+    mae = torch.mean(torch.abs(1000.0 * g - 1000.0 * o))
+    rmse = torch.sqrt(torch.mean((1000.0 * g - 1000.0 * o) ** 2))
+    imae = torch.mean(torch.abs(1.0 / (0.001 * g + eps) - 1.0 / (0.001 * o + eps)))
+    irmse = torch.sqrt(torch.mean((1.0 / (0.001 * g + eps) - 1.0 / (0.001 * o + eps)) ** 2))
+    return torch.stack([mae, rmse, imae, irmse])

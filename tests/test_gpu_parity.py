@@ -319,3 +319,15 @@ def test_outlier_removal_matches_reference_golden(golden_dir):
     rs, rv = O.remove_outliers(big.cpu(), vbig.cpu(), 7, 1.5)
     assert torch.equal(sd2.cpu(), rs) and torch.equal(vm2.cpu(), rv)
     assert 0 < float(vm2.sum()) < float(vbig.sum())          # some points were removed, not all
+
+
+def test_eval_metrics_on_device():
+    from oracle import proxytta_oracle as O
+    from proxytta.model import eval_metrics
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(2, 1, 352, 1216, generator=g) * 90.0
+    gt[torch.rand(gt.shape, generator=g) < 0.7] = 0.0            # semi-dense ground truth
+    out = (gt + torch.randn(gt.shape, generator=g)).clamp(min=0.1) + (gt == 0) * 5.0
+    ref = O.eval_metrics(out, gt, 0.5, 80.0)
+    got = eval_metrics(out.cuda(), gt.cuda(), 0.5, 80.0).cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5)

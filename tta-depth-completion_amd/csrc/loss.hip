@@ -202,3 +202,48 @@ int ptta_launch_loss_backward(const float* depth, const float* image, const floa
     PTTA_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- validation metrics on device (src/tta_main.py:779-798 + src/eval_utils.py:117-174) --------------
+// mask = gt > 0 and min_eval <= gt <= max_eval; MAE / RMSE in millimetres, iMAE / iRMSE in 1/km, over
+// the masked pixels of the whole batch.  Replaces the D2H copy of a full depth map per frame
+// (tta_main.py:769-770) with a 16-byte result.
+#define MET_BLOCKS 256
+__global__ __launch_bounds__(256) void eval_metrics_reduce_kernel(const float* __restrict__ depth, const float* __restrict__ gt, long n,
+                                                                  float min_eval, float max_eval, double* __restrict__ part) {
+    __shared__ double red[4][5];
+    double a[5] = {0, 0, 0, 0, 0};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float g = gt[i];
+        if (!(g > 0.f) || g < min_eval || g > max_eval) continue;
+        const float o = depth[i];
+        const float d = 1000.0f * g - 1000.0f * o;
+        const float id = 1.0f / (0.001f * g + 1e-9f) - 1.0f / (0.001f * o + 1e-9f);
+        a[0] += 1.0; a[1] += fabsf(d); a[2] += (double)d * d; a[3] += fabsf(id); a[4] += (double)id * id;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a[k] += __shfl_xor(a[k], o);
+    }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 5; ++k) red[threadIdx.x >> 6][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < 5) part[blockIdx.x * 5 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void eval_metrics_finalize_kernel(const double* __restrict__ part, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    double s[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < MET_BLOCKS; ++b)
+        for (int k = 0; k < 5; ++k) s[k] += part[b * 5 + k];
+    out[0] = (float)(s[1] / s[0]);              // MAE   [mm]
+    out[1] = (float)sqrt(s[2] / s[0]);          // RMSE  [mm]
+    out[2] = (float)(s[3] / s[0]);              // iMAE  [1/km]
+    out[3] = (float)sqrt(s[4] / s[0]);          // iRMSE [1/km]
+}
+int ptta_launch_eval_metrics(const float* depth, const float* gt, long n, float min_eval, float max_eval, double* scratch, float* out4,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(eval_metrics_reduce_kernel, dim3(MET_BLOCKS), dim3(256), 0, s, depth, gt, n, min_eval, max_eval, scratch);
+    hipLaunchKernelGGL(eval_metrics_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, out4);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1054,6 +1054,13 @@ int ptta_outlier_removal(const float* sparse, const float* validity, float* spar
                                        (hipStream_t)s);
 }
 
+int ptta_eval_metrics(const float* depth, const float* ground_truth, int64_t numel, float min_evaluate_depth, float max_evaluate_depth,
+                      void* scratch, float* metrics_out, ptta_stream s) {
+    if (!depth || !ground_truth || !scratch || !metrics_out || numel < 1) return -22;
+    return ptta_launch_eval_metrics(depth, ground_truth, numel, min_evaluate_depth, max_evaluate_depth, (double*)scratch, metrics_out,
+                                    (hipStream_t)s);
+}
+
 int ptta_profile(ptta_handle c, int enable) {
     if (!c) return -1;
     c->prof_on = enable != 0;

@@ -105,6 +105,9 @@ int ptta_launch_loss_backward(const float* depth, const float* image, const floa
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
                               int N, int H, int W, const float* ws, float* gdepth, float* gref, hipStream_t s);
 
+int ptta_launch_eval_metrics(const float* depth, const float* gt, long n, float min_eval, float max_eval, double* scratch, float* out4,
+                             hipStream_t s);
+
 // ---- wgrad_adam.hip ---------------------------------------------------------------------------
 int ptta_wgrad_chunks(long pixels);
 int ptta_launch_wgrad32(const void* x, const void* gy, int bf16, int B, int H, int W, float* part,

@@ -382,3 +382,24 @@ class OutlierRemoval(object):
         if rc != 0:
             raise RuntimeError('ptta_outlier_removal failed (%d)' % rc)
         return sd_out, vm_out
+
+
+_metric_scratch = {}
+
+
+def eval_metrics(output_depth, ground_truth, min_evaluate_depth=0.0, max_evaluate_depth=100.0):
+    """MAE / RMSE (mm) and iMAE / iRMSE (1/km) of src/tta_main.py:779-798 as a 4-element device tensor."""
+    from . import _lib
+    from ._lib import ptr
+    from .engine import _stream
+    lib = _lib.load()
+    dev = output_depth.device
+    if dev not in _metric_scratch:
+        _metric_scratch[dev] = torch.empty(2048, device=dev, dtype=torch.float64)
+    out = torch.empty(4, device=dev, dtype=torch.float32)
+    o, g = output_depth.contiguous().float(), ground_truth.contiguous().float()
+    rc = lib.ptta_eval_metrics(ptr(o), ptr(g), o.numel(), float(min_evaluate_depth), float(max_evaluate_depth),
+                               ptr(_metric_scratch[dev]), ptr(out), _stream())
+    if rc != 0:
+        raise RuntimeError('ptta_eval_metrics failed (%d)' % rc)
+    return out

@@ -121,6 +121,21 @@ int ptta_outlier_removal(const float* sparse_depth, const float* validity, float
 int ptta_eval_metrics(const float* depth, const float* ground_truth, int64_t numel, float min_evaluate_depth,
                       float max_evaluate_depth, void* scratch, float* metrics_out, ptta_stream s);
 
+/* The reference's native extension `DCN` (external_src/NLSPN/src/model/deformconv/src/vision.cpp:7-12):
+ *   modulated_deform_conv_forward(input, weight, bias, offset, mask, kh,kw, sh,sw, ph,pw, dh,dw, group,
+ *                                 deformable_group, im2col_step) -> output           (modulated_deform_conv.h:10-26)
+ *   modulated_deform_conv_backward(..., grad_output, ...) -> [grad_input, grad_offset, grad_mask, grad_weight, grad_bias]
+ *                                                                                     (modulated_deform_conv.h:46-63)
+ * NCHW fp32 contiguous, offset (B, 2*K*dg, Ho, Wo), mask (B, K*dg, Ho, Wo).  im2col_step has no meaning here (no
+ * column buffer).  bias may be NULL; any grad_* pointer may be NULL.  Handle-free. */
+int ptta_mdconv_forward(const float* input, const float* weight, const float* bias, const float* offset, const float* mask,
+                        float* output, int b, int c, int h, int w, int c_out, int kh, int kw, int sh, int sw, int ph, int pw,
+                        int dh, int dw, int group, int deformable_group, ptta_stream s);
+int ptta_mdconv_backward(const float* input, const float* weight, const float* bias, const float* offset, const float* mask,
+                         const float* grad_output, float* grad_input, float* grad_offset, float* grad_mask, float* grad_weight,
+                         float* grad_bias, int b, int c, int h, int w, int c_out, int kh, int kw, int sh, int sw, int ph, int pw,
+                         int dh, int dw, int group, int deformable_group, ptta_stream s);
+
 /* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
  * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
 int ptta_set_graph(ptta_handle h, int enable);

@@ -94,3 +94,24 @@ def test_outlier_removal(golden_dir):
     sd, vm = O.remove_outliers(sparse, validity, 7, 1.5)
     np.testing.assert_array_equal(sd.numpy(), g['sparse_out'])
     np.testing.assert_array_equal(vm.numpy(), g['validity_out'])
+
+
+def test_dcn_oracle_properties():
+    """The DCN restatement has no golden vectors (the reference's extension cannot run here: 'parity
+    unpinned'); pin it with the reference's own property (deformconv/test.py:69-110): zero offset and unit
+    mask == nn.Conv2d, and an integer offset == a shifted read."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 9, 11, generator=g)
+    w = torch.randn(6, 2, 3, 3, generator=g) * 0.3
+    b = torch.randn(6, generator=g)
+    off = torch.zeros(2, 2 * 9 * 2, 9, 11)
+    msk = torch.ones(2, 9 * 2, 9, 11)
+    out = O.mdconv_forward(x, w, b, off, msk, 1, 1, 1, group=2, dg=2)
+    np.testing.assert_allclose(out.numpy(), F.conv2d(x, w, b, padding=1, groups=2).numpy(), rtol=1e-5, atol=1e-5)
+    # 1x1 kernel, offset (0, +1): out[y, x] = in[y, x + 1] (zero beyond the right edge)
+    x1 = torch.randn(1, 1, 5, 7, generator=g)
+    off1 = torch.zeros(1, 2, 5, 7); off1[:, 1] = 1.0
+    out1 = O.mdconv_forward(x1, torch.ones(1, 1, 1, 1), None, off1, torch.ones(1, 1, 5, 7), 1, 0, 1)
+    exp = torch.zeros_like(x1); exp[..., :-1] = x1[..., 1:]
+    np.testing.assert_allclose(out1.numpy(), exp.numpy(), atol=1e-6)

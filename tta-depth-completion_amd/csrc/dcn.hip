@@ -1,0 +1,214 @@
+// Modulated deformable convolution (DCNv2) forward / backward — the reference's ONLY native code:
+// the pybind module `DCN` (external_src/NLSPN/src/model/deformconv/src/vision.cpp:7-12,
+// src/modulated_deform_conv.h:10-63, CUDA in src/cuda/modulated_deform_conv_cuda.cu:19-280 and
+// src/cuda/modulated_deform_im2col_cuda.cuh:25-328), used by NLSPN's propagation layer
+// (nlspnmodel_adapt.py:239-253,288-338) with C = 1, 3x3 / 1x1 kernels.
+//
+// The reference materialises an im2col buffer (9x the input) and calls at::addmm per group; here
+// the sampling and the contraction are fused in one kernel per direction, no column buffer and no
+// GEMM library, NCHW fp32 as the reference's tensors:
+//   out[b,co,y,x] = bias[co] + sum_{ci in group(co)} sum_k W[co,ci,k] * mask[b,dg(ci),k,y,x]
+//                                 * bilinear(in[b,ci], y*s - p + i*d + off_h, x*s - p + j*d + off_w)
+// with the reference's boundary rule (a sample contributes iff -1 < h < H and -1 < w < W; corners
+// outside the image read 0, modulated_deform_im2col_cuda.cuh:25-54,:180).
+// Backward: grad_offset / grad_mask as gathers (:257-328), grad_input as the reference's atomicAdd
+// scatter onto the four bilinear corners (:197-254; float atomics, same non-determinism as the
+// reference), grad_weight / grad_bias as block-partial reductions + atomics.
+// The hot configuration (C_in = C_out = 1) keeps the 9 weights in registers; the general case
+// re-samples per output channel (correct, not tuned).
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+struct DcnP {
+    const float *in, *weight, *bias, *offset, *mask, *gout;
+    float *out, *gin, *goff, *gmask, *gweight, *gbias;
+    int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, group, dg;
+};
+
+struct Corner { int h0, w0; float lh, lw; bool inside; };
+__device__ __forceinline__ Corner corner_of(float h, float w, int H, int W) {
+    Corner c;
+    c.inside = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
+    const float fh = floorf(h), fw = floorf(w);
+    c.h0 = (int)fh; c.w0 = (int)fw; c.lh = h - fh; c.lw = w - fw;
+    return c;
+}
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ im, int H, int W, const Corner& c) {
+    if (!c.inside) return 0.f;
+    const int h1 = c.h0 + 1, w1 = c.w0 + 1;
+    const float v1 = (c.h0 >= 0 && c.w0 >= 0) ? im[c.h0 * W + c.w0] : 0.f;
+    const float v2 = (c.h0 >= 0 && w1 <= W - 1) ? im[c.h0 * W + w1] : 0.f;
+    const float v3 = (h1 <= H - 1 && c.w0 >= 0) ? im[h1 * W + c.w0] : 0.f;
+    const float v4 = (h1 <= H - 1 && w1 <= W - 1) ? im[h1 * W + w1] : 0.f;
+    const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+    return hh * hw * v1 + hh * c.lw * v2 + c.lh * hw * v3 + c.lh * c.lw * v4;
+}
+
+__global__ __launch_bounds__(256) void dcn_forward_kernel(DcnP p) {
+    const int K = p.kh * p.kw, cpg = p.C / p.group, opg = p.Co / p.group, cpd = p.C / p.dg;
+    const long total = (long)p.B * p.Co * p.Ho * p.Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % p.Wo); long t_ = idx / p.Wo;
+        const int y = (int)(t_ % p.Ho); t_ /= p.Ho;
+        const int co = (int)(t_ % p.Co); const int b = (int)(t_ / p.Co);
+        const int g = co / opg;
+        const long plane_o = (long)p.Ho * p.Wo, pix = (long)y * p.Wo + x;
+        float acc = p.bias ? p.bias[co] : 0.f;
+        for (int cl = 0; cl < cpg; ++cl) {
+            const int ci = g * cpg + cl, d = ci / cpd;
+            const float* im = p.in + ((long)b * p.C + ci) * p.H * p.W;
+            const float* off = p.offset + ((long)b * p.dg + d) * 2 * K * plane_o + pix;
+            const float* msk = p.mask + ((long)b * p.dg + d) * K * plane_o + pix;
+            const float* w = p.weight + ((long)co * cpg + cl) * K;
+            for (int k = 0; k < K; ++k) {
+                const int i = k / p.kw, j = k % p.kw;
+                const float h = (float)(y * p.sh - p.ph + i * p.dh) + off[(long)(2 * k) * plane_o];
+                const float ww = (float)(x * p.sw - p.pw + j * p.dw) + off[(long)(2 * k + 1) * plane_o];
+                const Corner c = corner_of(h, ww, p.H, p.W);
+                acc = fmaf(w[k] * msk[(long)k * plane_o], bilinear_at(im, p.H, p.W, c), acc);
+            }
+        }
+        p.out[idx] = acc;
+    }
+}
+
+// one thread per (b, deformable group, tap, y, x): grad_offset (h and w) and grad_mask;
+// the same thread scatters grad_input for its (tap, pixel) over the channels of the group.
+__global__ __launch_bounds__(256) void dcn_backward_data_kernel(DcnP p) {
+    const int K = p.kh * p.kw, cpg = p.C / p.group, opg = p.Co / p.group, cpd = p.C / p.dg;
+    const long plane_o = (long)p.Ho * p.Wo;
+    const long total = (long)p.B * p.dg * K * plane_o;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % p.Wo); long t_ = idx / p.Wo;
+        const int y = (int)(t_ % p.Ho); t_ /= p.Ho;
+        const int k = (int)(t_ % K); t_ /= K;
+        const int d = (int)(t_ % p.dg); const int b = (int)(t_ / p.dg);
+        const long pix = (long)y * p.Wo + x;
+        const int i = k / p.kw, j = k % p.kw;
+        const float* off = p.offset + ((long)b * p.dg + d) * 2 * K * plane_o + pix;
+        const float m = p.mask[(((long)b * p.dg + d) * K + k) * plane_o + pix];
+        const float h = (float)(y * p.sh - p.ph + i * p.dh) + off[(long)(2 * k) * plane_o];
+        const float w = (float)(x * p.sw - p.pw + j * p.dw) + off[(long)(2 * k + 1) * plane_o];
+        const Corner c = corner_of(h, w, p.H, p.W);
+        float g_h = 0.f, g_w = 0.f, g_m = 0.f;
+        for (int cd = 0; cd < cpd; ++cd) {
+            const int ci = d * cpd + cd, g = ci / cpg, cl = ci - g * cpg;
+            // column gradient: sum over the output channels connected to ci
+            float cg = 0.f;
+            for (int ol = 0; ol < opg; ++ol) {
+                const int co = g * opg + ol;
+                cg = fmaf(p.weight[((long)co * cpg + cl) * K + k], p.gout[((long)b * p.Co + co) * plane_o + pix], cg);
+            }
+            if (!c.inside) continue;
+            const float* im = p.in + ((long)b * p.C + ci) * p.H * p.W;
+            const int h1 = c.h0 + 1, w1 = c.w0 + 1;
+            const bool o1 = c.h0 >= 0 && c.w0 >= 0, o2 = c.h0 >= 0 && w1 <= p.W - 1, o3 = h1 <= p.H - 1 && c.w0 >= 0, o4 = h1 <= p.H - 1 && w1 <= p.W - 1;
+            const float v1 = o1 ? im[c.h0 * p.W + c.w0] : 0.f, v2 = o2 ? im[c.h0 * p.W + w1] : 0.f;
+            const float v3 = o3 ? im[h1 * p.W + c.w0] : 0.f, v4 = o4 ? im[h1 * p.W + w1] : 0.f;
+            const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+            g_m = fmaf(cg, hh * hw * v1 + hh * c.lw * v2 + c.lh * hw * v3 + c.lh * c.lw * v4, g_m);
+            // mdmcn_get_coordinate_weight (:84-125)
+            g_h = fmaf(cg * m, -hw * v1 - c.lw * v2 + hw * v3 + c.lw * v4, g_h);
+            g_w = fmaf(cg * m, -hh * v1 + hh * v2 - c.lh * v3 + c.lh * v4, g_w);
+            // col2im (:197-254): scatter onto the in-bounds bilinear corners
+            if (p.gin) {
+                float* gi = p.gin + ((long)b * p.C + ci) * p.H * p.W;
+                const float t = cg * m;
+                if (o1) atomicAdd(gi + c.h0 * p.W + c.w0, hh * hw * t);
+                if (o2) atomicAdd(gi + c.h0 * p.W + w1, hh * c.lw * t);
+                if (o3) atomicAdd(gi + h1 * p.W + c.w0, c.lh * hw * t);
+                if (o4) atomicAdd(gi + h1 * p.W + w1, c.lh * c.lw * t);
+            }
+        }
+        if (p.goff) {
+            float* go = p.goff + ((long)b * p.dg + d) * 2 * K * plane_o + pix;
+            go[(long)(2 * k) * plane_o] = g_h;
+            go[(long)(2 * k + 1) * plane_o] = g_w;
+        }
+        if (p.gmask) p.gmask[(((long)b * p.dg + d) * K + k) * plane_o + pix] = g_m;
+    }
+}
+
+// grad_weight[co, cl, k] = sum_{b,y,x} gout * mask * bilinear ; blockIdx.y = (co, cl, k)
+__global__ __launch_bounds__(256) void dcn_backward_weight_kernel(DcnP p) {
+    __shared__ float red[4];
+    const int K = p.kh * p.kw, cpg = p.C / p.group, opg = p.Co / p.group, cpd = p.C / p.dg;
+    const int wk = blockIdx.y;
+    const int k = wk % K, cl = (wk / K) % cpg, co = wk / (K * cpg);
+    const int g = co / opg, ci = g * cpg + cl, d = ci / cpd;
+    const int i = k / p.kw, j = k % p.kw;
+    const long plane_o = (long)p.Ho * p.Wo;
+    const long total = (long)p.B * plane_o;
+    float acc = 0.f;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long pix = idx % plane_o; const int b = (int)(idx / plane_o);
+        const int y = (int)(pix / p.Wo), x = (int)(pix % p.Wo);
+        const float* off = p.offset + ((long)b * p.dg + d) * 2 * K * plane_o + pix;
+        const float h = (float)(y * p.sh - p.ph + i * p.dh) + off[(long)(2 * k) * plane_o];
+        const float w = (float)(x * p.sw - p.pw + j * p.dw) + off[(long)(2 * k + 1) * plane_o];
+        const Corner c = corner_of(h, w, p.H, p.W);
+        const float col = p.mask[(((long)b * p.dg + d) * K + k) * plane_o + pix] * bilinear_at(p.in + ((long)b * p.C + ci) * p.H * p.W, p.H, p.W, c);
+        acc = fmaf(p.gout[((long)b * p.Co + co) * plane_o + pix], col, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(p.gweight + wk, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void dcn_backward_bias_kernel(DcnP p) {
+    __shared__ float red[4];
+    const int co = blockIdx.y;
+    const long plane_o = (long)p.Ho * p.Wo, total = (long)p.B * plane_o;
+    float acc = 0.f;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+        acc += p.gout[((idx / plane_o) * p.Co + co) * plane_o + idx % plane_o];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(p.gbias + co, red[0] + red[1] + red[2] + red[3]);
+}
+
+static int dcn_fill(DcnP& p, const DcnArgs& a) {
+    if (a.kh < 1 || a.kw < 1 || a.group < 1 || a.dg < 1 || a.C % a.group || a.Co % a.group || a.C % a.dg) return -22;
+    p.in = a.in; p.weight = a.weight; p.bias = a.bias; p.offset = a.offset; p.mask = a.mask; p.gout = a.gout;
+    p.out = a.out; p.gin = a.gin; p.goff = a.goff; p.gmask = a.gmask; p.gweight = a.gweight; p.gbias = a.gbias;
+    p.B = a.B; p.C = a.C; p.H = a.H; p.W = a.W; p.Co = a.Co; p.kh = a.kh; p.kw = a.kw; p.sh = a.sh; p.sw = a.sw;
+    p.ph = a.ph; p.pw = a.pw; p.dh = a.dh; p.dw = a.dw; p.group = a.group; p.dg = a.dg;
+    p.Ho = (a.H + 2 * a.ph - (a.dh * (a.kh - 1) + 1)) / a.sh + 1;
+    p.Wo = (a.W + 2 * a.pw - (a.dw * (a.kw - 1) + 1)) / a.sw + 1;
+    return (p.Ho < 1 || p.Wo < 1) ? -22 : 0;
+}
+
+int ptta_launch_dcn_forward(const DcnArgs& a, hipStream_t s) {
+    DcnP p;
+    const int rc = dcn_fill(p, a); if (rc) return rc;
+    const long total = (long)p.B * p.Co * p.Ho * p.Wo;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dcn_forward_kernel, dim3((int)blocks), dim3(256), 0, s, p);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+int ptta_launch_dcn_backward(const DcnArgs& a, hipStream_t s) {
+    DcnP p;
+    const int rc = dcn_fill(p, a); if (rc) return rc;
+    const int K = p.kh * p.kw, cpg = p.C / p.group;
+    const long plane_o = (long)p.Ho * p.Wo;
+    if (p.gin) { if (hipMemsetAsync(p.gin, 0, (size_t)p.B * p.C * p.H * p.W * 4, s) != hipSuccess) return -5; }
+    if (p.gweight) { if (hipMemsetAsync(p.gweight, 0, (size_t)p.Co * cpg * K * 4, s) != hipSuccess) return -5; }
+    if (p.gbias) { if (hipMemsetAsync(p.gbias, 0, (size_t)p.Co * 4, s) != hipSuccess) return -5; }
+    if (p.gin || p.goff || p.gmask) {
+        const long total = (long)p.B * p.dg * K * plane_o;
+        long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(dcn_backward_data_kernel, dim3((int)blocks), dim3(256), 0, s, p);
+    }
+    const long npix = (long)p.B * plane_o;
+    int bx = (int)((npix + 256 * 8 - 1) / (256 * 8)); if (bx < 1) bx = 1; if (bx > 256) bx = 256;
+    if (p.gweight) hipLaunchKernelGGL(dcn_backward_weight_kernel, dim3(bx, p.Co * cpg * K), dim3(256), 0, s, p);
+    if (p.gbias) hipLaunchKernelGGL(dcn_backward_bias_kernel, dim3(bx, p.Co), dim3(256), 0, s, p);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1061,6 +1061,32 @@ int ptta_eval_metrics(const float* depth, const float* ground_truth, int64_t num
                                     (hipStream_t)s);
 }
 
+static void dcn_args(DcnArgs& a, const float* input, const float* weight, const float* bias, const float* offset, const float* mask,
+                     int b, int c, int h, int w, int c_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int group, int dg) {
+    a.in = input; a.weight = weight; a.bias = bias; a.offset = offset; a.mask = mask;
+    a.B = b; a.C = c; a.H = h; a.W = w; a.Co = c_out; a.kh = kh; a.kw = kw; a.sh = sh; a.sw = sw; a.ph = ph; a.pw = pw;
+    a.dh = dh; a.dw = dw; a.group = group; a.dg = dg;
+}
+
+int ptta_mdconv_forward(const float* input, const float* weight, const float* bias, const float* offset, const float* mask, float* output,
+                        int b, int c, int h, int w, int c_out, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                        int group, int deformable_group, ptta_stream s) {
+    if (!input || !weight || !offset || !mask || !output) return -22;
+    DcnArgs a; dcn_args(a, input, weight, bias, offset, mask, b, c, h, w, c_out, kh, kw, sh, sw, ph, pw, dh, dw, group, deformable_group);
+    a.out = output;
+    return ptta_launch_dcn_forward(a, (hipStream_t)s);
+}
+
+int ptta_mdconv_backward(const float* input, const float* weight, const float* bias, const float* offset, const float* mask,
+                         const float* grad_output, float* grad_input, float* grad_offset, float* grad_mask, float* grad_weight,
+                         float* grad_bias, int b, int c, int h, int w, int c_out, int kh, int kw, int sh, int sw, int ph, int pw,
+                         int dh, int dw, int group, int deformable_group, ptta_stream s) {
+    if (!input || !weight || !offset || !mask || !grad_output) return -22;
+    DcnArgs a; dcn_args(a, input, weight, bias, offset, mask, b, c, h, w, c_out, kh, kw, sh, sw, ph, pw, dh, dw, group, deformable_group);
+    a.gout = grad_output; a.gin = grad_input; a.goff = grad_offset; a.gmask = grad_mask; a.gweight = grad_weight; a.gbias = grad_bias;
+    return ptta_launch_dcn_backward(a, (hipStream_t)s);
+}
+
 int ptta_profile(ptta_handle c, int enable) {
     if (!c) return -1;
     c->prof_on = enable != 0;

@@ -129,3 +129,12 @@ int ptta_launch_bn2d_bwd_finalize(const float* part, int nblocks, long R, const 
 int ptta_launch_adam(float* p, float* m, float* v, const float* g, long n, const float* hyper /*lr,b1,b2,eps,wd*/,
                      const int* step_dev, hipStream_t s);
 int ptta_launch_step_inc(int* step_dev, hipStream_t s);
+
+// ---- dcn.hip (modulated deformable convolution, NCHW fp32) -------------------------------------
+struct DcnArgs {
+    const float *in = nullptr, *weight = nullptr, *bias = nullptr, *offset = nullptr, *mask = nullptr, *gout = nullptr;
+    float *out = nullptr, *gin = nullptr, *goff = nullptr, *gmask = nullptr, *gweight = nullptr, *gbias = nullptr;
+    int B = 1, C = 1, H = 0, W = 0, Co = 1, kh = 3, kw = 3, sh = 1, sw = 1, ph = 1, pw = 1, dh = 1, dw = 1, group = 1, dg = 1;
+};
+int ptta_launch_dcn_forward(const DcnArgs& a, hipStream_t s);
+int ptta_launch_dcn_backward(const DcnArgs& a, hipStream_t s);

@@ -75,12 +75,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())     # (modulo only matters for plumbing tests on a 1-GPU box)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        # 'nccl' IS RCCL on ROCm; PTTA_BENCH_BACKEND=gloo exists only to exercise this path on one GPU
+        dist.init_process_group(os.environ.get('PTTA_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
 
     from proxytta import synth
     from proxytta.engine import ADAPTED, Engine
@@ -120,7 +121,7 @@ def main():
     ms, abytes, macs, launches = eng.profile_read(1)      # class 1 = stride-1, relu-in
     eng.profile(False)
     if dist is not None:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        t = torch.tensor([elapsed], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     finite = bool(torch.isfinite(info).all().item())

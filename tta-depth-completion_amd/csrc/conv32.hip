@@ -173,9 +173,11 @@ __device__ __forceinline__ int x3_stage_pix(int idx) { return ((idx >> 5) << 3) 
 
 template <bool RELU, bool UP, bool MASK, bool ADD>
 __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) {
-    // one LDS array: [halo tile | lo weight fragments]
-    __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * X3_STRIDE + 18 * 64 * 16];
+    // one LDS array: [halo tile | lo weight fragments | (UP) half-resolution source window of the bilinear skip]
+    constexpr int UPH = 6, UPW = 18;                      // an 8x32 output tile reads <= 5x17 source pixels
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * X3_STRIDE + 18 * 64 * 16 + (UP ? UPH * UPW * 128 : 0)];
     unsigned char* const wl_lds = lds + X3_PH * X3_PW * X3_STRIDE;
+    float* const up_lds = (float*)(wl_lds + 18 * 64 * 16);
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -246,6 +248,20 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
             }
         }
         if (PREFETCH && tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x);
+        // bilinear x2 skip: stage the source window once per tile as whole 128-B lines (clamped at the
+        // borders; only indices the lerp actually produces are ever read back)
+        int uy0 = 0, ux0 = 0;
+        if (UP) {
+            const int Hu = H >> 1, Wu = W >> 1;
+            uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
+            const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
+            for (int idx = tid; idx < UPH * UPW * 8; idx += 256) {
+                const int q = idx & 7, pix = idx >> 3;
+                const int r = pix / UPW, cc = pix - r * UPW;
+                const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
+                *(float4*)(up_lds + pix * 32 + 4 * q) = *(const float4*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q);
+            }
+        }
         __syncthreads();
         // ---- two output rows per wave ------------------------------------------------------------
 #pragma unroll 1
@@ -272,7 +288,25 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
                 }
                 if (kx == 2) __builtin_amdgcn_sched_barrier(0);      // bound the ds_read prefetch depth (VGPR pressure)
             }
-            epi_tile<float, UP, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+            if (UP) {
+                // (conv + bias) + bilinear, in the reference's order; the skip comes from LDS (lane = channel:
+                // consecutive banks), then the generic epilogue runs without bias / gather
+                const float bias = (p.epi.bias ? p.epi.bias : kZeroBias)[i];
+                const Lerp ly = lerp_coef(y, H >> 1, sy);
+                const float* r0 = up_lds + (ly.i0 - uy0) * UPW * 32 + i;
+                const float* r1 = up_lds + (ly.i1 - uy0) * UPW * 32 + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = min(x0 + acc_row(r, h), W - 1);
+                    const Lerp lx = lerp_coef(px, W >> 1, sx);
+                    const int c0 = (lx.i0 - ux0) * 32, c1 = (lx.i1 - ux0) * 32;
+                    acc[r] = (acc[r] + bias) + (ly.l0 * (lx.l0 * r0[c0] + lx.l1 * r0[c1]) + ly.l1 * (lx.l0 * r1[c0] + lx.l1 * r1[c1]));
+                }
+                Epi<float> e2 = p.epi; e2.bias = nullptr; e2.up = nullptr;
+                epi_tile<float, false, MASK, ADD>(e2, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+            } else {
+                epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+            }
         }
         __syncthreads();
     }

@@ -76,6 +76,20 @@ struct ptta_ctx {
     hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
     hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t cap_stream = nullptr;    // private stream to capture on (the caller's may be the un-capturable null stream)
+    // intra-step concurrency: the MLP heads run on a second stream beside decoder 3 (forward) and beside
+    // the first decoder-3 gradients (backward); fork/join with events (graph edges under capture)
+    int use_aux = 1;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux(hipStream_t) {
+        if (!use_aux || prof_on) return nullptr;
+        if (!aux_stream) {
+            if (hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+        }
+        return aux_stream;
+    }
     float *in_image = nullptr, *in_loss_image = nullptr, *in_sparse = nullptr, *in_validity = nullptr;
     void drop_graphs() {
         for (int k = 0; k < 4; ++k) {
@@ -454,8 +468,12 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
     return 0;
 }
 
-// One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half.
+int heads_forward(ptta_ctx* c, hipStream_t s);
+
+// One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half;
+// the MLP heads (which only need depth_encoder3's output) run on the auxiliary stream beside decoder 3.
 int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
+    hipStream_t s2 = train ? c->aux(s) : nullptr;
     const int Nn = c->Nn, B2 = train ? 2 * Nn : Nn;
     const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
@@ -556,6 +574,11 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     CV("depth_encoder3.enc2.1", false, CONV_S2, c->e3_1, B2, B2, H2, W2, true, e_raw(c->e3_2a));
     { E e; e.raw = c->feat; e.sum = c->w2; e.up = c->z2; e.up_nb = B2; e.add1 = c->m; e.add1_nb = B2;   // w2 = feat + m
       CV("depth_encoder3.enc2.3", false, CONV_S1, c->e3_2a, B2, B2, H4, W4, true, e); }
+    if (train && s2) {
+        HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+        RUN(heads_forward(c, s2));
+        HIPCHK(hipEventRecord(c->ev_join, s2));
+    }
     // decoder 3: real frames only (the proxy pass stops at depth_encoder3, :509-532)
     CV("depth_decoder3.dec2.1", false, CONV_T2, c->w2, B2, Nn, H4, W4, true, e_raw(c->t3));
     { E e; e.sum = c->s1_3; e.add1 = c->e3_1; e.add1_nb = B2; e.add2 = c->c1; e.add2_nb = B2;
@@ -571,6 +594,10 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         RUN(ptta_launch_conv_out1(a, s));
     }
 #undef CV
+    if (train) {
+        if (s2) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+        else RUN(heads_forward(c, s));
+    }
     return 0;
 }
 
@@ -618,7 +645,7 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
 }
 
 // data gradients from d(depth_net) [Nn,1,Hp,Wp] and d(feat) down to conv1_rgb_meta, then its wgrad
-int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s) {
+int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_aux) {
     const int Nn = c->Nn, B2 = 2 * Nn;
     const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
@@ -642,6 +669,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s) {
     CV("depth_decoder3.dec1.3", true, CONV_S1, c->ds0_3, Nn, Nn, H1, W1, false, em(c->du3, c->u3, Nn));
     CV("depth_decoder3.dec1.1", true, CONV_S2, c->du3, Nn, Nn, H1, W1, false, em(c->ds1_3, c->s1_3, Nn));
     CV("depth_decoder3.dec2.3", true, CONV_S1, c->ds1_3, Nn, Nn, H2, W2, false, em(c->dt3, c->t3, Nn));
+    if (join_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));       // d feat from the heads (auxiliary stream)
     { E e; e.raw = c->dw2; e.mask = c->w2; e.mask_nb = B2; e.sum = c->dfeat_tot; e.add1 = c->g_feat; e.add1_nb = Nn;
       CV("depth_decoder3.dec2.1", true, CONV_S2, c->dt3, Nn, Nn, H2, W2, false, e); }
     // ---- encoder 3 ----
@@ -745,6 +773,8 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     c->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
     const char* gr = getenv("PTTA_GRAPH");
     c->use_graph = (gr && strcmp(gr, "0") == 0) ? 0 : 1;
+    const char* ax = getenv("PTTA_AUX_STREAM");
+    c->use_aux = (ax && strcmp(ax, "0") == 0) ? 0 : 1;
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
     c->x3 = (arith && strcmp(arith, "exact") == 0) ? 0 : 1;
     c->hp = *hp;
@@ -761,6 +791,7 @@ void ptta_destroy(ptta_handle h) {
     if (!h) return;
     h->drop_graphs();
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+    if (h->aux_stream) { hipStreamDestroy(h->aux_stream); hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); }
     for (void* p : h->allocs) if (p) hipFree(p);
     for (auto& pc : h->prof) for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     delete h;
@@ -910,8 +941,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
     if (!c || !image || !sparse) return -1;
     hipStream_t s = (hipStream_t)s_;
     c->fwd_valid = false;
-    RUN(forward_common(c, image, sparse, true, s));
-    RUN(heads_forward(c, s));
+    RUN(forward_common(c, image, sparse, true, s));      // includes the heads (beside decoder 3)
     const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), dbytes, hipMemcpyDeviceToDevice, s));
     if (emb_out) HIPCHK(hipMemcpyAsync(emb_out, c->emb, ebytes, hipMemcpyDeviceToDevice, s));
@@ -961,9 +991,17 @@ int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref,
                            c->N, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
         g_net = c->g_net;
     }
-    if (grad_ref) { RUN(heads_backward(c, grad_ref, s)); }
-    else HIPCHK(hipMemsetAsync(c->g_feat, 0, (size_t)c->Rg * 32 * c->es, s));
-    RUN(backbone_backward(c, g_net, s));
+    bool join_aux = false;
+    if (grad_ref) {
+        hipStream_t s2 = c->aux(s);
+        if (s2) {
+            HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+            RUN(heads_backward(c, grad_ref, s2));
+            HIPCHK(hipEventRecord(c->ev_join, s2));
+            join_aux = true;
+        } else RUN(heads_backward(c, grad_ref, s));
+    } else HIPCHK(hipMemsetAsync(c->g_feat, 0, (size_t)c->Rg * 32 * c->es, s));
+    RUN(backbone_backward(c, g_net, s, join_aux));
     if (c->meta_mode == PTTA_META_1LAYER) {
         if (gw_out) HIPCHK(hipMemcpyAsync(gw_out, c->gW, 9216 * 4, hipMemcpyDeviceToDevice, s));
         if (gb_out) HIPCHK(hipMemcpyAsync(gb_out, c->gB, 32 * 4, hipMemcpyDeviceToDevice, s));

@@ -74,6 +74,68 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(ConvInP<T> p) {
     }
 }
 
+// LDS-staged variant (the shipped one): a block owns an 8x32 output tile, the (8+2)x(32+2) window of
+// each input plane is staged once (zero-filled outside the image / for the proxy pass's zero image), so the
+// 9*cin A operands of a lane are ds_read_b32 at compile-time offsets instead of per-tap address arithmetic
+// and bounds tests (the direct form spent ~36 VALU instructions per MFMA on them).
+#define CI_TH 8
+#define CI_PW 36            // padded row: 34 used
+template <typename T, int CIN, bool MASK>
+__global__ __launch_bounds__(256) void conv_in_lds_kernel(ConvInP<T> p) {
+    constexpr int K = 9 * CIN, NS = (K + 1) / 2, PLANE = (CI_TH + 2) * CI_PW;
+    __shared__ float tile[CIN * PLANE + 4];                      // + a zero word for the padded k
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float w[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) w[s] = p.w[s * 64 + lane];
+    if (tid == 0) tile[CIN * PLANE] = 0.f;
+    const int H = p.H, W = p.W;
+    const int ntx = (W + 31) >> 5, nty = (H + CI_TH - 1) / CI_TH;
+    const long ntiles = (long)p.B * ntx * nty;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        long t_ = t;
+        const int ty = (int)(t_ % nty); t_ /= nty;
+        const int tx = (int)(t_ % ntx);
+        const int b = (int)(t_ / ntx);
+        const int y0 = ty * CI_TH, x0 = tx << 5;
+        const bool live = b < p.zero_from_b;
+        for (int idx = tid; idx < CIN * (CI_TH + 2) * 34; idx += 256) {
+            const int px = idx % 34; int r_ = idx / 34;
+            const int py = r_ % (CI_TH + 2); const int ci = r_ / (CI_TH + 2);
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            float v = 0.f;
+            if (live && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const Plane& pl = p.pl[ci];
+                v = pl.p[(size_t)(b % pl.nb) * pl.bstride + (size_t)gy * W + gx];
+            }
+            tile[ci * PLANE + py * CI_PW + px] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr, y = y0 + row;
+            if (y >= H) break;
+            const float* base = tile + row * CI_PW + i;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int k0 = 2 * s, k1 = 2 * s + 1;
+                const int o0 = (k0 % CIN) * PLANE + ((k0 / CIN) / 3) * CI_PW + (k0 / CIN) % 3;
+                const int o1 = (k1 < K) ? (k1 % CIN) * PLANE + ((k1 / CIN) / 3) * CI_PW + (k1 / CIN) % 3 : -1;
+                // lane half h supplies k = 2s + h; the padded k reads the zero word
+                const float a = h ? (o1 >= 0 ? base[o1] : tile[CIN * PLANE]) : base[o0];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[s], acc, 0, 0, 0);
+            }
+            epi_tile<T, false, MASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, 0.f, 0.f);
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ void conv_in_naive_kernel(ConvInP<T> p, int cin) {
     const long total = (long)p.B * p.H * p.W * 32;
@@ -143,6 +205,16 @@ static int launch_conv_in_t(const ConvInArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((conv_in_naive_kernel<T>), dim3(blocks), dim3(256), 0, s, p, a.cin);
     } else {
         p.w = a.wfrag;
+        if (!a.up && !a.add1) {          // every use on the path: bias (+ ReLU mask in the backward) only
+            const long tiles = (long)p.B * ((p.W + 31) / 32) * ((p.H + CI_TH - 1) / CI_TH);
+            const int blocks = (int)(tiles > 2048 ? 2048 : tiles);
+#define CL_(C) do { if (a.mask) hipLaunchKernelGGL((conv_in_lds_kernel<T, C, true>), dim3(blocks), dim3(256), 0, s, p); \
+                    else hipLaunchKernelGGL((conv_in_lds_kernel<T, C, false>), dim3(blocks), dim3(256), 0, s, p); } while (0)
+            if (a.cin == 1) CL_(1); else if (a.cin == 2) CL_(2); else CL_(3);
+#undef CL_
+            PTTA_CHECK_LAUNCH();
+            return 0;
+        }
         const long items = (long)p.B * ((p.W + 31) / 32) * p.H;
         long blocks = (items + 3) / 4; if (blocks > 2048) blocks = 2048;
         if (a.cin == 1) hipLaunchKernelGGL((conv_in_mfma_kernel<T, 1>), dim3((int)blocks), dim3(256), 0, s, p);

@@ -10,6 +10,7 @@
 // materialised), the train-mode batch statistics of the produced layer come out of the epilogue
 // as per-row-block partial column sums (deterministic two-stage reduction, no atomics), and in
 // the backward the ReLU mask / BatchNorm-backward reductions are fused the same way.
+#include <cstdlib>
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -160,6 +161,7 @@ __device__ __forceinline__ int stage_row(int idx) { return ((idx >> 5) << 3) + (
 struct GemmX3P {
     GemmP g;
     const bf16_t* Whi; const bf16_t* Wlo;
+    const bf16_t* Wil;           // interleaved [n][k/32][hi 32 | lo 32] (wide kernel)
 };
 
 template <int WGM, int WGN, int TM, int TN, int PRO, int EPI>
@@ -346,9 +348,10 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_wide_kernel(GemmX3P q) {
                     rh[it][1] = *(const float4*)(p.A2 + gr * p.K + k + 4);
                 }
             }
-            const long off = (long)(n0 + stage_row(idx)) * p.K + k0 + 8 * (idx & 3);
-            rbh[it] = *(const uint4*)(q.Whi + off);
-            rbl[it] = *(const uint4*)(q.Wlo + off);
+            // interleaved planes: row n, K-slice j = one 128-B line [hi 32 | lo 32] -> every fetched line is fully used
+            const long off = ((long)(n0 + stage_row(idx)) * (p.K >> 5) + (k0 >> 5)) * 64 + 8 * (idx & 3);
+            rbh[it] = *(const uint4*)(q.Wil + off);
+            rbl[it] = *(const uint4*)(q.Wil + off + 32);
         }
     };
     auto store_slice = [&](int k0, int stage) {
@@ -459,16 +462,22 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_wide_kernel(GemmX3P q) {
 }
 
 // split an fp32 [N][K] weight into bf16 hi / lo planes
-__global__ void split_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n) {
+__global__ void split_weight_kernel(const float* __restrict__ w, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                    bf16_t* __restrict__ il, long n, int K) {
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
         const float v = w[k];
-        const bf16_t hh = f2bf(v);
-        hi[k] = hh; lo[k] = f2bf(v - bf2f(hh));
+        const bf16_t hh = f2bf(v), ll = f2bf(v - bf2f(hh));
+        hi[k] = hh; lo[k] = ll;
+        if (il && (K & 31) == 0) {
+            const long row = k / K; const int kk = (int)(k % K);
+            const long base = (row * (K >> 5) + (kk >> 5)) * 64 + (kk & 31);
+            il[base] = hh; il[base + 32] = ll;
+        }
     }
 }
-void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, long n, hipStream_t s) {
+void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, bf16_t* il, long n, int K, hipStream_t s) {
     long b = (n + 255) / 256; if (b > 1024) b = 1024;
-    hipLaunchKernelGGL(split_weight_kernel, dim3((int)b), dim3(256), 0, s, w, hi, lo, n);
+    hipLaunchKernelGGL(split_weight_kernel, dim3((int)b), dim3(256), 0, s, w, hi, lo, il, n, K);
 }
 
 int ptta_gemm_row_blocks(int R) { return (R + GEMM_BM - 1) / GEMM_BM; }
@@ -482,9 +491,9 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     p.pscale = a.pscale; p.pshift = a.pshift; p.pmean = a.pmean; p.pinv = a.pinv; p.pc1 = a.pc1; p.pc2 = a.pc2;
     p.eH = a.eH; p.escale = a.escale; p.eshift = a.eshift; p.emean = a.emean; p.einv = a.einv; p.part = a.part;
     if (a.x3 && !a.a_bf16) {
-        GemmX3P q; q.g = p; q.Whi = a.Whi; q.Wlo = a.Wlo;
+        GemmX3P q; q.g = p; q.Whi = a.Whi; q.Wlo = a.Wlo; q.Wil = a.Wil;
         const int key3 = a.pro * 10 + a.epi;
-        if (a.N == 512) {
+        if (a.N == 512 && a.Wil) {
             dim3 grid(2, (a.R + 255) / 256);
 #define GW_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_wide_kernel<PRO, EPI>), grid, dim3(512), 0, s, q)
             switch (key3) {

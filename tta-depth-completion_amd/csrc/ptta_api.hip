@@ -29,7 +29,7 @@ namespace {
 struct L32 { ConvW f{}, b{}; float* bias = nullptr; int transposed = 0; };
 struct LIn { float *wfrag = nullptr, *wcanon = nullptr, *bias = nullptr, *bw = nullptr; int cin = 1; };
 struct LOut { float *w = nullptr, *bias = nullptr, *bfrag = nullptr, *bcanon = nullptr; };
-struct Lin { float *W = nullptr, *Wt = nullptr, *bias = nullptr; bf16_t *Whi = nullptr, *Wlo = nullptr, *Wthi = nullptr, *Wtlo = nullptr; int N = 0, K = 0; };
+struct Lin { float *W = nullptr, *Wt = nullptr, *bias = nullptr; bf16_t *Whi = nullptr, *Wlo = nullptr, *Wthi = nullptr, *Wtlo = nullptr, *Wil = nullptr, *Wtil = nullptr; int N = 0, K = 0; };
 struct BNorm { float *gamma = nullptr, *beta = nullptr, *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
                float *mean = nullptr, *inv = nullptr, *scale = nullptr, *shift = nullptr; };
 struct Dbg { const void* p; long numel; int is_act; };
@@ -255,6 +255,7 @@ void build_registry(ptta_ctx* c) {
             const size_t ne = (size_t)l->N * l->K;
             l->Whi = (bf16_t*)c->dalloc(ne * 2); l->Wlo = (bf16_t*)c->dalloc(ne * 2);
             l->Wthi = (bf16_t*)c->dalloc(ne * 2); l->Wtlo = (bf16_t*)c->dalloc(ne * 2);
+            l->Wil = (bf16_t*)c->dalloc(ne * 4); l->Wtil = (bf16_t*)c->dalloc(ne * 4);
         }
         c->fc[std::string(p) + ".0"] = a; c->fc[std::string(p) + ".3"] = b;
         BNorm n; n.gamma = c->falloc(512); n.beta = c->falloc(512);
@@ -606,13 +607,13 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
     const Lin& l0 = c->fc[name + ".0"]; const Lin& l3 = c->fc[name + ".3"]; BNorm& bn = c->bn[name + ".1"];
     const int R = (int)c->Rg;
     GemmArgs g; g.A = A; g.a_bf16 = a_bf16; g.W = l0.W; g.bias = l0.bias; g.C = hidden; g.R = R; g.K = K; g.N = 512; g.epi = 1; g.part = c->bn_part;
-    g.x3 = c->x3; g.Whi = l0.Whi; g.Wlo = l0.Wlo;
+    g.x3 = c->x3; g.Whi = l0.Whi; g.Wlo = l0.Wlo; g.Wil = l0.Wil;
     RUN(ptta_launch_gemm(g, s));
     RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(g), R, 512, bn.gamma, bn.beta, 1e-5f, 0.1f, bn.rm, bn.rv, bn.nbt,
                                 bn.mean, bn.inv, bn.scale, bn.shift, s));
     GemmArgs g2; g2.A = hidden; g2.W = l3.W; g2.bias = l3.bias; g2.C = out; g2.R = R; g2.K = 512; g2.N = 512; g2.pro = 1;
     g2.pscale = bn.scale; g2.pshift = bn.shift;
-    g2.x3 = c->x3; g2.Whi = l3.Whi; g2.Wlo = l3.Wlo;
+    g2.x3 = c->x3; g2.Whi = l3.Whi; g2.Wlo = l3.Wlo; g2.Wil = l3.Wil;
     RUN(ptta_launch_gemm(g2, s));
     return 0;
 }
@@ -632,7 +633,7 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     const int R = (int)c->Rg;
     GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;
     g.eH = c->h1; g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part;
-    g.x3 = c->x3; g.Whi = l3.Wthi; g.Wlo = l3.Wtlo;
+    g.x3 = c->x3; g.Whi = l3.Wthi; g.Wlo = l3.Wtlo; g.Wil = l3.Wtil;
     RUN(ptta_launch_gemm(g, s));
     RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R, 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
     GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = c->g_feat_f32; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;
@@ -873,8 +874,8 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
             if (numel != (long)l.N * l.K) return c->fail("bad shape for " + name, -22);
             HIPCHK(hipMemcpyAsync(l.W, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s));
             hipLaunchKernelGGL(transpose_kernel, dim3(nblk(numel)), dim3(256), 0, s, src, l.Wt, l.N, l.K);
-            ptta_split_weight(l.W, l.Whi, l.Wlo, numel, s);
-            ptta_split_weight(l.Wt, l.Wthi, l.Wtlo, numel, s);
+            ptta_split_weight(l.W, l.Whi, l.Wlo, l.Wil, numel, l.K, s);            // [N][K]
+            ptta_split_weight(l.Wt, l.Wthi, l.Wtlo, l.Wtil, numel, l.N, s);        // transposed: [K][N]
         } else if (is_b) { HIPCHK(hipMemcpyAsync(l.bias, src, (size_t)l.N * 4, hipMemcpyDeviceToDevice, s)); }
         else return c->fail("unknown key " + name, -2);
         return 0;

@@ -82,8 +82,9 @@ struct GemmArgs {
     const float* escale = nullptr; const float* eshift = nullptr; const float* emean = nullptr; const float* einv = nullptr;
     float* part = nullptr;                     // [row_blocks][2][N] partial column statistics
     int x3 = 0; const bf16_t* Whi = nullptr; const bf16_t* Wlo = nullptr;   // bf16x3 arithmetic: pre-split [N][K] weight
+    const bf16_t* Wil = nullptr;               // the same, interleaved per 32-k slice (one 128-B line per row and slice)
 };
-void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, long n, hipStream_t s);
+void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, bf16_t* il, long n, int K, hipStream_t s);
 int ptta_gemm_row_blocks(int R);
 int ptta_gemm_part_blocks(const GemmArgs& a);
 int ptta_launch_gemm(const GemmArgs& a, hipStream_t s);

@@ -92,21 +92,30 @@ __global__ __launch_bounds__(256) void cos_rows_kernel(const float* __restrict__
     if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void loss_finalize_kernel(float* __restrict__ ws, int N, int H, int W, long R, int has_cos,
-                                     const float* __restrict__ w3, float* __restrict__ loss_info) {
-    // single thread: a few hundred adds in fixed order
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one block: parallel fixed-shape reductions of the partials (deterministic), then thread 0 finishes
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(float* __restrict__ ws, int N, int H, int W, long R, int has_cos,
+                                                            const float* __restrict__ w3, float* __restrict__ loss_info) {
+    __shared__ double red[4];
     const float w_sd = w3[0], w_sm = w3[1], w_cos = w3[2];
     const float* dp = ws + ws_depth_off(N);
+    const int t = threadIdx.x;
     double l_sd = 0.0, smx = 0.0, smy = 0.0;
     for (int n = 0; n < N; ++n) {
-        double num = 0.0, den = 0.0;
-        for (int b = 0; b < LOSS_PB; ++b) {
-            const float* q = dp + ((size_t)n * LOSS_PB + b) * 4;
-            num += q[0]; den += q[1]; smx += q[2]; smy += q[3];
-        }
+        double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (t < LOSS_PB) { const float* q = dp + ((size_t)n * LOSS_PB + t) * 4; q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; }
+        const double num = block_sum_d(q0, red), den = block_sum_d(q1, red);
+        smx += block_sum_d(q2, red); smy += block_sum_d(q3, red);
         l_sd += num / den;                                   // NaN if a sample has no valid point, as the reference
-        ws[WS_SD + n] = (float)((double)w_sd / ((double)N * den));
+        if (t == 0) ws[WS_SD + n] = (float)((double)w_sd / ((double)N * den));
     }
     l_sd /= N;
     const double cntx = (double)N * H * (W - 1), cnty = (double)N * (H - 1) * W;
@@ -115,10 +124,12 @@ __global__ void loss_finalize_kernel(float* __restrict__ ws, int N, int H, int W
     float wc = w_cos;
     if (has_cos) {
         const float* cp = ws + ws_cos_off(N);
-        for (int b = 0; b < LOSS_CB; ++b) l_cos += cp[b];
-        l_cos /= (double)R;
+        double a = 0.0;
+        for (int b = t; b < LOSS_CB; b += 256) a += cp[b];
+        l_cos = block_sum_d(a, red) / (double)R;
         if ((float)l_cos < 0.3f) wc = 0.f;                   // external_model_adapt.py:424-425
     }
+    if (t != 0) return;
     ws[WS_SCAL + 0] = has_cos ? (float)(-2.0 * wc / (double)R) : 0.f;
     ws[WS_SCAL + 1] = (float)(w_sm / cntx);
     ws[WS_SCAL + 2] = (float)(w_sm / cnty);
@@ -137,7 +148,7 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
     const int has_cos = (emb && ref) ? 1 : 0;
     if (has_cos)
         hipLaunchKernelGGL(cos_rows_kernel, dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, ws, N, H, W, R, has_cos, w3_dev, loss_info);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, ws, N, H, W, R, has_cos, w3_dev, loss_info);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,117 @@
+"""Edge cases and the other BASELINE.json shapes, HIP path vs the oracle (through the C-ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import proxytta_oracle as O
+from proxytta import synth
+from tests.util import ONE, make_engine, rel_mae
+
+pytestmark = pytest.mark.gpu
+HP = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1,
+          max_input_depth=80.0)
+
+
+def _oracle():
+    return O.MsgChnOracle(synth.formula_state_dict(ONE), ONE, max_input_depth=80.0, lr=1e-3, w_sd=1.0, w_sm=2.0, w_cos=0.1)
+
+
+@pytest.mark.parametrize('shape', [(1, 256, 320), (1, 480, 640), (3, 48, 80)])
+def test_other_config_shapes_against_oracle(shape):
+    """BASELINE.json configs[0] (320x256 VOID frame), the 640x480 VOID shape and an odd batch."""
+    n, h, w = shape
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', HP)
+    o = _oracle()
+    image, sparse = synth.synthetic_frame(5, h, w, n, density=1500.0 / (h * w) if h >= 256 else 0.05, dmin=0.2, dmax=8.0)
+    r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+    info, depth = eng.step(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda(), want_depth=True)
+    assert rel_mae(depth, r['depth']) < 1e-4
+    li = r['loss_info']
+    np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=2e-4)
+    # the post-update depth also carries the (sign-flip) gradient noise of the step through Adam; with 1500-point
+    # indoor frames the depth itself is O(1), so hold it to the north_star tolerance, not tighter
+    d_eval = eng.forward_eval(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())
+    assert rel_mae(d_eval, o.forward_eval(torch.from_numpy(image), torch.from_numpy(sparse))) < 1e-3
+    eng.close()
+
+
+def test_frame_without_valid_points_gives_nan_like_the_reference():
+    """sparse_depth_consistency_loss_func divides by sum(w) with no eps (src/loss_utils.py:116-137): a frame
+    with no valid point yields NaN in the reference; the HIP path must not hide it."""
+    n, h, w = 1, 32, 48
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', HP)
+    image, _ = synth.synthetic_frame(1, h, w, n)
+    sparse = torch.zeros(n, 1, h, w)
+    o = _oracle()
+    r = o.step(torch.from_numpy(image), sparse)
+    info, _ = eng.step(torch.from_numpy(image).cuda(), sparse.cuda())
+    assert np.isnan(r['loss_info']['loss_sparse_depth']) and bool(torch.isnan(info[2]))
+    assert bool(torch.isnan(info[0]))
+    eng.close()
+
+
+def test_max_input_depth_clamp_and_none():
+    """max_input_depth clamps the sparse input in forward AND in the loss (external_model_adapt.py:108,:192-193);
+    None disables both."""
+    n, h, w = 1, 32, 48
+    image, sparse = synth.synthetic_frame(2, h, w, n, dmin=1.0, dmax=200.0)
+    for mid in (80.0, None):
+        hp = dict(HP); hp['max_input_depth'] = mid
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp)
+        o = O.MsgChnOracle(synth.formula_state_dict(ONE), ONE, max_input_depth=mid, lr=1e-3, w_sd=1.0, w_sm=2.0, w_cos=0.1)
+        r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+        info, depth = eng.step(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda(), want_depth=True)
+        assert rel_mae(depth, r['depth']) < 1e-4
+        assert abs(float(info[2]) - r['loss_info']['loss_sparse_depth']) < 2e-4 * abs(r['loss_info']['loss_sparse_depth'])
+        eng.close()
+
+
+def test_explicit_validity_and_separate_loss_image():
+    """step(image1, sparse, validity_map=filtered validity, loss_image=image): tta_main.py:610 feeds the
+    normalised image to the network and the un-normalised one to the smoothness weights (:620)."""
+    n, h, w = 2, 32, 48
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', HP)
+    o = _oracle()
+    image, sparse = synth.synthetic_frame(3, h, w, n, density=0.2)
+    loss_image = 255.0 * image
+    sp_t = torch.from_numpy(sparse)
+    val = torch.where(sp_t > 0, torch.ones_like(sp_t), sp_t)
+    sd_f, val_f = O.remove_outliers(sp_t, val, 7, 1.5)
+    r = o.step(torch.from_numpy(image), sd_f, validity_map=val_f, loss_image=torch.from_numpy(loss_image))
+    info, depth = eng.step(torch.from_numpy(image).cuda(), sd_f.cuda(), validity=val_f.cuda(),
+                           loss_image=torch.from_numpy(loss_image).cuda(), want_depth=True)
+    assert rel_mae(depth, r['depth']) < 1e-4
+    li = r['loss_info']
+    np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=2e-4)
+    eng.close()
+
+
+def test_bf16_storage_mode_is_measured_not_parity():
+    """bf16 activation storage (BASELINE config 2 names bf16): runs, finite, and its error against the fp32
+    oracle is the documented ~1e-2 (it does NOT meet the 1e-3 bar)."""
+    n, h, w = 1, 64, 96
+    eng, sd, adapted = make_engine(n, h, w, 'bf16', HP)
+    o = _oracle()
+    image, sparse = synth.synthetic_frame(0, h, w, n)
+    r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+    info, depth = eng.step(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda(), want_depth=True)
+    err = rel_mae(depth, r['depth'])
+    assert torch.isfinite(depth).all() and 1e-4 < err < 3e-2
+    eng.close()
+
+
+def test_shared_parameter_step_single_rank_equals_fused_step():
+    """proxytta.distributed.shared_parameter_step (split calls + gradient all-reduce + Adam) with one rank is the
+    fused step."""
+    from proxytta.distributed import shared_parameter_step
+    n, h, w = 1, 32, 48
+    image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(4, h, w, n)]
+    e1, sd1, ad1 = make_engine(n, h, w, 'fp32', HP)
+    e2, sd2, ad2 = make_engine(n, h, w, 'fp32', HP)
+    info1, _ = e1.step(image, sparse)
+    info2, _ = shared_parameter_step(e2, image, sparse, w=(HP['w_sparse_depth'], HP['w_smoothness'], HP['w_cos']))
+    torch.cuda.synchronize()
+    assert torch.allclose(info1, info2, rtol=1e-6)
+    for k in ad1:
+        assert torch.equal(ad1[k][0], ad2[k][0])
+    e1.close(); e2.close()

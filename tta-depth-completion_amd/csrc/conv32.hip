@@ -181,17 +181,6 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // hi weight fragments stay in registers (72 VGPRs), lo fragments in LDS (read once per use)
-    uint4 wh[9][2];
-    {
-        const uint4* ph = (const uint4*)p.wpack;
-        const uint4* pl = (const uint4*)p.wpack2;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
-    }
     const int H = p.Hout, W = p.Wout;
     const int ntx = (W + 31) >> 5, nty = (H + X3_TH - 1) / X3_TH;
     const long ntiles = (long)p.B * ntx * nty;
@@ -227,6 +216,19 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
         }
     };
     if (PREFETCH && blockIdx.x < ntiles) issue_loads(blockIdx.x);
+    // hi weight fragments stay in registers (72 VGPRs), lo fragments in LDS (read once per use).  Loaded AFTER the
+    // first tile's loads were issued so that the two L2 round trips overlap (the small low-resolution launches are
+    // one tile per block: their duration is this latency chain).
+    uint4 wh[9][2];
+    {
+        const uint4* ph = (const uint4*)p.wpack;
+        const uint4* pl = (const uint4*)p.wpack2;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+    }
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y0, x0;

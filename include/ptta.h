@@ -136,6 +136,15 @@ int ptta_mdconv_backward(const float* input, const float* weight, const float* b
                          float* grad_bias, int b, int c, int h, int w, int c_out, int kh, int kw, int sh, int sw, int ph, int pw,
                          int dh, int dw, int group, int deformable_group, ptta_stream s);
 
+/* Photometric normalisation of the network input, fused into the first convolution's loads (and into
+ * the dual-corner padding): replaces Transforms.normalize_images (src/transforms.py:668-710) as called at
+ * src/tta_main.py:454-464,652 -- image -> (image / divisor - mean[c]) / std[c].  [0,1] is (255, 0, 1);
+ * [-1,1] is (255, .5, .5); standard normalisation is (255, mean, std).  After this call `image` in
+ * ptta_forward_train / ptta_forward_eval / ptta_step is the RAW image; the loss keeps using the raw image
+ * unless a separate loss_image is passed, which is what the reference does (tta_main.py:610,620).
+ * mean / std may be NULL (0 / 1).  (1, 0, 1) switches it off. */
+int ptta_set_image_norm(ptta_handle h, float divisor, const float* mean, const float* stdv);
+
 /* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
  * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
 int ptta_set_graph(ptta_handle h, int enable);

@@ -115,3 +115,37 @@ def test_shared_parameter_step_single_rank_equals_fused_step():
     for k in ad1:
         assert torch.equal(ad1[k][0], ad2[k][0])
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize('rng,shape', [([0, 1], (2, 32, 48)), ([-1, 1], (1, 32, 48)),
+                                       ([[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]], (1, 32, 48)),
+                                       ([[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]], (1, 36, 52))])
+def test_fused_image_normalisation(rng, shape):
+    """set_image_norm(normalized_image_range): the engine takes the RAW 0..255 image, normalises it inside the
+    first convolution (or inside the dual-corner padding for sizes that are not multiples of 16) and the loss uses
+    the raw image -- equal to the reference flow normalize_images -> forward(image1) / compute_loss(image)
+    (transforms.py:668-710, tta_main.py:610,620)."""
+    n, h, w = shape
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', HP)
+    o = _oracle()
+    image01, sparse = synth.synthetic_frame(5, h, w, n, density=0.2)
+    raw = torch.from_numpy(np.floor(image01 * 255.0).astype(np.float32))
+    if rng == [0, 1]:
+        img1 = raw / 255.0
+    elif rng == [-1, 1]:
+        img1 = 2.0 * (raw / 255.0) - 1.0
+    else:
+        mean = torch.tensor(rng[0]).view(1, 3, 1, 1); std = torch.tensor(rng[1]).view(1, 3, 1, 1)
+        img1 = (raw / 255.0 - mean) / std
+    sp_t = torch.from_numpy(sparse)
+    r = o.step(img1, sp_t, loss_image=raw)
+    eng.set_image_norm(rng)
+    info, depth = eng.step(raw.cuda(), sp_t.cuda(), want_depth=True)
+    assert rel_mae(depth, r['depth']) < 1e-4
+    li = r['loss_info']
+    np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=2e-4)
+    d_eval = eng.forward_eval(raw.cuda(), sp_t.cuda())
+    assert rel_mae(d_eval, o.forward_eval(img1, sp_t)) < 1e-4
+    with pytest.raises(ValueError):
+        eng.set_image_norm([0, 2])
+    eng.close()

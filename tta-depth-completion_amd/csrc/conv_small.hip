@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) void conv_in_mfma_kernel(ConvInP<T> p) {
             float a = 0.f;
             if (live && kval && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W)
                 a = pp[(size_t)(b % pnb) * pbs + (size_t)yi * p.W + xi];
+            {
+                const Plane& pq = h ? p.pl[c1] : p.pl[c0];
+                if (pq.norm && live && kval && yi >= 0 && yi < p.H && xi >= 0 && xi < p.W) a = (a / pq.div - pq.mean) / pq.stdv;
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[s], acc, 0, 0, 0);
         }
         Lerp ly = {0, 0, 0.f, 0.f};
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256) void conv_in_lds_kernel(ConvInP<T> p) {
             if (live && gy >= 0 && gy < H && gx >= 0 && gx < W) {
                 const Plane& pl = p.pl[ci];
                 v = pl.p[(size_t)(b % pl.nb) * pl.bstride + (size_t)gy * W + gx];
+                if (pl.norm) v = (v / pl.div - pl.mean) / pl.stdv;
             }
             tile[ci * PLANE + py * CI_PW + px] = v;
         }
@@ -153,8 +158,9 @@ __global__ void conv_in_naive_kernel(ConvInP<T> p, int cin) {
                 if (yi < 0 || yi >= p.H || xi < 0 || xi >= p.W) continue;
                 for (int ci = 0; ci < cin; ++ci) {
                     const Plane& pl = p.pl[ci];
-                    acc = fmaf(pl.p[(size_t)(b % pl.nb) * pl.bstride + (size_t)yi * p.W + xi],
-                               p.w[(tap * cin + ci) * 32 + co], acc);
+                    float v = pl.p[(size_t)(b % pl.nb) * pl.bstride + (size_t)yi * p.W + xi];
+                    if (pl.norm) v = (v / pl.div - pl.mean) / pl.stdv;
+                    acc = fmaf(v, p.w[(tap * cin + ci) * 32 + co], acc);
                 }
             }
         Lerp ly = {0, 0, 0.f, 0.f}, lx = {0, 0, 0.f, 0.f};

@@ -36,6 +36,8 @@ struct Dbg { const void* p; long numel; int is_act; };
 
 }  // namespace
 
+struct ImgNorm { int on; float div; float mean[3]; float stdv[3]; };
+
 struct ptta_ctx {
     int N = 1, H = 0, W = 0, Hp = 0, Wp = 0, pt = 0, pr = 0, dual = 0, Nn = 1;
     int bf16 = 0, naive = 0, es = 4, x3 = 1;
@@ -124,6 +126,7 @@ struct ptta_ctx {
     int H2, W2, H4, W4, H8, W8, H16, W16;
     long Rg = 0;                 // embedding rows = Nn * H4 * W4
     float *img_pad = nullptr, *sp_pad = nullptr, *zero_plane = nullptr;
+    ImgNorm img_norm = ImgNorm{0, 1.f, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
     float *dclamp, *d12, *d14, *out1, *p12, *q, *p11, *depth_net, *depth_final, *validity_tmp;
     void *c0a, *c0, *c1a, *c1, *c2a, *c2, *m, *c3a, *c3, *c4a, *c4;
     void *e1_0a, *e1_0, *e1_1a, *e1_1, *e1_2a, *y1, *y2, *t1, *y3, *s1_1, *u1, *y4, *s0_1, *v1;
@@ -150,7 +153,7 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
 }
 // dual-corner zero padding (src/msg_chn_model_adapt.py:75-103): item k=0 pads top/right, k=1 bottom/left
 __global__ void pad_dual_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W,
-                                int Hp, int Wp, int pt, int pr) {
+                                int Hp, int Wp, int pt, int pr, ImgNorm nm = ImgNorm{0, 1.f, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}}) {
     const long total = (long)2 * N * C * Hp * Wp;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int x = (int)(idx % Wp); long t_ = idx / Wp;
@@ -159,7 +162,10 @@ __global__ void pad_dual_kernel(const float* __restrict__ src, float* __restrict
         const int n = (int)(t_ % N); const int k = (int)(t_ / N);
         const int sy = k == 0 ? y - pt : y, sx = k == 0 ? x : x - pr;
         float v = 0.f;
-        if (sy >= 0 && sy < H && sx >= 0 && sx < W) v = src[(((long)n * C + ch) * H + sy) * W + sx];
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            v = src[(((long)n * C + ch) * H + sy) * W + sx];
+            if (nm.on) v = (v / nm.div - nm.mean[ch]) / nm.stdv[ch];     // the reference normalises before it pads
+        }
         dst[idx] = v;
     }
 }
@@ -483,7 +489,12 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     {
         const LIn& li = c->lin_in["rgb_encoder.init.0"];
         ConvInArgs a; a.cin = 3; a.zero_from_b = Nn;
-        for (int ch = 0; ch < 3; ++ch) { a.pl[ch].p = image + (size_t)ch * H1 * W1; a.pl[ch].nb = Nn; a.pl[ch].bstride = 3L * H1 * W1; }
+        for (int ch = 0; ch < 3; ++ch) {
+            a.pl[ch].p = image + (size_t)ch * H1 * W1; a.pl[ch].nb = Nn; a.pl[ch].bstride = 3L * H1 * W1;
+            if (c->img_norm.on && !c->dual) {            // dual-corner padding normalises while it pads
+                a.pl[ch].norm = 1; a.pl[ch].div = c->img_norm.div; a.pl[ch].mean = c->img_norm.mean[ch]; a.pl[ch].stdv = c->img_norm.stdv[ch];
+            }
+        }
         a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->c0a;
         a.B = B2; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
         RUN(ptta_launch_conv_in(a, s));
@@ -727,7 +738,7 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
     for (auto& ad : c->adapted) if (!ad.p) return c->fail("adapted parameter " + ad.name + " not bound (ptta_bind_adapted)", -3);
     const float* img = image; const float* sp = sparse;
     if (c->dual) {
-        hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * 3 * c->Hp * c->Wp)), dim3(256), 0, s, image, c->img_pad, c->N, 3, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
+        hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * 3 * c->Hp * c->Wp)), dim3(256), 0, s, image, c->img_pad, c->N, 3, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr, c->img_norm);
         hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * c->Hp * c->Wp)), dim3(256), 0, s, sparse, c->sp_pad, c->N, 1, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
         img = c->img_pad; sp = c->sp_pad;
     }
@@ -1075,6 +1086,21 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
     }
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
     if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const float* stdv) {
+    if (!c) return -1;
+    if (!(divisor > 0.f)) return c->fail("ptta_set_image_norm: divisor must be positive", -22);
+    ImgNorm nm = ImgNorm{0, divisor, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+    for (int k = 0; k < 3; ++k) {
+        if (mean) nm.mean[k] = mean[k];
+        if (stdv) { if (!(stdv[k] > 0.f)) return c->fail("ptta_set_image_norm: std must be positive", -22); nm.stdv[k] = stdv[k]; }
+    }
+    nm.on = !(divisor == 1.f && nm.mean[0] == 0.f && nm.mean[1] == 0.f && nm.mean[2] == 0.f && nm.stdv[0] == 1.f &&
+              nm.stdv[1] == 1.f && nm.stdv[2] == 1.f);
+    c->img_norm = nm;
+    c->drop_graphs();          // the constants are kernel arguments of the captured launches
     return 0;
 }
 

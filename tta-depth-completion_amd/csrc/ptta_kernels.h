@@ -28,7 +28,10 @@ void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, 
 int ptta_launch_conv32(const Conv32Args& a, hipStream_t s);
 
 // ---- conv_small.hip ---------------------------------------------------------------------------
-struct Plane { const float* p = nullptr; int nb = 1; long bstride = 0; };
+struct Plane { const float* p = nullptr; int nb = 1; long bstride = 0;
+               // optional photometric normalisation applied while loading (transforms.py:668-710):
+               // v -> (v / div - mean) / stdv, in-bounds samples only (the conv's zero padding stays zero)
+               int norm = 0; float div = 1.f, mean = 0.f, stdv = 1.f; };
 struct ConvInArgs {      // planar fp32 (cin = 1..3) -> 32-channel NHWC
     Plane pl[3]; int cin = 1; int zero_from_b = 1 << 30;
     const float* wfrag = nullptr;   // [14][64] fp32 MFMA fragments

@@ -50,6 +50,7 @@ SIGNATURES = [
     ('ptta_eval_metrics', c_int, [_P, _P, c_int64, c_float, c_float, _P, _P, _P]),
     ('ptta_mdconv_forward', c_int, [_P] * 6 + [c_int] * 15 + [_P]),
     ('ptta_mdconv_backward', c_int, [_P] * 11 + [c_int] * 15 + [_P]),
+    ('ptta_set_image_norm', c_int, [_P, c_float, POINTER(c_float), POINTER(c_float)]),
     ('ptta_set_graph', c_int, [_P, c_int]),
     ('ptta_profile', c_int, [_P, c_int]),
     ('ptta_profile_read', c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),

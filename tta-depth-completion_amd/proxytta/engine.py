@@ -23,6 +23,25 @@ def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def image_norm_constants(normalized_image_range):
+    """(divisor, mean[3], std[3]) of `normalized_image_range` as interpreted by
+    Transforms.normalize_images (src/transforms.py:681-708)."""
+    r = list(normalized_image_range)
+    standard = any(isinstance(v, (tuple, list)) for v in r)
+    if r == [0, 1]:
+        return 255.0, [0.0] * 3, [1.0] * 3
+    if standard:
+        mean, std = list(r[0]), list(r[1])
+        if len(mean) != 3 or len(std) != 3:
+            raise ValueError('Unsupported normalization range: {}'.format(normalized_image_range))
+        return 255.0, mean, std
+    if r == [-1, 1]:
+        return 255.0, [0.5] * 3, [0.5] * 3
+    if r == [0, 255]:
+        return 1.0, [0.0] * 3, [1.0] * 3
+    raise ValueError('Unsupported normalization range: {}'.format(normalized_image_range))
+
+
 class Engine:
     """One (batch, height, width, dtype) instance of the MSG_CHN ProxyTTA step on the current GPU."""
 
@@ -187,6 +206,16 @@ class Engine:
                                      ptr(sparse), ptr(None if validity is None else validity.contiguous()),
                                      ptr(depth), ptr(info), _stream()), 'ptta_step')
         return info, depth
+
+    def set_image_norm(self, normalized_image_range):
+        """Fuse Transforms.normalize_images (src/transforms.py:668-710) into the first convolution: the
+        engine then takes RAW images.  Accepts the reference's `normalized_image_range` values: [0, 1],
+        [-1, 1], [0, 255], or [mean, std] with 3-element lists; anything else raises ValueError like the
+        reference does."""
+        div, mean, std = image_norm_constants(normalized_image_range)
+        m = (ctypes.c_float * 3)(*mean)
+        s = (ctypes.c_float * 3)(*std)
+        self._chk(self.lib.ptta_set_image_norm(self.handle, float(div), m, s), 'ptta_set_image_norm')
 
     def set_graph(self, enable):
         self._chk(self.lib.ptta_set_graph(self.handle, int(bool(enable))), 'ptta_set_graph')

@@ -217,8 +217,20 @@ class MsgChnModel_Adapt(object):
                 p = params[name]
                 st = self._opt_state.setdefault(name, {'exp_avg': torch.zeros_like(p.data), 'exp_avg_sq': torch.zeros_like(p.data)})
                 eng.bind_adapted(name, p.data, st['exp_avg'], st['exp_avg_sq'])
+            if getattr(self, '_image_norm', None) is not None:
+                eng.set_image_norm(self._image_norm)
             self._engines[key] = eng
         return eng
+
+    def set_image_norm(self, normalized_image_range):
+        """Take RAW images from now on: Transforms.normalize_images (src/transforms.py:668-710, called at
+        src/tta_main.py:454-464,652) is fused into the first convolution's loads.  The loss keeps seeing the
+        raw image, as in the reference (tta_main.py:610 vs :620)."""
+        from .engine import image_norm_constants
+        image_norm_constants(normalized_image_range)        # validate now (raises ValueError like the reference)
+        self._image_norm = normalized_image_range
+        for eng in self._engines.values():
+            eng.set_image_norm(normalized_image_range)
 
     def set_hparams(self, **kw):
         self.hparams.update({k: v for k, v in kw.items() if k in self.hparams})
@@ -339,6 +351,9 @@ class ExternalModel_Adapt(object):
         self.model.convert_syncbn(apex)
 
     # ---- fused entry points -----------------------------------------------------------------
+    def set_image_norm(self, normalized_image_range):
+        self.model.set_image_norm(normalized_image_range)
+
     def step(self, image, sparse_depth, validity_map=None, loss_image=None, want_depth=False):
         """One TTA step (src/tta_main.py:610-633) in one library call; returns (loss_info[4], depth)."""
         return self.model.step(image, sparse_depth, validity_map, loss_image, want_depth)

@@ -1,0 +1,194 @@
+"""Generate NLSPN golden vectors by running the REAL reference (read-only at /root/reference) on CPU.
+
+Runs only in the build container.  No reference file is modified or copied; it is imported in place with
+harness-side shims (NLSPN row):
+  (1) ``.cuda()`` / ``.to('cuda')`` are no-ops, cwd = reference root;
+  (2) ``torchvision.models.resnet34`` is rebuilt from the reference's OWN ``BasicBlock`` / ``conv1x1``
+      (nlspnmodel_adapt.py:59-116) in the torchvision layout [3,4,6,3] — only layer1..4 are used (:400-406);
+  (3) ``skimage.restoration`` is an import-only stub (biharmonic hole filling acts only on exact zeros of the eval
+      output; the generator asserts there are none);
+  (4) module ``DCN``: the reference's deformable convolution has CUDA kernels only (its CPU files are AT_ERROR
+      stubs), so ``modulated_deform_conv_forward/backward`` are backed by ``oracle.proxytta_oracle.mdconv_forward``
+      and its autograd.  Everything else (convs, BN, heads, affinity normalisation, loss, Adam) is the reference.
+
+Driven surface: ExternalModel_Adapt('nlspn') -> _prepare_head, adapt_parameters('meta_bn'), forward,
+compute_loss(loss_type='adapt'), backward, torch.optim.Adam.step, eval forward (src/tta_main.py:583-633, :729-736).
+Usage:  python tests/golden/make_golden_nlspn.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tta-depth-completion_amd'))
+from oracle import proxytta_oracle as O  # noqa: E402
+from proxytta import synth  # noqa: E402
+
+LOSS_TYPE = 'adapt_meta_selfsup_seq_ema_reverse'
+PREPARE = 'meta_selfsup_seq_1layer_ema'
+MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+
+
+def import_reference():
+    os.chdir(REF)
+    sys.path.insert(0, os.path.join(REF, 'src'))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    orig_to = nn.Module.to
+
+    def to(self, *a, **k):
+        a = [x for x in a if 'cuda' not in str(x)]
+        if 'cuda' in str(k.get('device', '')):
+            k.pop('device')
+        return orig_to(self, *a, **k) if (a or k) else self
+    nn.Module.to = to
+    tv = types.ModuleType('torchvision')
+    tvm = types.ModuleType('torchvision.models')
+    tv.models = tvm
+    sys.modules['torchvision'] = tv
+    sys.modules['torchvision.models'] = tvm
+    sk = types.ModuleType('skimage')
+    skr = types.ModuleType('skimage.restoration')
+    sk.restoration = skr
+
+    def no_inpaint(*a, **k):
+        raise RuntimeError('eval output contains exact zeros: biharmonic inpainting is not available here')
+    skr.inpaint = types.SimpleNamespace(inpaint_biharmonic=no_inpaint)
+    sys.modules['skimage'] = sk
+    sys.modules['skimage.restoration'] = skr
+
+    dcn = types.ModuleType('DCN')
+
+    def fwd(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, step):
+        assert sh == sw and ph == pw and dh == dw
+        return O.mdconv_forward(input, weight, bias, offset, mask, sh, ph, dh, group, dg)
+
+    def bwd(input, weight, bias, offset, mask, grad_output, kh, kw, sh, sw, ph, pw, dh, dw, group, dg, step):
+        with torch.enable_grad():
+            ins = [t.detach().clone().requires_grad_(True) for t in (input, offset, mask, weight, bias)]
+            out = O.mdconv_forward(ins[0], ins[3], ins[4], ins[1], ins[2], sh, ph, dh, group, dg)
+            g = torch.autograd.grad(out, ins, grad_output, allow_unused=True)
+        g = [torch.zeros_like(t) if x is None else x for x, t in zip(g, ins)]
+        return g[0], g[1], g[2], g[3], g[4]
+    dcn.modulated_deform_conv_forward = fwd
+    dcn.modulated_deform_conv_backward = bwd
+    sys.modules['DCN'] = dcn
+
+    import nlspn_model_adapt  # noqa: F401  (sets up the NLSPN sys.path entries)
+    import nlspnmodel_adapt as NM
+
+    def resnet34(pretrained=False):
+        net = types.SimpleNamespace()
+        inpl = 64
+        for li, (planes, nb, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]):
+            blocks = []
+            for b in range(nb):
+                s = stride if b == 0 else 1
+                ds = None
+                if s != 1 or inpl != planes:
+                    ds = nn.Sequential(NM.conv1x1(inpl, planes, s), nn.BatchNorm2d(planes))
+                blocks.append(NM.BasicBlock(inpl, planes, s, ds))
+                inpl = planes
+            setattr(net, 'layer%d' % (li + 1), nn.Sequential(*blocks))
+        return net
+    tvm.resnet34 = resnet34
+    import external_model_adapt
+    return external_model_adapt
+
+
+def nlspn_frame(idx, h, w, n):
+    """Raw 0..1 image -> ImageNet-normalised network input (adapt_nlspn_vkitti.sh:25) + the raw image for the loss."""
+    image01, sparse = synth.synthetic_frame(idx, h, w, n, density=0.1)
+    raw = np.floor(image01 * 255.0).astype(np.float32)
+    image1 = ((raw / np.float32(255.0) - MEAN) / STD).astype(np.float32)
+    return raw, image1, sparse
+
+
+def sample_rows(x, k=24):
+    idx = np.linspace(0, x.shape[0] - 1, min(k, x.shape[0])).astype(np.int64)
+    return idx, x[idx]
+
+
+def run_case(ema, name, h, w, n, steps, hp):
+    model = ema.ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], device=torch.device('cpu'))
+    model._prepare_head(PREPARE)
+    net = model.model.model
+    sd = synth.formula_state_dict_nlspn(PREPARE)
+    assert list(sd.keys()) == list(net.state_dict().keys()), 'key table drifted from reference'
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    params = model.adapt_parameters(mode='meta_bn')
+    pnames = {id(p): k for k, p in net.named_parameters()}
+    names = [pnames[id(p)] for p in params]
+    opt = torch.optim.Adam(params, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'])
+    out = {'meta': np.array([h, w, n, steps], dtype=np.int64),
+           'hp': np.array([hp['lr'], hp['betas'][0], hp['betas'][1], hp['eps'], hp['weight_decay'], hp['w_sd'], hp['w_sm'],
+                           hp['w_cos'], hp['max_input_depth']], dtype=np.float64),
+           'adapted_names': np.array(names)}
+    # a subset of the 88 adapted tensors is stored per step (first/last layers, one per stage)
+    keep = [k for k in names if k.startswith(('conv1_rgb_meta', 'conv2.0.bn1', 'conv3.0.downsample.1', 'conv5.2.bn2', 'conv6.1',
+                                              'dec5.1', 'dec2.1', 'id_dec1.1', 'gd_dec1.1', 'cf_dec1.1'))]
+    for s in range(steps):
+        raw, image1, sparse_np = nlspn_frame(s, h, w, n)
+        image, sparse, loss_image = torch.from_numpy(image1), torch.from_numpy(sparse_np), torch.from_numpy(raw)
+        validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+        model.train()
+        depth, emb, ref = model.forward(image=image, sparse_depth=sparse, loss_type=LOSS_TYPE)
+        loss, info = model.compute_loss(
+            input_rgb=loss_image, output_depth=depth, sparse_depth=sparse.detach(), validity_map=validity.detach(),
+            embedding=emb, reference=ref, w_loss_sparse_depth=hp['w_sd'], w_loss_smoothness=hp['w_sm'],
+            w_loss_cos=hp['w_cos'], loss_type='adapt')
+        opt.zero_grad()
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+        assert all(k in grads for k in names), 'an adapted tensor got no gradient'
+        opt.step()
+        model.eval()
+        with torch.no_grad():
+            depth_eval = model.forward(image=image, sparse_depth=sparse, loss_type=LOSS_TYPE)
+        p = 's%d/' % s
+        out[p + 'depth_train'] = depth.detach().numpy()
+        out[p + 'depth_eval'] = depth_eval.numpy()
+        out[p + 'n_zero_train'] = np.array(int((depth == 0).sum()))
+        e, r = emb.detach().numpy(), ref.detach().numpy()
+        idx, out[p + 'emb_rows'] = sample_rows(e)
+        _, out[p + 'ref_rows'] = sample_rows(r)
+        out[p + 'row_idx'] = idx
+        out[p + 'emb_shape'] = np.array(e.shape)
+        out[p + 'emb_abs_mean'] = np.array(np.abs(e).mean(dtype=np.float64))
+        out[p + 'ref_abs_mean'] = np.array(np.abs(r).mean(dtype=np.float64))
+        out[p + 'loss_info'] = np.array([float(torch.as_tensor(info[k]).detach()) for k in
+                                         ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')])
+        # per-tensor gradient norms for all 88 adapted tensors, full tensors for the kept subset
+        out[p + 'grad_norms'] = np.array([float(grads[k].double().norm()) for k in names])
+        named = dict(net.named_parameters())
+        out[p + 'param_norms'] = np.array([float(named[k].detach().double().norm()) for k in names])
+        for k in keep:
+            out[p + 'grad/' + k] = grads[k].numpy()
+            out[p + 'param/' + k] = named[k].detach().numpy().copy()
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, {k: out['s%d/loss_info' % (steps - 1)] for k in ['last']},
+          'zeros(train)=', [int(out['s%d/n_zero_train' % s]) for s in range(steps)], flush=True)
+
+
+def main():
+    ema = import_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sd=1.0, w_sm=2.0, w_cos=0.1, max_input_depth=80.0)
+    run_case(ema, 'nlspn_32x64', 32, 64, 1, 2, hp)
+    run_case(ema, 'nlspn_48x80_n2', 48, 80, 2, 1, hp)
+    # the canonical script's weights: sparse-depth term only, lr 3e-4 (bash/adapt/adapt_nlspn_vkitti.sh:7-14,47-49)
+    run_case(ema, 'nlspn_32x64_canonical', 32, 64, 1, 1, dict(hp, lr=3e-4, w_sm=0.0, w_cos=0.0))
+
+
+if __name__ == '__main__':
+    main()

@@ -115,3 +115,51 @@ def test_dcn_oracle_properties():
     out1 = O.mdconv_forward(x1, torch.ones(1, 1, 1, 1), None, off1, torch.ones(1, 1, 5, 7), 1, 0, 1)
     exp = torch.zeros_like(x1); exp[..., :-1] = x1[..., 1:]
     np.testing.assert_allclose(out1.numpy(), exp.numpy(), atol=1e-6)
+
+
+# ---- NLSPN: oracle/nlspn_oracle.py against tests/golden/nlspn_*.npz ------------------------
+NLSPN_CASES = ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical']
+_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+
+
+def nlspn_frame(idx, h, w, n):
+    image01, sparse = synth.synthetic_frame(idx, h, w, n, density=0.1)
+    raw = np.floor(image01 * 255.0).astype(np.float32)
+    return raw, ((raw / np.float32(255.0) - _MEAN) / _STD).astype(np.float32), sparse
+
+
+@pytest.mark.parametrize('name', NLSPN_CASES)
+def test_nlspn_oracle_matches_reference(golden_dir, name):
+    from oracle import nlspn_oracle as N
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
+    torch.set_num_threads(4)
+    o = N.NlspnOracle(synth.formula_state_dict_nlspn(), max_input_depth=mid, lr=lr, betas=(b1, b2), eps=eps,
+                      weight_decay=wd, w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
+    assert o.names == [str(x) for x in g['adapted_names']]          # 88 tensors, reference order
+    assert len(o.names) == 88 and sum(o.P[k].numel() for k in o.names) == 40048
+    for s in range(steps):
+        raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(s, h, w, n)]
+        r = o.step(image1, sparse, loss_image=raw)
+        p = 's%d/' % s
+        assert rel_mae(r['depth'], g[p + 'depth_train']) < 2e-5
+        idx = g[p + 'row_idx']
+        assert tuple(r['emb'].shape) == tuple(g[p + 'emb_shape'])
+        assert rel_mae(r['emb'][idx], g[p + 'emb_rows']) < 1e-4
+        assert rel_mae(r['ref'][idx], g[p + 'ref_rows']) < 1e-4
+        li = r['loss_info']
+        np.testing.assert_allclose([li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']],
+                                   g[p + 'loss_info'], rtol=5e-5)
+        gn = np.array([float(r['grads'][k].double().norm()) for k in o.names])
+        np.testing.assert_allclose(gn, g[p + 'grad_norms'], rtol=5e-3, atol=1e-7)
+        pn = np.array([float(o.P[k].detach().double().norm()) for k in o.names])
+        np.testing.assert_allclose(pn, g[p + 'param_norms'], rtol=2e-4)      # Adam moves every entry by ~lr whatever the gradient size
+        for key in g.files:
+            if key.startswith(p + 'grad/'):
+                k = key[len(p + 'grad/'):]
+                assert rel_mae(r['grads'][k], g[key]) < 5e-3, k            # fp32 cancellation in BN-affine gradients
+                assert rel_mae(o.P[k].detach(), g[p + 'param/' + k]) < 5e-4, k
+        d_eval = o.forward_eval(image1, sparse)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 2e-5

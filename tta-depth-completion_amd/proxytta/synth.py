@@ -75,6 +75,70 @@ def msg_chn_keys(prepare_mode='meta_selfsup_seq_1layer_ema'):
     return keys
 
 
+def _bn_keys(prefix, ch):
+    return [(prefix + '.weight', (ch,)), (prefix + '.bias', (ch,)), (prefix + '.running_mean', (ch,)),
+            (prefix + '.running_var', (ch,)), (prefix + '.num_batches_tracked', ())]
+
+
+def nlspn_keys(prepare_mode='meta_selfsup_seq_1layer_ema'):
+    """Ordered (name, shape) list of the NLSPN TTA network's state_dict: NLSPNModel_Adapt.__init__
+    (external_src/NLSPN/src/model/nlspnmodel_adapt.py:376-452) with the ResNet34 stages [3,4,6,3] of
+    BasicBlocks (:70-116), the propagation layer (:189-253) and the heads / meta layer of
+    _prepare_head (:1333-1376)."""
+    if '1layer' not in prepare_mode:
+        raise NotImplementedError('NLSPN key table covers the canonical 1layer meta layer only')
+    keys = [('conv1_rgb.0.weight', (48, 3, 3, 3)), ('conv1_rgb.0.bias', (48,)),
+            ('conv1_dep.0.weight', (16, 1, 3, 3)), ('conv1_dep.0.bias', (16,))]
+    inpl = 64
+    for stage, (planes, nblocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]):
+        for b in range(nblocks):
+            pre = 'conv%d.%d' % (stage + 2, b)
+            keys += [(pre + '.conv1.weight', (planes, inpl, 3, 3))] + _bn_keys(pre + '.bn1', planes)
+            keys += [(pre + '.conv2.weight', (planes, planes, 3, 3))] + _bn_keys(pre + '.bn2', planes)
+            if b == 0 and (stride != 1 or inpl != planes):
+                keys += [(pre + '.downsample.0.weight', (planes, inpl, 1, 1))] + _bn_keys(pre + '.downsample.1', planes)
+            inpl = planes
+    keys += [('conv6.0.weight', (512, 512, 3, 3))] + _bn_keys('conv6.1', 512)
+    for name, cin, cout in (('dec5', 512, 256), ('dec4', 768, 128), ('dec3', 384, 64), ('dec2', 192, 64)):
+        keys += [(name + '.0.weight', (cin, cout, 3, 3))] + _bn_keys(name + '.1', cout)       # ConvTranspose2d: (Cin, Cout, 3, 3)
+    keys += [('id_dec1.0.weight', (64, 128, 3, 3))] + _bn_keys('id_dec1.1', 64)
+    keys += [('id_dec0.0.weight', (1, 128, 3, 3)), ('id_dec0.0.bias', (1,))]
+    keys += [('gd_dec1.0.weight', (64, 128, 3, 3))] + _bn_keys('gd_dec1.1', 64)
+    keys += [('gd_dec0.0.weight', (8, 128, 3, 3)), ('gd_dec0.0.bias', (8,))]
+    keys += [('cf_dec1.0.weight', (32, 128, 3, 3))] + _bn_keys('cf_dec1.1', 32)
+    keys += [('cf_dec0.0.weight', (1, 96, 3, 3)), ('cf_dec0.0.bias', (1,))]
+    keys += [('prop_layer.aff_scale_const', (1,)), ('prop_layer.w', (1, 1, 3, 3)), ('prop_layer.b', (1,)),
+             ('prop_layer.w_conf', (1, 1, 1, 1)),
+             ('prop_layer.conv_offset_aff.weight', (24, 8, 3, 3)), ('prop_layer.conv_offset_aff.bias', (24,))]
+    keys += _mlp_keys('proj', 512, 1024, 1024)
+    keys += _mlp_keys('proj_t', 512, 1024, 1024)
+    keys += _mlp_keys('pred', 1024, 1024, 1024)
+    keys += [('conv1_rgb_meta.weight', (48, 48, 3, 3)), ('conv1_rgb_meta.bias', (48,))]
+    return keys
+
+
+def formula_state_dict_nlspn(prepare_mode='meta_selfsup_seq_1layer_ema', gain=1.0):
+    sd = {k: formula_tensor(k, s, gain) for k, s in nlspn_keys(prepare_mode)}
+    # fixed (non-trainable) constants of the propagation layer (nlspnmodel_adapt.py:227-247)
+    sd['prop_layer.aff_scale_const'] = np.full((1,), 0.5 * 8, dtype=np.float32)
+    sd['prop_layer.w'] = np.ones((1, 1, 3, 3), dtype=np.float32)
+    sd['prop_layer.b'] = np.zeros((1,), dtype=np.float32)
+    sd['prop_layer.w_conf'] = np.ones((1, 1, 1, 1), dtype=np.float32)
+    # Conditioning of the heads, so the synthetic network behaves like a trained one instead of diverging in the 18
+    # propagation sweeps: metres-scale sparse depth is brought to O(1) by conv1_dep, the initial depth sits at a
+    # positive level (keeps the clamped output free of exact zeros, which the reference's eval path would send to
+    # skimage's biharmonic inpainting), offsets are O(1) pixel and affinities mostly positive.
+    sd['conv1_dep.0.weight'] = (sd['conv1_dep.0.weight'] / 40.0).astype(np.float32)
+    sd['id_dec0.0.bias'] = np.full((1,), 10.0, dtype=np.float32)
+    sd['gd_dec0.0.weight'] = (sd['gd_dec0.0.weight'] * 0.25).astype(np.float32)
+    sd['cf_dec0.0.weight'] = (sd['cf_dec0.0.weight'] * 0.5).astype(np.float32)
+    sd['prop_layer.conv_offset_aff.weight'] = (sd['prop_layer.conv_offset_aff.weight'] * 0.5).astype(np.float32)
+    b = sd['prop_layer.conv_offset_aff.bias'].copy()
+    b[16:] += 0.5
+    sd['prop_layer.conv_offset_aff.bias'] = b
+    return sd
+
+
 def formula_tensor(name, shape, gain=1.0):
     """One state_dict entry, Kaiming-scaled so activations stay O(1) through ~50 layers."""
     n = int(np.prod(shape)) if len(shape) else 1

@@ -25,7 +25,7 @@ extern "C" {
 typedef struct ptta_ctx* ptta_handle;
 typedef void* ptta_stream;              /* hipStream_t */
 
-enum { PTTA_BACKBONE_MSG_CHN = 0 };
+enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1 };
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
 enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
 

@@ -1,0 +1,151 @@
+"""NLSPN backbone on libptta_hip against the oracle (oracle/nlspn_oracle.py) and the golden
+vectors generated from the real reference (tests/golden/nlspn_*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from proxytta import synth
+from proxytta.engine import Engine
+from tests.util import rel_mae
+
+pytestmark = pytest.mark.gpu
+
+MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+HP = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1,
+          max_input_depth=80.0)
+
+
+def nlspn_frame(idx, h, w, n):
+    image01, sparse = synth.synthetic_frame(idx, h, w, n, density=0.1)
+    raw = np.floor(image01 * 255.0).astype(np.float32)
+    return raw, ((raw / np.float32(255.0) - MEAN) / STD).astype(np.float32), sparse
+
+
+def make_nlspn(n, h, w, hp=HP):
+    eng = Engine(n, h, w, backbone='nlspn', **hp)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
+    eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32})
+    adapted = {}
+    for k in eng.adapted:
+        p = sd[k].clone().contiguous()
+        adapted[k] = (p, torch.zeros_like(p), torch.zeros_like(p))
+        eng.bind_adapted(k, *adapted[k])
+    return eng, sd, adapted
+
+
+def _oracle(hp=HP):
+    from oracle import nlspn_oracle as N
+    return N, N.NlspnOracle(synth.formula_state_dict_nlspn(), max_input_depth=hp['max_input_depth'], lr=hp['lr'], betas=hp['betas'],
+                            eps=hp['eps'], weight_decay=hp['weight_decay'], w_sd=hp['w_sparse_depth'], w_sm=hp['w_smoothness'],
+                            w_cos=hp['w_cos'])
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def test_adapted_set_is_the_reference_list():
+    eng, sd, adapted = make_nlspn(1, 32, 64)
+    N, o = _oracle()
+    assert eng.adapted == o.names and len(eng.adapted) == 88 and sum(eng.adapted_numel.values()) == 40048
+    eng.close()
+
+
+@pytest.mark.parametrize('shape', [(1, 32, 64), (2, 48, 80)])
+def test_forward_train_and_eval_match_oracle(shape):
+    n, h, w = shape
+    eng, sd, adapted = make_nlspn(n, h, w)
+    N, o = _oracle()
+    raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(0, h, w, n)]
+    with torch.no_grad():
+        d_ref, e_ref, r_ref, inter = N.network_forward(o.P, image1, torch.clamp(sparse, 0, 80.0), True, want_intermediates=True)
+    depth, emb, ref = eng.forward_train(image1.cuda(), sparse.cuda())
+    fe6 = eng.debug_tensor('fe6').view(2 * n, h // 16, w // 16, 512)[:n]
+    assert rel_mae(fe6, nhwc(inter['fe6'])) < 1e-4
+    assert rel_mae(eng.debug_tensor('pred_init').view(n, 1, h, w), inter['pred_init']) < 1e-4
+    assert rel_mae(eng.debug_tensor('confidence').view(n, 1, h, w), inter['confidence']) < 1e-4
+    off9 = eng.debug_tensor('off9').view(n, h, w, 18).permute(0, 3, 1, 2)
+    aff9 = eng.debug_tensor('aff9').view(n, h, w, 9).permute(0, 3, 1, 2)
+    assert rel_mae(off9, inter['offset']) < 1e-4
+    assert rel_mae(aff9, inter['aff']) < 1e-4
+    assert rel_mae(depth, d_ref) < 1e-4
+    assert rel_mae(emb, e_ref) < 1e-3 and rel_mae(ref, r_ref) < 1e-3
+    d_eval = eng.forward_eval(image1.cuda(), sparse.cuda())
+    assert rel_mae(d_eval, o.forward_eval(image1, sparse)) < 1e-4
+    eng.close()
+
+
+@pytest.mark.parametrize('name', ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical'])
+def test_step_matches_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
+    hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=mid)
+    eng, sd, adapted = make_nlspn(n, h, w, hp)
+    names = [str(x) for x in g['adapted_names']]
+    assert eng.adapted == names
+    for s in range(steps):
+        raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(s, h, w, n)]
+        info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+        p = 's%d/' % s
+        assert rel_mae(depth, g[p + 'depth_train']) < 1e-3            # north_star: 1e-3 relative MAE on depth
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2e-3)
+        if s == 0:
+            # Gradients of the deep BatchNorm affine parameters are ill-conditioned: the fp32 CPU reference itself sits
+            # ~1e-2 from an fp64 evaluation (a few ReLU-mask / sign flips), so 3e-2 is the meaningful bound; after the
+            # first update Adam turns that noise into +-lr parameter moves, so later steps are pinned on depth and loss
+            # here and on gradients by test_second_step_from_oracle_state.
+            gn = np.array([float(eng.grad(k, adapted[k][0]).double().norm()) for k in names])
+            np.testing.assert_allclose(gn, g[p + 'grad_norms'], rtol=3e-2, atol=1e-6)
+            for key in g.files:
+                if key.startswith(p + 'grad/'):
+                    k = key[len(p + 'grad/'):]
+                    assert rel_mae(eng.grad(k, adapted[k][0]), g[key]) < 3e-2, k
+                    assert rel_mae(adapted[k][0], g[p + 'param/' + k]) < 2e-3, k
+        d_eval = eng.forward_eval(image1, sparse)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-3
+    eng.close()
+
+
+def test_second_step_from_oracle_state():
+    """Step 2 of a sequence, started from the oracle's exact post-step-1 parameters and Adam moments: gradients, the
+    Adam update and the depth map against the oracle's second step."""
+    n, h, w = 1, 32, 64
+    N, o = _oracle()
+    raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(0, h, w, n)]
+    o.step(image1, sparse, loss_image=raw)
+    eng, sd, adapted = make_nlspn(n, h, w)
+    for i, k in enumerate(o.names):
+        adapted[k][0].copy_(o.P[k].detach())
+        adapted[k][1].copy_(o.opt.m[i])
+        adapted[k][2].copy_(o.opt.v[i])
+    eng.set_adam_step(1)
+    raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(1, h, w, n)]
+    r = o.step(image1, sparse, loss_image=raw)
+    info, depth = eng.step(image1.cuda(), sparse.cuda(), loss_image=raw.cuda(), want_depth=True)
+    assert eng.adam_step_count() == 2
+    assert rel_mae(depth, r['depth']) < 1e-5
+    for i, k in enumerate(eng.adapted):
+        assert rel_mae(eng.grad(k, adapted[k][0]), r['grads'][k]) < 3e-2, k
+        assert rel_mae(adapted[k][0], o.P[k].detach()) < 2e-3, k
+        assert rel_mae(adapted[k][1], o.opt.m[i]) < 3e-2, k
+    eng.close()
+
+
+def test_fused_image_normalisation_nlspn():
+    n, h, w = 1, 32, 64
+    eng, sd, adapted = make_nlspn(n, h, w)
+    N, o = _oracle()
+    raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(1, h, w, n)]
+    eng.set_image_norm([[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]])
+    d = eng.forward_eval(raw.cuda(), sparse.cuda())
+    assert rel_mae(d, o.forward_eval(image1, sparse)) < 1e-4
+    eng.close()
+
+
+def test_size_must_be_multiple_of_16():
+    with pytest.raises(RuntimeError):
+        Engine(1, 36, 52, backbone='nlspn', **HP)

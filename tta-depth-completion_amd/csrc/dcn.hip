@@ -25,25 +25,6 @@ struct DcnP {
     int B, C, H, W, Co, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw, group, dg;
 };
 
-struct Corner { int h0, w0; float lh, lw; bool inside; };
-__device__ __forceinline__ Corner corner_of(float h, float w, int H, int W) {
-    Corner c;
-    c.inside = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
-    const float fh = floorf(h), fw = floorf(w);
-    c.h0 = (int)fh; c.w0 = (int)fw; c.lh = h - fh; c.lw = w - fw;
-    return c;
-}
-__device__ __forceinline__ float bilinear_at(const float* __restrict__ im, int H, int W, const Corner& c) {
-    if (!c.inside) return 0.f;
-    const int h1 = c.h0 + 1, w1 = c.w0 + 1;
-    const float v1 = (c.h0 >= 0 && c.w0 >= 0) ? im[c.h0 * W + c.w0] : 0.f;
-    const float v2 = (c.h0 >= 0 && w1 <= W - 1) ? im[c.h0 * W + w1] : 0.f;
-    const float v3 = (h1 <= H - 1 && c.w0 >= 0) ? im[h1 * W + c.w0] : 0.f;
-    const float v4 = (h1 <= H - 1 && w1 <= W - 1) ? im[h1 * W + w1] : 0.f;
-    const float hh = 1.f - c.lh, hw = 1.f - c.lw;
-    return hh * hw * v1 + hh * c.lw * v2 + c.lh * hw * v3 + c.lh * c.lw * v4;
-}
-
 __global__ __launch_bounds__(256) void dcn_forward_kernel(DcnP p) {
     const int K = p.kh * p.kw, cpg = p.C / p.group, opg = p.Co / p.group, cpd = p.C / p.dg;
     const long total = (long)p.B * p.Co * p.Ho * p.Wo;

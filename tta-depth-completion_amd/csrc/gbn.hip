@@ -1,0 +1,158 @@
+// Batch-statistics normalisation for the NLSPN backbone, any channel count, on strided NHWC views.
+// adapt_parameters('meta_bn') (src/nlspn_model_adapt.py:322-337) drops the running statistics of every
+// BatchNorm2d, so train AND eval forwards normalise with the statistics of the current batch; the MLP heads'
+// BatchNorm1d (nlspnmodel_adapt.py:1398-1404) are in train mode on the TTA path: same arithmetic with H*W = rows.
+//   forward : mean/var (biased) per (pass, channel) -> y = act(x*scale+shift) [+ res -> relu]
+//   backward: g1 = gy*act'(y);  dbeta = sum g1, dgamma = sum g1*xhat;  gx += gamma*inv*(g1 - dbeta/R - xhat*dgamma/R)
+// "pass" = an equal slice of the batch with its own statistics: the grad pass and the no-grad proxy pass of one
+// step are batched as [real | proxy] and must not share statistics (they are separate forward calls in the
+// reference, nlspnmodel_adapt.py:866-916).  All reductions are two-stage with a fixed order (deterministic).
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+#define GBN_BLOCKS 64
+
+// partial sums over the pixels of one pass: MODE 0: {sum x, sum x^2}; MODE 1: {sum g1, sum g1*xhat}
+// part layout [pass][block][2][C]
+template <int MODE>
+__global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView y, int npass, int act, int res_relu,
+                                                        const float* __restrict__ mean, const float* __restrict__ inv,
+                                                        float* __restrict__ part) {
+    extern __shared__ float red[];                       // [nsub][2][CT]
+    const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
+    const int lc = threadIdx.x % CT, sub = threadIdx.x / CT;
+    const int pass = blockIdx.y;
+    const long ppp = (long)(x.B / npass) * x.H * x.W;    // pixels per pass
+    const long pix0 = (long)pass * ppp;
+    for (int cb = 0; cb < C; cb += CT) {
+        const int c = cb + lc;
+        float s1 = 0.f, s2 = 0.f;
+        if (sub < nsub && c < C) {
+            float mu = 0.f, iv = 0.f;
+            if (MODE == 1) { mu = mean[pass * C + c]; iv = inv[pass * C + c]; }
+            for (long p = (long)blockIdx.x * nsub + sub; p < ppp; p += (long)gridDim.x * nsub) {
+                const float xv = x.p[(pix0 + p) * x.ld + c];
+                if (MODE == 0) { s1 += xv; s2 += xv * xv; }
+                else {
+                    float gv = g.p[(pix0 + p) * g.ld + c];
+                    const float yv = y.p[(pix0 + p) * y.ld + c];
+                    if (res_relu || act == GACT_RELU) gv = yv > 0.f ? gv : 0.f;
+                    else if (act == GACT_LRELU) gv = yv > 0.f ? gv : 0.2f * gv;
+                    s1 += gv; s2 += gv * (xv - mu) * iv;
+                }
+            }
+        }
+        __syncthreads();
+        if (sub < nsub && c < C) { red[(sub * 2 + 0) * CT + lc] = s1; red[(sub * 2 + 1) * CT + lc] = s2; }
+        __syncthreads();
+        if (threadIdx.x < CT && c < C) {
+            float a1 = 0.f, a2 = 0.f;
+            for (int k = 0; k < nsub; ++k) { a1 += red[(k * 2 + 0) * CT + lc]; a2 += red[(k * 2 + 1) * CT + lc]; }
+            float* o = part + (((long)pass * gridDim.x + blockIdx.x) * 2) * C;
+            o[c] = a1; o[C + c] = a2;
+        }
+    }
+}
+
+// forward finalize: per (pass, c): mean, inv, scale = gamma*inv, shift = beta - mean*scale   (st = [4][npass][C])
+__global__ void gbn_finalize_kernel(const float* __restrict__ part, int nblocks, int npass, int C, long R, float eps,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ st) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npass * C) return;
+    const int pass = idx / C, c = idx % C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        const float* o = part + (((long)pass * nblocks + b) * 2) * C;
+        s1 += (double)o[c]; s2 += (double)o[C + c];
+    }
+    const double m = s1 / (double)R;
+    double var = s2 / (double)R - m * m; if (var < 0.0) var = 0.0;
+    const float iv = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * iv;
+    const int n = npass * C;
+    st[idx] = (float)m; st[n + idx] = iv; st[2 * n + idx] = sc; st[3 * n + idx] = beta[c] - (float)m * sc;
+}
+
+// y = act(x*scale+shift) ; with res: y = relu(x*scale+shift + res)   (BasicBlock.forward, nlspnmodel_adapt.py:98-116)
+__global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act, const float* __restrict__ st) {
+    const int C = x.C, n = npass * C;
+    const long total = (long)x.B * x.H * x.W * C;
+    const long ppp = (long)(x.B / npass) * x.H * x.W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C); const long pix = idx / C;
+        const int pass = (int)(pix / ppp);
+        float v = fmaf(x.p[pix * x.ld + c], st[2 * n + pass * C + c], st[3 * n + pass * C + c]);
+        if (res.p) { v += res.p[pix * res.ld + c]; v = v > 0.f ? v : 0.f; }
+        else if (act == GACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        y.p[pix * y.ld + c] = v;
+    }
+}
+
+int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
+                            const float* beta, float* part, float* st, hipStream_t s) {
+    const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
+    const size_t lds = (size_t)nsub * 2 * CT * sizeof(float);
+    const long R = (long)(x.B / npass) * x.H * x.W;
+    int blocks = (int)((R + nsub - 1) / nsub); if (blocks > GBN_BLOCKS) blocks = GBN_BLOCKS; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((gbn_stats_kernel<0>), dim3(blocks, npass), dim3(256), lds, s, x, x, x, npass, 0, 0, nullptr, nullptr, part);
+    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 127) / 128), dim3(128), 0, s, part, blocks, npass, C, R, eps, gamma, beta, st);
+    const long total = (long)x.B * x.H * x.W * C;
+    long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
+    hipLaunchKernelGGL(gbn_apply_kernel, dim3((int)ab), dim3(256), 0, s, x, res, y, npass, act, st);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+int ptta_gbn_part_floats(int C, int npass) { return npass * GBN_BLOCKS * 2 * C; }
+
+// backward finalize (pass 0 = the grad pass only): dbeta, dgamma, and bw = [gscale, c1, c2][C]
+__global__ void gbn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long R, const float* __restrict__ gamma,
+                                        const float* __restrict__ inv, float* dgamma, float* dbeta, float* __restrict__ bw) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) { const float* o = part + ((long)b * 2) * C; s1 += (double)o[c]; s2 += (double)o[C + c]; }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    bw[c] = gamma[c] * inv[c]; bw[C + c] = (float)(s1 / (double)R); bw[2 * C + c] = (float)(s2 / (double)R);
+}
+
+// gx (+)= gscale*(g1 - c1 - xhat*c2) ; gres += g1 (residual branch of a BasicBlock)
+__global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView gres, int act, int res_relu, int acc_gx, int acc_gres,
+                                     const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ bw) {
+    const int C = x.C;
+    const long total = (long)g.B * g.H * g.W * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C); const long pix = idx / C;
+        float gv = g.p[pix * g.ld + c];
+        const float yv = y.p[pix * y.ld + c];
+        if (res_relu || act == GACT_RELU) gv = yv > 0.f ? gv : 0.f;
+        else if (act == GACT_LRELU) gv = yv > 0.f ? gv : 0.2f * gv;
+        const float xh = (x.p[pix * x.ld + c] - mean[c]) * inv[c];
+        const float d = bw[c] * (gv - bw[C + c] - xh * bw[2 * C + c]);
+        float* o = gx.p + pix * gx.ld + c;
+        *o = acc_gx ? *o + d : d;
+        if (gres.p) { float* r = gres.p + pix * gres.ld + c; *r = acc_gres ? *r + gv : gv; }
+    }
+}
+
+// x: raw conv output (saved), g: gradient of y over the grad-pass items (g.B = items of pass 0), y: saved output.
+// st: forward statistics [4][npass][C] (pass 0 is used).  dgamma/dbeta may be null (frozen affine parameters).
+int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, const GView& gx, const GView& gres, int npass, int act,
+                             int res_relu, int acc_gx, int acc_gres, const float* gamma, const float* st, float* part, float* bw, float* dgamma,
+                             float* dbeta, hipStream_t s) {
+    const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
+    const size_t lds = (size_t)nsub * 2 * CT * sizeof(float);
+    GView x0 = x; x0.B = g.B;
+    GView y0 = y; y0.B = g.B;
+    const long R = (long)g.B * g.H * g.W;
+    int blocks = (int)((R + nsub - 1) / nsub); if (blocks > GBN_BLOCKS) blocks = GBN_BLOCKS; if (blocks < 1) blocks = 1;
+    const float* mean = st; const float* inv = st + (long)npass * C;
+    hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part);
+    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, blocks, C, R, gamma, inv, dgamma, dbeta, bw);
+    const long total = R * C;
+    long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
+    hipLaunchKernelGGL(gbn_bwd_apply_kernel, dim3((int)ab), dim3(256), 0, s, x0, g, y0, gx, gres, act, res_relu, acc_gx, acc_gres, mean, inv, bw);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

@@ -19,6 +19,7 @@
 #include "../../include/ptta.h"
 #include "ptta_common.h"
 #include "ptta_kernels.h"
+#include "nlspn.h"
 
 #define PTTA_VERSION 1
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return c->fail(std::string(#x) + ": " + hipGetErrorString(e_), -100 - (int)e_); } while (0)
@@ -39,6 +40,7 @@ struct Dbg { const void* p; long numel; int is_act; };
 struct ImgNorm { int on; float div; float mean[3]; float stdv[3]; };
 
 struct ptta_ctx {
+    nlspn_engine* nl = nullptr;      // backbone NLSPN: every entry point forwards to nlspn_api.hip
     int N = 1, H = 0, W = 0, Hp = 0, Wp = 0, pt = 0, pr = 0, dual = 0, Nn = 1;
     int bf16 = 0, naive = 0, es = 4, x3 = 1;
     ptta_hparams hp{};
@@ -767,13 +769,23 @@ extern "C" {
 
 int ptta_version(void) { return PTTA_VERSION; }
 
-const char* ptta_last_error(ptta_handle h) { return h ? h->err.c_str() : "null handle"; }
+const char* ptta_last_error(ptta_handle h) { return h ? (h->nl && h->err.empty() ? nlspn_last_error(h->nl) : h->err.c_str()) : "null handle"; }
 
 int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int height, int width, int dtype, const ptta_hparams* hp) {
     if (!out) return -1;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -19;          // no HIP device: fail loudly
+    if (backbone_id == PTTA_BACKBONE_NLSPN) {
+        if (meta_mode != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32) return -38;
+        int rc = 0;
+        nlspn_engine* e = nlspn_create(n, height, width, hp, &rc);
+        if (!e) return rc ? rc : -12;
+        ptta_ctx* c = new ptta_ctx();
+        c->nl = e; c->N = n; c->H = height; c->W = width; c->hp = *hp;
+        *out = c;
+        return 0;
+    }
     if (backbone_id != PTTA_BACKBONE_MSG_CHN || (meta_mode != PTTA_META_1LAYER && meta_mode != PTTA_META_2LAYERS)) return -38;
     if (n < 1 || height < 16 || width < 16 || (dtype != PTTA_DTYPE_F32 && dtype != PTTA_DTYPE_BF16) || !hp) return -22;
     ptta_ctx* c = new ptta_ctx();
@@ -801,6 +813,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
 
 void ptta_destroy(ptta_handle h) {
     if (!h) return;
+    if (h->nl) { nlspn_destroy(h->nl); delete h; return; }
     h->drop_graphs();
     if (h->cap_stream) hipStreamDestroy(h->cap_stream);
     if (h->aux_stream) { hipStreamDestroy(h->aux_stream); hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); }
@@ -810,6 +823,8 @@ void ptta_destroy(ptta_handle h) {
 }
 
 int ptta_set_hparams(ptta_handle c, const ptta_hparams* hp, ptta_stream s) {
+    if (c && c->nl) return nlspn_set_hparams(c->nl, hp, (hipStream_t)s);
+
     if (!c || !hp) return -1;
     if (hp->max_input_depth != c->hp.max_input_depth) c->drop_graphs();     // baked into kernel arguments
     c->hp = *hp;
@@ -819,6 +834,8 @@ int ptta_set_hparams(ptta_handle c, const ptta_hparams* hp, ptta_stream s) {
 static long shape_numel(const int64_t* shape, int ndim) { long n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
 
 int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, const int64_t* shape, int ndim, ptta_stream s_) {
+    if (c && c->nl) return nlspn_load_weights(c->nl, name_, tensor, shape, ndim, (hipStream_t)s_);
+
     if (!c || !name_ || !tensor) return -1;
     c->drop_graphs();
     hipStream_t s = (hipStream_t)s_;
@@ -905,6 +922,8 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
 }
 
 int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp_avg, float* exp_avg_sq) {
+    if (c && c->nl) return nlspn_bind_adapted(c->nl, name_, param, exp_avg, exp_avg_sq);
+
     if (!c || !name_ || !param) return -1;
     c->drop_graphs();
     const std::string name(name_);
@@ -917,13 +936,17 @@ int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp
     return c->fail("not an adapted parameter: " + name, -2);
 }
 
-int ptta_adapted_count(ptta_handle c) { return c ? (int)c->adapted.size() : 0; }
+int ptta_adapted_count(ptta_handle c) { return c ? (c->nl ? nlspn_adapted_count(c->nl) : (int)c->adapted.size()) : 0; }
 const char* ptta_adapted_name(ptta_handle c, int index, int64_t* numel) {
+    if (c && c->nl) return nlspn_adapted_name(c->nl, index, numel);
+
     if (!c || index < 0 || index >= (int)c->adapted.size()) return nullptr;
     if (numel) *numel = c->adapted[index].n;
     return c->adapted[index].name.c_str();
 }
 int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity, ptta_stream s) {
+    if (c && c->nl) return nlspn_get_grad(c->nl, name, dst, capacity, (hipStream_t)s);
+
     if (!c || !name || !dst) return -1;
     for (auto& ad : c->adapted)
         if (ad.name == name) {
@@ -935,21 +958,27 @@ int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity,
 }
 
 int ptta_set_adam_step(ptta_handle c, int step, ptta_stream s) {
+    if (c && c->nl) return nlspn_set_adam_step(c->nl, step, (hipStream_t)s);
+
     if (!c) return -1;
     HIPCHK(hipMemcpyAsync(c->step_dev, &step, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)s));
     HIPCHK(hipStreamSynchronize((hipStream_t)s));
     return 0;
 }
 int ptta_get_adam_step(ptta_handle c, int* step, ptta_stream s) {
+    if (c && c->nl) return nlspn_get_adam_step(c->nl, step, (hipStream_t)s);
+
     if (!c || !step) return -1;
     HIPCHK(hipMemcpyAsync(step, c->step_dev, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)s));
     HIPCHK(hipStreamSynchronize((hipStream_t)s));
     return 0;
 }
 
-int64_t ptta_embedding_rows(ptta_handle c) { return c ? c->Rg : 0; }
+int64_t ptta_embedding_rows(ptta_handle c) { return c ? (c->nl ? nlspn_embedding_rows(c->nl) : c->Rg) : 0; }
 
 int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, float* depth_out, float* emb_out, float* ref_out, ptta_stream s_) {
+    if (c && c->nl) return nlspn_forward_train(c->nl, image, sparse, depth_out, emb_out, ref_out, (hipStream_t)s_);
+
     if (!c || !image || !sparse) return -1;
     hipStream_t s = (hipStream_t)s_;
     c->fwd_valid = false;
@@ -963,6 +992,8 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
 }
 
 int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, float* depth_out, ptta_stream s_) {
+    if (c && c->nl) return nlspn_forward_eval(c->nl, image, sparse, depth_out, (hipStream_t)s_);
+
     if (!c || !image || !sparse || !depth_out) return -1;
     hipStream_t s = (hipStream_t)s_;
     c->fwd_valid = false;                      // the eval pass overwrites the saved activations
@@ -974,6 +1005,8 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
 int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                       const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos,
                       float* loss_info_out, ptta_stream s_) {
+    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+
     if (!c || !loss_image || !depth || !sparse || !validity || !loss_info_out) return -1;
     if (rows > c->Rg) return c->fail("rows exceeds the handle's embedding rows", -22);
     hipStream_t s = (hipStream_t)s_;
@@ -987,6 +1020,8 @@ int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth
 
 int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                        const float* emb, const float* ref, int64_t rows, float* gdepth, float* gref, ptta_stream s_) {
+    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+
     if (!c || !loss_image || !depth || !sparse || !validity || !gdepth) return -1;
     RUN(ptta_launch_loss_backward(depth, loss_image, sparse, validity, c->hp.max_input_depth, emb, ref, rows, 512,
                                   c->N, c->H, c->W, c->loss_ws, gdepth, gref, (hipStream_t)s_));
@@ -994,6 +1029,8 @@ int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* dept
 }
 
 int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref, float* gw_out, float* gb_out, ptta_stream s_) {
+    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+
     if (!c || !grad_depth) return -1;
     if (!c->fwd_valid) return c->fail("ptta_backward without a preceding ptta_forward_train", -3);
     hipStream_t s = (hipStream_t)s_;
@@ -1022,6 +1059,8 @@ int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref,
 }
 
 int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream s_) {
+    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+
     if (!c) return -1;
     for (auto& ad : c->adapted) if (!ad.p || !ad.m || !ad.v) return c->fail("Adam state of " + ad.name + " not bound", -3);
     if ((gw || gb) && c->meta_mode != PTTA_META_1LAYER) return c->fail("explicit gradients are a 1layer convenience; use the internal ones", -22);
@@ -1057,6 +1096,7 @@ static int step_body(ptta_handle c, const float* image, const float* loss_image,
 int ptta_step(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
               float* depth_out, float* loss_info_out, ptta_stream s_) {
     if (!c || !image || !sparse) return -1;
+    if (c->nl) return nlspn_step(c->nl, image, loss_image, sparse, validity, depth_out, loss_info_out, (hipStream_t)s_);
     hipStream_t s = (hipStream_t)s_;
     if (!loss_image) loss_image = image;
     const size_t ibytes = (size_t)c->N * 3 * c->H * c->W * 4, pbytes = (size_t)c->N * c->H * c->W * 4;
@@ -1090,6 +1130,8 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
 }
 
 int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const float* stdv) {
+    if (c && c->nl) return nlspn_set_image_norm(c->nl, divisor, mean, stdv);
+
     if (!c) return -1;
     if (!(divisor > 0.f)) return c->fail("ptta_set_image_norm: divisor must be positive", -22);
     ImgNorm nm = ImgNorm{0, divisor, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
@@ -1105,6 +1147,8 @@ int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const f
 }
 
 int ptta_set_graph(ptta_handle c, int enable) {
+    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+
     if (!c) return -1;
     c->use_graph = enable ? 1 : 0;
     if (!enable) c->drop_graphs();
@@ -1153,6 +1197,8 @@ int ptta_mdconv_backward(const float* input, const float* weight, const float* b
 }
 
 int ptta_profile(ptta_handle c, int enable) {
+    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+
     if (!c) return -1;
     c->prof_on = enable != 0;
     for (auto& pc : c->prof) { pc.used = 0; pc.bytes = 0; pc.macs = 0; }
@@ -1160,6 +1206,8 @@ int ptta_profile(ptta_handle c, int enable) {
 }
 
 int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_bytes, double* macs, int64_t* launches, ptta_stream s_) {
+    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+
     if (!c || klass < 0 || klass >= 6) return -1;
     HIPCHK(hipStreamSynchronize((hipStream_t)s_));
     ptta_ctx::ProfClass& pc = c->prof[klass];
@@ -1177,6 +1225,8 @@ int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_by
 }
 
 int ptta_debug_tensor(ptta_handle c, const char* name, float* dst, int64_t capacity, int64_t* numel_host, ptta_stream s_) {
+    if (c && c->nl) return nlspn_debug_tensor(c->nl, name, dst, capacity, numel_host, (hipStream_t)s_);
+
     if (!c || !name) return -1;
     auto it = c->dbg.find(name);
     if (it == c->dbg.end()) return c->fail(std::string("no debug tensor ") + name, -2);

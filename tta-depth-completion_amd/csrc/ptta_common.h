@@ -174,4 +174,27 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // conv geometry
 enum { CONV_S1 = 0, CONV_S2 = 1, CONV_T2 = 2 };
 
+// ---- bilinear sampling with the deformable-convolution boundary rule (modulated_deform_im2col_cuda.cuh:25-54,:180):
+// a sample contributes iff -1 < h < H and -1 < w < W; corners outside the image read 0
+struct Corner { int h0, w0; float lh, lw; bool inside; };
+__device__ __forceinline__ Corner corner_of(float h, float w, int H, int W) {
+    Corner c;
+    c.inside = (h > -1.f) && (w > -1.f) && (h < (float)H) && (w < (float)W);
+    const float fh = floorf(h), fw = floorf(w);
+    c.h0 = (int)fh; c.w0 = (int)fw; c.lh = h - fh; c.lw = w - fw;
+    return c;
+}
+__device__ __forceinline__ float bilinear_at(const float* __restrict__ im, int H, int W, const Corner& c) {
+    if (!c.inside) return 0.f;
+    const int h1 = c.h0 + 1, w1 = c.w0 + 1;
+    const float v1 = (c.h0 >= 0 && c.w0 >= 0) ? im[c.h0 * W + c.w0] : 0.f;
+    const float v2 = (c.h0 >= 0 && w1 <= W - 1) ? im[c.h0 * W + w1] : 0.f;
+    const float v3 = (h1 <= H - 1 && c.w0 >= 0) ? im[h1 * W + c.w0] : 0.f;
+    const float v4 = (h1 <= H - 1 && w1 <= W - 1) ? im[h1 * W + w1] : 0.f;
+    const float hh = 1.f - c.lh, hw = 1.f - c.lw;
+    return hh * hw * v1 + hh * c.lw * v2 + c.lh * hw * v3 + c.lh * c.lw * v4;
+}
+
+
+
 #define PTTA_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -142,3 +142,38 @@ struct DcnArgs {
 };
 int ptta_launch_dcn_forward(const DcnArgs& a, hipStream_t s);
 int ptta_launch_dcn_backward(const DcnArgs& a, hipStream_t s);
+
+// ---- generic NHWC layers of the NLSPN backbone: gconv.hip / gbn.hip / nlspn_prop.hip -----------------------------
+enum { GACT_NONE = 0, GACT_RELU = 1, GACT_LRELU = 2, GACT_SIGMOID = 3 };
+struct GView {           // strided NHWC view: element (b,y,x,c) at p[((b*H + y)*W + x)*ld + c]; p already includes the channel offset
+    float* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0;
+};
+struct GConvArgs {
+    GView x, y;
+    const float* w = nullptr;       // packed [tap][cin][cout] (ptta_gpack)
+    const float* bias = nullptr;    // [cout] or null
+    int k = 3, stride = 1, transposed = 0, act = GACT_NONE, accumulate = 0;
+    long wld = 0, wts = 0;          // weight row stride (columns of the packed matrix) and tap stride; 0 = dense (cout, cin*cout)
+};
+void ptta_gpack(const float* src, float* dst, int KK, int A, int B, long a_stride, long b_stride, int flip, hipStream_t s);
+int ptta_launch_gconv_direct(const GConvArgs& a, hipStream_t s);
+int ptta_launch_gact_bwd(const GView& g, const GView& y, int act, hipStream_t s);
+int ptta_launch_gnchw_to_nhwc(const float* src, int src_nb, const GView& y, int zero_from_b, int norm, float div, const float* mean,
+                              const float* stdv, hipStream_t s);
+int ptta_gwgrad_slabs(long pixels);
+int ptta_launch_gwgrad(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s);
+
+int ptta_gbn_part_floats(int C, int npass);
+int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
+                            const float* beta, float* part, float* st, hipStream_t s);
+int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, const GView& gx, const GView& gres, int npass, int act,
+                             int res_relu, int acc_gx, int acc_gres, const float* gamma, const float* st, float* part, float* bw,
+                             float* dgamma, float* dbeta, hipStream_t s);
+
+int ptta_launch_nl_affinity_fwd(const GView& oa, const float* conf, const float* S, int legacy, float* off9, float* aff9, hipStream_t s);
+int ptta_launch_nl_prop_fwd(const float* feat, const float* fix, const float* off9, const float* aff9, float* out, int B, int H, int W,
+                            hipStream_t s);
+int ptta_launch_nl_prop_bwd(const float* feat, const float* fix, const float* off9, const float* aff9, const float* gout, float* gfeat,
+                            float* goff9, float* gaff9, int B, int H, int W, hipStream_t s);
+int ptta_launch_nl_affinity_bwd(const GView& oa, const float* conf, const float* S, int legacy, const float* goff9, const float* gaff9,
+                                const GView& goa, float* gconf, hipStream_t s);

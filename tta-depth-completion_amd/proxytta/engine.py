@@ -47,7 +47,7 @@ class Engine:
 
     def __init__(self, n, height, width, dtype='fp32', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0,
-                 max_input_depth=None, meta='1layer'):
+                 max_input_depth=None, meta='1layer', backbone='msg_chn'):
         if not torch.cuda.is_available():
             raise RuntimeError('proxytta needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
@@ -55,17 +55,29 @@ class Engine:
         self.n, self.h, self.w = int(n), int(height), int(width)
         self.dtype = dtype
         self.meta = meta
+        self.backbone = backbone
+        self.emb_dim = 1024 if backbone == 'nlspn' else 512
         self.adapted = adapted_names(meta)
         self.hp = Hparams(lr, betas[0], betas[1], eps, weight_decay, w_sparse_depth, w_smoothness,
                           w_cos, -1.0 if max_input_depth is None else float(max_input_depth))
         self.handle = c_void_p()
         code = {'fp32': _lib.PTTA_DTYPE_F32, 'bf16': _lib.PTTA_DTYPE_BF16}[dtype]
-        rc = self.lib.ptta_create(byref(self.handle), _lib.PTTA_BACKBONE_MSG_CHN,
+        rc = self.lib.ptta_create(byref(self.handle),
+                                  _lib.PTTA_BACKBONE_NLSPN if backbone == 'nlspn' else _lib.PTTA_BACKBONE_MSG_CHN,
                                   _lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER,
                                   self.n, self.h, self.w, code, byref(self.hp))
         if rc != 0:
             raise RuntimeError('ptta_create failed (%d)' % rc)
         self.rows = int(self.lib.ptta_embedding_rows(self.handle))
+        if backbone == 'nlspn':
+            # 88 tensors (conv1_rgb_meta + every BatchNorm2d gamma/beta, src/nlspn_model_adapt.py:322-337): ask the library
+            self.adapted = []
+            self.adapted_numel = {}
+            for i in range(int(self.lib.ptta_adapted_count(self.handle))):
+                n = c_int64(0)
+                name = self.lib.ptta_adapted_name(self.handle, i, byref(n)).decode()
+                self.adapted.append(name)
+                self.adapted_numel[name] = int(n.value)
         self._keep = {}           # tensors whose storage the library borrows
         self.device = torch.device('cuda', torch.cuda.current_device())
 
@@ -134,7 +146,7 @@ class Engine:
         depth = torch.empty((self.n, 1, self.h, self.w), device=image.device, dtype=torch.float32)
         emb = ref = None
         if want_emb:
-            emb = torch.empty((self.rows, 512), device=image.device, dtype=torch.float32)
+            emb = torch.empty((self.rows, self.emb_dim), device=image.device, dtype=torch.float32)
             ref = torch.empty_like(emb)
         self._chk(self.lib.ptta_forward_train(self.handle, ptr(image), ptr(sparse), ptr(depth), ptr(emb),
                                               ptr(ref), _stream()), 'ptta_forward_train')

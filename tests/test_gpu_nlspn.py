@@ -24,8 +24,26 @@ def nlspn_frame(idx, h, w, n):
     return raw, ((raw / np.float32(255.0) - MEAN) / STD).astype(np.float32), sparse
 
 
-def make_nlspn(n, h, w, hp=HP):
-    eng = Engine(n, h, w, backbone='nlspn', **hp)
+# 'naive': direct fp32 kernels everywhere (exact arithmetic, tight bounds); 'default': bf16x3 matrix-core convolutions
+# (each product carries ~2^-17 relative error, through ~40 normalised layers)
+TOL = {'naive': dict(feat=1e-4, depth=1e-4, emb=1e-3, grad=3e-2, param=2e-3),
+       'default': dict(feat=1e-3, depth=1e-3, emb=5e-3, grad=8e-2, param=4e-3)}
+MODES = ['naive', 'default']
+
+
+def make_nlspn(n, h, w, hp=HP, impl='default'):
+    old = os.environ.get('PTTA_CONV_IMPL')
+    if impl == 'naive':
+        os.environ['PTTA_CONV_IMPL'] = 'naive'
+    else:
+        os.environ.pop('PTTA_CONV_IMPL', None)
+    try:
+        eng = Engine(n, h, w, backbone='nlspn', **hp)
+    finally:
+        if old is None:
+            os.environ.pop('PTTA_CONV_IMPL', None)
+        else:
+            os.environ['PTTA_CONV_IMPL'] = old
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
     eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32})
     adapted = {}
@@ -54,37 +72,41 @@ def test_adapted_set_is_the_reference_list():
     eng.close()
 
 
+@pytest.mark.parametrize('impl', MODES)
 @pytest.mark.parametrize('shape', [(1, 32, 64), (2, 48, 80)])
-def test_forward_train_and_eval_match_oracle(shape):
+def test_forward_train_and_eval_match_oracle(shape, impl):
     n, h, w = shape
-    eng, sd, adapted = make_nlspn(n, h, w)
+    tol = TOL[impl]
+    eng, sd, adapted = make_nlspn(n, h, w, impl=impl)
     N, o = _oracle()
     raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(0, h, w, n)]
     with torch.no_grad():
         d_ref, e_ref, r_ref, inter = N.network_forward(o.P, image1, torch.clamp(sparse, 0, 80.0), True, want_intermediates=True)
     depth, emb, ref = eng.forward_train(image1.cuda(), sparse.cuda())
     fe6 = eng.debug_tensor('fe6').view(2 * n, h // 16, w // 16, 512)[:n]
-    assert rel_mae(fe6, nhwc(inter['fe6'])) < 1e-4
-    assert rel_mae(eng.debug_tensor('pred_init').view(n, 1, h, w), inter['pred_init']) < 1e-4
-    assert rel_mae(eng.debug_tensor('confidence').view(n, 1, h, w), inter['confidence']) < 1e-4
+    assert rel_mae(fe6, nhwc(inter['fe6'])) < tol['feat']
+    assert rel_mae(eng.debug_tensor('pred_init').view(n, 1, h, w), inter['pred_init']) < tol['feat']
+    assert rel_mae(eng.debug_tensor('confidence').view(n, 1, h, w), inter['confidence']) < tol['feat']
     off9 = eng.debug_tensor('off9').view(n, h, w, 18).permute(0, 3, 1, 2)
     aff9 = eng.debug_tensor('aff9').view(n, h, w, 9).permute(0, 3, 1, 2)
-    assert rel_mae(off9, inter['offset']) < 1e-4
-    assert rel_mae(aff9, inter['aff']) < 1e-4
-    assert rel_mae(depth, d_ref) < 1e-4
-    assert rel_mae(emb, e_ref) < 1e-3 and rel_mae(ref, r_ref) < 1e-3
+    assert rel_mae(off9, inter['offset']) < tol['feat']
+    assert rel_mae(aff9, inter['aff']) < tol['feat']
+    assert rel_mae(depth, d_ref) < tol['depth']
+    assert rel_mae(emb, e_ref) < tol['emb'] and rel_mae(ref, r_ref) < tol['emb']
     d_eval = eng.forward_eval(image1.cuda(), sparse.cuda())
-    assert rel_mae(d_eval, o.forward_eval(image1, sparse)) < 1e-4
+    assert rel_mae(d_eval, o.forward_eval(image1, sparse)) < tol['depth']
     eng.close()
 
 
+@pytest.mark.parametrize('impl', MODES)
 @pytest.mark.parametrize('name', ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical'])
-def test_step_matches_golden(golden_dir, name):
+def test_step_matches_golden(golden_dir, name, impl):
+    tol = TOL[impl]
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps = [int(x) for x in g['meta']]
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
     hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=mid)
-    eng, sd, adapted = make_nlspn(n, h, w, hp)
+    eng, sd, adapted = make_nlspn(n, h, w, hp, impl=impl)
     names = [str(x) for x in g['adapted_names']]
     assert eng.adapted == names
     for s in range(steps):
@@ -99,25 +121,27 @@ def test_step_matches_golden(golden_dir, name):
             # first update Adam turns that noise into +-lr parameter moves, so later steps are pinned on depth and loss
             # here and on gradients by test_second_step_from_oracle_state.
             gn = np.array([float(eng.grad(k, adapted[k][0]).double().norm()) for k in names])
-            np.testing.assert_allclose(gn, g[p + 'grad_norms'], rtol=3e-2, atol=1e-6)
+            np.testing.assert_allclose(gn, g[p + 'grad_norms'], rtol=tol['grad'], atol=1e-6)
             for key in g.files:
                 if key.startswith(p + 'grad/'):
                     k = key[len(p + 'grad/'):]
-                    assert rel_mae(eng.grad(k, adapted[k][0]), g[key]) < 3e-2, k
-                    assert rel_mae(adapted[k][0], g[p + 'param/' + k]) < 2e-3, k
+                    assert rel_mae(eng.grad(k, adapted[k][0]), g[key]) < tol['grad'], k
+                    assert rel_mae(adapted[k][0], g[p + 'param/' + k]) < tol['param'], k
         d_eval = eng.forward_eval(image1, sparse)
         assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-3
     eng.close()
 
 
-def test_second_step_from_oracle_state():
+@pytest.mark.parametrize('impl', MODES)
+def test_second_step_from_oracle_state(impl):
     """Step 2 of a sequence, started from the oracle's exact post-step-1 parameters and Adam moments: gradients, the
     Adam update and the depth map against the oracle's second step."""
     n, h, w = 1, 32, 64
     N, o = _oracle()
     raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(0, h, w, n)]
     o.step(image1, sparse, loss_image=raw)
-    eng, sd, adapted = make_nlspn(n, h, w)
+    tol = TOL[impl]
+    eng, sd, adapted = make_nlspn(n, h, w, impl=impl)
     for i, k in enumerate(o.names):
         adapted[k][0].copy_(o.P[k].detach())
         adapted[k][1].copy_(o.opt.m[i])
@@ -127,11 +151,11 @@ def test_second_step_from_oracle_state():
     r = o.step(image1, sparse, loss_image=raw)
     info, depth = eng.step(image1.cuda(), sparse.cuda(), loss_image=raw.cuda(), want_depth=True)
     assert eng.adam_step_count() == 2
-    assert rel_mae(depth, r['depth']) < 1e-5
+    assert rel_mae(depth, r['depth']) < tol['depth']
     for i, k in enumerate(eng.adapted):
-        assert rel_mae(eng.grad(k, adapted[k][0]), r['grads'][k]) < 3e-2, k
-        assert rel_mae(adapted[k][0], o.P[k].detach()) < 2e-3, k
-        assert rel_mae(adapted[k][1], o.opt.m[i]) < 3e-2, k
+        assert rel_mae(eng.grad(k, adapted[k][0]), r['grads'][k]) < tol['grad'], k
+        assert rel_mae(adapted[k][0], o.P[k].detach()) < tol['param'], k
+        assert rel_mae(adapted[k][1], o.opt.m[i]) < tol['grad'], k
     eng.close()
 
 

@@ -1,0 +1,197 @@
+// Matrix-core path of the generic NHWC convolution (NLSPN backbone): stride-1 3x3 (and 1x1) convolutions with any
+// channel counts that are multiples of 16, one or two channel-concatenated sources, fp32 storage, bf16x3 arithmetic
+// (x = xh + xl, w = wh + wl; xl*wh + xh*wl + xh*wh on v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the same
+// arithmetic as the MSG_CHN hot path (conv32.hip), generalised over input-channel chunks and output-channel tiles.
+//
+// Block = 256 threads = 4 waves, output tile 8 rows x 32 pixels x 32 output channels (one MFMA column fragment).
+// K loop over 32-channel chunks of the source(s): the (8+2)x(32+2) halo of the chunk is split into bf16 hi/lo while
+// it is staged into LDS ([pixel][hi 64 B | lo 64 B], 144-B stride: conflict-free ds_read_b128), the chunk's weight
+// fragments come pre-split from global memory: hi in registers (72 VGPRs), lo in LDS.  Each wave owns two rows of
+// the tile: 2 x f32x16 accumulators live across the whole K loop.  The next chunk's halo loads are issued before
+// the current chunk's MFMAs.  Output channel tiles of the same pixel tile are adjacent in the grid (L2 reuse).
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void gsplit2(float a, float b, unsigned& hi, unsigned& lo) {
+    float2_t v = {a, b};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    float2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+}
+__device__ __forceinline__ int gstage_pix(int idx) { return ((idx >> 5) << 3) + (((idx >> 2) & 1) << 2) + ((idx >> 3) & 3); }
+
+#define GX_TH 8
+#define GX_STRIDE 144
+
+// fragment (nf, chunk, tap, kk): lane l holds column co = 32 nf + (l & 31), rows ci = 32 chunk + 16 kk + 8 (l >> 5) + e
+__global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1,
+                                  int Co, int nchunks, int nf_total, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+    const long total = (long)nf_total * nchunks * KK * 2 * 64 * 8;
+    const int nch0 = (C0 + 31) / 32;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(idx & 7); long t_ = idx >> 3;
+        const int lane = (int)(t_ & 63); t_ >>= 6;
+        const int kk = (int)(t_ & 1); t_ >>= 1;
+        const int t = (int)(t_ % KK); t_ /= KK;
+        const int c = (int)(t_ % nchunks); const int nf = (int)(t_ / nchunks);
+        const int s = c < nch0 ? 0 : 1;
+        const int cl = (s == 0 ? c : c - nch0) * 32 + kk * 16 + (lane >> 5) * 8 + e;
+        const int Cs = s == 0 ? C0 : C1;
+        const int co = nf * 32 + (lane & 31);
+        float v = 0.f;
+        if (cl < Cs && co < Co) v = canon[(long)t * wts + (long)((s == 0 ? c0_0 : c0_1) + cl) * wld + co];
+        const bf16_t h = f2bf(v);
+        hi[idx] = h; lo[idx] = f2bf(v - bf2f(h));
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void gconv_x3_s1_kernel(GX3Args p) {
+    constexpr int PAD = KS / 2, PH = GX_TH + 2 * PAD, PW = 32 + 2 * PAD, KK = KS * KS;
+    constexpr int NIT = (((PH * PW + 7) / 8) * 32 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[PH * PW * GX_STRIDE + KK * 2 * 64 * 16];
+    unsigned char* const wl_lds = lds + PH * PW * GX_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W;
+    const int ntx = (W + 31) >> 5, nty = (H + GX_TH - 1) / GX_TH;
+    // block -> (pixel tile, output-channel tile); channel tile fastest
+    const int nfl = (int)(blockIdx.x % p.nnf);
+    long t_ = blockIdx.x / p.nnf;
+    const int ty = (int)(t_ % nty); t_ /= nty;
+    const int tx = (int)(t_ % ntx);
+    const int b = (int)(t_ / ntx);
+    const int y0 = ty * GX_TH, x0 = tx << 5;
+    const int nf = p.nf0 + nfl;
+    const int nch0 = (p.C0 + 31) >> 5;
+
+    float4 v0[NIT], v1[NIT];
+    auto issue_loads = [&](int c) {
+        const bool s1 = c >= nch0;
+        const float* src = s1 ? p.x1 : p.x0;
+        const int ld = s1 ? p.ld1 : p.ld0, Cs = s1 ? p.C1 : p.C0, cb = (s1 ? c - nch0 : c) << 5;
+        const float* inb = src + (size_t)b * H * W * ld + cb;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int g = idx & 3, pix = gstage_pix(idx);
+            const int py = pix / PW, px = pix - py * PW;
+            const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
+            if (pix < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W && cb + 8 * g < Cs) {
+                const float* q = inb + ((size_t)gy * W + gx) * ld + 8 * g;
+                v0[it] = *(const float4*)q; v1[it] = *(const float4*)(q + 4);
+            }
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
+
+    issue_loads(0);
+    for (int c = 0; c < p.nchunks; ++c) {
+        // this chunk's weight fragments: hi -> registers, lo -> LDS
+        uint4 wh[KK][2];
+        const uint4* ph = p.whi + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64);
+        const uint4* pl = p.wlo + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64);
+#pragma unroll
+        for (int t = 0; t < KK; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+        if (c) __syncthreads();                       // the previous chunk's MFMAs are done with the LDS tile
+        for (int idx = tid; idx < KK * 2 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int pix = gstage_pix(idx);
+            if (pix < PH * PW) {
+                const float4 a0 = v0[it], a1 = v1[it];
+                uint4 hi, lo;
+                gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
+                gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
+                unsigned char* dst = lds + pix * GX_STRIDE + 16 * (idx & 3);
+                *(uint4*)dst = hi;
+                *(uint4*)(dst + 64) = lo;
+            }
+        }
+        if (c + 1 < p.nchunks) issue_loads(c + 1);
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap) {
+                const int ky = tap / KS, kx = tap % KS;
+                const unsigned char* a = lds + ((row + ky) * PW + i + kx) * GX_STRIDE + 16 * h;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[rr], 0, 0, 0);
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[rr], 0, 0, 0);
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rr], 0, 0, 0);
+                }
+                if (kx == KS - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // epilogue: lane = output channel (column i of the fragment), 16 pixels per lane
+    const int co = nf * 32 + i - p.nf0 * 32;          // channel inside the output view
+    if (co >= p.Cy) return;
+    const float bias = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int y = y0 + 2 * wave + rr;
+        if (y >= H) continue;
+        float* yrow = p.y + ((size_t)b * H + y) * W * p.ldy + co;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int x = x0 + acc_row(r, h);
+            if (x >= W) continue;
+            float* dst = yrow + (size_t)x * p.ldy;
+            float v = acc[rr][r] + bias;
+            if (p.accumulate) v += *dst;
+            if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+            else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+            *dst = v;
+        }
+    }
+}
+
+}  // namespace
+
+void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
+                     hipStream_t s) {
+    const int nchunks = (C0 + 31) / 32 + (C1 + 31) / 32, nf_total = (Co + 31) / 32;
+    const long total = (long)nf_total * nchunks * KK * 2 * 64 * 8;
+    long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(gfrag_pack_kernel, dim3((int)blocks), dim3(256), 0, s, canon, wld, wts, KK, C0, C1, c0_0, c0_1, Co, nchunks, nf_total, hi, lo);
+}
+long ptta_gfrag_elems(int KK, int C0, int C1, int Co) {
+    return (long)((Co + 31) / 32) * ((C0 + 31) / 32 + (C1 + 31) / 32) * KK * 2 * 64 * 8;
+}
+
+int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
+    if ((a.C0 & 15) || (a.C1 & 15) || (a.ld0 & 3) || (a.ld1 & 3)) return -22;
+    if (a.nchunks != (a.C0 + 31) / 32 + (a.C1 + 31) / 32) return -22;
+    const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + GX_TH - 1) / GX_TH);
+    const long blocks = tiles * a.nnf;
+    if (blocks < 1 || blocks > 0x7fffffffL) return -22;
+    if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else if (ks == 1) hipLaunchKernelGGL((gconv_x3_s1_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else return -22;
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}

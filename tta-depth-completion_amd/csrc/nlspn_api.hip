@@ -45,6 +45,9 @@ struct Tn {
 struct GConvW {            // frozen convolution weights, packed once at load time
     float *wf = nullptr, *wb = nullptr, *bias = nullptr;
     int Ci = 0, Co = 0, k = 3, stride = 1, transposed = 0;
+    int C0 = 0, C1 = 0;                                   // source split of the input channels (torch.cat order)
+    bf16_t *ff_hi = nullptr, *ff_lo = nullptr, *fb_hi = nullptr, *fb_lo = nullptr;     // bf16x3 MFMA fragments (forward / data gradient)
+    bool mf = false, mb = false;                          // matrix-core kernel usable for forward / data gradient
     bool loaded = false, has_bias = false;
 };
 
@@ -112,7 +115,8 @@ struct nlspn_engine {
     int t_img = -1, t_sd = -1, t_pred = -1, t_oa = -1, t_conf = -1, t_fe6 = -1, t_emb = -1, t_ref = -1;
     float *off9 = nullptr, *aff9 = nullptr, *goff9 = nullptr, *gaff9 = nullptr, *feats = nullptr, *depth = nullptr, *gdepth = nullptr,
           *gy = nullptr, *gping = nullptr;
-    int legacy = 0;
+    int legacy = 0, naive = 0;
+    bf16_t *meta_ff_hi = nullptr, *meta_ff_lo = nullptr, *meta_fb_hi = nullptr, *meta_fb_lo = nullptr;
     int norm_on = 0; float norm_div = 1.f, norm_mean[3] = {0, 0, 0}, norm_std[3] = {1, 1, 1};
     bool fwd_valid = false;
 
@@ -160,6 +164,9 @@ struct nlspn_engine {
         o.train_only = train_only; o.bwd = bwd;
         GConvW& cw = convs[wname];
         cw.Ci = T[x0].C + (x1 >= 0 ? T[x1].C : 0); cw.Co = T[y].C; cw.k = k; cw.stride = stride; cw.transposed = transposed;
+        cw.C0 = T[x0].C; cw.C1 = x1 >= 0 ? T[x1].C : 0;
+        cw.mf = !naive && stride == 1 && !transposed && (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0;
+        cw.mb = !naive && stride == 1 && !transposed && (cw.Co % 16) == 0 && (cw.C0 % 32) == 0;
         ops.push_back(o);
     }
     // y = act(bn(x)) [+ res, relu]; adapted gamma/beta unless frozen (heads)
@@ -299,8 +306,11 @@ struct nlspn_engine {
         wg_part = falloc((size_t)ptta_gwgrad_slabs((long)N * P) * (9 * 48 * 48 + 48));
         for (auto& kv : convs) {
             GConvW& cw = kv.second;
+            const int KK = cw.k * cw.k;
+            if (cw.mf) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.C0, cw.C1, cw.Co); cw.ff_hi = (bf16_t*)dalloc(n * 2); cw.ff_lo = (bf16_t*)dalloc(n * 2); }
+            if (cw.mb) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.Ci); cw.fb_hi = (bf16_t*)dalloc(n * 2); cw.fb_lo = (bf16_t*)dalloc(n * 2); }
             if (kv.first == "conv1_rgb_meta") continue;
-            const size_t n = (size_t)cw.k * cw.k * cw.Ci * cw.Co;
+            const size_t n = (size_t)KK * cw.Ci * cw.Co;
             cw.wf = falloc(n); cw.wb = falloc(n); cw.bias = falloc(cw.Co);
         }
     }
@@ -351,8 +361,14 @@ struct nlspn_engine {
             ptta_gpack(src, cw.wf, KK, cw.Ci, cw.Co, (long)cw.Co * KK, KK, 0, s);
             ptta_gpack(src, cw.wb, KK, cw.Co, cw.Ci, KK, (long)cw.Co * KK, 0, s);
         }
+        pack_frags(cw, cw.wf, cw.wb, s);
         cw.loaded = true;
         return 0;
+    }
+    void pack_frags(GConvW& cw, const float* wf, const float* wb, hipStream_t s) {
+        const int KK = cw.k * cw.k;
+        if (cw.mf) ptta_gfrag_pack(wf, cw.Co, (long)cw.Ci * cw.Co, KK, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);
+        if (cw.mb) ptta_gfrag_pack(wb, cw.Ci, (long)cw.Co * cw.Ci, KK, cw.Co, 0, 0, 0, cw.Ci, cw.fb_hi, cw.fb_lo, s);
     }
 };
 
@@ -366,6 +382,18 @@ int run_conv_fwd(nlspn_engine* e, const Op& o, bool train, hipStream_t s) {
     if (!meta && !cw.loaded) return e->fail("weights of " + o.wname + " not loaded (ptta_load_weights)", -3);
     const float* wf = meta ? e->meta_wf : cw.wf;
     const float* bias = meta ? e->adapted[o.ad_b].p : (cw.has_bias ? cw.bias : nullptr);
+    if (cw.mf) {
+        GX3Args a;
+        const GView x0 = e->view(o.x[0], o.xw[0], train), y = e->view(o.y, o.yw, train);
+        a.x0 = x0.p; a.C0 = x0.C; a.ld0 = x0.ld;
+        if (o.nsrc == 2) { const GView x1 = e->view(o.x[1], o.xw[1], train); a.x1 = x1.p; a.C1 = x1.C; a.ld1 = x1.ld; }
+        a.B = y.B; a.H = y.H; a.W = y.W;
+        a.whi = (const uint4*)cw.ff_hi; a.wlo = (const uint4*)cw.ff_lo;
+        a.nchunks = (a.C0 + 31) / 32 + (a.C1 + 31) / 32; a.nf0 = 0; a.nnf = (cw.Co + 31) / 32;
+        a.y = y.p; a.ldy = y.ld; a.Cy = y.C; a.bias = bias; a.act = o.act;
+        if (ptta_launch_gconv_x3(a, o.k, s)) return e->fail("conv " + o.wname + " (matrix-core) launch failed", -5);
+        return 0;
+    }
     for (int sidx = 0; sidx < o.nsrc; ++sidx) {
         GConvArgs a;
         a.x = e->view(o.x[sidx], o.xw[sidx], train); a.y = e->view(o.y, o.yw, train);
@@ -404,6 +432,7 @@ int forward(nlspn_engine* e, const float* image, const float* sparse, bool train
     // the adapted conv is re-packed from the bound tensor on every forward
     ptta_gpack(e->adapted[0].p, e->meta_wf, 9, 48, 48, 9, 48L * 9, 0, s);
     ptta_gpack(e->adapted[0].p, e->meta_wb, 9, 48, 48, 48L * 9, 9, 1, s);
+    e->pack_frags(e->convs["conv1_rgb_meta"], e->meta_wf, e->meta_wb, s);
     for (const Op& o : e->ops) {
         if (o.train_only && !train) continue;
         const int rc = o.kind == K_CONV ? run_conv_fwd(e, o, train, s) : run_bn_fwd(e, o, train, s);
@@ -430,6 +459,17 @@ int run_conv_bwd(nlspn_engine* e, const Op& o, hipStream_t s) {
     if (o.act != GACT_NONE && ptta_launch_gact_bwd(gy, yv, o.act, s)) return e->fail("activation gradient failed", -5);
     for (int sidx = 0; sidx < o.nsrc; ++sidx) {
         if (!e->T[o.x[sidx]].need_grad) continue;
+        if (cw.mb && (o.c0[sidx] % 32) == 0) {
+            GX3Args a;
+            const GView gx = e->view(o.x[sidx], W_GRAD, true, true);
+            a.x0 = gy.p; a.C0 = gy.C; a.ld0 = gy.ld;
+            a.B = gy.B; a.H = gy.H; a.W = gy.W;
+            a.whi = (const uint4*)cw.fb_hi; a.wlo = (const uint4*)cw.fb_lo;
+            a.nchunks = (a.C0 + 31) / 32; a.nf0 = o.c0[sidx] / 32; a.nnf = (gx.C + 31) / 32;
+            a.y = gx.p; a.ldy = gx.ld; a.Cy = gx.C; a.accumulate = o.first_x[sidx] ? 0 : 1;
+            if (ptta_launch_gconv_x3(a, o.k, s)) return e->fail("data gradient of " + o.wname + " (matrix-core) failed", -5);
+            continue;
+        }
         GConvArgs a;
         a.x = gy; a.y = e->view(o.x[sidx], W_GRAD, true, true);
         a.w = (meta ? e->meta_wb : cw.wb) + o.c0[sidx]; a.wld = cw.Ci; a.wts = (long)cw.Co * cw.Ci;
@@ -505,6 +545,8 @@ nlspn_engine* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int* rc)
     if ((h % 16) || (w % 16)) { *rc = -38; return nullptr; }      // decoder crops of nlspnmodel_adapt.py:474-490 are not implemented
     nlspn_engine* e = new nlspn_engine();
     e->N = n; e->H = h; e->W = w; e->hp = *hp;
+    const char* impl = getenv("PTTA_CONV_IMPL");
+    e->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;          // direct fp32 kernels everywhere (validation)
     e->build();
     if (e->oom || !e->step_dev) { nlspn_destroy(e); *rc = -12; return nullptr; }
     const float one[1] = {4.0f};                                  // affinity_gamma * num = 0.5 * 8 (nlspnmodel_adapt.py:231-233)

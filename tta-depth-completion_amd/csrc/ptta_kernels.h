@@ -177,3 +177,18 @@ int ptta_launch_nl_prop_bwd(const float* feat, const float* fix, const float* of
                             float* goff9, float* gaff9, int B, int H, int W, hipStream_t s);
 int ptta_launch_nl_affinity_bwd(const GView& oa, const float* conf, const float* S, int legacy, const float* goff9, const float* gaff9,
                                 const GView& goa, float* gconf, hipStream_t s);
+
+// ---- gconv_mfma.hip: matrix-core (bf16x3) stride-1 convolution over 1-2 NHWC sources -------------------------------
+struct GX3Args {
+    const float* x0 = nullptr; int C0 = 0, ld0 = 0;
+    const float* x1 = nullptr; int C1 = 0, ld1 = 0;
+    int B = 0, H = 0, W = 0;
+    const uint4* whi = nullptr; const uint4* wlo = nullptr;   // fragments [co tile][chunk][tap][2][64 lanes] x 8 bf16
+    int nchunks = 0, nf0 = 0, nnf = 0;                        // first output-channel tile of this launch, number of tiles
+    float* y = nullptr; int ldy = 0, Cy = 0;                  // output view starting at channel 32*nf0 of the packed matrix
+    const float* bias = nullptr; int act = GACT_NONE, accumulate = 0;
+};
+void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
+                     hipStream_t s);
+long ptta_gfrag_elems(int KK, int C0, int C1, int Co);
+int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s);

@@ -170,6 +170,98 @@ __global__ __launch_bounds__(256, 2) void gconv_x3_s1_kernel(GX3Args p) {
     }
 }
 
+
+// ---- stride-2 and transposed (fractionally strided) geometries: direct A loads, no LDS ----------------------------
+// One wave = 32 outputs of one output row (transposed: of one x parity, so that all lanes use the same taps) x 32
+// output channels.  A fragments (8 fp32 channels of one input pixel per lane) are loaded straight from global
+// memory, split into bf16 hi/lo in registers and fed to three MFMAs; weight fragments (hi and lo) stream from L1/L2.
+// These layers are ~5 % of the network's multiply-accumulates (ResNet stage entries, conv6, the four decoder
+// transposed convolutions and their data gradients).
+//   MODE 1 (S2): y[oy][ox] = sum x[2oy+ky-pad][2ox+kx-pad] w[tap]
+//   MODE 2 (T2): y[oy][ox] = sum over taps with (oy+pad-ky), (ox+pad-kx) even of x[(oy+pad-ky)/2][(ox+pad-kx)/2] w[tap]
+template <int MODE, int KS>
+__global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin, int Win) {
+    constexpr int PAD = KS / 2, KK = KS * KS;
+    const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int Hout = p.H, Wout = p.W;
+    const int Wt = MODE == 2 ? Win : Wout;
+    const int nseg = (Wt + 31) >> 5, npar = MODE == 2 ? 2 : 1;
+    const long nitems = (long)p.B * nseg * npar * Hout;
+    const int nch0 = (p.C0 + 31) >> 5;
+    // block -> (4 consecutive items, channel tile); channel tile fastest
+    const int nfl = (int)(blockIdx.x % p.nnf);
+    const long item = (long)(blockIdx.x / p.nnf) * 4 + wave;
+    if (item >= nitems) return;
+    const int nf = p.nf0 + nfl;
+    long t_ = item;
+    const int y = (int)(t_ % Hout); t_ /= Hout;
+    int xpar = 0;
+    if (MODE == 2) { xpar = (int)(t_ & 1); t_ >>= 1; }
+    const int seg = (int)(t_ % nseg);
+    const int b = (int)(t_ / nseg);
+    const int x0 = seg << 5;
+    const bool lane_in = (x0 + i) < Wt;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c = 0; c < p.nchunks; ++c) {
+        const bool s1 = c >= nch0;
+        const float* src = s1 ? p.x1 : p.x0;
+        const int ld = s1 ? p.ld1 : p.ld0, Cs = s1 ? p.C1 : p.C0, cb = (s1 ? c - nch0 : c) << 5;
+        const float* inb = src + (size_t)b * Hin * Win * ld + cb + 8 * h;
+        const uint4* ph = p.whi + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + lane;
+        const uint4* pl = p.wlo + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + lane;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            bool active = true;
+            int yi, xi;
+            if (MODE == 1) { yi = 2 * y + ky - PAD; xi = 2 * (x0 + i) + kx - PAD; }
+            else {
+                const int ty = y + PAD - ky, tx = xpar + PAD - kx;
+                active = ((ty & 1) == 0) && ((tx & 1) == 0);
+                yi = ty >> 1; xi = x0 + i + (tx >> 1);
+            }
+            active = active && (yi >= 0) && (yi < Hin);
+            if (!active) continue;                                    // wave-uniform
+            const bool ok = lane_in && (xi >= 0) && (xi < Win);
+            const float* q = inb + ((size_t)yi * Win + (ok ? xi : 0)) * ld;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+                if (ok && cb + 16 * k + 8 * h < Cs) { a0 = *(const float4*)(q + 16 * k); a1 = *(const float4*)(q + 16 * k + 4); }
+                uint4 hi, lo;
+                gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
+                gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, hi), al = __builtin_bit_cast(bf16x8, lo);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, ph[(tap * 2 + k) * 64]);
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, pl[(tap * 2 + k) * 64]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+        }
+    }
+    const int co = nf * 32 + i - p.nf0 * 32;
+    if (co >= p.Cy) return;
+    const float bias = p.bias ? p.bias[co] : 0.f;
+    float* yrow = p.y + ((size_t)b * Hout + y) * Wout * p.ldy + co;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int xl = x0 + acc_row(r, h);
+        if (xl >= Wt) continue;
+        const int x = MODE == 2 ? 2 * xl + xpar : xl;
+        float* dst = yrow + (size_t)x * p.ldy;
+        float v = acc[r] + bias;
+        if (p.accumulate) v += *dst;
+        if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        *dst = v;
+    }
+}
+
 }  // namespace
 
 void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
@@ -192,6 +284,22 @@ int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
     if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else if (ks == 1) hipLaunchKernelGGL((gconv_x3_s1_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else return -22;
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+// mode 1: stride-2 convolution (a.H/a.W = output size, input = hin x win); mode 2: stride-2 transposed convolution
+int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, int win, hipStream_t s) {
+    if ((a.C0 & 15) || (a.C1 & 15) || (a.ld0 & 3) || (a.ld1 & 3) || (ks != 1 && ks != 3) || (mode != 1 && mode != 2)) return -22;
+    if (a.nchunks != (a.C0 + 31) / 32 + (a.C1 + 31) / 32) return -22;
+    const int Wt = mode == 2 ? win : a.W;
+    const long nitems = (long)a.B * ((Wt + 31) / 32) * (mode == 2 ? 2 : 1) * a.H;
+    const long blocks = ((nitems + 3) / 4) * a.nnf;
+    if (blocks < 1 || blocks > 0x7fffffffL) return -22;
+#define L_(M, K) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win)
+    if (mode == 1) { if (ks == 3) L_(1, 3); else L_(1, 1); }
+    else { if (ks == 3) L_(2, 3); else L_(2, 1); }
+#undef L_
     PTTA_CHECK_LAUNCH();
     return 0;
 }

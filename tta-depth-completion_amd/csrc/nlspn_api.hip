@@ -165,8 +165,8 @@ struct nlspn_engine {
         GConvW& cw = convs[wname];
         cw.Ci = T[x0].C + (x1 >= 0 ? T[x1].C : 0); cw.Co = T[y].C; cw.k = k; cw.stride = stride; cw.transposed = transposed;
         cw.C0 = T[x0].C; cw.C1 = x1 >= 0 ? T[x1].C : 0;
-        cw.mf = !naive && stride == 1 && !transposed && (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0;
-        cw.mb = !naive && stride == 1 && !transposed && (cw.Co % 16) == 0 && (cw.C0 % 32) == 0;
+        cw.mf = !naive && (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0;
+        cw.mb = !naive && (cw.Co % 16) == 0 && (cw.C1 == 0 || (cw.C0 % 32) == 0);
         ops.push_back(o);
     }
     // y = act(bn(x)) [+ res, relu]; adapted gamma/beta unless frozen (heads)
@@ -391,7 +391,10 @@ int run_conv_fwd(nlspn_engine* e, const Op& o, bool train, hipStream_t s) {
         a.whi = (const uint4*)cw.ff_hi; a.wlo = (const uint4*)cw.ff_lo;
         a.nchunks = (a.C0 + 31) / 32 + (a.C1 + 31) / 32; a.nf0 = 0; a.nnf = (cw.Co + 31) / 32;
         a.y = y.p; a.ldy = y.ld; a.Cy = y.C; a.bias = bias; a.act = o.act;
-        if (ptta_launch_gconv_x3(a, o.k, s)) return e->fail("conv " + o.wname + " (matrix-core) launch failed", -5);
+        int rc;
+        if (o.stride == 1 && !o.transposed) rc = ptta_launch_gconv_x3(a, o.k, s);
+        else rc = ptta_launch_gconv_x3_strided(a, o.k, o.transposed ? 2 : 1, x0.H, x0.W, s);
+        if (rc) return e->fail("conv " + o.wname + " (matrix-core) launch failed", -5);
         return 0;
     }
     for (int sidx = 0; sidx < o.nsrc; ++sidx) {
@@ -467,7 +470,11 @@ int run_conv_bwd(nlspn_engine* e, const Op& o, hipStream_t s) {
             a.whi = (const uint4*)cw.fb_hi; a.wlo = (const uint4*)cw.fb_lo;
             a.nchunks = (a.C0 + 31) / 32; a.nf0 = o.c0[sidx] / 32; a.nnf = (gx.C + 31) / 32;
             a.y = gx.p; a.ldy = gx.ld; a.Cy = gx.C; a.accumulate = o.first_x[sidx] ? 0 : 1;
-            if (ptta_launch_gconv_x3(a, o.k, s)) return e->fail("data gradient of " + o.wname + " (matrix-core) failed", -5);
+            a.B = gx.B; a.H = gx.H; a.W = gx.W;                  // output geometry = the source's
+            int rc;
+            if (o.stride == 1 && !o.transposed) rc = ptta_launch_gconv_x3(a, o.k, s);
+            else rc = ptta_launch_gconv_x3_strided(a, o.k, o.transposed ? 1 : 2, gy.H, gy.W, s);     // convT -> strided conv, strided conv -> convT
+            if (rc) return e->fail("data gradient of " + o.wname + " (matrix-core) failed", -5);
             continue;
         }
         GConvArgs a;

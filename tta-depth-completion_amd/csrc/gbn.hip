@@ -10,7 +10,7 @@
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
-#define GBN_BLOCKS 64
+#define GBN_BLOCKS 1024
 
 // partial sums over the pixels of one pass: MODE 0: {sum x, sum x^2}; MODE 1: {sum g1, sum g1*xhat}
 // part layout [pass][block][2][C]
@@ -30,7 +30,16 @@ __global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView 
         if (sub < nsub && c < C) {
             float mu = 0.f, iv = 0.f;
             if (MODE == 1) { mu = mean[pass * C + c]; iv = inv[pass * C + c]; }
-            for (long p = (long)blockIdx.x * nsub + sub; p < ppp; p += (long)gridDim.x * nsub) {
+            const long pstride = (long)gridDim.x * nsub;
+            long p = (long)blockIdx.x * nsub + sub;
+            if (MODE == 0) {
+                for (; p + 3 * pstride < ppp; p += 4 * pstride) {           // four independent loads in flight
+                    const float a0 = x.p[(pix0 + p) * x.ld + c], a1 = x.p[(pix0 + p + pstride) * x.ld + c];
+                    const float a2 = x.p[(pix0 + p + 2 * pstride) * x.ld + c], a3 = x.p[(pix0 + p + 3 * pstride) * x.ld + c];
+                    s1 += (a0 + a1) + (a2 + a3); s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            }
+            for (; p < ppp; p += pstride) {
                 const float xv = x.p[(pix0 + p) * x.ld + c];
                 if (MODE == 0) { s1 += xv; s2 += xv * xv; }
                 else {
@@ -54,17 +63,25 @@ __global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView 
     }
 }
 
+// wave-parallel fixed-order sum of the block partials of one (pass, channel): lane l takes blocks l, l+64, ...
+__device__ __forceinline__ void gbn_sum_partials(const float* __restrict__ part, int nblocks, int C, int c, double& s1, double& s2) {
+    const int lane = threadIdx.x & 63;
+    double a1 = 0.0, a2 = 0.0;
+    for (int b = lane; b < nblocks; b += 64) { const float* o = part + ((long)b * 2) * C; a1 += (double)o[c]; a2 += (double)o[C + c]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+    s1 = a1; s2 = a2;
+}
+
 // forward finalize: per (pass, c): mean, inv, scale = gamma*inv, shift = beta - mean*scale   (st = [4][npass][C])
-__global__ void gbn_finalize_kernel(const float* __restrict__ part, int nblocks, int npass, int C, long R, float eps,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ st) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* __restrict__ part, int nblocks, int npass, int C, long R, float eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ st) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= npass * C) return;
     const int pass = idx / C, c = idx % C;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        const float* o = part + (((long)pass * nblocks + b) * 2) * C;
-        s1 += (double)o[c]; s2 += (double)o[C + c];
-    }
+    double s1, s2;
+    gbn_sum_partials(part + ((long)pass * nblocks * 2) * C, nblocks, C, c, s1, s2);
+    if (threadIdx.x & 63) return;
     const double m = s1 / (double)R;
     double var = s2 / (double)R - m * m; if (var < 0.0) var = 0.0;
     const float iv = (float)(1.0 / sqrt(var + (double)eps));
@@ -96,7 +113,7 @@ int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, in
     const long R = (long)(x.B / npass) * x.H * x.W;
     int blocks = (int)((R + nsub - 1) / nsub); if (blocks > GBN_BLOCKS) blocks = GBN_BLOCKS; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((gbn_stats_kernel<0>), dim3(blocks, npass), dim3(256), lds, s, x, x, x, npass, 0, 0, nullptr, nullptr, part);
-    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 127) / 128), dim3(128), 0, s, part, blocks, npass, C, R, eps, gamma, beta, st);
+    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, R, eps, gamma, beta, st);
     const long total = (long)x.B * x.H * x.W * C;
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
     hipLaunchKernelGGL(gbn_apply_kernel, dim3((int)ab), dim3(256), 0, s, x, res, y, npass, act, st);
@@ -106,12 +123,13 @@ int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, in
 int ptta_gbn_part_floats(int C, int npass) { return npass * GBN_BLOCKS * 2 * C; }
 
 // backward finalize (pass 0 = the grad pass only): dbeta, dgamma, and bw = [gscale, c1, c2][C]
-__global__ void gbn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long R, const float* __restrict__ gamma,
-                                        const float* __restrict__ inv, float* dgamma, float* dbeta, float* __restrict__ bw) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long R, const float* __restrict__ gamma,
+                                                               const float* __restrict__ inv, float* dgamma, float* dbeta, float* __restrict__ bw) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) { const float* o = part + ((long)b * 2) * C; s1 += (double)o[c]; s2 += (double)o[C + c]; }
+    double s1, s2;
+    gbn_sum_partials(part, nblocks, C, c, s1, s2);
+    if (threadIdx.x & 63) return;
     if (dbeta) dbeta[c] = (float)s1;
     if (dgamma) dgamma[c] = (float)s2;
     bw[c] = gamma[c] * inv[c]; bw[C + c] = (float)(s1 / (double)R); bw[2 * C + c] = (float)(s2 / (double)R);
@@ -149,7 +167,7 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
     int blocks = (int)((R + nsub - 1) / nsub); if (blocks > GBN_BLOCKS) blocks = GBN_BLOCKS; if (blocks < 1) blocks = 1;
     const float* mean = st; const float* inv = st + (long)npass * C;
     hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part);
-    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, blocks, C, R, gamma, inv, dgamma, dbeta, bw);
+    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, C, R, gamma, inv, dgamma, dbeta, bw);
     const long total = R * C;
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
     hipLaunchKernelGGL(gbn_bwd_apply_kernel, dim3((int)ab), dim3(256), 0, s, x0, g, y0, gx, gres, act, res_relu, acc_gx, acc_gres, mean, inv, bw);

@@ -262,6 +262,84 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
     }
 }
 
+// ---- weight gradient of a stride-1 3x3 convolution with up to 64 x 64 channels (the adapted conv1_rgb_meta,
+// Conv2d(48,48,3,1,1), nlspnmodel_adapt.py:1371) on the fp32 matrix cores: dW[co][ci][tap] = sum_p gy[p][co] x[p+tap][ci].
+// One wave per (pixel chunk, 32x32 channel-block pair): nine 32x32 accumulators (one per tap) + one for the bias,
+// K = pixels, two pixels per v_mfma_f32_32x32x2_f32; a second fixed-order pass sums the chunk partials.
+#define GWG_PART (10 * 1024)
+__global__ __launch_bounds__(64) void gwgrad_mfma_kernel(GView x, GView gy, int nchunks, int ncib, float* __restrict__ part) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    const int H = x.H, W = x.W;
+    const long P = (long)x.B * H * W;
+    const long per = ((P + nchunks - 1) / nchunks + 7) & ~7L;
+    const long p0 = (long)blockIdx.x * per;
+    long p1 = p0 + per; if (p1 > P) p1 = P;
+    const int cob = blockIdx.y / ncib, cib = blockIdx.y % ncib;
+    const int co = cob * 32 + i, ci = cib * 32 + i;
+    const bool cov = co < gy.C, civ = ci < x.C;
+    f32x16 acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (long pp = p0; pp < p1; pp += 8) {
+        float a[4], bv[4][9];
+        bool pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long pix = pp + 2 * u + h;
+            pv[u] = pix < p1;
+            int px = 0, py = 0;
+            a[u] = 0.f;
+            if (pv[u]) {
+                px = (int)(pix % W); py = (int)((pix / W) % H);
+                if (cov) a[u] = gy.p[pix * gy.ld + co];
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+                bv[u][tap] = 0.f;
+                if (pv[u] && civ && yy >= 0 && yy < H && xx >= 0 && xx < W) bv[u][tap] = x.p[(pix + (long)(tap / 3 - 1) * W + (tap % 3 - 1)) * x.ld + ci];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u][tap], acc[tap], 0, 0, 0);
+            acc[9] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], pv[u] ? 1.f : 0.f, acc[9], 0, 0, 0);
+        }
+    }
+    float* out = part + ((long)blockIdx.x * gridDim.y + blockIdx.y) * GWG_PART;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(tap * 32 + acc_row(r, h)) * 32 + i] = acc[tap][r];
+    if (i == 0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[9 * 1024 + acc_row(r, h)] = acc[9][r];
+}
+
+// one wave per output element group: 64 lanes sum the chunk partials of one (tap, co, ci) in a fixed order
+__global__ __launch_bounds__(256) void gwgrad_mfma_reduce_kernel(const float* __restrict__ part, int nchunks, int npairs, int ncib, int Ci, int Co,
+                                                                 float* __restrict__ gw, float* __restrict__ gb) {
+    const int lane = threadIdx.x & 63;
+    const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nw = 9L * Co * Ci;
+    if (e >= nw + Co) return;
+    int tap = 0, co, ci = 0;
+    if (e < nw) { tap = (int)(e / ((long)Co * Ci)); const int r = (int)(e % ((long)Co * Ci)); co = r / Ci; ci = r % Ci; }
+    else co = (int)(e - nw);
+    const int pair = (co >> 5) * ncib + (e < nw ? (ci >> 5) : 0);
+    const long off = e < nw ? ((long)tap * 32 + (co & 31)) * 32 + (ci & 31) : 9 * 1024 + (co & 31);
+    double s = 0.0;
+    for (int k = lane; k < nchunks; k += 64) s += (double)part[((long)k * npairs + pair) * GWG_PART + off];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (lane) return;
+    if (e < nw) gw[((long)co * Ci + ci) * 9 + tap] = (float)s;
+    else if (gb) gb[co] = (float)s;
+}
+
 }  // namespace
 
 void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
@@ -300,6 +378,20 @@ int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, in
     if (mode == 1) { if (ks == 3) L_(1, 3); else L_(1, 1); }
     else { if (ks == 3) L_(2, 3); else L_(2, 1); }
 #undef L_
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+int ptta_gwgrad_mfma_chunks(long pixels) { long n = (pixels + 127) / 128; return (int)(n > 1024 ? 1024 : (n < 1 ? 1 : n)); }
+long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co) {
+    return (long)ptta_gwgrad_mfma_chunks(pixels) * ((Ci + 31) / 32) * ((Co + 31) / 32) * GWG_PART;
+}
+int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s) {
+    const int nchunks = ptta_gwgrad_mfma_chunks((long)x.B * x.H * x.W);
+    const int ncib = (x.C + 31) / 32, ncob = (gy.C + 31) / 32, npairs = ncib * ncob;
+    hipLaunchKernelGGL(gwgrad_mfma_kernel, dim3(nchunks, npairs), dim3(64), 0, s, x, gy, nchunks, ncib, part);
+    const long n = 9L * x.C * gy.C + gy.C;
+    hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nchunks, npairs, ncib, x.C, gy.C, gw, gb);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

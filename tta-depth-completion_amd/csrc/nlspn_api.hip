@@ -303,7 +303,7 @@ struct nlspn_engine {
         loss_ws = falloc((size_t)ptta_loss_ws_floats(N, H, W, rows()));
         step_dev = (int*)dalloc(sizeof(int));
         bn_part = falloc((size_t)ptta_gbn_part_floats(1024, 2)); bn_bw = falloc(3 * 1024);
-        wg_part = falloc((size_t)ptta_gwgrad_slabs((long)N * P) * (9 * 48 * 48 + 48));
+        { const size_t a = (size_t)ptta_gwgrad_slabs((long)N * P) * (9 * 48 * 48 + 48), b = (size_t)ptta_gwgrad_mfma_part_floats((long)N * P, 48, 48); wg_part = falloc(a > b ? a : b); }
         for (auto& kv : convs) {
             GConvW& cw = kv.second;
             const int KK = cw.k * cw.k;
@@ -488,7 +488,8 @@ int run_conv_bwd(nlspn_engine* e, const Op& o, hipStream_t s) {
     }
     if (meta) {
         const GView xv = e->view(o.x[0], W_GRAD, true);
-        if (ptta_launch_gwgrad(xv, gy, e->wg_part, e->gall + e->adapted[o.ad_w].goff, e->gall + e->adapted[o.ad_b].goff, s))
+        if ((e->naive ? ptta_launch_gwgrad(xv, gy, e->wg_part, e->gall + e->adapted[o.ad_w].goff, e->gall + e->adapted[o.ad_b].goff, s)
+                      : ptta_launch_gwgrad_mfma(xv, gy, e->wg_part, e->gall + e->adapted[o.ad_w].goff, e->gall + e->adapted[o.ad_b].goff, s)))
             return e->fail("weight gradient failed", -5);
     }
     return 0;

@@ -132,7 +132,7 @@ int ptta_launch_gact_bwd(const GView& g, const GView& y, int act, hipStream_t s)
 
 // (N,C,H,W) planar -> NHWC view, with the optional photometric normalisation (v/div - mean[c])/std[c]; zero_from_b:
 // items >= zero_from_b are written as zeros (the proxy pass's zero image, nlspnmodel_adapt.py:908)
-__global__ void gnchw_to_nhwc_kernel(const float* __restrict__ src, int src_nb, GView y, int zero_from_b, int norm, float div,
+__global__ void gnchw_to_nhwc_kernel(const float* __restrict__ src, int src_nb, int src_c, GView y, int zero_from_b, int norm, float div,
                                      float m0, float m1, float m2, float s0, float s1, float s2) {
     const long total = (long)y.B * y.H * y.W * y.C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -140,18 +140,18 @@ __global__ void gnchw_to_nhwc_kernel(const float* __restrict__ src, int src_nb, 
         const long hw = (long)y.H * y.W;
         const int b = (int)(pix / hw); const long r = pix % hw;
         float v = 0.f;
-        if (b < zero_from_b) {
-            v = src[((long)(b % src_nb) * y.C + c) * hw + r];
+        if (b < zero_from_b && c < src_c) {
+            v = src[((long)(b % src_nb) * src_c + c) * hw + r];
             if (norm) { const float m = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2); v = (v / div - m) / sd; }
         }
         y.p[pix * y.ld + c] = v;
     }
 }
-int ptta_launch_gnchw_to_nhwc(const float* src, int src_nb, const GView& y, int zero_from_b, int norm, float div, const float* mean,
+int ptta_launch_gnchw_to_nhwc(const float* src, int src_nb, int src_c, const GView& y, int zero_from_b, int norm, float div, const float* mean,
                               const float* stdv, hipStream_t s) {
     const long total = (long)y.B * y.H * y.W * y.C;
     long blocks = (total + 255) / 256; if (blocks > 16384) blocks = 16384; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(gnchw_to_nhwc_kernel, dim3((int)blocks), dim3(256), 0, s, src, src_nb, y, zero_from_b, norm, div,
+    hipLaunchKernelGGL(gnchw_to_nhwc_kernel, dim3((int)blocks), dim3(256), 0, s, src, src_nb, src_c, y, zero_from_b, norm, div,
                        mean ? mean[0] : 0.f, mean ? mean[1] : 0.f, mean ? mean[2] : 0.f, stdv ? stdv[0] : 1.f, stdv ? stdv[1] : 1.f,
                        stdv ? stdv[2] : 1.f);
     PTTA_CHECK_LAUNCH();

@@ -46,6 +46,7 @@ struct GConvW {            // frozen convolution weights, packed once at load ti
     float *wf = nullptr, *wb = nullptr, *bias = nullptr;
     int Ci = 0, Co = 0, k = 3, stride = 1, transposed = 0;
     int C0 = 0, C1 = 0;                                   // source split of the input channels (torch.cat order)
+    int Ci_real = 0;                                      // > 0: the state_dict tensor has fewer input channels than the zero-padded activation
     bf16_t *ff_hi = nullptr, *ff_lo = nullptr, *fb_hi = nullptr, *fb_lo = nullptr;     // bf16x3 MFMA fragments (forward / data gradient)
     bool mf = false, mb = false;                          // matrix-core kernel usable for forward / data gradient
     bool loaded = false, has_bias = false;
@@ -112,6 +113,7 @@ struct nlspn_engine {
     int* step_dev = nullptr;
     float *bn_part = nullptr, *bn_bw = nullptr, *wg_part = nullptr;
     // inputs / propagation
+    int t_sd16 = -1;
     int t_img = -1, t_sd = -1, t_pred = -1, t_oa = -1, t_conf = -1, t_fe6 = -1, t_emb = -1, t_ref = -1;
     float *off9 = nullptr, *aff9 = nullptr, *goff9 = nullptr, *gaff9 = nullptr, *feats = nullptr, *depth = nullptr, *gdepth = nullptr,
           *gy = nullptr, *gping = nullptr;
@@ -185,15 +187,19 @@ struct nlspn_engine {
         const int N2 = 2 * N;
         // the adapted meta conv comes first in the reference's parameter list (src/nlspn_model_adapt.py:324-328)
         const int ad_mw = add_adapted("conv1_rgb_meta.weight", 48L * 48 * 9), ad_mb = add_adapted("conv1_rgb_meta.bias", 48);
-        t_img = tensor("image", N2, H, W, 3, false);
+        // the 3-channel image and the 1-channel sparse depth are staged zero-padded to 16 channels so that their first
+        // convolutions run on the matrix-core kernel too (weight rows of the padding channels are zero)
+        t_img = tensor("image", N2, H, W, naive ? 3 : 16, false);
         t_sd = tensor("sparse", N2, H, W, 1, false);
+        const int sd16 = naive ? t_sd : tensor("sparse16", N2, H, W, 16, false);
         const int rgb1 = tensor("rgb1", N2, H, W, 48, false);
         const int fe1 = tensor("fe1", N2, H, W, 64, true);
         const int fe1_rgb = slice("fe1_rgb", fe1, 0, 48), fe1_dep = slice("fe1_dep", fe1, 48, 16);
         conv("conv1_rgb.0", t_img, -1, rgb1, 3, 1, 0, GACT_LRELU, W_BOTH, W_BOTH, false, false);
         conv("conv1_rgb_meta", rgb1, -1, fe1_rgb, 3, 1, 0, GACT_NONE, W_BOTH, W_BOTH);
         ops.back().ad_w = ad_mw; ops.back().ad_b = ad_mb;
-        conv("conv1_dep.0", t_sd, -1, fe1_dep, 3, 1, 0, GACT_LRELU, W_BOTH, W_BOTH, false, false);
+        conv("conv1_dep.0", sd16, -1, fe1_dep, 3, 1, 0, GACT_LRELU, W_BOTH, W_BOTH, false, false);
+        if (!naive) { convs["conv1_rgb.0"].Ci_real = 3; convs["conv1_dep.0"].Ci_real = 1; t_sd16 = sd16; }
         // ResNet34 stages (nlspnmodel_adapt.py:400-406; BasicBlock :70-116)
         const int planes[4] = {64, 128, 256, 512}, nblocks[4] = {3, 4, 6, 3};
         int hh = H, ww = W, cur = fe1, fe[7]; fe[1] = fe1;
@@ -308,7 +314,7 @@ struct nlspn_engine {
             GConvW& cw = kv.second;
             const int KK = cw.k * cw.k;
             if (cw.mf) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.C0, cw.C1, cw.Co); cw.ff_hi = (bf16_t*)dalloc(n * 2); cw.ff_lo = (bf16_t*)dalloc(n * 2); }
-            if (cw.mb) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.Ci); cw.fb_hi = (bf16_t*)dalloc(n * 2); cw.fb_lo = (bf16_t*)dalloc(n * 2); }
+            if (cw.mb && !cw.Ci_real) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.Ci); cw.fb_hi = (bf16_t*)dalloc(n * 2); cw.fb_lo = (bf16_t*)dalloc(n * 2); }
             if (kv.first == "conv1_rgb_meta") continue;
             const size_t n = (size_t)KK * cw.Ci * cw.Co;
             cw.wf = falloc(n); cw.wb = falloc(n); cw.bias = falloc(cw.Co);
@@ -345,21 +351,22 @@ struct nlspn_engine {
         }
         if (leaf != "weight") return fail("unknown state_dict key " + name, -2);
         const int KK = cw.k * cw.k;
+        const int Ci = cw.Ci_real ? cw.Ci_real : cw.Ci;
         if (cw.k == 1 && ndim == 2) {                  // nn.Linear (N, K)
-            if (shape[0] != cw.Co || shape[1] != cw.Ci) return fail("shape mismatch for " + name, -22);
+            if (shape[0] != cw.Co || shape[1] != Ci) return fail("shape mismatch for " + name, -22);
         } else if (ndim != 4 || shape[2] != cw.k || shape[3] != cw.k ||
-                   (cw.transposed ? (shape[0] != cw.Ci || shape[1] != cw.Co) : (shape[0] != cw.Co || shape[1] != cw.Ci)))
+                   (cw.transposed ? (shape[0] != Ci || shape[1] != cw.Co) : (shape[0] != cw.Co || shape[1] != Ci)))
             return fail("shape mismatch for " + name, -22);
         if (!cw.transposed) {
             // forward P[t][ci][co] = W[co][ci][t]; data gradient P[t][co][ci] = W[co][ci][flip t] (stride 1: a conv with
             // flipped taps; stride 2: consumed by the transposed kernel, which wants the taps unflipped)
-            ptta_gpack(src, cw.wf, KK, cw.Ci, cw.Co, KK, (long)cw.Ci * KK, 0, s);
-            ptta_gpack(src, cw.wb, KK, cw.Co, cw.Ci, (long)cw.Ci * KK, KK, cw.stride == 1 ? 1 : 0, s);
+            ptta_gpack(src, cw.wf, KK, Ci, cw.Co, KK, (long)Ci * KK, 0, s);
+            ptta_gpack(src, cw.wb, KK, cw.Co, Ci, (long)Ci * KK, KK, cw.stride == 1 ? 1 : 0, s);
         } else {
             // ConvTranspose2d weight (Ci, Co, k, k): forward P[t][ci][co] = W[ci][co][t]; gradient = stride-2 conv with
             // P[t][co][ci] = W[ci][co][t]
-            ptta_gpack(src, cw.wf, KK, cw.Ci, cw.Co, (long)cw.Co * KK, KK, 0, s);
-            ptta_gpack(src, cw.wb, KK, cw.Co, cw.Ci, KK, (long)cw.Co * KK, 0, s);
+            ptta_gpack(src, cw.wf, KK, Ci, cw.Co, (long)cw.Co * KK, KK, 0, s);
+            ptta_gpack(src, cw.wb, KK, cw.Co, Ci, KK, (long)cw.Co * KK, 0, s);
         }
         pack_frags(cw, cw.wf, cw.wb, s);
         cw.loaded = true;
@@ -367,8 +374,9 @@ struct nlspn_engine {
     }
     void pack_frags(GConvW& cw, const float* wf, const float* wb, hipStream_t s) {
         const int KK = cw.k * cw.k;
-        if (cw.mf) ptta_gfrag_pack(wf, cw.Co, (long)cw.Ci * cw.Co, KK, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);
-        if (cw.mb) ptta_gfrag_pack(wb, cw.Ci, (long)cw.Co * cw.Ci, KK, cw.Co, 0, 0, 0, cw.Ci, cw.fb_hi, cw.fb_lo, s);
+        if (cw.mf && cw.Ci_real) ptta_gfrag_pack(wf, cw.Co, (long)cw.Ci_real * cw.Co, KK, cw.Ci_real, 0, 0, 0, cw.Co, cw.ff_hi, cw.ff_lo, s);
+        else if (cw.mf) ptta_gfrag_pack(wf, cw.Co, (long)cw.Ci * cw.Co, KK, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);
+        if (cw.mb && !cw.Ci_real) ptta_gfrag_pack(wb, cw.Ci, (long)cw.Co * cw.Ci, KK, cw.Co, 0, 0, 0, cw.Ci, cw.fb_hi, cw.fb_lo, s);
     }
 };
 
@@ -430,8 +438,12 @@ int forward(nlspn_engine* e, const float* image, const float* sparse, bool train
     const int Be = train ? 2 * N : N;
     // inputs: image -> NHWC (normalised on the fly; proxy half = zero image), sparse depth clamped (external_model_adapt.py:108)
     GView iv = e->view(e->t_img, W_BOTH, train);
-    if (ptta_launch_gnchw_to_nhwc(image, N, iv, N, e->norm_on, e->norm_div, e->norm_mean, e->norm_std, s)) return e->fail("image staging failed", -5);
+    if (ptta_launch_gnchw_to_nhwc(image, N, 3, iv, N, e->norm_on, e->norm_div, e->norm_mean, e->norm_std, s)) return e->fail("image staging failed", -5);
     hipLaunchKernelGGL(clamp_dup_kernel, dim3(nb(P * Be)), dim3(256), 0, s, sparse, e->T[e->t_sd].p, (long)N * P, Be / N, e->hp.max_input_depth);
+    if (e->t_sd16 >= 0) {
+        GView sv = e->view(e->t_sd16, W_BOTH, train);
+        if (ptta_launch_gnchw_to_nhwc(e->T[e->t_sd].p, Be, 1, sv, Be, 0, 1.f, nullptr, nullptr, s)) return e->fail("sparse staging failed", -5);
+    }
     // the adapted conv is re-packed from the bound tensor on every forward
     ptta_gpack(e->adapted[0].p, e->meta_wf, 9, 48, 48, 9, 48L * 9, 0, s);
     ptta_gpack(e->adapted[0].p, e->meta_wb, 9, 48, 48, 48L * 9, 9, 1, s);

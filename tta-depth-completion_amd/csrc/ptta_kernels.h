@@ -158,7 +158,7 @@ struct GConvArgs {
 void ptta_gpack(const float* src, float* dst, int KK, int A, int B, long a_stride, long b_stride, int flip, hipStream_t s);
 int ptta_launch_gconv_direct(const GConvArgs& a, hipStream_t s);
 int ptta_launch_gact_bwd(const GView& g, const GView& y, int act, hipStream_t s);
-int ptta_launch_gnchw_to_nhwc(const float* src, int src_nb, const GView& y, int zero_from_b, int norm, float div, const float* mean,
+int ptta_launch_gnchw_to_nhwc(const float* src, int src_nb, int src_c, const GView& y, int zero_from_b, int norm, float div, const float* mean,
                               const float* stdv, hipStream_t s);
 int ptta_gwgrad_slabs(long pixels);
 int ptta_launch_gwgrad(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s);

@@ -91,18 +91,30 @@ __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* __restri
 }
 
 // y = act(x*scale+shift) ; with res: y = relu(x*scale+shift + res)   (BasicBlock.forward, nlspnmodel_adapt.py:98-116)
+// four channels per thread (every channel count and row stride on this path is a multiple of 4)
 __global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act, const float* __restrict__ st) {
-    const int C = x.C, n = npass * C;
-    const long total = (long)x.B * x.H * x.W * C;
+    const int C4 = x.C >> 2, n = npass * x.C;
+    const long total = (long)x.B * x.H * x.W * C4;
     const long ppp = (long)(x.B / npass) * x.H * x.W;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C); const long pix = idx / C;
+        const int c = (int)(idx % C4) << 2; const long pix = idx / C4;
         const int pass = (int)(pix / ppp);
-        float v = fmaf(x.p[pix * x.ld + c], st[2 * n + pass * C + c], st[3 * n + pass * C + c]);
-        if (res.p) { v += res.p[pix * res.ld + c]; v = v > 0.f ? v : 0.f; }
-        else if (act == GACT_RELU) v = v > 0.f ? v : 0.f;
-        else if (act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
-        y.p[pix * y.ld + c] = v;
+        const float4 xv = *(const float4*)(x.p + pix * x.ld + c);
+        const float4 sc = *(const float4*)(st + 2 * n + pass * x.C + c), sh = *(const float4*)(st + 3 * n + pass * x.C + c);
+        float v[4] = {fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w)};
+        if (res.p) {
+            const float4 r = *(const float4*)(res.p + pix * res.ld + c);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        } else if (act == GACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        } else if (act == GACT_LRELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.2f * v[k];
+        }
+        *(float4*)(y.p + pix * y.ld + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -114,7 +126,8 @@ int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, in
     int blocks = (int)((R + nsub - 1) / nsub); if (blocks > GBN_BLOCKS) blocks = GBN_BLOCKS; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((gbn_stats_kernel<0>), dim3(blocks, npass), dim3(256), lds, s, x, x, x, npass, 0, 0, nullptr, nullptr, part);
     hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, R, eps, gamma, beta, st);
-    const long total = (long)x.B * x.H * x.W * C;
+    if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
+    const long total = (long)x.B * x.H * x.W * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
     hipLaunchKernelGGL(gbn_apply_kernel, dim3((int)ab), dim3(256), 0, s, x, res, y, npass, act, st);
     PTTA_CHECK_LAUNCH();
@@ -135,22 +148,37 @@ __global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(const float* __re
     bw[c] = gamma[c] * inv[c]; bw[C + c] = (float)(s1 / (double)R); bw[2 * C + c] = (float)(s2 / (double)R);
 }
 
-// gx (+)= gscale*(g1 - c1 - xhat*c2) ; gres += g1 (residual branch of a BasicBlock)
+// gx (+)= gscale*(g1 - c1 - xhat*c2) ; gres (+)= g1 (residual branch of a BasicBlock); four channels per thread
 __global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView gres, int act, int res_relu, int acc_gx, int acc_gres,
                                      const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ bw) {
-    const int C = x.C;
-    const long total = (long)g.B * g.H * g.W * C;
+    const int C = x.C, C4 = C >> 2;
+    const long total = (long)g.B * g.H * g.W * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % C); const long pix = idx / C;
-        float gv = g.p[pix * g.ld + c];
-        const float yv = y.p[pix * y.ld + c];
-        if (res_relu || act == GACT_RELU) gv = yv > 0.f ? gv : 0.f;
-        else if (act == GACT_LRELU) gv = yv > 0.f ? gv : 0.2f * gv;
-        const float xh = (x.p[pix * x.ld + c] - mean[c]) * inv[c];
-        const float d = bw[c] * (gv - bw[C + c] - xh * bw[2 * C + c]);
-        float* o = gx.p + pix * gx.ld + c;
-        *o = acc_gx ? *o + d : d;
-        if (gres.p) { float* r = gres.p + pix * gres.ld + c; *r = acc_gres ? *r + gv : gv; }
+        const int c = (int)(idx % C4) << 2; const long pix = idx / C4;
+        const float4 g4 = *(const float4*)(g.p + pix * g.ld + c), y4 = *(const float4*)(y.p + pix * y.ld + c);
+        const float4 x4 = *(const float4*)(x.p + pix * x.ld + c);
+        const float4 mu = *(const float4*)(mean + c), iv = *(const float4*)(inv + c);
+        const float4 b0 = *(const float4*)(bw + c), b1 = *(const float4*)(bw + C + c), b2 = *(const float4*)(bw + 2 * C + c);
+        float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+        const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        const float m_[4] = {mu.x, mu.y, mu.z, mu.w}, i_[4] = {iv.x, iv.y, iv.z, iv.w};
+        const float s_[4] = {b0.x, b0.y, b0.z, b0.w}, c1[4] = {b1.x, b1.y, b1.z, b1.w}, c2[4] = {b2.x, b2.y, b2.z, b2.w};
+        float d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (res_relu || act == GACT_RELU) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+            else if (act == GACT_LRELU) gv[k] = yv[k] > 0.f ? gv[k] : 0.2f * gv[k];
+            const float xh = (xv[k] - m_[k]) * i_[k];
+            d[k] = s_[k] * (gv[k] - c1[k] - xh * c2[k]);
+        }
+        float4* o = (float4*)(gx.p + pix * gx.ld + c);
+        if (acc_gx) { const float4 t = *o; d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
+        *o = make_float4(d[0], d[1], d[2], d[3]);
+        if (gres.p) {
+            float4* r = (float4*)(gres.p + pix * gres.ld + c);
+            if (acc_gres) { const float4 t = *r; gv[0] += t.x; gv[1] += t.y; gv[2] += t.z; gv[3] += t.w; }
+            *r = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        }
     }
 }
 
@@ -168,7 +196,8 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
     const float* mean = st; const float* inv = st + (long)npass * C;
     hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part);
     hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, C, R, gamma, inv, dgamma, dbeta, bw);
-    const long total = R * C;
+    if ((C & 3) || (x.ld & 3) || (g.ld & 3) || (y.ld & 3) || (gx.ld & 3) || (gres.p && (gres.ld & 3))) return -22;
+    const long total = R * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
     hipLaunchKernelGGL(gbn_bwd_apply_kernel, dim3((int)ab), dim3(256), 0, s, x0, g, y0, gx, gres, act, res_relu, acc_gx, acc_gres, mean, inv, bw);
     PTTA_CHECK_LAUNCH();

@@ -112,18 +112,35 @@ __global__ __launch_bounds__(256) void nl_prop_fwd_kernel(const float* __restric
     }
 }
 
-// one thread per pixel: g_aff9 / g_off9 accumulate over the sweeps (same thread every sweep -> deterministic), the
-// feature gradient is scattered with atomics onto the corners that are not pinned by the sparse input
+// one thread per pixel, one block per 16x16 tile: g_aff9 / g_off9 accumulate over the sweeps (same thread every sweep ->
+// deterministic); the feature gradient is scattered onto the corners that are not pinned by the sparse input.  Offsets
+// are a few pixels at most, so the scatter goes to an LDS copy of the tile + a 4-pixel apron (ds_add_f32) and is
+// flushed with one global atomic per touched cell; targets outside the apron fall back to global atomics directly.
+#define PB_T 16
+#define PB_R 4
+#define PB_W (PB_T + 2 * PB_R)
 __global__ __launch_bounds__(256) void nl_prop_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ fix,
                                                           const float* __restrict__ off9, const float* __restrict__ aff9,
                                                           const float* __restrict__ gout, float* __restrict__ gfeat,
                                                           float* __restrict__ goff9, float* __restrict__ gaff9, int B, int H, int W) {
-    const long P = (long)H * W, total = (long)B * P;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(idx / P); const long pix = idx % P;
-        const int y = (int)(pix / W), x = (int)(pix % W);
-        const float* fb = feat + (long)b * P; const float* xb = fix + (long)b * P;
-        float* gb = gfeat + (long)b * P;
+    __shared__ float tile[PB_W * PB_W];
+    const long P = (long)H * W;
+    const int ntx = (W + PB_T - 1) / PB_T, nty = (H + PB_T - 1) / PB_T;
+    const int b = blockIdx.x / (ntx * nty), tr = blockIdx.x % (ntx * nty);
+    const int ty0 = (tr / ntx) * PB_T, tx0 = (tr % ntx) * PB_T;
+    for (int k = threadIdx.x; k < PB_W * PB_W; k += 256) tile[k] = 0.f;
+    __syncthreads();
+    const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15);
+    const float* fb = feat + (long)b * P; const float* xb = fix + (long)b * P;
+    float* gb = gfeat + (long)b * P;
+    auto scatter = [&](int qy, int qx, float v) {
+        if (xb[qy * W + qx] > 0.f) return;                         // pinned by the sparse input: no gradient to the feature
+        const int ly = qy - ty0 + PB_R, lx = qx - tx0 + PB_R;
+        if (ly >= 0 && ly < PB_W && lx >= 0 && lx < PB_W) atomicAdd(&tile[ly * PB_W + lx], v);
+        else atomicAdd(gb + qy * W + qx, v);
+    };
+    if (y < H && x < W) {
+        const long idx = (long)b * P + (long)y * W + x;
         const float* o = off9 + idx * 18; const float* a = aff9 + idx * 9;
         float* go = goff9 + idx * 18; float* ga = gaff9 + idx * 9;
         const float g = gout[idx];
@@ -136,11 +153,18 @@ __global__ __launch_bounds__(256) void nl_prop_bwd_kernel(const float* __restric
             go[2 * k] += ga_ * (-hw * t.v1 - t.c.lw * t.v2 + hw * t.v3 + t.c.lw * t.v4);
             go[2 * k + 1] += ga_ * (-hh * t.v1 + hh * t.v2 - t.c.lh * t.v3 + t.c.lh * t.v4);
             const int h1 = t.c.h0 + 1, w1 = t.c.w0 + 1;
-            if (t.o1 && !(xb[t.c.h0 * W + t.c.w0] > 0.f)) atomicAdd(gb + t.c.h0 * W + t.c.w0, hh * hw * ga_);
-            if (t.o2 && !(xb[t.c.h0 * W + w1] > 0.f)) atomicAdd(gb + t.c.h0 * W + w1, hh * t.c.lw * ga_);
-            if (t.o3 && !(xb[h1 * W + t.c.w0] > 0.f)) atomicAdd(gb + h1 * W + t.c.w0, t.c.lh * hw * ga_);
-            if (t.o4 && !(xb[h1 * W + w1] > 0.f)) atomicAdd(gb + h1 * W + w1, t.c.lh * t.c.lw * ga_);
+            if (t.o1) scatter(t.c.h0, t.c.w0, hh * hw * ga_);
+            if (t.o2) scatter(t.c.h0, w1, hh * t.c.lw * ga_);
+            if (t.o3) scatter(h1, t.c.w0, t.c.lh * hw * ga_);
+            if (t.o4) scatter(h1, w1, t.c.lh * t.c.lw * ga_);
         }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < PB_W * PB_W; k += 256) {
+        const float v = tile[k];
+        if (v == 0.f) continue;
+        const int qy = ty0 - PB_R + k / PB_W, qx = tx0 - PB_R + k % PB_W;
+        if (qy >= 0 && qy < H && qx >= 0 && qx < W) atomicAdd(gb + qy * W + qx, v);
     }
 }
 
@@ -212,8 +236,8 @@ int ptta_launch_nl_prop_fwd(const float* feat, const float* fix, const float* of
 }
 int ptta_launch_nl_prop_bwd(const float* feat, const float* fix, const float* off9, const float* aff9, const float* gout, float* gfeat,
                             float* goff9, float* gaff9, int B, int H, int W, hipStream_t s) {
-    hipLaunchKernelGGL(nl_prop_bwd_kernel, dim3(nblocks((long)B * H * W)), dim3(256), 0, s, feat, fix, off9, aff9, gout, gfeat, goff9,
-                       gaff9, B, H, W);
+    const int tiles = B * ((W + PB_T - 1) / PB_T) * ((H + PB_T - 1) / PB_T);
+    hipLaunchKernelGGL(nl_prop_bwd_kernel, dim3(tiles), dim3(256), 0, s, feat, fix, off9, aff9, gout, gfeat, goff9, gaff9, B, H, W);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

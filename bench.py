@@ -61,6 +61,44 @@ def cpu_baseline(steps=3):
             'sample': '%d steps of the same 352x1216 workload after 1 warm-up (PyTorch-CPU oracle, fp32, %.2f s/step)' % (steps, dt)}
 
 
+def nlspn_workload(frames=3, inner_iter=3):
+    """BASELINE config 3 (not the headline metric): NLSPN backbone, 352x1216, 3 TTA steps per frame + the scored eval
+    forward, adapt_mode meta_bn (88 adapted tensors), batch 1, inputs resident in HBM.  Reported beside the metric."""
+    from proxytta import synth
+    from proxytta.engine import Engine
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+    eng = Engine(1, H, W, backbone='nlspn', lr=3e-4, w_sparse_depth=1.0, w_smoothness=0.0, w_cos=0.0, max_input_depth=80.0)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
+    eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32})
+    keep = []
+    for k in eng.adapted:
+        keep.append((sd[k].clone().contiguous(), torch.zeros_like(sd[k]), torch.zeros_like(sd[k])))
+        eng.bind_adapted(k, *keep[-1])
+    data = []
+    for i in range(2):
+        image01, sparse = synth.synthetic_frame(i, H, W, 1)
+        data.append((torch.from_numpy(((np.floor(image01 * 255) / 255 - mean) / std).astype(np.float32)).cuda(), torch.from_numpy(sparse).cuda()))
+    eng.step(*data[0]); eng.forward_eval(*data[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        for _ in range(inner_iter):
+            info, _ = eng.step(*data[f % 2])
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / (frames * inner_iter)
+    t0 = time.perf_counter()
+    for f in range(frames):
+        d = eng.forward_eval(*data[f % 2])
+    torch.cuda.synchronize()
+    t_eval = (time.perf_counter() - t0) / frames
+    out = {'workload': 'NLSPN (ResNet34 + 18-sweep propagation), 352x1216, %d TTA steps/frame, meta_bn (88 adapted tensors), batch 1' % inner_iter,
+           'ms_per_step': 1e3 * t_step, 'frames_per_s': 1.0 / (inner_iter * t_step), 'eval_forward_ms': 1e3 * t_eval,
+           'finite': bool(torch.isfinite(info).all().item() and torch.isfinite(d).all().item())}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -68,6 +106,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-nlspn', action='store_true', help='skip the NLSPN (BASELINE config 3) side measurement')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -160,8 +199,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
     eng.close()
+    if rank == 0:
+        if world == 1 and not args.no_nlspn:
+            out['other_workloads'] = {'nlspn': nlspn_workload()}
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

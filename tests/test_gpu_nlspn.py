@@ -173,3 +173,36 @@ def test_fused_image_normalisation_nlspn():
 def test_size_must_be_multiple_of_16():
     with pytest.raises(RuntimeError):
         Engine(1, 36, 52, backbone='nlspn', **HP)
+
+
+def test_external_model_adapt_facade_nlspn(golden_dir):
+    """The reference's driver calls (src/tta_main.py:309-354, 610-633, 729-736) against the façade:
+    ExternalModel_Adapt('nlspn') -> _prepare_head -> load weights -> adapt_parameters('meta_bn') -> Adam -> step -> eval."""
+    from proxytta.model import ExternalModel_Adapt
+    g = np.load(os.path.join(golden_dir, 'nlspn_32x64.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    model = ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=80.0, device=torch.device('cuda'))
+    model._prepare_head('meta_selfsup_seq_1layer_ema')
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict_nlspn().items()})
+    params = model.adapt_parameters(mode='meta_bn')
+    assert len(params) == 88 and sum(p.numel() for p in params) == 40048
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    model.model.bind_optimizer(opt)
+    model.model.set_hparams(w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1)
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+    model.train()
+    info, depth = model.step(image1, sparse, loss_image=raw, want_depth=True)
+    assert rel_mae(depth, g['s0/depth_train']) < 1e-3
+    np.testing.assert_allclose(info.cpu().numpy(), g['s0/loss_info'], rtol=2e-3)
+    assert float(opt.state[params[0]]['step']) == 1.0 and float(opt.state[params[0]]['exp_avg'].abs().sum()) > 0
+    model.eval()
+    d_eval = model.forward(image1, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
+    assert rel_mae(d_eval, g['s0/depth_eval']) < 1e-3
+    model.train()
+    with pytest.raises(NotImplementedError):
+        model.forward(image1, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
+    # fused normalisation through the façade
+    model.set_image_norm([[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]])
+    model.eval()
+    d2 = model.forward(raw, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
+    assert rel_mae(d2, d_eval) < 1e-4

@@ -62,3 +62,18 @@ def test_checkpoint_roundtrip(tmp_path):
     assert step == 7
     for k, v in m.model.state_dict().items():
         assert torch.equal(v, m2.model.state_dict()[k])
+
+
+def test_nlspn_key_table_and_adapted_list():
+    """NLSPN state_dict key table (303 keys / 31,533,196 values, checked against the reference when the golden
+    vectors were generated) and the 'meta_bn' adapted list derived from it (88 tensors / 40,048 values)."""
+    from proxytta import synth
+    from proxytta.nlspn import nlspn_adapted_names
+    keys = synth.nlspn_keys()
+    assert len(keys) == 303
+    import numpy as np
+    assert sum(int(np.prod(s)) if len(s) else 1 for _, s in keys) == 31533196
+    names = nlspn_adapted_names([k for k, _ in keys])
+    shapes = dict(keys)
+    assert len(names) == 88 and sum(int(np.prod(shapes[k])) for k in names) == 40048
+    assert names[:2] == ['conv1_rgb_meta.weight', 'conv1_rgb_meta.bias'] and names[2] == 'conv2.0.bn1.weight'

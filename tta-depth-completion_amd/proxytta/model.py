@@ -291,8 +291,12 @@ class ExternalModel_Adapt(object):
         if model_name == 'msg_chn':
             self.model = MsgChnModel_Adapt(device=device, max_predict_depth=max_predict_depth, dtype=dtype,
                                            max_input_depth=max_input_depth)
-        elif model_name == 'nlspn' or 'costdcnet' in model_name:
-            raise NotImplementedError('%s is not on the MI355X hot path yet (SURVEY.md §8 rows a16/a17)' % model_name)
+        elif model_name == 'nlspn':
+            from .nlspn import NlspnModel_Adapt
+            self.model = NlspnModel_Adapt(device=device, max_depth=max_predict_depth, offset=offset, dataset_name=dataset_name,
+                                          from_scratch=from_scratch, max_input_depth=max_input_depth)
+        elif 'costdcnet' in model_name:
+            raise NotImplementedError('%s is not on the MI355X hot path yet (SURVEY.md §8 row a17)' % model_name)
         else:
             raise ValueError('Unsupported depth completion model: {}'.format(model_name))
 

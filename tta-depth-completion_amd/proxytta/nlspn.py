@@ -1,0 +1,118 @@
+"""Host-side mirror of src/nlspn_model_adapt.py (NLSPNModel_Adapt, the per-backbone adapter the reference selects
+with model_name='nlspn', src/external_model_adapt.py:61-63) on libptta_hip.
+
+What is on the accelerated path: the canonical TTA flow of bash/adapt/adapt_nlspn_*.sh --
+prepare_mode 'meta_selfsup_seq_1layer_ema', adapt_mode 'meta_bn', loss_type 'adapt_meta_selfsup_seq_ema_reverse':
+``step()`` (forward [grad pass + zero-image proxy pass + heads] + adapt_loss + backward + Adam on the 88 adapted
+tensors, src/tta_main.py:610-633) and the eval ``forward()`` (:729-736).  The split training forward /
+compute_loss / loss.backward() surface is MSG_CHN-only for now; calling it raises NotImplementedError.
+Frame sizes must be multiples of 16 (the decoder crops of nlspnmodel_adapt.py:474-490 are not implemented).
+The eval path's biharmonic hole filling (src/nlspn_model_adapt.py:124-127, skimage on the CPU) is not applied: exact
+zeros of the clamped output are returned as zeros.
+"""
+import torch
+import torch.nn as nn
+
+from . import synth
+from .engine import Engine
+from .model import MsgChnModel_Adapt, _init_tensor, _Tree
+
+_BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked')
+
+
+def nlspn_adapted_names(keys):
+    """adapt_parameters('meta_bn') (src/nlspn_model_adapt.py:322-337): parameters whose name contains 'meta', then
+    weight / bias of every BatchNorm2d in module order (the heads' BatchNorm1d are not BatchNorm2d)."""
+    names = [k for k in keys if 'meta' in k]
+    for k in keys:
+        if k.endswith('.running_mean') and not k.startswith(('proj', 'pred')):
+            pre = k[:-len('.running_mean')]
+            names += [pre + '.weight', pre + '.bias']
+    return names
+
+
+class NlspnModel_Adapt(MsgChnModel_Adapt):
+    """Counterpart of src/nlspn_model_adapt.py:13-486."""
+
+    def __init__(self, device=torch.device('cuda'), max_depth=100.0, inpainting=False, use_pretrained=False, dataset_name=None,
+                 from_scratch=False, offset=False, max_input_depth=None):
+        if offset:
+            raise NotImplementedError("legacy offsets (offset=True) are not wired through the façade yet")
+        self.max_predict_depth = max_depth
+        self.max_depth = max_depth
+        self.max_input_depth = max_input_depth
+        self.device = device
+        self.dtype = 'fp32'
+        self.training = True
+        self.prepare_mode = None
+        self.model = _Tree()
+        for k, s in synth.nlspn_keys():
+            if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
+                continue                                      # come with _prepare_head
+            self.model._leaf(k, self._init(k, s), not k.endswith(_BUFFERS))
+        self._engines = {}
+        self._opt_state = {}
+        self.hparams = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0)
+        self.total_time = self.train_time = self.eval_time = 0.0
+        self.to(device)
+
+    @staticmethod
+    def _init(name, shape):
+        if name == 'prop_layer.aff_scale_const':
+            return torch.full((1,), 0.5 * 8)
+        if name in ('prop_layer.w', 'prop_layer.w_conf'):
+            return torch.ones(shape)
+        if name == 'prop_layer.b' or name.startswith('prop_layer.conv_offset_aff'):
+            return torch.zeros(shape)                         # nlspnmodel_adapt.py:221-222: zero-initialised
+        return _init_tensor(name, shape)
+
+    def _prepare_head(self, mode=''):
+        """NLSPNModel_Adapt._prepare_head (nlspnmodel_adapt.py:1333-1396)."""
+        if 'meta' not in mode or 'selfsup' not in mode or 'ema' not in mode or 'seq' not in mode or '1layer' not in mode:
+            raise NotImplementedError('hot path covers prepare_mode meta_selfsup_seq_1layer_ema, got %r' % mode)
+        self.prepare_mode = mode
+        self.meta = '1layer'
+        for k, s in synth.nlspn_keys(mode):
+            if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
+                self.model._leaf(k, _init_tensor(k, s).to(self.device), not k.endswith(_BUFFERS))
+        self.adapted = nlspn_adapted_names([k for k, _ in synth.nlspn_keys(mode)])
+        self._engines.clear()
+
+    def adapt_parameters(self, mode=None):
+        if mode != 'meta_bn':
+            raise NotImplementedError("adapt_mode %r: only 'meta_bn' (the NLSPN scripts' mode) is on the accelerated path" % mode)
+        params = dict(self.model.named_parameters())
+        return nn.ParameterList([params[k] for k in self.adapted])
+
+    def _engine(self, image):
+        n, _, h, w = image.shape
+        key = (n, h, w)
+        eng = self._engines.get(key)
+        if eng is None:
+            if self.prepare_mode is None:
+                raise RuntimeError('_prepare_head(mode) must be called before forward (tta_main.py:322)')
+            eng = Engine(n, h, w, backbone='nlspn', max_input_depth=self.max_input_depth, **self.hparams)
+            assert eng.adapted == self.adapted, 'adapted parameter list drifted from the library'
+            eng.load_state_dict({k: v for k, v in self.model.state_dict().items() if v.dtype == torch.float32})
+            params = dict(self.model.named_parameters())
+            for name in self.adapted:
+                p = params[name]
+                st = self._opt_state.setdefault(name, {'exp_avg': torch.zeros_like(p.data), 'exp_avg_sq': torch.zeros_like(p.data)})
+                eng.bind_adapted(name, p.data, st['exp_avg'], st['exp_avg_sq'])
+            if getattr(self, '_image_norm', None) is not None:
+                eng.set_image_norm(self._image_norm)
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, image, sparse_depth, intrinsics=None, crop_mask=None, loss_type='pretrain'):
+        if self.training and 'adapt' in loss_type:
+            raise NotImplementedError('NLSPN: the split training forward is not exposed; use step() (fused forward + loss + '
+                                      'backward + Adam) -- SURVEY.md §8 row a16')
+        with torch.no_grad():
+            return self._engine(image).forward_eval(image, sparse_depth)
+
+    def save_model(self, checkpoint_path, step, optimizer, meanvar=None):
+        ckpt = {'net': self.model.state_dict(), 'optimizer': optimizer.state_dict() if optimizer else {}, 'train_step': step}
+        if meanvar is not None:
+            ckpt['meanvar'] = meanvar                         # src/nlspn_model_adapt.py:473-475
+        torch.save(ckpt, checkpoint_path)

@@ -87,8 +87,8 @@ def test_forward_train_and_eval_match_oracle(shape, impl):
     assert rel_mae(fe6, nhwc(inter['fe6'])) < tol['feat']
     assert rel_mae(eng.debug_tensor('pred_init').view(n, 1, h, w), inter['pred_init']) < tol['feat']
     assert rel_mae(eng.debug_tensor('confidence').view(n, 1, h, w), inter['confidence']) < tol['feat']
-    off9 = eng.debug_tensor('off9').view(n, h, w, 18).permute(0, 3, 1, 2)
-    aff9 = eng.debug_tensor('aff9').view(n, h, w, 9).permute(0, 3, 1, 2)
+    off9 = eng.debug_tensor('off9').view(n, 18, h, w)
+    aff9 = eng.debug_tensor('aff9').view(n, 9, h, w)
     assert rel_mae(off9, inter['offset']) < tol['feat']
     assert rel_mae(aff9, inter['aff']) < tol['feat']
     assert rel_mae(depth, d_ref) < tol['depth']

@@ -46,7 +46,9 @@ struct GConvW {            // frozen convolution weights, packed once at load ti
     float *wf = nullptr, *wb = nullptr, *bias = nullptr;
     int Ci = 0, Co = 0, k = 3, stride = 1, transposed = 0;
     int C0 = 0, C1 = 0;                                   // source split of the input channels (torch.cat order)
+    int Co_pad = 0;
     int Ci_real = 0;                                      // > 0: the state_dict tensor has fewer input channels than the zero-padded activation
+    float* gpad = nullptr;                                // zero-padded copy of the output gradient (Co_pad channels)
     bf16_t *ff_hi = nullptr, *ff_lo = nullptr, *fb_hi = nullptr, *fb_lo = nullptr;     // bf16x3 MFMA fragments (forward / data gradient)
     bool mf = false, mb = false;                          // matrix-core kernel usable for forward / data gradient
     bool loaded = false, has_bias = false;
@@ -89,6 +91,13 @@ __global__ void clamp_bwd_kernel(const float* __restrict__ g, const float* __res
 }
 __global__ void validity_kernel(const float* __restrict__ sp, float* __restrict__ v, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { const float s = sp[i]; v[i] = s > 0.f ? 1.f : s; }
+}
+__global__ void pad_channels_kernel(const float* __restrict__ src, int lds_, int C, float* __restrict__ dst, int Cp, long npix) {
+    const long total = npix * Cp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp); const long p = i / Cp;
+        dst[i] = c < C ? src[p * lds_ + c] : 0.f;
+    }
 }
 inline int nb(long total) { long b = (total + 255) / 256; if (b > 16384) b = 16384; if (b < 1) b = 1; return (int)b; }
 
@@ -168,7 +177,8 @@ struct nlspn_engine {
         cw.Ci = T[x0].C + (x1 >= 0 ? T[x1].C : 0); cw.Co = T[y].C; cw.k = k; cw.stride = stride; cw.transposed = transposed;
         cw.C0 = T[x0].C; cw.C1 = x1 >= 0 ? T[x1].C : 0;
         cw.mf = !naive && (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0;
-        cw.mb = !naive && (cw.Co % 16) == 0 && (cw.C1 == 0 || (cw.C0 % 32) == 0);
+        cw.mb = !naive && ((cw.Co % 16) == 0 || (stride == 1 && !transposed)) && (cw.C1 == 0 || (cw.C0 % 32) == 0);
+        cw.Co_pad = (cw.Co + 15) / 16 * 16;               // data gradient of a conv with < 16 output channels: gy is zero-padded
         ops.push_back(o);
     }
     // y = act(bn(x)) [+ res, relu]; adapted gamma/beta unless frozen (heads)
@@ -314,6 +324,7 @@ struct nlspn_engine {
             GConvW& cw = kv.second;
             const int KK = cw.k * cw.k;
             if (cw.mf) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.C0, cw.C1, cw.Co); cw.ff_hi = (bf16_t*)dalloc(n * 2); cw.ff_lo = (bf16_t*)dalloc(n * 2); }
+            if (cw.mb && !cw.Ci_real && cw.Co_pad != cw.Co) cw.gpad = falloc((size_t)N * T[0].H * T[0].W * cw.Co_pad);
             if (cw.mb && !cw.Ci_real) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.Ci); cw.fb_hi = (bf16_t*)dalloc(n * 2); cw.fb_lo = (bf16_t*)dalloc(n * 2); }
             if (kv.first == "conv1_rgb_meta") continue;
             const size_t n = (size_t)KK * cw.Ci * cw.Co;
@@ -472,12 +483,21 @@ int run_conv_bwd(nlspn_engine* e, const Op& o, hipStream_t s) {
     GView gy = e->view(o.y, W_GRAD, true, true);
     const GView yv = e->view(o.y, W_GRAD, true);
     if (o.act != GACT_NONE && ptta_launch_gact_bwd(gy, yv, o.act, s)) return e->fail("activation gradient failed", -5);
+    bool padded = false;
     for (int sidx = 0; sidx < o.nsrc; ++sidx) {
         if (!e->T[o.x[sidx]].need_grad) continue;
         if (cw.mb && (o.c0[sidx] % 32) == 0) {
             GX3Args a;
             const GView gx = e->view(o.x[sidx], W_GRAD, true, true);
             a.x0 = gy.p; a.C0 = gy.C; a.ld0 = gy.ld;
+            if (cw.gpad) {                                   // < 16 gradient channels: matrix-core kernel on a zero-padded copy
+                if (sidx == 0 || !padded) {
+                    hipLaunchKernelGGL(pad_channels_kernel, dim3(nb((long)gy.B * gy.H * gy.W * cw.Co_pad)), dim3(256), 0, s, gy.p, gy.ld, gy.C,
+                                       cw.gpad, cw.Co_pad, (long)gy.B * gy.H * gy.W);
+                    padded = true;
+                }
+                a.x0 = cw.gpad; a.C0 = cw.Co_pad; a.ld0 = cw.Co_pad;
+            }
             a.B = gy.B; a.H = gy.H; a.W = gy.W;
             a.whi = (const uint4*)cw.fb_hi; a.wlo = (const uint4*)cw.fb_lo;
             a.nchunks = (a.C0 + 31) / 32; a.nf0 = o.c0[sidx] / 32; a.nnf = (gx.C + 31) / 32;

@@ -9,7 +9,8 @@
 //   nl_prop_bwd     : its gradient (tap-affinity and offset gradients as gathers, feature gradient as a scatter
 //                     of float atomics like the reference's col2im, modulated_deform_im2col_cuda.cuh:197-254),
 //   nl_affinity_bwd : gradient of the fused affinity pass wrt the conv output and the confidence map.
-// Layouts: feature / confidence / sparse maps planar [B][H*W]; off9 [B][H*W][18] (h,w per tap), aff9 [B][H*W][9];
+// Layouts: feature / confidence / sparse maps planar [B][H*W]; off9 [B][18][H*W] (h,w per tap), aff9 [B][9][H*W]
+// (the reference's NCHW offset / mask tensors: consecutive lanes read consecutive addresses);
 // the conv output is a strided NHWC view with 24 channels (o1 | o2 | aff as torch.chunk sees them, :259-260).
 #include "ptta_common.h"
 #include "ptta_kernels.h"
@@ -57,17 +58,17 @@ __global__ __launch_bounds__(256) void nl_affinity_fwd_kernel(GView oa, const fl
         for (int k = 0; k < 24; ++k) v[k] = src[k];
         AffPix r;
         aff_forward_pixel(v, conf + (long)b * P, H, W, y, x, S, legacy, r);
-        float* o = off9 + idx * 18; float* a = aff9 + idx * 9;
+        float* o = off9 + (long)b * 18 * P + pix; float* a = aff9 + (long)b * 9 * P + pix;
         float sum = 0.f;
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
             const int k = tap_of_pair(n);
-            o[2 * k] = v[2 * n]; o[2 * k + 1] = v[2 * n + 1];
+            o[(long)(2 * k) * P] = v[2 * n]; o[(long)(2 * k + 1) * P] = v[2 * n + 1];
             const float an = r.a[n] / r.sp;
-            a[k] = an; sum += an;
+            a[(long)k * P] = an; sum += an;
         }
-        o[8] = 0.f; o[9] = 0.f;
-        a[4] = 1.f - sum;
+        o[8 * P] = 0.f; o[9 * P] = 0.f;
+        a[4 * P] = 1.f - sum;
     }
 }
 
@@ -101,12 +102,12 @@ __global__ __launch_bounds__(256) void nl_prop_fwd_kernel(const float* __restric
         const int b = (int)(idx / P); const long pix = idx % P;
         const int y = (int)(pix / W), x = (int)(pix % W);
         const float* fb = feat + (long)b * P; const float* xb = fix + (long)b * P;
-        const float* o = off9 + idx * 18; const float* a = aff9 + idx * 9;
+        const float* o = off9 + (long)b * 18 * P + pix; const float* a = aff9 + (long)b * 9 * P + pix;
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const Tap t = tap_sample(fb, xb, H, W, (float)(y + k / 3 - 1) + o[2 * k], (float)(x + k % 3 - 1) + o[2 * k + 1]);
-            acc = fmaf(a[k], tap_value(t), acc);
+            const Tap t = tap_sample(fb, xb, H, W, (float)(y + k / 3 - 1) + o[(long)(2 * k) * P], (float)(x + k % 3 - 1) + o[(long)(2 * k + 1) * P]);
+            acc = fmaf(a[(long)k * P], tap_value(t), acc);
         }
         out[idx] = acc;
     }
@@ -140,18 +141,18 @@ __global__ __launch_bounds__(256) void nl_prop_bwd_kernel(const float* __restric
         else atomicAdd(gb + qy * W + qx, v);
     };
     if (y < H && x < W) {
-        const long idx = (long)b * P + (long)y * W + x;
-        const float* o = off9 + idx * 18; const float* a = aff9 + idx * 9;
-        float* go = goff9 + idx * 18; float* ga = gaff9 + idx * 9;
+        const long pix = (long)y * W + x, idx = (long)b * P + pix;
+        const float* o = off9 + (long)b * 18 * P + pix; const float* a = aff9 + (long)b * 9 * P + pix;
+        float* go = goff9 + (long)b * 18 * P + pix; float* ga = gaff9 + (long)b * 9 * P + pix;
         const float g = gout[idx];
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const Tap t = tap_sample(fb, xb, H, W, (float)(y + k / 3 - 1) + o[2 * k], (float)(x + k % 3 - 1) + o[2 * k + 1]);
-            const float hh = 1.f - t.c.lh, hw = 1.f - t.c.lw, ga_ = g * a[k];
-            ga[k] += g * tap_value(t);
+            const Tap t = tap_sample(fb, xb, H, W, (float)(y + k / 3 - 1) + o[(long)(2 * k) * P], (float)(x + k % 3 - 1) + o[(long)(2 * k + 1) * P]);
+            const float hh = 1.f - t.c.lh, hw = 1.f - t.c.lw, ga_ = g * a[(long)k * P];
+            ga[(long)k * P] += g * tap_value(t);
             // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
-            go[2 * k] += ga_ * (-hw * t.v1 - t.c.lw * t.v2 + hw * t.v3 + t.c.lw * t.v4);
-            go[2 * k + 1] += ga_ * (-hh * t.v1 + hh * t.v2 - t.c.lh * t.v3 + t.c.lh * t.v4);
+            go[(long)(2 * k) * P] += ga_ * (-hw * t.v1 - t.c.lw * t.v2 + hw * t.v3 + t.c.lw * t.v4);
+            go[(long)(2 * k + 1) * P] += ga_ * (-hh * t.v1 + hh * t.v2 - t.c.lh * t.v3 + t.c.lh * t.v4);
             const int h1 = t.c.h0 + 1, w1 = t.c.w0 + 1;
             if (t.o1) scatter(t.c.h0, t.c.w0, hh * hw * ga_);
             if (t.o2) scatter(t.c.h0, w1, hh * t.c.lw * ga_);
@@ -184,12 +185,12 @@ __global__ __launch_bounds__(256) void nl_affinity_bwd_kernel(GView oa, const fl
         for (int k = 0; k < 24; ++k) v[k] = src[k];
         AffPix r;
         aff_forward_pixel(v, conf + (long)b * P, H, W, y, x, S, legacy, r);
-        const float* go = goff9 + idx * 18; const float* ga = gaff9 + idx * 9;
+        const float* go = goff9 + (long)b * 18 * P + pix; const float* ga = gaff9 + (long)b * 9 * P + pix;
         float* dst = goa.p + idx * goa.ld;
         // centre = 1 - sum(a_hat): G_n = g_hat_n - g_centre ; a_hat = a / sp ; sp = max(sum|a| + 1e-4, 1)
         float G[8], dot = 0.f;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) { G[n] = ga[tap_of_pair(n)] - ga[4]; dot += G[n] * (r.a[n] / r.sp); }
+        for (int n = 0; n < 8; ++n) { G[n] = ga[(long)tap_of_pair(n) * P] - ga[4 * P]; dot += G[n] * (r.a[n] / r.sp); }
         const bool through = !(r.s < 1.f);
         float* gcb = gconf + (long)b * P;
 #pragma unroll
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void nl_affinity_bwd_kernel(GView oa, const fl
             const float g_t = g_a * r.c[n], g_c = g_a * r.t[n];
             const float th = r.t[n] * (S + 1e-8f);                    // tanh(raw)
             dst[16 + n] = g_t * (1.f - th * th) / (S + 1e-8f);
-            dst[2 * n] = go[2 * k]; dst[2 * n + 1] = go[2 * k + 1];   // offsets are used (not detached) only by the sweeps
+            dst[2 * n] = go[(long)(2 * k) * P]; dst[2 * n + 1] = go[(long)(2 * k + 1) * P];   // offsets are used (not detached) only by the sweeps
             // confidence gather at the detached offset: scatter g_c onto the bilinear corners
             float oh = v[2 * n], ow = v[2 * n + 1];
             if (legacy) { oh += (float)(k / 3) - 1.f; ow += (float)(k % 3) - 1.f; }

@@ -223,10 +223,12 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
                 active = ((ty & 1) == 0) && ((tx & 1) == 0);
                 yi = ty >> 1; xi = x0 + i + (tx >> 1);
             }
-            active = active && (yi >= 0) && (yi < Hin);
-            if (!active) continue;                                    // wave-uniform
-            const bool ok = lane_in && (xi >= 0) && (xi < Win);
-            const float* q = inb + ((size_t)yi * Win + (ok ? xi : 0)) * ld;
+            // stride 2: out-of-range rows are folded into the load predicate (zero operands) so that the nine taps form
+            // one branch-free region and their loads can all be in flight; transposed: 5 to 8 of the 9 taps are
+            // inactive by parity (wave-uniform), skipping them is worth the branch
+            if (MODE == 2 && !(active && yi >= 0 && yi < Hin)) continue;
+            const bool ok = lane_in && (xi >= 0) && (xi < Win) && (yi >= 0) && (yi < Hin);
+            const float* q = inb + ((size_t)(ok ? yi : 0) * Win + (ok ? xi : 0)) * ld;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;

@@ -1,4 +1,4 @@
-/* libptta_hip — C ABI of the MI355X-native ProxyTTA test-time-adaptation step (MSG_CHN backbone).
+/* libptta_hip — C ABI of the MI355X-native ProxyTTA test-time-adaptation step (MSG_CHN and NLSPN backbones).
  *
  * This is the drop-in boundary for the hot path of seobbro/TTA-depth-completion.  The reference
  * has no FFI for this path (it is Python calling ATen); each entry point below names the Python
@@ -25,6 +25,15 @@ extern "C" {
 typedef struct ptta_ctx* ptta_handle;
 typedef void* ptta_stream;              /* hipStream_t */
 
+/* PTTA_BACKBONE_NLSPN: ExternalModel_Adapt(model_name='nlspn') -- src/nlspn_model_adapt.py:13-128 ->
+ * NLSPNModel_Adapt._rgbd_meta_contrast (external_src/NLSPN/src/model/nlspnmodel_adapt.py:850-944), adapter settings of
+ * src/nlspn_model_adapt.py:56-68, adapt_parameters('meta_bn') (:322-337).  meta_mode must be PTTA_META_1LAYER, dtype
+ * PTTA_DTYPE_F32, height and width multiples of 16.  Differences from the MSG_CHN handle: embeddings are (rows, 1024)
+ * with rows = n*(H/16)*(W/16); ptta_adapted_count() is 88 (conv1_rgb_meta + every BatchNorm2d weight/bias, in the
+ * reference's order) and every one of them must be bound; ptta_load_weights ignores BatchNorm running statistics
+ * (dropped by 'meta_bn') and the values of adapted tensors (the bound tensors are read instead);
+ * ptta_loss_forward/backward, ptta_backward, ptta_adam_step, ptta_set_graph and ptta_profile return -38 (use
+ * ptta_step / ptta_forward_train / ptta_forward_eval / ptta_get_grad). */
 enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1 };
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
 enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */

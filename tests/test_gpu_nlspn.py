@@ -206,3 +206,26 @@ def test_external_model_adapt_facade_nlspn(golden_dir):
     model.eval()
     d2 = model.forward(raw, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
     assert rel_mae(d2, d_eval) < 1e-4
+
+
+def test_error_paths_fail_loudly():
+    """Unknown keys, wrong shapes, unbound adapted tensors and MSG_CHN-only entry points are errors with a message,
+    never a silent fallback."""
+    eng = Engine(1, 32, 64, backbone='nlspn', **HP)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
+    with pytest.raises(RuntimeError, match='unknown state_dict key'):
+        eng.load_state_dict({'conv99.0.weight': sd['conv6.0.weight']})
+    with pytest.raises(RuntimeError, match='shape mismatch'):
+        eng.load_state_dict({'conv6.0.weight': sd['dec5.0.weight']})
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, 32, 64, 1)]
+    with pytest.raises(RuntimeError, match='not bound'):
+        eng.forward_eval(image1, sparse)
+    for k in eng.adapted:
+        eng.bind_adapted(k, sd[k].clone(), torch.zeros_like(sd[k]), torch.zeros_like(sd[k]))
+    with pytest.raises(RuntimeError, match='not loaded'):
+        eng.forward_eval(image1, sparse)
+    with pytest.raises(RuntimeError, match='not an adapted parameter'):
+        eng.bind_adapted('conv6.0.weight', sd['conv6.0.weight'], sd['conv6.0.weight'], sd['conv6.0.weight'])
+    with pytest.raises(RuntimeError, match='NLSPN'):
+        eng.backward(torch.zeros(1, 1, 32, 64, device='cuda'), None)
+    eng.close()

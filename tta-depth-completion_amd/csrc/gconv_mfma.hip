@@ -4,11 +4,14 @@
 // arithmetic as the MSG_CHN hot path (conv32.hip), generalised over input-channel chunks and output-channel tiles.
 //
 // Block = 256 threads = 4 waves, output tile 8 rows x 32 pixels x 32 output channels (one MFMA column fragment).
-// K loop over 32-channel chunks of the source(s): the (8+2)x(32+2) halo of the chunk is split into bf16 hi/lo while
-// it is staged into LDS ([pixel][hi 64 B | lo 64 B], 144-B stride: conflict-free ds_read_b128), the chunk's weight
-// fragments come pre-split from global memory: hi in registers (72 VGPRs), lo in LDS.  Each wave owns two rows of
-// the tile: 2 x f32x16 accumulators live across the whole K loop.  The next chunk's halo loads are issued before
-// the current chunk's MFMAs.  Output channel tiles of the same pixel tile are adjacent in the grid (L2 reuse).
+// K loop over 16-channel sub-chunks of the source(s): the (8+2)x(32+2) halo of the sub-chunk is split into bf16 hi/lo
+// while it is staged into LDS ([pixel][hi 32 B | lo 32 B | pad 16 B]: conflict-free ds_read_b128) and ALL weight
+// fragments of the sub-chunk (hi and lo, 18 KB for 3x3, pre-split in global memory) are staged cooperatively next to
+// it -- 45 KB of LDS and ~160 VGPRs, three blocks per CU.  Each wave owns two rows of the tile: 2 x f32x16
+// accumulators live across the whole K loop; the next sub-chunk's halo and weights are loaded into registers before
+// the current sub-chunk's MFMAs.  Output channel tiles of the same pixel tile are adjacent in the grid (L2 reuse).
+// (Measured alternatives, all slower: hi fragments in registers per wave -- 2.5x the weight traffic through L1, the
+// bottleneck by ablation; 64-channel output tiles; double-buffered LDS with hi fragments in registers.)
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -24,10 +27,8 @@ __device__ __forceinline__ void gsplit2(float a, float b, unsigned& hi, unsigned
     float2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
-__device__ __forceinline__ int gstage_pix(int idx) { return ((idx >> 5) << 3) + (((idx >> 2) & 1) << 2) + ((idx >> 3) & 3); }
 
 #define GX_TH 8
-#define GX_STRIDE 144
 
 // fragment (nf, chunk, tap, kk): lane l holds column co = 32 nf + (l & 31), rows ci = 32 chunk + 16 kk + 8 (l >> 5) + e
 __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1,
@@ -51,18 +52,22 @@ __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, lon
     }
 }
 
+#define GX_STR16 80                                      // LDS bytes per pixel: hi 32 | lo 32 | pad 16
 template <int KS>
-__global__ __launch_bounds__(256, 2) void gconv_x3_s1_kernel(GX3Args p) {
+__global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
     constexpr int PAD = KS / 2, PH = GX_TH + 2 * PAD, PW = 32 + 2 * PAD, KK = KS * KS;
-    constexpr int NIT = (((PH * PW + 7) / 8) * 32 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[PH * PW * GX_STRIDE + KK * 2 * 64 * 16];
-    unsigned char* const wl_lds = lds + PH * PW * GX_STRIDE;
+    constexpr int NPIX = PH * PW;
+    constexpr int NIT = (NPIX * 2 + 255) / 256;          // (pixel, 8-channel group) items per thread
+    constexpr int NWF = KK * 64 * 2;                     // weight uint4 per sub-chunk: [hi | lo][tap][lane]
+    constexpr int NW = (NWF + 255) / 256;
+    constexpr int ACT = NPIX * GX_STR16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[ACT + NWF * 16];
+    uint4* const wlds = (uint4*)(lds + ACT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
     const int ntx = (W + 31) >> 5, nty = (H + GX_TH - 1) / GX_TH;
-    // block -> (pixel tile, output-channel tile); channel tile fastest
     const int nfl = (int)(blockIdx.x % p.nnf);
     long t_ = blockIdx.x / p.nnf;
     const int ty = (int)(t_ % nty); t_ /= nty;
@@ -71,24 +76,34 @@ __global__ __launch_bounds__(256, 2) void gconv_x3_s1_kernel(GX3Args p) {
     const int y0 = ty * GX_TH, x0 = tx << 5;
     const int nf = p.nf0 + nfl;
     const int nch0 = (p.C0 + 31) >> 5;
+    const int nq = 2 * p.nchunks;
 
     float4 v0[NIT], v1[NIT];
-    auto issue_loads = [&](int c) {
+    uint4 wr[NW];
+    auto issue_loads = [&](int q) __attribute__((always_inline)) {
+        const int c = q >> 1, kk = q & 1;
         const bool s1 = c >= nch0;
         const float* src = s1 ? p.x1 : p.x0;
-        const int ld = s1 ? p.ld1 : p.ld0, Cs = s1 ? p.C1 : p.C0, cb = (s1 ? c - nch0 : c) << 5;
+        const int ld = s1 ? p.ld1 : p.ld0, Cs = s1 ? p.C1 : p.C0, cb = ((s1 ? c - nch0 : c) << 5) + 16 * kk;
         const float* inb = src + (size_t)b * H * W * ld + cb;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
-            const int g = idx & 3, pix = gstage_pix(idx);
+            const int g = idx & 1, pix = idx >> 1;
             const int py = pix / PW, px = pix - py * PW;
             const int gy = y0 - PAD + py, gx = x0 - PAD + px;
             v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
-            if (pix < PH * PW && gy >= 0 && gy < H && gx >= 0 && gx < W && cb + 8 * g < Cs) {
-                const float* q = inb + ((size_t)gy * W + gx) * ld + 8 * g;
-                v0[it] = *(const float4*)q; v1[it] = *(const float4*)(q + 4);
+            if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && cb < Cs) {
+                const float* s_ = inb + ((size_t)gy * W + gx) * ld + 8 * g;
+                v0[it] = *(const float4*)s_; v1[it] = *(const float4*)(s_ + 4);
             }
+        }
+        const size_t wbase = ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + kk * 64;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int idx = tid + 256 * j;                // [hl][tap][lane]
+            const int hl = idx / (KK * 64), r = idx - hl * (KK * 64);
+            wr[j] = idx < NWF ? (hl ? p.wlo : p.whi)[wbase + (r >> 6) * 128 + (r & 63)] : make_uint4(0, 0, 0, 0);
         }
     };
     f32x16 acc[2];
@@ -98,56 +113,46 @@ __global__ __launch_bounds__(256, 2) void gconv_x3_s1_kernel(GX3Args p) {
         for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
 
     issue_loads(0);
-    for (int c = 0; c < p.nchunks; ++c) {
-        // this chunk's weight fragments: hi -> registers, lo -> LDS
-        uint4 wh[KK][2];
-        const uint4* ph = p.whi + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64);
-        const uint4* pl = p.wlo + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64);
-#pragma unroll
-        for (int t = 0; t < KK; ++t)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-        if (c) __syncthreads();                       // the previous chunk's MFMAs are done with the LDS tile
-        for (int idx = tid; idx < KK * 2 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+    for (int q = 0; q < nq; ++q) {
+        if (q) __syncthreads();                          // previous sub-chunk's MFMAs are done with the LDS tile
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
-            const int pix = gstage_pix(idx);
-            if (pix < PH * PW) {
+            const int pix = idx >> 1;
+            if (pix < NPIX) {
                 const float4 a0 = v0[it], a1 = v1[it];
                 uint4 hi, lo;
                 gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
                 gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
-                unsigned char* dst = lds + pix * GX_STRIDE + 16 * (idx & 3);
+                unsigned char* dst = lds + pix * GX_STR16 + 16 * (idx & 1);
                 *(uint4*)dst = hi;
-                *(uint4*)(dst + 64) = lo;
+                *(uint4*)(dst + 32) = lo;
             }
         }
-        if (c + 1 < p.nchunks) issue_loads(c + 1);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < NWF) wlds[idx] = wr[j];
+        }
+        if (q + 1 < nq) issue_loads(q + 1);
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row = 2 * wave + rr;
+        for (int tap = 0; tap < KK; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, wlds[tap * 64 + lane]);
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, wlds[KK * 64 + tap * 64 + lane]);
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                const int ky = tap / KS, kx = tap % KS;
-                const unsigned char* a = lds + ((row + ky) * PW + i + kx) * GX_STRIDE + 16 * h;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[rr], 0, 0, 0);
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[rr], 0, 0, 0);
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rr], 0, 0, 0);
-                }
-                if (kx == KS - 1) __builtin_amdgcn_sched_barrier(0);
+            for (int rr = 0; rr < 2; ++rr) {
+                const unsigned char* a = lds + ((2 * wave + rr + ky) * PW + i + kx) * GX_STR16 + 16 * h;
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
+                const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[rr], 0, 0, 0);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[rr], 0, 0, 0);
+                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rr], 0, 0, 0);
             }
         }
     }
-    // epilogue: lane = output channel (column i of the fragment), 16 pixels per lane
-    const int co = nf * 32 + i - p.nf0 * 32;          // channel inside the output view
+    const int co = nf * 32 + i - p.nf0 * 32;
     if (co >= p.Cy) return;
     const float bias = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
@@ -169,7 +174,6 @@ __global__ __launch_bounds__(256, 2) void gconv_x3_s1_kernel(GX3Args p) {
         }
     }
 }
-
 
 // ---- stride-2 and transposed (fractionally strided) geometries: direct A loads, no LDS ----------------------------
 // One wave = 32 outputs of one output row (transposed: of one x parity, so that all lanes use the same taps) x 32

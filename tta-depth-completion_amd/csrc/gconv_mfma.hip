@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
 
     issue_loads(0);
     for (int q = 0; q < nq; ++q) {
-        if (q) __syncthreads();                          // previous sub-chunk's MFMAs are done with the LDS tile
+        if (q) lds_barrier();                            // previous sub-chunk's MFMAs are done with the LDS tile
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             if (idx < NWF) wlds[idx] = wr[j];
         }
         if (q + 1 < nq) issue_loads(q + 1);
-        __syncthreads();
+        lds_barrier();                                   // LDS-only: the loads just issued stay in flight during the MFMAs
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int ky = tap / KS, kx = tap % KS;

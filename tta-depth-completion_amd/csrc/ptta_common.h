@@ -197,4 +197,14 @@ __device__ __forceinline__ float bilinear_at(const float* __restrict__ im, int H
 
 
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding GLOBAL load
+// (s_waitcnt vmcnt(0)), which turns a register prefetch issued before the barrier into a synchronous load; this one
+// waits for the wave's LDS operations and leaves vector-memory loads in flight across the barrier
+// (cdna_hip_programming.md, "Pipelining across barriers").
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 #define PTTA_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
                 *(float4*)(up_lds + pix * 32 + 4 * q) = *(const float4*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q);
             }
         }
-        __syncthreads();
+        lds_barrier();          // LDS-only: the next tile's global loads (issued above) stay in flight during the MFMAs
         // ---- two output rows per wave ------------------------------------------------------------
 #pragma unroll 1
         for (int rr = 0; rr < 2; ++rr) {

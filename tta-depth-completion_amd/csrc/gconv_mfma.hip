@@ -186,12 +186,16 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
 template <int MODE, int KS>
 __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin, int Win) {
     constexpr int PAD = KS / 2, KK = KS * KS;
+    // stride 2: two output rows per wave, tap-outer / row-inner, so the A loads of both rows are in flight before the
+    // first MFMA and the weight fragments are fetched once per two rows; transposed: one row (its active taps depend on
+    // the row parity)
+    constexpr int R = MODE == 1 ? 2 : 1;
     const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int Hout = p.H, Wout = p.W;
     const int Wt = MODE == 2 ? Win : Wout;
-    const int nseg = (Wt + 31) >> 5, npar = MODE == 2 ? 2 : 1;
-    const long nitems = (long)p.B * nseg * npar * Hout;
+    const int nseg = (Wt + 31) >> 5, npar = MODE == 2 ? 2 : 1, nyg = (Hout + R - 1) / R;
+    const long nitems = (long)p.B * nseg * npar * nyg;
     const int nch0 = (p.C0 + 31) >> 5;
     // block -> (4 consecutive items, channel tile); channel tile fastest
     const int nfl = (int)(blockIdx.x % p.nnf);
@@ -199,16 +203,18 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
     if (item >= nitems) return;
     const int nf = p.nf0 + nfl;
     long t_ = item;
-    const int y = (int)(t_ % Hout); t_ /= Hout;
+    const int yg = (int)(t_ % nyg); t_ /= nyg;
     int xpar = 0;
     if (MODE == 2) { xpar = (int)(t_ & 1); t_ >>= 1; }
     const int seg = (int)(t_ % nseg);
     const int b = (int)(t_ / nseg);
-    const int x0 = seg << 5;
+    const int x0 = seg << 5, ybase = yg * R;
     const bool lane_in = (x0 + i) < Wt;
-    f32x16 acc;
+    f32x16 acc[R];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
     for (int c = 0; c < p.nchunks; ++c) {
         const bool s1 = c >= nch0;
         const float* src = s1 ? p.x1 : p.x0;
@@ -219,52 +225,62 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
-            bool active = true;
-            int yi, xi;
-            if (MODE == 1) { yi = 2 * y + ky - PAD; xi = 2 * (x0 + i) + kx - PAD; }
-            else {
-                const int ty = y + PAD - ky, tx = xpar + PAD - kx;
-                active = ((ty & 1) == 0) && ((tx & 1) == 0);
-                yi = ty >> 1; xi = x0 + i + (tx >> 1);
+            if (MODE == 2) {
+                const int ty = ybase + PAD - ky, tx = xpar + PAD - kx;
+                const int yi = ty >> 1;
+                if ((ty & 1) || (tx & 1) || yi < 0 || yi >= Hin) continue;          // wave-uniform: 5 to 8 of 9 taps are inactive by parity
             }
-            // stride 2: out-of-range rows are folded into the load predicate (zero operands) so that the nine taps form
-            // one branch-free region and their loads can all be in flight; transposed: 5 to 8 of the 9 taps are
-            // inactive by parity (wave-uniform), skipping them is worth the branch
-            if (MODE == 2 && !(active && yi >= 0 && yi < Hin)) continue;
-            const bool ok = lane_in && (xi >= 0) && (xi < Win) && (yi >= 0) && (yi < Hin);
-            const float* q = inb + ((size_t)(ok ? yi : 0) * Win + (ok ? xi : 0)) * ld;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-                if (ok && cb + 16 * k + 8 * h < Cs) { a0 = *(const float4*)(q + 16 * k); a1 = *(const float4*)(q + 16 * k + 4); }
-                uint4 hi, lo;
-                gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
-                gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, hi), al = __builtin_bit_cast(bf16x8, lo);
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, ph[(tap * 2 + k) * 64]);
                 const bf16x8 bl = __builtin_bit_cast(bf16x8, pl[(tap * 2 + k) * 64]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                bf16x8 ah[R], al[R];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    const int y = ybase + rr;
+                    int yi, xi;
+                    if (MODE == 1) { yi = 2 * y + ky - PAD; xi = 2 * (x0 + i) + kx - PAD; }
+                    else { yi = (y + PAD - ky) >> 1; xi = x0 + i + ((xpar + PAD - kx) >> 1); }
+                    // out-of-range rows / columns / channels are folded into the load predicate (zero operands): branch-free
+                    const bool ok = lane_in && y < Hout && xi >= 0 && xi < Win && yi >= 0 && yi < Hin && cb + 16 * k + 8 * h < Cs;
+                    const float* q = inb + ((size_t)(ok ? yi : 0) * Win + (ok ? xi : 0)) * ld + 16 * k;
+                    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+                    if (ok) { a0 = *(const float4*)q; a1 = *(const float4*)(q + 4); }
+                    uint4 hi, lo;
+                    gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
+                    gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
+                    ah[rr] = __builtin_bit_cast(bf16x8, hi); al[rr] = __builtin_bit_cast(bf16x8, lo);
+                }
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh, acc[rr], 0, 0, 0);
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl, acc[rr], 0, 0, 0);
+                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bh, acc[rr], 0, 0, 0);
+                }
             }
         }
     }
     const int co = nf * 32 + i - p.nf0 * 32;
     if (co >= p.Cy) return;
     const float bias = p.bias ? p.bias[co] : 0.f;
-    float* yrow = p.y + ((size_t)b * Hout + y) * Wout * p.ldy + co;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int xl = x0 + acc_row(r, h);
-        if (xl >= Wt) continue;
-        const int x = MODE == 2 ? 2 * xl + xpar : xl;
-        float* dst = yrow + (size_t)x * p.ldy;
-        float v = acc[r] + bias;
-        if (p.accumulate) v += *dst;
-        if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
-        else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
-        else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-        *dst = v;
+    for (int rr = 0; rr < R; ++rr) {
+        const int y = ybase + rr;
+        if (y >= Hout) break;
+        float* yrow = p.y + ((size_t)b * Hout + y) * Wout * p.ldy + co;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int xl = x0 + acc_row(r, h);
+            if (xl >= Wt) continue;
+            const int x = MODE == 2 ? 2 * xl + xpar : xl;
+            float* dst = yrow + (size_t)x * p.ldy;
+            float v = acc[rr][r] + bias;
+            if (p.accumulate) v += *dst;
+            if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
+            else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+            else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+            *dst = v;
+        }
     }
 }
 
@@ -377,7 +393,7 @@ int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, in
     if ((a.C0 & 15) || (a.C1 & 15) || (a.ld0 & 3) || (a.ld1 & 3) || (ks != 1 && ks != 3) || (mode != 1 && mode != 2)) return -22;
     if (a.nchunks != (a.C0 + 31) / 32 + (a.C1 + 31) / 32) return -22;
     const int Wt = mode == 2 ? win : a.W;
-    const long nitems = (long)a.B * ((Wt + 31) / 32) * (mode == 2 ? 2 : 1) * a.H;
+    const long nitems = (long)a.B * ((Wt + 31) / 32) * (mode == 2 ? 2 : 1) * (mode == 1 ? (a.H + 1) / 2 : a.H);   // stride 2: two rows per wave
     const long blocks = ((nitems + 3) / 4) * a.nnf;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
 #define L_(M, K) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win)

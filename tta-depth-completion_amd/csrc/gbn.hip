@@ -118,13 +118,16 @@ __global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act
     }
 }
 
+// fused_blocks > 0: `part` was already filled by the producing convolution's epilogue ([pass][fused_blocks][2][C]), skip the
+// statistics pass
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
-                            const float* beta, float* part, float* st, hipStream_t s) {
+                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks) {
     const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
     const size_t lds = (size_t)nsub * 2 * CT * sizeof(float);
     const long R = (long)(x.B / npass) * x.H * x.W;
     int blocks = (int)((R + nsub - 1) / nsub); if (blocks > GBN_BLOCKS) blocks = GBN_BLOCKS; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((gbn_stats_kernel<0>), dim3(blocks, npass), dim3(256), lds, s, x, x, x, npass, 0, 0, nullptr, nullptr, part);
+    if (fused_blocks > 0) blocks = fused_blocks;
+    else hipLaunchKernelGGL((gbn_stats_kernel<0>), dim3(blocks, npass), dim3(256), lds, s, x, x, x, npass, 0, 0, nullptr, nullptr, part);
     hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, R, eps, gamma, beta, st);
     if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
     const long total = (long)x.B * x.H * x.W * (C >> 2);

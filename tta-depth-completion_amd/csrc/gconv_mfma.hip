@@ -152,13 +152,14 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             }
         }
     }
-    const int co = nf * 32 + i - p.nf0 * 32;
-    if (co >= p.Cy) return;
-    const float bias = p.bias ? p.bias[co] : 0.f;
+    const int co = nf * 32 + i - p.nf0 * 32;          // channel inside the output view
+    const bool cok = co < p.Cy;
+    const float bias = (cok && p.bias) ? p.bias[co] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int y = y0 + 2 * wave + rr;
-        if (y >= H) continue;
+        if (y >= H || !cok) continue;
         float* yrow = p.y + ((size_t)b * H + y) * W * p.ldy + co;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -171,6 +172,23 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
             else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
             *dst = v;
+            s1 += v; s2 += v * v;
+        }
+    }
+    if (p.stat_part) {
+        // fused BatchNorm statistics of this tile: lane halves, then the four waves through LDS (fixed order)
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        lds_barrier();                                    // everyone is done with the tile buffers
+        float* red = (float*)lds;                         // [wave 4][2][32]
+        if (h == 0) { red[(wave * 2 + 0) * 32 + i] = s1; red[(wave * 2 + 1) * 32 + i] = s2; }
+        lds_barrier();
+        if (tid < 64 && (tid & 31) + nf * 32 - p.nf0 * 32 < p.Cy) {
+            const int which = tid >> 5, ch = tid & 31;
+            const float v = (red[(0 * 2 + which) * 32 + ch] + red[(1 * 2 + which) * 32 + ch]) + (red[(2 * 2 + which) * 32 + ch] + red[(3 * 2 + which) * 32 + ch]);
+            const int bpp = p.B / p.stat_npass, pass = b / bpp;
+            const long tile = ((long)(b - pass * bpp) * ntx + tx) * nty + ty;
+            const long tiles_pp = (long)bpp * ntx * nty;
+            p.stat_part[((pass * tiles_pp + tile) * 2 + which) * p.stat_C + (nf - p.nf0) * 32 + ch] = v;
         }
     }
 }
@@ -374,6 +392,8 @@ void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int
 long ptta_gfrag_elems(int KK, int C0, int C1, int Co) {
     return (long)((Co + 31) / 32) * ((C0 + 31) / 32 + (C1 + 31) / 32) * KK * 2 * 64 * 8;
 }
+
+int ptta_gconv_x3_tiles(int B, int H, int W) { return B * ((W + 31) / 32) * ((H + GX_TH - 1) / GX_TH); }
 
 int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
     if ((a.C0 & 15) || (a.C1 & 15) || (a.ld0 & 3) || (a.ld1 & 3)) return -22;

@@ -69,6 +69,9 @@ struct Op {
     std::string bname;
     int ad_g = -1, ad_beta = -1;
     float* st = nullptr;
+    float* part = nullptr;            // this BatchNorm's partial-statistics buffer
+    int fused_from = -1;              // index of the producing CONV op whose epilogue fills `part` (stride-1 matrix-core kernel)
+    int stat_to = -1;                 // (CONV) index of the BN op that consumes this conv's fused statistics
     bool first_raw = true, first_res = true;
 };
 
@@ -189,6 +192,17 @@ struct nlspn_engine {
         if (frozen) frozen_bn[bname] = std::make_pair(falloc(C), falloc(C));
         else { o.ad_g = add_adapted(bname + ".weight", C); o.ad_beta = add_adapted(bname + ".bias", C); }
         o.st = falloc((size_t)4 * 2 * C);
+        // statistics fused into the producing convolution's epilogue when that is the stride-1 matrix-core kernel
+        for (int k = (int)ops.size() - 1; k >= 0; --k) {
+            Op& pr = ops[k];
+            if (pr.kind != K_CONV || pr.y != x) continue;
+            const GConvW& cw = convs[pr.wname];
+            if (cw.mf && pr.stride == 1 && !pr.transposed && pr.act == GACT_NONE && pr.yw == w && T[x].ld == T[x].C) {
+                o.fused_from = k; pr.stat_to = (int)ops.size();
+                o.part = falloc((size_t)2 * ptta_gconv_x3_tiles(2 * N, T[x].H, T[x].W) * C);
+            }
+            break;
+        }
         ops.push_back(o);
     }
 
@@ -233,6 +247,7 @@ struct nlspn_engine {
                     conv(P + ".downsample.0", cur, -1, rd, 1, stride, 0, GACT_NONE, W_BOTH, W_BOTH);
                     bn(P + ".downsample.1", rd, d, -1, GACT_NONE, W_BOTH);
                     ops.push_back(bn2);
+                    if (bn2.fused_from >= 0) ops[bn2.fused_from].stat_to = (int)ops.size() - 1;     // bn2 moved behind the downsample ops
                     idt = d;
                 } else {
                     bn(P + ".bn2", r2, out, idt, GACT_NONE, W_BOTH);
@@ -410,6 +425,7 @@ int run_conv_fwd(nlspn_engine* e, const Op& o, bool train, hipStream_t s) {
         a.whi = (const uint4*)cw.ff_hi; a.wlo = (const uint4*)cw.ff_lo;
         a.nchunks = (a.C0 + 31) / 32 + (a.C1 + 31) / 32; a.nf0 = 0; a.nnf = (cw.Co + 31) / 32;
         a.y = y.p; a.ldy = y.ld; a.Cy = y.C; a.bias = bias; a.act = o.act;
+        if (o.stat_to >= 0) { a.stat_part = e->ops[o.stat_to].part; a.stat_C = y.C; a.stat_npass = (o.yw == W_BOTH && train) ? 2 : 1; }
         int rc;
         if (o.stride == 1 && !o.transposed) rc = ptta_launch_gconv_x3(a, o.k, s);
         else rc = ptta_launch_gconv_x3_strided(a, o.k, o.transposed ? 2 : 1, x0.H, x0.W, s);
@@ -437,7 +453,8 @@ int run_bn_fwd(nlspn_engine* e, const Op& o, bool train, hipStream_t s) {
     const GView x = e->view(o.x[0], o.xw[0], train), y = e->view(o.y, o.yw, train);
     GView res; if (o.res >= 0) res = e->view(o.res, o.xw[0], train);
     const int npass = (o.xw[0] == W_BOTH && train) ? 2 : 1;
-    if (ptta_launch_gbn_forward(x, res, y, npass, o.act, BN_EPS, bn_gamma(e, o), bn_beta(e, o), e->bn_part, o.st, s))
+    const int fused = o.fused_from >= 0 ? ptta_gconv_x3_tiles(x.B / npass, x.H, x.W) : 0;
+    if (ptta_launch_gbn_forward(x, res, y, npass, o.act, BN_EPS, bn_gamma(e, o), bn_beta(e, o), fused ? o.part : e->bn_part, o.st, s, fused))
         return e->fail("batch-norm " + o.bname + " launch failed", -5);
     return 0;
 }

@@ -165,7 +165,8 @@ int ptta_launch_gwgrad(const GView& x, const GView& gy, float* part, float* gw, 
 
 int ptta_gbn_part_floats(int C, int npass);
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
-                            const float* beta, float* part, float* st, hipStream_t s);
+                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks = 0);
+int ptta_gconv_x3_tiles(int B, int H, int W);
 int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, const GView& gx, const GView& gres, int npass, int act,
                              int res_relu, int acc_gx, int acc_gres, const float* gamma, const float* st, float* part, float* bw,
                              float* dgamma, float* dbeta, hipStream_t s);
@@ -187,6 +188,9 @@ struct GX3Args {
     int nchunks = 0, nf0 = 0, nnf = 0;                        // first output-channel tile of this launch, number of tiles
     float* y = nullptr; int ldy = 0, Cy = 0;                  // output view starting at channel 32*nf0 of the packed matrix
     const float* bias = nullptr; int act = GACT_NONE, accumulate = 0;
+    // optional fused BatchNorm statistics of the OUTPUT (stride-1 kernel): per (pass, pixel tile) partial sums
+    // {sum y, sum y^2} per channel, layout [pass][tile][2][stat_C]; stat_npass equal slices of the batch
+    float* stat_part = nullptr; int stat_C = 0, stat_npass = 1;
 };
 void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
                      hipStream_t s);

@@ -261,9 +261,11 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
                     else { yi = (y + PAD - ky) >> 1; xi = x0 + i + ((xpar + PAD - kx) >> 1); }
                     // out-of-range rows / columns / channels are folded into the load predicate (zero operands): branch-free
                     const bool ok = lane_in && y < Hout && xi >= 0 && xi < Win && yi >= 0 && yi < Hin && cb + 16 * k + 8 * h < Cs;
-                    const float* q = inb + ((size_t)(ok ? yi : 0) * Win + (ok ? xi : 0)) * ld + 16 * k;
-                    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-                    if (ok) { a0 = *(const float4*)q; a1 = *(const float4*)(q + 4); }
+                    // unconditional loads from a clamped (always valid) address + select: no exec-masked branch per load, so
+                    // the loads of all taps can be in flight together
+                    const float* q = ok ? inb + ((size_t)yi * Win + xi) * ld + 16 * k : src;
+                    float4 a0 = *(const float4*)q, a1 = *(const float4*)(q + 4);
+                    if (!ok) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
                     uint4 hi, lo;
                     gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
                     gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);

@@ -32,8 +32,8 @@ typedef void* ptta_stream;              /* hipStream_t */
  * with rows = n*(H/16)*(W/16); ptta_adapted_count() is 88 (conv1_rgb_meta + every BatchNorm2d weight/bias, in the
  * reference's order) and every one of them must be bound; ptta_load_weights ignores BatchNorm running statistics
  * (dropped by 'meta_bn') and the values of adapted tensors (the bound tensors are read instead);
- * ptta_loss_forward/backward, ptta_backward, ptta_adam_step, ptta_set_graph and ptta_profile return -38 (use
- * ptta_step / ptta_forward_train / ptta_forward_eval / ptta_get_grad). */
+ * ptta_backward ignores its two output pointers (read the 88 gradients with ptta_get_grad) and ptta_adam_step takes
+ * NULL gradients (it uses the internal ones); ptta_set_graph and ptta_profile return -38. */
 enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1 };
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
 enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */

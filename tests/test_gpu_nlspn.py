@@ -198,9 +198,6 @@ def test_external_model_adapt_facade_nlspn(golden_dir):
     model.eval()
     d_eval = model.forward(image1, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
     assert rel_mae(d_eval, g['s0/depth_eval']) < 1e-3
-    model.train()
-    with pytest.raises(NotImplementedError):
-        model.forward(image1, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
     # fused normalisation through the façade
     model.set_image_norm([[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]])
     model.eval()
@@ -226,6 +223,41 @@ def test_error_paths_fail_loudly():
         eng.forward_eval(image1, sparse)
     with pytest.raises(RuntimeError, match='not an adapted parameter'):
         eng.bind_adapted('conv6.0.weight', sd['conv6.0.weight'], sd['conv6.0.weight'], sd['conv6.0.weight'])
-    with pytest.raises(RuntimeError, match='NLSPN'):
-        eng.backward(torch.zeros(1, 1, 32, 64, device='cuda'), None)
+    with pytest.raises(RuntimeError, match='without a preceding'):
+        eng.backward_all(torch.zeros(1, 1, 32, 64, device='cuda'), None, {})
     eng.close()
+
+
+def test_reference_style_driver_nlspn(golden_dir):
+    """src/tta_main.py:610-633 verbatim against the façade: forward -> compute_loss -> zero_grad -> loss.backward() ->
+    torch.optim.Adam.step() on the 88 adapted tensors, then the eval forward; golden step 0."""
+    from proxytta.model import ExternalModel_Adapt
+    g = np.load(os.path.join(golden_dir, 'nlspn_32x64.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    model = ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=80.0, device=torch.device('cuda'))
+    model._prepare_head('meta_selfsup_seq_1layer_ema')
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict_nlspn().items()})
+    params = model.adapt_parameters(mode='meta_bn')
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+    validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+    model.train()
+    depth, emb, ref = model.forward(image=image1, sparse_depth=sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
+    loss, info = model.compute_loss(input_rgb=raw, output_depth=depth, sparse_depth=sparse, validity_map=validity, embedding=emb,
+                                    reference=ref, w_loss_sparse_depth=1.0, w_loss_smoothness=2.0, w_loss_cos=0.1, loss_type='adapt')
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert rel_mae(depth.detach(), g['s0/depth_train']) < 1e-3
+    np.testing.assert_allclose([float(info[k]) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')], g['s0/loss_info'], rtol=2e-3)
+    named = dict(model.model.model.named_parameters())
+    names = [str(x) for x in g['adapted_names']]
+    gn = np.array([float(named[k].grad.double().norm()) for k in names])
+    np.testing.assert_allclose(gn, g['s0/grad_norms'], rtol=8e-2, atol=1e-6)
+    for key in g.files:
+        if key.startswith('s0/param/'):
+            k = key[len('s0/param/'):]
+            assert rel_mae(named[k].detach(), g[key]) < 4e-3, k
+    model.eval()
+    d_eval = model.forward(image1, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
+    assert rel_mae(d_eval, g['s0/depth_eval']) < 1e-3

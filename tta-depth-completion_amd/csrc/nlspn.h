@@ -24,3 +24,9 @@ int nlspn_step(nlspn_engine* e, const float* image, const float* loss_image, con
                float* depth_out, float* loss_info_out, hipStream_t s);
 int nlspn_get_grad(nlspn_engine* e, const char* name, float* dst, int64_t capacity, hipStream_t s);
 int nlspn_debug_tensor(nlspn_engine* e, const char* name, float* dst, int64_t capacity, int64_t* numel, hipStream_t s);
+int nlspn_loss_forward(nlspn_engine* e, const float* loss_image, const float* depth, const float* sparse, const float* validity,
+                       const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos, float* loss_info_out, hipStream_t s);
+int nlspn_loss_backward(nlspn_engine* e, const float* loss_image, const float* depth, const float* sparse, const float* validity,
+                        const float* emb, const float* ref, int64_t rows, float* grad_depth_out, float* grad_ref_out, hipStream_t s);
+int nlspn_backward(nlspn_engine* e, const float* grad_depth, const float* grad_ref, hipStream_t s);
+int nlspn_adam_step(nlspn_engine* e, hipStream_t s);

@@ -121,6 +121,7 @@ struct nlspn_engine {
     std::map<std::string, int> aid;
     float* gall = nullptr; long gall_n = 0;
     float *meta_wf = nullptr, *meta_wb = nullptr;
+    float* w3_tmp = nullptr;
     float *hyper = nullptr, *loss_ws = nullptr, *loss_info = nullptr, *validity_tmp = nullptr, *S = nullptr;
     int* step_dev = nullptr;
     float *bn_part = nullptr, *bn_bw = nullptr, *wg_part = nullptr;
@@ -330,7 +331,7 @@ struct nlspn_engine {
         validity_tmp = falloc((size_t)N * P);
         gall = falloc((size_t)gall_n);
         meta_wf = falloc(48 * 48 * 9); meta_wb = falloc(48 * 48 * 9);
-        hyper = falloc(8); loss_info = falloc(4); S = falloc(1);
+        hyper = falloc(8); loss_info = falloc(4); S = falloc(1); w3_tmp = falloc(4);
         loss_ws = falloc((size_t)ptta_loss_ws_floats(N, H, W, rows()));
         step_dev = (int*)dalloc(sizeof(int));
         bn_part = falloc((size_t)ptta_gbn_part_floats(1024, 2)); bn_bw = falloc(3 * 1024);
@@ -725,5 +726,38 @@ int nlspn_debug_tensor(nlspn_engine* e, const char* name, float* dst, int64_t ca
     if (!dst) return 0;
     if (capacity < n) return e->fail("debug tensor: destination too small", -22);
     if (hipMemcpyAsync(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return e->fail("memcpy failed", -5);
+    return 0;
+}
+
+// ---- the reference's split calls: compute_loss / loss.backward() / optimizer.step() (src/tta_main.py:619-633) ----------
+int nlspn_loss_forward(nlspn_engine* e, const float* loss_image, const float* depth, const float* sparse, const float* validity,
+                       const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos, float* loss_info_out, hipStream_t s) {
+    if (rows > e->rows()) return e->fail("rows exceeds the handle's embedding rows", -22);
+    const float w3[3] = {w_sd, w_sm, w_cos};
+    if (hipMemcpyAsync(e->w3_tmp, w3, sizeof(w3), hipMemcpyHostToDevice, s) != hipSuccess) return e->fail("memcpy failed", -5);
+    if (hipStreamSynchronize(s) != hipSuccess) return e->fail("sync failed", -5);          // w3 is on the stack
+    if (ptta_launch_loss_forward(depth, loss_image, sparse, validity, e->hp.max_input_depth, emb, ref, rows, 1024, e->w3_tmp, e->N, e->H,
+                                 e->W, e->loss_ws, loss_info_out, s)) return e->fail("loss forward failed", -5);
+    return 0;
+}
+int nlspn_loss_backward(nlspn_engine* e, const float* loss_image, const float* depth, const float* sparse, const float* validity,
+                        const float* emb, const float* ref, int64_t rows, float* grad_depth_out, float* grad_ref_out, hipStream_t s) {
+    if (ptta_launch_loss_backward(depth, loss_image, sparse, validity, e->hp.max_input_depth, emb, ref, rows, 1024, e->N, e->H, e->W,
+                                  e->loss_ws, grad_depth_out, grad_ref_out, s)) return e->fail("loss backward failed", -5);
+    return 0;
+}
+int nlspn_backward(nlspn_engine* e, const float* grad_depth, const float* grad_ref, hipStream_t s) {
+    if (!e->fwd_valid) return e->fail("ptta_backward without a preceding ptta_forward_train", -3);
+    const size_t nb_ = (size_t)e->N * e->H * e->W * sizeof(float), rb = (size_t)e->rows() * 1024 * sizeof(float);
+    if (hipMemcpyAsync(e->gdepth, grad_depth, nb_, hipMemcpyDeviceToDevice, s) != hipSuccess) return e->fail("memcpy failed", -5);
+    if (grad_ref) { if (hipMemcpyAsync(e->T[e->t_ref].g, grad_ref, rb, hipMemcpyDeviceToDevice, s) != hipSuccess) return e->fail("memcpy failed", -5); }
+    else if (hipMemsetAsync(e->T[e->t_ref].g, 0, rb, s) != hipSuccess) return e->fail("memset failed", -5);
+    return backward(e, s);
+}
+int nlspn_adam_step(nlspn_engine* e, hipStream_t s) {
+    for (auto& ad : e->adapted) if (!ad.p || !ad.m || !ad.v) return e->fail("Adam state of " + ad.name + " not bound", -3);
+    if (ptta_launch_step_inc(e->step_dev, s)) return e->fail("step counter failed", -5);
+    for (auto& ad : e->adapted)
+        if (ptta_launch_adam(ad.p, ad.m, ad.v, e->gall + ad.goff, ad.n, e->hyper, e->step_dev, s)) return e->fail("adam failed", -5);
     return 0;
 }

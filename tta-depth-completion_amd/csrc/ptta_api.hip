@@ -1005,7 +1005,7 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
 int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                       const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos,
                       float* loss_info_out, ptta_stream s_) {
-    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+    if (c && c->nl) return nlspn_loss_forward(c->nl, loss_image, depth, sparse, validity, emb, ref, rows, w_sd, w_sm, w_cos, loss_info_out, (hipStream_t)s_);
 
     if (!c || !loss_image || !depth || !sparse || !validity || !loss_info_out) return -1;
     if (rows > c->Rg) return c->fail("rows exceeds the handle's embedding rows", -22);
@@ -1020,7 +1020,7 @@ int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth
 
 int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                        const float* emb, const float* ref, int64_t rows, float* gdepth, float* gref, ptta_stream s_) {
-    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+    if (c && c->nl) return nlspn_loss_backward(c->nl, loss_image, depth, sparse, validity, emb, ref, rows, gdepth, gref, (hipStream_t)s_);
 
     if (!c || !loss_image || !depth || !sparse || !validity || !gdepth) return -1;
     RUN(ptta_launch_loss_backward(depth, loss_image, sparse, validity, c->hp.max_input_depth, emb, ref, rows, 512,
@@ -1029,7 +1029,7 @@ int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* dept
 }
 
 int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref, float* gw_out, float* gb_out, ptta_stream s_) {
-    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+    if (c && c->nl) return grad_depth ? nlspn_backward(c->nl, grad_depth, grad_ref, (hipStream_t)s_) : -1;   // gradients: ptta_get_grad
 
     if (!c || !grad_depth) return -1;
     if (!c->fwd_valid) return c->fail("ptta_backward without a preceding ptta_forward_train", -3);
@@ -1059,7 +1059,7 @@ int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref,
 }
 
 int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream s_) {
-    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+    if (c && c->nl) return (gw || gb) ? c->fail("explicit gradients are an MSG_CHN 1layer convenience", -22) : nlspn_adam_step(c->nl, (hipStream_t)s_);
 
     if (!c) return -1;
     for (auto& ad : c->adapted) if (!ad.p || !ad.m || !ad.v) return c->fail("Adam state of " + ad.name + " not bound", -3);

@@ -3,9 +3,9 @@ with model_name='nlspn', src/external_model_adapt.py:61-63) on libptta_hip.
 
 What is on the accelerated path: the canonical TTA flow of bash/adapt/adapt_nlspn_*.sh --
 prepare_mode 'meta_selfsup_seq_1layer_ema', adapt_mode 'meta_bn', loss_type 'adapt_meta_selfsup_seq_ema_reverse':
-``step()`` (forward [grad pass + zero-image proxy pass + heads] + adapt_loss + backward + Adam on the 88 adapted
-tensors, src/tta_main.py:610-633) and the eval ``forward()`` (:729-736).  The split training forward /
-compute_loss / loss.backward() surface is MSG_CHN-only for now; calling it raises NotImplementedError.
+the reference's own call sequence ``forward`` / ``compute_loss`` / ``loss.backward()`` / ``optimizer.step()``
+(src/tta_main.py:610-633, autograd Functions over ptta_forward_train / ptta_loss_* / ptta_backward), the fused
+``step()`` (the same in one library call, Adam on device for the 88 adapted tensors) and the eval ``forward()`` (:729-736).
 Frame sizes must be multiples of 16 (the decoder crops of nlspnmodel_adapt.py:474-490 are not implemented).
 The eval path's biharmonic hole filling (src/nlspn_model_adapt.py:124-127, skimage on the CPU) is not applied: exact
 zeros of the clamped output are returned as zeros.
@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import synth
 from .engine import Engine
-from .model import MsgChnModel_Adapt, _init_tensor, _Tree
+from .model import MsgChnModel_Adapt, _ForwardFn, _init_tensor, _Tree
 
 _BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked')
 
@@ -106,8 +106,10 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
 
     def forward(self, image, sparse_depth, intrinsics=None, crop_mask=None, loss_type='pretrain'):
         if self.training and 'adapt' in loss_type:
-            raise NotImplementedError('NLSPN: the split training forward is not exposed; use step() (fused forward + loss + '
-                                      'backward + Adam) -- SURVEY.md §8 row a16')
+            # (depth, emb, ref) with autograd edges to the 88 adapted tensors: loss.backward() runs ptta_loss_backward +
+            # ptta_backward and fills their .grad (src/tta_main.py:610-632)
+            params = dict(self.model.named_parameters())
+            return _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted])
         with torch.no_grad():
             return self._engine(image).forward_eval(image, sparse_depth)
 

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
 // transposed convolutions and their data gradients).
 //   MODE 1 (S2): y[oy][ox] = sum x[2oy+ky-pad][2ox+kx-pad] w[tap]
 //   MODE 2 (T2): y[oy][ox] = sum over taps with (oy+pad-ky), (ox+pad-kx) even of x[(oy+pad-ky)/2][(ox+pad-kx)/2] w[tap]
-template <int MODE, int KS>
+template <int MODE, int KS, int KSPLIT>
 __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin, int Win) {
     constexpr int PAD = KS / 2, KK = KS * KS;
     // stride 2: two output rows per wave, tap-outer / row-inner, so the A loads of both rows are in flight before the
@@ -215,9 +215,11 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
     const int nseg = (Wt + 31) >> 5, npar = MODE == 2 ? 2 : 1, nyg = (Hout + R - 1) / R;
     const long nitems = (long)p.B * nseg * npar * nyg;
     const int nch0 = (p.C0 + 31) >> 5;
-    // block -> (4 consecutive items, channel tile); channel tile fastest
+    // block -> (4 consecutive items, channel tile); channel tile fastest.  KSPLIT = 4 (few pixels, many channels: the
+    // 1/8 and 1/16-resolution layers): the block's four waves share ONE item and split its K loop (chunk c goes to wave
+    // c mod 4), partial accumulators are summed through LDS in a fixed order -- 4x more blocks, 4x shorter latency chains
     const int nfl = (int)(blockIdx.x % p.nnf);
-    const long item = (long)(blockIdx.x / p.nnf) * 4 + wave;
+    const long item = KSPLIT == 4 ? (long)(blockIdx.x / p.nnf) : (long)(blockIdx.x / p.nnf) * 4 + wave;
     if (item >= nitems) return;
     const int nf = p.nf0 + nfl;
     long t_ = item;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
     for (int rr = 0; rr < R; ++rr)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
-    for (int c = 0; c < p.nchunks; ++c) {
+    for (int c = KSPLIT == 4 ? wave : 0; c < p.nchunks; c += KSPLIT == 4 ? 4 : 1) {
         const bool s1 = c >= nch0;
         const float* src = s1 ? p.x1 : p.x0;
         const int ld = s1 ? p.ld1 : p.ld0, Cs = s1 ? p.C1 : p.C0, cb = (s1 ? c - nch0 : c) << 5;
@@ -279,6 +281,21 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
                 }
             }
         }
+    }
+    if constexpr (KSPLIT == 4) {
+        __shared__ float red[3][R][16][64];
+        if (wave) {
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][rr][r][lane] = acc[rr][r];
+        }
+        __syncthreads();
+        if (wave) return;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rr][r] = (acc[rr][r] + red[0][rr][r][lane]) + (red[1][rr][r][lane] + red[2][rr][r][lane]);
     }
     const int co = nf * 32 + i - p.nf0 * 32;
     if (co >= p.Cy) return;
@@ -416,9 +433,12 @@ int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, in
     if (a.nchunks != (a.C0 + 31) / 32 + (a.C1 + 31) / 32) return -22;
     const int Wt = mode == 2 ? win : a.W;
     const long nitems = (long)a.B * ((Wt + 31) / 32) * (mode == 2 ? 2 : 1) * (mode == 1 ? (a.H + 1) / 2 : a.H);   // stride 2: two rows per wave
-    const long blocks = ((nitems + 3) / 4) * a.nnf;
+    // few pixels and a long K loop: split K over the block's waves
+    const bool split = a.nchunks >= 4 && ((nitems + 3) / 4) * a.nnf < 1536;
+    const long blocks = (split ? nitems : (nitems + 3) / 4) * a.nnf;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
-#define L_(M, K) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win)
+#define L_(M, K) do { if (split) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 4>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); \
+                      else hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); } while (0)
     if (mode == 1) { if (ks == 3) L_(1, 3); else L_(1, 1); }
     else { if (ks == 3) L_(2, 3); else L_(2, 1); }
 #undef L_

@@ -261,3 +261,31 @@ def test_reference_style_driver_nlspn(golden_dir):
     model.eval()
     d_eval = model.forward(image1, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
     assert rel_mae(d_eval, g['s0/depth_eval']) < 1e-3
+
+
+def test_full_size_properties():
+    """BASELINE config 3 size (352x1216), where the CPU oracle is too slow: (i) the bf16x3 matrix-core path agrees
+    with the exact direct-kernel path (validated against oracle and golden vectors above) on depth and loss,
+    (ii) the training forward's depth equals the eval forward's depth for the same parameters (both normalise
+    with batch statistics; the proxy half of the training batch must not leak into the real half's statistics),
+    (iii) a step moves every one of the 88 adapted tensors by at most lr per entry (Adam's first step) and by a
+    non-zero amount."""
+    n, h, w = 1, 352, 1216
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+    out = {}
+    for impl in MODES:
+        eng, sd, adapted = make_nlspn(n, h, w, impl=impl)
+        d_train, emb, ref = eng.forward_train(image1, sparse)
+        d_eval = eng.forward_eval(image1, sparse)
+        assert torch.isfinite(d_train).all() and torch.isfinite(emb).all() and torch.isfinite(ref).all()
+        assert rel_mae(d_train, d_eval) < 1e-6
+        before = {k: adapted[k][0].clone() for k in eng.adapted}
+        info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+        assert torch.isfinite(info).all()
+        for k in eng.adapted:
+            delta = (adapted[k][0] - before[k]).abs()
+            assert float(delta.max()) <= HP['lr'] * 1.001 and float(delta.max()) > 0, k
+        out[impl] = (depth.clone(), info.cpu().numpy().copy())
+        eng.close()
+    assert rel_mae(out['default'][0], out['naive'][0]) < 1e-3
+    np.testing.assert_allclose(out['default'][1], out['naive'][1], rtol=2e-3)

@@ -68,7 +68,7 @@ def nlspn_workload(frames=3, inner_iter=3):
     from proxytta.engine import Engine
     mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
     std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
-    eng = Engine(1, H, W, backbone='nlspn', lr=3e-4, w_sparse_depth=1.0, w_smoothness=0.0, w_cos=0.0, max_input_depth=80.0)
+    eng = Engine(1, H, W, backbone='nlspn', legacy_offset=True, lr=3e-4, w_sparse_depth=1.0, w_smoothness=0.0, w_cos=0.0, max_input_depth=80.0)
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
     eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32})
     keep = []
@@ -92,7 +92,7 @@ def nlspn_workload(frames=3, inner_iter=3):
         d = eng.forward_eval(*data[f % 2])
     torch.cuda.synchronize()
     t_eval = (time.perf_counter() - t0) / frames
-    out = {'workload': 'NLSPN (ResNet34 + 18-sweep propagation), 352x1216, %d TTA steps/frame, meta_bn (88 adapted tensors), batch 1' % inner_iter,
+    out = {'workload': 'NLSPN (ResNet34 + 18-sweep propagation), 352x1216, %d TTA steps/frame, meta_bn (88 adapted tensors), legacy offsets as src/tta_main.py:317, batch 1' % inner_iter,
            'ms_per_step': 1e3 * t_step, 'frames_per_s': 1.0 / (inner_iter * t_step), 'eval_forward_ms': 1e3 * t_eval,
            'finite': bool(torch.isfinite(info).all().item() and torch.isfinite(d).all().item())}
     eng.close()

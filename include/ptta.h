@@ -27,7 +27,7 @@ typedef void* ptta_stream;              /* hipStream_t */
 
 /* PTTA_BACKBONE_NLSPN: ExternalModel_Adapt(model_name='nlspn') -- src/nlspn_model_adapt.py:13-128 ->
  * NLSPNModel_Adapt._rgbd_meta_contrast (external_src/NLSPN/src/model/nlspnmodel_adapt.py:850-944), adapter settings of
- * src/nlspn_model_adapt.py:56-68, adapt_parameters('meta_bn') (:322-337).  meta_mode must be PTTA_META_1LAYER, dtype
+ * src/nlspn_model_adapt.py:56-68, adapt_parameters('meta_bn') (:322-337).  meta_mode must be PTTA_META_1LAYER (optionally | PTTA_NLSPN_LEGACY_OFFSET), dtype
  * PTTA_DTYPE_F32, height and width multiples of 16.  Differences from the MSG_CHN handle: embeddings are (rows, 1024)
  * with rows = n*(H/16)*(W/16); ptta_adapted_count() is 88 (conv1_rgb_meta + every BatchNorm2d weight/bias, in the
  * reference's order) and every one of them must be bound; ptta_load_weights ignores BatchNorm running statistics
@@ -36,7 +36,11 @@ typedef void* ptta_stream;              /* hipStream_t */
  * NULL gradients (it uses the internal ones); ptta_set_graph and ptta_profile return -38. */
 enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1 };
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
-enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
+enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };
+/* NLSPN only, OR-ed into meta_mode: ExternalModel_Adapt(..., offset=True) -> args.legacy (src/nlspn_model_adapt.py:62):
+ * the confidence gathers add each tap's own (dy, dx) to the learned offset (nlspnmodel_adapt.py:297-302).
+ * src/tta_main.py:309-317 always constructs the model this way. */
+enum { PTTA_NLSPN_LEGACY_OFFSET = 0x100 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
 
 /* Hyper-parameters of the step.  Reference: src/tta.py:10-160 flags learning_rates,
  * optimizer_betas, optimizer_epsilon, w_weight_decay, w_loss_sparse_depth, w_loss_smoothness,

@@ -117,8 +117,8 @@ def sample_rows(x, k=24):
     return idx, x[idx]
 
 
-def run_case(ema, name, h, w, n, steps, hp):
-    model = ema.ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], device=torch.device('cpu'))
+def run_case(ema, name, h, w, n, steps, hp, offset=False):
+    model = ema.ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], offset=offset, device=torch.device('cpu'))
     model._prepare_head(PREPARE)
     net = model.model.model
     sd = synth.formula_state_dict_nlspn(PREPARE)
@@ -131,7 +131,7 @@ def run_case(ema, name, h, w, n, steps, hp):
     out = {'meta': np.array([h, w, n, steps], dtype=np.int64),
            'hp': np.array([hp['lr'], hp['betas'][0], hp['betas'][1], hp['eps'], hp['weight_decay'], hp['w_sd'], hp['w_sm'],
                            hp['w_cos'], hp['max_input_depth']], dtype=np.float64),
-           'adapted_names': np.array(names)}
+           'adapted_names': np.array(names), 'legacy': np.array(int(offset))}
     # a subset of the 88 adapted tensors is stored per step (first/last layers, one per stage)
     keep = [k for k in names if k.startswith(('conv1_rgb_meta', 'conv2.0.bn1', 'conv3.0.downsample.1', 'conv5.2.bn2', 'conv6.1',
                                               'dec5.1', 'dec2.1', 'id_dec1.1', 'gd_dec1.1', 'cf_dec1.1'))]
@@ -188,6 +188,9 @@ def main():
     run_case(ema, 'nlspn_48x80_n2', 48, 80, 2, 1, hp)
     # the canonical script's weights: sparse-depth term only, lr 3e-4 (bash/adapt/adapt_nlspn_vkitti.sh:7-14,47-49)
     run_case(ema, 'nlspn_32x64_canonical', 32, 64, 1, 1, dict(hp, lr=3e-4, w_sm=0.0, w_cos=0.0))
+    # what src/tta_main.py:309-317 actually constructs: offset=True -> args.legacy=True (the confidence gathers add the
+    # tap's own (dy, dx) to the learned offset, nlspnmodel_adapt.py:297-302)
+    run_case(ema, 'nlspn_32x64_legacy', 32, 64, 1, 1, hp, offset=True)
 
 
 if __name__ == '__main__':

@@ -31,14 +31,14 @@ TOL = {'naive': dict(feat=1e-4, depth=1e-4, emb=1e-3, grad=3e-2, param=2e-3),
 MODES = ['naive', 'default']
 
 
-def make_nlspn(n, h, w, hp=HP, impl='default'):
+def make_nlspn(n, h, w, hp=HP, impl='default', legacy=False):
     old = os.environ.get('PTTA_CONV_IMPL')
     if impl == 'naive':
         os.environ['PTTA_CONV_IMPL'] = 'naive'
     else:
         os.environ.pop('PTTA_CONV_IMPL', None)
     try:
-        eng = Engine(n, h, w, backbone='nlspn', **hp)
+        eng = Engine(n, h, w, backbone='nlspn', legacy_offset=legacy, **hp)
     finally:
         if old is None:
             os.environ.pop('PTTA_CONV_IMPL', None)
@@ -99,14 +99,14 @@ def test_forward_train_and_eval_match_oracle(shape, impl):
 
 
 @pytest.mark.parametrize('impl', MODES)
-@pytest.mark.parametrize('name', ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical'])
+@pytest.mark.parametrize('name', ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical', 'nlspn_32x64_legacy'])
 def test_step_matches_golden(golden_dir, name, impl):
     tol = TOL[impl]
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps = [int(x) for x in g['meta']]
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
     hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=mid)
-    eng, sd, adapted = make_nlspn(n, h, w, hp, impl=impl)
+    eng, sd, adapted = make_nlspn(n, h, w, hp, impl=impl, legacy=bool(int(g['legacy'])))
     names = [str(x) for x in g['adapted_names']]
     assert eng.adapted == names
     for s in range(steps):

@@ -118,7 +118,7 @@ def test_dcn_oracle_properties():
 
 
 # ---- NLSPN: oracle/nlspn_oracle.py against tests/golden/nlspn_*.npz ------------------------
-NLSPN_CASES = ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical']
+NLSPN_CASES = ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical', 'nlspn_32x64_legacy']
 _MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
 _STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
 
@@ -137,7 +137,7 @@ def test_nlspn_oracle_matches_reference(golden_dir, name):
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
     torch.set_num_threads(4)
     o = N.NlspnOracle(synth.formula_state_dict_nlspn(), max_input_depth=mid, lr=lr, betas=(b1, b2), eps=eps,
-                      weight_decay=wd, w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
+                      weight_decay=wd, w_sd=w_sd, w_sm=w_sm, w_cos=w_cos, legacy=bool(int(g['legacy'])))
     assert o.names == [str(x) for x in g['adapted_names']]          # 88 tensors, reference order
     assert len(o.names) == 88 and sum(o.P[k].numel() for k in o.names) == 40048
     for s in range(steps):

@@ -6,7 +6,7 @@
 #include "../../include/ptta.h"
 
 struct nlspn_engine;
-nlspn_engine* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int* rc);
+nlspn_engine* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int legacy_offset, int* rc);
 void nlspn_destroy(nlspn_engine* e);
 const char* nlspn_last_error(nlspn_engine* e);
 int nlspn_set_hparams(nlspn_engine* e, const ptta_hparams* hp, hipStream_t s);

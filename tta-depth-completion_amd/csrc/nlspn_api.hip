@@ -597,12 +597,12 @@ int upload_hparams(nlspn_engine* e, hipStream_t s) {
 
 }  // namespace
 
-nlspn_engine* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int* rc) {
+nlspn_engine* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int legacy_offset, int* rc) {
     *rc = 0;
     if (n < 1 || h < 16 || w < 16 || !hp) { *rc = -22; return nullptr; }
     if ((h % 16) || (w % 16)) { *rc = -38; return nullptr; }      // decoder crops of nlspnmodel_adapt.py:474-490 are not implemented
     nlspn_engine* e = new nlspn_engine();
-    e->N = n; e->H = h; e->W = w; e->hp = *hp;
+    e->N = n; e->H = h; e->W = w; e->hp = *hp; e->legacy = legacy_offset ? 1 : 0;
     const char* impl = getenv("PTTA_CONV_IMPL");
     e->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;          // direct fp32 kernels everywhere (validation)
     e->build();

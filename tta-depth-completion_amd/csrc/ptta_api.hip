@@ -777,9 +777,9 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -19;          // no HIP device: fail loudly
     if (backbone_id == PTTA_BACKBONE_NLSPN) {
-        if (meta_mode != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32) return -38;
+        if ((meta_mode & ~PTTA_NLSPN_LEGACY_OFFSET) != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32) return -38;
         int rc = 0;
-        nlspn_engine* e = nlspn_create(n, height, width, hp, &rc);
+        nlspn_engine* e = nlspn_create(n, height, width, hp, (meta_mode & PTTA_NLSPN_LEGACY_OFFSET) ? 1 : 0, &rc);
         if (!e) return rc ? rc : -12;
         ptta_ctx* c = new ptta_ctx();
         c->nl = e; c->N = n; c->H = height; c->W = width; c->hp = *hp;

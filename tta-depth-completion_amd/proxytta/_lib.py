@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libptta_hip.so')
 
 PTTA_BACKBONE_MSG_CHN = 0
 PTTA_BACKBONE_NLSPN = 1
+PTTA_NLSPN_LEGACY_OFFSET = 0x100
 PTTA_META_1LAYER = 0
 PTTA_META_2LAYERS = 1
 PTTA_DTYPE_F32 = 0

@@ -47,7 +47,7 @@ class Engine:
 
     def __init__(self, n, height, width, dtype='fp32', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0,
-                 max_input_depth=None, meta='1layer', backbone='msg_chn'):
+                 max_input_depth=None, meta='1layer', backbone='msg_chn', legacy_offset=False):
         if not torch.cuda.is_available():
             raise RuntimeError('proxytta needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
@@ -64,7 +64,8 @@ class Engine:
         code = {'fp32': _lib.PTTA_DTYPE_F32, 'bf16': _lib.PTTA_DTYPE_BF16}[dtype]
         rc = self.lib.ptta_create(byref(self.handle),
                                   _lib.PTTA_BACKBONE_NLSPN if backbone == 'nlspn' else _lib.PTTA_BACKBONE_MSG_CHN,
-                                  _lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER,
+                                  (_lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER) |
+                                  (_lib.PTTA_NLSPN_LEGACY_OFFSET if (legacy_offset and backbone == 'nlspn') else 0),
                                   self.n, self.h, self.w, code, byref(self.hp))
         if rc != 0:
             raise RuntimeError('ptta_create failed (%d)' % rc)

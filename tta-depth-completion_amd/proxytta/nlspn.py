@@ -36,8 +36,7 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
 
     def __init__(self, device=torch.device('cuda'), max_depth=100.0, inpainting=False, use_pretrained=False, dataset_name=None,
                  from_scratch=False, offset=False, max_input_depth=None):
-        if offset:
-            raise NotImplementedError("legacy offsets (offset=True) are not wired through the façade yet")
+        self.legacy = bool(offset)                            # args.legacy = offset (src/nlspn_model_adapt.py:62)
         self.max_predict_depth = max_depth
         self.max_depth = max_depth
         self.max_input_depth = max_input_depth
@@ -91,7 +90,7 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
         if eng is None:
             if self.prepare_mode is None:
                 raise RuntimeError('_prepare_head(mode) must be called before forward (tta_main.py:322)')
-            eng = Engine(n, h, w, backbone='nlspn', max_input_depth=self.max_input_depth, **self.hparams)
+            eng = Engine(n, h, w, backbone='nlspn', legacy_offset=self.legacy, max_input_depth=self.max_input_depth, **self.hparams)
             assert eng.adapted == self.adapted, 'adapted parameter list drifted from the library'
             eng.load_state_dict({k: v for k, v in self.model.state_dict().items() if v.dtype == torch.float32})
             params = dict(self.model.named_parameters())

@@ -109,6 +109,9 @@ int ptta_backward(ptta_handle h, const float* grad_depth, const float* grad_ref,
  * 2layers meta layer has seven adapted tensors: two conv weights, one conv bias, two BatchNorm
  * gamma/beta pairs).  ptta_adapted_count/name enumerate them in state_dict order. */
 int ptta_get_grad(ptta_handle h, const char* name, float* dst, int64_t capacity, ptta_stream s);
+/* Overwrite the stored gradient of one adapted parameter (e.g. with the mean over ranks that DistributedDataParallel
+ * would have produced, src/msg_chn_model_adapt.py:476-480) before ptta_adam_step(h, NULL, NULL, s). */
+int ptta_set_grad(ptta_handle h, const char* name, const float* src, int64_t numel, ptta_stream s);
 int ptta_adapted_count(ptta_handle h);
 const char* ptta_adapted_name(ptta_handle h, int index, int64_t* numel_host);
 

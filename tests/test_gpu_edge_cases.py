@@ -117,6 +117,24 @@ def test_shared_parameter_step_single_rank_equals_fused_step():
     e1.close(); e2.close()
 
 
+def test_shared_parameter_step_2layers_meta():
+    """The general path of shared_parameter_step (gradients read from / written back to the library, on-device Adam)
+    with the 7-tensor 2layers meta layer, one rank: equals the fused step."""
+    from proxytta.distributed import shared_parameter_step
+    n, h, w = 1, 32, 48
+    image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(4, h, w, n)]
+    e1, sd1, ad1 = make_engine(n, h, w, 'fp32', HP, meta='2layers')
+    e2, sd2, ad2 = make_engine(n, h, w, 'fp32', HP, meta='2layers')
+    assert len(e2.adapted) == 7
+    info1, _ = e1.step(image, sparse)
+    info2, _ = shared_parameter_step(e2, image, sparse, w=(HP['w_sparse_depth'], HP['w_smoothness'], HP['w_cos']))
+    torch.cuda.synchronize()
+    assert torch.allclose(info1, info2, rtol=1e-6)
+    for k in ad1:
+        assert torch.allclose(ad1[k][0], ad2[k][0], rtol=0, atol=1e-7), k
+    e1.close(); e2.close()
+
+
 @pytest.mark.parametrize('rng,shape', [([0, 1], (2, 32, 48)), ([-1, 1], (1, 32, 48)),
                                        ([[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]], (1, 32, 48)),
                                        ([[0.485, 0.456, 0.406], [0.229, 0.224, 0.225]], (1, 36, 52))])

@@ -289,3 +289,21 @@ def test_full_size_properties():
         eng.close()
     assert rel_mae(out['default'][0], out['naive'][0]) < 1e-3
     np.testing.assert_allclose(out['default'][1], out['naive'][1], rtol=2e-3)
+
+
+def test_shared_parameter_step_nlspn():
+    """proxytta.distributed.shared_parameter_step on the NLSPN engine (88 gradients as one flat message, ptta_set_grad,
+    on-device Adam) with one rank equals the fused step up to the float atomics of the propagation gradient."""
+    from proxytta.distributed import shared_parameter_step
+    n, h, w = 1, 32, 64
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+    e1, sd1, ad1 = make_nlspn(n, h, w)
+    e2, sd2, ad2 = make_nlspn(n, h, w)
+    info1, _ = e1.step(image1, sparse, loss_image=raw)
+    info2, _ = shared_parameter_step(e2, image1, sparse, loss_image=raw, w=(HP['w_sparse_depth'], HP['w_smoothness'], HP['w_cos']))
+    torch.cuda.synchronize()
+    assert torch.allclose(info1, info2, rtol=1e-5)
+    assert e2.adam_step_count() == 1
+    for k in ad1:
+        assert rel_mae(ad2[k][0], ad1[k][0]) < 1e-5, k
+    e1.close(); e2.close()

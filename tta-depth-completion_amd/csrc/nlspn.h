@@ -30,3 +30,4 @@ int nlspn_loss_backward(nlspn_engine* e, const float* loss_image, const float* d
                         const float* emb, const float* ref, int64_t rows, float* grad_depth_out, float* grad_ref_out, hipStream_t s);
 int nlspn_backward(nlspn_engine* e, const float* grad_depth, const float* grad_ref, hipStream_t s);
 int nlspn_adam_step(nlspn_engine* e, hipStream_t s);
+int nlspn_set_grad(nlspn_engine* e, const char* name, const float* src, int64_t numel, hipStream_t s);

@@ -761,3 +761,11 @@ int nlspn_adam_step(nlspn_engine* e, hipStream_t s) {
         if (ptta_launch_adam(ad.p, ad.m, ad.v, e->gall + ad.goff, ad.n, e->hyper, e->step_dev, s)) return e->fail("adam failed", -5);
     return 0;
 }
+int nlspn_set_grad(nlspn_engine* e, const char* name, const float* src, int64_t numel, hipStream_t s) {
+    auto it = e->aid.find(name ? name : "");
+    if (it == e->aid.end()) return e->fail(std::string("not an adapted parameter: ") + (name ? name : "(null)"), -2);
+    const Adapted& a = e->adapted[it->second];
+    if (numel != a.n) return e->fail("ptta_set_grad: size mismatch", -22);
+    if (hipMemcpyAsync(e->gall + a.goff, src, (size_t)a.n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return e->fail("memcpy failed", -5);
+    return 0;
+}

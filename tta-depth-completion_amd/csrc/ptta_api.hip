@@ -957,6 +957,18 @@ int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity,
     return c->fail(std::string("not an adapted parameter: ") + name, -2);
 }
 
+int ptta_set_grad(ptta_handle c, const char* name, const float* src, int64_t numel, ptta_stream s) {
+    if (c && c->nl) return nlspn_set_grad(c->nl, name, src, numel, (hipStream_t)s);
+    if (!c || !name || !src) return -1;
+    for (auto& ad : c->adapted)
+        if (ad.name == name) {
+            if (numel != ad.n) return c->fail("ptta_set_grad: size mismatch", -22);
+            HIPCHK(hipMemcpyAsync(ad.g, src, (size_t)ad.n * 4, hipMemcpyDeviceToDevice, (hipStream_t)s));
+            return 0;
+        }
+    return c->fail(std::string("not an adapted parameter: ") + name, -2);
+}
+
 int ptta_set_adam_step(ptta_handle c, int step, ptta_stream s) {
     if (c && c->nl) return nlspn_set_adam_step(c->nl, step, (hipStream_t)s);
 

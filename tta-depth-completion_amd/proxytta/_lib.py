@@ -43,6 +43,7 @@ SIGNATURES = [
     ('ptta_loss_forward', c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, c_float, c_float, c_float, _P, _P]),
     ('ptta_loss_backward', c_int, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     ('ptta_backward', c_int, [_P, _P, _P, _P, _P, _P]),
+    ('ptta_set_grad', c_int, [_P, c_char_p, _P, c_int64, _P]),
     ('ptta_get_grad', c_int, [_P, c_char_p, _P, c_int64, _P]),
     ('ptta_adapted_count', c_int, [_P]),
     ('ptta_adapted_name', c_char_p, [_P, c_int, POINTER(c_int64)]),

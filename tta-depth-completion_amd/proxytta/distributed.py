@@ -8,8 +8,10 @@ Two modes:
   * shared-parameter batched TTA (what the reference's DDP does, src/msg_chn_model_adapt.py:476-480,
     src/tta_main.py:354): every rank runs forward+loss+backward on its slice of the batch, then ONE
     collective: mean all-reduce of the adapted-parameter gradients only (37 KB for the MSG_CHN 1layer
-    meta conv; the reference all-reduces all 5.8 MB of gradients and discards most of them), then
-    the same Adam update everywhere.
+    meta conv, 160 KB for NLSPN's 88 meta_bn tensors; the reference all-reduces every gradient and
+    discards most of them), then the same Adam update everywhere.  Not reproduced: the reference also
+    converts BatchNorm to SyncBatchNorm (src/tta_main.py:326), i.e. batch statistics over the global batch;
+    here every rank normalises with its own slice's statistics.
 """
 import torch
 import torch.distributed as dist
@@ -47,7 +49,17 @@ def shared_parameter_step(engine, image, sparse, validity=None, loss_image=None,
         loss_image = image
     info = engine.loss_forward(loss_image, depth, sparse, validity, emb, ref, *w)
     gd, gr = engine.loss_backward(loss_image, depth, sparse, validity, emb, ref)
-    gw, gb = engine.backward(gd, gr)
-    allreduce_adapted_grads([gw, gb], group)
-    engine.adam_step(gw, gb)
+    if getattr(engine, 'backbone', 'msg_chn') == 'msg_chn' and len(engine.adapted) == 2:
+        gw, gb = engine.backward(gd, gr)
+        allreduce_adapted_grads([gw, gb], group)
+        engine.adam_step(gw, gb)
+        return info, depth
+    # any adapted set (MSG_CHN 2layers: 7 tensors, NLSPN meta_bn: 88): gradients stay in the library; they are read,
+    # reduced as ONE flat message, written back and consumed by the on-device Adam
+    like = {k: torch.empty(engine.adapted_numel[k], device=depth.device) for k in engine.adapted}
+    grads = engine.backward_all(gd, gr, like)
+    allreduce_adapted_grads(grads, group)
+    for k, g in zip(engine.adapted, grads):
+        engine.set_grad(k, g)
+    engine.adam_step()
     return info, depth

@@ -70,15 +70,18 @@ class Engine:
         if rc != 0:
             raise RuntimeError('ptta_create failed (%d)' % rc)
         self.rows = int(self.lib.ptta_embedding_rows(self.handle))
+        # adapted tensors in the reference's order, from the library (MSG_CHN 1layer: 2, 2layers: 7, NLSPN meta_bn: 88,
+        # src/nlspn_model_adapt.py:322-337)
+        names, self.adapted_numel = [], {}
+        for i in range(int(self.lib.ptta_adapted_count(self.handle))):
+            n = c_int64(0)
+            name = self.lib.ptta_adapted_name(self.handle, i, byref(n)).decode()
+            names.append(name)
+            self.adapted_numel[name] = int(n.value)
         if backbone == 'nlspn':
-            # 88 tensors (conv1_rgb_meta + every BatchNorm2d gamma/beta, src/nlspn_model_adapt.py:322-337): ask the library
-            self.adapted = []
-            self.adapted_numel = {}
-            for i in range(int(self.lib.ptta_adapted_count(self.handle))):
-                n = c_int64(0)
-                name = self.lib.ptta_adapted_name(self.handle, i, byref(n)).decode()
-                self.adapted.append(name)
-                self.adapted_numel[name] = int(n.value)
+            self.adapted = names
+        else:
+            assert names == list(self.adapted), (names, self.adapted)
         self._keep = {}           # tensors whose storage the library borrows
         self.device = torch.device('cuda', torch.cuda.current_device())
 
@@ -189,6 +192,11 @@ class Engine:
         out = torch.empty_like(like)
         self._chk(self.lib.ptta_get_grad(self.handle, name.encode(), ptr(out), out.numel(), _stream()), 'ptta_get_grad')
         return out
+
+    def set_grad(self, name, value):
+        """Overwrite the stored gradient of an adapted parameter (reduced over ranks) before adam_step()."""
+        value = value.contiguous()
+        self._chk(self.lib.ptta_set_grad(self.handle, name.encode(), ptr(value), value.numel(), _stream()), 'ptta_set_grad')
 
     def backward_all(self, grad_depth, grad_ref, params):
         """loss.backward() for any meta layer: returns the gradients of `params` ({name: tensor})."""

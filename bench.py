@@ -61,6 +61,33 @@ def cpu_baseline(steps=3):
             'sample': '%d steps of the same 352x1216 workload after 1 warm-up (PyTorch-CPU oracle, fp32, %.2f s/step)' % (steps, dt)}
 
 
+def nlspn_macs(h, w, n=1):
+    """Multiply-accumulates of one NLSPN TTA step from the architecture (nlspnmodel_adapt.py:385-452, ResNet34
+    BasicBlocks :70-116): (training forward incl. the proxy pass and the heads, eval forward, minimal backward).
+    The training forward is 1,113 GMAC at 352x1216 -- the number SURVEY.md §8d measured with hooks on the reference."""
+    px = lambda s: n * (h // s) * (w // s)
+    enc = [(px(1), 3, 48, 9), (px(1), 48, 48, 9), (px(1), 1, 16, 9)]
+    inpl, s = 64, 1
+    for planes, nb, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        for b in range(nb):
+            st = stride if b == 0 else 1
+            s *= st
+            enc += [(px(s), inpl, planes, 9), (px(s), planes, planes, 9)]
+            if st != 1 or inpl != planes:
+                enc.append((px(s), inpl, planes, 1))
+            inpl = planes
+    enc.append((px(16), 512, 512, 9))
+    dec = [(px(8), 512, 256, 2.25), (px(4), 768, 128, 2.25), (px(2), 384, 64, 2.25), (px(1), 192, 64, 2.25),
+           (px(1), 128, 64, 9), (px(1), 128, 1, 9), (px(1), 128, 64, 9), (px(1), 128, 8, 9), (px(1), 128, 32, 9),
+           (px(1), 96, 1, 9), (px(1), 8, 24, 9)]
+    m = lambda layers: sum(p * ci * co * t for p, ci, co, t in layers)
+    mlp = px(16) * 512 * 1024 + px(16) * 1024 * 1024
+    fwd_train = 2 * m(enc) + m(dec) + 2 * mlp + 2 * px(16) * 1024 * 1024
+    fwd_eval = m(enc) + m(dec)
+    bwd = (m(enc) - m(enc[:3])) + m(dec) + mlp + px(1) * 48 * 48 * 9
+    return fwd_train, fwd_eval, bwd
+
+
 def nlspn_workload(frames=3, inner_iter=3):
     """BASELINE config 3 (not the headline metric): NLSPN backbone, 352x1216, 3 TTA steps per frame + the scored eval
     forward, adapt_mode meta_bn (88 adapted tensors), batch 1, inputs resident in HBM.  Reported beside the metric."""
@@ -94,6 +121,10 @@ def nlspn_workload(frames=3, inner_iter=3):
     t_eval = (time.perf_counter() - t0) / frames
     out = {'workload': 'NLSPN (ResNet34 + 18-sweep propagation), 352x1216, %d TTA steps/frame, meta_bn (88 adapted tensors), legacy offsets as src/tta_main.py:317, batch 1' % inner_iter,
            'ms_per_step': 1e3 * t_step, 'frames_per_s': 1.0 / (inner_iter * t_step), 'eval_forward_ms': 1e3 * t_eval,
+           'step_roofline': (lambda f, e, b: {'bound': 'mfma', 'alg_gmac_per_step': (f + b) / 1e9, 'alg_gmac_eval_forward': e / 1e9,
+                                                'achieved': 3 * 2.0 * (f + b) / t_step / 1e12, 'peak': MFMA_BF16_PEAK / 1e12, 'unit': 'TFLOP/s',
+                                                'frac': 3 * 2.0 * (f + b) / t_step / MFMA_BF16_PEAK,
+                                                'note': 'bf16x3: three bf16 MFMAs per fp32 product; fp32-equivalent rate = achieved / 3'})(*nlspn_macs(H, W)),
            'finite': bool(torch.isfinite(info).all().item() and torch.isfinite(d).all().item())}
     eng.close()
     return out

@@ -263,14 +263,16 @@ def test_reference_style_driver_nlspn(golden_dir):
     assert rel_mae(d_eval, g['s0/depth_eval']) < 1e-3
 
 
-def test_full_size_properties():
-    """BASELINE config 3 size (352x1216), where the CPU oracle is too slow: (i) the bf16x3 matrix-core path agrees
+@pytest.mark.parametrize('shape', [(1, 352, 1216), (3, 240, 1216), (4, 224, 320)])
+def test_full_size_properties(shape):
+    """BASELINE config 3 size (352x1216) and the per-GPU batches of the reference's two NLSPN scripts (n_batch 12 at
+    240x1216 and 16 at 224x320 over 4 GPUs, bash/adapt/adapt_nlspn_{vkitti,nyuv2}.sh), where the CPU oracle is too slow: (i) the bf16x3 matrix-core path agrees
     with the exact direct-kernel path (validated against oracle and golden vectors above) on depth and loss,
     (ii) the training forward's depth equals the eval forward's depth for the same parameters (both normalise
     with batch statistics; the proxy half of the training batch must not leak into the real half's statistics),
     (iii) a step moves every one of the 88 adapted tensors by at most lr per entry (Adam's first step) and by a
     non-zero amount."""
-    n, h, w = 1, 352, 1216
+    n, h, w = shape
     raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
     out = {}
     for impl in MODES:

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
         }
         if (q + 1 < nq) issue_loads(q + 1);
         lds_barrier();                                   // LDS-only: the loads just issued stay in flight during the MFMAs
+        __builtin_amdgcn_s_setprio(1);                    // MFMA phase outranks the other blocks' staging code at issue
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
                 acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rr], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     const int co = nf * 32 + i - p.nf0 * 32;          // channel inside the output view
     const bool cok = co < p.Cy;

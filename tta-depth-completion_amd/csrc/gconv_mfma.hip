@@ -1,5 +1,5 @@
 // Matrix-core path of the generic NHWC convolution (NLSPN backbone): stride-1 3x3 (and 1x1) convolutions with any
-// channel counts that are multiples of 16, one or two channel-concatenated sources, fp32 storage, bf16x3 arithmetic
+// channel counts that are multiples of 8, one or two channel-concatenated sources, fp32 storage, bf16x3 arithmetic
 // (x = xh + xl, w = wh + wl; xl*wh + xh*wl + xh*wh on v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the same
 // arithmetic as the MSG_CHN hot path (conv32.hip), generalised over input-channel chunks and output-channel tiles.
 //
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             const int py = pix / PW, px = pix - py * PW;
             const int gy = y0 - PAD + py, gx = x0 - PAD + px;
             v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
-            if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && cb < Cs) {
+            if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && cb + 8 * g < Cs) {
                 const float* s_ = inb + ((size_t)gy * W + gx) * ld + 8 * g;
                 v0[it] = *(const float4*)s_; v1[it] = *(const float4*)(s_ + 4);
             }
@@ -417,7 +417,7 @@ long ptta_gfrag_elems(int KK, int C0, int C1, int Co) {
 int ptta_gconv_x3_tiles(int B, int H, int W) { return B * ((W + 31) / 32) * ((H + GX_TH - 1) / GX_TH); }
 
 int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
-    if ((a.C0 & 15) || (a.C1 & 15) || (a.ld0 & 3) || (a.ld1 & 3)) return -22;
+    if ((a.C0 & 7) || (a.C1 & 7) || (a.ld0 & 3) || (a.ld1 & 3)) return -22;        // channel counts: multiples of 8
     if (a.nchunks != (a.C0 + 31) / 32 + (a.C1 + 31) / 32) return -22;
     const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + GX_TH - 1) / GX_TH);
     const long blocks = tiles * a.nnf;

@@ -180,7 +180,7 @@ struct nlspn_engine {
         GConvW& cw = convs[wname];
         cw.Ci = T[x0].C + (x1 >= 0 ? T[x1].C : 0); cw.Co = T[y].C; cw.k = k; cw.stride = stride; cw.transposed = transposed;
         cw.C0 = T[x0].C; cw.C1 = x1 >= 0 ? T[x1].C : 0;
-        cw.mf = !naive && (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0;
+        cw.mf = !naive && (stride == 1 && !transposed ? (cw.C0 % 8) == 0 && (cw.C1 % 8) == 0 : (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0);
         cw.mb = !naive && ((cw.Co % 16) == 0 || (stride == 1 && !transposed)) && (cw.C1 == 0 || (cw.C0 % 32) == 0);
         cw.Co_pad = (cw.Co + 15) / 16 * 16;               // data gradient of a conv with < 16 output channels: gy is zero-padded
         ops.push_back(o);

@@ -139,8 +139,8 @@ struct nlspn_engine {
     void* dalloc(size_t bytes) {
         void* p = nullptr;
         if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { oom = true; return nullptr; }
-        hipMemset(p, 0, bytes ? bytes : 16);
         allocs.push_back(p);
+        if (hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess) { oom = true; return nullptr; }
         return p;
     }
     float* falloc(size_t n) { return (float*)dalloc(n * sizeof(float)); }
@@ -608,13 +608,13 @@ nlspn_engine* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int lega
     e->build();
     if (e->oom || !e->step_dev) { nlspn_destroy(e); *rc = -12; return nullptr; }
     const float one[1] = {4.0f};                                  // affinity_gamma * num = 0.5 * 8 (nlspnmodel_adapt.py:231-233)
-    hipMemcpy(e->S, one, sizeof(one), hipMemcpyHostToDevice);
+    if (hipMemcpy(e->S, one, sizeof(one), hipMemcpyHostToDevice) != hipSuccess) { nlspn_destroy(e); *rc = -5; return nullptr; }
     if (upload_hparams(e, nullptr)) { nlspn_destroy(e); *rc = -5; return nullptr; }
     return e;
 }
 void nlspn_destroy(nlspn_engine* e) {
     if (!e) return;
-    for (void* p : e->allocs) if (p) hipFree(p);
+    for (void* p : e->allocs) if (p) (void)hipFree(p);
     delete e;
 }
 const char* nlspn_last_error(nlspn_engine* e) { return e->err.c_str(); }

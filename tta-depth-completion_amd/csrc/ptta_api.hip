@@ -89,16 +89,16 @@ struct ptta_ctx {
         if (!use_aux || prof_on) return nullptr;
         if (!aux_stream) {
             if (hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-            hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
-            hipEventCreateWithFlags(&ev_join, hipEventDisableTiming);
+            if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; return nullptr; }
         }
         return aux_stream;
     }
     float *in_image = nullptr, *in_loss_image = nullptr, *in_sparse = nullptr, *in_validity = nullptr;
     void drop_graphs() {
         for (int k = 0; k < 4; ++k) {
-            if (gexec[k]) { hipGraphExecDestroy(gexec[k]); gexec[k] = nullptr; }
-            if (graph[k]) { hipGraphDestroy(graph[k]); graph[k] = nullptr; }
+            if (gexec[k]) { (void)hipGraphExecDestroy(gexec[k]); gexec[k] = nullptr; }
+            if (graph[k]) { (void)hipGraphDestroy(graph[k]); graph[k] = nullptr; }
         }
     }
 
@@ -108,8 +108,8 @@ struct ptta_ctx {
     void* dalloc(size_t bytes) {
         void* p = nullptr;
         if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { oom = true; return nullptr; }
-        hipMemset(p, 0, bytes ? bytes : 16);
         allocs.push_back(p);
+        if (hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess) { oom = true; return nullptr; }
         return p;
     }
     float* falloc(size_t n) { return (float*)dalloc(n * sizeof(float)); }
@@ -379,9 +379,9 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     const long pout = mode == CONV_S1 ? pin : (mode == CONV_S2 ? pin / 4 : pin * 4);
     pc.bytes += (double)((pin + pout) * 32 + 9216) * c->es;
     pc.macs += (double)(mode == CONV_T2 ? pin : pout) * 9.0 * 32.0 * 32.0;
-    hipEventRecord(pc.ev[pc.used].first, s);
+    (void)hipEventRecord(pc.ev[pc.used].first, s);
     const int rc = ptta_launch_conv32(a, s);
-    hipEventRecord(pc.ev[pc.used].second, s);
+    (void)hipEventRecord(pc.ev[pc.used].second, s);
     pc.used++;
     return rc;
 }
@@ -815,10 +815,10 @@ void ptta_destroy(ptta_handle h) {
     if (!h) return;
     if (h->nl) { nlspn_destroy(h->nl); delete h; return; }
     h->drop_graphs();
-    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-    if (h->aux_stream) { hipStreamDestroy(h->aux_stream); hipEventDestroy(h->ev_fork); hipEventDestroy(h->ev_join); }
-    for (void* p : h->allocs) if (p) hipFree(p);
-    for (auto& pc : h->prof) for (auto& e : pc.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
+    for (void* p : h->allocs) if (p) (void)hipFree(p);
+    for (auto& pc : h->prof) for (auto& e : pc.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete h;
 }
 
@@ -1126,7 +1126,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
                                      (key & 2) ? c->in_validity : nullptr, (ptta_stream)c->cap_stream);
             hipGraph_t g = nullptr;
             const hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
-            if (rc != 0) { if (g) hipGraphDestroy(g); return rc; }
+            if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
             if (e != hipSuccess || !g) return c->fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e), -100 - (int)e);
             c->graph[key] = g;
             HIPCHK(hipGraphInstantiate(&c->gexec[key], g, nullptr, nullptr, 0));
@@ -1277,9 +1277,9 @@ int ptta_op_conv32(const float* in, const float* weight, const float* bias, floa
             a.in = in; a.in_nb = b; a.out_raw = out; a.bf16 = 0;
             rc = ptta_launch_conv32(a, s);
         }
-        hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(s);
     }
-    hipFree(w.mf32); hipFree(w.mbf16); hipFree(w.mlo); hipFree(w.canon); hipFree(tin); hipFree(tout);
+    (void)hipFree(w.mf32); (void)hipFree(w.mbf16); (void)hipFree(w.mlo); (void)hipFree(w.canon); (void)hipFree(tin); (void)hipFree(tout);
     return rc;
 }
 

@@ -249,7 +249,7 @@ def test_reference_style_driver_nlspn(golden_dir):
     loss.backward()
     opt.step()
     assert rel_mae(depth.detach(), g['s0/depth_train']) < 1e-3
-    np.testing.assert_allclose([float(info[k]) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')], g['s0/loss_info'], rtol=2e-3)
+    np.testing.assert_allclose([float(torch.as_tensor(info[k]).detach()) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')], g['s0/loss_info'], rtol=2e-3)
     named = dict(model.model.model.named_parameters())
     names = [str(x) for x in g['adapted_names']]
     gn = np.array([float(named[k].grad.double().norm()) for k in names])

@@ -78,7 +78,7 @@ def test_adapt_loss_gate(golden_dir):
         ref = (emb + float(g[tag + '/noise']) * u('gate/noise' + tag, rows, dim)).requires_grad_(True)
         loss, info = O.adapt_loss(image, depth, sparse, validity, emb, ref, 1.0, 2.0, 0.1, 80.0)
         loss.backward()
-        got = [float(info[k]) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')]
+        got = [float(info[k].detach()) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')]
         np.testing.assert_allclose(got, g[tag + '/loss_info'], rtol=1e-5)
         np.testing.assert_allclose(depth.grad.numpy(), g[tag + '/grad_depth'], rtol=1e-5, atol=1e-9)
         gr = ref.grad.numpy() if ref.grad is not None else np.zeros((rows, dim), np.float32)

@@ -68,7 +68,10 @@ class Engine:
                                   (_lib.PTTA_NLSPN_LEGACY_OFFSET if (legacy_offset and backbone == 'nlspn') else 0),
                                   self.n, self.h, self.w, code, byref(self.hp))
         if rc != 0:
-            raise RuntimeError('ptta_create failed (%d)' % rc)
+            why = {-19: 'no HIP device', -12: 'out of device memory', -22: 'invalid size / argument',
+                   -38: 'configuration not on the accelerated path (NLSPN needs height and width multiples of 16, fp32 and '
+                        'the 1layer meta conv; MSG_CHN needs the 1layer or 2layers meta layer)'}.get(rc, 'see include/ptta.h')
+            raise RuntimeError('ptta_create failed (%d): %s' % (rc, why))
         self.rows = int(self.lib.ptta_embedding_rows(self.handle))
         # adapted tensors in the reference's order, from the library (MSG_CHN 1layer: 2, 2layers: 7, NLSPN meta_bn: 88,
         # src/nlspn_model_adapt.py:322-337)

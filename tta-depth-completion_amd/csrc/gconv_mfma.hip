@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.H, W = p.W;
     const int ntx = (W + 31) >> 5, nty = (H + GX_TH - 1) / GX_TH;
-    const int nfl = (int)(blockIdx.x % p.nnf);
-    long t_ = blockIdx.x / p.nnf;
+    const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);      // the channel tiles of one pixel tile stay on one XCD / L2
+    const int nfl = (int)(bid % p.nnf);
+    long t_ = bid / p.nnf;
     const int ty = (int)(t_ % nty); t_ /= nty;
     const int tx = (int)(t_ % ntx);
     const int b = (int)(t_ / ntx);

@@ -197,6 +197,15 @@ __device__ __forceinline__ float bilinear_at(const float* __restrict__ im, int H
 
 
 
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id, and every XCD has its own L2.  This bijective
+// remap gives each XCD a CONTIGUOUS range of logical ids, so neighbours in the logical order (the output-channel tiles
+// of one pixel tile, adjacent pixel tiles) share an L2 instead of each fetching the same input tile from HBM / the
+// Infinity Cache through a different L2 (cdna_hip_programming.md, "XCD swizzle must be bijective").
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned orig, unsigned nwg) {
+    const unsigned xcd = orig & 7u, q = nwg >> 3, r = nwg & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding GLOBAL load
 // (s_waitcnt vmcnt(0)), which turns a register prefetch issued before the barrier into a synchronous load; this one
 // waits for the wave's LDS operations and leaves vector-memory loads in flight across the barrier

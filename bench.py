@@ -88,6 +88,26 @@ def nlspn_macs(h, w, n=1):
     return fwd_train, fwd_eval, bwd
 
 
+def nlspn_cpu_baseline(inner_iter=3):
+    """The NLSPN oracle (PyTorch CPU restatement, oracle/nlspn_oracle.py) on this box's host cores: one eval forward as
+    warm-up, then ONE timed TTA step of the same 352x1216 workload (about 10 s on 16 threads)."""
+    from oracle import nlspn_oracle as NO
+    from proxytta import synth
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+    image01, sparse = synth.synthetic_frame(0, H, W, 1)
+    raw = np.floor(image01 * 255.0).astype(np.float32)
+    im, sp, rawt = torch.from_numpy(((raw / np.float32(255.0) - mean) / std).astype(np.float32)), torch.from_numpy(sparse), torch.from_numpy(raw)
+    o = NO.NlspnOracle(synth.formula_state_dict_nlspn(), max_input_depth=80.0, lr=3e-4, w_sd=1.0, w_sm=0.0, w_cos=0.0, legacy=True)
+    o.forward_eval(im, sp)
+    t0 = time.time()
+    o.step(im, sp, loss_image=rawt)
+    dt = time.time() - t0
+    return {'value': 1.0 / (inner_iter * dt), 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 TTA step of the same 352x1216 workload after one eval forward (PyTorch-CPU oracle, fp32, %.1f s/step; %d steps/frame)' % (dt, inner_iter)}
+
+
 def nlspn_workload(frames=3, inner_iter=3):
     """BASELINE config 3 (not the headline metric): NLSPN backbone, 352x1216, 3 TTA steps per frame + the scored eval
     forward, adapt_mode meta_bn (88 adapted tensors), batch 1, inputs resident in HBM.  Reported beside the metric."""
@@ -234,6 +254,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_nlspn:
             out['other_workloads'] = {'nlspn': nlspn_workload()}
+            if not args.no_cpu_baseline:
+                out['other_workloads']['nlspn']['cpu_baseline'] = nlspn_cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -124,12 +124,16 @@ int ptta_launch_bn_bwd_apply32(const void* x, const void* g, void* dx, int bf16,
 
 // From the MODE-1 partials: BatchNorm parameter gradients and the constants of the input gradient.
 //   dbeta = sum g1 ; dgamma = sum g1*xhat ; c1 = dbeta/R ; c2 = dgamma/R ; gscale = gamma*inv
-__global__ void bn2d_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, long R, const float* __restrict__ gamma,
-                                         const float* __restrict__ inv, float* dgamma, float* dbeta, float* gscale, float* c1, float* c2) {
-    const int ch = threadIdx.x;
+// one wave per channel: lane l sums partial blocks l, l+64, ... in a fixed order, then xor-shuffles
+__global__ __launch_bounds__(256) void bn2d_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, long R, const float* __restrict__ gamma,
+                                                                const float* __restrict__ inv, float* dgamma, float* dbeta, float* gscale, float* c1, float* c2) {
+    const int ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (ch >= 32) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s1 += (double)part[((long)b * 2 + 0) * 32 + ch]; s2 += (double)part[((long)b * 2 + 1) * 32 + ch]; }
+    for (int b = lane; b < nblocks; b += 64) { s1 += (double)part[((long)b * 2 + 0) * 32 + ch]; s2 += (double)part[((long)b * 2 + 1) * 32 + ch]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
+    if (lane) return;
     if (dbeta) dbeta[ch] = (float)s1;
     if (dgamma) dgamma[ch] = (float)s2;
     c1[ch] = (float)(s1 / (double)R); c2[ch] = (float)(s2 / (double)R);
@@ -137,7 +141,7 @@ __global__ void bn2d_bwd_finalize_kernel(const float* __restrict__ part, int nbl
 }
 int ptta_launch_bn2d_bwd_finalize(const float* part, int nblocks, long R, const float* gamma, const float* inv, float* dgamma,
                                   float* dbeta, float* gscale, float* c1, float* c2, hipStream_t s) {
-    hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, part, nblocks, R, gamma, inv, dgamma, dbeta, gscale, c1, c2);
+    hipLaunchKernelGGL(bn2d_bwd_finalize_kernel, dim3(8), dim3(256), 0, s, part, nblocks, R, gamma, inv, dgamma, dbeta, gscale, c1, c2);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* __restri
 
 // y = act(x*scale+shift) ; with res: y = relu(x*scale+shift + res)   (BasicBlock.forward, nlspnmodel_adapt.py:98-116)
 // four channels per thread (every channel count and row stride on this path is a multiple of 4)
-__global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act, const float* __restrict__ st) {
+__global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act, const float* __restrict__ st, int res_relu = 1) {
     const int C4 = x.C >> 2, n = npass * x.C;
     const long total = (long)x.B * x.H * x.W * C4;
     const long ppp = (long)(x.B / npass) * x.H * x.W;
@@ -105,8 +105,10 @@ __global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act
         if (res.p) {
             const float4 r = *(const float4*)(res.p + pix * res.ld + c);
             v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            if (res_relu) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+            }
         } else if (act == GACT_RELU) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
@@ -137,6 +139,17 @@ int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, in
     return 0;
 }
 int ptta_gbn_part_floats(int C, int npass) { return npass * GBN_BLOCKS * 2 * C; }
+
+// normalise (+activation) (+residual, optionally without the BasicBlock's ReLU) from finalized statistics st = [4][npass][C]
+int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int npass, int act, const float* st, int res_relu, hipStream_t s) {
+    const int C = x.C;
+    if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
+    const long total = (long)x.B * x.H * x.W * (C >> 2);
+    long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
+    hipLaunchKernelGGL(gbn_apply_kernel, dim3((int)ab), dim3(256), 0, s, x, res, y, npass, act, st, res_relu);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
 
 // backward finalize (pass 0 = the grad pass only): dbeta, dgamma, and bw = [gscale, c1, c2][C]
 __global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long R, const float* __restrict__ gamma,

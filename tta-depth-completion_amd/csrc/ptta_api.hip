@@ -65,6 +65,12 @@ struct ptta_ctx {
         float *st1 = nullptr, *st2 = nullptr;          // [pass 2][mean, inv, scale, shift][C]
         float *rm1 = nullptr, *rv1 = nullptr, *rm2 = nullptr, *rv2 = nullptr; long long *nbt1 = nullptr, *nbt2 = nullptr;
         float *cs_part = nullptr, *bw = nullptr;       // statistics partials; [gscale, c1, c2, scratch] x 32
+        // generic-layer path (default arithmetic): the 128-channel hidden map as ONE NHWC-128 tensor, one launch per conv
+        bool generic = false;
+        float *gh = nullptr, *ga1 = nullptr, *gt = nullptr, *gdt = nullptr, *gda1 = nullptr, *gdh = nullptr;
+        float *w1c = nullptr, *w2c = nullptr, *w2bc = nullptr;                       // canonical [tap][cin][cout] packs of the adapted weights
+        bf16_t *w1hi = nullptr, *w1lo = nullptr, *w2hi = nullptr, *w2lo = nullptr, *w2bhi = nullptr, *w2blo = nullptr;
+        float *gst1 = nullptr, *gst2 = nullptr, *part1 = nullptr, *part2 = nullptr, *gbw = nullptr, *gpart = nullptr, *wgp = nullptr;
     } m2;
     float* hyper = nullptr;      // device: lr b1 b2 eps wd | w_sd w_sm w_cos
     float* w3_tmp = nullptr;     // device: loss weights of the standalone loss call
@@ -339,6 +345,21 @@ void build_workspace(ptta_ctx* c) {
             m2.da1 = c->act("meta_da1", Nn, H4, W4); m2.dh = c->act("meta_dh", Nn, H4, W4);
             m2.st1 = c->falloc(2 * 4 * 128); m2.st2 = c->falloc(2 * 4 * 32);
             m2.cs_part = c->falloc((size_t)ptta_chan_stats_blocks() * 2 * 32); m2.bw = c->falloc(4 * 32);
+            m2.generic = !c->bf16 && !c->naive && c->x3;
+            if (m2.generic) {
+                const size_t px2 = (size_t)B2 * H4 * W4, px1 = (size_t)Nn * H4 * W4;
+                m2.gh = c->falloc(px2 * 128); m2.ga1 = c->falloc(px2 * 128); m2.gt = c->falloc(px2 * 32);
+                m2.gdt = c->falloc(px1 * 32); m2.gda1 = c->falloc(px1 * 128); m2.gdh = c->falloc(px1 * 128);
+                m2.w1c = c->falloc(9 * 32 * 128); m2.w2c = c->falloc(9 * 128 * 32); m2.w2bc = c->falloc(9 * 32 * 128);
+                m2.w1hi = (bf16_t*)c->dalloc(2 * ptta_gfrag_elems(9, 32, 0, 128)); m2.w1lo = (bf16_t*)c->dalloc(2 * ptta_gfrag_elems(9, 32, 0, 128));
+                m2.w2hi = (bf16_t*)c->dalloc(2 * ptta_gfrag_elems(9, 128, 0, 32)); m2.w2lo = (bf16_t*)c->dalloc(2 * ptta_gfrag_elems(9, 128, 0, 32));
+                m2.w2bhi = (bf16_t*)c->dalloc(2 * ptta_gfrag_elems(9, 32, 0, 128)); m2.w2blo = (bf16_t*)c->dalloc(2 * ptta_gfrag_elems(9, 32, 0, 128));
+                m2.gst1 = c->falloc(4 * 2 * 128); m2.gst2 = c->falloc(4 * 2 * 32);
+                const size_t tiles = (size_t)ptta_gconv_x3_tiles(B2, H4, W4);
+                m2.part1 = c->falloc(tiles * 2 * 128); m2.part2 = c->falloc(tiles * 2 * 32);
+                m2.gbw = c->falloc(3 * 128); m2.gpart = c->falloc((size_t)ptta_gbn_part_floats(128, 1));
+                m2.wgp = c->falloc((size_t)ptta_gwgrad_mfma_part_floats((long)px1, 128, 32));
+            }
         }
     }
     c->gW = c->adapted[0].g; c->gB = c->adapted[1].g;
@@ -409,6 +430,41 @@ int meta_forward(ptta_ctx* c, bool train, int B, hipStream_t s) {
     const ptta_ctx::Adapted* A = c->adapted.data();          // 0 W1, 1 g1, 2 b1, 3 W2, 4 bias2, 5 g2, 6 b2
     const long P = (long)Nn * H4 * W4;                         // pixels per pass
     const int npass = train ? B / Nn : 1;
+    if (m2.generic) {
+        // one matrix-core launch per convolution on NHWC-128 tensors (gconv_mfma.hip), BatchNorm statistics reduced in the
+        // conv epilogues, one finalize per pass (running statistics: real frames first, then proxy frames), one apply
+        if (!train && (!m2.rm1 || !m2.rv1 || !m2.rm2 || !m2.rv2)) return c->fail("meta BatchNorm running statistics not loaded", -3);
+        GView x; x.p = (float*)c->c2; x.B = B; x.H = H4; x.W = W4; x.C = 32; x.ld = 32;
+        GView hv = x; hv.p = m2.gh; hv.C = 128; hv.ld = 128;
+        GView av = hv; av.p = m2.ga1;
+        GView tv = x; tv.p = m2.gt;
+        GView mv = x; mv.p = (float*)c->m;
+        const int tiles_pp = ptta_gconv_x3_tiles(B / npass, H4, W4);
+        auto finalize = [&](float* part, int C, const float* gamma, const float* beta, float* rm, float* rv, long long* nbt, float* st) -> int {
+            if (!train) return ptta_launch_bn_eval_affine(gamma, beta, rm, rv, 1e-5f, st + 2 * C, st + 3 * C, C, s);       // npass == 1
+            for (int pass = 0; pass < npass; ++pass)
+                if (ptta_launch_bn_finalize(part + (size_t)pass * tiles_pp * 2 * C, tiles_pp, (int)P, C, gamma, beta, 1e-5f, 0.1f, rm, rv, nbt,
+                                            st + pass * C, st + (npass + pass) * C, st + (2 * npass + pass) * C, st + (3 * npass + pass) * C, s)) return -5;
+            return 0;
+        };
+        GX3Args a;
+        a.x0 = x.p; a.C0 = 32; a.ld0 = 32; a.B = B; a.H = H4; a.W = W4;
+        a.whi = (const uint4*)m2.w1hi; a.wlo = (const uint4*)m2.w1lo; a.nchunks = 1; a.nf0 = 0; a.nnf = 4;
+        a.y = hv.p; a.ldy = 128; a.Cy = 128;
+        if (train) { a.stat_part = m2.part1; a.stat_C = 128; a.stat_npass = npass; }
+        RUN(ptta_launch_gconv_x3(a, 3, s));
+        RUN(finalize(m2.part1, 128, A[1].p, A[2].p, m2.rm1, m2.rv1, m2.nbt1, m2.gst1));
+        RUN(ptta_launch_gbn_apply(hv, GView(), av, npass, GACT_LRELU, m2.gst1, 0, s));
+        GX3Args b2;
+        b2.x0 = av.p; b2.C0 = 128; b2.ld0 = 128; b2.B = B; b2.H = H4; b2.W = W4;
+        b2.whi = (const uint4*)m2.w2hi; b2.wlo = (const uint4*)m2.w2lo; b2.nchunks = 4; b2.nf0 = 0; b2.nnf = 1;
+        b2.y = tv.p; b2.ldy = 32; b2.Cy = 32; b2.bias = A[4].p;
+        if (train) { b2.stat_part = m2.part2; b2.stat_C = 32; b2.stat_npass = npass; }
+        RUN(ptta_launch_gconv_x3(b2, 3, s));
+        RUN(finalize(m2.part2, 32, A[5].p, A[6].p, m2.rm2, m2.rv2, m2.nbt2, m2.gst2));
+        RUN(ptta_launch_gbn_apply(tv, x, mv, npass, GACT_NONE, m2.gst2, 0, s));            // + x, no activation (Res_Conv.forward :35-36)
+        return 0;
+    }
     const int nblk = ptta_chan_stats_blocks();
     for (int g = 0; g < 4; ++g) { E e; e.raw = m2.h[g]; RUN(conv32w(c, s, &m2.w1f[g], nullptr, c->c2, B, B, H4, W4, e)); }
     if (train) {
@@ -452,6 +508,30 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
     ptta_ctx::Adapted* A = c->adapted.data();
     const int H4 = c->H4, W4 = c->W4, Nn = c->Nn;
     const long P = (long)Nn * H4 * W4;
+    if (m2.generic) {
+        const int npass = 2;                                   // layout of the training forward's statistics
+        GView x; x.p = (float*)c->c2; x.B = Nn; x.H = H4; x.W = W4; x.C = 32; x.ld = 32;
+        GView hv = x; hv.p = m2.gh; hv.C = 128; hv.ld = 128;
+        GView av = hv; av.p = m2.ga1;
+        GView tv = x; tv.p = m2.gt;
+        GView gm = x; gm.p = (float*)c->dm_total;
+        GView dt = x; dt.p = m2.gdt;
+        GView da1 = hv; da1.p = m2.gda1;
+        GView dh = hv; dh.p = m2.gdh;
+        // BatchNorm2d(32) (no activation, the residual branch carries no adapted parameter): d gamma2, d beta2, d t
+        RUN(ptta_launch_gbn_backward(tv, gm, tv, dt, GView(), npass, GACT_NONE, 0, 0, 0, A[5].p, m2.gst2, m2.gpart, m2.gbw, A[5].g, A[6].g, s));
+        // conv2: weight + bias gradient (one launch over the 128 input channels), data gradient to the hidden map
+        RUN(ptta_launch_gwgrad_mfma(av, dt, m2.wgp, A[3].g, A[4].g, s));
+        GX3Args a;
+        a.x0 = dt.p; a.C0 = 32; a.ld0 = 32; a.B = Nn; a.H = H4; a.W = W4;
+        a.whi = (const uint4*)m2.w2bhi; a.wlo = (const uint4*)m2.w2blo; a.nchunks = 1; a.nf0 = 0; a.nnf = 4;
+        a.y = da1.p; a.ldy = 128; a.Cy = 128;
+        RUN(ptta_launch_gconv_x3(a, 3, s));
+        // LeakyReLU(0.2) + BatchNorm2d(128): d gamma1, d beta1, d h; conv1 weight gradient
+        RUN(ptta_launch_gbn_backward(hv, da1, av, dh, GView(), npass, GACT_LRELU, 0, 0, 0, A[1].p, m2.gst1, m2.gpart, m2.gbw, A[1].g, A[2].g, s));
+        RUN(ptta_launch_gwgrad_mfma(x, dh, m2.wgp, A[0].g, nullptr, s));
+        return 0;
+    }
     const int nblk = ptta_chan_stats_blocks();
     float *gsc = m2.bw, *c1 = m2.bw + 32, *c2 = m2.bw + 64, *scr = m2.bw + 96;
     // BatchNorm2d(32) backward: d gamma2, d beta2, d t
@@ -745,7 +825,16 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
         img = c->img_pad; sp = c->sp_pad;
     }
     RUN(ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
-    if (c->meta_mode == PTTA_META_2LAYERS) {
+    if (c->meta_mode == PTTA_META_2LAYERS && c->m2.generic) {
+        auto& m2 = c->m2;
+        const float* W1 = c->adapted[0].p; const float* W2 = c->adapted[3].p;       // (128,32,3,3), (32,128,3,3)
+        ptta_gpack(W1, m2.w1c, 9, 32, 128, 9, 32L * 9, 0, s);                        // forward  P[t][ci][co]
+        ptta_gfrag_pack(m2.w1c, 128, 32L * 128, 9, 32, 0, 0, 0, 128, m2.w1hi, m2.w1lo, s);
+        ptta_gpack(W2, m2.w2c, 9, 128, 32, 9, 128L * 9, 0, s);
+        ptta_gfrag_pack(m2.w2c, 32, 128L * 32, 9, 128, 0, 0, 0, 32, m2.w2hi, m2.w2lo, s);
+        ptta_gpack(W2, m2.w2bc, 9, 32, 128, 128L * 9, 9, 1, s);                      // data gradient  P[t][co][ci] = W2[co][ci][8-t]
+        ptta_gfrag_pack(m2.w2bc, 128, 32L * 128, 9, 32, 0, 0, 0, 128, m2.w2bhi, m2.w2blo, s);
+    } else if (c->meta_mode == PTTA_META_2LAYERS) {
         for (int g = 0; g < 4; ++g) {
             ptta_pack_conv32(c->adapted[0].p + (size_t)g * 9216, c->m2.w1f[g], 0, 0, s);            // W1 rows 32g..32g+31
             ptta_pack_conv32(c->adapted[3].p, c->m2.w2f[g], 0, 0, s, 128, 32 * g);                 // W2 columns 32g..

@@ -167,6 +167,7 @@ int ptta_gbn_part_floats(int C, int npass);
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
                             const float* beta, float* part, float* st, hipStream_t s, int fused_blocks = 0);
 int ptta_gconv_x3_tiles(int B, int H, int W);
+int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int npass, int act, const float* st, int res_relu, hipStream_t s);
 int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, const GView& gx, const GView& gres, int npass, int act,
                              int res_relu, int acc_gx, int acc_gres, const float* gamma, const float* st, float* part, float* bw,
                              float* dgamma, float* dbeta, hipStream_t s);

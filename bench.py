@@ -61,6 +61,32 @@ def cpu_baseline(steps=3):
             'sample': '%d steps of the same 352x1216 workload after 1 warm-up (PyTorch-CPU oracle, fp32, %.2f s/step)' % (steps, dt)}
 
 
+def msgchn_2layers_workload(steps=30):
+    """MSG_CHN with the `2layers` meta layer (Res_Conv(32,128) + 2 BatchNorm2d, 7 adapted tensors): the recipe of
+    bash/adapt/adapt_msgchn_vkitti.sh:26.  Same 352x1216 synthetic frames as the headline (1layer) configuration."""
+    from proxytta import synth
+    from proxytta.engine import Engine
+    mode = 'meta_selfsup_seq_2layers_ema'
+    eng = Engine(1, H, W, meta='2layers', **HP)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(mode).items()}
+    eng.load_state_dict(sd)
+    for name in eng.adapted:
+        eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(i, H, W, 1)] for i in range(4)]
+    for i in range(5):
+        eng.step(*frames[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        info, _ = eng.step(*frames[i % 4])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {'workload': 'MSG_CHN 2layers meta (Res_Conv(32,128), 7 adapted tensors), 352x1216, 1 TTA step/frame, batch 1',
+           'ms_per_step': 1e3 * dt, 'frames_per_s': 1.0 / dt, 'finite': bool(torch.isfinite(info).all().item())}
+    eng.close()
+    return out
+
+
 def nlspn_macs(h, w, n=1):
     """Multiply-accumulates of one NLSPN TTA step from the architecture (nlspnmodel_adapt.py:385-452, ResNet34
     BasicBlocks :70-116): (training forward incl. the proxy pass and the heads, eval forward, minimal backward).
@@ -253,7 +279,7 @@ def main():
     eng.close()
     if rank == 0:
         if world == 1 and not args.no_nlspn:
-            out['other_workloads'] = {'nlspn': nlspn_workload()}
+            out['other_workloads'] = {'msg_chn_2layers': msgchn_2layers_workload(), 'nlspn': nlspn_workload()}
             if not args.no_cpu_baseline:
                 out['other_workloads']['nlspn']['cpu_baseline'] = nlspn_cpu_baseline()
         print(json.dumps(out))

@@ -176,6 +176,58 @@ def nlspn_workload(frames=3, inner_iter=3):
     return out
 
 
+def plumbing_only(args, rank, world):
+    """The multi-rank skeleton of main() without device work (tests/test_distributed_cpu.py): rendezvous on 127.0.0.1,
+    warm-up, barrier, K timed no-op steps, barrier, MAX over ranks, rank 0 prints the JSON line with value null."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'TTA frames/sec (fwd+loss+bwd+Adam) at 352x1216', 'value': None, 'unit': 'frames/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none', 'data': 'none',
+                          'config': {'workload': 'plumbing only: no device work', 'parallelism': 'independent frame streams, dp%d, no collectives' % world}}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start N child processes, one per GPU (as
+    src/tta.py:189-269 spawns one adapt_ddp per GPU), BEFORE this process touches the GPU, forward rank 0's JSON line and
+    exit with the worst child code.  Under torch.distributed.run (RANK set) this is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=os.environ.get('MASTER_PORT', str(port)))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out0.decode().splitlines():          # ONE JSON line on stdout; library chatter (e.g. gloo's) to stderr
+        print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -183,12 +235,21 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-nlspn', action='store_true', help='skip the NLSPN (BASELINE config 3) side measurement')
+    ap.add_argument('--no-nlspn', action='store_true', help='skip the side measurements (2layers, NLSPN, CostDCNet)')
+    ap.add_argument('--plumbing-only', action='store_true',
+                    help='tests only: run launcher / rendezvous / barrier / max-over-ranks / JSON with NO device work '
+                         '(value is null, "data": "none"); lets the multi-rank path run on a CPU box with gloo')
     args = ap.parse_args()
 
+    if 'RANK' not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)' % (args.gpus, world))
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the product path has no CPU fallback')
     torch.cuda.set_device(local_rank % torch.cuda.device_count())     # (modulo only matters for plumbing tests on a 1-GPU box)

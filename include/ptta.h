@@ -10,8 +10,12 @@
  *     own layouts: images (N,3,H,W), depth maps (N,1,H,W), embeddings (rows,512), all fp32,
  *     contiguous.  Weights are passed as the reference's state_dict tensors (fp32, NCHW) and are
  *     re-packed internally.
- *   - all work is enqueued on the hipStream_t argument (pass torch.cuda.current_stream()); no
- *     call synchronises the device or allocates after ptta_create.
+ *   - all work is enqueued on the hipStream_t argument (pass torch.cuda.current_stream()); nothing
+ *     is allocated after ptta_create and no call on the path synchronises (host constants travel as
+ *     kernel arguments).  The only calls that wait for the stream are the ones that RETURN a host
+ *     value (ptta_get_adam_step, ptta_profile_read) and the ones that destroy a captured graph
+ *     (they wait for its last replay: ptta_load_weights, ptta_bind_adapted, ptta_set_image_norm,
+ *     ptta_set_graph(0), a changed max_input_depth in ptta_set_hparams).
  *   - return value 0 = ok, <0 = error; ptta_last_error() returns a message.  Nothing is printed.
  *   - one handle per (process, GPU); a handle is not thread-safe.
  */

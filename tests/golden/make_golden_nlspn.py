@@ -37,6 +37,9 @@ MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
 STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
 
 
+HOLES = {'allow': False, 'count': 0}
+
+
 def import_reference():
     os.chdir(REF)
     sys.path.insert(0, os.path.join(REF, 'src'))
@@ -59,8 +62,14 @@ def import_reference():
     skr = types.ModuleType('skimage.restoration')
     sk.restoration = skr
 
-    def no_inpaint(*a, **k):
-        raise RuntimeError('eval output contains exact zeros: biharmonic inpainting is not available here')
+    def no_inpaint(depth, mask, *a, **k):
+        # scikit-image is absent.  Small cases: there must be no hole.  Full-size cases (HOLES['allow']): the holes (exact
+        # zeros where the clamp at nlspnmodel_adapt.py:371 cut a negative prediction) are left as they are and counted, so
+        # the fixture pins the eval output BEFORE hole filling.
+        if not HOLES['allow']:
+            raise RuntimeError('eval output contains exact zeros: biharmonic inpainting is not available here')
+        HOLES['count'] += int(np.asarray(mask).sum())
+        return depth
     skr.inpaint = types.SimpleNamespace(inpaint_biharmonic=no_inpaint)
     sys.modules['skimage'] = sk
     sys.modules['skimage.restoration'] = skr
@@ -117,7 +126,7 @@ def sample_rows(x, k=24):
     return idx, x[idx]
 
 
-def run_case(ema, name, h, w, n, steps, hp, offset=False):
+def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False):
     model = ema.ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], offset=offset, device=torch.device('cpu'))
     model._prepare_head(PREPARE)
     net = model.model.model
@@ -154,9 +163,16 @@ def run_case(ema, name, h, w, n, steps, hp, offset=False):
         with torch.no_grad():
             depth_eval = model.forward(image=image, sparse_depth=sparse, loss_type=LOSS_TYPE)
         p = 's%d/' % s
-        out[p + 'depth_train'] = depth.detach().numpy()
-        out[p + 'depth_eval'] = depth_eval.numpy()
+        if sampled:         # full-size cases: checksums + 4096 sampled pixels + 8x8 block means (make_golden_fullsize.py)
+            from make_golden_fullsize import pix_index, summarise
+            out['pix_idx'] = pix_index(n * h * w)
+            summarise(out, p + 'depth_train', depth)
+            summarise(out, p + 'depth_eval', depth_eval)
+        else:
+            out[p + 'depth_train'] = depth.detach().numpy()
+            out[p + 'depth_eval'] = depth_eval.numpy()
         out[p + 'n_zero_train'] = np.array(int((depth == 0).sum()))
+        out[p + 'n_zero_eval'] = np.array(int((depth_eval == 0).sum()))
         e, r = emb.detach().numpy(), ref.detach().numpy()
         idx, out[p + 'emb_rows'] = sample_rows(e)
         _, out[p + 'ref_rows'] = sample_rows(r)
@@ -184,6 +200,13 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sd=1.0, w_sm=2.0, w_cos=0.1, max_input_depth=80.0)
+    if len(sys.argv) > 1:       # larger cases, one per invocation (minutes of CPU each): `96x320` or `352x1216`
+        sys.path.insert(0, HERE)
+        h, w = [int(x) for x in sys.argv[1].split('x')]
+        HOLES['allow'] = True
+        # what src/tta_main.py runs: legacy offsets; the canonical script's loss weights (adapt_nlspn_vkitti.sh) + a smoothness term
+        run_case(ema, 'nlspn_%dx%d_legacy' % (h, w), h, w, 1, 1, dict(hp, lr=3e-4), offset=True, sampled=True)
+        return
     run_case(ema, 'nlspn_32x64', 32, 64, 1, 2, hp)
     run_case(ema, 'nlspn_48x80_n2', 48, 80, 2, 1, hp)
     # the canonical script's weights: sparse-depth term only, lr 3e-4 (bash/adapt/adapt_nlspn_vkitti.sh:7-14,47-49)

@@ -45,3 +45,43 @@ def test_gloo_world2_grad_allreduce_and_sharding():
 def test_single_process_is_identity():
     g = [torch.ones(3), torch.zeros(2)]
     assert D.allreduce_adapted_grads(g) is g
+
+
+def _bench(cmd, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable] + cmd, cwd=root, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_one_rank_per_gpu():
+    """`python bench.py --gpus 2` (no launcher around it) starts 2 ranks before touching any device, rendezvous on
+    127.0.0.1, barrier + MAX-over-ranks timing, ONE JSON line from rank 0 with n_gpus = 2 (device work stubbed out)."""
+    out = _bench(['bench.py', '--gpus', '2', '--steps', '4', '--warmup', '1', '--plumbing-only'])
+    assert out['n_gpus'] == 2 and out['steps'] == 4 and out['warmup'] == 1 and out['scaling'] == 'weak'
+    assert out['value'] is None and out['data'] == 'none' and out['ms_per_step'] >= 1.0
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's launch line: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2."""
+    out = _bench(['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                  '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--plumbing-only'])
+    assert out['n_gpus'] == 2 and out['steps'] == 3
+
+
+def test_bench_refuses_mismatched_world():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--plumbing-only'], cwd=root, capture_output=True, text=True,
+                       env=dict(os.environ, RANK='0', WORLD_SIZE='4'), timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE' in r.stderr

@@ -167,3 +167,50 @@ def test_fused_image_normalisation(rng, shape):
     with pytest.raises(ValueError):
         eng.set_image_norm([0, 2])
     eng.close()
+
+
+def test_adam_step_count_continues_across_frame_shapes(tmp_path):
+    """torch.optim.Adam keeps ONE step count per parameter; the façade builds one engine per (N, H, W).  A shape change
+    (last short batch of a loader with drop_last=False, src/tta_main.py:281) must continue the bias correction, and a
+    checkpoint restored through restore_model(optimizer=...) must rebind the replaced Adam state."""
+    from proxytta.model import ExternalModel_Adapt
+    model = ExternalModel_Adapt('msg_chn', 0.0, 80.0, max_input_depth=80.0, device=torch.device('cuda'))
+    model._prepare_head(ONE)
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict(ONE).items()})
+    params = model.adapt_parameters(mode='meta')
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    model.model.set_hparams(w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1)
+    model.model.bind_optimizer(opt)
+    o = _oracle()
+    shapes = [(1, 32, 48), (1, 32, 48), (2, 32, 64), (1, 32, 48)]
+    for i, (n, h, w) in enumerate(shapes):
+        image, sparse = synth.synthetic_frame(60 + i, h, w, n)
+        o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+        model.step(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())
+        if i == 1:                      # save + restore in the middle of the sequence
+            path = str(tmp_path / 'ckpt.pth')
+            model.save_model(path, i, opt)
+            model.restore_model(path, optimizer=opt)
+    assert model.model._adam_t == len(shapes)
+    assert float(opt.state[params[0]]['step']) == len(shapes)
+    for k, prm in zip(('conv1_rgb_meta.weight', 'conv1_rgb_meta.bias'), params):
+        assert rel_mae(prm, o.P[k].detach()) < 2e-3, k
+    assert rel_mae(opt.state[params[0]]['exp_avg'], o.opt.m[0]) < 3e-2
+
+
+def test_get_time_hook():
+    """forward(loss_type containing 'time') accumulates wall-clock like the reference's networks do
+    (network_exp_msg_chn_adapt.py:338-340,407-414); forward(loss_type='get_time') reads [total, train, eval]."""
+    from proxytta.model import CANONICAL_LOSS_TYPE, ExternalModel_Adapt
+    model = ExternalModel_Adapt('msg_chn', 0.0, 80.0, max_input_depth=80.0, device=torch.device('cuda'))
+    model._prepare_head(ONE)
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict(ONE).items()})
+    image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(0, 32, 48, 1)]
+    assert model.forward(image, sparse, loss_type='get_time') == [0.0, 0.0, 0.0]
+    model.train()
+    model.forward(image, sparse, loss_type=CANONICAL_LOSS_TYPE + '_time')
+    model.eval()
+    model.forward(image, sparse, loss_type=CANONICAL_LOSS_TYPE + '_time')
+    model.forward(image, sparse, loss_type=CANONICAL_LOSS_TYPE)           # not timed
+    total, train, evalt = model.forward(image, sparse, loss_type='get_time')
+    assert train > 0 and evalt > 0 and abs(total - train - evalt) < 1e-9

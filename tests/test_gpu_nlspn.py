@@ -309,3 +309,30 @@ def test_shared_parameter_step_nlspn():
     for k in ad1:
         assert rel_mae(ad2[k][0], ad1[k][0]) < 1e-5, k
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize('name', ['nlspn_96x320_legacy', 'nlspn_352x1216_legacy'])
+def test_full_size_step_matches_reference(golden_dir, name):
+    """Default arithmetic at 96x320 and at the BASELINE size 352x1216 against vectors produced by the REAL reference
+    (tests/golden/make_golden_nlspn.py <size>): 4096 sampled pixels, 8x8 block means and checksums of the training and
+    the post-update eval depth, loss terms, gradient norms of all 88 adapted tensors, full gradients of ten of them."""
+    from tests.test_gpu_fullsize import _check_map
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
+    hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=mid)
+    eng, sd, adapted = make_nlspn(n, h, w, hp, legacy=True)
+    names = [str(x) for x in g['adapted_names']]
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+    info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+    _check_map(depth, g, 's0/depth_train', 1e-3)                       # north_star: 1e-3 relative MAE
+    np.testing.assert_allclose(info.cpu().numpy(), g['s0/loss_info'], rtol=2e-3)
+    gn = np.array([float(eng.grad(k, adapted[k][0]).double().norm()) for k in names])
+    np.testing.assert_allclose(gn, g['s0/grad_norms'], rtol=TOL['default']['grad'], atol=1e-6)
+    for key in g.files:
+        if key.startswith('s0/grad/'):
+            k = key[len('s0/grad/'):]
+            assert rel_mae(eng.grad(k, adapted[k][0]), g[key]) < TOL['default']['grad'], k
+    # the reference's eval output BEFORE its skimage hole filling (exact zeros stay zeros on both sides)
+    _check_map(eng.forward_eval(image1, sparse), g, 's0/depth_eval', 1e-3)
+    eng.close()

@@ -163,3 +163,75 @@ def test_nlspn_oracle_matches_reference(golden_dir, name):
                 assert rel_mae(o.P[k].detach(), g[p + 'param/' + k]) < 5e-4, k
         d_eval = o.forward_eval(image1, sparse)
         assert rel_mae(d_eval, g[p + 'depth_eval']) < 2e-5
+
+
+# ---- full-size reference vectors (tests/golden/make_golden_fullsize.py): checksums + sampled pixels -------------
+def _check_map(t, g, key, tol):
+    a = t.detach().numpy().astype(np.float32)
+    flat = a.reshape(-1)
+    assert rel_mae(flat[g['pix_idx']], g[key + '_pix']) < tol, key
+    n, c, h, w = a.shape
+    blk = a.reshape(n, c, h // 8, 8, w // 8, 8).mean(axis=(3, 5), dtype=np.float64)
+    assert rel_mae(blk, g[key + '_blk']) < tol, key
+    assert abs(flat.sum(dtype=np.float64) - float(g[key + '_sum'])) < tol * float(g[key + '_abs_mean']) * flat.size
+
+
+@pytest.mark.parametrize('name,mode,max_steps', [('msgchn_1layer_256x320', 'meta_selfsup_seq_1layer_ema', 2),
+                                                 ('msgchn_2layers_256x320', 'meta_selfsup_seq_2layers_ema', 1),
+                                                 ('msgchn_1layer_352x1216', 'meta_selfsup_seq_1layer_ema', 1),
+                                                 ('msgchn_1layer_64x96_seq10', 'meta_selfsup_seq_1layer_ema', 10)])
+def test_oracle_matches_reference_full_size(golden_dir, name, mode, max_steps):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps, frame0 = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid, gain = [float(x) for x in g['hp']]
+    torch.set_num_threads(8)
+    o = O.MsgChnOracle(synth.formula_state_dict(mode, gain), mode, max_input_depth=mid, lr=lr, betas=(b1, b2), eps=eps,
+                       weight_decay=wd, w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
+    eval_tol = 2e-4 if '2layers' in mode else 2e-5
+    for s in range(min(steps, max_steps)):
+        image, sparse = [torch.from_numpy(x) for x in synth.synthetic_frame(frame0 + s, h, w, n)]
+        r = o.step(image, sparse)
+        p = 's%d/' % s
+        _check_map(r['depth'], g, p + 'depth_train', 2e-5)
+        li = r['loss_info']
+        np.testing.assert_allclose([li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], g[p + 'loss_info'], rtol=5e-5)
+        for k in o.names:
+            if p + 'grad/' + k in g.files and np.abs(g[p + 'grad/' + k]).max() >= 1e-6:
+                # after 10 steps the two fp32 trajectories have drifted by a few sign() flips of the L1/TV gradients
+                assert rel_mae(r['grads'][k], g[p + 'grad/' + k]) < (1e-3 if s == 0 else 5e-3), k
+                assert rel_mae(o.P[k].detach(), g[p + 'param/' + k]) < (1e-4 if s == 0 else 1e-3), k
+        _check_map(o.forward_eval(image, sparse), g, p + 'depth_eval', eval_tol)
+
+
+def test_eval_metrics_oracle_matches_reference(golden_dir):
+    """oracle.eval_metrics against numbers computed by the reference's src/eval_utils.py (make_golden_fullsize.py)."""
+    g = np.load(os.path.join(golden_dir, 'eval_metrics.npz'))
+    n, h, w = [int(x) for x in g['meta']]
+    u = lambda tag: synth.hash_uniform(tag, n * h * w).reshape(n, 1, h, w).astype(np.float32)
+    gt = (u('em/gt') * 90.0).astype(np.float32)
+    gt[u('em/mask') < 0.7] = 0.0
+    outd = (np.maximum(gt + (u('em/noise') - 0.5) * 3.0, 0.1).astype(np.float32) + (gt == 0) * 5.0).astype(np.float32)
+    for key in g.files:
+        if key != 'meta':
+            lo, hi = [float(x) for x in key.split('_')]
+            np.testing.assert_allclose(O.eval_metrics(torch.from_numpy(outd), torch.from_numpy(gt), lo, hi).numpy(), g[key], rtol=1e-6)
+
+
+def test_nlspn_oracle_matches_reference_96x320(golden_dir):
+    """Larger NLSPN reference case (legacy offsets as src/tta_main.py:309-317 constructs the model), stored as sampled
+    pixels + block means + checksums (tests/golden/make_golden_nlspn.py 96x320)."""
+    from oracle import nlspn_oracle as N
+    g = np.load(os.path.join(golden_dir, 'nlspn_96x320_legacy.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
+    torch.set_num_threads(8)
+    o = N.NlspnOracle(synth.formula_state_dict_nlspn(), max_input_depth=mid, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd,
+                      w_sd=w_sd, w_sm=w_sm, w_cos=w_cos, legacy=True)
+    raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(0, h, w, n)]
+    r = o.step(image1, sparse, loss_image=raw)
+    _check_map(r['depth'], g, 's0/depth_train', 5e-5)
+    li = r['loss_info']
+    np.testing.assert_allclose([li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], g['s0/loss_info'], rtol=1e-4)
+    gn = np.array([float(r['grads'][k].double().norm()) for k in o.names])
+    np.testing.assert_allclose(gn, g['s0/grad_norms'], rtol=1e-2, atol=1e-7)
+    _check_map(o.forward_eval(image1, sparse), g, 's0/depth_eval', 5e-5)

@@ -590,8 +590,7 @@ int backward(nlspn_engine* e, hipStream_t s) {
 int upload_hparams(nlspn_engine* e, hipStream_t s) {
     const ptta_hparams& hp = e->hp;
     const float h8[8] = {hp.lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.w_sparse_depth, hp.w_smoothness, hp.w_cos};
-    if (hipMemcpyAsync(e->hyper, h8, sizeof(h8), hipMemcpyHostToDevice, s) != hipSuccess) return e->fail("hyper-parameter upload failed", -5);
-    if (hipStreamSynchronize(s) != hipSuccess) return e->fail("sync failed", -5);
+    if (ptta_launch_set_floats(e->hyper, h8, 8, s)) return e->fail("hyper-parameter upload failed", -5);     // by kernel argument: no sync
     return 0;
 }
 
@@ -645,8 +644,7 @@ const char* nlspn_adapted_name(nlspn_engine* e, int index, int64_t* numel) {
     return e->adapted[index].name.c_str();
 }
 int nlspn_set_adam_step(nlspn_engine* e, int step, hipStream_t s) {
-    if (hipMemcpyAsync(e->step_dev, &step, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) return e->fail("memcpy failed", -5);
-    return hipStreamSynchronize(s) == hipSuccess ? 0 : e->fail("sync failed", -5);
+    return ptta_launch_set_int(e->step_dev, step, s) ? e->fail("set step failed", -5) : 0;
 }
 int nlspn_get_adam_step(nlspn_engine* e, int* step, hipStream_t s) {
     if (hipMemcpyAsync(step, e->step_dev, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return e->fail("memcpy failed", -5);
@@ -734,8 +732,7 @@ int nlspn_loss_forward(nlspn_engine* e, const float* loss_image, const float* de
                        const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos, float* loss_info_out, hipStream_t s) {
     if (rows > e->rows()) return e->fail("rows exceeds the handle's embedding rows", -22);
     const float w3[3] = {w_sd, w_sm, w_cos};
-    if (hipMemcpyAsync(e->w3_tmp, w3, sizeof(w3), hipMemcpyHostToDevice, s) != hipSuccess) return e->fail("memcpy failed", -5);
-    if (hipStreamSynchronize(s) != hipSuccess) return e->fail("sync failed", -5);          // w3 is on the stack
+    if (ptta_launch_set_floats(e->w3_tmp, w3, 3, s)) return e->fail("loss weight upload failed", -5);
     if (ptta_launch_loss_forward(depth, loss_image, sparse, validity, e->hp.max_input_depth, emb, ref, rows, 1024, e->w3_tmp, e->N, e->H,
                                  e->W, e->loss_ws, loss_info_out, s)) return e->fail("loss forward failed", -5);
     return 0;

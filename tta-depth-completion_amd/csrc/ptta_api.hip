@@ -101,7 +101,9 @@ struct ptta_ctx {
         return aux_stream;
     }
     float *in_image = nullptr, *in_loss_image = nullptr, *in_sparse = nullptr, *in_validity = nullptr;
+    hipEvent_t ev_replay = nullptr;      // recorded after every hipGraphLaunch: a graph is only destroyed once its last replay is done
     void drop_graphs() {
+        if (ev_replay) (void)hipEventSynchronize(ev_replay);
         for (int k = 0; k < 4; ++k) {
             if (gexec[k]) { (void)hipGraphExecDestroy(gexec[k]); gexec[k] = nullptr; }
             if (graph[k]) { (void)hipGraphDestroy(graph[k]); graph[k] = nullptr; }
@@ -811,8 +813,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
 int push_hparams(ptta_ctx* c, hipStream_t s) {
     const float h[8] = {c->hp.lr, c->hp.beta1, c->hp.beta2, c->hp.eps, c->hp.weight_decay,
                         c->hp.w_sparse_depth, c->hp.w_smoothness, c->hp.w_cos};
-    HIPCHK(hipMemcpyAsync(c->hyper, h, sizeof(h), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));     // h is on the stack
+    RUN(ptta_launch_set_floats(c->hyper, h, 8, s));      // by kernel argument: no host sync
     return 0;
 }
 
@@ -859,6 +860,8 @@ extern "C" {
 int ptta_version(void) { return PTTA_VERSION; }
 
 const char* ptta_last_error(ptta_handle h) { return h ? (h->nl && h->err.empty() ? nlspn_last_error(h->nl) : h->err.c_str()) : "null handle"; }
+// calls forwarded to the NLSPN engine clear the wrapper-level message, so a later nlspn_last_error is not masked by a stale one
+#define NLFWD(call) do { if (c && c->nl) { c->err.clear(); return (call); } } while (0)
 
 int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int height, int width, int dtype, const ptta_hparams* hp) {
     if (!out) return -1;
@@ -904,6 +907,7 @@ void ptta_destroy(ptta_handle h) {
     if (!h) return;
     if (h->nl) { nlspn_destroy(h->nl); delete h; return; }
     h->drop_graphs();
+    if (h->ev_replay) (void)hipEventDestroy(h->ev_replay);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
     for (void* p : h->allocs) if (p) (void)hipFree(p);
@@ -912,7 +916,7 @@ void ptta_destroy(ptta_handle h) {
 }
 
 int ptta_set_hparams(ptta_handle c, const ptta_hparams* hp, ptta_stream s) {
-    if (c && c->nl) return nlspn_set_hparams(c->nl, hp, (hipStream_t)s);
+    NLFWD(nlspn_set_hparams(c->nl, hp, (hipStream_t)s));
 
     if (!c || !hp) return -1;
     if (hp->max_input_depth != c->hp.max_input_depth) c->drop_graphs();     // baked into kernel arguments
@@ -923,7 +927,7 @@ int ptta_set_hparams(ptta_handle c, const ptta_hparams* hp, ptta_stream s) {
 static long shape_numel(const int64_t* shape, int ndim) { long n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
 
 int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, const int64_t* shape, int ndim, ptta_stream s_) {
-    if (c && c->nl) return nlspn_load_weights(c->nl, name_, tensor, shape, ndim, (hipStream_t)s_);
+    NLFWD(nlspn_load_weights(c->nl, name_, tensor, shape, ndim, (hipStream_t)s_));
 
     if (!c || !name_ || !tensor) return -1;
     c->drop_graphs();
@@ -1011,7 +1015,7 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
 }
 
 int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp_avg, float* exp_avg_sq) {
-    if (c && c->nl) return nlspn_bind_adapted(c->nl, name_, param, exp_avg, exp_avg_sq);
+    NLFWD(nlspn_bind_adapted(c->nl, name_, param, exp_avg, exp_avg_sq));
 
     if (!c || !name_ || !param) return -1;
     c->drop_graphs();
@@ -1027,14 +1031,14 @@ int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp
 
 int ptta_adapted_count(ptta_handle c) { return c ? (c->nl ? nlspn_adapted_count(c->nl) : (int)c->adapted.size()) : 0; }
 const char* ptta_adapted_name(ptta_handle c, int index, int64_t* numel) {
-    if (c && c->nl) return nlspn_adapted_name(c->nl, index, numel);
+    NLFWD(nlspn_adapted_name(c->nl, index, numel));
 
     if (!c || index < 0 || index >= (int)c->adapted.size()) return nullptr;
     if (numel) *numel = c->adapted[index].n;
     return c->adapted[index].name.c_str();
 }
 int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity, ptta_stream s) {
-    if (c && c->nl) return nlspn_get_grad(c->nl, name, dst, capacity, (hipStream_t)s);
+    NLFWD(nlspn_get_grad(c->nl, name, dst, capacity, (hipStream_t)s));
 
     if (!c || !name || !dst) return -1;
     for (auto& ad : c->adapted)
@@ -1047,7 +1051,7 @@ int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity,
 }
 
 int ptta_set_grad(ptta_handle c, const char* name, const float* src, int64_t numel, ptta_stream s) {
-    if (c && c->nl) return nlspn_set_grad(c->nl, name, src, numel, (hipStream_t)s);
+    NLFWD(nlspn_set_grad(c->nl, name, src, numel, (hipStream_t)s));
     if (!c || !name || !src) return -1;
     for (auto& ad : c->adapted)
         if (ad.name == name) {
@@ -1059,15 +1063,14 @@ int ptta_set_grad(ptta_handle c, const char* name, const float* src, int64_t num
 }
 
 int ptta_set_adam_step(ptta_handle c, int step, ptta_stream s) {
-    if (c && c->nl) return nlspn_set_adam_step(c->nl, step, (hipStream_t)s);
+    NLFWD(nlspn_set_adam_step(c->nl, step, (hipStream_t)s));
 
     if (!c) return -1;
-    HIPCHK(hipMemcpyAsync(c->step_dev, &step, sizeof(int), hipMemcpyHostToDevice, (hipStream_t)s));
-    HIPCHK(hipStreamSynchronize((hipStream_t)s));
+    RUN(ptta_launch_set_int(c->step_dev, step, (hipStream_t)s));
     return 0;
 }
 int ptta_get_adam_step(ptta_handle c, int* step, ptta_stream s) {
-    if (c && c->nl) return nlspn_get_adam_step(c->nl, step, (hipStream_t)s);
+    NLFWD(nlspn_get_adam_step(c->nl, step, (hipStream_t)s));
 
     if (!c || !step) return -1;
     HIPCHK(hipMemcpyAsync(step, c->step_dev, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)s));
@@ -1078,7 +1081,7 @@ int ptta_get_adam_step(ptta_handle c, int* step, ptta_stream s) {
 int64_t ptta_embedding_rows(ptta_handle c) { return c ? (c->nl ? nlspn_embedding_rows(c->nl) : c->Rg) : 0; }
 
 int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, float* depth_out, float* emb_out, float* ref_out, ptta_stream s_) {
-    if (c && c->nl) return nlspn_forward_train(c->nl, image, sparse, depth_out, emb_out, ref_out, (hipStream_t)s_);
+    NLFWD(nlspn_forward_train(c->nl, image, sparse, depth_out, emb_out, ref_out, (hipStream_t)s_));
 
     if (!c || !image || !sparse) return -1;
     hipStream_t s = (hipStream_t)s_;
@@ -1093,7 +1096,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
 }
 
 int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, float* depth_out, ptta_stream s_) {
-    if (c && c->nl) return nlspn_forward_eval(c->nl, image, sparse, depth_out, (hipStream_t)s_);
+    NLFWD(nlspn_forward_eval(c->nl, image, sparse, depth_out, (hipStream_t)s_));
 
     if (!c || !image || !sparse || !depth_out) return -1;
     hipStream_t s = (hipStream_t)s_;
@@ -1106,14 +1109,13 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
 int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                       const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos,
                       float* loss_info_out, ptta_stream s_) {
-    if (c && c->nl) return nlspn_loss_forward(c->nl, loss_image, depth, sparse, validity, emb, ref, rows, w_sd, w_sm, w_cos, loss_info_out, (hipStream_t)s_);
+    NLFWD(nlspn_loss_forward(c->nl, loss_image, depth, sparse, validity, emb, ref, rows, w_sd, w_sm, w_cos, loss_info_out, (hipStream_t)s_));
 
     if (!c || !loss_image || !depth || !sparse || !validity || !loss_info_out) return -1;
     if (rows > c->Rg) return c->fail("rows exceeds the handle's embedding rows", -22);
     hipStream_t s = (hipStream_t)s_;
     const float w3[3] = {w_sd, w_sm, w_cos};
-    HIPCHK(hipMemcpyAsync(c->w3_tmp, w3, sizeof(w3), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));
+    RUN(ptta_launch_set_floats(c->w3_tmp, w3, 3, s));
     RUN(ptta_launch_loss_forward(depth, loss_image, sparse, validity, c->hp.max_input_depth, emb, ref, rows, 512, c->w3_tmp,
                                  c->N, c->H, c->W, c->loss_ws, loss_info_out, s));
     return 0;
@@ -1121,7 +1123,7 @@ int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth
 
 int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                        const float* emb, const float* ref, int64_t rows, float* gdepth, float* gref, ptta_stream s_) {
-    if (c && c->nl) return nlspn_loss_backward(c->nl, loss_image, depth, sparse, validity, emb, ref, rows, gdepth, gref, (hipStream_t)s_);
+    NLFWD(nlspn_loss_backward(c->nl, loss_image, depth, sparse, validity, emb, ref, rows, gdepth, gref, (hipStream_t)s_));
 
     if (!c || !loss_image || !depth || !sparse || !validity || !gdepth) return -1;
     RUN(ptta_launch_loss_backward(depth, loss_image, sparse, validity, c->hp.max_input_depth, emb, ref, rows, 512,
@@ -1130,7 +1132,7 @@ int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* dept
 }
 
 int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref, float* gw_out, float* gb_out, ptta_stream s_) {
-    if (c && c->nl) return grad_depth ? nlspn_backward(c->nl, grad_depth, grad_ref, (hipStream_t)s_) : -1;   // gradients: ptta_get_grad
+    NLFWD(grad_depth ? nlspn_backward(c->nl, grad_depth, grad_ref, (hipStream_t)s_) : -1);   // gradients: ptta_get_grad
 
     if (!c || !grad_depth) return -1;
     if (!c->fwd_valid) return c->fail("ptta_backward without a preceding ptta_forward_train", -3);
@@ -1221,6 +1223,8 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
             HIPCHK(hipGraphInstantiate(&c->gexec[key], g, nullptr, nullptr, 0));
         }
         HIPCHK(hipGraphLaunch(c->gexec[key], s));
+        if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_replay, s));
         c->fwd_valid = true;
     } else {
         RUN(step_body(c, image, loss_image, sparse, validity, s_));
@@ -1231,7 +1235,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
 }
 
 int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const float* stdv) {
-    if (c && c->nl) return nlspn_set_image_norm(c->nl, divisor, mean, stdv);
+    NLFWD(nlspn_set_image_norm(c->nl, divisor, mean, stdv));
 
     if (!c) return -1;
     if (!(divisor > 0.f)) return c->fail("ptta_set_image_norm: divisor must be positive", -22);
@@ -1326,7 +1330,7 @@ int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_by
 }
 
 int ptta_debug_tensor(ptta_handle c, const char* name, float* dst, int64_t capacity, int64_t* numel_host, ptta_stream s_) {
-    if (c && c->nl) return nlspn_debug_tensor(c->nl, name, dst, capacity, numel_host, (hipStream_t)s_);
+    NLFWD(nlspn_debug_tensor(c->nl, name, dst, capacity, numel_host, (hipStream_t)s_));
 
     if (!c || !name) return -1;
     auto it = c->dbg.find(name);

@@ -133,6 +133,8 @@ int ptta_launch_bn2d_bwd_finalize(const float* part, int nblocks, long R, const 
 int ptta_launch_adam(float* p, float* m, float* v, const float* g, long n, const float* hyper /*lr,b1,b2,eps,wd*/,
                      const int* step_dev, hipStream_t s);
 int ptta_launch_step_inc(int* step_dev, hipStream_t s);
+int ptta_launch_set_floats(float* dst, const float* host_src, int n /*<= 8*/, hipStream_t s);   // by kernel argument: no sync
+int ptta_launch_set_int(int* dst, int v, hipStream_t s);
 
 // ---- dcn.hip (modulated deformable convolution, NCHW fp32) -------------------------------------
 struct DcnArgs {

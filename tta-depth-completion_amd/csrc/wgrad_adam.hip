@@ -122,6 +122,23 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
 
 __global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
 
+// Small host constants travel as KERNEL ARGUMENTS (copied at launch), so setting hyper-parameters, loss weights or the
+// Adam step count never synchronises the stream and never reads host memory after the call returns.
+struct F8 { float v[8]; };
+__global__ void set_floats_kernel(float* dst, F8 src, int n) { if ((int)threadIdx.x < n) dst[threadIdx.x] = src.v[threadIdx.x]; }
+__global__ void set_int_kernel(int* dst, int v) { if (threadIdx.x == 0) *dst = v; }
+int ptta_launch_set_floats(float* dst, const float* host_src, int n, hipStream_t s) {
+    if (n < 0 || n > 8) return -22;
+    F8 f{};
+    for (int i = 0; i < n; ++i) f.v[i] = host_src[i];
+    hipLaunchKernelGGL(set_floats_kernel, dim3(1), dim3(64), 0, s, dst, f, n);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+int ptta_launch_set_int(int* dst, int v, hipStream_t s) {
+    hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(64), 0, s, dst, v);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 int ptta_launch_step_inc(int* step_dev, hipStream_t s) {
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, step_dev);
     PTTA_CHECK_LAUNCH();

@@ -38,10 +38,20 @@ def allreduce_adapted_grads(grads, group=None):
     return grads
 
 
-def shared_parameter_step(engine, image, sparse, validity=None, loss_image=None, group=None,
-                          w=(1.0, 1.0, 1.0)):
+_warned = []
+
+
+def shared_parameter_step(engine, image, sparse, validity=None, loss_image=None, group=None, w=None):
     """Batched TTA across ranks with shared adapted parameters: local forward / loss / backward
-    through the library, one gradient all-reduce, fused Adam with the reduced gradients."""
+    through the library, one gradient all-reduce, fused Adam with the reduced gradients.
+    `w` = (w_sparse_depth, w_smoothness, w_cos); default: the engine's hyper-parameters."""
+    if w is None:
+        w = (engine.hp.w_sparse_depth, engine.hp.w_smoothness, engine.hp.w_cos)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and not _warned:
+        import warnings
+        _warned.append(1)
+        warnings.warn('shared_parameter_step: BatchNorm statistics are per rank (the reference converts to SyncBatchNorm, '
+                      'src/tta_main.py:326); results differ from a single-process run on the global batch')
     depth, emb, ref = engine.forward_train(image, sparse)
     if validity is None:
         validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)

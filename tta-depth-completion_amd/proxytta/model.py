@@ -123,10 +123,37 @@ class MsgChnModel_Adapt(object):
             self.model._leaf(k, _init_tensor(k, s), not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
         self._engines = {}
         self._opt_state = {}
+        self._adam_t = 0              # torch.optim.Adam's state['step'], shared by every per-shape engine
+        self.sync_bn = False
         self.hparams = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                             w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0)
         self.total_time = self.train_time = self.eval_time = 0.0
         self.to(device)
+
+    def _clear_engines(self):
+        """Release every per-shape engine (workspaces are GBs at full size: do not wait for __del__)."""
+        engines, self._engines = getattr(self, '_engines', {}), {}
+        for eng in engines.values():
+            eng.close()
+
+    def _timed(self, fn, loss_type):
+        """The reference's wall-clock hook: `'time' in loss_type` brackets the network forward with
+        torch.cuda.synchronize() + time.time() and accumulates train_time / eval_time / total_time
+        (network_exp_msg_chn_adapt.py:338-340,407-414); read back by forward(loss_type='get_time')."""
+        if 'time' not in loss_type:
+            return fn()
+        import time
+        torch.cuda.synchronize()
+        t0 = time.time()
+        out = fn()
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        if self.training:
+            self.train_time += dt
+        else:
+            self.eval_time += dt
+        self.total_time += dt
+        return out
 
     # ---- reference surface -----------------------------------------------------------------
     def _prepare_head(self, mode=''):
@@ -142,7 +169,7 @@ class MsgChnModel_Adapt(object):
             if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
                 self.model._leaf(k, _init_tensor(k, s).to(self.device),
                                  not k.endswith(('running_mean', 'running_var', 'num_batches_tracked')))
-        self._engines.clear()
+        self._clear_engines()
 
     def parameters(self):
         return list(self.model.parameters())
@@ -167,24 +194,30 @@ class MsgChnModel_Adapt(object):
     def to(self, device):
         self.device = device
         self.model.to(device)
-        self._engines.clear()
+        self._clear_engines()
 
     def data_parallel(self):
         raise NotImplementedError('one process per GPU; use proxytta.distributed')
 
     def distributed_data_parallel(self, rank):
         """The reference wraps in DDP (msg_chn_model_adapt.py:476-480) and all-reduces every
-        gradient; here only the adapted-parameter gradients are reduced (proxytta.distributed)."""
+        gradient; here only the adapted-parameter gradients are reduced: drive the step through
+        proxytta.distributed.shared_parameter_step (one flat all-reduce), not through loss.backward()."""
         self.ddp_rank = rank
 
     def convert_syncbn(self, apex=False):
-        self.sync_bn = True        # statistics exchange is handled by proxytta.distributed
+        """SyncBatchNorm.convert_sync_batchnorm (msg_chn_model_adapt.py:547-556): from now on train-mode BatchNorm
+        statistics are those of the GLOBAL batch.  With one rank that is what the engine computes anyway; with
+        several ranks the statistics are exchanged inside proxytta.distributed.shared_parameter_step."""
+        self.sync_bn = True
 
     def restore_model(self, restore_path, optimizer=None):
         ckpt = torch.load(restore_path, map_location=self.device)
         self.load_state_dict(ckpt['net'])
         if optimizer is not None and 'optimizer' in ckpt:
             optimizer.load_state_dict(ckpt['optimizer'])
+            if getattr(self, '_optimizer', None) is optimizer:
+                self.bind_optimizer(optimizer)      # load_state_dict REPLACED exp_avg / exp_avg_sq / step: rebind them
         return optimizer, ckpt.get('train_step', 0)
 
     def save_model(self, checkpoint_path, step, optimizer, meanvar=None):
@@ -219,8 +252,17 @@ class MsgChnModel_Adapt(object):
                 eng.bind_adapted(name, p.data, st['exp_avg'], st['exp_avg_sq'])
             if getattr(self, '_image_norm', None) is not None:
                 eng.set_image_norm(self._image_norm)
+            eng._t = 0
             self._engines[key] = eng
         return eng
+
+    def _sync_adam_step(self, eng):
+        """Every (batch, height, width) has its own engine and device-side step counter; torch.optim.Adam has ONE
+        `step` per parameter, so the bias correction must continue across shape changes (last short batch of a
+        loader with drop_last=False, src/tta_main.py:281)."""
+        if eng._t != self._adam_t:
+            eng.set_adam_step(self._adam_t)
+            eng._t = self._adam_t
 
     def set_image_norm(self, normalized_image_range):
         """Take RAW images from now on: Transforms.normalize_images (src/transforms.py:668-710, called at
@@ -254,7 +296,8 @@ class MsgChnModel_Adapt(object):
                 st['exp_avg'] = torch.zeros_like(p.data)
                 st['exp_avg_sq'] = torch.zeros_like(p.data)
             self._opt_state[name] = st
-        self._engines.clear()
+            self._adam_t = int(float(st['step']))
+        self._clear_engines()
         self._optimizer = optimizer
 
     # ---- forward / loss -----------------------------------------------------------------------
@@ -263,13 +306,16 @@ class MsgChnModel_Adapt(object):
             raise NotImplementedError('loss_type %r is not on the accelerated path' % loss_type)
         if self.training and 'adapt' in loss_type:
             params = dict(self.model.named_parameters())
-            return _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted])
+            return self._timed(lambda: _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted]), loss_type)
         with torch.no_grad():
-            return self._engine(image).forward_eval(image, sparse_depth)
+            return self._timed(lambda: self._engine(image).forward_eval(image, sparse_depth), loss_type)
 
     def step(self, image, sparse_depth, validity_map=None, loss_image=None, want_depth=False):
         eng = self._engine(image)
+        self._sync_adam_step(eng)
         info, depth = eng.step(image, sparse_depth, validity_map, loss_image, want_depth)
+        self._adam_t += 1
+        eng._t = self._adam_t
         opt = getattr(self, '_optimizer', None)
         if opt is not None:
             for p in opt.param_groups[0]['params']:

@@ -51,6 +51,8 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
             self.model._leaf(k, self._init(k, s), not k.endswith(_BUFFERS))
         self._engines = {}
         self._opt_state = {}
+        self._adam_t = 0
+        self.sync_bn = False
         self.hparams = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0)
         self.total_time = self.train_time = self.eval_time = 0.0
         self.to(device)
@@ -75,7 +77,7 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
             if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
                 self.model._leaf(k, _init_tensor(k, s).to(self.device), not k.endswith(_BUFFERS))
         self.adapted = nlspn_adapted_names([k for k, _ in synth.nlspn_keys(mode)])
-        self._engines.clear()
+        self._clear_engines()
 
     def adapt_parameters(self, mode=None):
         if mode != 'meta_bn':
@@ -100,6 +102,7 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
                 eng.bind_adapted(name, p.data, st['exp_avg'], st['exp_avg_sq'])
             if getattr(self, '_image_norm', None) is not None:
                 eng.set_image_norm(self._image_norm)
+            eng._t = 0
             self._engines[key] = eng
         return eng
 
@@ -108,9 +111,9 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
             # (depth, emb, ref) with autograd edges to the 88 adapted tensors: loss.backward() runs ptta_loss_backward +
             # ptta_backward and fills their .grad (src/tta_main.py:610-632)
             params = dict(self.model.named_parameters())
-            return _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted])
+            return self._timed(lambda: _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted]), loss_type)
         with torch.no_grad():
-            return self._engine(image).forward_eval(image, sparse_depth)
+            return self._timed(lambda: self._engine(image).forward_eval(image, sparse_depth), loss_type)
 
     def save_model(self, checkpoint_path, step, optimizer, meanvar=None):
         ckpt = {'net': self.model.state_dict(), 'optimizer': optimizer.state_dict() if optimizer else {}, 'train_step': step}

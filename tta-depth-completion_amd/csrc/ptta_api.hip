@@ -76,6 +76,7 @@ struct ptta_ctx {
     float* w3_tmp = nullptr;     // device: loss weights of the standalone loss call
     int* step_dev = nullptr;
     bool fwd_valid = false;
+    bool proxy_rgb_valid = false;   // proxy half of c0..c4 holds the zero-image encoder outputs for the current weights
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
     struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double bytes = 0, macs = 0; };
     bool prof_on = false;
@@ -561,6 +562,49 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
 
 int heads_forward(ptta_ctx* c, hipStream_t s);
 
+// RGBEncoder.forward (:252-264) on `nb` frames written at batch offset `boff` of the c0..c4 buffers; frames with index
+// >= zero_from_b see a zero image (the proxy pass's torch.zeros_like(rgb), :511).
+int rgb_encoder(ptta_ctx* c, const float* image, int nb, int boff, int zero_from_b, hipStream_t s) {
+    const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
+    auto at = [&](void* base, int h, int w) { return (void*)((char*)base + (size_t)boff * h * w * 32 * c->es); };
+    auto e_raw = [](void* raw) { E e; e.raw = raw; return e; };
+#define CV(...) RUN(conv32(c, s, __VA_ARGS__))
+    {
+        const LIn& li = c->lin_in["rgb_encoder.init.0"];
+        ConvInArgs a; a.cin = 3; a.zero_from_b = zero_from_b;
+        for (int ch = 0; ch < 3; ++ch) {
+            a.pl[ch].p = image + (size_t)ch * H1 * W1; a.pl[ch].nb = c->Nn; a.pl[ch].bstride = 3L * H1 * W1;
+            if (c->img_norm.on && !c->dual) {            // dual-corner padding normalises while it pads
+                a.pl[ch].norm = 1; a.pl[ch].div = c->img_norm.div; a.pl[ch].mean = c->img_norm.mean[ch]; a.pl[ch].stdv = c->img_norm.stdv[ch];
+            }
+        }
+        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = at(c->c0a, H1, W1);
+        a.B = nb; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
+        RUN(ptta_launch_conv_in(a, s));
+    }
+    CV("rgb_encoder.init.2", false, CONV_S1, at(c->c0a, H1, W1), nb, nb, H1, W1, true, e_raw(at(c->c0, H1, W1)));
+    CV("rgb_encoder.enc1.1", false, CONV_S2, at(c->c0, H1, W1), nb, nb, H1, W1, true, e_raw(at(c->c1a, H2, W2)));
+    CV("rgb_encoder.enc1.3", false, CONV_S1, at(c->c1a, H2, W2), nb, nb, H2, W2, true, e_raw(at(c->c1, H2, W2)));
+    CV("rgb_encoder.enc2.1", false, CONV_S2, at(c->c1, H2, W2), nb, nb, H2, W2, true, e_raw(at(c->c2a, H4, W4)));
+    CV("rgb_encoder.enc2.3", false, CONV_S1, at(c->c2a, H4, W4), nb, nb, H4, W4, true, e_raw(at(c->c2, H4, W4)));
+    CV("rgb_encoder.enc3.1", false, CONV_S2, at(c->c2, H4, W4), nb, nb, H4, W4, true, e_raw(at(c->c3a, H8, W8)));
+    CV("rgb_encoder.enc3.3", false, CONV_S1, at(c->c3a, H8, W8), nb, nb, H8, W8, true, e_raw(at(c->c3, H8, W8)));
+    CV("rgb_encoder.enc4.1", false, CONV_S2, at(c->c3, H8, W8), nb, nb, H8, W8, true, e_raw(at(c->c4a, H16, W16)));
+    CV("rgb_encoder.enc4.3", false, CONV_S1, at(c->c4a, H16, W16), nb, nb, H16, W16, true, e_raw(at(c->c4, H16, W16)));
+#undef CV
+    return 0;
+}
+
+// The proxy pass feeds torch.zeros_like(rgb) through the frozen RGB encoder (:509-515): its c0..c4 depend only on the
+// encoder weights and the frame size, so they are computed ONCE per (handle, weights) into the proxy half of the
+// buffers instead of in every step (the eval forward only writes the real half).  Never runs inside a graph capture.
+int ensure_proxy_rgb(ptta_ctx* c, const float* any_image, hipStream_t s) {
+    if (c->proxy_rgb_valid) return 0;
+    RUN(rgb_encoder(c, any_image, c->Nn, c->Nn, 0, s));
+    c->proxy_rgb_valid = true;
+    return 0;
+}
+
 // One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half;
 // the MLP heads (which only need depth_encoder3's output) run on the auxiliary stream beside decoder 3.
 int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
@@ -570,28 +614,9 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
     auto e_raw = [](void* raw) { E e; e.raw = raw; return e; };
     // ---- RGB encoder (RGBEncoder.forward :252-264) + meta layer (:481-482) ----
-    {
-        const LIn& li = c->lin_in["rgb_encoder.init.0"];
-        ConvInArgs a; a.cin = 3; a.zero_from_b = Nn;
-        for (int ch = 0; ch < 3; ++ch) {
-            a.pl[ch].p = image + (size_t)ch * H1 * W1; a.pl[ch].nb = Nn; a.pl[ch].bstride = 3L * H1 * W1;
-            if (c->img_norm.on && !c->dual) {            // dual-corner padding normalises while it pads
-                a.pl[ch].norm = 1; a.pl[ch].div = c->img_norm.div; a.pl[ch].mean = c->img_norm.mean[ch]; a.pl[ch].stdv = c->img_norm.stdv[ch];
-            }
-        }
-        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->c0a;
-        a.B = B2; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
-        RUN(ptta_launch_conv_in(a, s));
-    }
-    CV("rgb_encoder.init.2", false, CONV_S1, c->c0a, B2, B2, H1, W1, true, e_raw(c->c0));
-    CV("rgb_encoder.enc1.1", false, CONV_S2, c->c0, B2, B2, H1, W1, true, e_raw(c->c1a));
-    CV("rgb_encoder.enc1.3", false, CONV_S1, c->c1a, B2, B2, H2, W2, true, e_raw(c->c1));
-    CV("rgb_encoder.enc2.1", false, CONV_S2, c->c1, B2, B2, H2, W2, true, e_raw(c->c2a));
-    CV("rgb_encoder.enc2.3", false, CONV_S1, c->c2a, B2, B2, H4, W4, true, e_raw(c->c2));
-    CV("rgb_encoder.enc3.1", false, CONV_S2, c->c2, B2, B2, H4, W4, true, e_raw(c->c3a));
-    CV("rgb_encoder.enc3.3", false, CONV_S1, c->c3a, B2, B2, H8, W8, true, e_raw(c->c3));
-    CV("rgb_encoder.enc4.1", false, CONV_S2, c->c3, B2, B2, H8, W8, true, e_raw(c->c4a));
-    CV("rgb_encoder.enc4.3", false, CONV_S1, c->c4a, B2, B2, H16, W16, true, e_raw(c->c4));
+    // train: the proxy half of c0..c4 (zero image through frozen weights) is a constant of the handle, computed once by
+    // ensure_proxy_rgb(); only the real frames go through the encoder here
+    RUN(rgb_encoder(c, image, Nn, 0, Nn, s));
     RUN(meta_forward(c, train, B2, s));
 
     // ---- stage 1/4 (:487-489): depth-only encoder shared by both passes ----
@@ -825,6 +850,7 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
         hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * c->Hp * c->Wp)), dim3(256), 0, s, sparse, c->sp_pad, c->N, 1, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
         img = c->img_pad; sp = c->sp_pad;
     }
+    if (train) RUN(ensure_proxy_rgb(c, img, s));
     RUN(ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
     if (c->meta_mode == PTTA_META_2LAYERS && c->m2.generic) {
         auto& m2 = c->m2;
@@ -931,6 +957,7 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
 
     if (!c || !name_ || !tensor) return -1;
     c->drop_graphs();
+    c->proxy_rgb_valid = false;
     hipStream_t s = (hipStream_t)s_;
     const std::string name(name_);
     const long numel = shape_numel(shape, ndim);
@@ -1211,6 +1238,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
         if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
         if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
         if (!c->gexec[key]) {
+            RUN(ensure_proxy_rgb(c, c->in_image, s));        // outside the capture: the graph holds the real-frame encoder only
             if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
             HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
             const int rc = step_body(c, c->in_image, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse,

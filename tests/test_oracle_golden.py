@@ -235,3 +235,67 @@ def test_nlspn_oracle_matches_reference_96x320(golden_dir):
     gn = np.array([float(r['grads'][k].double().norm()) for k in o.names])
     np.testing.assert_allclose(gn, g['s0/grad_norms'], rtol=1e-2, atol=1e-7)
     _check_map(o.forward_eval(image1, sparse), g, 's0/depth_eval', 5e-5)
+
+
+# ---- CostDCNet: oracle/costdcnet_oracle.py against tests/golden/costdcnet_*.npz ----------------------
+def costdc_frame(idx, h, w, n, density):
+    image01, sparse = synth.synthetic_frame(idx, h, w, n, density=density, dmin=0.3, dmax=7.5)
+    raw = np.floor(image01 * 255.0).astype(np.float32)
+    return raw, ((raw / np.float32(255.0) - _MEAN) / _STD).astype(np.float32), sparse
+
+
+@pytest.mark.parametrize('name', ['costdcnet_64x96', 'costdcnet_64x64_n2', 'costdcnet_72x100_pad'])
+def test_costdcnet_oracle_matches_reference(golden_dir, name):
+    """The reference (real code, MinkowskiEngine provided by oracle/minkowski_lite.py) vs the functional restatement:
+    depth, embeddings, loss terms, all 32 adapted gradients / parameters / Adam moments, every tracked BatchNorm buffer."""
+    from oracle import costdcnet_oracle as CO
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, max_depth = [float(x) for x in g['hp']]
+    torch.set_num_threads(4)
+    o = CO.CostDcnOracle(synth.formula_state_dict_costdcnet(), max_depth=max_depth, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd,
+                         w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
+    assert o.names == [str(x) for x in g['adapted_names']] and len(o.names) == 32
+    assert sum(o.P[k].numel() for k in o.names) == 5200
+    for s in range(steps):
+        raw, image1, sparse = [torch.from_numpy(x) for x in costdc_frame(s, h, w, n, float(g['density']))]
+        r = o.step(image1, sparse, loss_image=raw)
+        p = 's%d/' % s
+        assert rel_mae(r['depth'], g[p + 'depth_train']) < 1e-5
+        idx = g[p + 'row_idx']
+        assert tuple(r['emb'].shape) == tuple(g[p + 'emb_shape'])
+        assert rel_mae(r['emb'][idx], g[p + 'emb_rows']) < 1e-4 and rel_mae(r['ref'][idx], g[p + 'ref_rows']) < 1e-4
+        li = r['loss_info']
+        np.testing.assert_allclose([li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], g[p + 'loss_info'], rtol=2e-5,
+                                   atol=1e-8)      # the smoothness term is ~1e-5 on 0..255-scale random images
+        for i, k in enumerate(o.names):
+            assert rel_mae(r['grads'][k], g[p + 'grad/' + k]) < 1e-3, k
+            assert rel_mae(o.P[k].detach(), g[p + 'param/' + k]) < 1e-4, k
+            assert rel_mae(o.opt.m[i], g[p + 'exp_avg/' + k]) < 1e-3, k
+        for k in g.files:
+            if k.startswith(p + 'buf/'):
+                assert rel_mae(o.P[k[len(p) + 4:]], g[k]) < 1e-4, k
+        assert rel_mae(o.forward_eval(image1, sparse), g[p + 'depth_eval']) < 1e-5
+
+
+def test_minkowski_lite_matches_dense_convolution():
+    """The sparse-convolution stand-in on a FULLY occupied grid equals a dense zero-padded Conv3d with the kernel taps in
+    the documented order (first spatial axis fastest), and a stride-(1,2,2) convolution equals the dense strided one."""
+    import torch.nn.functional as F
+    from oracle import minkowski_lite as ML
+    g = torch.Generator().manual_seed(0)
+    D, H, W, Ci, Co = 4, 6, 8, 3, 5
+    x = torch.randn(1, Ci, D, H, W, generator=g)
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing='ij')
+    C = torch.stack([torch.zeros(D * H * W, dtype=torch.long), zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)], 1)
+    st = ML.SparseTensor(x[0].reshape(Ci, -1).t().contiguous(), C)
+    K = torch.randn(27, Ci, Co, generator=g)
+    # kernel index k = (d0+1) + 3*(d1+1) + 9*(d2+1)  ->  dense weight [co][ci][d0][d1][d2]
+    wd = K.reshape(3, 3, 3, Ci, Co).permute(4, 3, 2, 1, 0).contiguous()
+    out = ML.sparse_conv(st, K, 3, 1)
+    dense, _, _ = out.dense()
+    np.testing.assert_allclose(dense.numpy(), F.conv3d(x, wd, padding=1).numpy(), rtol=1e-4, atol=1e-5)
+    out2 = ML.sparse_conv(st, K, 3, (1, 2, 2))
+    d2, _, ts = out2.dense()
+    assert list(ts) == [1, 2, 2]
+    np.testing.assert_allclose(d2.numpy(), F.conv3d(x, wd, padding=1, stride=(1, 2, 2)).numpy(), rtol=1e-4, atol=1e-5)

@@ -18,6 +18,7 @@
 // Three geometries share the body: CONV_S1 (stride 1, pad 1), CONV_S2 (stride 2, pad 1) and
 // CONV_T2 (transposed, stride 2, pad 1, output_padding 1; a tile = 32 outputs of one x-parity so
 // that the active taps are wave-uniform).
+#include <cstdlib>
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
                 epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
             }
         }
-        __syncthreads();
+        lds_barrier();          // LDS reuse only: do not wait for this tile's stores (nor the prefetch) to drain
     }
 }
 
@@ -521,7 +522,8 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     if constexpr (sizeof(T) == 4 && MODE == CONV_S1) if (!a.naive && a.x3) {
         p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
         const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
-        const int blocks = (int)(tiles > 512 ? 512 : tiles);     // 2 resident blocks per CU, persistent
+        static const int cap = getenv("PTTA_S1_BLOCKS") ? atoi(getenv("PTTA_S1_BLOCKS")) : 512;
+        const int blocks = (int)(tiles > cap ? cap : tiles);     // 2 resident blocks per CU, persistent
         const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
         if (a.relu_in) launch_x3<true>(pf, flags, blocks, s); else launch_x3<false>(pf, flags, blocks, s);
         PTTA_CHECK_LAUNCH();

@@ -418,8 +418,9 @@ __global__ __launch_bounds__(512, 2) void gemm_x3_wide_kernel(GemmX3P q) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();          // LDS hand-over only: slice k+2's global loads stay in flight across the barrier
     }
+    __syncthreads();
 
 #pragma unroll
     for (int b = 0; b < TN; ++b) {

@@ -174,3 +174,77 @@ def synthetic_frame(frame_idx, height, width, n=1, density=0.05, dmin=1.0, dmax=
     sparse = np.where(keep, depth, 0.0)
     return (image.reshape(n, 3, height, width).astype(np.float32),
             sparse.reshape(n, 1, height, width).astype(np.float32))
+
+
+# ---- CostDCNet ----------------------------------------------------------------------------------
+def _me_bn_keys(prefix, ch):
+    return _bn_keys(prefix + '.bn', ch)           # MinkowskiBatchNorm wraps an nn.BatchNorm1d called `bn`
+
+
+def _p3d_keys(prefix, cin, cout):
+    """P3D block (external_src/costdcnet/models/unet3d.py:66-84): 1x3x3 conv - BN3d - ELU - 3x1x1 conv - BN3d - ELU."""
+    return ([(prefix + '.conv1.weight', (cout, cin, 1, 3, 3))] + _bn_keys(prefix + '.bn1', cout) +
+            [(prefix + '.conv2.weight', (cout, cout, 3, 1, 1))] + _bn_keys(prefix + '.bn2', cout))
+
+
+def costdcnet_keys(prepare_mode='meta_selfsup_seq_1layer_ema'):
+    """Ordered (name, shape) list of the CostDCNet TTA network's state_dict: CostDCNet.__init__
+    (external_src/costdcnet/CostDCNet_adapt.py:13-23: Encoder2D(4,16), Encoder3D(1,16,planes=(32,48,64)),
+    UNet3D(32,16,f_maps=[32,48,64,80])) plus the heads / meta layer of _prepare_head (:426-496, 'selfsup'+'ema'+'1layer')."""
+    if '1layer' not in prepare_mode:
+        raise NotImplementedError('CostDCNet key table covers the canonical 1layer meta layer only')
+    keys = [('enc2d.conv1.weight', (64, 4, 3, 3)), ('enc2d.conv1.bias', (64,))] + _bn_keys('enc2d.norm1', 64)
+    inpl = 64
+    for li, (planes, stride) in enumerate([(64, 1), (96, 2), (128, 2)]):
+        for b in range(2):
+            pre = 'enc2d.layer%d.%d' % (li + 1, b)
+            s = stride if b == 0 else 1
+            keys += [(pre + '.conv1.weight', (planes, inpl, 3, 3)), (pre + '.conv1.bias', (planes,)),
+                     (pre + '.conv2.weight', (planes, planes, 3, 3)), (pre + '.conv2.bias', (planes,))]
+            keys += _bn_keys(pre + '.norm1', planes) + _bn_keys(pre + '.norm2', planes)
+            if s != 1:          # norm3 is registered twice (attribute + inside `downsample`): both key sets exist, same tensors
+                keys += _bn_keys(pre + '.norm3', planes)
+                keys += [(pre + '.downsample.0.weight', (planes, inpl, 1, 1)), (pre + '.downsample.0.bias', (planes,))]
+                keys += _bn_keys(pre + '.downsample.1', planes)
+            inpl = planes
+    keys += [('enc2d.conv2.weight', (16, 128, 1, 1)), ('enc2d.conv2.bias', (16,))]
+    # sparse encoder (models/encoder3d.py:33-103); MinkowskiConvolution kernels are (27, Cin, Cout), no bias
+    keys += [('enc3d.conv1.kernel', (27, 1, 32))] + _me_bn_keys('enc3d.bn0', 32)
+    inpl = 32
+    for bi, planes in enumerate((32, 48, 64)):
+        pre = 'enc3d.block%d.0' % (bi + 1)
+        keys += [(pre + '.conv1.kernel', (27, inpl, planes))] + _me_bn_keys(pre + '.norm1', planes)
+        keys += [(pre + '.conv2.kernel', (27, planes, planes))] + _me_bn_keys(pre + '.norm2', planes)
+        if bi > 0:
+            keys += [(pre + '.downsample.0.kernel', (1, inpl, planes))] + _me_bn_keys(pre + '.downsample.1', planes)
+        inpl = planes
+    keys += [('enc3d.conv2.kernel', (64, 16))]
+    # UNet3D (models/unet3d.py:7-47): DoubleConv = two P3D blocks
+    f = (32, 48, 64, 80)
+    keys += _p3d_keys('unet3d.inc.double_conv.0', 32, f[0]) + _p3d_keys('unet3d.inc.double_conv.1', f[0], f[0])
+    for i in range(3):          # Down: MaxPool3d(2) + DoubleConv(in, out, mid=in)
+        pre = 'unet3d.down%d.maxpool_conv.1.double_conv' % (i + 1)
+        keys += _p3d_keys(pre + '.0', f[i], f[i]) + _p3d_keys(pre + '.1', f[i], f[i + 1])
+    for name, cin, cout in (('up2', f[3] + f[2], f[2]), ('up3', f[2] + f[1], f[1]), ('up4', f[1] + f[0], f[0])):
+        pre = 'unet3d.%s.conv.double_conv' % name       # Up: DoubleConv(in, out, mid=out)
+        keys += _p3d_keys(pre + '.0', cin, cout) + _p3d_keys(pre + '.1', cout, cout)
+    keys += [('unet3d.classif0.weight', (16, 32, 1, 1, 1)), ('unet3d.classif0.bias', (16,))]
+    keys += _mlp_keys('proj', 160, 512, 512) + _mlp_keys('proj_t', 160, 512, 512) + _mlp_keys('pred', 512, 512, 512)
+    keys += [('conv1_rgb_meta.weight', (16, 16, 3, 3)), ('conv1_rgb_meta.bias', (16,))]
+    return keys
+
+
+def formula_state_dict_costdcnet(prepare_mode='meta_selfsup_seq_1layer_ema', gain=1.0):
+    sd = {k: formula_tensor(k, s, gain) for k, s in costdcnet_keys(prepare_mode)}
+    for k in list(sd):          # the reference holds ONE BatchNorm behind both names
+        if '.downsample.1.' in k and k.startswith('enc2d.'):
+            sd[k] = sd[k.replace('.downsample.1.', '.norm3.')]
+        if k.endswith('.kernel'):       # (K, Cin, Cout): fan-in = K * Cin, not formula_tensor's prod(shape[1:])
+            s = sd[k].shape
+            fan_in = s[0] * s[1] if len(s) == 3 else s[0]
+            u = hash_uniform(k, sd[k].size) * 2.0 - 1.0
+            sd[k] = (u * np.sqrt(3.0) * gain * np.sqrt(2.0 / fan_in)).reshape(s).astype(np.float32)
+    # sparse inputs are residuals in [-0.5, 0.5] plane units on a handful of voxels: lift the first sparse layer so the
+    # 3-D branch carries signal comparable to the image branch (a trained network does)
+    sd['enc3d.conv1.kernel'] = (sd['enc3d.conv1.kernel'] * 4.0).astype(np.float32)
+    return sd

@@ -12,12 +12,27 @@
 
 #define GBN_BLOCKS 1024
 
+// activation gradient from the SAVED OUTPUT yv: relu / leaky-relu by sign, ELU: 1 for y > 0, y + 1 (= e^x) otherwise
+__device__ __forceinline__ float gbn_act_grad(float gv, float yv, int act) {
+    if (act == GACT_RELU) return yv > 0.f ? gv : 0.f;
+    if (act == GACT_LRELU) return yv > 0.f ? gv : 0.2f * gv;
+    if (act == GACT_ELU) return yv > 0.f ? gv : gv * (yv + 1.f);
+    return gv;
+}
+__device__ __forceinline__ float gbn_act(float v, int act) {
+    if (act == GACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == GACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    if (act == GACT_ELU) return v > 0.f ? v : expm1f(v);
+    return v;
+}
+
 // partial sums over the pixels of one pass: MODE 0: {sum x, sum x^2}; MODE 1: {sum g1, sum g1*xhat}
 // part layout [pass][block][2][C]
 template <int MODE>
 __global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView y, int npass, int act, int res_relu,
                                                         const float* __restrict__ mean, const float* __restrict__ inv,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, const float* __restrict__ fscale = nullptr,
+                                                        const float* __restrict__ fshift = nullptr) {
     extern __shared__ float red[];                       // [nsub][2][CT]
     const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
     const int lc = threadIdx.x % CT, sub = threadIdx.x / CT;
@@ -45,8 +60,10 @@ __global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView 
                 else {
                     float gv = g.p[(pix0 + p) * g.ld + c];
                     const float yv = y.p[(pix0 + p) * y.ld + c];
-                    if (res_relu || act == GACT_RELU) gv = yv > 0.f ? gv : 0.f;
-                    else if (act == GACT_LRELU) gv = yv > 0.f ? gv : 0.2f * gv;
+                    if (res_relu) {
+                        gv = yv > 0.f ? gv : 0.f;
+                        if (fscale) gv = fmaf(xv, fscale[c], fshift[c]) > 0.f ? gv : 0.f;      // inner ReLU of relu(relu(bn x) + res)
+                    } else gv = gbn_act_grad(gv, yv, act);
                     s1 += gv; s2 += gv * (xv - mu) * iv;
                 }
             }
@@ -92,7 +109,8 @@ __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* __restri
 
 // y = act(x*scale+shift) ; with res: y = relu(x*scale+shift + res)   (BasicBlock.forward, nlspnmodel_adapt.py:98-116)
 // four channels per thread (every channel count and row stride on this path is a multiple of 4)
-__global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act, const float* __restrict__ st, int res_relu = 1) {
+__global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act, const float* __restrict__ st, int res_relu = 1,
+                                 int act_first = 0) {
     const int C4 = x.C >> 2, n = npass * x.C;
     const long total = (long)x.B * x.H * x.W * C4;
     const long ppp = (long)(x.B / npass) * x.H * x.W;
@@ -104,17 +122,18 @@ __global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act
         float v[4] = {fmaf(xv.x, sc.x, sh.x), fmaf(xv.y, sc.y, sh.y), fmaf(xv.z, sc.z, sh.z), fmaf(xv.w, sc.w, sh.w)};
         if (res.p) {
             const float4 r = *(const float4*)(res.p + pix * res.ld + c);
+            if (act_first) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = gbn_act(v[k], act);
+            }
             v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
             if (res_relu) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
             }
-        } else if (act == GACT_RELU) {
+        } else if (act != GACT_NONE) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
-        } else if (act == GACT_LRELU) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : 0.2f * v[k];
+            for (int k = 0; k < 4; ++k) v[k] = gbn_act(v[k], act);
         }
         *(float4*)(y.p + pix * y.ld + c) = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -123,7 +142,7 @@ __global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act
 // fused_blocks > 0: `part` was already filled by the producing convolution's epilogue ([pass][fused_blocks][2][C]), skip the
 // statistics pass
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
-                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks) {
+                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks, int act_first) {
     const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
     const size_t lds = (size_t)nsub * 2 * CT * sizeof(float);
     const long R = (long)(x.B / npass) * x.H * x.W;
@@ -134,19 +153,20 @@ int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, in
     if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
     const long total = (long)x.B * x.H * x.W * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
-    hipLaunchKernelGGL(gbn_apply_kernel, dim3((int)ab), dim3(256), 0, s, x, res, y, npass, act, st);
+    hipLaunchKernelGGL(gbn_apply_kernel, dim3((int)ab), dim3(256), 0, s, x, res, y, npass, act, st, 1, act_first);
     PTTA_CHECK_LAUNCH();
     return 0;
 }
 int ptta_gbn_part_floats(int C, int npass) { return npass * GBN_BLOCKS * 2 * C; }
 
 // normalise (+activation) (+residual, optionally without the BasicBlock's ReLU) from finalized statistics st = [4][npass][C]
-int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int npass, int act, const float* st, int res_relu, hipStream_t s) {
+int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int npass, int act, const float* st, int res_relu, hipStream_t s,
+                          int act_first) {
     const int C = x.C;
     if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
     const long total = (long)x.B * x.H * x.W * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
-    hipLaunchKernelGGL(gbn_apply_kernel, dim3((int)ab), dim3(256), 0, s, x, res, y, npass, act, st, res_relu);
+    hipLaunchKernelGGL(gbn_apply_kernel, dim3((int)ab), dim3(256), 0, s, x, res, y, npass, act, st, res_relu, act_first);
     PTTA_CHECK_LAUNCH();
     return 0;
 }
@@ -166,7 +186,8 @@ __global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(const float* __re
 
 // gx (+)= gscale*(g1 - c1 - xhat*c2) ; gres (+)= g1 (residual branch of a BasicBlock); four channels per thread
 __global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView gres, int act, int res_relu, int acc_gx, int acc_gres,
-                                     const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ bw) {
+                                     const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ bw,
+                                     const float* __restrict__ fscale = nullptr, const float* __restrict__ fshift = nullptr) {
     const int C = x.C, C4 = C >> 2;
     const long total = (long)g.B * g.H * g.W * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -179,13 +200,15 @@ __global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView 
         const float yv[4] = {y4.x, y4.y, y4.z, y4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
         const float m_[4] = {mu.x, mu.y, mu.z, mu.w}, i_[4] = {iv.x, iv.y, iv.z, iv.w};
         const float s_[4] = {b0.x, b0.y, b0.z, b0.w}, c1[4] = {b1.x, b1.y, b1.z, b1.w}, c2[4] = {b2.x, b2.y, b2.z, b2.w};
-        float d[4];
+        float d[4], gb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (res_relu || act == GACT_RELU) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
-            else if (act == GACT_LRELU) gv[k] = yv[k] > 0.f ? gv[k] : 0.2f * gv[k];
+            if (res_relu) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;                      // gradient of the block's final ReLU (goes to the residual too)
+            else gv[k] = gbn_act_grad(gv[k], yv[k], act);
+            gb[k] = gv[k];
+            if (res_relu && fscale) gb[k] = fmaf(xv[k], fscale[c + k], fshift[c + k]) > 0.f ? gv[k] : 0.f;   // inner ReLU of relu(relu(bn x) + res)
             const float xh = (xv[k] - m_[k]) * i_[k];
-            d[k] = s_[k] * (gv[k] - c1[k] - xh * c2[k]);
+            d[k] = s_[k] * (gb[k] - c1[k] - xh * c2[k]);
         }
         float4* o = (float4*)(gx.p + pix * gx.ld + c);
         if (acc_gx) { const float4 t = *o; d[0] += t.x; d[1] += t.y; d[2] += t.z; d[3] += t.w; }
@@ -202,7 +225,7 @@ __global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView 
 // st: forward statistics [4][npass][C] (pass 0 is used).  dgamma/dbeta may be null (frozen affine parameters).
 int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, const GView& gx, const GView& gres, int npass, int act,
                              int res_relu, int acc_gx, int acc_gres, const float* gamma, const float* st, float* part, float* bw, float* dgamma,
-                             float* dbeta, hipStream_t s) {
+                             float* dbeta, hipStream_t s, int act_first) {
     const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
     const size_t lds = (size_t)nsub * 2 * CT * sizeof(float);
     GView x0 = x; x0.B = g.B;
@@ -210,12 +233,56 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
     const long R = (long)g.B * g.H * g.W;
     int blocks = (int)((R + nsub - 1) / nsub); if (blocks > GBN_BLOCKS) blocks = GBN_BLOCKS; if (blocks < 1) blocks = 1;
     const float* mean = st; const float* inv = st + (long)npass * C;
-    hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part);
+    // act_first (CostDCNet's ResBlock, encoder2d.py:44-52): the inner ReLU's mask is recomputed from x and the forward affine
+    const float* fscale = (act_first && res_relu) ? st + 2L * npass * C : nullptr;
+    const float* fshift = (act_first && res_relu) ? st + 3L * npass * C : nullptr;
+    hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, fscale, fshift);
     hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, C, R, gamma, inv, dgamma, dbeta, bw);
     if ((C & 3) || (x.ld & 3) || (g.ld & 3) || (y.ld & 3) || (gx.ld & 3) || (gres.p && (gres.ld & 3))) return -22;
     const long total = R * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
-    hipLaunchKernelGGL(gbn_bwd_apply_kernel, dim3((int)ab), dim3(256), 0, s, x0, g, y0, gx, gres, act, res_relu, acc_gx, acc_gres, mean, inv, bw);
+    hipLaunchKernelGGL(gbn_bwd_apply_kernel, dim3((int)ab), dim3(256), 0, s, x0, g, y0, gx, gres, act, res_relu, acc_gx, acc_gres, mean, inv, bw,
+                       fscale, fshift);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ---- tracked BatchNorm (BatchNorm3d / BatchNorm1d / MinkowskiBatchNorm of CostDCNet keep their running statistics) --------
+// train: after the forward finalize, running = (1 - m) * running + m * batch (unbiased variance), one update per pass in
+// order (real frames first, then the proxy pass, as the reference's two forward calls), `repeats` times each when the
+// reference runs the layer several times on the same input; num_batches_tracked += npass * repeats.
+__global__ void gbn_running_update_kernel(const float* __restrict__ st, int npass, int C, long R, float momentum, float eps,
+                                          float* rm, float* rv, long long* nbt, int repeats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += (long long)npass * repeats;
+    if (c >= C) return;
+    float m = rm[c], v = rv[c];
+    for (int pass = 0; pass < npass; ++pass) {
+        const float mu = st[pass * C + c], iv = st[(long)npass * C + pass * C + c];
+        double var = 1.0 / ((double)iv * (double)iv) - (double)eps;
+        if (var < 0.0) var = 0.0;
+        const float unb = (float)(R > 1 ? var * (double)R / (double)(R - 1) : var);
+        for (int k = 0; k < repeats; ++k) { m = (1.f - momentum) * m + momentum * mu; v = (1.f - momentum) * v + momentum * unb; }
+    }
+    rm[c] = m; rv[c] = v;
+}
+int ptta_launch_gbn_running_update(const float* st, int npass, int C, long R, float momentum, float eps, float* rm, float* rv, long long* nbt,
+                                   int repeats, hipStream_t s) {
+    hipLaunchKernelGGL(gbn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, s, st, npass, C, R, momentum, eps, rm, rv, nbt, repeats);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+// eval: st (npass = 1 layout [mean, inv, scale, shift][C]) from the running statistics
+__global__ void gbn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                       const float* __restrict__ rv, float eps, int C, float* __restrict__ st) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float iv = 1.f / sqrtf(rv[c] + eps), sc = gamma[c] * iv;
+    st[c] = rm[c]; st[C + c] = iv; st[2 * C + c] = sc; st[3 * C + c] = beta[c] - rm[c] * sc;
+}
+int ptta_launch_gbn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* st, hipStream_t s) {
+    hipLaunchKernelGGL(gbn_eval_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, s, gamma, beta, rm, rv, eps, C, st);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,361 @@
+// Generic NHWC layer-graph engine of libptta_hip, shared by the backbones whose adapted set crosses the whole network
+// (NLSPN: nlspn_api.hip, CostDCNet: costdc_api.hip).
+//
+// A network is a flat op list built once per handle ("program"):
+//   CONV  one or two channel-concatenated NHWC sources (torch.cat never materialises), 3x3 / 1x1, stride 1 / 2 or stride-2
+//         transposed, optional fused activation; matrix-core (bf16x3) kernels of gconv_mfma.hip, direct fp32 kernels of
+//         gconv.hip for odd channel counts and for PTTA_CONV_IMPL=naive validation;
+//   BN    batch-statistics normalisation (+activation, + residual add), adapted or frozen affine parameters, optionally
+//         TRACKED (running statistics updated in train mode, used in eval mode: BatchNorm3d / BatchNorm1d of CostDCNet);
+//   FUNC  backbone-specific kernels (pooling, resampling, fusion ...) as forward / backward closures.
+// The grad pass and the no-grad proxy pass (zero image) of a training step are batched as [real | proxy] with separate
+// batch statistics per pass.  The backward sweep is the op list in reverse: every data gradient is again a CONV with
+// re-packed weights, BatchNorm gradients for gamma/beta, weight gradients for adapted convolutions, then Adam on device.
+// The first writer of each gradient buffer overwrites, later ones accumulate (decided at build time): no gradient memsets.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ptta.h"
+#include "ptta_common.h"
+#include "ptta_kernels.h"
+
+int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s);
+long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co);
+int ptta_launch_gbn_running_update(const float* st, int npass, int C, long R, float momentum, float eps, float* rm, float* rv, long long* nbt,
+                                   int repeats, hipStream_t s);
+int ptta_launch_gbn_eval_affine(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C, float* st, hipStream_t s);
+
+#define NCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_), -100 - (int)e_); } while (0)
+#define NRUN(x) do { int r_ = (x); if (r_ != 0) return fail(std::string(#x) + " failed", r_ < 0 ? r_ : -r_); } while (0)
+
+namespace gnet {
+
+enum { W_BOTH = 0, W_GRAD = 1, W_PROXY = 2 };
+enum { K_CONV = 0, K_BN = 1, K_FUNC = 2 };
+const float BN_EPS = 1e-5f;
+
+struct Tn {
+    std::string name;
+    float *p = nullptr, *g = nullptr;
+    int items = 0, per = 0, H = 0, W = 0, C = 0, ld = 0;      // per = items of ONE pass (frames, or frames x depth planes)
+    bool need_grad = false;
+};
+
+struct GConvW {            // convolution weights, packed at load time (frozen) or at every forward (adapted)
+    float *wf = nullptr, *wb = nullptr, *bias = nullptr;
+    int Ci = 0, Co = 0, k = 3, stride = 1, transposed = 0;
+    int C0 = 0, C1 = 0;                                   // source split of the input channels (torch.cat order)
+    int Co_pad = 0;
+    int Ci_real = 0;                                      // > 0: the state_dict tensor has fewer input channels than the zero-padded activation
+    int vcol = 0;                                         // 3x1x1 Conv3d stored as a 3x3 filter with only the middle column set
+    float* gpad = nullptr;                                // zero-padded copy of the output gradient (Co_pad channels)
+    bf16_t *ff_hi = nullptr, *ff_lo = nullptr, *fb_hi = nullptr, *fb_lo = nullptr;     // bf16x3 MFMA fragments (forward / data gradient)
+    bool mf = false, mb = false;                          // matrix-core kernel usable for forward / data gradient
+    bool loaded = false, has_bias = false;
+    long gpad_pix = 0;
+};
+
+struct Op {
+    int kind = K_CONV;
+    bool train_only = false, bwd = true;
+    // conv
+    int nsrc = 1, x[2] = {-1, -1}, c0[2] = {0, 0}, xw[2] = {W_BOTH, W_BOTH};
+    int y = -1, yw = W_BOTH;
+    int k = 3, stride = 1, transposed = 0, act = GACT_NONE;
+    int rH = 0, rW = 0;                 // > 0: every tensor of this op is re-viewed as images of rH x rW (same memory):
+                                        // a 3x1x1 Conv3d over [B][D][H][W][C] is a vertical 3-tap conv over [B][D][H*W][C]
+    std::string wname;
+    int ad_w = -1, ad_b = -1;           // adapted (bound) weight / bias
+    bool first_x[2] = {true, true};
+    // bn
+    int res = -1;
+    std::string bname;
+    int ad_g = -1, ad_beta = -1;
+    float* st = nullptr;
+    float* part = nullptr;            // this BatchNorm's partial-statistics buffer
+    int fused_from = -1;              // index of the producing CONV op whose epilogue fills `part` (stride-1 matrix-core kernel)
+    int stat_to = -1;                 // (CONV) index of the BN op that consumes this conv's fused statistics
+    bool first_raw = true, first_res = true;
+    bool tracked = false;             // running statistics kept: updated in train mode (momentum 0.1), used in eval mode
+    bool act_first = false;           // with a residual: y = relu(act(bn(x)) + res) instead of relu(bn(x) + res)
+    int stat_repeats = 1;             // the reference runs this layer `repeats` times per training forward on the same input
+    float *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
+    // func
+    std::function<int(bool, hipStream_t)> ffwd;
+    std::function<int(hipStream_t)> fbwd;
+};
+
+struct Adapted { std::string name; long n = 0, goff = 0; float *p = nullptr, *m = nullptr, *v = nullptr; };
+
+__global__ void gnet_pad_channels_kernel(const float* __restrict__ src, int lds_, int C, float* __restrict__ dst, int Cp, long npix);
+inline int nb(long total) { long b = (total + 255) / 256; if (b > 16384) b = 16384; if (b < 1) b = 1; return (int)b; }
+
+}  // namespace gnet
+
+struct GNet {
+    typedef gnet::Tn Tn; typedef gnet::Op Op; typedef gnet::GConvW GConvW; typedef gnet::Adapted Adapted;
+    int N = 1, H = 0, W = 0;            // network batch / size (after dual-corner padding, if any)
+    int Nu = 1, Hu = 0, Wu = 0;         // caller's batch / size
+    ptta_hparams hp{};
+    std::string err;
+    std::vector<void*> allocs;
+    bool oom = false;
+    std::vector<Tn> T;
+    std::map<std::string, int> tid;
+    std::vector<Op> ops;
+    std::map<std::string, GConvW> convs;
+    std::map<std::string, std::pair<float*, float*>> frozen_bn;     // BatchNorm gamma/beta that are not adapted
+    std::vector<Adapted> adapted;
+    std::map<std::string, int> aid;
+    float* gall = nullptr; long gall_n = 0;
+    float* w3_tmp = nullptr;
+    float *hyper = nullptr, *loss_ws = nullptr, *loss_info = nullptr, *validity_tmp = nullptr;
+    int* step_dev = nullptr;
+    float *bn_part = nullptr, *bn_bw = nullptr, *wg_part = nullptr;
+    float *depth = nullptr, *gdepth = nullptr;     // (Nu,1,Hu,Wu): network output / its gradient
+    int t_emb = -1, t_ref = -1;
+    int naive = 0;
+    int norm_on = 0; float norm_div = 1.f, norm_mean[3] = {0, 0, 0}, norm_std[3] = {1, 1, 1};
+    bool fwd_valid = false;
+    int max_bn_C = 16;
+
+    virtual ~GNet() { for (void* p : allocs) if (p) (void)hipFree(p); }
+    // ---- backbone-specific ------------------------------------------------------------------------------------------
+    virtual int forward(const float* image, const float* sparse, bool train, hipStream_t s) = 0;    // fills `depth`
+    virtual int backward(hipStream_t s) = 0;                    // consumes gdepth and T[t_ref].g
+    virtual long rows() const = 0;
+    virtual int emb_dim() const = 0;
+    virtual int load_extra(const std::string& name, const float* src, const int64_t* shape, int ndim, hipStream_t s) { (void)src; (void)shape; (void)ndim; (void)s; return fail("unknown state_dict key " + name, -2); }
+    virtual int debug_extra(const std::string& nm, const float** src, long* n) { (void)src; (void)n; return fail("unknown debug tensor " + nm, -2); }
+
+    int fail(const std::string& m, int code) { err = m; return code; }
+    void* dalloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { oom = true; return nullptr; }
+        allocs.push_back(p);
+        if (hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess) { oom = true; return nullptr; }
+        return p;
+    }
+    float* falloc(size_t n) { return (float*)dalloc(n * sizeof(float)); }
+
+    // items: allocated items (2*per for tensors that hold both passes); per: items of one pass (default N)
+    int tensor(const std::string& name, int items, int h, int w, int c, bool need_grad, int per = 0) {
+        Tn t; t.name = name; t.items = items; t.per = per > 0 ? per : N; t.H = h; t.W = w; t.C = c; t.ld = c; t.need_grad = need_grad;
+        t.p = falloc((size_t)items * h * w * c);
+        if (need_grad) t.g = falloc((size_t)t.per * h * w * c);
+        T.push_back(t); tid[name] = (int)T.size() - 1;
+        return (int)T.size() - 1;
+    }
+    int slice(const std::string& name, int parent, int c_off, int c) {
+        Tn t = T[parent]; t.name = name; t.C = c; t.p = T[parent].p + c_off; t.g = T[parent].g ? T[parent].g + c_off : nullptr;
+        T.push_back(t); tid[name] = (int)T.size() - 1;
+        return (int)T.size() - 1;
+    }
+    GView view(int t, int which, bool train, bool grad = false) const {
+        const Tn& tn = T[t];
+        GView v; v.H = tn.H; v.W = tn.W; v.C = tn.C; v.ld = tn.ld;
+        v.B = (which == gnet::W_BOTH && train) ? 2 * tn.per : tn.per;
+        v.p = (grad ? tn.g : tn.p);
+        if (which == gnet::W_PROXY && !grad) v.p += (size_t)tn.per * tn.H * tn.W * tn.ld;
+        return v;
+    }
+    static void review(GView& v, int rH, int rW) {              // same memory, images of rH x rW
+        if (rH <= 0) return;
+        const long pix = (long)v.B * v.H * v.W;
+        v.B = (int)(pix / ((long)rH * rW)); v.H = rH; v.W = rW;
+    }
+
+    // ---- program construction --------------------------------------------------------------------------------------
+    int add_adapted(const std::string& name, long n) {
+        Adapted a; a.name = name; a.n = n; a.goff = gall_n; gall_n += n;
+        adapted.push_back(a); aid[name] = (int)adapted.size() - 1;
+        return (int)adapted.size() - 1;
+    }
+    Op& conv(const std::string& wname, int x0, int x1, int y, int k, int stride, int transposed, int act, int xw, int yw,
+             bool train_only = false, bool bwd = true) {
+        using namespace gnet;
+        Op o; o.kind = K_CONV; o.wname = wname; o.x[0] = x0; o.x[1] = x1; o.nsrc = x1 >= 0 ? 2 : 1; o.c0[0] = 0; o.c0[1] = x1 >= 0 ? T[x0].C : 0;
+        o.y = y; o.k = k; o.stride = stride; o.transposed = transposed; o.act = act; o.xw[0] = o.xw[1] = xw; o.yw = yw;
+        o.train_only = train_only; o.bwd = bwd;
+        GConvW& cw = convs[wname];
+        cw.Ci = T[x0].C + (x1 >= 0 ? T[x1].C : 0); cw.Co = T[y].C; cw.k = k; cw.stride = stride; cw.transposed = transposed;
+        cw.C0 = T[x0].C; cw.C1 = x1 >= 0 ? T[x1].C : 0;
+        cw.mf = !naive && (stride == 1 && !transposed ? (cw.C0 % 8) == 0 && (cw.C1 % 8) == 0 : (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0);
+        cw.mb = !naive && ((cw.Co % 16) == 0 || (stride == 1 && !transposed)) && (cw.C1 == 0 || (cw.C0 % 32) == 0);
+        cw.Co_pad = (cw.Co + 15) / 16 * 16;               // data gradient of a conv with < 16 output channels: gy is zero-padded
+        const long pix = (long)T[y].per * T[y].H * T[y].W;
+        if (pix > cw.gpad_pix) cw.gpad_pix = pix;
+        ops.push_back(o);
+        return ops.back();
+    }
+    // y = act(bn(x)) [+ res, relu]; adapted gamma/beta unless frozen
+    Op& bn(const std::string& bname, int x, int y, int res, int act, int w, bool frozen = false, bool train_only = false, bool bwd = true) {
+        using namespace gnet;
+        Op o; o.kind = K_BN; o.bname = bname; o.x[0] = x; o.y = y; o.res = res; o.act = act; o.xw[0] = w; o.yw = w;
+        o.train_only = train_only; o.bwd = bwd;
+        const int C = T[x].C;
+        if (C > max_bn_C) max_bn_C = C;
+        if (frozen) frozen_bn[bname] = std::make_pair(falloc(C), falloc(C));
+        else { o.ad_g = add_adapted(bname + ".weight", C); o.ad_beta = add_adapted(bname + ".bias", C); }
+        o.st = falloc((size_t)4 * 2 * C);
+        // statistics fused into the producing convolution's epilogue when that is the stride-1 matrix-core kernel
+        for (int k = (int)ops.size() - 1; k >= 0; --k) {
+            Op& pr = ops[k];
+            if (pr.kind != K_CONV || pr.y != x) continue;
+            const GConvW& cw = convs[pr.wname];
+            if (cw.mf && pr.stride == 1 && !pr.transposed && pr.act == GACT_NONE && pr.yw == w && T[x].ld == T[x].C) {
+                o.fused_from = k; pr.stat_to = (int)ops.size();
+                o.rH = pr.rH; o.rW = pr.rW;
+                GView v; v.B = 2 * T[x].per; v.H = T[x].H; v.W = T[x].W; review(v, o.rH, o.rW);
+                o.part = falloc((size_t)2 * ptta_gconv_x3_tiles(v.B, v.H, v.W) * C);
+            }
+            break;
+        }
+        ops.push_back(o);
+        return ops.back();
+    }
+    Op& func(std::function<int(bool, hipStream_t)> f, std::function<int(hipStream_t)> b, bool train_only = false) {
+        Op o; o.kind = gnet::K_FUNC; o.ffwd = f; o.fbwd = b; o.bwd = (bool)b; o.train_only = train_only;
+        ops.push_back(o);
+        return ops.back();
+    }
+
+    // first writer of every gradient buffer overwrites, later ones accumulate; `seeded`: buffers written before the sweep
+    void plan_backward(const std::vector<int>& seeded) {
+        using namespace gnet;
+        std::vector<char> written(T.size(), 0);
+        auto first = [&](int t) {
+            // slices share their parent's buffer only through disjoint channels: tracking per tensor id is exact
+            const bool f = !written[t]; written[t] = 1; return f;
+        };
+        for (int t : seeded) first(t);
+        for (int i = (int)ops.size() - 1; i >= 0; --i) {
+            Op& o = ops[i];
+            if (!o.bwd) continue;
+            if (o.kind == K_CONV) {
+                for (int s = 0; s < o.nsrc; ++s) if (T[o.x[s]].need_grad) o.first_x[s] = first(o.x[s]);
+            } else if (o.kind == K_BN) {
+                o.first_raw = first(o.x[0]);
+                if (o.res >= 0) o.first_res = first(o.res);
+            }
+        }
+    }
+    void mark_written(int) {}
+
+    // workspace shared by every backbone; call after the program is built
+    void alloc_common(long max_wgrad_pixels, int wg_ci, int wg_co) {
+        gall = falloc((size_t)(gall_n > 0 ? gall_n : 1));
+        hyper = falloc(8); loss_info = falloc(4); w3_tmp = falloc(4);
+        loss_ws = falloc((size_t)ptta_loss_ws_floats(Nu, Hu, Wu, rows()));
+        step_dev = (int*)dalloc(sizeof(int));
+        depth = falloc((size_t)Nu * Hu * Wu); gdepth = falloc((size_t)Nu * Hu * Wu); validity_tmp = falloc((size_t)Nu * Hu * Wu);
+        bn_part = falloc((size_t)ptta_gbn_part_floats(max_bn_C, 2)); bn_bw = falloc((size_t)3 * max_bn_C);
+        { const size_t a = (size_t)ptta_gwgrad_slabs(max_wgrad_pixels) * (9 * wg_ci * wg_co + wg_co),
+                       b = (size_t)ptta_gwgrad_mfma_part_floats(max_wgrad_pixels, wg_ci, wg_co); wg_part = falloc(a > b ? a : b); }
+        for (auto& kv : convs) {
+            GConvW& cw = kv.second;
+            const int KK = cw.k * cw.k;
+            if (cw.mf) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.C0, cw.C1, cw.Co); cw.ff_hi = (bf16_t*)dalloc(n * 2); cw.ff_lo = (bf16_t*)dalloc(n * 2); }
+            if (cw.mb && !cw.Ci_real && cw.Co_pad != cw.Co) cw.gpad = falloc((size_t)cw.gpad_pix * cw.Co_pad);
+            if (cw.mb && !cw.Ci_real) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.Ci); cw.fb_hi = (bf16_t*)dalloc(n * 2); cw.fb_lo = (bf16_t*)dalloc(n * 2); }
+            const size_t n = (size_t)KK * cw.Ci * cw.Co;
+            cw.wf = falloc(n); cw.wb = falloc(n); cw.bias = falloc(cw.Co);
+        }
+    }
+
+    // ---- weights ---------------------------------------------------------------------------------------------------
+    void pack_frags(GConvW& cw, hipStream_t s) {
+        const int KK = cw.k * cw.k;
+        if (cw.mf && cw.Ci_real) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci_real * cw.Co, KK, cw.Ci_real, 0, 0, 0, cw.Co, cw.ff_hi, cw.ff_lo, s);
+        else if (cw.mf) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci * cw.Co, KK, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);
+        if (cw.mb && !cw.Ci_real) ptta_gfrag_pack(cw.wb, cw.Ci, (long)cw.Co * cw.Ci, KK, cw.Co, 0, 0, 0, cw.Ci, cw.fb_hi, cw.fb_lo, s);
+    }
+    // src: Conv2d (Co,Ci,k,k) / ConvTranspose2d (Ci,Co,k,k) / Linear (Co,Ci) weight
+    void pack_conv_weight(GConvW& cw, const float* src, hipStream_t s) {
+        const int KK = cw.k * cw.k;
+        const int Ci = cw.Ci_real ? cw.Ci_real : cw.Ci;
+        if (!cw.transposed) {
+            // forward P[t][ci][co] = W[co][ci][t]; data gradient P[t][co][ci] = W[co][ci][flip t] (stride 1: a conv with
+            // flipped taps; stride 2: consumed by the transposed kernel, which wants the taps unflipped)
+            ptta_gpack(src, cw.wf, KK, Ci, cw.Co, KK, (long)Ci * KK, 0, s);
+            ptta_gpack(src, cw.wb, KK, cw.Co, Ci, (long)Ci * KK, KK, cw.stride == 1 ? 1 : 0, s);
+        } else {
+            // ConvTranspose2d weight (Ci, Co, k, k): forward P[t][ci][co] = W[ci][co][t]; gradient = stride-2 conv with
+            // P[t][co][ci] = W[ci][co][t]
+            ptta_gpack(src, cw.wf, KK, Ci, cw.Co, (long)cw.Co * KK, KK, 0, s);
+            ptta_gpack(src, cw.wb, KK, cw.Co, Ci, KK, (long)cw.Co * KK, 0, s);
+        }
+        pack_frags(cw, s);
+    }
+    int load(const char* name_c, const void* tensor_, const int64_t* shape, int ndim, hipStream_t s);
+    // adapted convolutions are re-packed from the bound tensors on every forward
+    void repack_adapted(hipStream_t s) {
+        for (const Op& o : ops)
+            if (o.kind == gnet::K_CONV && o.ad_w >= 0) pack_conv_weight(convs[o.wname], adapted[o.ad_w].p, s);
+    }
+
+    // ---- execution -------------------------------------------------------------------------------------------------
+    const float* bn_gamma(const Op& o) { return o.ad_g >= 0 ? adapted[o.ad_g].p : frozen_bn[o.bname].first; }
+    const float* bn_beta(const Op& o) { return o.ad_beta >= 0 ? adapted[o.ad_beta].p : frozen_bn[o.bname].second; }
+    int run_conv_fwd(const Op& o, bool train, hipStream_t s);
+    int run_bn_fwd(const Op& o, bool train, hipStream_t s);
+    int run_conv_bwd(const Op& o, hipStream_t s);
+    int run_bn_bwd(const Op& o, hipStream_t s);
+    int run_ops_fwd(bool train, hipStream_t s) {
+        for (const Op& o : ops) {
+            if (o.train_only && !train) continue;
+            const int rc = o.kind == gnet::K_CONV ? run_conv_fwd(o, train, s) : (o.kind == gnet::K_BN ? run_bn_fwd(o, train, s) : o.ffwd(train, s));
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    int run_ops_bwd(hipStream_t s) {
+        for (int i = (int)ops.size() - 1; i >= 0; --i) {
+            const Op& o = ops[i];
+            if (!o.bwd) continue;
+            const int rc = o.kind == gnet::K_CONV ? run_conv_bwd(o, s) : (o.kind == gnet::K_BN ? run_bn_bwd(o, s) : o.fbwd(s));
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    int upload_hparams(hipStream_t s) {
+        const float h8[8] = {hp.lr, hp.beta1, hp.beta2, hp.eps, hp.weight_decay, hp.w_sparse_depth, hp.w_smoothness, hp.w_cos};
+        if (ptta_launch_set_floats(hyper, h8, 8, s)) return fail("hyper-parameter upload failed", -5);     // by kernel argument: no sync
+        return 0;
+    }
+
+    // ---- the C-ABI entry points (ptta_api.hip forwards to these) ---------------------------------------------------------
+    int set_hparams(const ptta_hparams* h, hipStream_t s) { hp = *h; return upload_hparams(s); }
+    int set_image_norm(float div, const float* mean, const float* stdv);
+    int bind_adapted(const char* name, float* p, float* m, float* v);
+    int adapted_count() const { return (int)adapted.size(); }
+    const char* adapted_name(int index, int64_t* numel) const {
+        if (index < 0 || index >= (int)adapted.size()) return nullptr;
+        if (numel) *numel = adapted[index].n;
+        return adapted[index].name.c_str();
+    }
+    int set_adam_step(int step, hipStream_t s) { return ptta_launch_set_int(step_dev, step, s) ? fail("set step failed", -5) : 0; }
+    int get_adam_step(int* step, hipStream_t s) {
+        if (hipMemcpyAsync(step, step_dev, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return fail("memcpy failed", -5);
+        return hipStreamSynchronize(s) == hipSuccess ? 0 : fail("sync failed", -5);       // returns a host value: has to wait
+    }
+    int forward_train(const float* image, const float* sparse, float* depth_out, float* emb, float* ref, hipStream_t s);
+    int forward_eval(const float* image, const float* sparse, float* depth_out, hipStream_t s);
+    int step(const float* image, const float* loss_image, const float* sparse, const float* validity, float* depth_out, float* loss_info_out, hipStream_t s);
+    int get_grad(const char* name, float* dst, int64_t capacity, hipStream_t s);
+    int set_grad(const char* name, const float* src, int64_t numel, hipStream_t s);
+    int debug_tensor(const char* name, float* dst, int64_t capacity, int64_t* numel, hipStream_t s);
+    int loss_forward(const float* loss_image, const float* depth_, const float* sparse, const float* validity, const float* emb, const float* ref,
+                     int64_t rows_, float w_sd, float w_sm, float w_cos, float* loss_info_out, hipStream_t s);
+    int loss_backward(const float* loss_image, const float* depth_, const float* sparse, const float* validity, const float* emb, const float* ref,
+                      int64_t rows_, float* grad_depth_out, float* grad_ref_out, hipStream_t s);
+    int backward_from(const float* grad_depth, const float* grad_ref, hipStream_t s);
+    int adam_step(hipStream_t s);
+};

@@ -40,7 +40,7 @@ struct Dbg { const void* p; long numel; int is_act; };
 struct ImgNorm { int on; float div; float mean[3]; float stdv[3]; };
 
 struct ptta_ctx {
-    nlspn_engine* nl = nullptr;      // backbone NLSPN: every entry point forwards to nlspn_api.hip
+    GNet* nl = nullptr;              // backbones on the generic layer-graph engine (NLSPN, CostDCNet): every entry point forwards to it
     int N = 1, H = 0, W = 0, Hp = 0, Wp = 0, pt = 0, pr = 0, dual = 0, Nn = 1;
     int bf16 = 0, naive = 0, es = 4, x3 = 1;
     ptta_hparams hp{};
@@ -885,8 +885,8 @@ extern "C" {
 
 int ptta_version(void) { return PTTA_VERSION; }
 
-const char* ptta_last_error(ptta_handle h) { return h ? (h->nl && h->err.empty() ? nlspn_last_error(h->nl) : h->err.c_str()) : "null handle"; }
-// calls forwarded to the NLSPN engine clear the wrapper-level message, so a later nlspn_last_error is not masked by a stale one
+const char* ptta_last_error(ptta_handle h) { return h ? (h->nl && h->err.empty() ? h->nl->err.c_str() : h->err.c_str()) : "null handle"; }
+// calls forwarded to a GNet engine clear the wrapper-level message, so the engine's later message is not masked by a stale one
 #define NLFWD(call) do { if (c && c->nl) { c->err.clear(); return (call); } } while (0)
 
 int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int height, int width, int dtype, const ptta_hparams* hp) {
@@ -897,7 +897,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     if (backbone_id == PTTA_BACKBONE_NLSPN) {
         if ((meta_mode & ~PTTA_NLSPN_LEGACY_OFFSET) != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32) return -38;
         int rc = 0;
-        nlspn_engine* e = nlspn_create(n, height, width, hp, (meta_mode & PTTA_NLSPN_LEGACY_OFFSET) ? 1 : 0, &rc);
+        GNet* e = nlspn_create(n, height, width, hp, (meta_mode & PTTA_NLSPN_LEGACY_OFFSET) ? 1 : 0, &rc);
         if (!e) return rc ? rc : -12;
         ptta_ctx* c = new ptta_ctx();
         c->nl = e; c->N = n; c->H = height; c->W = width; c->hp = *hp;
@@ -931,7 +931,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
 
 void ptta_destroy(ptta_handle h) {
     if (!h) return;
-    if (h->nl) { nlspn_destroy(h->nl); delete h; return; }
+    if (h->nl) { delete h->nl; delete h; return; }
     h->drop_graphs();
     if (h->ev_replay) (void)hipEventDestroy(h->ev_replay);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -942,7 +942,7 @@ void ptta_destroy(ptta_handle h) {
 }
 
 int ptta_set_hparams(ptta_handle c, const ptta_hparams* hp, ptta_stream s) {
-    NLFWD(nlspn_set_hparams(c->nl, hp, (hipStream_t)s));
+    NLFWD(c->nl->set_hparams(hp, (hipStream_t)s));
 
     if (!c || !hp) return -1;
     if (hp->max_input_depth != c->hp.max_input_depth) c->drop_graphs();     // baked into kernel arguments
@@ -953,7 +953,7 @@ int ptta_set_hparams(ptta_handle c, const ptta_hparams* hp, ptta_stream s) {
 static long shape_numel(const int64_t* shape, int ndim) { long n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
 
 int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, const int64_t* shape, int ndim, ptta_stream s_) {
-    NLFWD(nlspn_load_weights(c->nl, name_, tensor, shape, ndim, (hipStream_t)s_));
+    NLFWD((name_ && tensor) ? c->nl->load(name_, tensor, shape, ndim, (hipStream_t)s_) : -1);
 
     if (!c || !name_ || !tensor) return -1;
     c->drop_graphs();
@@ -1042,7 +1042,7 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
 }
 
 int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp_avg, float* exp_avg_sq) {
-    NLFWD(nlspn_bind_adapted(c->nl, name_, param, exp_avg, exp_avg_sq));
+    NLFWD(c->nl->bind_adapted(name_, param, exp_avg, exp_avg_sq));
 
     if (!c || !name_ || !param) return -1;
     c->drop_graphs();
@@ -1056,16 +1056,16 @@ int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp
     return c->fail("not an adapted parameter: " + name, -2);
 }
 
-int ptta_adapted_count(ptta_handle c) { return c ? (c->nl ? nlspn_adapted_count(c->nl) : (int)c->adapted.size()) : 0; }
+int ptta_adapted_count(ptta_handle c) { return c ? (c->nl ? c->nl->adapted_count() : (int)c->adapted.size()) : 0; }
 const char* ptta_adapted_name(ptta_handle c, int index, int64_t* numel) {
-    NLFWD(nlspn_adapted_name(c->nl, index, numel));
+    NLFWD(c->nl->adapted_name(index, numel));
 
     if (!c || index < 0 || index >= (int)c->adapted.size()) return nullptr;
     if (numel) *numel = c->adapted[index].n;
     return c->adapted[index].name.c_str();
 }
 int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity, ptta_stream s) {
-    NLFWD(nlspn_get_grad(c->nl, name, dst, capacity, (hipStream_t)s));
+    NLFWD(c->nl->get_grad(name, dst, capacity, (hipStream_t)s));
 
     if (!c || !name || !dst) return -1;
     for (auto& ad : c->adapted)
@@ -1078,7 +1078,7 @@ int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity,
 }
 
 int ptta_set_grad(ptta_handle c, const char* name, const float* src, int64_t numel, ptta_stream s) {
-    NLFWD(nlspn_set_grad(c->nl, name, src, numel, (hipStream_t)s));
+    NLFWD(c->nl->set_grad(name, src, numel, (hipStream_t)s));
     if (!c || !name || !src) return -1;
     for (auto& ad : c->adapted)
         if (ad.name == name) {
@@ -1090,14 +1090,14 @@ int ptta_set_grad(ptta_handle c, const char* name, const float* src, int64_t num
 }
 
 int ptta_set_adam_step(ptta_handle c, int step, ptta_stream s) {
-    NLFWD(nlspn_set_adam_step(c->nl, step, (hipStream_t)s));
+    NLFWD(c->nl->set_adam_step(step, (hipStream_t)s));
 
     if (!c) return -1;
     RUN(ptta_launch_set_int(c->step_dev, step, (hipStream_t)s));
     return 0;
 }
 int ptta_get_adam_step(ptta_handle c, int* step, ptta_stream s) {
-    NLFWD(nlspn_get_adam_step(c->nl, step, (hipStream_t)s));
+    NLFWD(c->nl->get_adam_step(step, (hipStream_t)s));
 
     if (!c || !step) return -1;
     HIPCHK(hipMemcpyAsync(step, c->step_dev, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)s));
@@ -1105,10 +1105,10 @@ int ptta_get_adam_step(ptta_handle c, int* step, ptta_stream s) {
     return 0;
 }
 
-int64_t ptta_embedding_rows(ptta_handle c) { return c ? (c->nl ? nlspn_embedding_rows(c->nl) : c->Rg) : 0; }
+int64_t ptta_embedding_rows(ptta_handle c) { return c ? (c->nl ? c->nl->rows() : c->Rg) : 0; }
 
 int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, float* depth_out, float* emb_out, float* ref_out, ptta_stream s_) {
-    NLFWD(nlspn_forward_train(c->nl, image, sparse, depth_out, emb_out, ref_out, (hipStream_t)s_));
+    NLFWD(c->nl->forward_train(image, sparse, depth_out, emb_out, ref_out, (hipStream_t)s_));
 
     if (!c || !image || !sparse) return -1;
     hipStream_t s = (hipStream_t)s_;
@@ -1123,7 +1123,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
 }
 
 int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, float* depth_out, ptta_stream s_) {
-    NLFWD(nlspn_forward_eval(c->nl, image, sparse, depth_out, (hipStream_t)s_));
+    NLFWD(c->nl->forward_eval(image, sparse, depth_out, (hipStream_t)s_));
 
     if (!c || !image || !sparse || !depth_out) return -1;
     hipStream_t s = (hipStream_t)s_;
@@ -1136,7 +1136,7 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
 int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                       const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos,
                       float* loss_info_out, ptta_stream s_) {
-    NLFWD(nlspn_loss_forward(c->nl, loss_image, depth, sparse, validity, emb, ref, rows, w_sd, w_sm, w_cos, loss_info_out, (hipStream_t)s_));
+    NLFWD(c->nl->loss_forward(loss_image, depth, sparse, validity, emb, ref, rows, w_sd, w_sm, w_cos, loss_info_out, (hipStream_t)s_));
 
     if (!c || !loss_image || !depth || !sparse || !validity || !loss_info_out) return -1;
     if (rows > c->Rg) return c->fail("rows exceeds the handle's embedding rows", -22);
@@ -1150,7 +1150,7 @@ int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth
 
 int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                        const float* emb, const float* ref, int64_t rows, float* gdepth, float* gref, ptta_stream s_) {
-    NLFWD(nlspn_loss_backward(c->nl, loss_image, depth, sparse, validity, emb, ref, rows, gdepth, gref, (hipStream_t)s_));
+    NLFWD(c->nl->loss_backward(loss_image, depth, sparse, validity, emb, ref, rows, gdepth, gref, (hipStream_t)s_));
 
     if (!c || !loss_image || !depth || !sparse || !validity || !gdepth) return -1;
     RUN(ptta_launch_loss_backward(depth, loss_image, sparse, validity, c->hp.max_input_depth, emb, ref, rows, 512,
@@ -1159,7 +1159,7 @@ int ptta_loss_backward(ptta_handle c, const float* loss_image, const float* dept
 }
 
 int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref, float* gw_out, float* gb_out, ptta_stream s_) {
-    NLFWD(grad_depth ? nlspn_backward(c->nl, grad_depth, grad_ref, (hipStream_t)s_) : -1);   // gradients: ptta_get_grad
+    NLFWD(grad_depth ? c->nl->backward_from(grad_depth, grad_ref, (hipStream_t)s_) : -1);   // gradients: ptta_get_grad
 
     if (!c || !grad_depth) return -1;
     if (!c->fwd_valid) return c->fail("ptta_backward without a preceding ptta_forward_train", -3);
@@ -1189,7 +1189,7 @@ int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref,
 }
 
 int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream s_) {
-    if (c && c->nl) return (gw || gb) ? c->fail("explicit gradients are an MSG_CHN 1layer convenience", -22) : nlspn_adam_step(c->nl, (hipStream_t)s_);
+    if (c && c->nl) return (gw || gb) ? c->fail("explicit gradients are an MSG_CHN 1layer convenience", -22) : c->nl->adam_step((hipStream_t)s_);
 
     if (!c) return -1;
     for (auto& ad : c->adapted) if (!ad.p || !ad.m || !ad.v) return c->fail("Adam state of " + ad.name + " not bound", -3);
@@ -1226,7 +1226,7 @@ static int step_body(ptta_handle c, const float* image, const float* loss_image,
 int ptta_step(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
               float* depth_out, float* loss_info_out, ptta_stream s_) {
     if (!c || !image || !sparse) return -1;
-    if (c->nl) return nlspn_step(c->nl, image, loss_image, sparse, validity, depth_out, loss_info_out, (hipStream_t)s_);
+    if (c->nl) return c->nl->step(image, loss_image, sparse, validity, depth_out, loss_info_out, (hipStream_t)s_);
     hipStream_t s = (hipStream_t)s_;
     if (!loss_image) loss_image = image;
     const size_t ibytes = (size_t)c->N * 3 * c->H * c->W * 4, pbytes = (size_t)c->N * c->H * c->W * 4;
@@ -1263,7 +1263,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
 }
 
 int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const float* stdv) {
-    NLFWD(nlspn_set_image_norm(c->nl, divisor, mean, stdv));
+    NLFWD(c->nl->set_image_norm(divisor, mean, stdv));
 
     if (!c) return -1;
     if (!(divisor > 0.f)) return c->fail("ptta_set_image_norm: divisor must be positive", -22);
@@ -1358,7 +1358,7 @@ int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_by
 }
 
 int ptta_debug_tensor(ptta_handle c, const char* name, float* dst, int64_t capacity, int64_t* numel_host, ptta_stream s_) {
-    NLFWD(nlspn_debug_tensor(c->nl, name, dst, capacity, numel_host, (hipStream_t)s_));
+    NLFWD(c->nl->debug_tensor(name, dst, capacity, numel_host, (hipStream_t)s_));
 
     if (!c || !name) return -1;
     auto it = c->dbg.find(name);

@@ -146,7 +146,7 @@ int ptta_launch_dcn_forward(const DcnArgs& a, hipStream_t s);
 int ptta_launch_dcn_backward(const DcnArgs& a, hipStream_t s);
 
 // ---- generic NHWC layers of the NLSPN backbone: gconv.hip / gbn.hip / nlspn_prop.hip -----------------------------
-enum { GACT_NONE = 0, GACT_RELU = 1, GACT_LRELU = 2, GACT_SIGMOID = 3 };
+enum { GACT_NONE = 0, GACT_RELU = 1, GACT_LRELU = 2, GACT_SIGMOID = 3, GACT_ELU = 4 };
 struct GView {           // strided NHWC view: element (b,y,x,c) at p[((b*H + y)*W + x)*ld + c]; p already includes the channel offset
     float* p = nullptr; int B = 0, H = 0, W = 0, C = 0, ld = 0;
 };
@@ -167,12 +167,13 @@ int ptta_launch_gwgrad(const GView& x, const GView& gy, float* part, float* gw, 
 
 int ptta_gbn_part_floats(int C, int npass);
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
-                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks = 0);
+                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks = 0, int act_first = 0);
 int ptta_gconv_x3_tiles(int B, int H, int W);
-int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int npass, int act, const float* st, int res_relu, hipStream_t s);
+int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int npass, int act, const float* st, int res_relu, hipStream_t s,
+                          int act_first = 0);
 int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, const GView& gx, const GView& gres, int npass, int act,
                              int res_relu, int acc_gx, int acc_gres, const float* gamma, const float* st, float* part, float* bw,
-                             float* dgamma, float* dbeta, hipStream_t s);
+                             float* dgamma, float* dbeta, hipStream_t s, int act_first = 0);
 
 int ptta_launch_nl_affinity_fwd(const GView& oa, const float* conf, const float* S, int legacy, float* off9, float* aff9, hipStream_t s);
 int ptta_launch_nl_prop_fwd(const float* feat, const float* fix, const float* off9, const float* aff9, float* out, int B, int H, int W,

@@ -38,7 +38,16 @@ typedef void* ptta_stream;              /* hipStream_t */
  * (dropped by 'meta_bn') and the values of adapted tensors (the bound tensors are read instead);
  * ptta_backward ignores its two output pointers (read the 88 gradients with ptta_get_grad) and ptta_adam_step takes
  * NULL gradients (it uses the internal ones); ptta_set_graph and ptta_profile return -38. */
-enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1 };
+/* PTTA_BACKBONE_COSTDCNET: ExternalModel_Adapt(model_name='costdcnet') -- src/costdcnet_model_adapt.py:31-114 ->
+ * CostDCNet._rgbd_meta_contrast (external_src/costdcnet/CostDCNet_adapt.py:207-256), res = 16 planes, up_scale = 4
+ * (src/costdcnet_model_adapt.py:47-52), adapt_parameters('meta_bn') (:357-378).  meta_mode PTTA_META_1LAYER, dtype
+ * PTTA_DTYPE_F32, hp.max_predict_depth > 0 (the far plane).  Shapes not divisible by 16 run the reference's dual-corner
+ * padding (:134-210).  Embeddings are (rows, 512) with rows = n'*(H'/32)*(W'/32) over the padded batch / size;
+ * ptta_adapted_count() is 32 (conv1_rgb_meta + every BatchNorm2d weight/bias of Encoder2D, the reference's order);
+ * ptta_load_weights BINDS the running statistics of BatchNorm3d / BatchNorm1d / the sparse encoder's BatchNorm
+ * (updated in place by training forwards, read by the eval forward) and ignores those of BatchNorm2d (dropped by
+ * 'meta_bn'); the other remarks of PTTA_BACKBONE_NLSPN apply. */
+enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1, PTTA_BACKBONE_COSTDCNET = 2 };
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
 enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };
 /* NLSPN only, OR-ed into meta_mode: ExternalModel_Adapt(..., offset=True) -> args.legacy (src/nlspn_model_adapt.py:62):
@@ -53,6 +62,7 @@ typedef struct {
     float lr, beta1, beta2, eps, weight_decay;
     float w_sparse_depth, w_smoothness, w_cos;
     float max_input_depth;              /* < 0: no clamp (max_input_depth=None) */
+    float max_predict_depth;            /* CostDCNet only: ExternalModel_Adapt(max_predict_depth) = far plane of the cost volume */
 } ptta_hparams;
 
 /* ExternalModel_Adapt(model_name='msg_chn', ...) + _prepare_head(prepare_mode)

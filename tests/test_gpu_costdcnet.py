@@ -1,0 +1,180 @@
+"""CostDCNet backbone (BASELINE config 5) on libptta_hip against the oracle
+(oracle/costdcnet_oracle.py) and the golden vectors generated from the real reference (tests/golden/costdcnet_*.npz;
+MinkowskiEngine provided by oracle/minkowski_lite.py on both sides: the sparse encoder's arithmetic is parity-unpinned)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from proxytta import synth
+from proxytta.engine import Engine
+from tests.util import rel_mae
+
+pytestmark = pytest.mark.gpu
+
+MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+MAX_DEPTH = 8.0
+HP = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=None)
+# 'naive': direct fp32 kernels (exact arithmetic); 'default': bf16x3 matrix-core convolutions
+TOL = {'naive': dict(depth=1e-4, emb=1e-3, grad=2e-2, param=2e-3), 'default': dict(depth=1e-3, emb=5e-3, grad=6e-2, param=4e-3)}
+MODES = ['naive', 'default']
+
+
+def costdc_frame(idx, h, w, n, density=0.05):
+    image01, sparse = synth.synthetic_frame(idx, h, w, n, density=density, dmin=0.3, dmax=7.5)
+    raw = np.floor(image01 * 255.0).astype(np.float32)
+    return raw, ((raw / np.float32(255.0) - MEAN) / STD).astype(np.float32), sparse
+
+
+def make_costdc(n, h, w, hp=HP, impl='default'):
+    old = os.environ.get('PTTA_CONV_IMPL')
+    if impl == 'naive':
+        os.environ['PTTA_CONV_IMPL'] = 'naive'
+    else:
+        os.environ.pop('PTTA_CONV_IMPL', None)
+    try:
+        eng = Engine(n, h, w, backbone='costdcnet', max_predict_depth=MAX_DEPTH, **hp)
+    finally:
+        if old is None:
+            os.environ.pop('PTTA_CONV_IMPL', None)
+        else:
+            os.environ['PTTA_CONV_IMPL'] = old
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_costdcnet().items()}
+    for k in list(sd):            # one BatchNorm behind two names
+        if k.startswith('enc2d.') and '.downsample.1.' in k:
+            sd[k] = sd[k.replace('.downsample.1.', '.norm3.')]
+    eng.load_state_dict(sd)
+    adapted = {}
+    for k in eng.adapted:
+        p = sd[k].clone().contiguous()
+        adapted[k] = (p, torch.zeros_like(p), torch.zeros_like(p))
+        eng.bind_adapted(k, *adapted[k])
+    return eng, sd, adapted
+
+
+def _oracle(hp=HP):
+    from oracle import costdcnet_oracle as CO
+    return CO, CO.CostDcnOracle(synth.formula_state_dict_costdcnet(), max_depth=MAX_DEPTH, max_input_depth=hp['max_input_depth'], lr=hp['lr'],
+                                betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'], w_sd=hp['w_sparse_depth'],
+                                w_sm=hp['w_smoothness'], w_cos=hp['w_cos'])
+
+
+def test_adapted_set_is_the_reference_list():
+    eng, sd, adapted = make_costdc(1, 64, 96)
+    CO, o = _oracle()
+    assert eng.adapted == o.names and len(eng.adapted) == 32 and sum(eng.adapted_numel.values()) == 5200
+    assert eng.rows == 1 * 2 * 3
+    eng.close()
+
+
+@pytest.mark.parametrize('impl', MODES)
+def test_intermediates_match_oracle(impl):
+    """Stage by stage: 2-D features, fused volume, cost volume, bottleneck, depth, embeddings (training forward)."""
+    n, h, w = 1, 64, 96
+    tol = TOL[impl]
+    eng, sd, adapted = make_costdc(n, h, w, impl=impl)
+    CO, o = _oracle()
+    raw, image1, sparse = [torch.from_numpy(x) for x in costdc_frame(0, h, w, n)]
+    pred, emb, ref, inter = CO.network_forward(o.P, image1, sparse, True, MAX_DEPTH, want_intermediates=True)
+    depth, e_, r_ = eng.forward_train(image1.cuda(), sparse.cuda())
+    h4, w4 = h // 4, w // 4
+    f2 = eng.debug_tensor('feat2d').view(2 * n, h4, w4, 16)[:n].permute(0, 3, 1, 2)
+    assert rel_mae(f2, inter['feat2d'].detach()) < tol['depth'] * 2
+    vol = eng.debug_tensor('vol').view(2 * n, 16, h4, w4, 32)[:n].permute(0, 4, 1, 2, 3)
+    assert rel_mae(vol[:, 16:], inter['vol'][:, 16:].detach()) < 1e-4, 'sparse encoder / densify'
+    assert rel_mae(vol[:, :16], inter['vol'][:, :16].detach()) < tol['depth'] * 2, 'fusion mask'
+    cost = eng.debug_tensor('cost').view(n, 16, h4, w4, 16).permute(0, 4, 1, 2, 3)
+    assert rel_mae(cost, inter['cost'].detach()) < tol['depth'] * 5
+    assert rel_mae(depth, pred.detach()) < tol['depth']
+    assert rel_mae(e_, emb) < tol['emb'] and rel_mae(r_, ref.detach()) < tol['emb']
+    eng.close()
+
+
+@pytest.mark.parametrize('impl', MODES)
+@pytest.mark.parametrize('name', ['costdcnet_64x96', 'costdcnet_64x64_n2', 'costdcnet_72x100_pad'])
+def test_step_matches_golden(golden_dir, name, impl):
+    tol = TOL[impl]
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, max_depth = [float(x) for x in g['hp']]
+    hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=None)
+    eng, sd, adapted = make_costdc(n, h, w, hp, impl=impl)
+    names = [str(x) for x in g['adapted_names']]
+    assert eng.adapted == names
+    for s in range(steps):
+        raw, image1, sparse = [torch.from_numpy(x).cuda() for x in costdc_frame(s, h, w, n, float(g['density']))]
+        info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+        p = 's%d/' % s
+        if s > 0:
+            # Adam's FIRST update moves every entry by +-lr (3e-3 in the CostDCNet scripts) whatever the gradient's size, so
+            # the handful of entries whose near-zero gradients differ in sign sit 2*lr apart afterwards (the fp32 CPU
+            # reference is as arbitrary there as this path): later steps are held to a bound, not to the tight tolerance
+            assert rel_mae(depth, g[p + 'depth_train']) < 5e-3, (name, s)
+            continue
+        assert rel_mae(depth, g[p + 'depth_train']) < tol['depth'], (name, s)
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2e-3, atol=1e-7)
+        for k in names:
+            assert rel_mae(eng.grad(k, adapted[k][0]), g[p + 'grad/' + k]) < tol['grad'], k
+            assert np.abs(adapted[k][0].cpu().numpy() - g[p + 'param/' + k]).max() <= 2.0 * lr * 1.01, k     # at worst a flipped +-lr step
+            assert rel_mae(adapted[k][0], g[p + 'param/' + k]) < 5 * tol['param'], k
+        for k in g.files:                       # tracked BatchNorm buffers (BatchNorm3d, heads, sparse encoder)
+            if k.startswith(p + 'buf/'):
+                assert rel_mae(sd[k[len(p) + 4:]], g[k]) < 2e-3, k
+        assert rel_mae(eng.forward_eval(image1, sparse), g[p + 'depth_eval']) < 5e-3
+        # the eval path itself, from the REFERENCE's post-step parameters (the tracked running statistics are this
+        # engine's own, updated by the training forward above): tight
+        keep = {k: adapted[k][0].clone() for k in names}
+        for k in names:
+            adapted[k][0].copy_(torch.from_numpy(g[p + 'param/' + k]))
+        assert rel_mae(eng.forward_eval(image1, sparse), g[p + 'depth_eval']) < (1e-5 if impl == 'naive' else 2e-4)
+        for k in names:
+            adapted[k][0].copy_(keep[k])
+    assert eng.adam_step_count() == steps
+    eng.close()
+
+
+@pytest.mark.parametrize('name', ['costdcnet_320x400', 'costdcnet_480x640'])
+def test_full_size_step_matches_reference(golden_dir, name):
+    """The ScanNet script's frame (bash/adapt/adapt_costdc_scannet.sh: 320x400) and BASELINE config 5's 480x640 VOID frame
+    (1500 points), default arithmetic, against sampled pixels / block means / checksums produced by the reference."""
+    from tests.test_gpu_fullsize import _check_map
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, max_depth = [float(x) for x in g['hp']]
+    hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=None)
+    eng, sd, adapted = make_costdc(n, h, w, hp)
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in costdc_frame(0, h, w, n, float(g['density']))]
+    info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+    _check_map(depth, g, 's0/depth_train', 1e-3)
+    np.testing.assert_allclose(info.cpu().numpy(), g['s0/loss_info'], rtol=2e-3, atol=1e-7)
+    for k in eng.adapted:
+        assert rel_mae(eng.grad(k, adapted[k][0]), g['s0/grad/' + k]) < TOL['default']['grad'], k
+        assert np.abs(adapted[k][0].cpu().numpy() - g['s0/param/' + k]).max() <= 2.0 * lr * 1.01, k
+    _check_map(eng.forward_eval(image1, sparse), g, 's0/depth_eval', 5e-3)                 # after this path's own Adam step (+-lr sign noise)
+    for k in eng.adapted:                                                                  # the eval path from the reference's parameters
+        adapted[k][0].copy_(torch.from_numpy(g['s0/param/' + k]))
+    _check_map(eng.forward_eval(image1, sparse), g, 's0/depth_eval', 2e-4)
+    eng.close()
+
+
+def test_split_calls_equal_fused_step():
+    """forward_train / loss_forward / loss_backward / backward / adam_step (the reference's call sequence,
+    src/tta_main.py:610-633) give the same parameters as the fused ptta_step."""
+    n, h, w = 1, 64, 96
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in costdc_frame(3, h, w, n)]
+    validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+    eng, sd, ad1 = make_costdc(n, h, w)
+    eng.step(image1, sparse, loss_image=raw)
+    eng.close()
+    eng, sd, ad2 = make_costdc(n, h, w)
+    depth, emb, ref = eng.forward_train(image1, sparse)
+    eng.loss_forward(raw, depth, sparse, validity, emb, ref, 1.0, 2.0, 0.1)
+    gd, gr = eng.loss_backward(raw, depth, sparse, validity, emb, ref)
+    eng.backward_all(gd, gr, {k: v[0] for k, v in ad2.items()})
+    eng.adam_step()
+    torch.cuda.synchronize()
+    for k in ad1:
+        assert torch.equal(ad1[k][0], ad2[k][0]), k
+    eng.close()

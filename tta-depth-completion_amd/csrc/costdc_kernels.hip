@@ -49,7 +49,7 @@ __global__ void cd_scatter_dual_grad_kernel(const float* __restrict__ g, float* 
 
 // ---- input staging: in_2d = cat([image, sparse], 1) (CD:210), zero image for the proxy frames (CD:235) -------------------
 // out: [passes*N][H][W][16]: channels 0..2 image (normalised on the fly), 3 sparse depth, 4..15 zero
-__global__ void cd_stage_kernel(const float* __restrict__ image, const float* __restrict__ sparse, float* __restrict__ out, int N, int passes, int H, int W,
+__global__ void cd_stage_kernel(const float* __restrict__ image, const float* __restrict__ sparse, float* __restrict__ out, int N, int passes, int H, int W, int C,
                                 int norm, float div, float m0, float m1, float m2, float s0, float s1, float s2) {
     const long P = (long)H * W, total = (long)passes * N * P;
     GRID_STRIDE(idx, total) {
@@ -60,9 +60,10 @@ __global__ void cd_stage_kernel(const float* __restrict__ image, const float* __
             v0.x = ip[0]; v0.y = ip[P]; v0.z = ip[2 * P];
             if (norm) { v0.x = (v0.x / div - m0) / s0; v0.y = (v0.y / div - m1) / s1; v0.z = (v0.z / div - m2) / s2; }
         }
-        float4* o = (float4*)(out + idx * 16);
+        float4* o = (float4*)(out + idx * C);           // C = 16 (zero-padded for the matrix-core kernel) or 4
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        o[0] = v0; o[1] = z; o[2] = z; o[3] = z;
+        o[0] = v0;
+        if (C == 16) { o[1] = z; o[2] = z; o[3] = z; }
     }
 }
 __global__ void cd_clamp_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, float maxd) {
@@ -73,12 +74,12 @@ __global__ void cd_clamp_kernel(const float* __restrict__ src, float* __restrict
 // level l holds voxels (frame, plane z, y, x) whose y, x are multiples of ts = 1 << l (tensor stride (1, ts, ts)); `vol` is
 // the dense index volume [N][16][H >> l][W >> l] (-1 = empty); points are numbered in (frame, plane, row, column) order by a
 // row count + scan + fill, so every reduction over points has a fixed order.
-__global__ void cd_l0_rowcount_kernel(const float* __restrict__ sparse, int N, int H, int W, float inv_z, int* __restrict__ rowcnt) {
+__global__ void cd_l0_rowcount_kernel(const float* __restrict__ sparse, int N, int H, int W, float z_step, int* __restrict__ rowcnt) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= N * H) return;
     const float* sp = sparse + (long)row * W;
     int c = 0;
-    for (int x = 0; x < W; ++x) { int z = (int)rintf(sp[x] * inv_z); z = z < 0 ? 0 : (z > 15 ? 15 : z); c += z != 0; }
+    for (int x = 0; x < W; ++x) { int z = (int)rintf(sp[x] / z_step); z = z < 0 ? 0 : (z > 15 ? 15 : z); c += z != 0; }
     rowcnt[row] = c;
 }
 // single block: exclusive scan of `n` counts -> offsets; total -> *cnt
@@ -410,9 +411,10 @@ int cd_launch_crop_avg(const float* net, float* out, int N, int H, int W, int Hp
 int cd_launch_scatter_dual_grad(const float* g, float* gnet, int N, int H, int W, int Hp, int Wp, int pt, int pr, hipStream_t s) {
     hipLaunchKernelGGL(cd_scatter_dual_grad_kernel, dim3(nbk((long)2 * N * Hp * Wp)), dim3(256), 0, s, g, gnet, N, H, W, Hp, Wp, pt, pr); LAUNCH_OK();
 }
-int cd_launch_stage(const float* image, const float* sparse, float* out, int N, int passes, int H, int W, int norm, float div, const float* mean,
+int cd_launch_stage(const float* image, const float* sparse, float* out, int N, int passes, int H, int W, int C, int norm, float div, const float* mean,
                     const float* stdv, hipStream_t s) {
-    hipLaunchKernelGGL(cd_stage_kernel, dim3(nbk((long)passes * N * H * W)), dim3(256), 0, s, image, sparse, out, N, passes, H, W, norm, div, mean[0], mean[1],
+    if (C != 4 && C != 16) return -22;
+    hipLaunchKernelGGL(cd_stage_kernel, dim3(nbk((long)passes * N * H * W)), dim3(256), 0, s, image, sparse, out, N, passes, H, W, C, norm, div, mean[0], mean[1],
                        mean[2], stdv[0], stdv[1], stdv[2]); LAUNCH_OK();
 }
 int cd_launch_clamp(const float* src, float* dst, long n, float maxd, hipStream_t s) {
@@ -423,7 +425,7 @@ int cd_sparse_levels_build(const CdSparse& q, const float* sparse, float z_step,
     const int N = q.N, H = q.H, W = q.W;
     for (int l = 0; l < 3; ++l)
         hipLaunchKernelGGL(cd_fill_int_kernel, dim3(nbk((long)N * 16 * (H >> l) * (W >> l))), dim3(256), 0, s, q.vol[l], (long)N * 16 * (H >> l) * (W >> l), -1);
-    hipLaunchKernelGGL(cd_l0_rowcount_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, sparse, N, H, W, 1.0f / z_step, q.rowcnt);
+    hipLaunchKernelGGL(cd_l0_rowcount_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, sparse, N, H, W, z_step, q.rowcnt);
     hipLaunchKernelGGL(cd_scan_kernel, dim3(1), dim3(1024), 0, s, q.rowcnt, N * H, q.rowoff, q.cnt + 0);
     hipLaunchKernelGGL(cd_l0_fill_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, sparse, N, H, W, z_step, q.rowoff, q.coords[0], q.feat_in, q.vol[0]);
     for (int l = 1; l < 3; ++l) {

@@ -87,7 +87,8 @@ struct Op {
     bool act_first = false;           // with a residual: y = relu(act(bn(x)) + res) instead of relu(bn(x) + res)
     int stat_repeats = 1;             // the reference runs this layer `repeats` times per training forward on the same input
     float *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
-    // func
+    // func: fx = tensors whose gradient buffers the backward closure writes (first_x[k] tells it to overwrite or accumulate)
+    int fx[2] = {-1, -1};
     std::function<int(bool, hipStream_t)> ffwd;
     std::function<int(hipStream_t)> fbwd;
 };
@@ -221,10 +222,11 @@ struct GNet {
         ops.push_back(o);
         return ops.back();
     }
-    Op& func(std::function<int(bool, hipStream_t)> f, std::function<int(hipStream_t)> b, bool train_only = false) {
-        Op o; o.kind = gnet::K_FUNC; o.ffwd = f; o.fbwd = b; o.bwd = (bool)b; o.train_only = train_only;
+    // closures receive the op's index so that they can read ops[i].first_x at run time
+    int func(std::function<int(bool, hipStream_t)> f, std::function<int(hipStream_t)> b, int fx0 = -1, int fx1 = -1, bool train_only = false) {
+        Op o; o.kind = gnet::K_FUNC; o.ffwd = f; o.fbwd = b; o.bwd = (bool)b; o.train_only = train_only; o.fx[0] = fx0; o.fx[1] = fx1;
         ops.push_back(o);
-        return ops.back();
+        return (int)ops.size() - 1;
     }
 
     // first writer of every gradient buffer overwrites, later ones accumulate; `seeded`: buffers written before the sweep
@@ -244,6 +246,8 @@ struct GNet {
             } else if (o.kind == K_BN) {
                 o.first_raw = first(o.x[0]);
                 if (o.res >= 0) o.first_res = first(o.res);
+            } else {
+                for (int k = 0; k < 2; ++k) if (o.fx[k] >= 0) o.first_x[k] = first(o.fx[k]);
             }
         }
     }

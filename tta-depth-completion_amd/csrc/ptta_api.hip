@@ -904,6 +904,16 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
         *out = c;
         return 0;
     }
+    if (backbone_id == PTTA_BACKBONE_COSTDCNET) {
+        if (meta_mode != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32 || !hp) return -38;
+        int rc = 0;
+        GNet* e = costdc_create(n, height, width, hp, hp->max_predict_depth, &rc);
+        if (!e) return rc ? rc : -12;
+        ptta_ctx* c = new ptta_ctx();
+        c->nl = e; c->N = n; c->H = height; c->W = width; c->hp = *hp;
+        *out = c;
+        return 0;
+    }
     if (backbone_id != PTTA_BACKBONE_MSG_CHN || (meta_mode != PTTA_META_1LAYER && meta_mode != PTTA_META_2LAYERS)) return -38;
     if (n < 1 || height < 16 || width < 16 || (dtype != PTTA_DTYPE_F32 && dtype != PTTA_DTYPE_BF16) || !hp) return -22;
     ptta_ctx* c = new ptta_ctx();
@@ -1280,7 +1290,7 @@ int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const f
 }
 
 int ptta_set_graph(ptta_handle c, int enable) {
-    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+    if (c && c->nl) return c->fail("not available for the NLSPN / CostDCNet backbones: use ptta_step / ptta_forward_*", -38);
 
     if (!c) return -1;
     c->use_graph = enable ? 1 : 0;
@@ -1330,7 +1340,7 @@ int ptta_mdconv_backward(const float* input, const float* weight, const float* b
 }
 
 int ptta_profile(ptta_handle c, int enable) {
-    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+    if (c && c->nl) return c->fail("not available for the NLSPN / CostDCNet backbones: use ptta_step / ptta_forward_*", -38);
 
     if (!c) return -1;
     c->prof_on = enable != 0;
@@ -1339,7 +1349,7 @@ int ptta_profile(ptta_handle c, int enable) {
 }
 
 int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_bytes, double* macs, int64_t* launches, ptta_stream s_) {
-    if (c && c->nl) return c->fail("not available for the NLSPN backbone: use ptta_step / ptta_forward_*", -38);
+    if (c && c->nl) return c->fail("not available for the NLSPN / CostDCNet backbones: use ptta_step / ptta_forward_*", -38);
 
     if (!c || klass < 0 || klass >= 6) return -1;
     HIPCHK(hipStreamSynchronize((hipStream_t)s_));

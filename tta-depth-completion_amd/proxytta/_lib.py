@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'libptta_hip.so')
 
 PTTA_BACKBONE_MSG_CHN = 0
 PTTA_BACKBONE_NLSPN = 1
+PTTA_BACKBONE_COSTDCNET = 2
 PTTA_NLSPN_LEGACY_OFFSET = 0x100
 PTTA_META_1LAYER = 0
 PTTA_META_2LAYERS = 1
@@ -23,7 +24,7 @@ CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
 class Hparams(ctypes.Structure):
     _fields_ = [('lr', c_float), ('beta1', c_float), ('beta2', c_float), ('eps', c_float),
                 ('weight_decay', c_float), ('w_sparse_depth', c_float), ('w_smoothness', c_float),
-                ('w_cos', c_float), ('max_input_depth', c_float)]
+                ('w_cos', c_float), ('max_input_depth', c_float), ('max_predict_depth', c_float)]
 
 
 # every symbol include/ptta.h declares: (name, restype, argtypes)

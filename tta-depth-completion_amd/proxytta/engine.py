@@ -47,7 +47,7 @@ class Engine:
 
     def __init__(self, n, height, width, dtype='fp32', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0,
-                 max_input_depth=None, meta='1layer', backbone='msg_chn', legacy_offset=False):
+                 max_input_depth=None, meta='1layer', backbone='msg_chn', legacy_offset=False, max_predict_depth=None):
         if not torch.cuda.is_available():
             raise RuntimeError('proxytta needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
@@ -57,13 +57,15 @@ class Engine:
         self.meta = meta
         self.backbone = backbone
         self.emb_dim = 1024 if backbone == 'nlspn' else 512
+        if backbone == 'costdcnet' and not max_predict_depth:
+            raise ValueError('CostDCNet needs max_predict_depth (the far plane of its cost volume, ExternalModel_Adapt(max_predict_depth))')
         self.adapted = adapted_names(meta)
         self.hp = Hparams(lr, betas[0], betas[1], eps, weight_decay, w_sparse_depth, w_smoothness,
-                          w_cos, -1.0 if max_input_depth is None else float(max_input_depth))
+                          w_cos, -1.0 if max_input_depth is None else float(max_input_depth), float(max_predict_depth or 0.0))
         self.handle = c_void_p()
         code = {'fp32': _lib.PTTA_DTYPE_F32, 'bf16': _lib.PTTA_DTYPE_BF16}[dtype]
         rc = self.lib.ptta_create(byref(self.handle),
-                                  _lib.PTTA_BACKBONE_NLSPN if backbone == 'nlspn' else _lib.PTTA_BACKBONE_MSG_CHN,
+                                  {'nlspn': _lib.PTTA_BACKBONE_NLSPN, 'costdcnet': _lib.PTTA_BACKBONE_COSTDCNET}.get(backbone, _lib.PTTA_BACKBONE_MSG_CHN),
                                   (_lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER) |
                                   (_lib.PTTA_NLSPN_LEGACY_OFFSET if (legacy_offset and backbone == 'nlspn') else 0),
                                   self.n, self.h, self.w, code, byref(self.hp))
@@ -81,7 +83,7 @@ class Engine:
             name = self.lib.ptta_adapted_name(self.handle, i, byref(n)).decode()
             names.append(name)
             self.adapted_numel[name] = int(n.value)
-        if backbone == 'nlspn':
+        if backbone in ('nlspn', 'costdcnet'):
             self.adapted = names
         else:
             assert names == list(self.adapted), (names, self.adapted)

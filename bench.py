@@ -232,6 +232,69 @@ def launch_ranks(args, argv):
     return max(abs(rc) for rc in rcs)
 
 
+def costdcnet_frames(count, h, w):
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+    from proxytta import synth
+    out = []
+    for i in range(count):
+        image01, sparse = synth.synthetic_frame(i, h, w, 1, density=1500.0 / (h * w), dmin=0.3, dmax=7.5)      # VOID-1500
+        raw = np.floor(image01 * 255.0).astype(np.float32)
+        out.append((raw, ((raw / np.float32(255.0) - mean) / std).astype(np.float32), sparse))
+    return out
+
+
+def costdcnet_workload(frames=6):
+    """BASELINE config 5's per-GPU work (not the headline metric): CostDCNet, 480x640 VOID-shaped frame with 1500 sparse points,
+    1 TTA step per frame (bash/adapt/adapt_costdc_*.sh: inner_iter 1) + the scored eval forward, adapt_mode meta_bn (32 adapted
+    tensors), batch 1, inputs resident in HBM."""
+    from proxytta import synth
+    from proxytta.engine import Engine
+    h, w = 480, 640
+    eng = Engine(1, h, w, backbone='costdcnet', max_predict_depth=8.0, lr=3e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_costdcnet().items()}
+    eng.load_state_dict(sd)
+    keep = []
+    for k in eng.adapted:
+        keep.append((sd[k].clone().contiguous(), torch.zeros_like(sd[k]), torch.zeros_like(sd[k])))
+        eng.bind_adapted(k, *keep[-1])
+    data = [[torch.from_numpy(x).cuda() for x in f] for f in costdcnet_frames(2, h, w)]
+    eng.step(data[0][1], data[0][2], loss_image=data[0][0]); eng.forward_eval(data[0][1], data[0][2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        info, _ = eng.step(data[f % 2][1], data[f % 2][2], loss_image=data[f % 2][0])
+    torch.cuda.synchronize()
+    t_step = (time.perf_counter() - t0) / frames
+    t0 = time.perf_counter()
+    for f in range(frames):
+        d = eng.forward_eval(data[f % 2][1], data[f % 2][2])
+    torch.cuda.synchronize()
+    t_eval = (time.perf_counter() - t0) / frames
+    out = {'workload': 'CostDCNet (Encoder2D + sparse 3-D encoder + P3D UNet3D, 16 planes), 480x640 VOID-shaped frame with 1500 points, '
+                       '1 TTA step/frame, meta_bn (32 adapted tensors), batch 1',
+           'ms_per_step': 1e3 * t_step, 'frames_per_s': 1.0 / t_step, 'eval_forward_ms': 1e3 * t_eval,
+           'finite': bool(torch.isfinite(info).all().item() and torch.isfinite(d).all().item())}
+    eng.close()
+    return out
+
+
+def costdcnet_cpu_baseline():
+    """The CostDCNet oracle (PyTorch CPU restatement, oracle/costdcnet_oracle.py) on this box's host cores: ONE timed TTA step
+    of the same 480x640 workload after one eval forward."""
+    from oracle import costdcnet_oracle as CO
+    from proxytta import synth
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    raw, im, sp = [torch.from_numpy(x) for x in costdcnet_frames(1, 480, 640)[0]]
+    o = CO.CostDcnOracle(synth.formula_state_dict_costdcnet(), max_depth=8.0, lr=3e-3, w_sd=1.0, w_sm=2.0, w_cos=0.1)
+    o.forward_eval(im, sp)
+    t0 = time.time()
+    o.step(im, sp, loss_image=raw)
+    dt = time.time() - t0
+    return {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 TTA step of the same 480x640 workload after one eval forward (PyTorch-CPU oracle, fp32, %.1f s/step)' % dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -346,9 +409,10 @@ def main():
     eng.close()
     if rank == 0:
         if world == 1 and not args.no_nlspn:
-            out['other_workloads'] = {'msg_chn_2layers': msgchn_2layers_workload(), 'nlspn': nlspn_workload()}
+            out['other_workloads'] = {'msg_chn_2layers': msgchn_2layers_workload(), 'nlspn': nlspn_workload(), 'costdcnet': costdcnet_workload()}
             if not args.no_cpu_baseline:
                 out['other_workloads']['nlspn']['cpu_baseline'] = nlspn_cpu_baseline()
+                out['other_workloads']['costdcnet']['cpu_baseline'] = costdcnet_cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -178,3 +178,41 @@ def test_split_calls_equal_fused_step():
     for k in ad1:
         assert torch.equal(ad1[k][0], ad2[k][0]), k
     eng.close()
+
+
+def test_external_model_adapt_facade_costdcnet(golden_dir):
+    """The reference's driver calls (src/tta_main.py:309-354, 610-633, 729-736) against the façade:
+    ExternalModel_Adapt('costdcnet') -> _prepare_head -> load weights -> adapt_parameters('meta_bn') -> Adam -> forward /
+    compute_loss / backward / optimizer.step -> eval forward; golden step 0."""
+    from proxytta.model import CANONICAL_LOSS_TYPE, ExternalModel_Adapt
+    g = np.load(os.path.join(golden_dir, 'costdcnet_64x96.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, max_depth = [float(x) for x in g['hp']]
+    model = ExternalModel_Adapt('costdcnet', 0.1, max_depth, max_input_depth=None, device=torch.device('cuda'))
+    model._prepare_head('meta_selfsup_seq_1layer_ema')
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict_costdcnet().items()})
+    params = model.adapt_parameters(mode='meta_bn')
+    names = [str(x) for x in g['adapted_names']]
+    assert len(params) == 32 and model.model.adapted == names
+    opt = torch.optim.Adam(params, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in costdc_frame(0, h, w, n, float(g['density']))]
+    validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+    model.train()
+    depth, emb, ref = model.forward(image=image1, sparse_depth=sparse, loss_type=CANONICAL_LOSS_TYPE)
+    loss, info = model.compute_loss(input_rgb=raw, output_depth=depth, sparse_depth=sparse, validity_map=validity, embedding=emb,
+                                    reference=ref, w_loss_sparse_depth=w_sd, w_loss_smoothness=w_sm, w_loss_cos=w_cos, loss_type='adapt')
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert rel_mae(depth, g['s0/depth_train']) < 1e-3
+    assert abs(float(loss.detach()) - g['s0/loss_info'][0]) < 2e-3 * abs(g['s0/loss_info'][0])
+    for k, prm in zip(names, params):
+        assert rel_mae(prm.grad, g['s0/grad/' + k]) < TOL['default']['grad'], k
+    model.eval()
+    with torch.no_grad():
+        d_eval = model.forward(image=image1, sparse_depth=sparse, loss_type=CANONICAL_LOSS_TYPE)
+    assert rel_mae(d_eval, g['s0/depth_eval']) < 5e-3
+    # the checkpoint carries the reference's key set (ResBlock.norm3 listed twice) and the updated running statistics
+    sd = model.model.state_dict()
+    assert list(sd.keys()) == [k for k, _ in synth.costdcnet_keys()]
+    assert rel_mae(sd['unet3d.inc.double_conv.0.bn1.running_mean'], g['s0/buf/unet3d.inc.double_conv.0.bn1.running_mean']) < 2e-3

@@ -1,5 +1,6 @@
 """CPU-only checks: the C-ABI library loads and exports every declared symbol (no compute calls),
 include/ptta.h and the ctypes table agree, the host mirror keeps the reference's surface."""
+import numpy as np
 import os
 import re
 
@@ -77,3 +78,18 @@ def test_nlspn_key_table_and_adapted_list():
     shapes = dict(keys)
     assert len(names) == 88 and sum(int(np.prod(shapes[k])) for k in names) == 40048
     assert names[:2] == ['conv1_rgb_meta.weight', 'conv1_rgb_meta.bias'] and names[2] == 'conv2.0.bn1.weight'
+
+
+def test_costdcnet_key_table_and_adapted_list():
+    """371 state_dict keys (the table is checked against the real reference in tests/golden/make_golden_costdcnet.py) and the
+    32-tensor / 5,200-value adapt_parameters('meta_bn') list in the reference's order."""
+    from proxytta import synth
+    from proxytta.costdcnet import costdcnet_adapted_names
+    keys = synth.costdcnet_keys()
+    assert len(keys) == 371
+    names = costdcnet_adapted_names([k for k, _ in keys])
+    shapes = dict(keys)
+    assert len(names) == 32 and names[:2] == ['conv1_rgb_meta.weight', 'conv1_rgb_meta.bias'] and names[2] == 'enc2d.norm1.weight'
+    assert sum(int(np.prod(shapes[k])) for k in names) == 5200
+    sd = synth.formula_state_dict_costdcnet()
+    assert np.array_equal(sd['enc2d.layer2.0.downsample.1.weight'], sd['enc2d.layer2.0.norm3.weight'])      # one module, two names

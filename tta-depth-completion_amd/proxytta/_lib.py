@@ -72,6 +72,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64: import it FIRST so that this library binds to the HIP runtime torch uses
+    # (loading libptta_hip.so first would pull /opt/rocm's copy into the process and torch would then see no device)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError('libptta_hip.so not found at %s: build it with `python -c "import '
                            '__graft_entry__ as g; g.build()"` — there is no CPU fallback' % LIB_PATH)

@@ -1,0 +1,118 @@
+"""Host-side mirror of src/costdcnet_model_adapt.py (CostDCNetModel_Adapt, the per-backbone adapter the reference selects
+with model_name='costdcnet', src/external_model_adapt.py:76-78) on libptta_hip.
+
+On the accelerated path: the canonical TTA flow of bash/adapt/adapt_costdc_*.sh -- prepare_mode
+'meta_selfsup_seq_1layer_ema', adapt_mode 'meta_bn', loss_type 'adapt_meta_selfsup_seq_ema_reverse': the reference's own
+call sequence forward / compute_loss / loss.backward() / optimizer.step() (src/tta_main.py:610-633), the fused step() and
+the eval forward (:729-736).  res = 16 depth planes, up_scale = 4 (src/costdcnet_model_adapt.py:47-52); frame sizes not
+divisible by 16 run the reference's dual-corner padding inside the library.  The sparse 3-D encoder's arithmetic lives in
+MinkowskiEngine in the reference (absent there, parity unpinned): see csrc/costdc_kernels.hip.
+"""
+import torch
+import torch.nn as nn
+
+from . import synth
+from .engine import Engine
+from .model import MsgChnModel_Adapt, _ForwardFn, _init_tensor, _Tree
+
+_BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked')
+
+
+def costdcnet_adapted_names(keys):
+    """adapt_parameters('meta_bn') (src/costdcnet_model_adapt.py:357-378): parameters whose name contains 'meta', then
+    weight / bias of every BatchNorm2d in module order = Encoder2D's (BatchNorm3d, BatchNorm1d and the sparse encoder's
+    MinkowskiBatchNorm are not BatchNorm2d; ResBlock.norm3 also sits inside `downsample` but a module is visited once)."""
+    names = [k for k in keys if 'meta' in k]
+    for k in keys:
+        if k.startswith('enc2d.') and k.endswith('.running_mean') and '.downsample.1.' not in k:
+            pre = k[:-len('.running_mean')]
+            names += [pre + '.weight', pre + '.bias']
+    return names
+
+
+class CostDCNetModel_Adapt(MsgChnModel_Adapt):
+    """Counterpart of src/costdcnet_model_adapt.py:31-556."""
+
+    def __init__(self, device=torch.device('cuda'), max_depth=10.0, max_input_depth=None):
+        self.max_predict_depth = max_depth
+        self.max_depth = max_depth
+        self.max_input_depth = max_input_depth
+        self.device = device
+        self.dtype = 'fp32'
+        self.training = True
+        self.prepare_mode = None
+        self.model = _Tree()
+        for k, s in synth.costdcnet_keys():
+            if k.startswith(('proj', 'pred', 'conv1_rgb_meta')) or ('.downsample.1.' in k and k.startswith('enc2d.')):
+                continue                                      # heads / meta layer come with _prepare_head; norm3 is one module
+            self.model._leaf(k, _init_tensor(k, s), not k.endswith(_BUFFERS))
+        self._engines = {}
+        self._opt_state = {}
+        self._adam_t = 0
+        self.sync_bn = False
+        self.hparams = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0)
+        self.total_time = self.train_time = self.eval_time = 0.0
+        self.to(device)
+
+    def _prepare_head(self, mode=''):
+        """CostDCNet._prepare_head (CostDCNet_adapt.py:426-496)."""
+        if 'meta' not in mode or 'selfsup' not in mode or 'ema' not in mode or 'seq' not in mode or '1layer' not in mode:
+            raise NotImplementedError('hot path covers prepare_mode meta_selfsup_seq_1layer_ema, got %r' % mode)
+        self.prepare_mode = mode
+        self.meta = '1layer'
+        for k, s in synth.costdcnet_keys(mode):
+            if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
+                self.model._leaf(k, _init_tensor(k, s).to(self.device), not k.endswith(_BUFFERS))
+        self.adapted = costdcnet_adapted_names([k for k, _ in synth.costdcnet_keys(mode)])
+        self._clear_engines()
+
+    def adapt_parameters(self, mode=None):
+        if mode != 'meta_bn':
+            raise NotImplementedError("adapt_mode %r: only 'meta_bn' (the CostDCNet scripts' mode) is on the accelerated path" % mode)
+        params = dict(self.model.named_parameters())
+        return nn.ParameterList([params[k] for k in self.adapted])
+
+    def state_dict(self):
+        """The reference's state_dict lists ResBlock.norm3 a second time as downsample.1 (same tensors)."""
+        sd = self.model.state_dict()
+        out = {}
+        for k, _ in synth.costdcnet_keys(self.prepare_mode or 'meta_selfsup_seq_1layer_ema'):
+            src = k.replace('.downsample.1.', '.norm3.') if k.startswith('enc2d.') else k
+            if src in sd:
+                out[k] = sd[src]
+        return out
+
+    def load_state_dict(self, state):
+        state = {k: v for k, v in state.items() if not (k.startswith('enc2d.') and '.downsample.1.' in k)}
+        super().load_state_dict(state)
+
+    def save_model(self, checkpoint_path, step, optimizer, meanvar=None):
+        torch.save({'net': self.state_dict(), 'optimizer': optimizer.state_dict() if optimizer else {}, 'train_step': step}, checkpoint_path)
+
+    def _engine(self, image):
+        n, _, h, w = image.shape
+        key = (n, h, w)
+        eng = self._engines.get(key)
+        if eng is None:
+            if self.prepare_mode is None:
+                raise RuntimeError('_prepare_head(mode) must be called before forward (tta_main.py:322)')
+            eng = Engine(n, h, w, backbone='costdcnet', max_input_depth=self.max_input_depth, max_predict_depth=self.max_depth, **self.hparams)
+            assert eng.adapted == self.adapted, 'adapted parameter list drifted from the library'
+            eng.load_state_dict(self.model.state_dict())      # running statistics are bound by pointer and updated in place
+            params = dict(self.model.named_parameters())
+            for name in self.adapted:
+                p = params[name]
+                st = self._opt_state.setdefault(name, {'exp_avg': torch.zeros_like(p.data), 'exp_avg_sq': torch.zeros_like(p.data)})
+                eng.bind_adapted(name, p.data, st['exp_avg'], st['exp_avg_sq'])
+            if getattr(self, '_image_norm', None) is not None:
+                eng.set_image_norm(self._image_norm)
+            eng._t = 0
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, image, sparse_depth, intrinsics=None, crop_mask=None, loss_type='pretrain'):
+        if self.training and 'adapt' in loss_type:
+            params = dict(self.model.named_parameters())
+            return self._timed(lambda: _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted]), loss_type)
+        with torch.no_grad():
+            return self._timed(lambda: self._engine(image).forward_eval(image, sparse_depth), loss_type)

@@ -325,7 +325,7 @@ class MsgChnModel_Adapt(object):
 
 
 class ExternalModel_Adapt(object):
-    """Counterpart of src/external_model_adapt.py:29 for model_name='msg_chn'."""
+    """Counterpart of src/external_model_adapt.py:29 (model_name 'msg_chn', 'nlspn', 'costdcnet')."""
 
     def __init__(self, model_name, min_predict_depth, max_predict_depth, max_input_depth=None, offset=False,
                  from_scratch=False, dataset_name=None, device=torch.device('cuda'), dtype='fp32'):
@@ -342,7 +342,8 @@ class ExternalModel_Adapt(object):
             self.model = NlspnModel_Adapt(device=device, max_depth=max_predict_depth, offset=offset, dataset_name=dataset_name,
                                           from_scratch=from_scratch, max_input_depth=max_input_depth)
         elif 'costdcnet' in model_name:
-            raise NotImplementedError('%s is not on the MI355X hot path yet (SURVEY.md §8 row a17)' % model_name)
+            from .costdcnet import CostDCNetModel_Adapt
+            self.model = CostDCNetModel_Adapt(device=device, max_depth=max_predict_depth, max_input_depth=max_input_depth)
         else:
             raise ValueError('Unsupported depth completion model: {}'.format(model_name))
 

@@ -7,8 +7,8 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-adam = [i for i, n in enumerate(names) if n.startswith('adam_kernel')]
-step = rows[adam[-3] + 1:adam[-1] + 1]
+adam = [i for i, n in enumerate(names) if n.startswith('adam_multi_kernel')]      # one launch per step
+step = rows[adam[-2] + 1:adam[-1] + 1]
 t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
 ksum = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in step) / 1e3
 print('step wall us %.1f  kernels %d  sum kernel us %.1f' % ((t1 - t0) / 1e3, len(step), ksum))

@@ -119,6 +119,8 @@ struct GNet {
     float* w3_tmp = nullptr;
     float *hyper = nullptr, *loss_ws = nullptr, *loss_info = nullptr, *validity_tmp = nullptr;
     int* step_dev = nullptr;
+    PttaAdamEntry* adam_tab = nullptr; unsigned* adam_ticket = nullptr; bool adam_tab_dirty = true;
+    std::vector<PttaAdamEntry> adam_host;      // stays alive: the asynchronous upload reads it
     float *bn_part = nullptr, *bn_bw = nullptr, *wg_part = nullptr;
     float *depth = nullptr, *gdepth = nullptr;     // (Nu,1,Hu,Wu): network output / its gradient
     int t_emb = -1, t_ref = -1;
@@ -259,6 +261,7 @@ struct GNet {
         hyper = falloc(8); loss_info = falloc(4); w3_tmp = falloc(4);
         loss_ws = falloc((size_t)ptta_loss_ws_floats(Nu, Hu, Wu, rows()));
         step_dev = (int*)dalloc(sizeof(int));
+        adam_tab = (PttaAdamEntry*)dalloc(adapted.size() * sizeof(PttaAdamEntry)); adam_ticket = (unsigned*)dalloc(sizeof(unsigned));
         depth = falloc((size_t)Nu * Hu * Wu); gdepth = falloc((size_t)Nu * Hu * Wu); validity_tmp = falloc((size_t)Nu * Hu * Wu);
         bn_part = falloc((size_t)ptta_gbn_part_floats(max_bn_C, 2)); bn_bw = falloc((size_t)3 * max_bn_C);
         { const size_t a = (size_t)ptta_gwgrad_slabs(max_wgrad_pixels) * (9 * wg_ci * wg_co + wg_co),

@@ -205,6 +205,7 @@ int GNet::bind_adapted(const char* name, float* p, float* m, float* v) {
     if (it == aid.end()) return fail(std::string("not an adapted parameter: ") + (name ? name : "(null)"), -2);
     Adapted& a = adapted[it->second];
     a.p = p; a.m = m; a.v = v;
+    adam_tab_dirty = true;
     return 0;
 }
 int GNet::forward_train(const float* image, const float* sparse, float* depth_out, float* emb, float* ref, hipStream_t s) {
@@ -224,9 +225,14 @@ int GNet::forward_eval(const float* image, const float* sparse, float* depth_out
 }
 int GNet::adam_step(hipStream_t s) {
     for (auto& ad : adapted) if (!ad.p || !ad.m || !ad.v) return fail("Adam state of " + ad.name + " not bound", -3);
-    if (ptta_launch_step_inc(step_dev, s)) return fail("step counter failed", -5);
-    for (auto& ad : adapted)
-        if (ptta_launch_adam(ad.p, ad.m, ad.v, gall + ad.goff, ad.n, hyper, step_dev, s)) return fail("adam failed", -5);
+    if (adam_tab_dirty) {              // after ptta_bind_adapted only: pointer table of every adapted tensor
+        adam_host.resize(adapted.size());
+        long off = 0;
+        for (size_t k = 0; k < adapted.size(); ++k) { const Adapted& ad = adapted[k]; adam_host[k] = PttaAdamEntry{ad.p, ad.m, ad.v, gall + ad.goff, ad.n, off}; off += ad.n; }
+        NCHK(hipMemcpyAsync(adam_tab, adam_host.data(), adam_host.size() * sizeof(PttaAdamEntry), hipMemcpyHostToDevice, s));
+        adam_tab_dirty = false;
+    }
+    if (ptta_launch_adam_multi(adam_tab, (int)adapted.size(), gall_n, hyper, step_dev, adam_ticket, s)) return fail("adam failed", -5);
     return 0;
 }
 int GNet::step(const float* image, const float* loss_image, const float* sparse, const float* validity, float* depth_out, float* loss_info_out, hipStream_t s) {
@@ -235,15 +241,12 @@ int GNet::step(const float* image, const float* loss_image, const float* sparse,
     int rc = forward(image, sparse, true, s);
     if (rc) return rc;
     const long NP = (long)Nu * Hu * Wu;
-    if (!validity) {
-        hipLaunchKernelGGL(gnet_validity_kernel, dim3(nb(NP)), dim3(256), 0, s, sparse, validity_tmp, NP);
-        validity = validity_tmp;
-    }
     const float* emb = T[t_emb].p; const float* ref = T[t_ref].p;
+    // validity == NULL: evaluated inside the loss kernels; the finalisation runs inside the two gradient kernels
     if (ptta_launch_loss_forward(depth, loss_image, sparse, validity, hp.max_input_depth, emb, ref, rows(), emb_dim(), hyper + 5,
-                                 Nu, Hu, Wu, loss_ws, loss_info, s)) return fail("loss forward failed", -5);
+                                 Nu, Hu, Wu, loss_ws, loss_info, s, 1)) return fail("loss forward failed", -5);
     if (ptta_launch_loss_backward(depth, loss_image, sparse, validity, hp.max_input_depth, emb, ref, rows(), emb_dim(), Nu, Hu,
-                                  Wu, loss_ws, gdepth, T[t_ref].g, s)) return fail("loss backward failed", -5);
+                                  Wu, loss_ws, gdepth, T[t_ref].g, s, hyper + 5, loss_info)) return fail("loss backward failed", -5);
     rc = backward(s);
     if (rc) return rc;
     rc = adam_step(s);

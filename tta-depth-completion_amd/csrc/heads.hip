@@ -11,6 +11,7 @@
 // as per-row-block partial column sums (deterministic two-stage reduction, no atomics), and in
 // the backward the ReLU mask / BatchNorm-backward reductions are fused the same way.
 #include <cstdlib>
+#include <cstring>
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -304,160 +305,184 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
     }
 }
 
-// ---- large-tile variant for N = 512: block = 256 rows x 256 columns, 8 waves (4 x 2), each wave
-// 64 x 128 outputs (2 x 4 MFMA tiles, 128 accumulator VGPRs).  Two LDS stages (2 x 80 KB = the whole
-// 160 KB of a CU): slice k is computed from stage k&1 while slice k+1 (already in registers) is
-// transformed (fused BN+ReLU / BN-backward), split and written to the other stage and slice k+2 is
-// being fetched from HBM/L2: one barrier per K slice, 48 MFMAs per wave between barriers.
+// ---- N = 512, wave-specialised: block = 128 rows x 256 columns, 8 waves = 4 MFMA waves (2 x 2, each 64 x 128 outputs,
+// 128 accumulator VGPRs) + 4 STAGING waves.  The staging waves own all data movement and the fused prologue (global ->
+// registers two K slices ahead -> BN+ReLU -> bf16 hi/lo split -> ds_write into the other LDS stage); the MFMA waves only
+// read fragments and issue MFMAs.  One LDS-only barrier per K slice; on every SIMD an MFMA wave and a staging wave are
+// co-resident, so the matrix cores run while the next slice is transformed.  Measured against the round-1 kernel (256x256
+// tile, 8 lock-step waves, two LDS stages: 24 % MFMA duty, 68 % of wave cycles parked) and against two independent 128x256
+// blocks per CU: 85 / 92 / 95 us per 26752x512x512 GEMM; ablations (profiles/r02_gemm_ablation.txt): stores 20 us, loads 16 us,
+// MFMAs 16 us, everything else 34 us and nothing overlaps across the block's single K loop -> the shape is bound by
+// per-block latency chains, not by the matrix cores.
 template <int PRO, int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_x3_wide_kernel(GemmX3P q) {
-    constexpr int BM = 256, BN = 256, TM = 2, TN = 4;
+__global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
+    constexpr int BM = 128, BN = 256, TM = 2, TN = 4;
+    constexpr int STAGE = (2 * BM + 2 * BN) * X3_ROW;         // 61,440 B
     const GemmP& p = q.g;
-    constexpr int STAGE = (2 * BM + 2 * BN) * X3_ROW;
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * STAGE];
-    float* red = (float*)sm;                                  // [4][2][BN], used after the K loop
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* red = (float*)sm;                                  // [2][2][BN], used after the K loop
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int i = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
     const int n0 = blockIdx.x * BN;
     const long row0 = (long)blockIdx.y * BM;
+    const int nslices = p.K >> 5;
 
-    f32x16 acc[TM][TN];
+    if (wave >= 4) {
+        // ================= staging waves =================
+        const int tid = threadIdx.x - 256;
+        struct Regs { float4 a[2][2]; uint4 bh[4], bl[4]; };          // one K slice in flight: [item][half], B hi / lo
+        Regs r0, r1;
+        auto load_slice = [&](int sl, Regs& rr) {
+            const int k0 = sl << 5;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    float4 ra[2][2], rh[2][2];
-    uint4 rbh[2], rbl[2];
-    auto load_slice = [&](int k0) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + 512 * it;
-            const long gr = row0 + stage_row(idx);
-            const int k = k0 + 8 * (idx & 3);
-            ra[it][0] = make_float4(0.f, 0.f, 0.f, 0.f); ra[it][1] = ra[it][0];
-            if (PRO == 2) { rh[it][0] = ra[it][0]; rh[it][1] = ra[it][0]; }
-            if (gr < p.R) {
-                ra[it][0] = *(const float4*)((const float*)p.A + gr * p.K + k);
-                ra[it][1] = *(const float4*)((const float*)p.A + gr * p.K + k + 4);
-                if (PRO == 2) {
-                    rh[it][0] = *(const float4*)(p.A2 + gr * p.K + k);
-                    rh[it][1] = *(const float4*)(p.A2 + gr * p.K + k + 4);
-                }
+            for (int it = 0; it < 2; ++it) {
+                const int idx = tid + 256 * it;
+                long gr = row0 + stage_row(idx);
+                if (gr >= p.R) gr = p.R - 1;                                  // clamped (rows beyond R are never stored)
+                const float* src = (const float*)p.A + gr * p.K + k0 + 8 * (idx & 3);
+                rr.a[it][0] = *(const float4*)src; rr.a[it][1] = *(const float4*)(src + 4);
             }
-            // interleaved planes: row n, K-slice j = one 128-B line [hi 32 | lo 32] -> every fetched line is fully used
-            const long off = ((long)(n0 + stage_row(idx)) * (p.K >> 5) + (k0 >> 5)) * 64 + 8 * (idx & 3);
-            rbh[it] = *(const uint4*)(q.Wil + off);
-            rbl[it] = *(const uint4*)(q.Wil + off + 32);
-        }
-    };
-    auto store_slice = [&](int k0, int stage) {
-        unsigned char* Ahi = sm + stage * STAGE; unsigned char* Alo = Ahi + BM * X3_ROW;
-        unsigned char* Bhi = Alo + BM * X3_ROW; unsigned char* Blo = Bhi + BN * X3_ROW;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + 512 * it;
-            const int row = stage_row(idx), kq = idx & 3;
-            const long gr = row0 + row;
-            const int k = k0 + 8 * kq;
-            float v[8] = {ra[it][0].x, ra[it][0].y, ra[it][0].z, ra[it][0].w, ra[it][1].x, ra[it][1].y, ra[it][1].z, ra[it][1].w};
-            if (gr < p.R) {
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + 256 * it;
+                const long off = ((long)(n0 + stage_row(idx)) * nslices + sl) * 64 + 8 * (idx & 3);
+                rr.bh[it] = *(const uint4*)(q.Wil + off);
+                rr.bl[it] = *(const uint4*)(q.Wil + off + 32);
+            }
+        };
+        auto store_slice = [&](int sl, const Regs& rr) {
+            unsigned char* const Ahi = sm + (sl & 1) * STAGE; unsigned char* const Alo = Ahi + BM * X3_ROW;
+            unsigned char* const Bhi = Alo + BM * X3_ROW; unsigned char* const Blo = Bhi + BN * X3_ROW;
+            const int k0 = sl << 5;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = tid + 256 * it;
+                const int row = stage_row(idx), kq = idx & 3;
+                const int k = k0 + 8 * kq;
+                float v[8] = {rr.a[it][0].x, rr.a[it][0].y, rr.a[it][0].z, rr.a[it][0].w, rr.a[it][1].x, rr.a[it][1].y, rr.a[it][1].z, rr.a[it][1].w};
                 if (PRO == 1) {
+                    const float4 s0 = *(const float4*)(p.pscale + k), s1 = *(const float4*)(p.pscale + k + 4);
+                    const float4 t0 = *(const float4*)(p.pshift + k), t1 = *(const float4*)(p.pshift + k + 4);
+                    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], p.pscale[k + e], p.pshift[k + e]), 0.f);
-                } else if (PRO == 2) {
-                    const float hh[8] = {rh[it][0].x, rh[it][0].y, rh[it][0].z, rh[it][0].w, rh[it][1].x, rh[it][1].y, rh[it][1].z, rh[it][1].w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        v[e] = p.pscale[k + e] * (v[e] - p.pc1[k + e] - (hh[e] - p.pmean[k + e]) * p.pinv[k + e] * p.pc2[k + e]);
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
                 }
-            }
-            uint4 hi, lo;
-            hsplit2(v[0], v[1], hi.x, lo.x); hsplit2(v[2], v[3], hi.y, lo.y);
-            hsplit2(v[4], v[5], hi.z, lo.z); hsplit2(v[6], v[7], hi.w, lo.w);
-            *(uint4*)(Ahi + row * X3_ROW + 16 * kq) = hi;
-            *(uint4*)(Alo + row * X3_ROW + 16 * kq) = lo;
-            *(uint4*)(Bhi + row * X3_ROW + 16 * kq) = rbh[it];
-            *(uint4*)(Blo + row * X3_ROW + 16 * kq) = rbl[it];
-        }
-    };
-
-    load_slice(0);
-    store_slice(0, 0);
-    if (32 < p.K) load_slice(32);
-    __syncthreads();
-    for (int k0 = 0, stage = 0; k0 < p.K; k0 += 32, stage ^= 1) {
-        const unsigned char* Ahi = sm + stage * STAGE; const unsigned char* Alo = Ahi + BM * X3_ROW;
-        const unsigned char* Bhi = Alo + BM * X3_ROW; const unsigned char* Blo = Bhi + BN * X3_ROW;
-        if (k0 + 32 < p.K) {
-            store_slice(k0 + 32, stage ^ 1);          // registers hold slice k+1 (landed during slice k-1's MFMAs)
-            if (k0 + 64 < p.K) load_slice(k0 + 64);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 ah[TM], al[TM];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int off = ((wm * TM + a) * 32 + i) * X3_ROW + 32 * ks + 16 * h;
-                ah[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Ahi + off));
-                al[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Alo + off));
+                uint4 hi, lo;
+                hsplit2(v[0], v[1], hi.x, lo.x); hsplit2(v[2], v[3], hi.y, lo.y);
+                hsplit2(v[4], v[5], hi.z, lo.z); hsplit2(v[6], v[7], hi.w, lo.w);
+                *(uint4*)(Ahi + row * X3_ROW + 16 * kq) = hi;
+                *(uint4*)(Alo + row * X3_ROW + 16 * kq) = lo;
             }
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int off = ((wn * TN + b) * 32 + i) * X3_ROW + 32 * ks + 16 * h;
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)(Bhi + off));
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(Blo + off));
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + 256 * it;
+                const int row = stage_row(idx), kq = idx & 3;
+                *(uint4*)(Bhi + row * X3_ROW + 16 * kq) = rr.bh[it];
+                *(uint4*)(Blo + row * X3_ROW + 16 * kq) = rr.bl[it];
+            }
+        };
+        load_slice(0, r0);
+        if (nslices > 1) load_slice(1, r1);
+        store_slice(0, r0);
+        if (nslices > 2) load_slice(2, r0);
+        lds_barrier();                                              // slice 0 staged
+        for (int sl = 0; sl < nslices; sl += 2) {
+            // during the MFMAs of slice sl: stage slice sl+1 (registers ring 1), refill ring 1 with slice sl+3
+            if (sl + 1 < nslices) { store_slice(sl + 1, r1); if (sl + 3 < nslices) load_slice(sl + 3, r1); }
+            lds_barrier();
+            if (sl + 1 >= nslices) break;
+            // during the MFMAs of slice sl+1: stage slice sl+2 (ring 0), refill ring 0 with slice sl+4
+            if (sl + 2 < nslices) { store_slice(sl + 2, r0); if (sl + 4 < nslices) load_slice(sl + 4, r0); }
+            lds_barrier();
+        }
+    } else {
+        // ================= MFMA waves =================
+        const int wm = wave >> 1, wn = wave & 1;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        lds_barrier();                                              // slice 0 staged
+        for (int sl = 0; sl < nslices; ++sl) {
+            const unsigned char* Ahi = sm + (sl & 1) * STAGE; const unsigned char* Alo = Ahi + BM * X3_ROW;
+            const unsigned char* Bhi = Alo + BM * X3_ROW; const unsigned char* Blo = Bhi + BN * X3_ROW;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[TM], al[TM];
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
+                    const int off = ((wm * TM + a) * 32 + i) * X3_ROW + 32 * ks + 16 * h;
+                    ah[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Ahi + off));
+                    al[a] = __builtin_bit_cast(bf16x8, *(const uint4*)(Alo + off));
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int off = ((wn * TN + b) * 32 + i) * X3_ROW + 32 * ks + 16 * h;
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)(Bhi + off));
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(Blo + off));
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh, acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl, acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh, acc[a][b], 0, 0, 0);
+                    }
                 }
             }
+            lds_barrier();          // hand the stage back; the other stage is complete
         }
-        lds_barrier();          // LDS hand-over only: slice k+2's global loads stay in flight across the barrier
-    }
-    __syncthreads();
-
+        // ---- epilogue (MFMA waves only): N = 512 is a compile-time row stride, one base pointer per wave, and a block that
+        // lies fully inside the R rows (always, when R is a multiple of 128) stores without per-element bounds branches ----
+        constexpr int NC = 512;
+        const bool full = row0 + BM <= p.R;
+        const long wrow = row0 + wm * TM * 32;
+        float* const cw = p.C + wrow * NC + n0 + wn * TN * 32 + i;
+        const float* const hw = EPI == 2 ? p.eH + wrow * NC + n0 + wn * TN * 32 + i : nullptr;
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int cl = (wn * TN + b) * 32 + i;
-        const int col = n0 + cl;
-        const float bias = p.bias ? p.bias[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
-        float esc = 0.f, esh = 0.f, emu = 0.f, eiv = 0.f;
-        if (EPI == 2) { esc = p.escale[col]; esh = p.eshift[col]; emu = p.emean[col]; eiv = p.einv[col]; }
+        for (int b = 0; b < TN; ++b) {
+            const int cl = (wn * TN + b) * 32 + i;
+            const int col = n0 + cl;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+            float esc = 0.f, esh = 0.f, emu = 0.f, eiv = 0.f;
+            if (EPI == 2) { esc = p.escale[col]; esh = p.eshift[col]; emu = p.emean[col]; eiv = p.einv[col]; }
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long row = row0 + (wm * TM + a) * 32 + acc_row(r, h);
-                if (row >= p.R) continue;
-                float v = acc[a][b][r] + bias;
-                if (EPI == 1) { s1 += v; s2 += v * v; }
+            for (int a = 0; a < TM; ++a) {
+                float hh[16];
                 if (EPI == 2) {
-                    const float hh = p.eH[row * p.N + col];
-                    v = (fmaf(hh, esc, esh) > 0.f) ? v : 0.f;
-                    s1 += v; s2 += v * (hh - emu) * eiv;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = a * 32 + acc_row(r, h);
+                        hh[r] = (full || wrow + lr < p.R) ? hw[(long)lr * NC + b * 32] : 0.f;
+                    }
                 }
-                p.C[row * p.N + col] = v;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = a * 32 + acc_row(r, h);
+                    const bool ok = full || wrow + lr < p.R;
+                    float v = acc[a][b][r] + bias;
+                    if (EPI == 2) v = (fmaf(hh[r], esc, esh) > 0.f) ? v : 0.f;
+                    if (ok) {
+                        if (EPI == 1) { s1 += v; s2 += v * v; }
+                        if (EPI == 2) { s1 += v; s2 += v * (hh[r] - emu) * eiv; }
+                        cw[(long)lr * NC + b * 32] = v;
+                    }
+                }
             }
-        }
-        if (EPI != 0) {
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            if (h == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
+            if (EPI != 0) {
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (h == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
+            }
         }
     }
     if (EPI != 0) {
         __syncthreads();
-        for (int t = tid; t < 2 * BN; t += 512) {
+        for (int t = threadIdx.x; t < 2 * BN; t += 512) {
             const int which = t / BN, c = t % BN;
-            const float v = (red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c]) +
-                            (red[(2 * 2 + which) * BN + c] + red[(3 * 2 + which) * BN + c]);
-            p.part[((long)blockIdx.y * 2 + which) * p.N + n0 + c] = v;
+            p.part[((long)blockIdx.y * 2 + which) * p.N + n0 + c] = red[(0 * 2 + which) * BN + c] + red[(1 * 2 + which) * BN + c];
         }
     }
 }
@@ -482,8 +507,8 @@ void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, bf16_t* il, long 
 }
 
 int ptta_gemm_row_blocks(int R) { return (R + GEMM_BM - 1) / GEMM_BM; }
-// number of row-block partials the launch of `a` writes (the wide bf16x3 kernel uses 256-row blocks)
-int ptta_gemm_part_blocks(const GemmArgs& a) { return (a.x3 && !a.a_bf16 && a.N == 512) ? (a.R + 255) / 256 : ptta_gemm_row_blocks(a.R); }
+// number of row-block partials the launch of `a` writes (every kernel here uses 128-row blocks)
+int ptta_gemm_part_blocks(const GemmArgs& a) { return ptta_gemm_row_blocks(a.R); }
 
 int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.K % GEMM_BK || a.N % 32) return -22;
@@ -494,15 +519,15 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.x3 && !a.a_bf16) {
         GemmX3P q; q.g = p; q.Whi = a.Whi; q.Wlo = a.Wlo; q.Wil = a.Wil;
         const int key3 = a.pro * 10 + a.epi;
-        if (a.N == 512 && a.Wil) {
-            dim3 grid(2, (a.R + 255) / 256);
-#define GW_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_wide_kernel<PRO, EPI>), grid, dim3(512), 0, s, q)
+        if (a.N == 512 && a.Wil && a.pro != 2) {
+            dim3 grid(2, (a.R + 127) / 128);
+#define GS_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_ws_kernel<PRO, EPI>), grid, dim3(512), 0, s, q)
             switch (key3) {
-                case 0: GW_(0, 0); break; case 1: GW_(0, 1); break; case 2: GW_(0, 2); break;
-                case 10: GW_(1, 0); break; case 11: GW_(1, 1); break;
+                case 0: GS_(0, 0); break; case 1: GS_(0, 1); break; case 2: GS_(0, 2); break;
+                case 10: GS_(1, 0); break; case 11: GS_(1, 1); break;
                 default: return -22;
             }
-#undef GW_
+#undef GS_
         } else if (a.N % 128 == 0) {
             dim3 grid(a.N / 128, ptta_gemm_row_blocks(a.R));
 #define GX_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_kernel<2, 2, 2, 2, PRO, EPI>), grid, dim3(256), 0, s, q)

@@ -30,6 +30,13 @@ static __host__ __device__ inline long ws_rows_off(int N) { return ws_cos_off(N)
 
 int ptta_loss_ws_floats(int N, int H, int W, long R) { return (int)(ws_rows_off(N) + 3 * R + 64); }
 
+// validity_map of the TTA step = where(sparse > 0, 1, sparse) on the RAW sparse depth (src/tta_main.py:583-586); computed on the
+// fly when the caller passes no map
+__device__ __forceinline__ float valid_w(const float* __restrict__ validity, const float* __restrict__ sparse, size_t i) {
+    if (validity) return validity[i];
+    const float s = sparse[i];
+    return s > 0.f ? 1.f : s;
+}
 __device__ __forceinline__ float clampd(float d, float max_d) { return max_d >= 0.f ? fminf(fmaxf(d, 0.f), max_d) : d; }
 __device__ __forceinline__ float edge_w(const float* img, size_t plane, size_t a, size_t b) {
     const float m = (fabsf(img[a] - img[b]) + fabsf(img[plane + a] - img[plane + b]) +
@@ -45,12 +52,12 @@ __global__ __launch_bounds__(256) void loss_depth_reduce_kernel(const float* __r
     const size_t plane = (size_t)H * W;
     const float* D = depth + n * plane;
     const float* S = sparse + n * plane;
-    const float* V = validity + n * plane;
+    const float* V = validity ? validity + n * plane : nullptr;
     const float* I = image + (size_t)n * 3 * plane;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(idx % W), y = (int)(idx / W);
-        const float d = D[idx], w = V[idx];
+        const float d = D[idx], w = valid_w(V, S, idx);
         a0 += w * fabsf(clampd(S[idx], max_d) - d);
         a1 += w;
         if (x < W - 1) a2 += edge_w(I, plane, idx, idx + 1) * fabsf(d - D[idx + 1]);
@@ -102,6 +109,51 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// The same finalisation as loss_finalize_kernel, run redundantly by EVERY block of the two gradient kernels of the fused
+// step (a few KB of partials from L2 per block) instead of as a 1-block launch between them: one ~20 us latency-bound
+// kernel less on the step's critical path.  fin: [0] coef_cos [1] cx [2] cy [3..3+N) per-sample sparse-depth coefficient.
+#define LOSS_FIN_MAXN 16
+__device__ void loss_finalize_block(const float* __restrict__ ws, int N, int H, int W, long R, int has_cos, const float* __restrict__ w3,
+                                    float* __restrict__ fin, float* __restrict__ loss_info, float* __restrict__ ws_out) {
+    __shared__ double red[4];
+    const float w_sd = w3[0], w_sm = w3[1], w_cos = w3[2];
+    const float* dp = ws + ws_depth_off(N);
+    const int t = threadIdx.x;
+    double l_sd = 0.0, smx = 0.0, smy = 0.0;
+    for (int n = 0; n < N; ++n) {
+        double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        if (t < LOSS_PB) { const float* q = dp + ((size_t)n * LOSS_PB + t) * 4; q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; }
+        const double num = block_sum_d(q0, red), den = block_sum_d(q1, red);
+        smx += block_sum_d(q2, red); smy += block_sum_d(q3, red);
+        l_sd += num / den;
+        if (t == 0) fin[3 + n] = (float)((double)w_sd / ((double)N * den));
+    }
+    l_sd /= N;
+    const double cntx = (double)N * H * (W - 1), cnty = (double)N * (H - 1) * W;
+    const double l_sm = smx / cntx + smy / cnty;
+    double l_cos = 0.0;
+    float wc = w_cos;
+    if (has_cos) {
+        const float* cp = ws + ws_cos_off(N);
+        double a = 0.0;
+        for (int b = t; b < LOSS_CB; b += 256) a += cp[b];
+        l_cos = block_sum_d(a, red) / (double)R;
+        if ((float)l_cos < 0.3f) wc = 0.f;                   // external_model_adapt.py:424-425
+    }
+    if (t == 0) {
+        fin[0] = has_cos ? (float)(-2.0 * wc / (double)R) : 0.f;
+        fin[1] = (float)(w_sm / cntx);
+        fin[2] = (float)(w_sm / cnty);
+        if (loss_info) {
+            loss_info[0] = (float)(w_sd * l_sd + w_sm * l_sm + (double)wc * l_cos);
+            loss_info[1] = (float)l_sm; loss_info[2] = (float)l_sd; loss_info[3] = (float)l_cos;
+            ws_out[WS_SCAL + 0] = fin[0]; ws_out[WS_SCAL + 1] = fin[1]; ws_out[WS_SCAL + 2] = fin[2];
+            for (int n = 0; n < N; ++n) ws_out[WS_SD + n] = fin[3 + n];
+        }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void loss_finalize_kernel(float* __restrict__ ws, int N, int H, int W, long R, int has_cos,
                                                             const float* __restrict__ w3, float* __restrict__ loss_info) {
     __shared__ double red[4];
@@ -142,24 +194,29 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(float* __restrict__ 
 int ptta_launch_loss_forward(const float* depth, const float* image, const float* sparse, const float* validity,
                              float max_input_depth, const float* emb, const float* ref, long R, int D,
                              const float* w3_dev, int N, int H, int W,
-                             float* ws, float* loss_info, hipStream_t s) {
+                             float* ws, float* loss_info, hipStream_t s, int defer_finalize) {
     hipLaunchKernelGGL(loss_depth_reduce_kernel, dim3(LOSS_PB, N), dim3(256), 0, s, depth, image, sparse, validity,
                        max_input_depth, H, W, ws + ws_depth_off(N));
     const int has_cos = (emb && ref) ? 1 : 0;
     if (has_cos)
         hipLaunchKernelGGL(cos_rows_kernel, dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, ws, N, H, W, R, has_cos, w3_dev, loss_info);
+    // defer_finalize (fused step, N <= LOSS_FIN_MAXN): ptta_launch_loss_backward(..., w3_dev, loss_info) finalises inside its kernels
+    if (!defer_finalize || N > LOSS_FIN_MAXN)
+        hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, ws, N, H, W, R, has_cos, w3_dev, loss_info);
     PTTA_CHECK_LAUNCH();
     return 0;
 }
 
 __global__ __launch_bounds__(256) void loss_depth_grad_kernel(const float* __restrict__ depth, const float* __restrict__ image,
                                                               const float* __restrict__ sparse, const float* __restrict__ validity,
-                                                              float max_d, int N, int H, int W, const float* __restrict__ ws,
-                                                              float* __restrict__ g) {
+                                                              float max_d, int N, int H, int W, float* __restrict__ ws,
+                                                              float* __restrict__ g, long R, int has_cos, const float* __restrict__ w3,
+                                                              float* __restrict__ loss_info) {
+    __shared__ float fin[3 + LOSS_FIN_MAXN];
     const size_t plane = (size_t)H * W;
     const size_t total = (size_t)N * plane;
-    const float cx = ws[WS_SCAL + 1], cy = ws[WS_SCAL + 2];
+    if (w3) loss_finalize_block(ws, N, H, W, R, has_cos, w3, fin, blockIdx.x == 0 ? loss_info : nullptr, ws);       // fused step
+    const float cx = w3 ? fin[1] : ws[WS_SCAL + 1], cy = w3 ? fin[2] : ws[WS_SCAL + 2];
     for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (size_t)gridDim.x * blockDim.x) {
         const int n = (int)(gi / plane);
         const size_t idx = gi % plane;
@@ -167,7 +224,8 @@ __global__ __launch_bounds__(256) void loss_depth_grad_kernel(const float* __res
         const float* D = depth + n * plane;
         const float* I = image + (size_t)n * 3 * plane;
         const float d = D[idx];
-        float v = ws[WS_SD + n] * validity[gi] * sgn(d - clampd(sparse[gi], max_d));
+        const float sd_n = w3 ? fin[3 + n] : ws[WS_SD + n];
+        float v = sd_n * valid_w(validity, sparse, gi) * sgn(d - clampd(sparse[gi], max_d));
         float tx = 0.f, ty = 0.f;
         if (x < W - 1) tx += edge_w(I, plane, idx, idx + 1) * sgn(d - D[idx + 1]);
         if (x > 0) tx -= edge_w(I, plane, idx - 1, idx) * sgn(D[idx - 1] - d);
@@ -179,9 +237,11 @@ __global__ __launch_bounds__(256) void loss_depth_grad_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void cos_grad_kernel(const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
                                                        const float* __restrict__ ws, const float* __restrict__ rowstats,
-                                                       float* __restrict__ gref) {
+                                                       float* __restrict__ gref, int N, int H, int W, const float* __restrict__ w3) {
+    __shared__ float fin[3 + LOSS_FIN_MAXN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float coef = ws[WS_SCAL + 0];
+    if (w3) loss_finalize_block(ws, N, H, W, R, 1, w3, fin, nullptr, nullptr);
+    const float coef = w3 ? fin[0] : ws[WS_SCAL + 0];
     for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
         const float ne = rowstats[3 * row], nr = rowstats[3 * row + 1], c = rowstats[3 * row + 2];
         const float ie = 1.f / ne, ir = 1.f / nr;
@@ -201,14 +261,17 @@ __global__ __launch_bounds__(256) void cos_grad_kernel(const float* __restrict__
 
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
-                              int N, int H, int W, const float* ws, float* gdepth, float* gref, hipStream_t s) {
+                              int N, int H, int W, float* ws, float* gdepth, float* gref, hipStream_t s, const float* w3_fused,
+                              float* loss_info_fused) {
     const size_t total = (size_t)N * H * W;
-    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    if (w3_fused && N > LOSS_FIN_MAXN) w3_fused = nullptr;          // the forward launched the finalize kernel in that case
+    int blocks = (int)((total + 255) / 256); if (blocks > (w3_fused ? 1024 : 4096)) blocks = w3_fused ? 1024 : 4096;
+    const int has_cos = (emb && ref) ? 1 : 0;
     hipLaunchKernelGGL(loss_depth_grad_kernel, dim3(blocks), dim3(256), 0, s, depth, image, sparse, validity,
-                       max_input_depth, N, H, W, ws, gdepth);
+                       max_input_depth, N, H, W, ws, gdepth, R, has_cos, w3_fused, loss_info_fused);
     if (emb && ref && gref) {
-        long cb = (R + 3) / 4; if (cb > 2048) cb = 2048;
-        hipLaunchKernelGGL(cos_grad_kernel, dim3((int)cb), dim3(256), 0, s, emb, ref, R, D, ws, ws + ws_rows_off(N), gref);
+        long cb = (R + 3) / 4; if (cb > (w3_fused ? 1024 : 2048)) cb = w3_fused ? 1024 : 2048;
+        hipLaunchKernelGGL(cos_grad_kernel, dim3((int)cb), dim3(256), 0, s, emb, ref, R, D, ws, ws + ws_rows_off(N), gref, N, H, W, w3_fused);
     }
     PTTA_CHECK_LAUNCH();
     return 0;

@@ -75,6 +75,8 @@ struct ptta_ctx {
     float* hyper = nullptr;      // device: lr b1 b2 eps wd | w_sd w_sm w_cos
     float* w3_tmp = nullptr;     // device: loss weights of the standalone loss call
     int* step_dev = nullptr;
+    PttaAdamEntry* adam_tab = nullptr; unsigned* adam_ticket = nullptr; bool adam_tab_dirty = true;
+    std::vector<PttaAdamEntry> adam_host;        // stays alive: the upload reads it
     bool fwd_valid = false;
     bool proxy_rgb_valid = false;   // proxy half of c0..c4 holds the zero-image encoder outputs for the current weights
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
@@ -371,6 +373,7 @@ void build_workspace(ptta_ctx* c) {
     c->in_sparse = c->falloc((size_t)c->N * c->H * c->W); c->in_validity = c->falloc((size_t)c->N * c->H * c->W);
     c->hyper = c->falloc(16); c->w3_tmp = c->falloc(4);
     c->step_dev = (int*)c->dalloc(16);
+    c->adam_tab = (PttaAdamEntry*)c->dalloc(8 * sizeof(PttaAdamEntry)); c->adam_ticket = (unsigned*)c->dalloc(16);
 #undef A_
 #undef M_
 }
@@ -1060,6 +1063,7 @@ int ptta_bind_adapted(ptta_handle c, const char* name_, float* param, float* exp
     for (size_t k = 0; k < c->adapted.size(); ++k)
         if (c->adapted[k].name == name) {
             c->adapted[k].p = param; c->adapted[k].m = exp_avg; c->adapted[k].v = exp_avg_sq;
+            c->adam_tab_dirty = true;
             if (c->meta_mode == PTTA_META_1LAYER) { if (k == 0) c->meta_w = param; else c->meta_b = param; }
             return 0;
         }
@@ -1198,6 +1202,18 @@ int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref,
     return 0;
 }
 
+// pointer table of the adapted tensors for the one-launch Adam; uploaded after ptta_bind_adapted only, never inside a capture
+static int ensure_adam_table(ptta_ctx* c, hipStream_t s) {
+    if (!c->adam_tab_dirty) return 0;
+    for (auto& ad : c->adapted) if (!ad.p || !ad.m || !ad.v) return 0;          // reported by ptta_adam_step
+    c->adam_host.resize(c->adapted.size());
+    long off = 0;
+    for (size_t k = 0; k < c->adapted.size(); ++k) { auto& ad = c->adapted[k]; c->adam_host[k] = PttaAdamEntry{ad.p, ad.m, ad.v, ad.g, ad.n, off}; off += ad.n; }
+    HIPCHK(hipMemcpyAsync(c->adam_tab, c->adam_host.data(), c->adam_host.size() * sizeof(PttaAdamEntry), hipMemcpyHostToDevice, s));
+    c->adam_tab_dirty = false;
+    return 0;
+}
+
 int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream s_) {
     if (c && c->nl) return (gw || gb) ? c->fail("explicit gradients are an MSG_CHN 1layer convenience", -22) : c->nl->adam_step((hipStream_t)s_);
 
@@ -1205,6 +1221,12 @@ int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream 
     for (auto& ad : c->adapted) if (!ad.p || !ad.m || !ad.v) return c->fail("Adam state of " + ad.name + " not bound", -3);
     if ((gw || gb) && c->meta_mode != PTTA_META_1LAYER) return c->fail("explicit gradients are a 1layer convenience; use the internal ones", -22);
     hipStream_t s = (hipStream_t)s_;
+    if (!gw && !gb) {                       // the internal gradients: every adapted tensor + the step count in one launch
+        RUN(ensure_adam_table(c, s));
+        long total = 0; for (auto& ad : c->adapted) total += ad.n;
+        RUN(ptta_launch_adam_multi(c->adam_tab, (int)c->adapted.size(), total, c->hyper, c->step_dev, c->adam_ticket, s));
+        return 0;
+    }
     RUN(ptta_launch_step_inc(c->step_dev, s));
     for (size_t k = 0; k < c->adapted.size(); ++k) {
         auto& ad = c->adapted[k];
@@ -1219,15 +1241,12 @@ static int step_body(ptta_handle c, const float* image, const float* loss_image,
                      ptta_stream s_) {
     hipStream_t s = (hipStream_t)s_;
     RUN(ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_));
-    const long npx = (long)c->N * c->H * c->W;
-    if (!validity) {
-        hipLaunchKernelGGL(validity_kernel, dim3(nblk(npx)), dim3(256), 0, s, sparse, c->validity_tmp, npx);
-        validity = c->validity_tmp;
-    }
+    // validity == NULL: where(sparse > 0, 1, sparse) is evaluated inside the loss kernels; the loss finalisation runs inside
+    // the two gradient kernels (no 1-block launch between forward and backward)
     RUN(ptta_launch_loss_forward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
-                                 c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info, s));
+                                 c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info, s, 1));
     RUN(ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
-                                  c->N, c->H, c->W, c->loss_ws, c->g_final, c->gref_buf, s));
+                                  c->N, c->H, c->W, c->loss_ws, c->g_final, c->gref_buf, s, c->hyper + 5, c->loss_info));
     RUN(ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_));
     RUN(ptta_adam_step(c, nullptr, nullptr, s_));
     return 0;
@@ -1249,6 +1268,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
         if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
         if (!c->gexec[key]) {
             RUN(ensure_proxy_rgb(c, c->in_image, s));        // outside the capture: the graph holds the real-frame encoder only
+            RUN(ensure_adam_table(c, s));
             if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
             HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
             const int rc = step_body(c, c->in_image, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse,

@@ -104,10 +104,12 @@ int ptta_loss_ws_floats(int N, int H, int W, long R);
 int ptta_launch_loss_forward(const float* depth, const float* image, const float* sparse, const float* validity,
                              float max_input_depth, const float* emb, const float* ref, long R, int D,
                              const float* w3_dev /* w_sd, w_sm, w_cos */, int N, int H, int W,
-                             float* ws, float* loss_info, hipStream_t s);
+                             float* ws, float* loss_info, hipStream_t s, int defer_finalize = 0);
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
-                              int N, int H, int W, const float* ws, float* gdepth, float* gref, hipStream_t s);
+                              int N, int H, int W, float* ws, float* gdepth, float* gref, hipStream_t s, const float* w3_fused = nullptr,
+                              float* loss_info_fused = nullptr);
+// validity may be NULL in both calls: where(sparse > 0, 1, sparse) is then computed on the fly (src/tta_main.py:583-586)
 
 int ptta_launch_eval_metrics(const float* depth, const float* gt, long n, float min_eval, float max_eval, double* scratch, float* out4,
                              hipStream_t s);
@@ -133,6 +135,9 @@ int ptta_launch_bn2d_bwd_finalize(const float* part, int nblocks, long R, const 
 int ptta_launch_adam(float* p, float* m, float* v, const float* g, long n, const float* hyper /*lr,b1,b2,eps,wd*/,
                      const int* step_dev, hipStream_t s);
 int ptta_launch_step_inc(int* step_dev, hipStream_t s);
+// every adapted tensor in one launch; also increments the step count (torch.optim.Adam's state['step'])
+struct PttaAdamEntry { float *p, *m, *v; const float* g; long n, off; };
+int ptta_launch_adam_multi(const PttaAdamEntry* tab_dev, int nt, long total, const float* hyper, int* step_dev, unsigned* ticket_dev, hipStream_t s);
 int ptta_launch_set_floats(float* dst, const float* host_src, int n /*<= 8*/, hipStream_t s);   // by kernel argument: no sync
 int ptta_launch_set_int(int* dst, int v, hipStream_t s);
 

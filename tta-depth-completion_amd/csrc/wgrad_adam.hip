@@ -120,6 +120,41 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
     }
 }
 
+// All adapted tensors in ONE launch (NLSPN adapts 88 tensors, CostDCNet 32: one ~5 us launch each otherwise), the step
+// count incremented by the last block to finish: t = *step + 1 is what every block uses, *step = t is written once all
+// blocks are done reading it.
+__global__ __launch_bounds__(256) void adam_multi_kernel(const PttaAdamEntry* __restrict__ tab, int nt, long total, const float* __restrict__ hyper,
+                                                         int* step, unsigned* ticket) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4];
+    const int t = *step + 1;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2s = (float)sqrt(bc2);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nt - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].off <= idx) lo = mid; else hi = mid - 1; }
+        const PttaAdamEntry e = tab[lo];
+        const long k = idx - e.off;
+        float gg = e.g[k];
+        const float pk = e.p[k];
+        if (wd != 0.f) gg = fmaf(wd, pk, gg);
+        const float mk = b1 * e.m[k] + (1.f - b1) * gg;
+        const float vk = b2 * e.v[k] + (1.f - b2) * gg * gg;
+        e.m[k] = mk; e.v[k] = vk;
+        e.p[k] = pk - step_size * (mk / (sqrtf(vk) / bc2s + eps));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(ticket, 1u);
+        if (done == gridDim.x - 1) { *step = t; *ticket = 0u; }
+    }
+}
+int ptta_launch_adam_multi(const PttaAdamEntry* tab_dev, int nt, long total, const float* hyper, int* step_dev, unsigned* ticket_dev, hipStream_t s) {
+    long blocks = (total + 255) / 256; if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((int)blocks), dim3(256), 0, s, tab_dev, nt, total, hyper, step_dev, ticket_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 __global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
 
 // Small host constants travel as KERNEL ARGUMENTS (copied at launch), so setting hyper-parameters, loss weights or the

@@ -74,13 +74,19 @@ __global__ void cd_clamp_kernel(const float* __restrict__ src, float* __restrict
 // level l holds voxels (frame, plane z, y, x) whose y, x are multiples of ts = 1 << l (tensor stride (1, ts, ts)); `vol` is
 // the dense index volume [N][16][H >> l][W >> l] (-1 = empty); points are numbered in (frame, plane, row, column) order by a
 // row count + scan + fill, so every reduction over points has a fixed order.
-__global__ void cd_l0_rowcount_kernel(const float* __restrict__ sparse, int N, int H, int W, float z_step, int* __restrict__ rowcnt) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ int cd_plane_of(float d, float z_step) { int z = (int)rintf(d / z_step); return z < 0 ? 0 : (z > 15 ? 15 : z); }
+// one wave per image row: lanes stride over the columns, ballot + popcount
+__global__ __launch_bounds__(256) void cd_l0_rowcount_kernel(const float* __restrict__ sparse, int N, int H, int W, float z_step, int* __restrict__ rowcnt) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N * H) return;
     const float* sp = sparse + (long)row * W;
     int c = 0;
-    for (int x = 0; x < W; ++x) { int z = (int)rintf(sp[x] / z_step); z = z < 0 ? 0 : (z > 15 ? 15 : z); c += z != 0; }
-    rowcnt[row] = c;
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool on = x < W && cd_plane_of(sp[x], z_step) != 0;
+        c += __popcll(__ballot(on));
+    }
+    if (lane == 0) rowcnt[row] = c;
 }
 // single block: exclusive scan of `n` counts -> offsets; total -> *cnt
 __global__ __launch_bounds__(1024) void cd_scan_kernel(const int* __restrict__ cntin, int n, int* __restrict__ off, int* __restrict__ total) {
@@ -108,21 +114,26 @@ __global__ __launch_bounds__(1024) void cd_scan_kernel(const int* __restrict__ c
 }
 // depth2MDP (CD:356-388): plane = clamp(round(d / z_step), 0, 15) (round half to even like torch.round), voxel kept when
 // plane != 0, feature = (d - plane * z_step) / z_step
-__global__ void cd_l0_fill_kernel(const float* __restrict__ sparse, int N, int H, int W, float z_step, const int* __restrict__ rowoff,
-                                  int4* __restrict__ coords, float* __restrict__ feat, int* __restrict__ vol) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void cd_l0_fill_kernel(const float* __restrict__ sparse, int N, int H, int W, float z_step, const int* __restrict__ rowoff,
+                                                         int4* __restrict__ coords, float* __restrict__ feat, int* __restrict__ vol) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N * H) return;
     const int n = row / H, y = row % H;
     const float* sp = sparse + (long)row * W;
-    int id = rowoff[row];
-    for (int x = 0; x < W; ++x) {
-        const float d = sp[x];
-        int z = (int)rintf(d / z_step); z = z < 0 ? 0 : (z > 15 ? 15 : z);
-        if (z == 0) continue;
-        coords[id] = make_int4(n, z, y, x);
-        feat[id] = (d - (float)z * z_step) / z_step;
-        vol[(((long)n * 16 + z) * H + y) * W + x] = id;
-        ++id;
+    int base = rowoff[row];
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const float d = x < W ? sp[x] : 0.f;
+        const int z = cd_plane_of(d, z_step);
+        const bool on = x < W && z != 0;
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int id = base + __popcll(m & ((1ull << lane) - 1ull));          // column order within the row
+            coords[id] = make_int4(n, z, y, x);
+            feat[id] = (d - (float)z * z_step) / z_step;
+            vol[(((long)n * 16 + z) * H + y) * W + x] = id;
+        }
+        base += __popcll(m);
     }
 }
 // coarser level: mark the cells floor(c / 2) of the finer level's voxels (idempotent stores), then count / scan / fill
@@ -132,20 +143,28 @@ __global__ void cd_mark_kernel(const int4* __restrict__ coords, const int* __res
         vol[(((long)c.x * 16 + c.y) * Hc + (c.z >> shift)) * Wc + (c.w >> shift)] = -2;          // occupied, id assigned below
     }
 }
-__global__ void cd_lc_rowcount_kernel(const int* __restrict__ vol, int rows, int Wc, int* __restrict__ rowcnt) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void cd_lc_rowcount_kernel(const int* __restrict__ vol, int rows, int Wc, int* __restrict__ rowcnt) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     int c = 0;
-    for (int x = 0; x < Wc; ++x) c += vol[(long)row * Wc + x] != -1;
-    rowcnt[row] = c;
+    for (int x0 = 0; x0 < Wc; x0 += 64) { const int x = x0 + lane; c += __popcll(__ballot(x < Wc && vol[(long)row * Wc + x] != -1)); }
+    if (lane == 0) rowcnt[row] = c;
 }
-__global__ void cd_lc_fill_kernel(int* __restrict__ vol, int rows, int Hc, int Wc, int shift, const int* __restrict__ rowoff, int4* __restrict__ coords) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void cd_lc_fill_kernel(int* __restrict__ vol, int rows, int Hc, int Wc, int shift, const int* __restrict__ rowoff, int4* __restrict__ coords) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const int y = row % Hc, z = (row / Hc) % 16, n = row / (Hc * 16);
-    int id = rowoff[row];
-    for (int x = 0; x < Wc; ++x)
-        if (vol[(long)row * Wc + x] != -1) { vol[(long)row * Wc + x] = id; coords[id] = make_int4(n, z, y << shift, x << shift); ++id; }
+    int base = rowoff[row];
+    for (int x0 = 0; x0 < Wc; x0 += 64) {
+        const int x = x0 + lane;
+        const bool on = x < Wc && vol[(long)row * Wc + x] != -1;
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int id = base + __popcll(m & ((1ull << lane) - 1ull));
+            vol[(long)row * Wc + x] = id; coords[id] = make_int4(n, z, y << shift, x << shift);
+        }
+        base += __popcll(m);
+    }
 }
 __global__ void cd_fill_int_kernel(int* __restrict__ p, long n, int v) { GRID_STRIDE(i, n) p[i] = v; }
 
@@ -193,6 +212,7 @@ __global__ void cd_sbn_finalize_kernel(const float* __restrict__ part, const int
     float mu, var;
     if (train) {
         double s1 = 0.0, s2 = 0.0;
+#pragma unroll 8
         for (int b = 0; b < SBN_BLOCKS; ++b) { s1 += (double)part[((long)b * 2) * C + c]; s2 += (double)part[((long)b * 2 + 1) * C + c]; }
         const double R = (double)(*cnt > 0 ? *cnt : 1);
         const double m = s1 / R; double v = s2 / R - m * m; if (v < 0.0) v = 0.0;
@@ -425,15 +445,15 @@ int cd_sparse_levels_build(const CdSparse& q, const float* sparse, float z_step,
     const int N = q.N, H = q.H, W = q.W;
     for (int l = 0; l < 3; ++l)
         hipLaunchKernelGGL(cd_fill_int_kernel, dim3(nbk((long)N * 16 * (H >> l) * (W >> l))), dim3(256), 0, s, q.vol[l], (long)N * 16 * (H >> l) * (W >> l), -1);
-    hipLaunchKernelGGL(cd_l0_rowcount_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, sparse, N, H, W, z_step, q.rowcnt);
+    hipLaunchKernelGGL(cd_l0_rowcount_kernel, dim3((N * H + 3) / 4), dim3(256), 0, s, sparse, N, H, W, z_step, q.rowcnt);
     hipLaunchKernelGGL(cd_scan_kernel, dim3(1), dim3(1024), 0, s, q.rowcnt, N * H, q.rowoff, q.cnt + 0);
-    hipLaunchKernelGGL(cd_l0_fill_kernel, dim3((N * H + 255) / 256), dim3(256), 0, s, sparse, N, H, W, z_step, q.rowoff, q.coords[0], q.feat_in, q.vol[0]);
+    hipLaunchKernelGGL(cd_l0_fill_kernel, dim3((N * H + 3) / 4), dim3(256), 0, s, sparse, N, H, W, z_step, q.rowoff, q.coords[0], q.feat_in, q.vol[0]);
     for (int l = 1; l < 3; ++l) {
         const int Hc = H >> l, Wc = W >> l, rows = N * 16 * Hc;
         hipLaunchKernelGGL(cd_mark_kernel, dim3(1024), dim3(256), 0, s, q.coords[l - 1], q.cnt + (l - 1), l, Hc, Wc, q.vol[l]);
-        hipLaunchKernelGGL(cd_lc_rowcount_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, q.vol[l], rows, Wc, q.rowcnt);
+        hipLaunchKernelGGL(cd_lc_rowcount_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, q.vol[l], rows, Wc, q.rowcnt);
         hipLaunchKernelGGL(cd_scan_kernel, dim3(1), dim3(1024), 0, s, q.rowcnt, rows, q.rowoff, q.cnt + l);
-        hipLaunchKernelGGL(cd_lc_fill_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, q.vol[l], rows, Hc, Wc, l, q.rowoff, q.coords[l]);
+        hipLaunchKernelGGL(cd_lc_fill_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, q.vol[l], rows, Hc, Wc, l, q.rowoff, q.coords[l]);
     }
     LAUNCH_OK();
 }

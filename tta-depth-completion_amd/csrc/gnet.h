@@ -57,6 +57,7 @@ struct GConvW {            // convolution weights, packed at load time (frozen) 
     int vcol = 0;                                         // 3x1x1 Conv3d stored as a 3x3 filter with only the middle column set
     float* gpad = nullptr;                                // zero-padded copy of the output gradient (Co_pad channels)
     bf16_t *ff_hi = nullptr, *ff_lo = nullptr, *fb_hi = nullptr, *fb_lo = nullptr;     // bf16x3 MFMA fragments (forward / data gradient)
+    bf16_t *fb1_hi = nullptr, *fb1_lo = nullptr;          // data-gradient fragments of the SECOND source when its channel offset is not a multiple of 32
     bool mf = false, mb = false;                          // matrix-core kernel usable for forward / data gradient
     bool loaded = false, has_bias = false;
     long gpad_pix = 0;
@@ -191,7 +192,7 @@ struct GNet {
         cw.Ci = T[x0].C + (x1 >= 0 ? T[x1].C : 0); cw.Co = T[y].C; cw.k = k; cw.stride = stride; cw.transposed = transposed;
         cw.C0 = T[x0].C; cw.C1 = x1 >= 0 ? T[x1].C : 0;
         cw.mf = !naive && (stride == 1 && !transposed ? (cw.C0 % 8) == 0 && (cw.C1 % 8) == 0 : (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0);
-        cw.mb = !naive && ((cw.Co % 16) == 0 || (stride == 1 && !transposed)) && (cw.C1 == 0 || (cw.C0 % 32) == 0);
+        cw.mb = !naive && ((cw.Co % 16) == 0 || (stride == 1 && !transposed));
         cw.Co_pad = (cw.Co + 15) / 16 * 16;               // data gradient of a conv with < 16 output channels: gy is zero-padded
         const long pix = (long)T[y].per * T[y].H * T[y].W;
         if (pix > cw.gpad_pix) cw.gpad_pix = pix;
@@ -272,6 +273,7 @@ struct GNet {
             if (cw.mf) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.C0, cw.C1, cw.Co); cw.ff_hi = (bf16_t*)dalloc(n * 2); cw.ff_lo = (bf16_t*)dalloc(n * 2); }
             if (cw.mb && !cw.Ci_real && cw.Co_pad != cw.Co) cw.gpad = falloc((size_t)cw.gpad_pix * cw.Co_pad);
             if (cw.mb && !cw.Ci_real) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.Ci); cw.fb_hi = (bf16_t*)dalloc(n * 2); cw.fb_lo = (bf16_t*)dalloc(n * 2); }
+            if (cw.mb && !cw.Ci_real && cw.C1 > 0 && (cw.C0 % 32) != 0) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.C1); cw.fb1_hi = (bf16_t*)dalloc(n * 2); cw.fb1_lo = (bf16_t*)dalloc(n * 2); }
             const size_t n = (size_t)KK * cw.Ci * cw.Co;
             cw.wf = falloc(n); cw.wb = falloc(n); cw.bias = falloc(cw.Co);
         }
@@ -283,6 +285,8 @@ struct GNet {
         if (cw.mf && cw.Ci_real) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci_real * cw.Co, KK, cw.Ci_real, 0, 0, 0, cw.Co, cw.ff_hi, cw.ff_lo, s);
         else if (cw.mf) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci * cw.Co, KK, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);
         if (cw.mb && !cw.Ci_real) ptta_gfrag_pack(cw.wb, cw.Ci, (long)cw.Co * cw.Ci, KK, cw.Co, 0, 0, 0, cw.Ci, cw.fb_hi, cw.fb_lo, s);
+        // second source at a channel offset that is not a tile boundary: its own fragment set (columns C0.. of the packed matrix)
+        if (cw.fb1_hi) ptta_gfrag_pack(cw.wb + cw.C0, cw.Ci, (long)cw.Co * cw.Ci, KK, cw.Co, 0, 0, 0, cw.C1, cw.fb1_hi, cw.fb1_lo, s);
     }
     // src: Conv2d (Co,Ci,k,k) / ConvTranspose2d (Ci,Co,k,k) / Linear (Co,Ci) weight
     void pack_conv_weight(GConvW& cw, const float* src, hipStream_t s) {

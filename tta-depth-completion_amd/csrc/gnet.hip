@@ -138,7 +138,8 @@ int GNet::run_conv_bwd(const Op& o, hipStream_t s) {
         if (!T[o.x[sidx]].need_grad) continue;
         GView gx = view(o.x[sidx], W_GRAD, true, true);
         review(gx, o.rH, o.rW);
-        if (cw.mb && (o.c0[sidx] % 32) == 0) {
+        const bool own_frags = sidx == 1 && cw.fb1_hi != nullptr;
+        if (cw.mb && ((o.c0[sidx] % 32) == 0 || own_frags)) {
             GX3Args a;
             a.x0 = gy.p; a.C0 = gy.C; a.ld0 = gy.ld;
             if (cw.gpad) {                                   // < 16 gradient channels: matrix-core kernel on a zero-padded copy
@@ -149,8 +150,8 @@ int GNet::run_conv_bwd(const Op& o, hipStream_t s) {
                 }
                 a.x0 = cw.gpad; a.C0 = cw.Co_pad; a.ld0 = cw.Co_pad;
             }
-            a.whi = (const uint4*)cw.fb_hi; a.wlo = (const uint4*)cw.fb_lo;
-            a.nchunks = (a.C0 + 31) / 32; a.nf0 = o.c0[sidx] / 32; a.nnf = (gx.C + 31) / 32;
+            a.whi = (const uint4*)(own_frags ? cw.fb1_hi : cw.fb_hi); a.wlo = (const uint4*)(own_frags ? cw.fb1_lo : cw.fb_lo);
+            a.nchunks = (a.C0 + 31) / 32; a.nf0 = own_frags ? 0 : o.c0[sidx] / 32; a.nnf = (gx.C + 31) / 32;
             a.y = gx.p; a.ldy = gx.ld; a.Cy = gx.C; a.accumulate = o.first_x[sidx] ? 0 : 1;
             a.B = gx.B; a.H = gx.H; a.W = gx.W;                  // output geometry = the source's
             int rc;

@@ -28,10 +28,16 @@ def test_other_config_shapes_against_oracle(shape):
     assert rel_mae(depth, r['depth']) < 1e-4
     li = r['loss_info']
     np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=2e-4)
-    # the post-update depth also carries the (sign-flip) gradient noise of the step through Adam; with 1500-point
-    # indoor frames the depth itself is O(1), so hold it to the north_star tolerance, not tighter
+    # the post-update depth also carries the (sign-flip) gradient noise of the step through Adam (entries with a near-zero
+    # gradient move by +-lr either way); with 1500-point indoor frames the depth itself is O(1): a bound for this path's own
+    # update, and the tight check from the ORACLE's post-step parameters
+    ref_eval = o.forward_eval(torch.from_numpy(image), torch.from_numpy(sparse))
     d_eval = eng.forward_eval(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())
-    assert rel_mae(d_eval, o.forward_eval(torch.from_numpy(image), torch.from_numpy(sparse))) < 1e-3
+    assert rel_mae(d_eval, ref_eval) < 3e-3
+    for k, (prm, m, v) in adapted.items():
+        prm.copy_(o.P[k].detach())
+    d_eval = eng.forward_eval(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())
+    assert rel_mae(d_eval, ref_eval) < 1e-4
     eng.close()
 
 

@@ -19,6 +19,7 @@
 // CONV_T2 (transposed, stride 2, pad 1, output_padding 1; a tile = 32 outputs of one x-parity so
 // that the active taps are wave-uniform).
 #include <cstdlib>
+#include <cstring>
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -320,7 +321,11 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
 // fragment (8 fp32 channels of one input pixel) is split into bf16 hi/lo in registers and fed to
 // three bf16 MFMAs.  The hi weight fragments are wave-stationary in VGPRs, the lo fragments sit
 // in LDS (loaded once per block).  Input lines are re-read from L1/L2 by neighbouring taps
-// (2.25x for stride 2), which is cheaper here than an 84 KB halo tile in LDS.
+// (2.25x for stride 2), which is cheaper here than an 84 KB halo tile in LDS.  Round 2 built the LDS-staged,
+// input-stationary transposed form (8x32 input tile, four parity accumulators per input row, 16 instead of 36 ds_reads):
+// faster kernel by kernel (forward 35 -> 18 us at full resolution) but SLOWER in the replayed step (2.396 vs 2.384 ms, same
+// box): its 79 KB of LDS cannot share a CU with the 120 KB GEMM blocks of the heads that run beside decoder 3, this
+// form's 18 KB can -- reverted; see DESIGN.md §8.
 template <int MODE, bool RELU, bool UP, bool MASK, bool ADD>
 __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float> p) {
     __shared__ __attribute__((aligned(16))) unsigned char wl_lds[18 * 64 * 16];

@@ -53,7 +53,12 @@ enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };
 /* NLSPN only, OR-ed into meta_mode: ExternalModel_Adapt(..., offset=True) -> args.legacy (src/nlspn_model_adapt.py:62):
  * the confidence gathers add each tap's own (dy, dx) to the learned offset (nlspnmodel_adapt.py:297-302).
  * src/tta_main.py:309-317 always constructs the model this way. */
-enum { PTTA_NLSPN_LEGACY_OFFSET = 0x100 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
+enum { PTTA_NLSPN_LEGACY_OFFSET = 0x100,
+       /* NLSPN, OR-ed into meta_mode: the adapted list of the reference's DDP run.  tta_main.py:326 converts every BatchNorm to
+        * SyncBatchNorm BEFORE adapt_parameters('meta_bn') (:339), whose isinstance test (src/nlspn_model_adapt.py:329-331) then
+        * also matches the heads' three BatchNorm1d: 94 adapted tensors (proj.1, proj_t.1, pred.1 weight/bias appended in
+        * module order) instead of 88.  proj / pred feed the detached embedding: their gradients stay zero. */
+       PTTA_NLSPN_SYNCBN_ADAPT = 0x200 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
 
 /* Hyper-parameters of the step.  Reference: src/tta.py:10-160 flags learning_rates,
  * optimizer_betas, optimizer_epsilon, w_weight_decay, w_loss_sparse_depth, w_loss_smoothness,
@@ -177,6 +182,17 @@ int ptta_set_image_norm(ptta_handle h, float divisor, const float* mean, const f
 
 /* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
  * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
+/* model.convert_syncbn() (src/tta_main.py:326 -> SyncBatchNorm.convert_sync_batchnorm, src/msg_chn_model_adapt.py:547-556)
+ * for the one-process-per-GPU run with shared adapted parameters: every training-mode BatchNorm then normalises with
+ * the statistics of the GLOBAL batch.  The library collapses a BatchNorm's partial sums into `exchange_buf` (device,
+ * float64, caller-owned, `capacity` elements >= 2 * 2 * widest BatchNorm), calls `fn(user, exchange_buf, count, stream)`
+ * -- which must SUM the first `count` elements over the ranks in place, ordered on `stream` (torch.distributed.all_reduce
+ * on RCCL does exactly that) -- and finalises with world_size x the local row count (equal local batches).  Gradients of
+ * adapted BatchNorm parameters come out already averaged over the ranks.  world_size 1 switches the exchange off.
+ * MSG_CHN handles replay no hipGraph while it is on. */
+typedef int (*ptta_allreduce_fn)(void* user, double* exchange_buf, long long count, ptta_stream s);
+int ptta_set_stat_sync(ptta_handle h, ptta_allreduce_fn fn, void* user, double* exchange_buf, int64_t capacity, int world_size);
+
 int ptta_set_graph(ptta_handle h, int enable);
 
 /* Measurement hook for bench.py: while enabled, every launch of the 3x3 32->32 convolution kernel

@@ -175,13 +175,13 @@ def model_forward(P, image, sparse_depth, training, max_input_depth=None, prop_t
     return network_forward(P, image, sparse_depth, training, prop_time, legacy)
 
 
-def adapted_names(P):
+def adapted_names(P, syncbn=False):
     """adapt_parameters('meta_bn') (AD:322-337) without SyncBatchNorm conversion: every parameter whose name
     contains 'meta', then weight/bias of every BatchNorm2d in module order (the heads' BatchNorm1d are not
     BatchNorm2d; after convert_syncbn (src/tta_main.py:326) they would be SyncBatchNorm and join the list)."""
     names = [k for k in P if 'meta' in k]
     for k in P:
-        if k.endswith('.running_mean') and not k.startswith(('proj', 'pred')):
+        if k.endswith('.running_mean') and (syncbn or not k.startswith(('proj', 'pred'))):
             pre = k[:-len('.running_mean')]
             names += [pre + '.weight', pre + '.bias']
     return names
@@ -191,11 +191,11 @@ class NlspnOracle:
     """model + Adam; ``step()`` = src/tta_main.py:583-633, ``forward_eval`` = :729-736."""
 
     def __init__(self, state_dict, max_input_depth=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 w_sd=1.0, w_sm=1.0, w_cos=1.0, prop_time=18, legacy=False):
+                 w_sd=1.0, w_sm=1.0, w_cos=1.0, prop_time=18, legacy=False, syncbn_adapted=False):
         self.P = {k: torch.as_tensor(v).clone() for k, v in state_dict.items()}
         self.max_input_depth = max_input_depth
         self.prop_time, self.legacy = prop_time, legacy
-        self.names = adapted_names(self.P)
+        self.names = adapted_names(self.P, syncbn_adapted)        # True: the 94-tensor list of the reference's DDP run
         for k in self.names:
             self.P[k].requires_grad_(True)
         self.opt = AdamState([self.P[k] for k in self.names], lr, betas, eps, weight_decay)

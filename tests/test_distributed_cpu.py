@@ -85,3 +85,30 @@ def test_bench_refuses_mismatched_world():
     r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--plumbing-only'], cwd=root, capture_output=True, text=True,
                        env=dict(os.environ, RANK='0', WORLD_SIZE='4'), timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE' in r.stderr
+
+
+def _syncbn_worker(rank, world, port, out):
+    """The SyncBatchNorm exchange protocol of ptta_set_stat_sync, in torch on CPU: per-rank {sum, sum of squares} -> SUM
+    all-reduce -> finalize with world x the local row count == BatchNorm over the concatenated batch."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    x_all = torch.randn(2 * 96, 32, generator=g) * 3 + 1.5
+    x = x_all[rank * 96:(rank + 1) * 96]
+    sums = torch.stack([x.double().sum(0), (x.double() ** 2).sum(0)])       # "collapse": double sums of the local partials
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)                             # the callback
+    R = world * x.shape[0]                                                  # finalize with world x local rows
+    mean = sums[0] / R
+    var = sums[1] / R - mean ** 2
+    y = (x - mean.float()) / torch.sqrt(var.float() + 1e-5)
+    ref = torch.nn.functional.batch_norm(x_all, None, None, None, None, True, 0.0, 1e-5)[rank * 96:(rank + 1) * 96]
+    out[rank] = bool(torch.allclose(y, ref, atol=2e-5))
+    dist.destroy_process_group()
+
+
+def test_syncbn_exchange_protocol_equals_global_batchnorm():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_syncbn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] and out[1]

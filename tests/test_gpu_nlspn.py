@@ -336,3 +336,57 @@ def test_full_size_step_matches_reference(golden_dir, name):
     # the reference's eval output BEFORE its skimage hole filling (exact zeros stay zeros on both sides)
     _check_map(eng.forward_eval(image1, sparse), g, 's0/depth_eval', 1e-3)
     eng.close()
+
+
+def test_syncbn_adapted_list_has_94_tensors():
+    """tta_main.py:326 converts to SyncBatchNorm BEFORE adapt_parameters('meta_bn'): the heads' BatchNorm1d join the adapted
+    list (94 tensors, module order proj.1, proj_t.1, pred.1).  proj_t carries the cosine-term gradient; proj / pred feed the
+    detached embedding and keep zero gradients.  Gradients and the update against the oracle with the same list."""
+    from oracle import nlspn_oracle as N
+    n, h, w = 1, 32, 64
+    eng = Engine(n, h, w, backbone='nlspn', syncbn_adapted=True, **HP)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
+    eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32})
+    adapted = {}
+    for k in eng.adapted:
+        p = sd[k].clone().contiguous()
+        adapted[k] = (p, torch.zeros_like(p), torch.zeros_like(p))
+        eng.bind_adapted(k, *adapted[k])
+    o = N.NlspnOracle(synth.formula_state_dict_nlspn(), max_input_depth=HP['max_input_depth'], lr=HP['lr'], w_sd=1.0, w_sm=2.0, w_cos=0.1,
+                      syncbn_adapted=True)
+    assert len(eng.adapted) == 94 and eng.adapted == o.names
+    assert eng.adapted[-6:] == ['proj.1.weight', 'proj.1.bias', 'proj_t.1.weight', 'proj_t.1.bias', 'pred.1.weight', 'pred.1.bias']
+    raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(0, h, w, n)]
+    r = o.step(image1, sparse, loss_image=raw)
+    eng.step(image1.cuda(), sparse.cuda(), loss_image=raw.cuda())
+    for k in ('proj_t.1.weight', 'proj_t.1.bias'):
+        assert rel_mae(eng.grad(k, adapted[k][0]), r['grads'][k]) < TOL['default']['grad'], k
+        assert rel_mae(adapted[k][0], o.P[k].detach()) < TOL['default']['param'], k
+    for k in ('proj.1.weight', 'pred.1.bias'):
+        assert float(eng.grad(k, adapted[k][0]).abs().max()) == 0.0 and torch.equal(adapted[k][0], sd[k])
+    eng.close()
+
+
+def test_heads_batchnorm_buffers_are_updated():
+    """meta_bn drops the running statistics of BatchNorm2d only: the heads' BatchNorm1d stay in train mode WITH tracking, so
+    every TTA step moves proj / proj_t / pred running_mean, running_var (momentum 0.1, unbiased) and num_batches_tracked --
+    what save_model writes after adaptation."""
+    n, h, w = 1, 32, 64
+    eng = Engine(n, h, w, backbone='nlspn', **HP)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
+    eng.load_state_dict(sd)
+    for k in eng.adapted:
+        p = sd[k].clone().contiguous()
+        eng.bind_adapted(k, p, torch.zeros_like(p), torch.zeros_like(p))
+    before = {k: sd[k].clone() for k in sd if k.startswith(('proj', 'pred')) and 'running' in k}
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+    eng.forward_train(image1, sparse)
+    hpre = eng.debug_tensor('proj_t.h').view(-1, 1024)          # pre-BatchNorm activations of proj_t
+    torch.cuda.synchronize()
+    exp_mean = 0.9 * before['proj_t.1.running_mean'] + 0.1 * hpre.mean(0)
+    exp_var = 0.9 * before['proj_t.1.running_var'] + 0.1 * hpre.var(0, unbiased=True)
+    assert rel_mae(sd['proj_t.1.running_mean'], exp_mean) < 1e-4 and rel_mae(sd['proj_t.1.running_var'], exp_var) < 1e-4
+    for k in ('proj.1', 'proj_t.1', 'pred.1'):
+        assert int(sd[k + '.num_batches_tracked']) == 1
+        assert not torch.equal(sd[k + '.running_mean'], before[k + '.running_mean'])
+    eng.close()

@@ -1,0 +1,110 @@
+"""Shared-parameter multi-rank mode = the reference's actual DDP run (src/tta_main.py:326-354): SyncBatchNorm statistics over
+the global batch (ptta_set_stat_sync) + mean all-reduce of the adapted-parameter gradients.  Two ranks (two processes on
+the one GPU of the test box, gloo backend: the collectives are the same calls as with RCCL) with HALF a batch each must
+reproduce the reference's single-process batch-2 golden run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, backbone, out):
+    for p in (ROOT, os.path.join(ROOT, 'tta-depth-completion_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from proxytta import distributed as D
+    from proxytta import synth
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    res = {}
+    if backbone == 'msg_chn':
+        from tests.util import golden_hp, make_engine
+        g = np.load(os.path.join(GOLD, 'msgchn_1layer_32x48_n2.npz'))
+        h, w, n, steps = [int(x) for x in g['meta']]
+        hp, gain = golden_hp(g)
+        eng, sd, adapted = make_engine(1, h, w, 'fp32', hp, gain, None)
+        eng.enable_stat_sync()
+        for s in range(steps):
+            image, sparse = [torch.from_numpy(x[rank:rank + 1]).cuda() for x in synth.synthetic_frame(s, h, w, n)]
+            info, depth = D.shared_parameter_step(eng, image, sparse)
+            res['s%d/info' % s] = info.cpu().numpy()
+            res['s%d/depth' % s] = depth.cpu().numpy()
+            for k, (prm, m, v) in adapted.items():
+                res['s%d/param/%s' % (s, k)] = prm.cpu().numpy().copy()
+                res['s%d/grad/%s' % (s, k)] = eng.grad(k, prm).cpu().numpy()
+            for k in ('proj.1.running_mean', 'pred.1.running_var'):
+                res['s%d/buf/%s' % (s, k)] = sd[k].cpu().numpy().copy()
+            res['s%d/eval' % s] = eng.forward_eval(image, sparse).cpu().numpy()
+    else:
+        from tests.test_gpu_costdcnet import costdc_frame, make_costdc
+        g = np.load(os.path.join(GOLD, 'costdcnet_64x64_n2.npz'))
+        h, w, n, steps = [int(x) for x in g['meta']]
+        eng, sd, adapted = make_costdc(1, h, w)
+        eng.enable_stat_sync()
+        raw, image1, sparse = [torch.from_numpy(x[rank:rank + 1]).cuda() for x in costdc_frame(0, h, w, n, float(g['density']))]
+        depth, emb, ref = eng.forward_train(image1, sparse)
+        res['depth'] = depth.cpu().numpy()
+        res['buf'] = sd['unet3d.inc.double_conv.0.bn1.running_mean'].cpu().numpy().copy()
+    out[rank] = res
+    eng.close()
+    dist.destroy_process_group()
+
+
+def _run(backbone):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), backbone, out), nprocs=2, join=True)
+    return out[0], out[1]
+
+
+def test_two_ranks_reproduce_the_batch2_reference_run():
+    from tests.util import rel_mae
+    r0, r1 = _run('msg_chn')
+    g = np.load(os.path.join(GOLD, 'msgchn_1layer_32x48_n2.npz'))
+    steps = int(g['meta'][3])
+    for s in range(steps):
+        p = 's%d/' % s
+        depth = np.concatenate([r0[p + 'depth'], r1[p + 'depth']], 0)
+        assert rel_mae(depth, g[p + 'depth_train']) < 1e-4                  # heads' BatchNorm does not touch the depth; the step count does
+        # loss terms are means over the batch: the reference's batch-2 values are the averages of the two ranks' values
+        np.testing.assert_allclose(0.5 * (r0[p + 'info'] + r1[p + 'info']), g[p + 'loss_info'], rtol=1e-4)
+        for k in ('conv1_rgb_meta.weight', 'conv1_rgb_meta.bias'):
+            assert np.array_equal(r0[p + 'param/' + k], r1[p + 'param/' + k])     # identical update on every rank
+            # each rank holds the gradient of ITS local loss; DDP's mean over the ranks is the batch-2 gradient
+            assert rel_mae(0.5 * (r0[p + 'grad/' + k] + r1[p + 'grad/' + k]), g[p + 'grad/' + k]) < 3e-2, k
+            assert rel_mae(r0[p + 'param/' + k], g[p + 'param/' + k]) < 1e-3, k
+        # SyncBatchNorm: running statistics of the heads are those of the GLOBAL batch, identical on both ranks
+        for k in ('proj.1.running_mean', 'pred.1.running_var'):
+            assert np.array_equal(r0[p + 'buf/' + k], r1[p + 'buf/' + k])
+            assert rel_mae(r0[p + 'buf/' + k], g[p + 'buf/' + k]) < 1e-4, k
+        assert rel_mae(np.concatenate([r0[p + 'eval'], r1[p + 'eval']], 0), g[p + 'depth_eval']) < 1e-4
+
+
+def test_costdcnet_forward_with_global_batch_statistics():
+    """Every BatchNorm of CostDCNet (BatchNorm2d, BatchNorm3d, the sparse encoder's voxel BatchNorm with its per-rank voxel
+    counts) sees the global batch: two ranks with one frame each reproduce the depth and the tracked running statistics of
+    the reference's batch-2 forward."""
+    from tests.util import rel_mae
+    r0, r1 = _run('costdcnet')
+    g = np.load(os.path.join(GOLD, 'costdcnet_64x64_n2.npz'))
+    assert rel_mae(np.concatenate([r0['depth'], r1['depth']], 0), g['s0/depth_train']) < 1e-3
+    assert np.array_equal(r0['buf'], r1['buf'])
+    assert rel_mae(r0['buf'], g['s0/buf/unet3d.inc.double_conv.0.bn1.running_mean']) < 2e-3

@@ -1,6 +1,7 @@
 // Launch interface of costdc_kernels.hip (internal; CostDCNet backbone).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "ptta_kernels.h"
 
 // sparse voxel sets of the 3-D encoder: three levels with tensor stride (1, 1<<l, 1<<l); counts live on the device
 struct CdSparse {
@@ -22,7 +23,7 @@ int cd_launch_clamp(const float* src, float* dst, long n, float maxd, hipStream_
 int cd_sparse_levels_build(const CdSparse& q, const float* sparse, float z_step, hipStream_t s);
 int cd_launch_sparse_conv(const CdSparse& q, const float* fin, int lin, int lout, const float* Wk, int ksize, int Ci, int Co, float* fout, hipStream_t s);
 int cd_launch_sparse_bn(const CdSparse& q, const float* f, const float* res, int level, int C, const float* gamma, const float* beta, float* rm, float* rv,
-                        long long* nbt, int train, int repeats, int relu, float* out, hipStream_t s);
+                        long long* nbt, int train, int repeats, int relu, float* out, hipStream_t s, const PttaStatSync* sync = nullptr);
 int cd_launch_densify(const CdSparse& q, const float* f, int C, float* dense, hipStream_t s);
 int cd_launch_fusion_fwd(const float* feat2d, const float* feat3d, float* vol, float* maskw, int N, int passes, int h, int w, hipStream_t s);
 int cd_launch_fusion_bwd(const float* gvol, const float* maskw, float* gfeat2d, int N, int h, int w, hipStream_t s);

@@ -221,7 +221,7 @@ struct costdc_engine : GNet {
         SBn& b = sbn[n];
         if (!train && (!b.rm || !b.rv)) return fail("running statistics of " + n + " not loaded", -3);
         // train: the reference evaluates the sparse encoder once per pass on the same input (CD:216, :237): two updates
-        return cd_launch_sparse_bn(sp, f, res, level, b.C, b.g, b.b, b.rm, b.rv, b.nbt, train ? 1 : 0, 2, relu, out, s) ? fail("sparse batch-norm " + n + " failed", -5) : 0;
+        return cd_launch_sparse_bn(sp, f, res, level, b.C, b.g, b.b, b.rm, b.rv, b.nbt, train ? 1 : 0, 2, relu, out, s, &stat_sync) ? fail("sparse batch-norm " + n + " failed", -5) : 0;
     }
     int sparse_encoder(bool train, hipStream_t s) {
         if (cd_sparse_levels_build(sp, sp_clamp, z_step, s)) return fail("depth2MDP failed", -5);

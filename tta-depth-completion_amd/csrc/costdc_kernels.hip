@@ -204,17 +204,31 @@ __global__ __launch_bounds__(64) void cd_sbn_stats_kernel(const float* __restric
 }
 // train: batch statistics (biased variance), running statistics updated `repeats` times (the reference runs the sparse
 // encoder once per pass on the same input); eval: running statistics.  st = [scale, shift][C]
+// SyncBatchNorm over the ranks (MinkowskiBatchNorm wraps an nn.BatchNorm1d, which convert_sync_batchnorm converts too):
+// double sums {sum[C], sum^2[C], voxel count} for the caller's all-reduce
+__global__ void cd_sbn_collapse_kernel(const float* __restrict__ part, const int* __restrict__ cnt, int C, double* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) out[2 * C] = (double)(*cnt);
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < SBN_BLOCKS; ++b) { s1 += (double)part[((long)b * 2) * C + c]; s2 += (double)part[((long)b * 2 + 1) * C + c]; }
+    out[c] = s1; out[C + c] = s2;
+}
 __global__ void cd_sbn_finalize_kernel(const float* __restrict__ part, const int* __restrict__ cnt, int C, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float* rm, float* rv, long long* nbt, int train, int repeats, float* __restrict__ st) {
+                                       const float* __restrict__ beta, float* rm, float* rv, long long* nbt, int train, int repeats, float* __restrict__ st,
+                                       const double* __restrict__ gsum = nullptr) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && train && nbt) *nbt += repeats;
     if (c >= C) return;
     float mu, var;
     if (train) {
-        double s1 = 0.0, s2 = 0.0;
+        double s1 = 0.0, s2 = 0.0, R;
+        if (gsum) { s1 = gsum[c]; s2 = gsum[C + c]; R = gsum[2 * C] > 0.0 ? gsum[2 * C] : 1.0; }      // global sums / voxel count
+        else {
 #pragma unroll 8
-        for (int b = 0; b < SBN_BLOCKS; ++b) { s1 += (double)part[((long)b * 2) * C + c]; s2 += (double)part[((long)b * 2 + 1) * C + c]; }
-        const double R = (double)(*cnt > 0 ? *cnt : 1);
+            for (int b = 0; b < SBN_BLOCKS; ++b) { s1 += (double)part[((long)b * 2) * C + c]; s2 += (double)part[((long)b * 2 + 1) * C + c]; }
+            R = (double)(*cnt > 0 ? *cnt : 1);
+        }
         const double m = s1 / R; double v = s2 / R - m * m; if (v < 0.0) v = 0.0;
         mu = (float)m; var = (float)v;
         if (rm && rv) {
@@ -463,10 +477,18 @@ int cd_launch_sparse_conv(const CdSparse& q, const float* fin, int lin, int lout
                        Ci, Co, fout); LAUNCH_OK();
 }
 int cd_launch_sparse_bn(const CdSparse& q, const float* f, const float* res, int level, int C, const float* gamma, const float* beta, float* rm, float* rv,
-                        long long* nbt, int train, int repeats, int relu, float* out, hipStream_t s) {
+                        long long* nbt, int train, int repeats, int relu, float* out, hipStream_t s, const PttaStatSync* sync) {
     if (C > 64) return -22;
     if (train) hipLaunchKernelGGL(cd_sbn_stats_kernel, dim3(SBN_BLOCKS), dim3(64), 0, s, f, q.cnt + level, C, q.bn_part);
-    hipLaunchKernelGGL(cd_sbn_finalize_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, gamma, beta, rm, rv, nbt, train, repeats, q.bn_st);
+    const double* gsum = nullptr;
+    if (train && sync && sync->fn && sync->world > 1) {
+        if (2 * C + 1 > sync->cap) return -22;
+        hipLaunchKernelGGL(cd_sbn_collapse_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, sync->buf);
+        const int rc = sync->fn(sync->user, sync->buf, 2 * C + 1, (void*)s);
+        if (rc) return rc < 0 ? rc : -rc;
+        gsum = sync->buf;
+    }
+    hipLaunchKernelGGL(cd_sbn_finalize_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, gamma, beta, rm, rv, nbt, train, repeats, q.bn_st, gsum);
     hipLaunchKernelGGL(cd_sbn_apply_kernel, dim3(2048), dim3(256), 0, s, f, res, q.cnt + level, C, q.bn_st, relu, out); LAUNCH_OK();
 }
 int cd_launch_densify(const CdSparse& q, const float* f, int C, float* dense, hipStream_t s) {

@@ -90,6 +90,43 @@ __device__ __forceinline__ void gbn_sum_partials(const float* __restrict__ part,
     s1 = a1; s2 = a2;
 }
 
+// ---- SyncBatchNorm exchange (ptta_kernels.h: PttaStatSync) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stat_collapse_kernel(const float* __restrict__ part, int nblocks, int C, int npass, double* __restrict__ out) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);               // (pass, which, c): one wave each
+    if (idx >= npass * 2 * C) return;
+    const int c = idx % C, which = (idx / C) & 1, pass = idx / (2 * C);
+    const int lane = threadIdx.x & 63;
+    double a = 0.0;
+    for (int b = lane; b < nblocks; b += 64) a += (double)part[(((long)pass * nblocks + b) * 2 + which) * C + c];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m);
+    if (lane == 0) out[idx] = a;
+}
+__global__ void stat_expand_kernel(const double* __restrict__ in, int nblocks, int C, int npass, float* __restrict__ part) {
+    const long total = (long)npass * nblocks * 2 * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); long t_ = i / C;
+        const int which = (int)(t_ & 1); t_ >>= 1;
+        const int b = (int)(t_ % nblocks); const int pass = (int)(t_ / nblocks);
+        const double v = in[((long)pass * 2 + which) * C + c];
+        const float hi = (float)v;
+        part[i] = b == 0 ? hi : (b == 1 ? (float)(v - (double)hi) : 0.f);
+    }
+}
+int ptta_stat_sync(const PttaStatSync* sy, float* part, int nblocks, int C, int npass, hipStream_t s) {
+    if (!sy || !sy->fn || sy->world <= 1) return 0;
+    const long n = (long)npass * 2 * C;
+    if (n > sy->cap) return -22;
+    hipLaunchKernelGGL(stat_collapse_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblocks, C, npass, sy->buf);
+    if (hipGetLastError() != hipSuccess) return -5;
+    const int rc = sy->fn(sy->user, sy->buf, (long long)n, (void*)s);       // SUM over the ranks, in place, ordered on `s`
+    if (rc) return rc < 0 ? rc : -rc;
+    const long total = (long)npass * nblocks * 2 * C;
+    long blocks = (total + 255) / 256; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(stat_expand_kernel, dim3((int)blocks), dim3(256), 0, s, sy->buf, nblocks, C, npass, part);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
 // forward finalize: per (pass, c): mean, inv, scale = gamma*inv, shift = beta - mean*scale   (st = [4][npass][C])
 __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* __restrict__ part, int nblocks, int npass, int C, long R, float eps,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ st) {
@@ -142,14 +179,16 @@ __global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act
 // fused_blocks > 0: `part` was already filled by the producing convolution's epilogue ([pass][fused_blocks][2][C]), skip the
 // statistics pass
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
-                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks, int act_first) {
+                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks, int act_first, const PttaStatSync* sync) {
     const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
     const size_t lds = (size_t)nsub * 2 * CT * sizeof(float);
     const long R = (long)(x.B / npass) * x.H * x.W;
     int blocks = (int)((R + nsub - 1) / nsub); if (blocks > GBN_BLOCKS) blocks = GBN_BLOCKS; if (blocks < 1) blocks = 1;
     if (fused_blocks > 0) blocks = fused_blocks;
     else hipLaunchKernelGGL((gbn_stats_kernel<0>), dim3(blocks, npass), dim3(256), lds, s, x, x, x, npass, 0, 0, nullptr, nullptr, part);
-    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, R, eps, gamma, beta, st);
+    long Rg = R;
+    if (sync && sync->world > 1) { const int rc = ptta_stat_sync(sync, part, blocks, C, npass, s); if (rc) return rc; Rg = R * sync->world; }
+    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, Rg, eps, gamma, beta, st);
     if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
     const long total = (long)x.B * x.H * x.W * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
@@ -173,14 +212,16 @@ int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int 
 
 // backward finalize (pass 0 = the grad pass only): dbeta, dgamma, and bw = [gscale, c1, c2][C]
 __global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long R, const float* __restrict__ gamma,
-                                                               const float* __restrict__ inv, float* dgamma, float* dbeta, float* __restrict__ bw) {
+                                                               const float* __restrict__ inv, float* dgamma, float* dbeta, float* __restrict__ bw,
+                                                               float grad_scale = 1.f) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s1, s2;
     gbn_sum_partials(part, nblocks, C, c, s1, s2);
     if (threadIdx.x & 63) return;
-    if (dbeta) dbeta[c] = (float)s1;
-    if (dgamma) dgamma[c] = (float)s2;
+    // with SyncBatchNorm the sums are global: 1/world of them = the DDP-averaged local parameter gradients
+    if (dbeta) dbeta[c] = (float)s1 * grad_scale;
+    if (dgamma) dgamma[c] = (float)s2 * grad_scale;
     bw[c] = gamma[c] * inv[c]; bw[C + c] = (float)(s1 / (double)R); bw[2 * C + c] = (float)(s2 / (double)R);
 }
 
@@ -225,7 +266,7 @@ __global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView 
 // st: forward statistics [4][npass][C] (pass 0 is used).  dgamma/dbeta may be null (frozen affine parameters).
 int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, const GView& gx, const GView& gres, int npass, int act,
                              int res_relu, int acc_gx, int acc_gres, const float* gamma, const float* st, float* part, float* bw, float* dgamma,
-                             float* dbeta, hipStream_t s, int act_first) {
+                             float* dbeta, hipStream_t s, int act_first, const PttaStatSync* sync) {
     const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
     const size_t lds = (size_t)nsub * 2 * CT * sizeof(float);
     GView x0 = x; x0.B = g.B;
@@ -237,7 +278,9 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
     const float* fscale = (act_first && res_relu) ? st + 2L * npass * C : nullptr;
     const float* fshift = (act_first && res_relu) ? st + 3L * npass * C : nullptr;
     hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, fscale, fshift);
-    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, C, R, gamma, inv, dgamma, dbeta, bw);
+    long Rg = R; float gsc = 1.f;
+    if (sync && sync->world > 1) { const int rc = ptta_stat_sync(sync, part, blocks, C, 1, s); if (rc) return rc; Rg = R * sync->world; gsc = 1.f / (float)sync->world; }
+    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, C, Rg, gamma, inv, dgamma, dbeta, bw, gsc);
     if ((C & 3) || (x.ld & 3) || (g.ld & 3) || (y.ld & 3) || (gx.ld & 3) || (gres.p && (gres.ld & 3))) return -22;
     const long total = R * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;

@@ -129,6 +129,7 @@ struct GNet {
     int norm_on = 0; float norm_div = 1.f, norm_mean[3] = {0, 0, 0}, norm_std[3] = {1, 1, 1};
     bool fwd_valid = false;
     int max_bn_C = 16;
+    PttaStatSync stat_sync;               // SyncBatchNorm exchange (ptta_set_stat_sync); world == 1: off
 
     virtual ~GNet() { for (void* p : allocs) if (p) (void)hipFree(p); }
     // ---- backbone-specific ------------------------------------------------------------------------------------------

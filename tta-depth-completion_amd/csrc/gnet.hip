@@ -116,10 +116,10 @@ int GNet::run_bn_fwd(const Op& o, bool train, hipStream_t s) {
     }
     GView xt = x; review(xt, o.rH, o.rW);
     const int fused = o.fused_from >= 0 ? ptta_gconv_x3_tiles(xt.B / npass, xt.H, xt.W) : 0;
-    if (ptta_launch_gbn_forward(x, res, y, npass, o.act, BN_EPS, bn_gamma(o), bn_beta(o), fused ? o.part : bn_part, o.st, s, fused, o.act_first ? 1 : 0))
+    if (ptta_launch_gbn_forward(x, res, y, npass, o.act, BN_EPS, bn_gamma(o), bn_beta(o), fused ? o.part : bn_part, o.st, s, fused, o.act_first ? 1 : 0, &stat_sync))
         return fail("batch-norm " + o.bname + " launch failed", -5);
     if (o.tracked && train && o.rm && o.rv) {
-        const long R = (long)(x.B / npass) * x.H * x.W;
+        const long R = (long)(x.B / npass) * x.H * x.W * (stat_sync.world > 1 ? stat_sync.world : 1);
         if (ptta_launch_gbn_running_update(o.st, npass, x.C, R, 0.1f, BN_EPS, o.rm, o.rv, o.nbt, o.stat_repeats, s))
             return fail("running statistics of " + o.bname + " failed", -5);
     }
@@ -187,7 +187,7 @@ int GNet::run_bn_bwd(const Op& o, hipStream_t s) {
     float* dg = o.ad_g >= 0 ? gall + adapted[o.ad_g].goff : nullptr;
     float* db = o.ad_beta >= 0 ? gall + adapted[o.ad_beta].goff : nullptr;
     if (ptta_launch_gbn_backward(x, g, y, gx, gres, npass, o.act, o.res >= 0 ? 1 : 0, o.first_raw ? 0 : 1, o.first_res ? 0 : 1,
-                                 bn_gamma(o), o.st, bn_part, bn_bw, dg, db, s, o.act_first ? 1 : 0))
+                                 bn_gamma(o), o.st, bn_part, bn_bw, dg, db, s, o.act_first ? 1 : 0, &stat_sync))
         return fail("batch-norm gradient of " + o.bname + " failed", -5);
     return 0;
 }

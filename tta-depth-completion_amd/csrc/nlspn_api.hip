@@ -43,7 +43,7 @@ struct nlspn_engine : GNet {
     int t_sd16 = -1;
     int t_img = -1, t_sd = -1, t_pred = -1, t_oa = -1, t_conf = -1, t_fe6 = -1;
     float *off9 = nullptr, *aff9 = nullptr, *goff9 = nullptr, *gaff9 = nullptr, *feats = nullptr, *gy = nullptr, *gping = nullptr;
-    int legacy = 0;
+    int legacy = 0, heads_adapted = 0;
 
     long rows() const override { return (long)N * (H / 16) * (W / 16); }
     int emb_dim() const override { return 1024; }
@@ -139,15 +139,17 @@ struct nlspn_engine : GNet {
             const int r = tensor(std::string(name) + ".h", N, H16, W16, 1024, bwd), a = tensor(std::string(name) + ".a", N, H16, W16, 1024, bwd);
             const int o = tensor(std::string(name) + ".out", N, H16, W16, dout, bwd);
             conv(std::string(name) + ".0", x, -1, r, 1, 1, 0, GACT_NONE, xw, W_GRAD, true, bwd);
-            bn(std::string(name) + ".1", r, a, -1, GACT_RELU, W_GRAD, true, true, bwd);
+            // BatchNorm1d of the heads: train mode on the TTA path, running statistics kept (meta_bn only drops BatchNorm2d's)
+            bn(std::string(name) + ".1", r, a, -1, GACT_RELU, W_GRAD, !heads_adapted, true, bwd).tracked = true;
             conv(std::string(name) + ".3", a, -1, o, 1, 1, 0, GACT_NONE, W_GRAD, W_GRAD, true, bwd);
             return o;
         };
+        // module order proj, proj_t, pred (:1340-1342): the order of their BatchNorm parameters in the 94-tensor adapted list
         const int pz = mlp("proj", fe[6], W_PROXY, 512, 1024, false);
-        t_emb = mlp("pred", pz, W_GRAD, 1024, 1024, false);
-        tid["emb"] = t_emb;
         t_ref = mlp("proj_t", fe[6], W_GRAD, 512, 1024, true);
         tid["ref"] = t_ref;
+        t_emb = mlp("pred", pz, W_GRAD, 1024, 1024, false);
+        tid["emb"] = t_emb;
 
         plan_backward({t_pred, t_oa, t_conf, t_ref});           // written by the propagation / loss gradients
         // ---- remaining workspace ----
@@ -164,7 +166,16 @@ struct nlspn_engine : GNet {
     int load_extra(const std::string& name, const float* src, const int64_t* shape, int ndim, hipStream_t s) override {
         (void)shape; (void)ndim;
         auto ends = [&](const char* suf) { const size_t l = strlen(suf); return name.size() >= l && name.compare(name.size() - l, l, suf) == 0; };
-        if (ends("num_batches_tracked") || ends("running_mean") || ends("running_var")) return 0;   // dropped by adapt_parameters('meta_bn') / train-mode BN1d
+        if (ends("num_batches_tracked") || ends("running_mean") || ends("running_var")) {
+            const size_t dot = name.rfind('.');
+            const std::string base = name.substr(0, dot), leaf = name.substr(dot + 1);
+            for (Op& o : ops)            // the heads' BatchNorm1d buffers are BOUND and updated in place by every training forward
+                if (o.kind == K_BN && o.tracked && o.bname == base) {
+                    if (leaf == "running_mean") o.rm = (float*)src; else if (leaf == "running_var") o.rv = (float*)src; else o.nbt = (long long*)src;
+                    return 0;
+                }
+            return 0;                    // BatchNorm2d: dropped by adapt_parameters('meta_bn')
+        }
         if (name == "prop_layer.aff_scale_const") { NCHK(hipMemcpyAsync(S, src, sizeof(float), hipMemcpyDeviceToDevice, s)); return 0; }
         if (name == "prop_layer.w" || name == "prop_layer.b" || name == "prop_layer.w_conf") return 0;   // constants ones / zero (nlspnmodel_adapt.py:239-247)
         return fail("unknown state_dict key " + name, -2);
@@ -236,7 +247,7 @@ GNet* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int legacy_offse
     if (n < 1 || h < 16 || w < 16 || !hp) { *rc = -22; return nullptr; }
     if ((h % 16) || (w % 16)) { *rc = -38; return nullptr; }      // decoder crops of nlspnmodel_adapt.py:474-490 are not implemented
     nlspn_engine* e = new nlspn_engine();
-    e->N = e->Nu = n; e->H = e->Hu = h; e->W = e->Wu = w; e->hp = *hp; e->legacy = legacy_offset ? 1 : 0;
+    e->N = e->Nu = n; e->H = e->Hu = h; e->W = e->Wu = w; e->hp = *hp; e->legacy = (legacy_offset & 1) ? 1 : 0; e->heads_adapted = (legacy_offset & 2) ? 1 : 0;
     const char* impl = getenv("PTTA_CONV_IMPL");
     e->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;          // direct fp32 kernels everywhere (validation)
     e->build();

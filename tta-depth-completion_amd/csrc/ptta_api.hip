@@ -78,6 +78,7 @@ struct ptta_ctx {
     PttaAdamEntry* adam_tab = nullptr; unsigned* adam_ticket = nullptr; bool adam_tab_dirty = true;
     std::vector<PttaAdamEntry> adam_host;        // stays alive: the upload reads it
     bool fwd_valid = false;
+    PttaStatSync stat_sync;          // SyncBatchNorm exchange across ranks (ptta_set_stat_sync); world == 1: off
     bool proxy_rgb_valid = false;   // proxy half of c0..c4 holds the zero-image encoder outputs for the current weights
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
     struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double bytes = 0, macs = 0; };
@@ -448,8 +449,10 @@ int meta_forward(ptta_ctx* c, bool train, int B, hipStream_t s) {
         const int tiles_pp = ptta_gconv_x3_tiles(B / npass, H4, W4);
         auto finalize = [&](float* part, int C, const float* gamma, const float* beta, float* rm, float* rv, long long* nbt, float* st) -> int {
             if (!train) return ptta_launch_bn_eval_affine(gamma, beta, rm, rv, 1e-5f, st + 2 * C, st + 3 * C, C, s);       // npass == 1
+            if (ptta_stat_sync(&c->stat_sync, part, tiles_pp, C, npass, s)) return -5;
+            const int wmul = c->stat_sync.world > 1 ? c->stat_sync.world : 1;
             for (int pass = 0; pass < npass; ++pass)
-                if (ptta_launch_bn_finalize(part + (size_t)pass * tiles_pp * 2 * C, tiles_pp, (int)P, C, gamma, beta, 1e-5f, 0.1f, rm, rv, nbt,
+                if (ptta_launch_bn_finalize(part + (size_t)pass * tiles_pp * 2 * C, tiles_pp, (int)P * wmul, C, gamma, beta, 1e-5f, 0.1f, rm, rv, nbt,
                                             st + pass * C, st + (npass + pass) * C, st + (2 * npass + pass) * C, st + (3 * npass + pass) * C, s)) return -5;
             return 0;
         };
@@ -525,7 +528,7 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
         GView da1 = hv; da1.p = m2.gda1;
         GView dh = hv; dh.p = m2.gdh;
         // BatchNorm2d(32) (no activation, the residual branch carries no adapted parameter): d gamma2, d beta2, d t
-        RUN(ptta_launch_gbn_backward(tv, gm, tv, dt, GView(), npass, GACT_NONE, 0, 0, 0, A[5].p, m2.gst2, m2.gpart, m2.gbw, A[5].g, A[6].g, s));
+        RUN(ptta_launch_gbn_backward(tv, gm, tv, dt, GView(), npass, GACT_NONE, 0, 0, 0, A[5].p, m2.gst2, m2.gpart, m2.gbw, A[5].g, A[6].g, s, 0, &c->stat_sync));
         // conv2: weight + bias gradient (one launch over the 128 input channels), data gradient to the hidden map
         RUN(ptta_launch_gwgrad_mfma(av, dt, m2.wgp, A[3].g, A[4].g, s));
         GX3Args a;
@@ -534,7 +537,7 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
         a.y = da1.p; a.ldy = 128; a.Cy = 128;
         RUN(ptta_launch_gconv_x3(a, 3, s));
         // LeakyReLU(0.2) + BatchNorm2d(128): d gamma1, d beta1, d h; conv1 weight gradient
-        RUN(ptta_launch_gbn_backward(hv, da1, av, dh, GView(), npass, GACT_LRELU, 0, 0, 0, A[1].p, m2.gst1, m2.gpart, m2.gbw, A[1].g, A[2].g, s));
+        RUN(ptta_launch_gbn_backward(hv, da1, av, dh, GView(), npass, GACT_LRELU, 0, 0, 0, A[1].p, m2.gst1, m2.gpart, m2.gbw, A[1].g, A[2].g, s, 0, &c->stat_sync));
         RUN(ptta_launch_gwgrad_mfma(x, dh, m2.wgp, A[0].g, nullptr, s));
         return 0;
     }
@@ -732,7 +735,8 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
     GemmArgs g; g.A = A; g.a_bf16 = a_bf16; g.W = l0.W; g.bias = l0.bias; g.C = hidden; g.R = R; g.K = K; g.N = 512; g.epi = 1; g.part = c->bn_part;
     g.x3 = c->x3; g.Whi = l0.Whi; g.Wlo = l0.Wlo; g.Wil = l0.Wil;
     RUN(ptta_launch_gemm(g, s));
-    RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(g), R, 512, bn.gamma, bn.beta, 1e-5f, 0.1f, bn.rm, bn.rv, bn.nbt,
+    RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
+    RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(g), R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.beta, 1e-5f, 0.1f, bn.rm, bn.rv, bn.nbt,
                                 bn.mean, bn.inv, bn.scale, bn.shift, s));
     GemmArgs g2; g2.A = hidden; g2.W = l3.W; g2.bias = l3.bias; g2.C = out; g2.R = R; g2.K = 512; g2.N = 512; g2.pro = 1;
     g2.pscale = bn.scale; g2.pshift = bn.shift;
@@ -758,7 +762,8 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     g.eH = c->h1; g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part;
     g.x3 = c->x3; g.Whi = l3.Wthi; g.Wlo = l3.Wtlo; g.Wil = l3.Wtil;
     RUN(ptta_launch_gemm(g, s));
-    RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R, 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
+    RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
+    RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
     GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = c->g_feat_f32; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;
     g2.pscale = c->bnb_gscale; g2.pmean = bn.mean; g2.pinv = bn.inv; g2.pc1 = c->bnb_c1; g2.pc2 = c->bnb_c2;
     g2.x3 = c->x3; g2.Whi = l0.Wthi; g2.Wlo = l0.Wtlo;
@@ -898,9 +903,9 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -19;          // no HIP device: fail loudly
     if (backbone_id == PTTA_BACKBONE_NLSPN) {
-        if ((meta_mode & ~PTTA_NLSPN_LEGACY_OFFSET) != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32) return -38;
+        if ((meta_mode & ~(PTTA_NLSPN_LEGACY_OFFSET | PTTA_NLSPN_SYNCBN_ADAPT)) != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32) return -38;
         int rc = 0;
-        GNet* e = nlspn_create(n, height, width, hp, (meta_mode & PTTA_NLSPN_LEGACY_OFFSET) ? 1 : 0, &rc);
+        GNet* e = nlspn_create(n, height, width, hp, ((meta_mode & PTTA_NLSPN_LEGACY_OFFSET) ? 1 : 0) | ((meta_mode & PTTA_NLSPN_SYNCBN_ADAPT) ? 2 : 0), &rc);
         if (!e) return rc ? rc : -12;
         ptta_ctx* c = new ptta_ctx();
         c->nl = e; c->N = n; c->H = height; c->W = width; c->hp = *hp;
@@ -1309,10 +1314,22 @@ int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const f
     return 0;
 }
 
+int ptta_set_stat_sync(ptta_handle c, ptta_allreduce_fn fn, void* user, double* exchange_buf, int64_t capacity, int world_size) {
+    if (!c || world_size < 1 || (world_size > 1 && (!fn || !exchange_buf || capacity < 2 * 1024))) return -22;
+    PttaStatSync sy; sy.fn = (ptta_allreduce_cb)fn; sy.user = user; sy.buf = exchange_buf; sy.cap = (long)capacity; sy.world = world_size;
+    if (c->nl) { c->err.clear(); c->nl->stat_sync = sy; return 0; }
+    if (world_size > 1 && c->meta_mode == PTTA_META_2LAYERS && !c->m2.generic) return c->fail("SyncBatchNorm needs the default arithmetic for the 2layers meta layer", -38);
+    c->stat_sync = sy;
+    c->drop_graphs();
+    if (world_size > 1) { c->use_graph = 0; c->use_aux = 0; }      // the step contains host-driven collectives: no graph replay, one stream
+    return 0;
+}
+
 int ptta_set_graph(ptta_handle c, int enable) {
     if (c && c->nl) return c->fail("not available for the NLSPN / CostDCNet backbones: use ptta_step / ptta_forward_*", -38);
 
     if (!c) return -1;
+    if (enable && c->stat_sync.world > 1) return c->fail("graph replay is not available with SyncBatchNorm exchange (ptta_set_stat_sync)", -38);
     c->use_graph = enable ? 1 : 0;
     if (!enable) c->drop_graphs();
     return 0;

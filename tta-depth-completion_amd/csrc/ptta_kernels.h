@@ -68,6 +68,15 @@ int ptta_launch_up2T_32(const void* gout, const void* add, void* gin, int B, int
 int ptta_launch_outlier_removal(const float* sparse, const float* validity, float* sparse_out, float* validity_out,
                                 int N, int H, int W, int ksize, float threshold, float* scratch, hipStream_t s);
 
+// ---- SyncBatchNorm across ranks (the reference converts every BatchNorm to SyncBatchNorm before its DDP run,
+// src/tta_main.py:326): the partial statistics of a BatchNorm [pass][block][2][C] are collapsed to double sums in the caller's
+// exchange buffer, summed over the ranks by the caller's collective (RCCL through torch.distributed), and written back as
+// block 0 (+ a low-order correction in block 1) so that the unchanged finalize kernels see GLOBAL sums; the row count they
+// divide by is multiplied by the world size (equal local batches, as DistributedSampler + drop_last give).
+typedef int (*ptta_allreduce_cb)(void* user, double* dev_buf, long long count, void* stream);
+struct PttaStatSync { ptta_allreduce_cb fn = nullptr; void* user = nullptr; double* buf = nullptr; long cap = 0; int world = 1; };
+int ptta_stat_sync(const PttaStatSync* sy, float* part, int nblocks, int C, int npass, hipStream_t s);      // gbn.hip
+
 // ---- heads.hip --------------------------------------------------------------------------------
 struct GemmArgs {
     const void* A = nullptr; int a_bf16 = 0;   // [R][K] (fp32, or bf16 NHWC features when a_bf16)
@@ -172,13 +181,14 @@ int ptta_launch_gwgrad(const GView& x, const GView& gy, float* part, float* gw, 
 
 int ptta_gbn_part_floats(int C, int npass);
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
-                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks = 0, int act_first = 0);
+                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks = 0, int act_first = 0,
+                            const PttaStatSync* sync = nullptr);
 int ptta_gconv_x3_tiles(int B, int H, int W);
 int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int npass, int act, const float* st, int res_relu, hipStream_t s,
                           int act_first = 0);
 int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, const GView& gx, const GView& gres, int npass, int act,
                              int res_relu, int acc_gx, int acc_gres, const float* gamma, const float* st, float* part, float* bw,
-                             float* dgamma, float* dbeta, hipStream_t s, int act_first = 0);
+                             float* dgamma, float* dbeta, hipStream_t s, int act_first = 0, const PttaStatSync* sync = nullptr);
 
 int ptta_launch_nl_affinity_fwd(const GView& oa, const float* conf, const float* S, int legacy, float* off9, float* aff9, hipStream_t s);
 int ptta_launch_nl_prop_fwd(const float* feat, const float* fix, const float* off9, const float* aff9, float* out, int B, int H, int W,

@@ -14,6 +14,7 @@ PTTA_BACKBONE_MSG_CHN = 0
 PTTA_BACKBONE_NLSPN = 1
 PTTA_BACKBONE_COSTDCNET = 2
 PTTA_NLSPN_LEGACY_OFFSET = 0x100
+PTTA_NLSPN_SYNCBN_ADAPT = 0x200
 PTTA_META_1LAYER = 0
 PTTA_META_2LAYERS = 1
 PTTA_DTYPE_F32 = 0
@@ -55,6 +56,7 @@ SIGNATURES = [
     ('ptta_mdconv_forward', c_int, [_P] * 6 + [c_int] * 15 + [_P]),
     ('ptta_mdconv_backward', c_int, [_P] * 11 + [c_int] * 15 + [_P]),
     ('ptta_set_image_norm', c_int, [_P, c_float, POINTER(c_float), POINTER(c_float)]),
+    ('ptta_set_stat_sync', c_int, [_P, _P, _P, _P, c_int64, c_int]),
     ('ptta_set_graph', c_int, [_P, c_int]),
     ('ptta_profile', c_int, [_P, c_int]),
     ('ptta_profile_read', c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),

@@ -107,6 +107,8 @@ class CostDCNetModel_Adapt(MsgChnModel_Adapt):
             if getattr(self, '_image_norm', None) is not None:
                 eng.set_image_norm(self._image_norm)
             eng._t = 0
+            if self.sync_bn:
+                eng.enable_stat_sync()
             self._engines[key] = eng
         return eng
 

@@ -9,9 +9,10 @@ Two modes:
     src/tta_main.py:354): every rank runs forward+loss+backward on its slice of the batch, then ONE
     collective: mean all-reduce of the adapted-parameter gradients only (37 KB for the MSG_CHN 1layer
     meta conv, 160 KB for NLSPN's 88 meta_bn tensors; the reference all-reduces every gradient and
-    discards most of them), then the same Adam update everywhere.  Not reproduced: the reference also
-    converts BatchNorm to SyncBatchNorm (src/tta_main.py:326), i.e. batch statistics over the global batch;
-    here every rank normalises with its own slice's statistics.
+    discards most of them), then the same Adam update everywhere.  The reference also converts BatchNorm to
+    SyncBatchNorm (src/tta_main.py:326): `Engine.enable_stat_sync()` (ptta_set_stat_sync) exchanges each BatchNorm's
+    partial sums over the ranks, so two ranks with half a batch each reproduce the single-process run on the whole batch
+    (tests/test_gpu_syncbn.py).  Without it every rank normalises with its own slice's statistics (a warning is issued).
 """
 import torch
 import torch.distributed as dist
@@ -47,11 +48,12 @@ def shared_parameter_step(engine, image, sparse, validity=None, loss_image=None,
     `w` = (w_sparse_depth, w_smoothness, w_cos); default: the engine's hyper-parameters."""
     if w is None:
         w = (engine.hp.w_sparse_depth, engine.hp.w_smoothness, engine.hp.w_cos)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and not _warned:
+    if (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and not _warned
+            and 'stat_sync' not in getattr(engine, '_keep', {})):
         import warnings
         _warned.append(1)
         warnings.warn('shared_parameter_step: BatchNorm statistics are per rank (the reference converts to SyncBatchNorm, '
-                      'src/tta_main.py:326); results differ from a single-process run on the global batch')
+                      'src/tta_main.py:326); call engine.enable_stat_sync() / model.convert_syncbn() to exchange them')
     depth, emb, ref = engine.forward_train(image, sparse)
     if validity is None:
         validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)

@@ -47,7 +47,8 @@ class Engine:
 
     def __init__(self, n, height, width, dtype='fp32', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0,
-                 max_input_depth=None, meta='1layer', backbone='msg_chn', legacy_offset=False, max_predict_depth=None):
+                 max_input_depth=None, meta='1layer', backbone='msg_chn', legacy_offset=False, max_predict_depth=None,
+                 syncbn_adapted=False):
         if not torch.cuda.is_available():
             raise RuntimeError('proxytta needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
@@ -67,7 +68,8 @@ class Engine:
         rc = self.lib.ptta_create(byref(self.handle),
                                   {'nlspn': _lib.PTTA_BACKBONE_NLSPN, 'costdcnet': _lib.PTTA_BACKBONE_COSTDCNET}.get(backbone, _lib.PTTA_BACKBONE_MSG_CHN),
                                   (_lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER) |
-                                  (_lib.PTTA_NLSPN_LEGACY_OFFSET if (legacy_offset and backbone == 'nlspn') else 0),
+                                  (_lib.PTTA_NLSPN_LEGACY_OFFSET if (legacy_offset and backbone == 'nlspn') else 0) |
+                                  (_lib.PTTA_NLSPN_SYNCBN_ADAPT if (syncbn_adapted and backbone == 'nlspn') else 0),
                                   self.n, self.h, self.w, code, byref(self.hp))
         if rc != 0:
             why = {-19: 'no HIP device', -12: 'out of device memory', -22: 'invalid size / argument',
@@ -242,6 +244,33 @@ class Engine:
         m = (ctypes.c_float * 3)(*mean)
         s = (ctypes.c_float * 3)(*std)
         self._chk(self.lib.ptta_set_image_norm(self.handle, float(div), m, s), 'ptta_set_image_norm')
+
+    def enable_stat_sync(self, group=None):
+        """model.convert_syncbn() for the one-process-per-GPU run (src/tta_main.py:326): train-mode BatchNorm statistics of
+        the GLOBAL batch.  The library hands a float64 buffer of partial sums to this callback, which sums it over the ranks
+        with torch.distributed (RCCL on ROCm; gloo works too) on the current stream."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world <= 1:
+            self._chk(self.lib.ptta_set_stat_sync(self.handle, None, None, None, 0, 1), 'ptta_set_stat_sync')
+            return
+        buf = torch.zeros(4 * 2 * 1024, device=self.device, dtype=torch.float64)
+
+        def _allreduce(user, ptr_, count, stream):
+            try:
+                # the collective must be ordered on the stream the library is enqueuing on (it may be an internal one)
+                ext = torch.cuda.ExternalStream(stream) if stream else torch.cuda.current_stream()
+                with torch.cuda.stream(ext):
+                    dist.all_reduce(buf[:count], op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception:                       # never raise through the C frame
+                import traceback
+                traceback.print_exc()
+                return -5
+        cb = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p)(_allreduce)
+        self._keep['stat_sync'] = (buf, cb)
+        self._chk(self.lib.ptta_set_stat_sync(self.handle, ctypes.cast(cb, c_void_p), None, c_void_p(buf.data_ptr()), buf.numel(), world),
+                  'ptta_set_stat_sync')
 
     def set_graph(self, enable):
         self._chk(self.lib.ptta_set_graph(self.handle, int(bool(enable))), 'ptta_set_graph')

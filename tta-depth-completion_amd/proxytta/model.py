@@ -210,6 +210,8 @@ class MsgChnModel_Adapt(object):
         statistics are those of the GLOBAL batch.  With one rank that is what the engine computes anyway; with
         several ranks the statistics are exchanged inside proxytta.distributed.shared_parameter_step."""
         self.sync_bn = True
+        for eng in self._engines.values():
+            eng.enable_stat_sync()
 
     def restore_model(self, restore_path, optimizer=None):
         ckpt = torch.load(restore_path, map_location=self.device)
@@ -253,6 +255,8 @@ class MsgChnModel_Adapt(object):
             if getattr(self, '_image_norm', None) is not None:
                 eng.set_image_norm(self._image_norm)
             eng._t = 0
+            if self.sync_bn:
+                eng.enable_stat_sync()          # no-op with one rank
             self._engines[key] = eng
         return eng
 

@@ -20,12 +20,14 @@ from .model import MsgChnModel_Adapt, _ForwardFn, _init_tensor, _Tree
 _BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked')
 
 
-def nlspn_adapted_names(keys):
+def nlspn_adapted_names(keys, syncbn=False):
     """adapt_parameters('meta_bn') (src/nlspn_model_adapt.py:322-337): parameters whose name contains 'meta', then
-    weight / bias of every BatchNorm2d in module order (the heads' BatchNorm1d are not BatchNorm2d)."""
+    weight / bias of every BatchNorm2d in module order (the heads' BatchNorm1d are not BatchNorm2d).  After
+    convert_syncbn() (src/tta_main.py:326 runs it BEFORE adapt_parameters) every BatchNorm is a SyncBatchNorm and the
+    isinstance test also matches the heads': proj.1, proj_t.1, pred.1 join the list (94 tensors)."""
     names = [k for k in keys if 'meta' in k]
     for k in keys:
-        if k.endswith('.running_mean') and not k.startswith(('proj', 'pred')):
+        if k.endswith('.running_mean') and (syncbn or not k.startswith(('proj', 'pred'))):
             pre = k[:-len('.running_mean')]
             names += [pre + '.weight', pre + '.bias']
     return names
@@ -76,8 +78,14 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
         for k, s in synth.nlspn_keys(mode):
             if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
                 self.model._leaf(k, _init_tensor(k, s).to(self.device), not k.endswith(_BUFFERS))
-        self.adapted = nlspn_adapted_names([k for k, _ in synth.nlspn_keys(mode)])
+        self.adapted = nlspn_adapted_names([k for k, _ in synth.nlspn_keys(mode)], self.sync_bn)
         self._clear_engines()
+
+    def convert_syncbn(self, apex=False):
+        super().convert_syncbn(apex)
+        if self.prepare_mode is not None:           # heads exist: the adapted list grows to the 94 tensors of the DDP run
+            self.adapted = nlspn_adapted_names([k for k, _ in synth.nlspn_keys(self.prepare_mode)], True)
+            self._clear_engines()
 
     def adapt_parameters(self, mode=None):
         if mode != 'meta_bn':
@@ -92,9 +100,10 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
         if eng is None:
             if self.prepare_mode is None:
                 raise RuntimeError('_prepare_head(mode) must be called before forward (tta_main.py:322)')
-            eng = Engine(n, h, w, backbone='nlspn', legacy_offset=self.legacy, max_input_depth=self.max_input_depth, **self.hparams)
+            eng = Engine(n, h, w, backbone='nlspn', legacy_offset=self.legacy, max_input_depth=self.max_input_depth,
+                         syncbn_adapted=self.sync_bn, **self.hparams)
             assert eng.adapted == self.adapted, 'adapted parameter list drifted from the library'
-            eng.load_state_dict({k: v for k, v in self.model.state_dict().items() if v.dtype == torch.float32})
+            eng.load_state_dict(self.model.state_dict())     # the heads' BatchNorm1d buffers are bound and updated in place
             params = dict(self.model.named_parameters())
             for name in self.adapted:
                 p = params[name]
@@ -103,6 +112,8 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
             if getattr(self, '_image_norm', None) is not None:
                 eng.set_image_norm(self._image_norm)
             eng._t = 0
+            if self.sync_bn:
+                eng.enable_stat_sync()
             self._engines[key] = eng
         return eng
 

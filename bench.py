@@ -352,6 +352,40 @@ def main():
         info, _ = eng.step(*frames[i % nframes])
     barrier()
     elapsed = time.perf_counter() - t0
+    # Second figure: the same K steps with every frame starting in PAGEABLE HOST memory, as the reference's
+    # dataloader hands it over (src/tta_main.py:519-523): pinned triple buffer + copy stream, frame k+1 travels while frame k
+    # is adapted.  Never `value` (that one is HBM-resident by contract).
+    from_host = None
+    if world == 1:
+        from proxytta.staging import FrameStager
+        host_frames = [synth.synthetic_frame(500 + i, H, W, 1) for i in range(nframes)]
+        st = FrameStager(1, H, W)
+        st.submit(*host_frames[0])
+        for phase, count in (('warmup', max(args.warmup, 2)), ('timed', args.steps)):
+            if phase == 'timed':
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+            for i in range(count):
+                st.submit(*host_frames[(i + 1) % nframes])
+                im, sp = st.acquire()
+                eng.step(im, sp)
+                st.release()
+        torch.cuda.synchronize()
+        host_elapsed = time.perf_counter() - th
+        st.acquire(); st.release()
+        # the reference's way on the same engine: blocking copy from pageable memory, then the step
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for i in range(args.steps):
+            im = torch.from_numpy(host_frames[i % nframes][0]).to('cuda')
+            sp = torch.from_numpy(host_frames[i % nframes][1]).to('cuda')
+            eng.step(im, sp)
+        torch.cuda.synchronize()
+        blocking_elapsed = time.perf_counter() - tb
+        from_host = {'value': args.steps / host_elapsed, 'unit': 'frames/s', 'ms_per_step': 1e3 * host_elapsed / args.steps,
+                     'h2d_bytes_per_frame': st.bytes_per_frame,
+                     'staging': 'pageable host frame -> pinned slot (host memcpy) -> async H2D on a copy stream, three slots, host-ordered by events',
+                     'blocking_to_device_ms_per_step': 1e3 * blocking_elapsed / args.steps}
     # Roofline leg: the timed region above replays a hipGraph, inside which kernels cannot be
     # bracketed by events, so the SAME K steps are re-run kernel by kernel right here with every
     # launch of the dominant kernel class bracketed by hipEvents on its launch stream.
@@ -404,6 +438,8 @@ def main():
                               'mfma_frac_per_gpu': (3 if es == 4 else 1) * ALG_FLOP_PER_STEP * (steps_per_s / world) / MFMA_BF16_PEAK},
             'roofline': roof,
         }
+        if from_host is not None:
+            out['from_host_memory'] = from_host
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
     eng.close()

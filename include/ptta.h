@@ -180,6 +180,15 @@ int ptta_mdconv_backward(const float* input, const float* weight, const float* b
  * mean / std may be NULL (0 / 1).  (1, 0, 1) switches it off. */
 int ptta_set_image_norm(ptta_handle h, float divisor, const float* mean, const float* stdv);
 
+/* Geometric augmentation on device: Transforms.crop + horizontal_flip + vertical_flip
+ * (src/transforms.py:337-407, 955-1034) in one pass over an N x C x H x W fp32 tensor:
+ *   dst[b,c,y,x] = src[b, c, start_y[b] + (vflip[b] ? ch-1-y : y), start_x[b] + (hflip[b] ? cw-1-x : x)]
+ * (the reference crops first and flips the cropped sample).  start_y / start_x (int32, device, per sample; NULL = 0) and
+ * hflip / vflip (uint8, device, per sample; NULL = no flip) are the caller's random draws; starts are clamped into the
+ * sample.  dst is N x C x crop_height x crop_width and must not alias src.  Handle-free, enqueues only. */
+int ptta_crop_flip(const float* src, float* dst, int n, int channels, int height, int width, int crop_height, int crop_width,
+                   const int32_t* start_y, const int32_t* start_x, const uint8_t* hflip, const uint8_t* vflip, ptta_stream s);
+
 /* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
  * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
 /* model.convert_syncbn() (src/tta_main.py:326 -> SyncBatchNorm.convert_sync_batchnorm, src/msg_chn_model_adapt.py:547-556)

@@ -299,3 +299,32 @@ def test_minkowski_lite_matches_dense_convolution():
     d2, _, ts = out2.dense()
     assert list(ts) == [1, 2, 2]
     np.testing.assert_allclose(d2.numpy(), F.conv3d(x, wd, padding=1, stride=(1, 2, 2)).numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ---- geometric augmentation ----------------------------------------------------------
+def _transform_cases(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'transforms_geometric.npz'))
+    for name in z['names']:
+        p = str(name) + '/'
+        cfg = z[p + 'cfg']
+        seed, n, H, W = (int(v) for v in cfg[:4])
+        crop = [int(v) for v in cfg[4:4 + int(cfg[8])]]
+        flips = (['horizontal'] if cfg[9] else []) + (['vertical'] if cfg[10] else []) or ['none']
+        yield str(name), z, p, seed, n, H, W, crop, flips, float(z[p + 'prob'])
+
+
+def test_transforms_oracle_reproduces_reference_crop_flip(golden_dir):
+    """The index-arithmetic oracle + the reference's draw order == the real Transforms class, bit for bit."""
+    import torch
+    from oracle import transforms_oracle as TO
+    seen_crop = seen_flip = 0
+    for name, z, p, seed, n, H, W, crop, flips, prob in _transform_cases(golden_dir):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        d = TO.draw(n, H, W, crop, flips, prob)
+        seen_crop += d['crop'] is not None
+        seen_flip += int(d['hflip'].any()) + int(d['vflip'].any())
+        np.testing.assert_array_equal(TO.apply(z[p + 'image'].astype(np.float32), d), z[p + 'image_out'], err_msg=name)
+        np.testing.assert_array_equal(TO.apply(z[p + 'sparse'], d), z[p + 'sparse_out'], err_msg=name)
+        np.testing.assert_array_equal(TO.adjust_intrinsics(z[p + 'K'], d, H, W), z[p + 'K_out'], err_msg=name)
+    assert seen_crop >= 4 and seen_flip >= 4          # the fixture exercises what it claims to

@@ -56,6 +56,7 @@ SIGNATURES = [
     ('ptta_mdconv_forward', c_int, [_P] * 6 + [c_int] * 15 + [_P]),
     ('ptta_mdconv_backward', c_int, [_P] * 11 + [c_int] * 15 + [_P]),
     ('ptta_set_image_norm', c_int, [_P, c_float, POINTER(c_float), POINTER(c_float)]),
+    ('ptta_crop_flip', c_int, [_P, _P] + [c_int] * 6 + [_P] * 5),
     ('ptta_set_stat_sync', c_int, [_P, _P, _P, _P, c_int64, c_int]),
     ('ptta_set_graph', c_int, [_P, c_int]),
     ('ptta_profile', c_int, [_P, c_int]),

@@ -180,6 +180,34 @@ int ptta_mdconv_backward(const float* input, const float* weight, const float* b
  * mean / std may be NULL (0 / 1).  (1, 0, 1) switches it off. */
 int ptta_set_image_norm(ptta_handle h, float divisor, const float* mean, const float* stdv);
 
+/* ---- Stage-2 head trainer ------------------------------------------------------------------------------
+ * One step of src/head_main.py:464-480 for MSG_CHN (fp32 handle, sizes divisible by 16) with loss_type
+ * 'head_selfsup_seq_ema_reverse' (reverse = 1) or 'head_selfsup_seq_ema' (reverse = 0), i.e.
+ * network_exp_msg_chn_adapt.py:610-699 (`_rgbd_meta_contrast_head`, mode without 'adapt'):
+ *   _update_head()           proj_t <- tau proj_t + (1 - tau) proj over parameters()                    (:701-703)
+ *   both backbone passes     no gradient, train-mode BatchNorm, stop at depth_encoder3                      (:626-676)
+ *   reverse:     emb = pred(proj(feat_zero).detach()), ref = proj(feat).detach()      -> pred trains      (:691-694)
+ *   not reverse: emb = pred(proj(feat)),               ref = proj(feat_zero).detach() -> proj, pred train (:681-684)
+ *   prepare_loss             mean(2 - 2 <normalize(emb), normalize(ref)>)          (src/external_model_adapt.py:524-541)
+ *   Adam                     over prepare_parameters('head_selfsup_ema') (src/msg_chn_model_adapt.py:297-304); parameters
+ *                            without a gradient are skipped like torch.optim.Adam skips .grad == None
+ * ptta_head_bind: name in {proj,pred}.{0,3}.{weight,bias}, {proj,pred}.1.{weight,bias} (param + both Adam moments, device fp32,
+ * caller-owned, updated in place) or proj_t.* (param only; bind all six or none).  After ptta_head_adam_step the handle's
+ * packed copies of the updated head weights are re-derived, so TTA calls on the same handle see them; after an EXTERNAL
+ * update of bound parameters call ptta_head_reload.  adam_step < 0 in ptta_head_set_hparams keeps the device-side count.
+ * ptta_head_step = forward + backward + adam_step.  loss_out: 1 device float.  Everything enqueues only. */
+int ptta_head_bind(ptta_handle h, const char* name, float* param, float* exp_avg, float* exp_avg_sq);
+int ptta_head_set_hparams(ptta_handle h, float lr, float beta1, float beta2, float eps, float weight_decay, float tau,
+                          int adam_step, ptta_stream s);
+int ptta_head_reload(ptta_handle h, ptta_stream s);
+int ptta_head_forward(ptta_handle h, const float* image, const float* sparse_depth, int reverse, float* emb_out, float* ref_out,
+                      ptta_stream s);
+int ptta_head_backward(ptta_handle h, float* loss_out, ptta_stream s);
+int ptta_head_adam_step(ptta_handle h, ptta_stream s);
+int ptta_head_step(ptta_handle h, const float* image, const float* sparse_depth, int reverse, float* loss_out, ptta_stream s);
+/* gradient of the last ptta_head_backward; *has_grad_host = 0 (and dst untouched) for parameters outside the graph */
+int ptta_head_get_grad(ptta_handle h, const char* name, float* dst, int64_t capacity, int* has_grad_host, ptta_stream s);
+
 /* Geometric augmentation on device: Transforms.crop + horizontal_flip + vertical_flip
  * (src/transforms.py:337-407, 955-1034) in one pass over an N x C x H x W fp32 tensor:
  *   dst[b,c,y,x] = src[b, c, start_y[b] + (vflip[b] ? ch-1-y : y), start_x[b] + (hflip[b] ? cw-1-x : x)]

@@ -1,0 +1,198 @@
+"""SURVEY.md 8f-4 on the GPU: the stage-2 head trainer (ptta_head_* behind Engine.head_*) against the REAL reference's
+fixtures (tests/golden/head_*.npz, make_golden_head.py) and against the oracle at a size the fixtures do not hold."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import head_oracle as HO
+from proxytta import synth
+from proxytta.engine import HEAD_PARAMS, HEAD_TARGETS, Engine
+from tests.golden.make_golden_head import perturbed_target
+from tests.util import ONE
+
+pytestmark = pytest.mark.gpu
+
+
+def make_head_engine(n, h, w, hp, tau, bind_target=True):
+    eng = Engine(n, h, w, dtype='fp32', max_input_depth=80.0)
+    sd_np = synth.formula_state_dict(ONE, 1.0)
+    sd_np.update(perturbed_target(sd_np))
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in sd_np.items()}
+    eng.load_state_dict(sd)
+    for name in eng.adapted:
+        eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+    moments = {}
+    for k in HEAD_PARAMS:
+        moments[k] = (torch.zeros_like(sd[k]), torch.zeros_like(sd[k]))
+        eng.bind_head(k, sd[k], *moments[k])
+    if bind_target:
+        for k in HEAD_TARGETS:
+            eng.bind_head(k, sd[k])
+    eng.set_head_hparams(tau=tau, adam_step=0, **hp)
+    return eng, sd, sd_np, moments
+
+
+def _check(z, key, value, rtol, atol, what):
+    value = value.detach().cpu().numpy() if torch.is_tensor(value) else np.asarray(value)
+    if key in z.files:
+        np.testing.assert_allclose(value, z[key], rtol=rtol, atol=atol, err_msg=what)
+        return
+    idx = np.linspace(0, value.shape[0] - 1, 24).astype(np.int64)
+    np.testing.assert_allclose(value[idx], z[key + '#rows'], rtol=rtol, atol=atol, err_msg=what)
+    s = z[key + '#sum']
+    assert abs(value.sum(dtype=np.float64) - s[0]) <= rtol * s[1] + atol * value.size, what
+
+
+def _grad_close(mine, want, first, what):
+    """Gradients are sums over thousands of rows through a ReLU: a pre-activation within rounding of zero flips its mask
+    under any other summation order and moves single entries by one row's contribution (~1e-5 here).  So: every entry
+    within 2 % of the tensor's largest entry, and the MEAN error three orders below the mean magnitude (first step; later
+    steps also carry Adam's first-step sign noise)."""
+    mine, want = np.asarray(mine, np.float64), np.asarray(want, np.float64)
+    if np.abs(want).max() < 1e-8:
+        # mathematically ZERO gradient (a bias in front of a BatchNorm: pred.0.bias, proj.0.bias, and proj.3.bias which only
+        # shifts pred's pre-BatchNorm hidden): the reference holds rounding noise
+        assert np.abs(mine).max() < 1e-6, what
+        return
+    d = np.abs(mine - want)
+    assert d.max() <= 0.02 * np.abs(want).max() + 1e-12, (what, d.max(), np.abs(want).max())
+    assert d.mean() <= (2e-3 if first else 2e-2) * np.abs(want).mean() + 1e-12, (what, d.mean(), np.abs(want).mean())
+
+
+def _grad_check(z, key, g, first, what):
+    g = g.detach().cpu().numpy()
+    if key in z.files:
+        _grad_close(g, z[key], first, what)
+        return
+    idx = np.linspace(0, g.shape[0] - 1, 24).astype(np.int64)
+    _grad_close(g[idx], z[key + '#rows'], first, what)
+    s = z[key + '#sum']
+    assert abs(g.sum(dtype=np.float64) - s[0]) <= (2e-3 if first else 2e-2) * s[1], what
+
+
+@pytest.mark.parametrize('name', ['head_reverse_32x48_n2', 'head_forward_32x48_n2', 'head_reverse_64x96'])
+def test_head_trainer_reproduces_reference(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = (int(v) for v in z['meta'])
+    lr, b1, b2, eps, wd, tau = (float(v) for v in z['hp'])
+    reverse = 'reverse' in str(z['loss_type'])
+    eng, sd, _, _ = make_head_engine(n, h, w, dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd), tau)
+    for s in range(steps):
+        image, sparse = (torch.from_numpy(a).cuda() for a in synth.synthetic_frame(s, h, w, n))
+        emb, ref = eng.head_forward(image, sparse, reverse)
+        loss = eng.head_backward()
+        p = 's%d/' % s
+        idx = z[p + 'row_idx']
+        np.testing.assert_allclose(emb.cpu().numpy()[idx], z[p + 'emb_rows'], rtol=2e-3, atol=2e-4 if s == 0 else 5e-3)
+        np.testing.assert_allclose(ref.cpu().numpy()[idx], z[p + 'ref_rows'], rtol=2e-3, atol=2e-4 if s == 0 else 5e-3)
+        assert abs(float(loss) - float(z[p + 'loss'])) < (2e-5 if s == 0 else 1e-4)
+        for k in HEAD_PARAMS:
+            g = eng.head_grad(k, sd[k])
+            assert bool(z[p + 'has_grad/' + k]) == (g is not None), k
+            if g is None:
+                continue
+            _grad_check(z, p + 'grad/' + k, g, s == 0, k)
+        eng.head_adam_step()
+    torch.cuda.synchronize()
+    last = 's%d/after/' % (steps - 1)
+    for k in sd:
+        if not k.startswith(('proj', 'pred')):
+            continue
+        if k in HEAD_PARAMS and (not reverse or k.startswith('pred')):
+            # Adam's first steps move every entry by ~lr whatever the gradient's size: entries with a near-zero gradient may
+            # take the other sign -> bound by the total travel; the gradients above are the tight check
+            _check(z, last + k, sd[k], 0, 2.5 * lr * steps, k)
+        elif k.endswith('num_batches_tracked'):
+            assert int(sd[k]) == int(z[last + k]), k
+        elif k.startswith('proj_t.') and not k.endswith(('running_mean', 'running_var')) and not reverse:
+            # EMA of a parameter that itself moved by Adam: (1 - tau) * travel
+            _check(z, last + k, sd[k], 1e-6, (1 - tau) * 2.5 * lr * steps * steps + 1e-7, k)
+        elif 'running' in k:
+            # statistics of hidden activations of magnitude ~30, downstream of Adam-updated weights (not reverse: proj.0 itself
+            # moved by +-lr per entry and its inputs are O(10))
+            _check(z, last + k, sd[k], 2e-4, 1e-3 if reverse else 2e-2, k)
+        else:
+            # untouched parameters and (reverse) the EMA of the constant proj
+            _check(z, last + k, sd[k], 1e-5, 1e-6, k)
+
+
+def test_head_trainer_against_oracle_other_shape():
+    """A shape and batch the fixtures do not hold, 2 steps each mode, incl. the EMA and the step counter."""
+    n, h, w = 3, 48, 80
+    hp = dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    for loss_type in ('head_selfsup_seq_ema_reverse', 'head_selfsup_seq_ema'):
+        eng, sd, sd_np, _ = make_head_engine(n, h, w, hp, 0.99)
+        o = HO.HeadTrainerOracle(sd_np, loss_type, max_input_depth=80.0, tau=0.99, **hp)
+        for s in range(2):
+            image, sparse = synth.synthetic_frame(10 + s, h, w, n)
+            r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+            emb, ref = eng.head_forward(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda(), 'reverse' in loss_type)
+            loss = eng.head_backward()
+            assert abs(float(loss) - r['loss']) < (2e-5 if s == 0 else 1e-4)
+            for k, g in r['grads'].items():
+                mine = eng.head_grad(k, sd[k]).cpu()
+                _grad_close(mine.numpy(), g.numpy(), s == 0, k)
+            eng.head_adam_step()
+        for k in HEAD_TARGETS:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), o.P[k].detach().numpy(), rtol=1e-5, atol=0.01 * 2.5 * 5e-4 * 4 + 1e-7, err_msg=k)
+        eng.close()
+
+
+def test_fused_head_step_equals_split_calls():
+    n, h, w = 1, 32, 64
+    hp = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    out = []
+    for fused in (False, True):
+        eng, sd, _, _ = make_head_engine(n, h, w, hp, 0.999)
+        losses = []
+        for s in range(3):
+            image, sparse = (torch.from_numpy(a).cuda() for a in synth.synthetic_frame(s, h, w, n))
+            if fused:
+                losses.append(eng.head_step(image, sparse, True))
+            else:
+                eng.head_forward(image, sparse, True, want=False)
+                losses.append(eng.head_backward())
+                eng.head_adam_step()
+        torch.cuda.synchronize()
+        out.append((torch.cat(losses).cpu(), {k: sd[k].cpu().clone() for k in HEAD_PARAMS + HEAD_TARGETS}))
+        eng.close()
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    assert float(out[0][0][-1]) < float(out[0][0][0])            # the loss goes down
+
+
+def test_tta_step_after_head_training_uses_the_trained_heads():
+    """The same handle adapts afterwards with the heads it just trained: its TTA step equals the oracle's TTA step from the
+    trained state dict."""
+    from oracle import proxytta_oracle as O
+    n, h, w = 1, 32, 64
+    hp = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    eng, sd, _, _ = make_head_engine(n, h, w, hp, 0.999)
+    for s in range(2):
+        image, sparse = (torch.from_numpy(a).cuda() for a in synth.synthetic_frame(s, h, w, n))
+        eng.head_step(image, sparse, True)
+    torch.cuda.synchronize()
+    trained = {k: v.detach().cpu().clone() for k, v in sd.items()}
+    image, sparse = synth.synthetic_frame(7, h, w, n)
+    o = O.MsgChnOracle(trained, ONE, max_input_depth=80.0, lr=1e-3, w_sd=1.0, w_sm=1.0, w_cos=1.0)
+    r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+    info, depth = eng.step(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda(), want_depth=True)
+    assert float((depth.cpu() - r['depth']).abs().mean() / r['depth'].abs().mean()) < 1e-4
+    li = r['loss_info']
+    np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=5e-4)
+
+
+def test_head_trainer_refusals():
+    eng = Engine(1, 36, 52, dtype='fp32')              # not divisible by 16: the dual-corner padded path
+    with pytest.raises(RuntimeError):
+        eng.bind_head('pred.0.weight', torch.zeros(512, 512, device='cuda'), torch.zeros(512, 512, device='cuda'), torch.zeros(512, 512, device='cuda'))
+    eng.close()
+    eng = Engine(1, 32, 48, dtype='fp32')
+    with pytest.raises(RuntimeError):
+        eng.bind_head('conv1_rgb_meta.weight', torch.zeros(32, 32, 3, 3, device='cuda'), torch.zeros(32, 32, 3, 3, device='cuda'), torch.zeros(32, 32, 3, 3, device='cuda'))
+    with pytest.raises(RuntimeError):
+        eng.head_backward()
+    eng.close()

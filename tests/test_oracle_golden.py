@@ -328,3 +328,51 @@ def test_transforms_oracle_reproduces_reference_crop_flip(golden_dir):
         np.testing.assert_array_equal(TO.apply(z[p + 'sparse'], d), z[p + 'sparse_out'], err_msg=name)
         np.testing.assert_array_equal(TO.adjust_intrinsics(z[p + 'K'], d, H, W), z[p + 'K_out'], err_msg=name)
     assert seen_crop >= 4 and seen_flip >= 4          # the fixture exercises what it claims to
+
+
+# ---- stage-2 head trainer --------------------------------------------------------------
+def _check_put(z, key, value, rtol, atol, what):
+    value = np.asarray(value)
+    if key in z.files:
+        np.testing.assert_allclose(value, z[key], rtol=rtol, atol=atol, err_msg=what)
+    else:
+        rows = z[key + '#rows']
+        idx = np.linspace(0, value.shape[0] - 1, 24).astype(np.int64)
+        np.testing.assert_allclose(value[idx], rows, rtol=rtol, atol=atol, err_msg=what)
+        s = z[key + '#sum']
+        assert abs(value.sum(dtype=np.float64) - s[0]) <= rtol * s[1] + atol * value.size, what
+
+
+@pytest.mark.parametrize('name', ['head_reverse_32x48_n2', 'head_forward_32x48_n2', 'head_reverse_64x96'])
+def test_head_trainer_oracle_matches_reference(golden_dir, name):
+    from oracle import head_oracle as HO
+    from tests.golden.make_golden_head import perturbed_target
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = (int(v) for v in z['meta'])
+    lr, b1, b2, eps, wd, tau = (float(v) for v in z['hp'])
+    sd = synth.formula_state_dict('meta_selfsup_seq_1layer_ema', 1.0)
+    sd.update(perturbed_target(sd))
+    o = HO.HeadTrainerOracle(sd, str(z['loss_type']), max_input_depth=80.0, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, tau=tau)
+    for s in range(steps):
+        image, sparse = synth.synthetic_frame(s, h, w, n)
+        r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+        p = 's%d/' % s
+        assert abs(r['loss'] - float(z[p + 'loss'])) < (2e-6 if s == 0 else 2e-5)
+        idx = z[p + 'row_idx']
+        at = 1e-5 if s == 0 else 3e-4         # later steps carry Adam's first-step sign noise of near-zero gradient entries
+        np.testing.assert_allclose(r['emb'].numpy()[idx], z[p + 'emb_rows'], rtol=1e-4, atol=at)
+        np.testing.assert_allclose(r['ref'].numpy()[idx], z[p + 'ref_rows'], rtol=1e-4, atol=at)
+        for k in z['head_names']:
+            k = str(k)
+            assert bool(z[p + 'has_grad/' + k]) == (k in r['grads']), k
+            if k in r['grads']:
+                _check_put(z, p + 'grad/' + k, r['grads'][k].numpy(), 2e-3 if s == 0 else 2e-2, 2e-8 if s == 0 else 2e-7, k)
+        if s == 0:
+            # after the FIRST Adam step every trained entry moved by lr * sign(g) (up to eps): compare where |g| is not tiny
+            continue
+    for k in o.P:
+        if k.startswith(('proj', 'pred')):
+            tol = 3 * lr * steps if (k in o.names and not k.startswith('proj_t')) else 1e-6
+            if 'running' in k:
+                tol = 2e-4          # statistics of activations downstream of Adam-updated weights (first-step sign noise)
+            _check_put(z, 's%d/after/%s' % (steps - 1, k), o.P[k].detach().numpy(), 1e-5, tol, k)

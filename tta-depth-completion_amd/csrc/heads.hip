@@ -534,6 +534,7 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
             switch (key3) {
                 case 0: GX_(0, 0); break; case 1: GX_(0, 1); break; case 2: GX_(0, 2); break;
                 case 10: GX_(1, 0); break; case 11: GX_(1, 1); break;
+                case 20: GX_(2, 0); break;                  // BN-backward prologue into a 512-wide layer (stage-2 head trainer)
                 default: return -22;
             }
 #undef GX_
@@ -561,6 +562,7 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
             case 100: GL_(2, 1, 0, false); break;
             case 110: GL_(2, 1, 1, false); break;
             case 20: GL_(2, 0, 2, false); break;
+            case 200: GL_(2, 2, 0, false); break;
             default: return -22;
         }
     } else {
@@ -623,7 +625,7 @@ int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, con
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int row_blocks, int R, int N,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       float* gscale, float* c1, float* c2) {
+                                       float* gscale, float* c1, float* c2, float* dgamma, float* dbeta) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= N) return;
@@ -636,12 +638,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     if (lane != 0) return;
     c1[c] = (float)(s1 / R); c2[c] = (float)(s2 / R);
     gscale[c] = gamma[c] * invstd[c];
+    if (dgamma) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }     // d gamma = sum g * xhat, d beta = sum g (stage-2 head trainer)
 }
 
 int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
-                                float* gscale, float* c1, float* c2, hipStream_t s) {
+                                float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma, float* dbeta) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + 3) / 4), dim3(256), 0, s, part, row_blocks, R, N, gamma,
-                       invstd, gscale, c1, c2);
+                       invstd, gscale, c1, c2, dgamma, dbeta);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

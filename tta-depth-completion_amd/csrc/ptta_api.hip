@@ -56,6 +56,15 @@ struct ptta_ctx {
     int meta_mode = 0;
     struct Adapted { std::string name; long n = 0; float *p = nullptr, *m = nullptr, *v = nullptr, *g = nullptr; };
     std::vector<Adapted> adapted;
+    // stage-2 head trainer: the twelve proj / pred parameters (bound like the adapted ones) + the six
+    // proj_t parameters the EMA writes; everything below is allocated by the first ptta_head_bind
+    struct HeadT { bool ready = false; std::vector<Adapted> prm, tgt; bool has_grad[12] = {};
+                   float *hyper = nullptr, *tau2 = nullptr, *loss = nullptr, *loss_part = nullptr, *wpart = nullptr, *bpart = nullptr, *dp = nullptr;
+                   float *sv_mean = nullptr, *sv_inv = nullptr, *sv_scale = nullptr, *sv_shift = nullptr;     // proj BatchNorm state of its FIRST application
+                   int* step = nullptr; unsigned* ticket = nullptr; PttaAdamEntry *tab = nullptr, *etab = nullptr;
+                   std::vector<PttaAdamEntry> tab_host, etab_host; int tab_n = 0; long tab_total = 0, etab_total = 0; int tab_mode = -1; bool etab_dirty = true;
+                   int reverse = 1; bool fwd_ok = false, bwd_ok = false; } head;
+    int head_swap = 0;               // heads_forward order: 0 = emb from the proxy pass (TTA, stage-2 reverse), 1 = emb from the real pass
     float *meta_w = nullptr, *meta_b = nullptr;      // 1layer aliases of adapted[0].p / adapted[1].p
     float *gW = nullptr, *gB = nullptr;
     // 2layers meta layer (Res_Conv(32,128)): four 32-channel groups
@@ -748,6 +757,17 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
 int heads_forward(ptta_ctx* c, hipStream_t s) {
     const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
     const void* feat_zero = (const char*)c->feat + half;
+    if (c->head_swap) {
+        // stage 2 without `reverse` (network_exp_msg_chn_adapt.py:681-684): emb = pred(proj(feat)), ref = proj(feat_zero); the
+        // BatchNorm state of proj's FIRST application is what its backward needs, the second one overwrites it -> saved aside
+        RUN(mlp_forward(c, "proj", c->feat, c->bf16, 32, c->h1, c->pz, s));
+        BNorm& bn = c->bn["proj.1"];
+        const float* src[4] = {bn.mean, bn.inv, bn.scale, bn.shift}; float* dst[4] = {c->head.sv_mean, c->head.sv_inv, c->head.sv_scale, c->head.sv_shift};
+        for (int k = 0; k < 4; ++k) HIPCHK(hipMemcpyAsync(dst[k], src[k], 512 * 4, hipMemcpyDeviceToDevice, s));
+        RUN(mlp_forward(c, "pred", c->pz, 0, 512, c->h2, c->emb, s));
+        RUN(mlp_forward(c, "proj", feat_zero, c->bf16, 32, c->h1z, c->ref, s));
+        return 0;
+    }
     RUN(mlp_forward(c, "proj", feat_zero, c->bf16, 32, c->h1z, c->pz, s));
     RUN(mlp_forward(c, "pred", c->pz, 0, 512, c->h2, c->emb, s));
     RUN(mlp_forward(c, "proj", c->feat, c->bf16, 32, c->h1, c->ref, s));     // last: its BN statistics are kept for backward
@@ -1295,6 +1315,213 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
     if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+
+// ============================ stage-2 head trainer =============================================
+// src/head_main.py:464-480 with loss_type 'head_selfsup_seq_ema[_reverse]' (network_exp_msg_chn_adapt.py:610-699): EMA of the
+// target head, both backbone passes without gradient, heads forward with train-mode BatchNorm1d, prepare_loss, backward into
+// pred (and proj when not `reverse`), Adam over the parameters that received a gradient.
+static const char* const HEAD_NAMES[12] = {"proj.0.weight", "proj.0.bias", "proj.1.weight", "proj.1.bias", "proj.3.weight", "proj.3.bias",
+                                           "pred.0.weight", "pred.0.bias", "pred.1.weight", "pred.1.bias", "pred.3.weight", "pred.3.bias"};
+static long head_numel(int k) { return k == 0 ? 512L * 32 : (k == 4 || k == 6 || k == 10) ? 512L * 512 : 512L; }
+
+static int head_init(ptta_ctx* c) {
+    if (c->head.ready) return 0;
+    if (c->nl) return c->fail("the stage-2 head trainer is built for MSG_CHN handles", -38);
+    if (c->bf16) return c->fail("the stage-2 head trainer needs an fp32 handle", -38);
+    if (c->dual) return c->fail("stage 2 runs on sizes divisible by 16 (the reference pads only in the 'adapt' forward, src/msg_chn_model_adapt.py:54-140)", -38);
+    if (c->stat_sync.world > 1) return c->fail("the stage-2 head trainer has no SyncBatchNorm exchange", -38);
+    auto& h = c->head;
+    h.prm.resize(12); h.tgt.resize(6);
+    for (int k = 0; k < 12; ++k) { h.prm[k].name = HEAD_NAMES[k]; h.prm[k].n = head_numel(k); h.prm[k].g = c->falloc((size_t)h.prm[k].n); }
+    for (int k = 0; k < 6; ++k) { h.tgt[k].name = std::string("proj_t.") + (HEAD_NAMES[k] + 5); h.tgt[k].n = head_numel(k); }
+    h.hyper = c->falloc(8); h.tau2 = c->falloc(2); h.loss = c->falloc(1); h.loss_part = c->falloc(1024);
+    const int chunks = ptta_linear_wgrad_chunks(c->Rg, nullptr);
+    h.wpart = c->falloc((size_t)chunks * 512 * 512); h.bpart = c->falloc((size_t)chunks * 512);
+    h.dp = c->falloc((size_t)c->Rg * 512);
+    h.sv_mean = c->falloc(512); h.sv_inv = c->falloc(512); h.sv_scale = c->falloc(512); h.sv_shift = c->falloc(512);
+    h.step = (int*)c->dalloc(4); h.ticket = (unsigned*)c->dalloc(4);
+    h.tab = (PttaAdamEntry*)c->dalloc(12 * sizeof(PttaAdamEntry)); h.etab = (PttaAdamEntry*)c->dalloc(6 * sizeof(PttaAdamEntry));
+    if (c->oom) return c->fail("out of device memory (head trainer workspace)", -12);
+    const float hy[7] = {1e-3f, 0.9f, 0.999f, 1e-8f, 0.f, 0.f, 0.f};
+    RUN(ptta_launch_set_floats(h.hyper, hy, 5, nullptr));
+    const float t2[2] = {0.999f, (float)(1.0 - 0.999)};
+    RUN(ptta_launch_set_floats(h.tau2, t2, 2, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));                 // creation-time only
+    h.ready = true;
+    return 0;
+}
+
+// re-derive the library's packed copies of one head tensor from its bound parameter (what ptta_load_weights does for it)
+static int head_reload(ptta_ctx* c, int k, hipStream_t s) {
+    const auto& e = c->head.prm[k];
+    if (!e.p) return 0;
+    const std::string name = e.name, base = name.substr(0, name.rfind('.'));
+    const bool is_w = name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0;
+    if (c->fc.count(base)) {
+        Lin& l = c->fc[base];
+        if (is_w) {
+            HIPCHK(hipMemcpyAsync(l.W, e.p, (size_t)e.n * 4, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(transpose_kernel, dim3(nblk(e.n)), dim3(256), 0, s, (const float*)e.p, l.Wt, l.N, l.K);
+            ptta_split_weight(l.W, l.Whi, l.Wlo, l.Wil, e.n, l.K, s);
+            ptta_split_weight(l.Wt, l.Wthi, l.Wtlo, l.Wtil, e.n, l.N, s);
+        } else HIPCHK(hipMemcpyAsync(l.bias, e.p, (size_t)e.n * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        BNorm& b = c->bn[base];
+        HIPCHK(hipMemcpyAsync(is_w ? b.gamma : b.beta, e.p, 512 * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+int ptta_head_bind(ptta_handle c, const char* name_, float* param, float* exp_avg, float* exp_avg_sq) {
+    if (!c || !name_ || !param) return -1;
+    RUN(head_init(c));
+    const std::string name(name_);
+    auto& h = c->head;
+    for (auto& e : h.prm) if (e.name == name) {
+        if (!exp_avg || !exp_avg_sq) return c->fail("Adam moments of " + name + " are required", -22);
+        e.p = param; e.m = exp_avg; e.v = exp_avg_sq; h.tab_mode = -1; h.etab_dirty = true; h.fwd_ok = h.bwd_ok = false;
+        return 0;
+    }
+    for (auto& e : h.tgt) if (e.name == name) { e.p = param; h.etab_dirty = true; return 0; }
+    return c->fail("not a head parameter: " + name, -2);
+}
+
+int ptta_head_set_hparams(ptta_handle c, float lr, float beta1, float beta2, float eps, float weight_decay, float tau, int adam_step,
+                          ptta_stream s_) {
+    if (!c) return -1;
+    RUN(head_init(c));
+    hipStream_t s = (hipStream_t)s_;
+    const float hy[5] = {lr, beta1, beta2, eps, weight_decay};
+    RUN(ptta_launch_set_floats(c->head.hyper, hy, 5, s));
+    const float t2[2] = {tau, (float)(1.0 - (double)tau)};
+    RUN(ptta_launch_set_floats(c->head.tau2, t2, 2, s));
+    if (adam_step >= 0) RUN(ptta_launch_set_int(c->head.step, adam_step, s));
+    return 0;
+}
+
+int ptta_head_reload(ptta_handle c, ptta_stream s) {
+    if (!c) return -1;
+    RUN(head_init(c));
+    c->drop_graphs();
+    for (int k = 0; k < 12; ++k) RUN(head_reload(c, k, (hipStream_t)s));
+    return 0;
+}
+
+int ptta_head_forward(ptta_handle c, const float* image, const float* sparse, int reverse, float* emb_out, float* ref_out, ptta_stream s_) {
+    if (!c || !image || !sparse) return -1;
+    RUN(head_init(c));
+    auto& h = c->head;
+    hipStream_t s = (hipStream_t)s_;
+    for (int k = (reverse ? 6 : 0); k < 12; ++k) if (!h.prm[k].p) return c->fail(std::string("head parameter not bound: ") + HEAD_NAMES[k], -3);
+    // _update_head(): proj_t <- tau proj_t + (1 - tau) proj, BEFORE the heads run (network_exp_msg_chn_adapt.py:682,691)
+    int nt = 0; for (auto& e : h.tgt) nt += e.p ? 1 : 0;
+    if (nt != 0 && nt != 6) return c->fail("bind all six proj_t parameters or none", -3);
+    if (nt == 6) {
+        if (h.etab_dirty) {
+            h.etab_host.resize(6); long off = 0;
+            for (int k = 0; k < 6; ++k) {
+                if (!h.prm[k].p) return c->fail("the EMA needs the proj parameters bound too", -3);
+                h.etab_host[k] = PttaAdamEntry{h.tgt[k].p, nullptr, nullptr, h.prm[k].p, h.tgt[k].n, off}; off += h.tgt[k].n;
+            }
+            h.etab_total = off;
+            HIPCHK(hipMemcpyAsync(h.etab, h.etab_host.data(), 6 * sizeof(PttaAdamEntry), hipMemcpyHostToDevice, s));
+            h.etab_dirty = false;
+        }
+        RUN(ptta_launch_ema_multi(h.etab, 6, h.etab_total, h.tau2, s));
+    }
+    h.reverse = reverse ? 1 : 0; h.bwd_ok = false;
+    c->head_swap = reverse ? 0 : 1;
+    const int rc = ptta_forward_train(c, image, sparse, nullptr, emb_out, ref_out, s_);
+    c->head_swap = 0;
+    if (rc != 0) return rc;
+    h.fwd_ok = true;
+    return 0;
+}
+
+int ptta_head_backward(ptta_handle c, float* loss_out, ptta_stream s_) {
+    if (!c) return -1;
+    auto& h = c->head;
+    if (!h.ready || !h.fwd_ok || !c->fwd_valid) return c->fail("ptta_head_backward needs the activations of the last ptta_head_forward", -3);
+    hipStream_t s = (hipStream_t)s_;
+    const long R = c->Rg;
+    float* g_emb = c->gref_buf;
+    RUN(ptta_launch_prepare_loss(c->emb, c->ref, R, 512, g_emb, h.loss_part, h.loss, s));
+    if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h.loss, 4, hipMemcpyDeviceToDevice, s));
+    for (int k = 0; k < 12; ++k) h.has_grad[k] = false;
+    auto G = [&](int k) { h.has_grad[k] = true; return h.prm[k].g; };
+    // one MLP: out = Linear3(relu(BN(Linear0(x)))).  g: d out; hid: pre-BN hidden; x: MLP input (K wide); st_*: BN state of THIS application
+    auto mlp_backward = [&](const char* name, int k0, const float* g, const float* hid, const void* x, int K,
+                            const float* st_mean, const float* st_inv, const float* st_scale, const float* st_shift, float* dx) -> int {
+        const Lin& l0 = c->fc[std::string(name) + ".0"]; const Lin& l3 = c->fc[std::string(name) + ".3"]; BNorm& bn = c->bn[std::string(name) + ".1"];
+        LinWgradArgs w3; w3.G = g; w3.X = hid; w3.xscale = st_scale; w3.xshift = st_shift; w3.Wpart = h.wpart; w3.bpart = h.bpart; w3.R = R; w3.O = 512; w3.I = 512;
+        RUN(ptta_launch_linear_wgrad(w3, G(k0 + 4), G(k0 + 5), s));
+        GemmArgs ga; ga.A = g; ga.W = l3.Wt; ga.C = c->gmask; ga.R = (int)R; ga.K = 512; ga.N = 512; ga.epi = 2;
+        ga.eH = hid; ga.escale = st_scale; ga.eshift = st_shift; ga.emean = st_mean; ga.einv = st_inv; ga.part = c->bn_part;
+        ga.x3 = c->x3; ga.Whi = l3.Wthi; ga.Wlo = l3.Wtlo; ga.Wil = l3.Wtil;
+        RUN(ptta_launch_gemm(ga, s));
+        RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(ga), (int)R, 512, bn.gamma, st_inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s,
+                                        G(k0 + 2), G(k0 + 3)));
+        LinWgradArgs w0; w0.G = c->gmask; w0.Gh = hid; w0.gscale = c->bnb_gscale; w0.gc1 = c->bnb_c1; w0.gc2 = c->bnb_c2; w0.gmean = st_mean; w0.ginv = st_inv;
+        w0.X = (const float*)x; w0.Wpart = h.wpart; w0.bpart = h.bpart; w0.R = R; w0.O = 512; w0.I = K;
+        RUN(ptta_launch_linear_wgrad(w0, G(k0), G(k0 + 1), s));
+        if (dx) {
+            GemmArgs g2; g2.A = c->gmask; g2.A2 = hid; g2.W = l0.Wt; g2.C = dx; g2.R = (int)R; g2.K = 512; g2.N = K; g2.pro = 2;
+            g2.pscale = c->bnb_gscale; g2.pmean = st_mean; g2.pinv = st_inv; g2.pc1 = c->bnb_c1; g2.pc2 = c->bnb_c2;
+            g2.x3 = c->x3; g2.Whi = l0.Wthi; g2.Wlo = l0.Wtlo;
+            RUN(ptta_launch_gemm(g2, s));
+        }
+        return 0;
+    };
+    BNorm& bp = c->bn["pred.1"];
+    // pred consumed c->pz in both modes (reverse: proj(feat_zero), otherwise proj(feat))
+    RUN(mlp_backward("pred", 6, g_emb, c->h2, c->pz, 512, bp.mean, bp.inv, bp.scale, bp.shift, h.reverse ? nullptr : h.dp));
+    if (!h.reverse)       // emb = pred(proj(feat)): continue into proj's first application (its BatchNorm state was saved aside)
+        RUN(mlp_backward("proj", 0, h.dp, c->h1, c->feat, 32, h.sv_mean, h.sv_inv, h.sv_scale, h.sv_shift, nullptr));
+    h.bwd_ok = true;
+    return 0;
+}
+
+int ptta_head_adam_step(ptta_handle c, ptta_stream s_) {
+    if (!c) return -1;
+    auto& h = c->head;
+    if (!h.ready || !h.bwd_ok) return c->fail("ptta_head_adam_step needs the gradients of ptta_head_backward", -3);
+    hipStream_t s = (hipStream_t)s_;
+    const int k0 = h.reverse ? 6 : 0;                         // torch.optim.Adam skips parameters whose .grad is None
+    if (h.tab_mode != h.reverse) {
+        h.tab_host.clear(); long off = 0;
+        for (int k = k0; k < 12; ++k) { auto& e = h.prm[k]; h.tab_host.push_back(PttaAdamEntry{e.p, e.m, e.v, e.g, e.n, off}); off += e.n; }
+        h.tab_n = 12 - k0; h.tab_total = off;
+        HIPCHK(hipMemcpyAsync(h.tab, h.tab_host.data(), h.tab_host.size() * sizeof(PttaAdamEntry), hipMemcpyHostToDevice, s));
+        h.tab_mode = h.reverse;
+    }
+    RUN(ptta_launch_adam_multi(h.tab, h.tab_n, h.tab_total, h.hyper, h.step, h.ticket, s));
+    c->drop_graphs();                                         // the TTA graph holds no head weights by value, but stay conservative
+    for (int k = k0; k < 12; ++k) RUN(head_reload(c, k, s));
+    h.bwd_ok = false;
+    return 0;
+}
+
+int ptta_head_step(ptta_handle c, const float* image, const float* sparse, int reverse, float* loss_out, ptta_stream s) {
+    RUN(ptta_head_forward(c, image, sparse, reverse, nullptr, nullptr, s));
+    RUN(ptta_head_backward(c, loss_out, s));
+    return ptta_head_adam_step(c, s);
+}
+
+int ptta_head_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity, int* has_grad_host, ptta_stream s) {
+    if (!c || !name) return -1;
+    auto& h = c->head;
+    if (!h.ready) return c->fail("no head parameter bound", -3);
+    for (int k = 0; k < 12; ++k) if (h.prm[k].name == name) {
+        if (has_grad_host) *has_grad_host = h.has_grad[k] ? 1 : 0;
+        if (dst && h.has_grad[k]) {
+            if (capacity < h.prm[k].n) return c->fail("capacity too small", -22);
+            HIPCHK(hipMemcpyAsync(dst, h.prm[k].g, (size_t)h.prm[k].n * 4, hipMemcpyDeviceToDevice, (hipStream_t)s));
+        }
+        return 0;
+    }
+    return c->fail(std::string("not a trainable head parameter: ") + name, -2);
 }
 
 int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const float* stdv) {

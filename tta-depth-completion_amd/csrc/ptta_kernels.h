@@ -105,7 +105,7 @@ int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, con
                             float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
                             float* mean, float* invstd, float* scale, float* shift, hipStream_t s);
 int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
-                                float* gscale, float* c1, float* c2, hipStream_t s);
+                                float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr);
 
 // ---- loss.hip ---------------------------------------------------------------------------------
 struct LossScalars;      // device-resident scalars, see loss.hip
@@ -149,6 +149,23 @@ struct PttaAdamEntry { float *p, *m, *v; const float* g; long n, off; };
 int ptta_launch_adam_multi(const PttaAdamEntry* tab_dev, int nt, long total, const float* hyper, int* step_dev, unsigned* ticket_dev, hipStream_t s);
 int ptta_launch_set_floats(float* dst, const float* host_src, int n /*<= 8*/, hipStream_t s);   // by kernel argument: no sync
 int ptta_launch_set_int(int* dst, int v, hipStream_t s);
+
+// ---- head_train.hip (stage-2 head trainer: Linear weight gradients, prepare loss, EMA) -----------
+struct LinWgradArgs {
+    const float* G = nullptr;      // [R][O] upstream gradient (pre-transform)
+    const float* Gh = nullptr;     // [R][O] pre-BatchNorm hidden: when set, G is BN-backward transformed on the fly
+    const float *gscale = nullptr, *gc1 = nullptr, *gc2 = nullptr, *gmean = nullptr, *ginv = nullptr;
+    const float* X = nullptr;      // [R][I] layer input
+    const float *xscale = nullptr, *xshift = nullptr;   // when set, X = relu(X * xscale + xshift) on the fly
+    float* Wpart = nullptr;        // [chunks][O][I]
+    float* bpart = nullptr;        // [chunks][O]
+    long R = 0; int O = 512, I = 512, rchunk = 0;
+};
+int ptta_linear_wgrad_chunks(long R, int* rchunk_out);
+int ptta_launch_linear_wgrad(LinWgradArgs a, float* dW /*[O][I]*/, float* db /*[O] or NULL*/, hipStream_t s);
+int ptta_launch_prepare_loss(const float* emb, const float* ref, long R, int C, float* g_emb, float* part /* >= 1024 floats */, float* loss,
+                             hipStream_t s);
+int ptta_launch_ema_multi(const PttaAdamEntry* tab_dev, int nt, long total, const float* tau_dev /* {tau, 1 - tau} */, hipStream_t s);
 
 // ---- dcn.hip (modulated deformable convolution, NCHW fp32) -------------------------------------
 struct DcnArgs {

@@ -56,6 +56,14 @@ SIGNATURES = [
     ('ptta_mdconv_forward', c_int, [_P] * 6 + [c_int] * 15 + [_P]),
     ('ptta_mdconv_backward', c_int, [_P] * 11 + [c_int] * 15 + [_P]),
     ('ptta_set_image_norm', c_int, [_P, c_float, POINTER(c_float), POINTER(c_float)]),
+    ('ptta_head_bind', c_int, [_P, c_char_p, _P, _P, _P]),
+    ('ptta_head_set_hparams', c_int, [_P, c_float, c_float, c_float, c_float, c_float, c_float, c_int, _P]),
+    ('ptta_head_reload', c_int, [_P, _P]),
+    ('ptta_head_forward', c_int, [_P, _P, _P, c_int, _P, _P, _P]),
+    ('ptta_head_backward', c_int, [_P, _P, _P]),
+    ('ptta_head_adam_step', c_int, [_P, _P]),
+    ('ptta_head_step', c_int, [_P, _P, _P, c_int, _P, _P]),
+    ('ptta_head_get_grad', c_int, [_P, c_char_p, _P, c_int64, POINTER(c_int), _P]),
     ('ptta_crop_flip', c_int, [_P, _P] + [c_int] * 6 + [_P] * 5),
     ('ptta_set_stat_sync', c_int, [_P, _P, _P, _P, c_int64, c_int]),
     ('ptta_set_graph', c_int, [_P, c_int]),

@@ -14,6 +14,10 @@ ADAPTED_2LAYERS = (_P2 + '0.0.weight', _P2 + '0.1.weight', _P2 + '0.1.bias', _P2
                    _P2 + '2.weight', _P2 + '2.bias')
 
 
+HEAD_PARAMS = tuple('%s.%s.%s' % (m, l, t) for m in ('proj', 'pred') for l in ('0', '1', '3') for t in ('weight', 'bias'))
+HEAD_TARGETS = tuple('proj_t' + k[4:] for k in HEAD_PARAMS[:6])
+
+
 def adapted_names(meta='1layer'):
     return ADAPTED_2LAYERS if meta == '2layers' else ADAPTED
 _BOUND_SUFFIX = ('running_mean', 'running_var', 'num_batches_tracked')
@@ -271,6 +275,54 @@ class Engine:
         self._keep['stat_sync'] = (buf, cb)
         self._chk(self.lib.ptta_set_stat_sync(self.handle, ctypes.cast(cb, c_void_p), None, c_void_p(buf.data_ptr()), buf.numel(), world),
                   'ptta_set_stat_sync')
+
+    # ---- stage-2 head trainer (include/ptta.h "Stage-2 head trainer"; src/head_main.py:464-480) ------------
+    def bind_head(self, name, param, exp_avg=None, exp_avg_sq=None):
+        ts = [t for t in (param, exp_avg, exp_avg_sq) if t is not None]
+        for t in ts:
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+        self._keep['head/' + name] = ts
+        self._chk(self.lib.ptta_head_bind(self.handle, name.encode(), ptr(param), ptr(exp_avg), ptr(exp_avg_sq)), 'ptta_head_bind')
+
+    def set_head_hparams(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, tau=0.999, adam_step=-1):
+        self._chk(self.lib.ptta_head_set_hparams(self.handle, lr, betas[0], betas[1], eps, weight_decay, tau, int(adam_step), _stream()),
+                  'ptta_head_set_hparams')
+
+    def head_reload(self):
+        self._chk(self.lib.ptta_head_reload(self.handle, _stream()), 'ptta_head_reload')
+
+    def head_forward(self, image, sparse, reverse=True, want=True):
+        image = self._f32(image, (self.n, 3, self.h, self.w))
+        sparse = self._f32(sparse, (self.n, 1, self.h, self.w))
+        emb = ref = None
+        if want:
+            emb = torch.empty((self.rows, self.emb_dim), device=image.device, dtype=torch.float32)
+            ref = torch.empty_like(emb)
+        self._chk(self.lib.ptta_head_forward(self.handle, ptr(image), ptr(sparse), int(bool(reverse)), ptr(emb), ptr(ref), _stream()),
+                  'ptta_head_forward')
+        return emb, ref
+
+    def head_backward(self):
+        loss = torch.empty(1, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.ptta_head_backward(self.handle, ptr(loss), _stream()), 'ptta_head_backward')
+        return loss
+
+    def head_adam_step(self):
+        self._chk(self.lib.ptta_head_adam_step(self.handle, _stream()), 'ptta_head_adam_step')
+
+    def head_step(self, image, sparse, reverse=True):
+        image = self._f32(image, (self.n, 3, self.h, self.w))
+        sparse = self._f32(sparse, (self.n, 1, self.h, self.w))
+        loss = torch.empty(1, device=image.device, dtype=torch.float32)
+        self._chk(self.lib.ptta_head_step(self.handle, ptr(image), ptr(sparse), int(bool(reverse)), ptr(loss), _stream()), 'ptta_head_step')
+        return loss
+
+    def head_grad(self, name, like):
+        """Gradient of a head parameter after head_backward(), or None when it is outside the graph (reverse: all of proj)."""
+        has = c_int(0)
+        out = torch.empty_like(like)
+        self._chk(self.lib.ptta_head_get_grad(self.handle, name.encode(), ptr(out), out.numel(), byref(has), _stream()), 'ptta_head_get_grad')
+        return out if has.value else None
 
     def set_graph(self, enable):
         self._chk(self.lib.ptta_set_graph(self.handle, int(bool(enable))), 'ptta_set_graph')

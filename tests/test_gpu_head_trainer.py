@@ -196,3 +196,61 @@ def test_head_trainer_refusals():
     with pytest.raises(RuntimeError):
         eng.head_backward()
     eng.close()
+
+
+def _facade(golden_z):
+    from proxytta.model import ExternalModel_Adapt
+    lr, b1, b2, eps, wd, tau = (float(v) for v in golden_z['hp'])
+    model = ExternalModel_Adapt('msg_chn', 0.0, 80.0, max_input_depth=80.0)
+    model._prepare_head(ONE)
+    head_params = model.prepare_parameters('head_selfsup_ema')            # re-creates the heads (head_main.py:268)
+    sd = synth.formula_state_dict(ONE, 1.0)
+    sd.update(perturbed_target(sd))
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    opt = torch.optim.Adam(head_params, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    return model, head_params, opt
+
+
+@pytest.mark.parametrize('name', ['head_reverse_32x48_n2', 'head_forward_32x48_n2'])
+def test_reference_style_stage2_loop_through_the_facade(golden_dir, name):
+    """The loop of src/head_main.py:441-480 written against the mirror: forward(loss_type) -> compute_loss('prepare') ->
+    zero_grad / backward / torch.optim.Adam.step; the losses follow the reference's fixture."""
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = (int(v) for v in z['meta'])
+    loss_type = str(z['loss_type'])
+    model, head_params, opt = _facade(z)
+    names = model.model._head_names
+    for s in range(steps):
+        image, sparse = (torch.from_numpy(a).cuda() for a in synth.synthetic_frame(s, h, w, n))
+        model.train(prepare=True)
+        output_depth, embedding, reference = model.forward(image=image, sparse_depth=sparse, loss_type=loss_type)
+        assert output_depth is None
+        loss, info = model.compute_loss(input_rgb=image, output_depth=output_depth, validity_map=None, ground_truth=None,
+                                        embedding=embedding, reference=reference, loss_type='prepare')
+        opt.zero_grad()
+        loss.backward()
+        for k, p in zip(names, head_params):
+            assert (p.grad is not None) == bool(z['s%d/has_grad/%s' % (s, k)]), k
+        opt.step()
+        assert abs(float(loss) - float(z['s%d/loss' % s])) < (2e-5 if s == 0 else 1e-4)
+    state = model.model.model.state_dict()
+    _check(z, 's%d/after/proj_t.3.weight' % (steps - 1), state['proj_t.3.weight'], 1e-5, 1e-5, 'proj_t.3.weight')
+    assert int(state['pred.1.num_batches_tracked']) == steps
+
+
+def test_facade_fused_head_step_matches_its_unfused_loop(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'head_reverse_32x48_n2.npz'))
+    h, w, n, steps = (int(v) for v in z['meta'])
+    loss_type = str(z['loss_type'])
+    model, head_params, opt = _facade(z)
+    model.bind_head_optimizer(opt, tau=float(z['hp'][5]))
+    for s in range(steps):
+        image, sparse = (torch.from_numpy(a).cuda() for a in synth.synthetic_frame(s, h, w, n))
+        loss = model.head_step(image, sparse, loss_type)
+        assert abs(float(loss) - float(z['s%d/loss' % s])) < (2e-5 if s == 0 else 1e-4)
+    names = model.model._head_names
+    st = opt.state[head_params[names.index('pred.3.weight')]]
+    assert int(float(st['step'])) == steps and float(st['exp_avg'].abs().sum()) > 0
+    assert 'step' not in opt.state[head_params[names.index('proj.0.weight')]] or int(float(opt.state[head_params[names.index('proj.0.weight')]]['step'])) == 0
+    state = model.model.model.state_dict()
+    _check(z, 's%d/after/pred.3.weight' % (steps - 1), state['pred.3.weight'], 0, 2.5 * float(z['hp'][0]) * steps, 'pred.3.weight')

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import synth
-from .engine import ADAPTED, Engine, adapted_names
+from .engine import ADAPTED, HEAD_TARGETS, Engine, adapted_names
 
 CANONICAL_LOSS_TYPE = 'adapt_meta_selfsup_seq_ema_reverse'
 
@@ -105,6 +105,21 @@ class _LossFn(torch.autograd.Function):
         return None, None, gd, None, None, None, gr, None, None, None
 
 
+class _PrepareLossFn(torch.autograd.Function):
+    """prepare_loss (src/external_model_adapt.py:524-541) of the last head forward; its backward hands the head parameters
+    the gradients ptta_head_backward already produced (parameters outside the graph get None, as in the reference)."""
+
+    @staticmethod
+    def forward(ctx, eng, names, *head_params):
+        loss = eng.head_backward()
+        ctx.grads = [eng.head_grad(k, p) for k, p in zip(names, head_params)]
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        return (None, None) + tuple(None if g is None else g * g_loss for g in ctx.grads)
+
+
 class MsgChnModel_Adapt(object):
     """Counterpart of src/msg_chn_model_adapt.py:11-556 on libptta_hip."""
 
@@ -179,6 +194,103 @@ class MsgChnModel_Adapt(object):
         if mode != 'meta':
             raise NotImplementedError("adapt_mode %r: only 'meta' is on the accelerated path" % mode)
         return nn.ParameterList([p for n, p in self.model.named_parameters() if 'meta' in n])
+
+    # ---- stage 2 (src/head_main.py:259-276, 464-480) ------------------------------------------------------
+    def prepare_parameters(self, mode=''):
+        """mode containing 'head' (head_main.py:268 passes 'head_selfsup_ema'): the heads are RE-CREATED -- the reference calls
+        `_prepare_head(mode)` again here (src/msg_chn_model_adapt.py:295-298), stage 2 trains them from scratch -- and the
+        proj / pred parameters without proj_t are returned (:300-304)."""
+        if 'head' not in mode or 'selfsup' not in mode or 'ema' not in mode:
+            raise NotImplementedError("prepare_parameters(%r): only the head trainer's 'head_selfsup_ema' is on the accelerated path" % mode)
+        if self.prepare_mode is None:
+            raise RuntimeError('_prepare_head(prepare_mode) first (head_main.py:259)')
+        if type(self) is not MsgChnModel_Adapt or self.meta != '1layer':
+            raise NotImplementedError('the stage-2 head trainer is built for MSG_CHN with the 1layer meta conv')
+        params = dict(self.model.named_parameters())
+        with torch.no_grad():
+            for k, shape in synth.msg_chn_keys(self.prepare_mode):
+                if k.startswith(('proj.', 'pred.')):
+                    t = params.get(k, None)
+                    tgt = t if t is not None else self.model.state_dict()[k]
+                    tgt.copy_(_init_tensor(k, shape).to(tgt.device))
+            state = self.model.state_dict()
+            for k in state:
+                if k.startswith('proj_t.'):
+                    state[k].copy_(state['proj.' + k[len('proj_t.'):]])          # copy.deepcopy(self.proj)
+        self._clear_engines()
+        self._head_names = [k for k, _ in self.model.named_parameters() if ('proj' in k or 'pred' in k) and '_t' not in k]
+        return [params[k] for k in self._head_names]
+
+    def bind_head_optimizer(self, optimizer, tau=0.999):
+        """Share Adam state with a torch.optim.Adam built on prepare_parameters(): `head_step` then updates its exp_avg /
+        exp_avg_sq / step in place, so optimizer.state_dict() (save_model) stays meaningful."""
+        params = dict(self.model.named_parameters())
+        g = optimizer.param_groups[0]
+        self._head_hp = dict(lr=g['lr'], betas=tuple(g['betas']), eps=g['eps'], weight_decay=g['weight_decay'], tau=tau)
+        self._head_opt = optimizer
+        self._head_state = {}
+        t = 0
+        for k in self._head_names:
+            st = optimizer.state[params[k]]
+            if 'exp_avg' not in st:
+                st['step'] = torch.tensor(0.0)
+                st['exp_avg'] = torch.zeros_like(params[k].data)
+                st['exp_avg_sq'] = torch.zeros_like(params[k].data)
+            self._head_state[k] = st
+            t = max(t, int(float(st['step'])))
+        self._head_t = t
+        self._clear_engines()
+
+    def _head_engine(self, image):
+        eng = self._engine(image)
+        if not getattr(eng, '_heads_bound', False):
+            if getattr(self, '_head_names', None) is None:
+                raise RuntimeError('prepare_parameters(\'head_selfsup_ema\') must be called before a head forward (head_main.py:268)')
+            params = dict(self.model.named_parameters())
+            state = getattr(self, '_head_state', None) or {}
+            for k in self._head_names:
+                st = state.get(k) or {'exp_avg': torch.zeros_like(params[k].data), 'exp_avg_sq': torch.zeros_like(params[k].data)}
+                state[k] = st
+                eng.bind_head(k, params[k].data, st['exp_avg'], st['exp_avg_sq'])
+            self._head_state = state
+            for k in HEAD_TARGETS:
+                eng.bind_head(k, params[k].data)
+            hp = getattr(self, '_head_hp', None) or dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, tau=0.999)
+            eng.set_head_hparams(adam_step=getattr(self, '_head_t', 0), **hp)
+            eng._heads_bound = True
+        return eng
+
+    def head_forward(self, image, sparse_depth, loss_type):
+        """forward(loss_type='head_selfsup_seq_ema[_reverse]') in training mode: (None, embedding, reference)
+        (network_exp_msg_chn_adapt.py:610-699); the EMA of proj_t runs first (:682,:691)."""
+        if 'ema' not in loss_type or 'adapt' in loss_type:
+            raise NotImplementedError('loss_type %r is not on the accelerated path' % loss_type)
+        eng = self._head_engine(image)
+        eng.head_reload()                 # a torch optimizer may have stepped the bound parameters since the last call
+        emb, ref = eng.head_forward(image, sparse_depth, 'reverse' in loss_type)
+        self._head_last = eng
+        return None, emb, ref
+
+    def prepare_loss(self, embedding, reference):
+        """compute_loss(loss_type='prepare'): the loss of the LAST head forward (embedding / reference are its outputs)."""
+        eng = getattr(self, '_head_last', None)
+        if eng is None:
+            raise RuntimeError('compute_loss(loss_type=\'prepare\') follows a head forward')
+        params = dict(self.model.named_parameters())
+        loss = _PrepareLossFn.apply(eng, tuple(self._head_names), *[params[k] for k in self._head_names])
+        return loss, {'loss': loss}
+
+    def head_step(self, image, sparse_depth, loss_type):
+        """Fused stage-2 step (head_main.py:464-480): EMA, forward, prepare loss, backward, Adam -- one library call."""
+        eng = self._head_engine(image)
+        loss = eng.head_step(image, sparse_depth, 'reverse' in loss_type)
+        self._head_t = getattr(self, '_head_t', 0) + 1
+        live = self._head_names if 'reverse' not in loss_type else [k for k in self._head_names if k.startswith('pred')]
+        for k in live:
+            st = self._head_state[k]
+            if 'step' in st:
+                st['step'] += 1
+        return loss
 
     def train(self):
         self.training = True
@@ -306,6 +418,10 @@ class MsgChnModel_Adapt(object):
 
     # ---- forward / loss -----------------------------------------------------------------------
     def forward(self, image, sparse_depth, intrinsics=None, crop_mask=None, loss_type='pretrain'):
+        if 'head' in loss_type and 'init_meta' not in loss_type and loss_type != 'prepare':
+            if not self.training:
+                raise NotImplementedError('the head forward is a training-mode call (head_main.py:441)')
+            return self.head_forward(image, sparse_depth, loss_type)
         if not ('meta' in loss_type and 'selfsup' in loss_type):
             raise NotImplementedError('loss_type %r is not on the accelerated path' % loss_type)
         if self.training and 'adapt' in loss_type:
@@ -362,6 +478,8 @@ class ExternalModel_Adapt(object):
     def compute_loss(self, input_rgb=None, output_depth=None, sparse_depth=None, validity_map=None,
                      embedding=None, reference=None, w_loss_sparse_depth=1.0, w_loss_smoothness=1.0,
                      w_loss_cos=1.0, loss_type='adapt', **unused):
+        if 'prepare' in loss_type:                  # src/external_model_adapt.py:155-158
+            return self.model.prepare_loss(embedding, reference)
         if 'adapt' not in loss_type:
             raise NotImplementedError('loss_type %r is not on the accelerated path' % loss_type)
         eng = self.model._engine(input_rgb)
@@ -378,6 +496,16 @@ class ExternalModel_Adapt(object):
 
     def adapt_parameters(self, mode=''):
         return self.model.adapt_parameters(mode=mode)
+
+    def prepare_parameters(self, mode=''):
+        return self.model.prepare_parameters(mode)
+
+    def bind_head_optimizer(self, optimizer, tau=0.999):
+        self.model.bind_head_optimizer(optimizer, tau)
+
+    def head_step(self, image, sparse_depth, loss_type='head_selfsup_seq_ema_reverse'):
+        """One stage-2 training step (src/head_main.py:464-480) in one library call; returns the loss (1 device float)."""
+        return self.model.head_step(image, sparse_depth, loss_type)
 
     def train(self, meta=False, prepare=False):
         self.model.train()

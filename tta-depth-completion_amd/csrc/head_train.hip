@@ -53,19 +53,29 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinWgradArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
 
-    int stage = 0;
-    for (long r0 = r_begin; r0 < r_end; r0 += 16, stage ^= 1) {
+    // software pipeline: the raw values of slice k+1 are fetched into registers before the MFMAs of slice k are issued
+    float gr[8], ghr[8], xr[8];
+    auto fetch = [&](long r0) __attribute__((always_inline)) {
         const long rb = r0 + 8 * hg;
-        // ---- this wave's A fragment: 8 rows of column o, straight from global ------------------------
-        float g[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const long r = rb + j;
-            float v = 0.f;
-            if (r < r_end) {
-                v = a.G[r * a.O + o];
-                if (GPRO) v = gs * (v - c1 - (a.Gh[r * a.O + o] - mu) * iv * c2);
-            }
+            const bool ok = r < r_end;
+            gr[j] = ok ? a.G[r * a.O + o] : 0.f;
+            if (GPRO) ghr[j] = ok ? a.Gh[r * a.O + o] : mu;
+            if (wave < NT) xr[j] = ok ? a.X[r * a.I + xi] : 0.f;
+        }
+    };
+    fetch(r_begin);
+    int stage = 0;
+    for (long r0 = r_begin; r0 < r_end; r0 += 16, stage ^= 1) {
+        const long rb = r0 + 8 * hg;
+        // ---- this wave's A fragment: 8 rows of column o (straight from global), transformed and split ----
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = gr[j];
+            if (GPRO) v = (rb + j < r_end) ? gs * (v - c1 - (ghr[j] - mu) * iv * c2) : 0.f;
             g[j] = v; bsum += v;
         }
         uint4 ah, al;
@@ -75,18 +85,15 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LinWgradArgs a) {
             float x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const long r = rb + j;
-                float v = 0.f;
-                if (r < r_end) {
-                    v = a.X[r * a.I + xi];
-                    if (XPRO) v = fmaxf(fmaf(v, xs, xsh), 0.f);
-                }
+                float v = xr[j];
+                if (XPRO) v = (rb + j < r_end) ? fmaxf(fmaf(v, xs, xsh), 0.f) : 0.f;
                 x[j] = v;
             }
             uint4 xh, xl;
             tsplit8(x, xh, xl);
             Bs[stage][wave][0][lane] = xh; Bs[stage][wave][1][lane] = xl;
         }
+        if (r0 + 16 < r_end) fetch(r0 + 16);
         __syncthreads();                 // two LDS stages: the next iteration writes the other one, so one barrier per slice
         const bf16x8 fah = __builtin_bit_cast(bf16x8, ah), fal = __builtin_bit_cast(bf16x8, al);
 #pragma unroll

@@ -64,6 +64,7 @@ struct ptta_ctx {
                    int* step = nullptr; unsigned* ticket = nullptr; PttaAdamEntry *tab = nullptr, *etab = nullptr;
                    std::vector<PttaAdamEntry> tab_host, etab_host; int tab_n = 0; long tab_total = 0, etab_total = 0; int tab_mode = -1; bool etab_dirty = true;
                    int reverse = 1; bool fwd_ok = false, bwd_ok = false; } head;
+    int skip_dec3 = 0;               // stage-2 head forward: no depth output
     int head_swap = 0;               // heads_forward order: 0 = emb from the proxy pass (TTA, stage-2 reverse), 1 = emb from the real pass
     float *meta_w = nullptr, *meta_b = nullptr;      // 1layer aliases of adapted[0].p / adapted[1].p
     float *gW = nullptr, *gB = nullptr;
@@ -715,7 +716,9 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         RUN(heads_forward(c, s2));
         HIPCHK(hipEventRecord(c->ev_join, s2));
     }
-    // decoder 3: real frames only (the proxy pass stops at depth_encoder3, :509-532)
+    // decoder 3: real frames only (the proxy pass stops at depth_encoder3, :509-532); the stage-2 head forward stops at
+    // depth_encoder3 for both passes (:652,:676)
+    if (!c->skip_dec3) {
     CV("depth_decoder3.dec2.1", false, CONV_T2, c->w2, B2, Nn, H4, W4, true, e_raw(c->t3));
     { E e; e.sum = c->s1_3; e.add1 = c->e3_1; e.add1_nb = B2; e.add2 = c->c1; e.add2_nb = B2;
       CV("depth_decoder3.dec2.3", false, CONV_S1, c->t3, Nn, Nn, H2, W2, true, e); }
@@ -728,6 +731,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         ConvOut1Args a; a.in = c->v3; a.in_nb = Nn; a.w = lo.w; a.bias = lo.bias; a.add = c->p11; a.add_nb = B2; a.out = c->depth_net;
         a.B = Nn; a.H = H1; a.W = W1; a.relu_in = 1; a.bf16 = c->bf16;                           // output = out3 + p11 (:506)
         RUN(ptta_launch_conv_out1(a, s));
+    }
     }
 #undef CV
     if (train) {
@@ -1151,7 +1155,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
 
     if (!c || !image || !sparse) return -1;
     hipStream_t s = (hipStream_t)s_;
-    c->fwd_valid = false;
+    c->fwd_valid = false; c->head.fwd_ok = false;
     RUN(forward_common(c, image, sparse, true, s));      // includes the heads (beside decoder 3)
     const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), dbytes, hipMemcpyDeviceToDevice, s));
@@ -1166,7 +1170,7 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
 
     if (!c || !image || !sparse || !depth_out) return -1;
     hipStream_t s = (hipStream_t)s_;
-    c->fwd_valid = false;                      // the eval pass overwrites the saved activations
+    c->fwd_valid = false; c->head.fwd_ok = false;        // the eval pass overwrites the saved activations
     RUN(forward_common(c, image, sparse, false, s));
     HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, hipMemcpyDeviceToDevice, s));
     return 0;
@@ -1432,9 +1436,10 @@ int ptta_head_forward(ptta_handle c, const float* image, const float* sparse, in
         RUN(ptta_launch_ema_multi(h.etab, 6, h.etab_total, h.tau2, s));
     }
     h.reverse = reverse ? 1 : 0; h.bwd_ok = false;
-    c->head_swap = reverse ? 0 : 1;
+    c->head_swap = reverse ? 0 : 1; c->skip_dec3 = 1;
     const int rc = ptta_forward_train(c, image, sparse, nullptr, emb_out, ref_out, s_);
-    c->head_swap = 0;
+    c->head_swap = 0; c->skip_dec3 = 0;
+    c->fwd_valid = false;              // no decoder-3 activations: not a forward ptta_backward may follow
     if (rc != 0) return rc;
     h.fwd_ok = true;
     return 0;
@@ -1443,7 +1448,7 @@ int ptta_head_forward(ptta_handle c, const float* image, const float* sparse, in
 int ptta_head_backward(ptta_handle c, float* loss_out, ptta_stream s_) {
     if (!c) return -1;
     auto& h = c->head;
-    if (!h.ready || !h.fwd_ok || !c->fwd_valid) return c->fail("ptta_head_backward needs the activations of the last ptta_head_forward", -3);
+    if (!h.ready || !h.fwd_ok) return c->fail("ptta_head_backward needs the activations of the last ptta_head_forward", -3);
     hipStream_t s = (hipStream_t)s_;
     const long R = c->Rg;
     float* g_emb = c->gref_buf;

@@ -40,7 +40,8 @@ def summarise(out, key, t):
     out[key + '_sum'] = np.array(flat.sum(dtype=np.float64))
     out[key + '_abs_mean'] = np.array(np.abs(flat).mean(dtype=np.float64))
     n, c, h, w = a.shape
-    out[key + '_blk'] = a.reshape(n, c, h // 8, 8, w // 8, 8).mean(axis=(3, 5), dtype=np.float64).astype(np.float32)
+    k = 8 if (h % 8 == 0 and w % 8 == 0) else 4          # 228 x 304 (NYUv2): 4 x 4 blocks
+    out[key + '_blk'] = a.reshape(n, c, h // k, k, w // k, k).mean(axis=(3, 5), dtype=np.float64).astype(np.float32)
 
 
 def run_case(ema, name, prepare_mode, h, w, n, steps, full_every=1, frame0=0, moments=True):

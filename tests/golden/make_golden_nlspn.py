@@ -205,6 +205,9 @@ def main():
         h, w = [int(x) for x in sys.argv[1].split('x')]
         HOLES['allow'] = True
         # what src/tta_main.py runs: legacy offsets; the canonical script's loss weights (adapt_nlspn_vkitti.sh) + a smoothness term
+        if h * w < 20000:       # small sizes NOT divisible by 16 (decoder crops of nlspnmodel_adapt.py:474-490): full maps, batch 2
+            run_case(ema, 'nlspn_%dx%d_n2_legacy' % (h, w), h, w, 2, 2, dict(hp, lr=3e-4), offset=True)
+            return
         run_case(ema, 'nlspn_%dx%d_legacy' % (h, w), h, w, 1, 1, dict(hp, lr=3e-4), offset=True, sampled=True)
         return
     run_case(ema, 'nlspn_32x64', 32, 64, 1, 2, hp)

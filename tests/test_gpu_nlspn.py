@@ -99,7 +99,7 @@ def test_forward_train_and_eval_match_oracle(shape, impl):
 
 
 @pytest.mark.parametrize('impl', MODES)
-@pytest.mark.parametrize('name', ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical', 'nlspn_32x64_legacy'])
+@pytest.mark.parametrize('name', ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical', 'nlspn_32x64_legacy', 'nlspn_40x56_n2_legacy'])
 def test_step_matches_golden(golden_dir, name, impl):
     tol = TOL[impl]
     g = np.load(os.path.join(golden_dir, name + '.npz'))
@@ -170,9 +170,13 @@ def test_fused_image_normalisation_nlspn():
     eng.close()
 
 
-def test_size_must_be_multiple_of_16():
+def test_sizes_not_divisible_by_16_have_the_reference_shapes():
+    """Odd encoder maps (nlspnmodel_adapt.py:474-490): 36 x 52 -> fe6 is 3 x 4, the embedding has N * 12 rows."""
+    eng = Engine(2, 36, 52, backbone='nlspn', **HP)
+    assert eng.rows == 2 * 3 * 4
+    eng.close()
     with pytest.raises(RuntimeError):
-        Engine(1, 36, 52, backbone='nlspn', **HP)
+        Engine(1, 8, 52, backbone='nlspn', **HP)
 
 
 def test_external_model_adapt_facade_nlspn(golden_dir):
@@ -311,7 +315,7 @@ def test_shared_parameter_step_nlspn():
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize('name', ['nlspn_96x320_legacy', 'nlspn_352x1216_legacy'])
+@pytest.mark.parametrize('name', ['nlspn_96x320_legacy', 'nlspn_352x1216_legacy', 'nlspn_228x304_legacy'])      # 228 x 304: NYUv2, not divisible by 16
 def test_full_size_step_matches_reference(golden_dir, name):
     """Default arithmetic at 96x320 and at the BASELINE size 352x1216 against vectors produced by the REAL reference
     (tests/golden/make_golden_nlspn.py <size>): 4096 sampled pixels, 8x8 block means and checksums of the training and

@@ -118,7 +118,8 @@ def test_dcn_oracle_properties():
 
 
 # ---- NLSPN: oracle/nlspn_oracle.py against tests/golden/nlspn_*.npz ------------------------
-NLSPN_CASES = ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical', 'nlspn_32x64_legacy']
+NLSPN_CASES = ['nlspn_32x64', 'nlspn_48x80_n2', 'nlspn_32x64_canonical', 'nlspn_32x64_legacy',
+               'nlspn_40x56_n2_legacy']        # 40 x 56: not divisible by 16 -> the decoder crops of nlspnmodel_adapt.py:474-490
 _MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
 _STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
 
@@ -171,7 +172,8 @@ def _check_map(t, g, key, tol):
     flat = a.reshape(-1)
     assert rel_mae(flat[g['pix_idx']], g[key + '_pix']) < tol, key
     n, c, h, w = a.shape
-    blk = a.reshape(n, c, h // 8, 8, w // 8, 8).mean(axis=(3, 5), dtype=np.float64)
+    k = 8 if (h % 8 == 0 and w % 8 == 0) else 4
+    blk = a.reshape(n, c, h // k, k, w // k, k).mean(axis=(3, 5), dtype=np.float64)
     assert rel_mae(blk, g[key + '_blk']) < tol, key
     assert abs(flat.sum(dtype=np.float64) - float(g[key + '_sum'])) < tol * float(g[key + '_abs_mean']) * flat.size
 
@@ -217,11 +219,13 @@ def test_eval_metrics_oracle_matches_reference(golden_dir):
             np.testing.assert_allclose(O.eval_metrics(torch.from_numpy(outd), torch.from_numpy(gt), lo, hi).numpy(), g[key], rtol=1e-6)
 
 
-def test_nlspn_oracle_matches_reference_96x320(golden_dir):
-    """Larger NLSPN reference case (legacy offsets as src/tta_main.py:309-317 constructs the model), stored as sampled
-    pixels + block means + checksums (tests/golden/make_golden_nlspn.py 96x320)."""
+@pytest.mark.parametrize('name', ['nlspn_96x320_legacy', 'nlspn_228x304_legacy'])
+def test_nlspn_oracle_matches_reference_96x320(golden_dir, name):
+    """Larger NLSPN reference cases (legacy offsets as src/tta_main.py:309-317 constructs the model), stored as sampled
+    pixels + block means + checksums (tests/golden/make_golden_nlspn.py 96x320 / 228x304 -- the NYUv2 size, whose height
+    is not divisible by 16: decoder crops)."""
     from oracle import nlspn_oracle as N
-    g = np.load(os.path.join(golden_dir, 'nlspn_96x320_legacy.npz'))
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps = [int(x) for x in g['meta']]
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
     torch.set_num_threads(8)

@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
             const int xl = x0 + acc_row(r, h);
             if (xl >= Wt) continue;
             const int x = MODE == 2 ? 2 * xl + xpar : xl;
+            if (MODE == 2 && x >= Wout) continue;         // odd output width: the gradient of a stride-2 conv over an odd-sized map
             float* dst = yrow + (size_t)x * p.ldy;
             float v = acc[rr][r] + bias;
             if (p.accumulate) v += *dst;

@@ -27,6 +27,27 @@ __global__ void clamp_dup_kernel(const float* __restrict__ src, float* __restric
         dst[i] = v;
     }
 }
+// `_concat` (nlspnmodel_adapt.py:474-490): dst[b][y][x][c] = src[b][y][x][c] for y < Hd, x < Wd (trailing rows / columns dropped)
+__global__ void crop_fwd_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int Hs, int Ws, int Hd, int Wd, int C) {
+    const long total = (long)B * Hd * Wd * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C); long t = idx / C;
+        const int x = (int)(t % Wd); t /= Wd;
+        const int y = (int)(t % Hd); const int b = (int)(t / Hd);
+        dst[idx] = src[(((long)b * Hs + y) * Ws + x) * C + c];
+    }
+}
+// its gradient: the cropped border received nothing
+__global__ void crop_bwd_kernel(const float* __restrict__ gdst, float* __restrict__ gsrc, int B, int Hs, int Ws, int Hd, int Wd, int C, int accumulate) {
+    const long total = (long)B * Hs * Ws * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C); long t = idx / C;
+        const int x = (int)(t % Ws); t /= Ws;
+        const int y = (int)(t % Hs); const int b = (int)(t / Hs);
+        const float g = (y < Hd && x < Wd) ? gdst[(((long)b * Hd + y) * Wd + x) * C + c] : 0.f;
+        gsrc[idx] = accumulate ? gsrc[idx] + g : g;
+    }
+}
 __global__ void relu_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = fmaxf(src[i], 0.f);
 }
@@ -45,11 +66,14 @@ struct nlspn_engine : GNet {
     float *off9 = nullptr, *aff9 = nullptr, *goff9 = nullptr, *gaff9 = nullptr, *feats = nullptr, *gy = nullptr, *gping = nullptr;
     int legacy = 0, heads_adapted = 0;
 
-    long rows() const override { return (long)N * (H / 16) * (W / 16); }
+    static int half(int v) { return (v + 1) / 2; }                 // 3x3 stride 2 padding 1: ceil
+    long rows() const override { return (long)N * half(half(half(half(H)))) * half(half(half(half(W)))); }
     int emb_dim() const override { return 1024; }
 
     void build() {
-        const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16;
+        // encoder sizes: every stride-2 3x3 convolution (padding 1) halves with ceil; fe2 is at full resolution (layer1 has
+        // stride 1), fe3 1/2, fe4 1/4, fe5 1/8, fe6 1/16
+        const int H2 = half(H), W2 = half(W), H4 = half(H2), W4 = half(W2), H8 = half(H4), W8 = half(W4), H16 = half(H8), W16 = half(W8);
         const int N2 = 2 * N;
         // the adapted meta conv comes first in the reference's parameter list (src/nlspn_model_adapt.py:324-328)
         const int ad_mw = add_adapted("conv1_rgb_meta.weight", 48L * 48 * 9), ad_mb = add_adapted("conv1_rgb_meta.bias", 48);
@@ -72,7 +96,7 @@ struct nlspn_engine : GNet {
         for (int st = 0; st < 4; ++st) {
             for (int b = 0; b < nblocks[st]; ++b) {
                 const int stride = (b == 0 && st > 0) ? 2 : 1;
-                const int ho = hh / stride, wo = ww / stride, C = planes[st];
+                const int ho = stride == 2 ? half(hh) : hh, wo = stride == 2 ? half(ww) : ww, C = planes[st];
                 char pre[64]; snprintf(pre, sizeof(pre), "conv%d.%d", st + 2, b);
                 const std::string P(pre);
                 const int r1 = tensor(P + ".r1", N2, ho, wo, C, true), a1 = tensor(P + ".a1", N2, ho, wo, C, true);
@@ -105,16 +129,34 @@ struct nlspn_engine : GNet {
             fe[6] = o; t_fe6 = o;
         }
         // shared decoder (:413-424): transposed convs over [decoder | encoder skip]
-        auto dec = [&](const char* name, int a, int b, int h, int w, int cout) {
-            const int r = tensor(std::string(name) + ".r", N, h, w, cout, true), o = tensor(std::string(name) + ".o", N, h, w, cout, true);
+        // a transposed convolution doubles its input; when an encoder map has an odd size the decoder map is one row / column
+        // larger and `_concat` crops it AFTER BatchNorm saw the whole map (nlspnmodel_adapt.py:474-490): the layer is built at
+        // its full size and a crop op feeds the next concatenation (its backward zero-fills the cropped border)
+        auto dec = [&](const char* name, int a, int b, int hin, int win, int h, int w, int cout) {
+            const int hf = 2 * hin, wf = 2 * win;
+            const int r = tensor(std::string(name) + ".r", N, hf, wf, cout, true), o = tensor(std::string(name) + ".o", N, hf, wf, cout, true);
             conv(std::string(name) + ".0", a, b, r, 3, 2, 1, GACT_NONE, W_GRAD, W_GRAD);
             bn(std::string(name) + ".1", r, o, -1, GACT_LRELU, W_GRAD);
-            return o;
+            if (hf == h && wf == w) return o;
+            const int oc = tensor(std::string(name) + ".crop", N, h, w, cout, true);
+            const int oi = func(nullptr, nullptr, o);
+            ops[oi].ffwd = [this, o, oc](bool, hipStream_t s) {
+                hipLaunchKernelGGL(crop_fwd_kernel, dim3(nb((long)T[oc].per * T[oc].H * T[oc].W * T[oc].C)), dim3(256), 0, s, (const float*)T[o].p, T[oc].p,
+                                   T[oc].per, T[o].H, T[o].W, T[oc].H, T[oc].W, T[oc].C);
+                return hipGetLastError() == hipSuccess ? 0 : fail("crop failed", -5);
+            };
+            ops[oi].fbwd = [this, o, oc, oi](hipStream_t s) {
+                hipLaunchKernelGGL(crop_bwd_kernel, dim3(nb((long)T[o].per * T[o].H * T[o].W * T[o].C)), dim3(256), 0, s, (const float*)T[oc].g, T[o].g,
+                                   T[o].per, T[o].H, T[o].W, T[oc].H, T[oc].W, T[o].C, ops[oi].first_x[0] ? 0 : 1);
+                return hipGetLastError() == hipSuccess ? 0 : fail("crop gradient failed", -5);
+            };
+            ops[oi].bwd = true;
+            return oc;
         };
-        const int fd5 = dec("dec5", fe[6], -1, H8, W8, 256);
-        const int fd4 = dec("dec4", fd5, fe[5], H4, W4, 128);
-        const int fd3 = dec("dec3", fd4, fe[4], H2, W2, 64);
-        const int fd2 = dec("dec2", fd3, fe[3], H, W, 64);
+        const int fd5 = dec("dec5", fe[6], -1, H16, W16, H8, W8, 256);
+        const int fd4 = dec("dec4", fd5, fe[5], H8, W8, H4, W4, 128);
+        const int fd3 = dec("dec3", fd4, fe[4], H4, W4, H2, W2, 64);
+        const int fd2 = dec("dec2", fd3, fe[3], H2, W2, H, W, 64);
         auto head1 = [&](const char* name, int cout) {
             const int r = tensor(std::string(name) + ".r", N, H, W, cout, true), o = tensor(std::string(name) + ".o", N, H, W, cout, true);
             conv(std::string(name) + ".0", fd2, fe[2], r, 3, 1, 0, GACT_NONE, W_GRAD, W_GRAD);
@@ -245,7 +287,6 @@ int nlspn_engine::backward(hipStream_t s) {
 GNet* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int legacy_offset, int* rc) {
     *rc = 0;
     if (n < 1 || h < 16 || w < 16 || !hp) { *rc = -22; return nullptr; }
-    if ((h % 16) || (w % 16)) { *rc = -38; return nullptr; }      // decoder crops of nlspnmodel_adapt.py:474-490 are not implemented
     nlspn_engine* e = new nlspn_engine();
     e->N = e->Nu = n; e->H = e->Hu = h; e->W = e->Wu = w; e->hp = *hp; e->legacy = (legacy_offset & 1) ? 1 : 0; e->heads_adapted = (legacy_offset & 2) ? 1 : 0;
     const char* impl = getenv("PTTA_CONV_IMPL");

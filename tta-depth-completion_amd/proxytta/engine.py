@@ -77,7 +77,7 @@ class Engine:
                                   self.n, self.h, self.w, code, byref(self.hp))
         if rc != 0:
             why = {-19: 'no HIP device', -12: 'out of device memory', -22: 'invalid size / argument',
-                   -38: 'configuration not on the accelerated path (NLSPN needs height and width multiples of 16, fp32 and '
+                   -38: 'configuration not on the accelerated path (NLSPN needs fp32 and '
                         'the 1layer meta conv; MSG_CHN needs the 1layer or 2layers meta layer)'}.get(rc, 'see include/ptta.h')
             raise RuntimeError('ptta_create failed (%d): %s' % (rc, why))
         self.rows = int(self.lib.ptta_embedding_rows(self.handle))

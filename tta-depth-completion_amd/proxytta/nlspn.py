@@ -6,7 +6,8 @@ prepare_mode 'meta_selfsup_seq_1layer_ema', adapt_mode 'meta_bn', loss_type 'ada
 the reference's own call sequence ``forward`` / ``compute_loss`` / ``loss.backward()`` / ``optimizer.step()``
 (src/tta_main.py:610-633, autograd Functions over ptta_forward_train / ptta_loss_* / ptta_backward), the fused
 ``step()`` (the same in one library call, Adam on device for the 88 adapted tensors) and the eval ``forward()`` (:729-736).
-Frame sizes must be multiples of 16 (the decoder crops of nlspnmodel_adapt.py:474-490 are not implemented).
+Any frame size from 16 x 16 up: encoder maps of odd size make the decoder maps one row / column larger and they are cropped
+before each concatenation as in nlspnmodel_adapt.py:474-490 (NYUv2's 228 x 304 is such a size).
 The eval path's biharmonic hole filling (src/nlspn_model_adapt.py:124-127, skimage on the CPU) is not applied: exact
 zeros of the clamped output are returned as zeros.
 """

@@ -11,7 +11,11 @@
 // accumulators live across the whole K loop; the next sub-chunk's halo and weights are loaded into registers before
 // the current sub-chunk's MFMAs.  Output channel tiles of the same pixel tile are adjacent in the grid (L2 reuse).
 // (Measured alternatives, all slower: hi fragments in registers per wave -- 2.5x the weight traffic through L1, the
-// bottleneck by ablation; 64-channel output tiles; double-buffered LDS with hi fragments in registers.)
+// bottleneck by ablation; 64-channel output tiles -- re-measured in round 2 as a template variant with two accumulator sets
+// per wave (8 instead of 12 ds_read_b128 per 12 MFMAs, halo staged once per 64 channels): 256 VGPRs, 64 KB of LDS, two
+// blocks per CU instead of three and the NLSPN step went 26.87 -> 28.35 ms on one box, i.e. the kernel is bound by how many
+// blocks overlap each other's stage -> barrier -> MFMA phases, not by LDS read bandwidth; double-buffered LDS with hi
+// fragments in registers.)
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 

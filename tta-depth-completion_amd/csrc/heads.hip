@@ -519,6 +519,8 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.x3 && !a.a_bf16) {
         GemmX3P q; q.g = p; q.Whi = a.Whi; q.Wlo = a.Wlo; q.Wil = a.Wil;
         const int key3 = a.pro * 10 + a.epi;
+        // (K = 32, the first Linear of proj: routed to the 128x128-tile kernel instead, the step is unchanged within noise --
+        //  2.317 vs 2.318 ms A/B on one box: that launch is bound by its 55 MB of fp32 stores, not by the tiling)
         if (a.N == 512 && a.Wil && a.pro != 2) {
             dim3 grid(2, (a.R + 127) / 128);
 #define GS_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_ws_kernel<PRO, EPI>), grid, dim3(512), 0, s, q)

@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
 // ---- stride-2 / transposed geometries, fp32 storage, bf16x3 arithmetic, direct loads ----------
 // Same per-wave tiling as conv32_mfma_kernel (32 outputs of one row / one x-parity), but each A
 // fragment (8 fp32 channels of one input pixel) is split into bf16 hi/lo in registers and fed to
-// three bf16 MFMAs.  The hi weight fragments are wave-stationary in VGPRs, the lo fragments sit
-// in LDS (loaded once per block).  Input lines are re-read from L1/L2 by neighbouring taps
+// three bf16 MFMAs.  The weight fragments (hi and lo, 36 KB) sit in LDS, loaded once per block -- the
+// registers go to the 36 activation loads that are in flight ahead of the MFMAs.  Input lines are re-read from L1/L2 by neighbouring taps
 // (2.25x for stride 2), which is cheaper here than an 84 KB halo tile in LDS.  Round 2 built the LDS-staged,
 // input-stationary transposed form (8x32 input tile, four parity accumulators per input row, 16 instead of 36 ds_reads):
 // faster kernel by kernel (forward 35 -> 18 us at full resolution) but SLOWER in the replayed step (2.396 vs 2.384 ms, same
@@ -328,19 +328,14 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
 // form's 18 KB can -- reverted; see DESIGN.md §8.
 template <int MODE, bool RELU, bool UP, bool MASK, bool ADD>
 __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float> p) {
-    __shared__ __attribute__((aligned(16))) unsigned char wl_lds[18 * 64 * 16];
+    __shared__ __attribute__((aligned(16))) unsigned char wl_lds[2 * 18 * 64 * 16];     // [hi | lo][tap][k][lane] weight fragments
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint4 wh[9][2];
     {
         const uint4* ph = (const uint4*)p.wpack;
         const uint4* pl = (const uint4*)p.wpack2;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+        for (int idx = tid; idx < 18 * 64; idx += 256) { *(uint4*)(wl_lds + idx * 16) = ph[idx]; *(uint4*)(wl_lds + (18 * 64 + idx) * 16) = pl[idx]; }
     }
     __syncthreads();
     const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
@@ -362,8 +357,12 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        // Loads are UNCONDITIONAL (clamped address + select) and issued three taps ahead of their MFMAs: with a per-load
+        // `if (ok)` every one of the 36 loads of an item waited for the previous one (s_waitcnt behind each exec branch), which
+        // at the 1/8 and 1/16-resolution layers -- one item per wave -- was the whole kernel: 12.3 us whatever the size.
+        float4 v[9][4];
+        bool act[9], okl[9];
+        auto fetch = [&](int tap) __attribute__((always_inline)) {
             const int ky = tap / 3, kx = tap % 3;
             bool active = true;
             int yi, xi;
@@ -375,29 +374,39 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
                 yi = ty >> 1; xi = x0 + i + (tx >> 1);
             }
             active = active && (yi >= 0) && (yi < p.Hin);
-            if (!active) continue;                                    // wave-uniform
-            const bool ok = lane_in && (xi >= 0) && (xi < p.Win);
-            const float* src = inb + ((size_t)yi * p.Win + (ok ? xi : 0)) * 32 + 8 * h;
-            float4 v[4];
+            act[tap] = active;                                          // wave-uniform
+            okl[tap] = active && lane_in && (xi >= 0) && (xi < p.Win);
+            if (!active) return;
+            const float* src = inb + ((size_t)yi * p.Win + (okl[tap] ? xi : 0)) * 32 + 8 * h;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                              // q = 2*kstep + half-of-8
-                v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok) v[q] = *(const float4*)(src + 16 * (q >> 1) + 4 * (q & 1));
-                if (RELU) v[q] = relu4(v[q]);
+            for (int q = 0; q < 4; ++q) v[tap][q] = *(const float4*)(src + 16 * (q >> 1) + 4 * (q & 1));      // q = 2*kstep + half-of-8
+        };
+        auto compute = [&](int tap) __attribute__((always_inline)) {
+            if (!act[tap]) return;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!okl[tap]) v[tap][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (RELU) v[tap][q] = relu4(v[tap][q]);
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 uint4 hi, lo;
-                split2(v[2 * k].x, v[2 * k].y, hi.x, lo.x); split2(v[2 * k].z, v[2 * k].w, hi.y, lo.y);
-                split2(v[2 * k + 1].x, v[2 * k + 1].y, hi.z, lo.z); split2(v[2 * k + 1].z, v[2 * k + 1].w, hi.w, lo.w);
+                split2(v[tap][2 * k].x, v[tap][2 * k].y, hi.x, lo.x); split2(v[tap][2 * k].z, v[tap][2 * k].w, hi.y, lo.y);
+                split2(v[tap][2 * k + 1].x, v[tap][2 * k + 1].y, hi.z, lo.z); split2(v[tap][2 * k + 1].z, v[tap][2 * k + 1].w, hi.w, lo.w);
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, hi), al = __builtin_bit_cast(bf16x8, lo);
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
+                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((18 + tap * 2 + k) * 64 + lane) * 16));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
             }
-        }
+        };
+        fetch(0); fetch(1); fetch(2);
+        fetch(3); fetch(4); fetch(5);
+        compute(0); compute(1); compute(2);
+        fetch(6); fetch(7); fetch(8);
+        compute(3); compute(4); compute(5);
+        compute(6); compute(7); compute(8);
         epi_tile<float, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx);
     }
 }

@@ -15,8 +15,11 @@
 // per wave (8 instead of 12 ds_read_b128 per 12 MFMAs, halo staged once per 64 channels): 256 VGPRs, 64 KB of LDS, two
 // blocks per CU instead of three and the NLSPN step went 26.87 -> 28.35 ms on one box, i.e. the kernel is bound by how many
 // blocks overlap each other's stage -> barrier -> MFMA phases, not by LDS read bandwidth; double-buffered LDS with hi
-// fragments in registers.)
-#include <cstdlib>
+// fragments in registers.  The ISA of THIS form drains its own register prefetch: the last weight load is conditional and the
+// compiler merges its result right behind it (s_waitcnt vmcnt(0) + v_mov in front of the barrier).  A version with two explicit
+// register sets and unconditional loads keeps 11 loads in flight across the MFMAs, needs 234 VGPRs (two blocks per CU) and
+// measures the same: 25.73 vs 25.66 ms per NLSPN step, A/B on one box -- three non-overlapping blocks hide as much as two
+// overlapping ones, and neither is bound by the loads.)
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -59,167 +62,7 @@ __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, lon
 
 #define GX_STR16 80                                      // LDS bytes per pixel: hi 32 | lo 32 | pad 16
 template <int KS>
-__global__ __launch_bounds__(256, 2) void gconv_x3_s1_kernel(GX3Args p) {
-    constexpr int PAD = KS / 2, PH = GX_TH + 2 * PAD, PW = 32 + 2 * PAD, KK = KS * KS;
-    constexpr int NPIX = PH * PW;
-    constexpr int NIT = (NPIX * 2 + 255) / 256;          // (pixel, 8-channel group) items per thread
-    constexpr int NWF = KK * 64 * 2;                     // weight uint4 per sub-chunk: [hi | lo][tap][lane]
-    constexpr int NW = (NWF + 255) / 256;
-    constexpr int ACT = NPIX * GX_STR16;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[ACT + NWF * 16];
-    uint4* const wlds = (uint4*)(lds + ACT);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int i = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = p.H, W = p.W;
-    const int ntx = (W + 31) >> 5, nty = (H + GX_TH - 1) / GX_TH;
-    const unsigned bid = xcd_swizzle(blockIdx.x, gridDim.x);      // the channel tiles of one pixel tile stay on one XCD / L2
-    const int nfl = (int)(bid % p.nnf);
-    long t_ = bid / p.nnf;
-    const int ty = (int)(t_ % nty); t_ /= nty;
-    const int tx = (int)(t_ % ntx);
-    const int b = (int)(t_ / ntx);
-    const int y0 = ty * GX_TH, x0 = tx << 5;
-    const int nf = p.nf0 + nfl;
-    const int nch0 = (p.C0 + 31) >> 5;
-    const int nq = 2 * p.nchunks;
-
-    // Two explicit register sets, the K loop unrolled by two: sub-chunk q+1 is loaded into the OTHER set while sub-chunk q is
-    // converted, so the compiler never has to copy (or spill) a loaded value before the barrier -- any such copy is an
-    // s_waitcnt vmcnt in front of the MFMAs, which is what serialised the "prefetch" of the one-set version (the ISA showed
-    // vmcnt(0) + v_mov right behind the last, conditional, weight load).  Loads are unconditional (clamped addresses); the
-    // zero-fill of out-of-range halo items happens at conversion time (okm).
-    struct Regs { float4 v0[NIT], v1[NIT]; uint4 wr[NW]; unsigned okm; };
-    Regs ra, rb;
-    auto issue_loads = [&](int q, Regs& r) __attribute__((always_inline)) {
-        const int c = q >> 1, kk = q & 1;
-        const bool s1 = c >= nch0;
-        const float* src = s1 ? p.x1 : p.x0;
-        const int ld = s1 ? p.ld1 : p.ld0, Cs = s1 ? p.C1 : p.C0, cb = ((s1 ? c - nch0 : c) << 5) + 16 * kk;
-        const float* inb = src + (size_t)b * H * W * ld + cb;
-        r.okm = 0;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + 256 * it;
-            const int g = idx & 1, pix = idx >> 1;
-            const int py = pix / PW, px = pix - py * PW;
-            const int gy = y0 - PAD + py, gx = x0 - PAD + px;
-            const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && cb + 8 * g < Cs;
-            const float* s_ = ok ? inb + ((size_t)gy * W + gx) * ld + 8 * g : src;
-            r.v0[it] = *(const float4*)s_; r.v1[it] = *(const float4*)(s_ + 4);
-            r.okm |= ok ? (1u << it) : 0u;
-        }
-        const size_t wbase = ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + kk * 64;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int idx = min(tid + 256 * j, NWF - 1);  // [hl][tap][lane]; the LDS write is what is predicated
-            const int hl = idx / (KK * 64), rr_ = idx - hl * (KK * 64);
-            r.wr[j] = (hl ? p.wlo : p.whi)[wbase + (rr_ >> 6) * 128 + (rr_ & 63)];
-        }
-    };
-    auto stage = [&](const Regs& r) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + 256 * it;
-            const int pix = idx >> 1;
-            if (pix < NPIX) {
-                float4 a0 = r.v0[it], a1 = r.v1[it];
-                if (!((r.okm >> it) & 1u)) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
-                uint4 hi, lo;
-                gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
-                gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
-                unsigned char* dst = lds + pix * GX_STR16 + 16 * (idx & 1);
-                *(uint4*)dst = hi;
-                *(uint4*)(dst + 32) = lo;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int idx = tid + 256 * j;
-            if (idx < NWF) wlds[idx] = r.wr[j];
-        }
-    };
-    f32x16 acc[2];
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
-    auto mfma_phase = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(1);                    // MFMA phase outranks the other blocks' staging code at issue
-#pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
-            const int ky = tap / KS, kx = tap % KS;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, wlds[tap * 64 + lane]);
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, wlds[KK * 64 + tap * 64 + lane]);
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const unsigned char* a = lds + ((2 * wave + rr + ky) * PW + i + kx) * GX_STR16 + 16 * h;
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
-                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[rr], 0, 0, 0);
-                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[rr], 0, 0, 0);
-                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rr], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    issue_loads(0, ra);
-    for (int q = 0; q < nq; q += 2) {                    // nq = 2 * nchunks is even
-        if (q) lds_barrier();                            // previous sub-chunk's MFMAs are done with the LDS tile
-        stage(ra);
-        issue_loads(q + 1, rb);
-        lds_barrier();                                   // LDS-only: the loads just issued stay in flight during the MFMAs
-        mfma_phase();
-        lds_barrier();
-        stage(rb);
-        if (q + 2 < nq) issue_loads(q + 2, ra);
-        lds_barrier();
-        mfma_phase();
-    }
-    const int co = nf * 32 + i - p.nf0 * 32;          // channel inside the output view
-    const bool cok = co < p.Cy;
-    const float bias = (cok && p.bias) ? p.bias[co] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int y = y0 + 2 * wave + rr;
-        if (y >= H || !cok) continue;
-        float* yrow = p.y + ((size_t)b * H + y) * W * p.ldy + co;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int x = x0 + acc_row(r, h);
-            if (x >= W) continue;
-            float* dst = yrow + (size_t)x * p.ldy;
-            float v = acc[rr][r] + bias;
-            if (p.accumulate) v += *dst;
-            if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
-            else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
-            else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-            *dst = v;
-            s1 += v; s2 += v * v;
-        }
-    }
-    if (p.stat_part) {
-        // fused BatchNorm statistics of this tile: lane halves, then the four waves through LDS (fixed order)
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        lds_barrier();                                    // everyone is done with the tile buffers
-        float* red = (float*)lds;                         // [wave 4][2][32]
-        if (h == 0) { red[(wave * 2 + 0) * 32 + i] = s1; red[(wave * 2 + 1) * 32 + i] = s2; }
-        lds_barrier();
-        if (tid < 64 && (tid & 31) + nf * 32 - p.nf0 * 32 < p.Cy) {
-            const int which = tid >> 5, ch = tid & 31;
-            const float v = (red[(0 * 2 + which) * 32 + ch] + red[(1 * 2 + which) * 32 + ch]) + (red[(2 * 2 + which) * 32 + ch] + red[(3 * 2 + which) * 32 + ch]);
-            const int bpp = p.B / p.stat_npass, pass = b / bpp;
-            const long tile = ((long)(b - pass * bpp) * ntx + tx) * nty + ty;
-            const long tiles_pp = (long)bpp * ntx * nty;
-            p.stat_part[((pass * tiles_pp + tile) * 2 + which) * p.stat_C + (nf - p.nf0) * 32 + ch] = v;
-        }
-    }
-}
-
-template <int KS>
-__global__ __launch_bounds__(256, 3) void gconv_x3_s1_old_kernel(GX3Args p) {
+__global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
     constexpr int PAD = KS / 2, PH = GX_TH + 2 * PAD, PW = 32 + 2 * PAD, KK = KS * KS;
     constexpr int NPIX = PH * PW;
     constexpr int NIT = (NPIX * 2 + 255) / 256;          // (pixel, 8-channel group) items per thread
@@ -589,9 +432,7 @@ int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
     const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + GX_TH - 1) / GX_TH);
     const long blocks = tiles * a.nnf;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
-    static const int use_old = getenv("PTTA_GX_OLD") ? atoi(getenv("PTTA_GX_OLD")) : 0;
-    if (ks == 3 && use_old) hipLaunchKernelGGL((gconv_x3_s1_old_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else if (ks == 1) hipLaunchKernelGGL((gconv_x3_s1_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else return -22;
     PTTA_CHECK_LAUNCH();

@@ -253,9 +253,10 @@ int nlspn_engine::forward(const float* image, const float* sparse, bool train, h
     // propagation (nlspnmodel_adapt.py:340-373) and the final clamp (:900)
     const GView oa = view(t_oa, W_GRAD, train);
     if (ptta_launch_nl_affinity_fwd(oa, T[t_conf].p, S, legacy, off9, aff9, s)) return fail("affinity launch failed", -5);
-    if (hipMemcpyAsync(feats, T[t_pred].p, (size_t)N * P * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("memcpy failed", -5);
+    // feats[k], k < PROP_TIME: the map sweep k samples, with the sparse input imposed; feats[PROP_TIME]: the raw last output
+    if (ptta_launch_nl_pin(T[t_pred].p, T[t_sd].p, feats, (long)N * P, s)) return fail("pin launch failed", -5);
     for (int k = 0; k < PROP_TIME; ++k)
-        if (ptta_launch_nl_prop_fwd(feats + (size_t)k * N * P, T[t_sd].p, off9, aff9, feats + (size_t)(k + 1) * N * P, N, H, W, s))
+        if (ptta_launch_nl_prop_fwd(feats + (size_t)k * N * P, T[t_sd].p, off9, aff9, feats + (size_t)(k + 1) * N * P, k + 1 < PROP_TIME ? 1 : 0, N, H, W, s))
             return fail("propagation launch failed", -5);
     hipLaunchKernelGGL(relu_copy_kernel, dim3(nb((long)N * P)), dim3(256), 0, s, feats + (size_t)PROP_TIME * N * P, depth, (long)N * P);
     if (hipGetLastError() != hipSuccess) return fail("launch failed", -5);

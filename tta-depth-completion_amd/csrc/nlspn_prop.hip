@@ -72,44 +72,67 @@ __global__ __launch_bounds__(256) void nl_affinity_fwd_kernel(GView oa, const fl
     }
 }
 
-// value of the map the reference propagates: (1-mask_fix)*feat + mask_fix*feat_fix (:362-364), mask_fix = fix > 0
-__device__ __forceinline__ float pres(const float* __restrict__ feat, const float* __restrict__ fix, int q) {
-    const float f = fix[q];
-    return f > 0.f ? f : feat[q];
+// The map the reference propagates is (1-mask_fix)*feat + mask_fix*feat_fix (:362-364), mask_fix = fix > 0.  The sweeps keep
+// it MATERIALISED ("pinned"): sweep k reads the pinned map of sweep k-1 with ONE load per bilinear corner (feat-or-fix was two
+// dependent loads) and writes pin(its raw output); only the last sweep writes the raw output (the network's result).
+__global__ __launch_bounds__(256) void nl_pin_kernel(const float* __restrict__ feat, const float* __restrict__ fix, float* __restrict__ out, long n) {
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
+        const float f = fix[k];
+        out[k] = f > 0.f ? f : feat[k];
+    }
 }
 
-struct Tap { Corner c; float v1, v2, v3, v4; bool o1, o2, o3, o4; };
-__device__ __forceinline__ Tap tap_sample(const float* __restrict__ feat, const float* __restrict__ fix, int H, int W, float h, float w) {
-    Tap t;
-    t.c = corner_of(h, w, H, W);
-    const int h1 = t.c.h0 + 1, w1 = t.c.w0 + 1;
-    t.o1 = t.c.inside && t.c.h0 >= 0 && t.c.w0 >= 0; t.o2 = t.c.inside && t.c.h0 >= 0 && w1 <= W - 1;
-    t.o3 = t.c.inside && h1 <= H - 1 && t.c.w0 >= 0; t.o4 = t.c.inside && h1 <= H - 1 && w1 <= W - 1;
-    t.v1 = t.o1 ? pres(feat, fix, t.c.h0 * W + t.c.w0) : 0.f; t.v2 = t.o2 ? pres(feat, fix, t.c.h0 * W + w1) : 0.f;
-    t.v3 = t.o3 ? pres(feat, fix, h1 * W + t.c.w0) : 0.f; t.v4 = t.o4 ? pres(feat, fix, h1 * W + w1) : 0.f;
+// Geometry of one bilinear tap: the four corner indices (clamped to a valid address when the corner does not contribute) and
+// whether each contributes (deformable-convolution boundary rule, ptta_common.h corner_of).  Loads are then UNCONDITIONAL:
+// behind per-corner branches every one of a pixel's 36 (forward) / 99 (backward) loads waited for the previous one.
+struct TapG { int q[4]; bool ok[4]; float lh, lw; };
+__device__ __forceinline__ TapG tap_geom(int H, int W, float h, float w) {
+    TapG t;
+    const Corner c = corner_of(h, w, H, W);
+    const int h1 = c.h0 + 1, w1 = c.w0 + 1;
+    t.ok[0] = c.inside && c.h0 >= 0 && c.w0 >= 0; t.ok[1] = c.inside && c.h0 >= 0 && w1 <= W - 1;
+    t.ok[2] = c.inside && h1 <= H - 1 && c.w0 >= 0; t.ok[3] = c.inside && h1 <= H - 1 && w1 <= W - 1;
+    t.q[0] = t.ok[0] ? c.h0 * W + c.w0 : 0; t.q[1] = t.ok[1] ? c.h0 * W + w1 : 0;
+    t.q[2] = t.ok[2] ? h1 * W + c.w0 : 0; t.q[3] = t.ok[3] ? h1 * W + w1 : 0;
+    t.lh = c.lh; t.lw = c.lw;
     return t;
 }
-__device__ __forceinline__ float tap_value(const Tap& t) {
-    const float hh = 1.f - t.c.lh, hw = 1.f - t.c.lw;
-    return hh * hw * t.v1 + hh * t.c.lw * t.v2 + t.c.lh * hw * t.v3 + t.c.lh * t.c.lw * t.v4;
+__device__ __forceinline__ float tap_blend(const TapG& t, const float* v) {
+    const float hh = 1.f - t.lh, hw = 1.f - t.lw;
+    return hh * hw * v[0] + hh * t.lw * v[1] + t.lh * hw * v[2] + t.lh * t.lw * v[3];
 }
 
-__global__ __launch_bounds__(256) void nl_prop_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ fix,
+__global__ __launch_bounds__(256) void nl_prop_fwd_kernel(const float* __restrict__ pinned, const float* __restrict__ fix,
                                                           const float* __restrict__ off9, const float* __restrict__ aff9,
-                                                          float* __restrict__ out, int B, int H, int W) {
+                                                          float* __restrict__ out, int pin_out, int B, int H, int W) {
     const long P = (long)H * W, total = (long)B * P;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int b = (int)(idx / P); const long pix = idx % P;
         const int y = (int)(pix / W), x = (int)(pix % W);
-        const float* fb = feat + (long)b * P; const float* xb = fix + (long)b * P;
+        const float* fb = pinned + (long)b * P;
         const float* o = off9 + (long)b * 18 * P + pix; const float* a = aff9 + (long)b * 9 * P + pix;
+        float ov[18], av[9];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) ov[k] = o[(long)k * P];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) av[k] = a[(long)k * P];
+        const float fx = pin_out ? fix[idx] : 0.f;
+        TapG t[9];
+        float v[9][4];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            t[k] = tap_geom(H, W, (float)(y + k / 3 - 1) + ov[2 * k], (float)(x + k % 3 - 1) + ov[2 * k + 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[k][j] = fb[t[k].q[j]];
+        }
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            const Tap t = tap_sample(fb, xb, H, W, (float)(y + k / 3 - 1) + o[(long)(2 * k) * P], (float)(x + k % 3 - 1) + o[(long)(2 * k + 1) * P]);
-            acc = fmaf(a[(long)k * P], tap_value(t), acc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (!t[k].ok[j]) v[k][j] = 0.f;
+            acc = fmaf(av[k], tap_blend(t[k], v[k]), acc);
         }
-        out[idx] = acc;
+        out[idx] = (pin_out && fx > 0.f) ? fx : acc;
     }
 }
 
@@ -117,10 +140,11 @@ __global__ __launch_bounds__(256) void nl_prop_fwd_kernel(const float* __restric
 // deterministic); the feature gradient is scattered onto the corners that are not pinned by the sparse input.  Offsets
 // are a few pixels at most, so the scatter goes to an LDS copy of the tile + a 4-pixel apron (ds_add_f32) and is
 // flushed with one global atomic per touched cell; targets outside the apron fall back to global atomics directly.
+// Loads are batched three taps at a time (offsets / affinities / accumulators first, then 12 corner values + 12 pin masks).
 #define PB_T 16
 #define PB_R 4
 #define PB_W (PB_T + 2 * PB_R)
-__global__ __launch_bounds__(256) void nl_prop_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ fix,
+__global__ __launch_bounds__(256, 4) void nl_prop_bwd_kernel(const float* __restrict__ pinned, const float* __restrict__ fix,
                                                           const float* __restrict__ off9, const float* __restrict__ aff9,
                                                           const float* __restrict__ gout, float* __restrict__ gfeat,
                                                           float* __restrict__ goff9, float* __restrict__ gaff9, int B, int H, int W) {
@@ -132,32 +156,51 @@ __global__ __launch_bounds__(256) void nl_prop_bwd_kernel(const float* __restric
     for (int k = threadIdx.x; k < PB_W * PB_W; k += 256) tile[k] = 0.f;
     __syncthreads();
     const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15);
-    const float* fb = feat + (long)b * P; const float* xb = fix + (long)b * P;
+    const float* fb = pinned + (long)b * P; const float* xb = fix + (long)b * P;
     float* gb = gfeat + (long)b * P;
-    auto scatter = [&](int qy, int qx, float v) {
-        if (xb[qy * W + qx] > 0.f) return;                         // pinned by the sparse input: no gradient to the feature
-        const int ly = qy - ty0 + PB_R, lx = qx - tx0 + PB_R;
-        if (ly >= 0 && ly < PB_W && lx >= 0 && lx < PB_W) atomicAdd(&tile[ly * PB_W + lx], v);
-        else atomicAdd(gb + qy * W + qx, v);
-    };
     if (y < H && x < W) {
         const long pix = (long)y * W + x, idx = (long)b * P + pix;
         const float* o = off9 + (long)b * 18 * P + pix; const float* a = aff9 + (long)b * 9 * P + pix;
         float* go = goff9 + (long)b * 18 * P + pix; float* ga = gaff9 + (long)b * 9 * P + pix;
         const float g = gout[idx];
+        float ov[18], av[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const Tap t = tap_sample(fb, xb, H, W, (float)(y + k / 3 - 1) + o[(long)(2 * k) * P], (float)(x + k % 3 - 1) + o[(long)(2 * k + 1) * P]);
-            const float hh = 1.f - t.c.lh, hw = 1.f - t.c.lw, ga_ = g * a[(long)k * P];
-            ga[(long)k * P] += g * tap_value(t);
-            // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
-            go[(long)(2 * k) * P] += ga_ * (-hw * t.v1 - t.c.lw * t.v2 + hw * t.v3 + t.c.lw * t.v4);
-            go[(long)(2 * k + 1) * P] += ga_ * (-hh * t.v1 + hh * t.v2 - t.c.lh * t.v3 + t.c.lh * t.v4);
-            const int h1 = t.c.h0 + 1, w1 = t.c.w0 + 1;
-            if (t.o1) scatter(t.c.h0, t.c.w0, hh * hw * ga_);
-            if (t.o2) scatter(t.c.h0, w1, hh * t.c.lw * ga_);
-            if (t.o3) scatter(h1, t.c.w0, t.c.lh * hw * ga_);
-            if (t.o4) scatter(h1, w1, t.c.lh * t.c.lw * ga_);
+        for (int k = 0; k < 18; ++k) ov[k] = o[(long)k * P];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) av[k] = a[(long)k * P];
+#pragma unroll
+        for (int k0 = 0; k0 < 9; k0 += 3) {
+            TapG t[3];
+            float v[3][4], m[3][4], gov[6], gav[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int k = k0 + kk;
+                gov[2 * kk] = go[(long)(2 * k) * P]; gov[2 * kk + 1] = go[(long)(2 * k + 1) * P]; gav[kk] = ga[(long)k * P];
+                t[kk] = tap_geom(H, W, (float)(y + k / 3 - 1) + ov[2 * k], (float)(x + k % 3 - 1) + ov[2 * k + 1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[kk][j] = fb[t[kk].q[j]]; m[kk][j] = xb[t[kk].q[j]]; }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) {
+                const int k = k0 + kk;
+                const TapG& tk = t[kk];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (!tk.ok[j]) v[kk][j] = 0.f;
+                const float hh = 1.f - tk.lh, hw = 1.f - tk.lw, ga_ = g * av[k];
+                ga[(long)k * P] = gav[kk] + g * tap_blend(tk, v[kk]);
+                // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
+                go[(long)(2 * k) * P] = gov[2 * kk] + ga_ * (-hw * v[kk][0] - tk.lw * v[kk][1] + hw * v[kk][2] + tk.lw * v[kk][3]);
+                go[(long)(2 * k + 1) * P] = gov[2 * kk + 1] + ga_ * (-hh * v[kk][0] + hh * v[kk][1] - tk.lh * v[kk][2] + tk.lh * v[kk][3]);
+                const float wgt[4] = {hh * hw * ga_, hh * tk.lw * ga_, tk.lh * hw * ga_, tk.lh * tk.lw * ga_};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!tk.ok[j] || m[kk][j] > 0.f) continue;            // outside, or pinned by the sparse input: no gradient to the feature
+                    const int qy = tk.q[j] / W, qx = tk.q[j] - qy * W;
+                    const int ly = qy - ty0 + PB_R, lx = qx - tx0 + PB_R;
+                    if (ly >= 0 && ly < PB_W && lx >= 0 && lx < PB_W) atomicAdd(&tile[ly * PB_W + lx], wgt[j]);
+                    else atomicAdd(gb + tk.q[j], wgt[j]);
+                }
+            }
         }
     }
     __syncthreads();
@@ -229,16 +272,21 @@ int ptta_launch_nl_affinity_fwd(const GView& oa, const float* conf, const float*
     PTTA_CHECK_LAUNCH();
     return 0;
 }
-int ptta_launch_nl_prop_fwd(const float* feat, const float* fix, const float* off9, const float* aff9, float* out, int B, int H, int W,
-                            hipStream_t s) {
-    hipLaunchKernelGGL(nl_prop_fwd_kernel, dim3(nblocks((long)B * H * W)), dim3(256), 0, s, feat, fix, off9, aff9, out, B, H, W);
+int ptta_launch_nl_pin(const float* feat, const float* fix, float* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(nl_pin_kernel, dim3(nblocks(n)), dim3(256), 0, s, feat, fix, out, n);
     PTTA_CHECK_LAUNCH();
     return 0;
 }
-int ptta_launch_nl_prop_bwd(const float* feat, const float* fix, const float* off9, const float* aff9, const float* gout, float* gfeat,
+int ptta_launch_nl_prop_fwd(const float* pinned, const float* fix, const float* off9, const float* aff9, float* out, int pin_out, int B, int H,
+                            int W, hipStream_t s) {
+    hipLaunchKernelGGL(nl_prop_fwd_kernel, dim3(nblocks((long)B * H * W)), dim3(256), 0, s, pinned, fix, off9, aff9, out, pin_out, B, H, W);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+int ptta_launch_nl_prop_bwd(const float* pinned, const float* fix, const float* off9, const float* aff9, const float* gout, float* gfeat,
                             float* goff9, float* gaff9, int B, int H, int W, hipStream_t s) {
     const int tiles = B * ((W + PB_T - 1) / PB_T) * ((H + PB_T - 1) / PB_T);
-    hipLaunchKernelGGL(nl_prop_bwd_kernel, dim3(tiles), dim3(256), 0, s, feat, fix, off9, aff9, gout, gfeat, goff9, gaff9, B, H, W);
+    hipLaunchKernelGGL(nl_prop_bwd_kernel, dim3(tiles), dim3(256), 0, s, pinned, fix, off9, aff9, gout, gfeat, goff9, gaff9, B, H, W);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -208,9 +208,11 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
                              float* dgamma, float* dbeta, hipStream_t s, int act_first = 0, const PttaStatSync* sync = nullptr);
 
 int ptta_launch_nl_affinity_fwd(const GView& oa, const float* conf, const float* S, int legacy, float* off9, float* aff9, hipStream_t s);
-int ptta_launch_nl_prop_fwd(const float* feat, const float* fix, const float* off9, const float* aff9, float* out, int B, int H, int W,
-                            hipStream_t s);
-int ptta_launch_nl_prop_bwd(const float* feat, const float* fix, const float* off9, const float* aff9, const float* gout, float* gfeat,
+int ptta_launch_nl_pin(const float* feat, const float* fix, float* out, long n, hipStream_t s);       // out = fix > 0 ? fix : feat
+// pinned: the propagated map with the sparse input already imposed; out = pin(raw sweep output) when pin_out, else the raw output
+int ptta_launch_nl_prop_fwd(const float* pinned, const float* fix, const float* off9, const float* aff9, float* out, int pin_out, int B, int H,
+                            int W, hipStream_t s);
+int ptta_launch_nl_prop_bwd(const float* pinned, const float* fix, const float* off9, const float* aff9, const float* gout, float* gfeat,
                             float* goff9, float* gaff9, int B, int H, int W, hipStream_t s);
 int ptta_launch_nl_affinity_bwd(const GView& oa, const float* conf, const float* S, int legacy, const float* goff9, const float* gaff9,
                                 const GView& goa, float* gconf, hipStream_t s);

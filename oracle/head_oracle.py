@@ -56,7 +56,7 @@ def head_forward(P, image, sparse_depth, reverse, max_input_depth=None, prepare_
 
 class HeadTrainerOracle:
     def __init__(self, state_dict, loss_type='head_selfsup_seq_ema_reverse', max_input_depth=None, lr=2e-4, betas=(0.9, 0.999),
-                 eps=1e-8, weight_decay=0.0, tau=0.999):
+                 eps=1e-8, weight_decay=0.0, tau=0.999, prepare_mode='meta_selfsup_seq_1layer_ema'):
         assert 'head' in loss_type and 'ema' in loss_type and 'adapt' not in loss_type
         self.reverse = 'reverse' in loss_type
         self.P = {k: torch.as_tensor(v).clone() for k, v in state_dict.items()}
@@ -64,11 +64,12 @@ class HeadTrainerOracle:
         for k in self.names:
             self.P[k].requires_grad_(True)
         self.max_input_depth, self.tau = max_input_depth, tau
+        self.prepare_mode = prepare_mode
         self.hp = (lr, betas, eps, weight_decay)
         self.opt = None
 
     def step(self, image, sparse_depth):
-        emb, ref = head_forward(self.P, image, sparse_depth, self.reverse, self.max_input_depth, tau=self.tau)
+        emb, ref = head_forward(self.P, image, sparse_depth, self.reverse, self.max_input_depth, prepare_mode=self.prepare_mode, tau=self.tau)
         loss = prepare_loss(emb, ref)
         params = [self.P[k] for k in self.names]
         grads = torch.autograd.grad(loss, params, allow_unused=True)

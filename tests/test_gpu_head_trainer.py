@@ -10,7 +10,7 @@ from oracle import head_oracle as HO
 from proxytta import synth
 from proxytta.engine import HEAD_PARAMS, HEAD_TARGETS, Engine
 from tests.golden.make_golden_head import perturbed_target
-from tests.util import ONE
+from tests.util import ONE, TWO
 
 pytestmark = pytest.mark.gpu
 
@@ -254,3 +254,36 @@ def test_facade_fused_head_step_matches_its_unfused_loop(golden_dir):
     assert 'step' not in opt.state[head_params[names.index('proj.0.weight')]] or int(float(opt.state[head_params[names.index('proj.0.weight')]]['step'])) == 0
     state = model.model.model.state_dict()
     _check(z, 's%d/after/pred.3.weight' % (steps - 1), state['pred.3.weight'], 0, 2.5 * float(z['hp'][0]) * steps, 'pred.3.weight')
+
+
+def test_head_trainer_with_the_2layers_meta_layer():
+    """Stage 2 on the `2layers` recipe (Res_Conv(32,128) with train-mode BatchNorm2d in the no-grad backbone pass): two reverse
+    steps against the oracle, incl. the meta BatchNorm's running statistics."""
+    n, h, w = 2, 32, 64
+    hp = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    from proxytta.engine import adapted_names
+    eng = Engine(n, h, w, dtype='fp32', max_input_depth=80.0, meta='2layers')
+    sd_np = synth.formula_state_dict(TWO, 1.0)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in sd_np.items()}
+    eng.load_state_dict(sd)
+    for name in adapted_names('2layers'):
+        eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+    for k in HEAD_PARAMS:
+        eng.bind_head(k, sd[k], torch.zeros_like(sd[k]), torch.zeros_like(sd[k]))
+    for k in HEAD_TARGETS:
+        eng.bind_head(k, sd[k])
+    eng.set_head_hparams(tau=0.999, adam_step=0, **hp)
+    o = HO.HeadTrainerOracle(sd_np, 'head_selfsup_seq_ema_reverse', max_input_depth=80.0, tau=0.999, prepare_mode=TWO, **hp)
+    for s in range(2):
+        image, sparse = synth.synthetic_frame(20 + s, h, w, n)
+        r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+        eng.head_forward(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda(), True, want=False)
+        loss = eng.head_backward()
+        assert abs(float(loss) - r['loss']) < (2e-5 if s == 0 else 1e-4)
+        for k, g in r['grads'].items():
+            _grad_close(eng.head_grad(k, sd[k]).cpu().numpy(), g.numpy(), s == 0, k)
+        eng.head_adam_step()
+    for k in sd:
+        if 'conv1_rgb_meta' in k and 'running' in k:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), o.P[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+    eng.close()

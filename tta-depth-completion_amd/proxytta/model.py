@@ -204,8 +204,8 @@ class MsgChnModel_Adapt(object):
             raise NotImplementedError("prepare_parameters(%r): only the head trainer's 'head_selfsup_ema' is on the accelerated path" % mode)
         if self.prepare_mode is None:
             raise RuntimeError('_prepare_head(prepare_mode) first (head_main.py:259)')
-        if type(self) is not MsgChnModel_Adapt or self.meta != '1layer':
-            raise NotImplementedError('the stage-2 head trainer is built for MSG_CHN with the 1layer meta conv')
+        if type(self) is not MsgChnModel_Adapt:
+            raise NotImplementedError('the stage-2 head trainer is built for MSG_CHN (1layer or 2layers meta layer)')
         params = dict(self.model.named_parameters())
         with torch.no_grad():
             for k, shape in synth.msg_chn_keys(self.prepare_mode):

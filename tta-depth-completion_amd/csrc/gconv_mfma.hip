@@ -212,7 +212,9 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
 // transposed convolutions and their data gradients).
 //   MODE 1 (S2): y[oy][ox] = sum x[2oy+ky-pad][2ox+kx-pad] w[tap]
 //   MODE 2 (T2): y[oy][ox] = sum over taps with (oy+pad-ky), (ox+pad-kx) even of x[(oy+pad-ky)/2][(ox+pad-kx)/2] w[tap]
-template <int MODE, int KS, int KSPLIT>
+// NCO = output-channel tiles (of 32) per wave: with two, every A fragment (uncoalesced 32-B pieces of strided pixels, split to
+// bf16 in registers) feeds two weight fragments
+template <int MODE, int KS, int KSPLIT, int NCO>
 __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin, int Win) {
     constexpr int PAD = KS / 2, KK = KS * KS;
     // stride 2: two output rows per wave, tap-outer / row-inner, so the A loads of both rows are in flight before the
@@ -229,8 +231,9 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
     // block -> (4 consecutive items, channel tile); channel tile fastest.  KSPLIT = 4 (few pixels, many channels: the
     // 1/8 and 1/16-resolution layers): the block's four waves share ONE item and split its K loop (chunk c goes to wave
     // c mod 4), partial accumulators are summed through LDS in a fixed order -- 4x more blocks, 4x shorter latency chains
-    const int nfl = (int)(blockIdx.x % p.nnf);
-    const long item = KSPLIT == 4 ? (long)(blockIdx.x / p.nnf) : (long)(blockIdx.x / p.nnf) * 4 + wave;
+    const int ngrp = p.nnf / NCO;
+    const int nfl = (int)(blockIdx.x % ngrp) * NCO;
+    const long item = KSPLIT == 4 ? (long)(blockIdx.x / ngrp) : (long)(blockIdx.x / ngrp) * 4 + wave;
     if (item >= nitems) return;
     const int nf = p.nf0 + nfl;
     long t_ = item;
@@ -241,11 +244,13 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
     const int b = (int)(t_ / nseg);
     const int x0 = seg << 5, ybase = yg * R;
     const bool lane_in = (x0 + i) < Wt;
-    f32x16 acc[R];
+    f32x16 acc[NCO][R];
+#pragma unroll
+    for (int t = 0; t < NCO; ++t)
 #pragma unroll
     for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[t][rr][r] = 0.f;
     for (int c = KSPLIT == 4 ? wave : 0; c < p.nchunks; c += KSPLIT == 4 ? 4 : 1) {
         const bool s1 = c >= nch0;
         const float* src = s1 ? p.x1 : p.x0;
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
         const float* inb = src + (size_t)b * Hin * Win * ld + cb + 8 * h;
         const uint4* ph = p.whi + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + lane;
         const uint4* pl = p.wlo + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + lane;
+        const size_t tstride = (size_t)p.nchunks * (KK * 2 * 64);                 // next output-channel tile
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
@@ -263,8 +269,12 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, ph[(tap * 2 + k) * 64]);
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, pl[(tap * 2 + k) * 64]);
+                bf16x8 bh[NCO], bl[NCO];
+#pragma unroll
+                for (int t = 0; t < NCO; ++t) {
+                    bh[t] = __builtin_bit_cast(bf16x8, ph[t * tstride + (tap * 2 + k) * 64]);
+                    bl[t] = __builtin_bit_cast(bf16x8, pl[t * tstride + (tap * 2 + k) * 64]);
+                }
                 bf16x8 ah[R], al[R];
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
@@ -285,31 +295,39 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
                     ah[rr] = __builtin_bit_cast(bf16x8, hi); al[rr] = __builtin_bit_cast(bf16x8, lo);
                 }
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr) {
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh, acc[rr], 0, 0, 0);
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl, acc[rr], 0, 0, 0);
-                    acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bh, acc[rr], 0, 0, 0);
-                }
+                for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                    for (int t = 0; t < NCO; ++t) {
+                        acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh[t], acc[t][rr], 0, 0, 0);
+                        acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl[t], acc[t][rr], 0, 0, 0);
+                        acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bh[t], acc[t][rr], 0, 0, 0);
+                    }
             }
         }
     }
     if constexpr (KSPLIT == 4) {
-        __shared__ float red[3][R][16][64];
+        __shared__ float red[3][NCO][R][16][64];
         if (wave) {
+#pragma unroll
+            for (int t = 0; t < NCO; ++t)
 #pragma unroll
             for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave - 1][rr][r][lane] = acc[rr][r];
+                for (int r = 0; r < 16; ++r) red[wave - 1][t][rr][r][lane] = acc[t][rr][r];
         }
         __syncthreads();
         if (wave) return;
 #pragma unroll
+        for (int t = 0; t < NCO; ++t)
+#pragma unroll
         for (int rr = 0; rr < R; ++rr)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rr][r] = (acc[rr][r] + red[0][rr][r][lane]) + (red[1][rr][r][lane] + red[2][rr][r][lane]);
+            for (int r = 0; r < 16; ++r) acc[t][rr][r] = (acc[t][rr][r] + red[0][t][rr][r][lane]) + (red[1][t][rr][r][lane] + red[2][t][rr][r][lane]);
     }
-    const int co = nf * 32 + i - p.nf0 * 32;
-    if (co >= p.Cy) return;
+#pragma unroll
+    for (int t = 0; t < NCO; ++t) {
+    const int co = (nf + t) * 32 + i - p.nf0 * 32;
+    if (co >= p.Cy) continue;
     const float bias = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
@@ -323,13 +341,14 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
             const int x = MODE == 2 ? 2 * xl + xpar : xl;
             if (MODE == 2 && x >= Wout) continue;         // odd output width: the gradient of a stride-2 conv over an odd-sized map
             float* dst = yrow + (size_t)x * p.ldy;
-            float v = acc[rr][r] + bias;
+            float v = acc[t][rr][r] + bias;
             if (p.accumulate) v += *dst;
             if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
             else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
             else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
             *dst = v;
         }
+    }
     }
 }
 
@@ -446,11 +465,17 @@ int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, in
     const int Wt = mode == 2 ? win : a.W;
     const long nitems = (long)a.B * ((Wt + 31) / 32) * (mode == 2 ? 2 : 1) * (mode == 1 ? (a.H + 1) / 2 : a.H);   // stride 2: two rows per wave
     // few pixels and a long K loop: split K over the block's waves
+    // few pixels and a long K loop (the 1/8 and 1/16-resolution layers): one item per block, K split over its waves, one channel
+    // tile per wave; otherwise two channel tiles per wave
     const bool split = a.nchunks >= 4 && ((nitems + 3) / 4) * a.nnf < 1536;
-    const long blocks = (split ? nitems : (nitems + 3) / 4) * a.nnf;
+    // (measured on the NLSPN step, same box: one tile 24.83 ms, two 24.36, four 24.47)
+    const int nco = (split || ks != 3 || (a.nnf & 1)) ? 1 : 2;
+    const int ngrp = a.nnf / nco;
+    const long blocks = (split ? nitems : (nitems + 3) / 4) * ngrp;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
-#define L_(M, K) do { if (split) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 4>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); \
-                      else hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); } while (0)
+#define L_(M, K) do { if (nco == 2) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); \
+                      else if (split) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); \
+                      else hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); } while (0)
     if (mode == 1) { if (ks == 3) L_(1, 3); else L_(1, 1); }
     else { if (ks == 3) L_(2, 3); else L_(2, 1); }
 #undef L_

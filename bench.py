@@ -181,6 +181,37 @@ def nlspn_workload(frames=3, inner_iter=3):
     return out
 
 
+def head_stage2_workload(steps=20):
+    """Stage-2 head trainer step (src/head_main.py:464-480) at the headline shape, both loss types; beside the metric."""
+    from proxytta import synth
+    from proxytta.engine import HEAD_PARAMS, HEAD_TARGETS, Engine
+    eng = Engine(1, H, W, dtype='fp32', **HP)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
+    eng.load_state_dict(sd)
+    for name in eng.adapted:
+        eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+    keep = []
+    for k in HEAD_PARAMS:
+        keep.append((torch.zeros_like(sd[k]), torch.zeros_like(sd[k])))
+        eng.bind_head(k, sd[k], *keep[-1])
+    for k in HEAD_TARGETS:
+        eng.bind_head(k, sd[k])
+    eng.set_head_hparams(lr=2e-4, adam_step=0)
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(700 + i, H, W, 1)] for i in range(4)]
+    out = {'workload': 'stage-2 head trainer step (EMA target, prepare loss, Linear weight gradients, Adam), MSG_CHN 1layer, 352x1216, batch 1'}
+    for name, reverse in (('head_selfsup_seq_ema_reverse', True), ('head_selfsup_seq_ema', False)):
+        for i in range(3):
+            eng.head_step(*frames[i % 4], reverse)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = eng.head_step(*frames[i % 4], reverse)
+        torch.cuda.synchronize()
+        out[name] = {'ms_per_step': 1e3 * (time.perf_counter() - t0) / steps, 'finite': bool(torch.isfinite(loss).all().item())}
+    eng.close()
+    return out
+
+
 def plumbing_only(args, rank, world):
     """The multi-rank skeleton of main() without device work (tests/test_distributed_cpu.py): rendezvous on 127.0.0.1,
     warm-up, barrier, K timed no-op steps, barrier, MAX over ranks, rank 0 prints the JSON line with value null."""
@@ -446,7 +477,8 @@ def main():
     eng.close()
     if rank == 0:
         if world == 1 and not args.no_nlspn:
-            out['other_workloads'] = {'msg_chn_2layers': msgchn_2layers_workload(), 'nlspn': nlspn_workload(), 'costdcnet': costdcnet_workload()}
+            out['other_workloads'] = {'msg_chn_2layers': msgchn_2layers_workload(), 'nlspn': nlspn_workload(), 'costdcnet': costdcnet_workload(),
+                                      'head_stage2': head_stage2_workload()}
             if not args.no_cpu_baseline:
                 out['other_workloads']['nlspn']['cpu_baseline'] = nlspn_cpu_baseline()
                 out['other_workloads']['costdcnet']['cpu_baseline'] = costdcnet_cpu_baseline()

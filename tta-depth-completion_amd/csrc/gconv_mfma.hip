@@ -61,9 +61,11 @@ __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, lon
 }
 
 #define GX_STR16 80                                      // LDS bytes per pixel: hi 32 | lo 32 | pad 16
-template <int KS>
+// VERT: only the middle column of the 3x3 window (a 3x1x1 Conv3d viewed as a vertical 3-tap convolution over [D][H*W] images,
+// gnet.h Op::rH/rW): three taps, no horizontal halo -- a third of the MFMAs of the zero-padded 3x3 form it replaces.
+template <int KS, bool VERT>
 __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
-    constexpr int PAD = KS / 2, PH = GX_TH + 2 * PAD, PW = 32 + 2 * PAD, KK = KS * KS;
+    constexpr int PAD = KS / 2, PADX = VERT ? 0 : PAD, KKX = VERT ? 1 : KS, PH = GX_TH + 2 * PAD, PW = 32 + 2 * PADX, KK = KS * KKX;
     constexpr int NPIX = PH * PW;
     constexpr int NIT = (NPIX * 2 + 255) / 256;          // (pixel, 8-channel group) items per thread
     constexpr int NWF = KK * 64 * 2;                     // weight uint4 per sub-chunk: [hi | lo][tap][lane]
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             const int idx = tid + 256 * it;
             const int g = idx & 1, pix = idx >> 1;
             const int py = pix / PW, px = pix - py * PW;
-            const int gy = y0 - PAD + py, gx = x0 - PAD + px;
+            const int gy = y0 - PAD + py, gx = x0 - PADX + px;
             v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
             if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && cb + 8 * g < Cs) {
                 const float* s_ = inb + ((size_t)gy * W + gx) * ld + 8 * g;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
         __builtin_amdgcn_s_setprio(1);                    // MFMA phase outranks the other blocks' staging code at issue
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
-            const int ky = tap / KS, kx = tap % KS;
+            const int ky = tap / KKX, kx = tap % KKX;
             const bf16x8 bh = __builtin_bit_cast(bf16x8, wlds[tap * 64 + lane]);
             const bf16x8 bl = __builtin_bit_cast(bf16x8, wlds[KK * 64 + tap * 64 + lane]);
 #pragma unroll
@@ -451,8 +453,9 @@ int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
     const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + GX_TH - 1) / GX_TH);
     const long blocks = tiles * a.nnf;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
-    if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else if (ks == 1) hipLaunchKernelGGL((gconv_x3_s1_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (ks == 3 && a.vert) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else if (ks == 1) hipLaunchKernelGGL((gconv_x3_s1_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else return -22;
     PTTA_CHECK_LAUNCH();
     return 0;

@@ -282,6 +282,13 @@ struct GNet {
 
     // ---- weights ---------------------------------------------------------------------------------------------------
     void pack_frags(GConvW& cw, hipStream_t s) {
+        if (cw.vcol) {
+            // 3x1x1 Conv3d: the matrix-core kernel's VERT form takes the three vertical taps only (canonical taps 1, 4, 7)
+            const long ts = (long)cw.Ci * cw.Co;
+            if (cw.mf) ptta_gfrag_pack(cw.wf + ts, cw.Co, 3 * ts, 3, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);
+            if (cw.mb) ptta_gfrag_pack(cw.wb + ts, cw.Ci, 3 * ts, 3, cw.Co, 0, 0, 0, cw.Ci, cw.fb_hi, cw.fb_lo, s);
+            return;
+        }
         const int KK = cw.k * cw.k;
         if (cw.mf && cw.Ci_real) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci_real * cw.Co, KK, cw.Ci_real, 0, 0, 0, cw.Co, cw.ff_hi, cw.ff_lo, s);
         else if (cw.mf) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci * cw.Co, KK, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);

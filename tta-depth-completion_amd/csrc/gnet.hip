@@ -79,7 +79,7 @@ int GNet::run_conv_fwd(const Op& o, bool train, hipStream_t s) {
         a.B = y.B; a.H = y.H; a.W = y.W;
         a.whi = (const uint4*)cw.ff_hi; a.wlo = (const uint4*)cw.ff_lo;
         a.nchunks = (a.C0 + 31) / 32 + (a.C1 + 31) / 32; a.nf0 = 0; a.nnf = (cw.Co + 31) / 32;
-        a.y = y.p; a.ldy = y.ld; a.Cy = y.C; a.bias = bias; a.act = o.act;
+        a.y = y.p; a.ldy = y.ld; a.Cy = y.C; a.bias = bias; a.act = o.act; a.vert = cw.vcol;
         if (o.stat_to >= 0 && (train || !ops[o.stat_to].tracked)) {
             a.stat_part = ops[o.stat_to].part; a.stat_C = y.C; a.stat_npass = (o.yw == W_BOTH && train) ? 2 : 1;
         }
@@ -154,6 +154,7 @@ int GNet::run_conv_bwd(const Op& o, hipStream_t s) {
             a.nchunks = (a.C0 + 31) / 32; a.nf0 = own_frags ? 0 : o.c0[sidx] / 32; a.nnf = (gx.C + 31) / 32;
             a.y = gx.p; a.ldy = gx.ld; a.Cy = gx.C; a.accumulate = o.first_x[sidx] ? 0 : 1;
             a.B = gx.B; a.H = gx.H; a.W = gx.W;                  // output geometry = the source's
+            a.vert = cw.vcol;
             int rc;
             if (o.stride == 1 && !o.transposed) rc = ptta_launch_gconv_x3(a, o.k, s);
             else rc = ptta_launch_gconv_x3_strided(a, o.k, o.transposed ? 1 : 2, gy.H, gy.W, s);     // convT -> strided conv, strided conv -> convT

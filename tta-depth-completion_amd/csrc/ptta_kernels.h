@@ -229,6 +229,7 @@ struct GX3Args {
     // optional fused BatchNorm statistics of the OUTPUT (stride-1 kernel): per (pass, pixel tile) partial sums
     // {sum y, sum y^2} per channel, layout [pass][tile][2][stat_C]; stat_npass equal slices of the batch
     float* stat_part = nullptr; int stat_C = 0, stat_npass = 1;
+    int vert = 0;                                             // stride-1 3x3 only: fragments hold the three vertical taps (3x1x1 Conv3d)
 };
 void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
                      hipStream_t s);

@@ -212,6 +212,59 @@ def head_stage2_workload(steps=20):
     return out
 
 
+def costdcnet_shared(args, rank, world, dist):
+    """BASELINE config 5: CostDCNet, 480x640, batched TTA with SHARED adapted parameters -- every rank adapts its own frame of
+    the global batch, BatchNorm statistics are those of the global batch (SyncBatchNorm, src/tta_main.py:326), ONE flat
+    all-reduce of the 32 adapted gradients per step (RCCL over xGMI on a multi-GPU node), identical Adam on every rank.
+    Optional workload (`--workload costdcnet-shared`); the headline metric stays the default one."""
+    from proxytta import synth
+    from proxytta.distributed import shared_parameter_step
+    from proxytta.engine import Engine
+    h, w = 480, 640
+    eng = Engine(1, h, w, backbone='costdcnet', max_predict_depth=8.0, lr=3e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_costdcnet().items()}
+    eng.load_state_dict(sd)
+    keep = []
+    for k in eng.adapted:
+        keep.append((sd[k].clone().contiguous(), torch.zeros_like(sd[k]), torch.zeros_like(sd[k])))
+        eng.bind_adapted(k, *keep[-1])
+    if world > 1:
+        eng.enable_stat_sync()
+    frames = costdcnet_frames(2, h, w)                          # every rank its own two frames of the stream
+    data = [[torch.from_numpy(np.roll(x, 7 * rank, axis=-1)).cuda() for x in f] for f in frames]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        shared_parameter_step(eng, data[i % 2][1], data[i % 2][2], loss_image=data[i % 2][0])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        info, _ = shared_parameter_step(eng, data[i % 2][1], data[i % 2][2], loss_image=data[i % 2][0])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(info).all().item())
+    eng.close()
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'TTA frames/sec (fwd+loss+bwd+Adam), CostDCNet 480x640, shared adapted parameters', 'value': world * args.steps / elapsed,
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 storage, bf16x3 MFMA arithmetic (fp32 accumulate)',
+            'data': 'synthetic',
+            'config': {'workload': 'CostDCNet, 480x640 VOID-shaped synthetic (1500 points), global batch = n_gpus frames, 1 TTA step, meta_bn (32 tensors)',
+                       'parallelism': 'dp%d: SyncBatchNorm statistics exchange per BatchNorm + one flat gradient all-reduce (5,200 floats) per step' % world,
+                       'finite': finite}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def plumbing_only(args, rank, world):
     """The multi-rank skeleton of main() without device work (tests/test_distributed_cpu.py): rendezvous on 127.0.0.1,
     warm-up, barrier, K timed no-op steps, barrier, MAX over ranks, rank 0 prints the JSON line with value null."""
@@ -335,6 +388,8 @@ def main():
     ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nlspn', action='store_true', help='skip the side measurements (2layers, NLSPN, CostDCNet)')
+    ap.add_argument('--workload', default='msg_chn', choices=['msg_chn', 'costdcnet-shared'],
+                    help="'costdcnet-shared': BASELINE config 5 (shared adapted parameters, all-reduce + SyncBatchNorm) instead of the headline metric")
     ap.add_argument('--plumbing-only', action='store_true',
                     help='tests only: run launcher / rendezvous / barrier / max-over-ranks / JSON with NO device work '
                          '(value is null, "data": "none"); lets the multi-rank path run on a CPU box with gloo')
@@ -359,6 +414,8 @@ def main():
         # 'nccl' IS RCCL on ROCm; PTTA_BENCH_BACKEND=gloo exists only to exercise this path on one GPU
         dist.init_process_group(os.environ.get('PTTA_BENCH_BACKEND', 'nccl'), rank=rank, world_size=world)
 
+    if args.workload == 'costdcnet-shared':
+        return costdcnet_shared(args, rank, world, dist)
     from proxytta import synth
     from proxytta.engine import ADAPTED, Engine
     eng = Engine(1, H, W, dtype=args.dtype, **HP)

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256) void nl_prop_fwd_kernel(const float* __restric
 // are a few pixels at most, so the scatter goes to an LDS copy of the tile + a 4-pixel apron (ds_add_f32) and is
 // flushed with one global atomic per touched cell; targets outside the apron fall back to global atomics directly.
 // Loads are batched three taps at a time (offsets / affinities / accumulators first, then 12 corner values + 12 pin masks).
-// Ablations at 352x1216 (one box): 91.6 us as is; without the accumulator read-modify-writes 92.0; without them AND without the
+// Round 2 added neighbour merging (below): 91 -> 74 us per sweep on the synthetic frames, whose offset fields are not smooth.
+// Ablations at 352x1216 before it (one box): 91.6 us as is; without the accumulator read-modify-writes 92.0; without them AND without the
 // corner gathers 92.1; with the scatter on memory-side global atomics instead of LDS 215.9 (half and half: 130.5) -- the 36
 // ds_add_f32 per pixel are the whole kernel (SQ_WAIT_INST_LDS = 40 % of its wave cycles), and LDS is still the faster home.
 #define PB_T 16
@@ -161,8 +162,12 @@ __global__ __launch_bounds__(256, 4) void nl_prop_bwd_kernel(const float* __rest
     const int y = ty0 + (threadIdx.x >> 4), x = tx0 + (threadIdx.x & 15);
     const float* fb = pinned + (long)b * P; const float* xb = fix + (long)b * P;
     float* gb = gfeat + (long)b * P;
-    if (y < H && x < W) {
-        const long pix = (long)y * W + x, idx = (long)b * P + pix;
+    // every lane runs the whole body (the neighbour merging below shuffles across lanes); lanes outside the image work on a
+    // clamped pixel and neither store nor scatter
+    const bool inimg = y < H && x < W;
+    const int col = threadIdx.x & 15, wrow = (threadIdx.x >> 4) & 3;            // position inside the wave's 4 x 16 pixel patch
+    {
+        const long pix = (long)min(y, H - 1) * W + min(x, W - 1), idx = (long)b * P + pix;
         const float* o = off9 + (long)b * 18 * P + pix; const float* a = aff9 + (long)b * 9 * P + pix;
         float* go = goff9 + (long)b * 18 * P + pix; float* ga = gaff9 + (long)b * 9 * P + pix;
         const float g = gout[idx];
@@ -190,18 +195,46 @@ __global__ __launch_bounds__(256, 4) void nl_prop_bwd_kernel(const float* __rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (!tk.ok[j]) v[kk][j] = 0.f;
                 const float hh = 1.f - tk.lh, hw = 1.f - tk.lw, ga_ = g * av[k];
-                ga[(long)k * P] = gav[kk] + g * tap_blend(tk, v[kk]);
-                // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
-                go[(long)(2 * k) * P] = gov[2 * kk] + ga_ * (-hw * v[kk][0] - tk.lw * v[kk][1] + hw * v[kk][2] + tk.lw * v[kk][3]);
-                go[(long)(2 * k + 1) * P] = gov[2 * kk + 1] + ga_ * (-hh * v[kk][0] + hh * v[kk][1] - tk.lh * v[kk][2] + tk.lh * v[kk][3]);
-                const float wgt[4] = {hh * hw * ga_, hh * tk.lw * ga_, tk.lh * hw * ga_, tk.lh * tk.lw * ga_};
+                if (inimg) {
+                    ga[(long)k * P] = gav[kk] + g * tap_blend(tk, v[kk]);
+                    // mdmcn_get_coordinate_weight (modulated_deform_im2col_cuda.cuh:84-125)
+                    go[(long)(2 * k) * P] = gov[2 * kk] + ga_ * (-hw * v[kk][0] - tk.lw * v[kk][1] + hw * v[kk][2] + tk.lw * v[kk][3]);
+                    go[(long)(2 * k + 1) * P] = gov[2 * kk + 1] + ga_ * (-hh * v[kk][0] + hh * v[kk][1] - tk.lh * v[kk][2] + tk.lh * v[kk][3]);
+                }
+                // contributions to the four corners; a corner outside the image or pinned by the sparse input receives nothing
+                float val[4] = {hh * hw * ga_, hh * tk.lw * ga_, tk.lh * hw * ga_, tk.lh * tk.lw * ga_};
+                bool act[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { act[j] = inimg && tk.ok[j] && !(m[kk][j] > 0.f) && val[j] != 0.f; if (!act[j]) val[j] = 0.f; }   // (+0 is not worth an atomic)
+                // Neighbour merging.  The LDS float atomics are this kernel's whole cost; where the offset field is smooth, the
+                // right-hand corners of a pixel ARE the left-hand corners of its right neighbour (and the lower corners the upper
+                // corners of the pixel below): hand the contribution to that lane (DPP row shift / one permute) instead of
+                // issuing an atomic of its own.  Exact: a hand-over happens only when the two cell indices are equal.
+                auto merge = [&](int src, int dst, bool horizontal) __attribute__((always_inline)) {
+                    const int sq = act[src] ? tk.q[src] : -1;
+                    int nq, rsq; float rv;
+                    if (horizontal) {
+                        nq = __builtin_amdgcn_update_dpp(0, tk.q[dst], 0x101, 0xf, 0xf, true);                        // row_shl:1 -> lane + 1
+                        rsq = __builtin_amdgcn_update_dpp(-1, sq, 0x111, 0xf, 0xf, false);                             // row_shr:1 -> lane - 1
+                        rv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(val[src]), 0x111, 0xf, 0xf, true));
+                    } else {
+                        nq = __shfl_down(tk.q[dst], 16); rsq = __shfl_up(sq, 16); rv = __shfl_up(val[src], 16);
+                    }
+                    const bool edge_s = horizontal ? col == 15 : wrow == 3, edge_r = horizontal ? col == 0 : wrow == 0;
+                    const bool give = !edge_s && sq >= 0 && nq == sq;
+                    const bool take = !edge_r && rsq >= 0 && rsq == tk.q[dst];
+                    if (take) { val[dst] += rv; act[dst] = true; }
+                    if (give) { act[src] = false; val[src] = 0.f; }
+                };
+                merge(1, 0, true); merge(3, 2, true);
+                merge(2, 0, false); merge(3, 1, false);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (!tk.ok[j] || m[kk][j] > 0.f) continue;            // outside, or pinned by the sparse input: no gradient to the feature
+                    if (!act[j]) continue;
                     const int qy = tk.q[j] / W, qx = tk.q[j] - qy * W;
                     const int ly = qy - ty0 + PB_R, lx = qx - tx0 + PB_R;
-                    if (ly >= 0 && ly < PB_W && lx >= 0 && lx < PB_W) atomicAdd(&tile[ly * PB_W + lx], wgt[j]);
-                    else atomicAdd(gb + tk.q[j], wgt[j]);
+                    if (ly >= 0 && ly < PB_W && lx >= 0 && lx < PB_W) atomicAdd(&tile[ly * PB_W + lx], val[j]);
+                    else atomicAdd(gb + tk.q[j], val[j]);
                 }
             }
         }

@@ -153,15 +153,20 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             const int ky = tap / KKX, kx = tap % KKX;
             const bf16x8 bh = __builtin_bit_cast(bf16x8, wlds[tap * 64 + lane]);
             const bf16x8 bl = __builtin_bit_cast(bf16x8, wlds[KK * 64 + tap * 64 + lane]);
+            // the two rows' MFMAs alternate: consecutive matrix instructions never accumulate into the same registers
+            bf16x8 ah[2], al[2];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const unsigned char* a = lds + ((2 * wave + rr + ky) * PW + i + kx) * GX_STR16 + 16 * h;
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
-                const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
-                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[rr], 0, 0, 0);
-                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[rr], 0, 0, 0);
-                acc[rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rr], 0, 0, 0);
+                ah[rr] = __builtin_bit_cast(bf16x8, *(const uint4*)a);
+                al[rr] = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
             }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh, acc[1], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
     }

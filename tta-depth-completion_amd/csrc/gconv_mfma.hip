@@ -416,6 +416,109 @@ __global__ __launch_bounds__(64) void gwgrad_mfma_kernel(GView x, GView gy, int 
         for (int r = 0; r < 16; ++r) out[9 * 1024 + acc_row(r, h)] = acc[9][r];
 }
 
+// ---- the same weight gradient on the bf16 matrix cores (bf16x3), for Ci, Co <= 64: dW[co][ci][tap] = sum_p gy[p][co] x[p+tap][ci] as a
+// reduction-GEMM over pixels, like head_train.hip's Linear gradient: an MFMA lane holds 8 consecutive k for one m, and with
+// k = pixel, m = channel those are 8 consecutive PIXELS of one channel -- 8 dword loads per fragment, straight from global.
+// Block = 4 waves = the (co tile, ci tile) pairs of a 64 x 64 problem; a K step is 16 consecutive pixels of one image row.
+// Per row offset dy the lane loads x[row + dy][p - 1 .. p + 8] ONCE (10 loads) and the three horizontal taps are register
+// renames of it (v[0..7], v[1..8], v[2..9]): 38 loads per step instead of 80.  Nine 32 x 32 accumulators per wave; the next
+// step's loads are issued before the current step's 27 MFMAs.  Partials in the layout of gwgrad_mfma_kernel (same reducer).
+// 352x1216, Conv2d(48,48,3): 876 -> see DESIGN.md (the fp32 form alternated a 40-load phase and a 40-MFMA phase per 8 pixels).
+__device__ __forceinline__ void wsplit8(const float* v, uint4& hi, uint4& lo) {
+    gsplit2(v[0], v[1], hi.x, lo.x); gsplit2(v[2], v[3], hi.y, lo.y);
+    gsplit2(v[4], v[5], hi.z, lo.z); gsplit2(v[6], v[7], hi.w, lo.w);
+}
+__global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int nitems_x, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, hg = lane >> 5;
+    const int cob = wave >> 1, cib = wave & 1;
+    const int H = x.H, W = x.W;
+    const int co = cob * 32 + c, ci = cib * 32 + c;
+    const bool cov = co < gy.C, civ = ci < x.C;
+    const float* gyc = gy.p + (cov ? co : 0);
+    const float* xc = x.p + (civ ? ci : 0);
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    const long nitems = (long)x.B * H * nitems_x;                     // item = 16 consecutive pixels of one row
+    struct Regs { float g[8]; float v[3][10]; unsigned gm, vm[3]; };      // raw loads + validity bits (zero-fill happens at use: no wait at the load)
+    auto fetch = [&](long item, Regs& r) __attribute__((always_inline)) {
+        const int xs = (int)(item % nitems_x); const long t_ = item / nitems_x;
+        const int y = (int)(t_ % H); const int b = (int)(t_ / H);
+        const int p0 = xs * 16 + 8 * hg;                               // this lane's first pixel of the step
+        const long rowbase = ((long)b * H + y) * W;
+        r.gm = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = p0 + j;
+            r.g[j] = gyc[(rowbase + min(px, W - 1)) * gy.ld];
+            r.gm |= (px < W && cov) ? (1u << j) : 0u;
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            const bool rok = yy >= 0 && yy < H && civ;
+            const long rb = ((long)b * H + min(max(yy, 0), H - 1)) * W;
+            r.vm[dy] = 0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int px = p0 + j - 1;
+                r.v[dy][j] = xc[(rb + min(max(px, 0), W - 1)) * x.ld];
+                r.vm[dy] |= (rok && px >= 0 && px < W) ? (1u << j) : 0u;
+            }
+        }
+    };
+    auto mma = [&](const Regs& rr_) __attribute__((always_inline)) {
+        Regs r = rr_;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (!((r.gm >> j) & 1u)) r.g[j] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) if (!((r.vm[dy] >> j) & 1u)) r.v[dy][j] = 0.f;
+        uint4 gh, gl;
+        wsplit8(r.g, gh, gl);
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, gh), al = __builtin_bit_cast(bf16x8, gl);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum += r.g[j];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                uint4 xh, xl;
+                wsplit8(&r.v[dy][dx], xh, xl);                         // pixels p + dx - 1 .. p + dx + 6: a register rename
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, xh), bl = __builtin_bit_cast(bf16x8, xl);
+                const int t = dy * 3 + dx;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+            }
+    };
+    Regs r0, r1;
+    long item = blockIdx.x;
+    if (item < nitems) fetch(item, r0);
+    while (item < nitems) {
+        const long n1 = item + gridDim.x;
+        if (n1 < nitems) fetch(n1, r1);
+        mma(r0);
+        if (n1 >= nitems) break;
+        const long n2 = n1 + gridDim.x;
+        if (n2 < nitems) fetch(n2, r0);
+        mma(r1);
+        item = n2;
+    }
+    float* out = part + ((long)blockIdx.x * 4 + wave) * GWG_PART;      // pair index = cob * 2 + cib = wave (ncib = 2)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(tap * 32 + acc_row(r, hg)) * 32 + c] = acc[tap][r];
+    bsum += __shfl_xor(bsum, 32);
+    if (hg == 0) out[9 * 1024 + c] = bsum;                            // bias partial of channel co (read from the pairs with cib == 0)
+}
+
 // one wave per output element group: 64 lanes sum the chunk partials of one (tap, co, ci) in a fixed order
 __global__ __launch_bounds__(256) void gwgrad_mfma_reduce_kernel(const float* __restrict__ part, int nchunks, int npairs, int ncib, int Ci, int Co,
                                                                  float* __restrict__ gw, float* __restrict__ gb) {
@@ -493,9 +596,22 @@ int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, in
 
 int ptta_gwgrad_mfma_chunks(long pixels) { long n = (pixels + 127) / 128; return (int)(n > 1024 ? 1024 : (n < 1 ? 1 : n)); }
 long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co) {
-    return (long)ptta_gwgrad_mfma_chunks(pixels) * ((Ci + 31) / 32) * ((Co + 31) / 32) * GWG_PART;
+    const long a = (long)ptta_gwgrad_mfma_chunks(pixels) * ((Ci + 31) / 32) * ((Co + 31) / 32) * GWG_PART;
+    const long b = 256L * 4 * GWG_PART;                                  // gwgrad_x3_kernel: 256 blocks x 4 tile pairs
+    return a > b ? a : b;
 }
 int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s) {
+    if (x.C <= 64 && gy.C <= 64 && x.C > 16) {
+        // bf16x3 form: 256 blocks of four waves, partials [block][4 pairs] reduced by the same kernel (it sees ncib = 2, ncob = 2)
+        const int nx = (x.W + 15) / 16;
+        const long nitems = (long)x.B * x.H * nx;
+        const int nblk = (int)(nitems < 256 ? nitems : 256);
+        hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, part);
+        const long n = 9L * x.C * gy.C + gy.C;
+        hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk, 4, 2, x.C, gy.C, gw, gb);
+        PTTA_CHECK_LAUNCH();
+        return 0;
+    }
     const int nchunks = ptta_gwgrad_mfma_chunks((long)x.B * x.H * x.W);
     const int ncib = (x.C + 31) / 32, ncob = (gy.C + 31) / 32, npairs = ncib * ncob;
     hipLaunchKernelGGL(gwgrad_mfma_kernel, dim3(nchunks, npairs), dim3(64), 0, s, x, gy, nchunks, ncib, part);

@@ -428,10 +428,11 @@ __device__ __forceinline__ void wsplit8(const float* v, uint4& hi, uint4& lo) {
     gsplit2(v[0], v[1], hi.x, lo.x); gsplit2(v[2], v[3], hi.y, lo.y);
     gsplit2(v[4], v[5], hi.z, lo.z); gsplit2(v[6], v[7], hi.w, lo.w);
 }
-__global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int nitems_x, float* __restrict__ part) {
+// single = 1 (Ci, Co <= 32): one tile pair; the four waves take different items instead and write a partial each.
+__global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int nitems_x, int single, float* __restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, hg = lane >> 5;
-    const int cob = wave >> 1, cib = wave & 1;
+    const int cob = single ? 0 : wave >> 1, cib = single ? 0 : wave & 1;
     const int H = x.H, W = x.W;
     const int co = cob * 32 + c, ci = cib * 32 + c;
     const bool cov = co < gy.C, civ = ci < x.C;
@@ -498,19 +499,20 @@ __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int n
             }
     };
     Regs r0, r1;
-    long item = blockIdx.x;
+    const long stride = single ? (long)gridDim.x * 4 : gridDim.x;
+    long item = single ? (long)blockIdx.x * 4 + wave : blockIdx.x;
     if (item < nitems) fetch(item, r0);
     while (item < nitems) {
-        const long n1 = item + gridDim.x;
+        const long n1 = item + stride;
         if (n1 < nitems) fetch(n1, r1);
         mma(r0);
         if (n1 >= nitems) break;
-        const long n2 = n1 + gridDim.x;
+        const long n2 = n1 + stride;
         if (n2 < nitems) fetch(n2, r0);
         mma(r1);
         item = n2;
     }
-    float* out = part + ((long)blockIdx.x * 4 + wave) * GWG_PART;      // pair index = cob * 2 + cib = wave (ncib = 2)
+    float* out = part + ((long)blockIdx.x * 4 + wave) * GWG_PART;      // pair index = cob * 2 + cib = wave (ncib = 2); single: chunk index
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -602,13 +604,17 @@ long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co) {
 }
 int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s) {
     if (x.C <= 64 && gy.C <= 64 && x.C > 16) {
-        // bf16x3 form: 256 blocks of four waves, partials [block][4 pairs] reduced by the same kernel (it sees ncib = 2, ncob = 2)
+        // bf16x3 form: blocks of four waves; > 32 channels: partials [block][4 pairs] (the reducer sees ncib = 2, ncob = 2);
+        // <= 32 channels: one pair, the waves split the items, partials [block * 4 + wave]
         const int nx = (x.W + 15) / 16;
         const long nitems = (long)x.B * x.H * nx;
-        const int nblk = (int)(nitems < 256 ? nitems : 256);
-        hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, part);
+        const int single = (x.C <= 32 && gy.C <= 32) ? 1 : 0;
+        const long cap = single ? 64 : 256;
+        const int nblk = (int)(nitems < cap ? nitems : cap);
+        hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, part);
         const long n = 9L * x.C * gy.C + gy.C;
-        hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk, 4, 2, x.C, gy.C, gw, gb);
+        if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb);
+        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk, 4, 2, x.C, gy.C, gw, gb);
         PTTA_CHECK_LAUNCH();
         return 0;
     }

@@ -340,7 +340,8 @@ void build_workspace(ptta_ctx* c) {
     M_(dp11, Nn, H1, W1); M_(dq, Nn, H2, W2); M_(dp12, Nn, H2, W2); M_(dout1, Nn, H4, W4);
     c->g_feat_f32 = c->falloc((size_t)c->Rg * 32);
     c->dbg["g_feat_f32"] = Dbg{c->g_feat_f32, c->Rg * 32, 0};
-    c->wgrad_part = c->falloc((size_t)ptta_wgrad_chunks(c->Rg) * 10 * 1024);
+    { const size_t a = (size_t)ptta_wgrad_chunks(c->Rg) * 10 * 1024, b = (size_t)ptta_gwgrad_mfma_part_floats(c->Rg, 32, 32);
+      c->wgrad_part = c->falloc(a > b ? a : b); }
     {
         const char* p2 = "conv1_rgb_meta.conv1_meta.";
         std::vector<std::pair<std::string, long>> names;
@@ -863,6 +864,13 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
 #undef CV
     // ---- weight gradient of the meta layer: input = c2 of the real frames ----
     if (c->meta_mode == PTTA_META_2LAYERS) return meta2_backward(c, s);
+    if (!c->bf16 && c->x3 && !c->naive) {
+        // default arithmetic: the bf16x3 reduction-GEMM form (gconv_mfma.hip gwgrad_x3_kernel, single-pair mode)
+        GView xv; xv.p = (float*)c->c2; xv.B = Nn; xv.H = H4; xv.W = W4; xv.C = 32; xv.ld = 32;
+        GView gv; gv.p = (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
+        RUN(ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s));
+        return 0;
+    }
     RUN(ptta_launch_wgrad32(c->c2, c->dm_total, c->bf16, Nn, H4, W4, c->wgrad_part, c->gW, c->gB, s));
     return 0;
 }

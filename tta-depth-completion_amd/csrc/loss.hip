@@ -12,7 +12,7 @@
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
-#define LOSS_PB 128          // depth-reduction blocks per sample
+#define LOSS_PB 256          // depth-reduction blocks per sample (<= 256: one finalize thread each)
 #define LOSS_CB 1024         // cosine-reduction blocks
 #define WS_SCAL 0            // [0] coef_cos [1] coef_smx [2] coef_smy
 #define WS_SD 16             // per-sample w_sd / (N * sum_w)

@@ -63,15 +63,22 @@ __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, lon
 #define GX_STR16 80                                      // LDS bytes per pixel: hi 32 | lo 32 | pad 16
 // VERT: only the middle column of the 3x3 window (a 3x1x1 Conv3d viewed as a vertical 3-tap convolution over [D][H*W] images,
 // gnet.h Op::rH/rW): three taps, no horizontal halo -- a third of the MFMAs of the zero-padded 3x3 form it replaces.
-template <int KS, bool VERT>
+// TIMING: s_memtime stamps around the phases of one block's K loop, printed by two blocks of the launch (diagnostic builds of the
+// launcher select it with PTTA_S1_STAMPS=<grid size in blocks>; the shipped instantiation has no stamps)
+#define STAMP(v) do { if constexpr (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
+template <int KS, bool VERT, bool TIMING = false>
 __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
+    unsigned long long T0 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0;
+    unsigned long long dA = 0, dW = 0, dS = 0, dL = 0, dB = 0, dM = 0;
+    STAMP(T0);
     constexpr int PAD = KS / 2, PADX = VERT ? 0 : PAD, KKX = VERT ? 1 : KS, PH = GX_TH + 2 * PAD, PW = 32 + 2 * PADX, KK = KS * KKX;
     constexpr int NPIX = PH * PW;
     constexpr int NIT = (NPIX * 2 + 255) / 256;          // (pixel, 8-channel group) items per thread
     constexpr int NWF = KK * 64 * 2;                     // weight uint4 per sub-chunk: [hi | lo][tap][lane]
     constexpr int NW = (NWF + 255) / 256;
     constexpr int ACT = NPIX * GX_STR16;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[ACT + NWF * 16];
+    constexpr int LDSB = ACT + NWF * 16 > 32768 ? ACT + NWF * 16 : 32768;     // the epilogue stages 4 x 8 KB through it
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB + 1024];
     uint4* const wlds = (uint4*)(lds + ACT);
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
@@ -124,8 +131,13 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
         for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
 
     issue_loads(0);
+    unsigned long long Tpro = 0; STAMP(Tpro);
     for (int q = 0; q < nq; ++q) {
+        STAMP(ta);
         if (q) lds_barrier();                            // previous sub-chunk's MFMAs are done with the LDS tile
+        STAMP(tb);
+        if constexpr (TIMING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(tc);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
@@ -145,8 +157,11 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             const int idx = tid + 256 * j;
             if (idx < NWF) wlds[idx] = wr[j];
         }
+        STAMP(td);
         if (q + 1 < nq) issue_loads(q + 1);
+        STAMP(te);
         lds_barrier();                                   // LDS-only: the loads just issued stay in flight during the MFMAs
+        STAMP(tf);
         __builtin_amdgcn_s_setprio(1);                    // MFMA phase outranks the other blocks' staging code at issue
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
@@ -169,11 +184,63 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh, acc[1], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
+        STAMP(tg);
+        dA += tb - ta; dW += tc - tb; dS += td - tc; dL += te - td; dB += tf - te; dM += tg - tf;
     }
+    unsigned long long Tloop = 0; STAMP(Tloop);
     const int co = nf * 32 + i - p.nf0 * 32;          // channel inside the output view
     const bool cok = co < p.Cy;
     const float bias = (cok && p.bias) ? p.bias[co] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    auto activate = [&](float v) {
+        if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        return v;
+    };
+    // The accumulator layout (lane = channel, register = pixel) would store one dword per lane, 32 store instructions per wave, and
+    // the vector-memory instruction path is what this kernel is bound by (in-kernel stamps: the epilogue was 35-40 % of a wave's
+    // life).  Transposed through the wave's own 8 KB of the (now idle) tile buffers -- [row 2][pixel 32][channel 32] floats, written
+    // conflict-free one pixel per half-wave, read back as float4 -- every lane stores 16 B: 8 store instructions per wave, each
+    // covering eight pixels x 128 contiguous bytes.  Bias / activation / statistics stay in the register layout (per-lane channel);
+    // a launch that accumulates adds the old values as float4 after the transpose and activates there.
+    const bool wide = !(p.accumulate && p.stat_part) && !(p.ldy & 3) && !(p.Cy & 3) && !(((size_t)p.y) & 15);
+    if (wide) {
+        lds_barrier();                                    // every wave is done with the tile buffers
+        float* const tw = (float*)lds + wave * 2048;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const bool yok = y0 + 2 * wave + rr < H;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = acc_row(r, h);
+                float v = acc[rr][r] + bias;
+                if (!p.accumulate) {
+                    v = activate(v);
+                    if (yok && cok && x0 + px < W) { s1 += v; s2 += v * v; }
+                }
+                tw[(rr * 32 + px) * 32 + i] = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-local: a wave's LDS operations execute in order
+        const int c4 = (lane & 7) * 4, pl = lane >> 3;
+        const int cbase = nf * 32 - p.nf0 * 32 + c4;
+        if (cbase < p.Cy) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int rr = k >> 2, px = (k & 3) * 8 + pl;
+                const int y = y0 + 2 * wave + rr, x = x0 + px;
+                if (y >= H || x >= W) continue;
+                float4 v = *(const float4*)(tw + (rr * 32 + px) * 32 + c4);
+                float* dst = p.y + (((size_t)b * H + y) * W + x) * p.ldy + cbase;
+                if (p.accumulate) {
+                    const float4 o = *(const float4*)dst;
+                    v.x = activate(v.x + o.x); v.y = activate(v.y + o.y); v.z = activate(v.z + o.z); v.w = activate(v.w + o.w);
+                }
+                *(float4*)dst = v;
+            }
+        }
+    } else {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int y = y0 + 2 * wave + rr;
@@ -186,18 +253,16 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             float* dst = yrow + (size_t)x * p.ldy;
             float v = acc[rr][r] + bias;
             if (p.accumulate) v += *dst;
-            if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
-            else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
-            else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+            v = activate(v);
             *dst = v;
             s1 += v; s2 += v * v;
         }
     }
+    }
     if (p.stat_part) {
         // fused BatchNorm statistics of this tile: lane halves, then the four waves through LDS (fixed order)
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        lds_barrier();                                    // everyone is done with the tile buffers
-        float* red = (float*)lds;                         // [wave 4][2][32]
+        float* red = (float*)(lds + LDSB);                // [wave 4][2][32], its own 1 KB behind the tile buffers
         if (h == 0) { red[(wave * 2 + 0) * 32 + i] = s1; red[(wave * 2 + 1) * 32 + i] = s2; }
         lds_barrier();
         if (tid < 64 && (tid & 31) + nf * 32 - p.nf0 * 32 < p.Cy) {
@@ -208,6 +273,12 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             const long tiles_pp = (long)bpp * ntx * nty;
             p.stat_part[((pass * tiles_pp + tile) * 2 + which) * p.stat_C + (nf - p.nf0) * 32 + ch] = v;
         }
+    }
+    if constexpr (TIMING) {
+        unsigned long long Tend = 0; STAMP(Tend);
+        if ((blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x / 3) && lane == 0)
+            printf("blk %u/%u wave %d nq %d: life %llu pro %llu loop %llu epi %llu | barA %llu vmwait %llu split %llu issue %llu barB %llu mfma %llu\n", blockIdx.x, gridDim.x, wave, nq,
+                   Tend - T0, Tpro - T0, Tloop - Tpro, Tend - Tloop, dA, dW, dS, dL, dB, dM);
     }
 }
 
@@ -563,7 +634,9 @@ int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
     const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + GX_TH - 1) / GX_TH);
     const long blocks = tiles * a.nnf;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
+    static const int exp_t = getenv("PTTA_S1_STAMPS") ? atoi(getenv("PTTA_S1_STAMPS")) : 0;   // diagnostic: in-kernel phase stamps (tools/exp_s1_stamps.sh)
     if (ks == 3 && a.vert) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else if (ks == 3 && exp_t && blocks == exp_t) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else if (ks == 1) hipLaunchKernelGGL((gconv_x3_s1_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else return -22;

@@ -94,6 +94,30 @@ __device__ __forceinline__ void epi_store(const Epi<T>& e, int b, int y, int x, 
 
 __device__ const float kZeroBias[32] = {0.f};
 
+// 4x4 transposes inside the lane quads of a 32x32 MFMA accumulator (DPP quad_perm, no LDS): on entry lane (i, h) holds in t[4g + a]
+// row (a + 8g + 4h), column i; on return it holds in t[4g + c] row ((i & 3) + 8g + 4h), column 4 (i >> 2) + c -- four consecutive
+// columns per lane, one float4 per g, and the 64 lanes of one g cover eight consecutive rows x 32 columns (1 KB when the row is
+// a 32-channel fp32 pixel).  The accumulator layout itself would store one dword per lane: four times the vector-memory
+// instructions, which is what the conv / GEMM epilogues are bound by.
+__device__ __forceinline__ float quad_xchg(float v, bool xor2) {
+    const int s = __float_as_int(v);
+    return __int_as_float(xor2 ? __builtin_amdgcn_update_dpp(s, s, 0x4E, 0xF, 0xF, false)      // quad_perm [2,3,0,1]
+                               : __builtin_amdgcn_update_dpp(s, s, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ void quad_transpose(f32x16& t, int lane) {
+    const bool odd = lane & 1, up = lane & 2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float x0 = t[4 * g], x1 = t[4 * g + 1], x2 = t[4 * g + 2], x3 = t[4 * g + 3];
+        float r;
+        r = quad_xchg(odd ? x0 : x1, false); x0 = odd ? r : x0; x1 = odd ? x1 : r;
+        r = quad_xchg(odd ? x2 : x3, false); x2 = odd ? r : x2; x3 = odd ? x3 : r;
+        r = quad_xchg(up ? x0 : x2, true); x0 = up ? r : x0; x2 = up ? x2 : r;
+        r = quad_xchg(up ? x1 : x3, true); x1 = up ? r : x1; x3 = up ? x3 : r;
+        t[4 * g] = x0; t[4 * g + 1] = x1; t[4 * g + 2] = x2; t[4 * g + 3] = x3;
+    }
+}
+
 // Tile form of the epilogue for the MFMA kernels: lane = channel `ch`, the 16 accumulator registers
 // are 16 pixels of one output row.  UP / MASK / ADD are compile-time so that every auxiliary load
 // of the tile is unconditional and can be issued back to back (a runtime "pointer or nothing" test
@@ -130,6 +154,55 @@ __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, i
         }
     }
     const size_t rowoff = (size_t)y * W;
+    if constexpr (sizeof(T) == 4) {
+        // fp32 storage: mask / store / add / store as float4 in the transposed layout (same arithmetic per element, in the same order)
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = v[r];
+        quad_transpose(t, ch + 32 * h);
+        const int j4 = (ch >> 2) * 4;
+        bool okg[4];
+        size_t xq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int px = x0 + (ch & 3) + 8 * g + 4 * h;
+            okg[g] = px < Wt;
+            xq[g] = ((size_t)((okg[g] ? px : Wt - 1) * xstep + xoff) + rowoff) * 32 + j4;
+        }
+        // every auxiliary load of the row is issued before the first store (a store between them would order them)
+        float4 mk[4], t1[4], t2[4];
+        if (MASK) {
+            const float* mb = (const float*)e.mask + (size_t)(b % e.mask_nb) * H * W * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mk[g] = *(const float4*)(mb + xq[g]);
+        }
+        if (ADD) {
+            const float* a1 = (const float*)e.add1 + (size_t)(b % e.add1_nb) * H * W * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t1[g] = *(const float4*)(a1 + xq[g]);
+            if (e.add2) {
+                const float* a2 = (const float*)e.add2 + (size_t)(b % e.add2_nb) * H * W * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) t2[g] = *(const float4*)(a2 + xq[g]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { t1[g].x += t2[g].x; t1[g].y += t2[g].y; t1[g].z += t2[g].z; t1[g].w += t2[g].w; }
+            }
+        }
+        float* const oraw = (float*)e.out_raw + (size_t)b * H * W * 32;
+        float* const osum = (float*)e.out_sum + (size_t)b * H * W * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 val = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+            if (MASK) {
+                val.x = mk[g].x > 0.0f ? val.x : 0.0f; val.y = mk[g].y > 0.0f ? val.y : 0.0f;
+                val.z = mk[g].z > 0.0f ? val.z : 0.0f; val.w = mk[g].w > 0.0f ? val.w : 0.0f;
+            }
+            if (e.out_raw && okg[g]) *(float4*)(oraw + xq[g]) = val;
+            if (ADD) { val.x += t1[g].x; val.y += t1[g].y; val.z += t1[g].z; val.w += t1[g].w; }
+            if (e.out_sum && okg[g]) *(float4*)(osum + xq[g]) = val;
+        }
+        return;
+    }
     if (MASK) {
         const T* mrow = e.mask + ((size_t)(b % e.mask_nb) * H * W + rowoff) * 32 + ch;
         float m[16];

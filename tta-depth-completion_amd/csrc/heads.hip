@@ -266,26 +266,38 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
         if (EPI == 2) { esc = p.escale[col]; esh = p.eshift[col]; emu = p.emean[col]; eiv = p.einv[col]; }
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-            float hh[16];
+            // global accesses in the quad-transposed layout (16 B per lane), arithmetic in the accumulator layout (see the
+            // wave-specialised kernel below)
+            const int tq = (i & 3) + 4 * h, tc = n0 + (wn * TN + b) * 32 + 4 * (i >> 2);
+            const long arow = row0 + (wm * TM + a) * 32;
+            f32x16 hh;
             if (EPI == 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    long row = row0 + (wm * TM + a) * 32 + acc_row(r, h);
+                for (int g = 0; g < 4; ++g) {
+                    long row = arow + 8 * g + tq;
                     if (row >= p.R) row = p.R - 1;
-                    hh[r] = p.eH[row * p.N + col];
+                    const float4 q = *(const float4*)(p.eH + row * p.N + tc);
+                    hh[4 * g] = q.x; hh[4 * g + 1] = q.y; hh[4 * g + 2] = q.z; hh[4 * g + 3] = q.w;
                 }
+                quad_transpose(hh, lane);
             }
+            f32x16 t;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long row = row0 + (wm * TM + a) * 32 + acc_row(r, h);
-                if (row >= p.R) continue;
+                const long row = arow + acc_row(r, h);
                 float v = acc[a][b][r] + bias;
-                if (EPI == 1) { s1 += v; s2 += v * v; }
-                if (EPI == 2) {
-                    v = (fmaf(hh[r], esc, esh) > 0.f) ? v : 0.f;
-                    s1 += v; s2 += v * (hh[r] - emu) * eiv;
+                if (EPI == 2) v = (fmaf(hh[r], esc, esh) > 0.f) ? v : 0.f;
+                if (row < p.R) {
+                    if (EPI == 1) { s1 += v; s2 += v * v; }
+                    if (EPI == 2) { s1 += v; s2 += v * (hh[r] - emu) * eiv; }
                 }
-                p.C[row * p.N + col] = v;
+                t[r] = v;
+            }
+            quad_transpose(t, lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const long row = arow + 8 * g + tq;
+                if (row < p.R) *(float4*)(p.C + row * p.N + tc) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
             }
         }
         if (EPI != 0) {
@@ -439,8 +451,12 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
         constexpr int NC = 512;
         const bool full = row0 + BM <= p.R;
         const long wrow = row0 + wm * TM * 32;
-        float* const cw = p.C + wrow * NC + n0 + wn * TN * 32 + i;
-        const float* const hw = EPI == 2 ? p.eH + wrow * NC + n0 + wn * TN * 32 + i : nullptr;
+        // Global accesses run in the quad-transposed layout (ptta_common.h quad_transpose): 16 B per lane, four instructions per
+        // 32x32 accumulator instead of sixteen; bias, ReLU mask and the column statistics stay in the accumulator layout (lane =
+        // column), so the arithmetic and its order are unchanged.  The mask input eH is fetched as float4 and transposed back.
+        const int tq = (i & 3) + 4 * h, tc = 4 * (i >> 2);           // row offset within a group of eight, first of four columns
+        float* const cw = p.C + wrow * NC + n0 + wn * TN * 32 + tc;
+        const float* const hw = EPI == 2 ? p.eH + wrow * NC + n0 + wn * TN * 32 + tc : nullptr;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int cl = (wn * TN + b) * 32 + i;
@@ -451,14 +467,17 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
             if (EPI == 2) { esc = p.escale[col]; esh = p.eshift[col]; emu = p.emean[col]; eiv = p.einv[col]; }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                float hh[16];
+                f32x16 hh;
                 if (EPI == 2) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int lr = a * 32 + acc_row(r, h);
-                        hh[r] = (full || wrow + lr < p.R) ? hw[(long)lr * NC + b * 32] : 0.f;
+                    for (int g = 0; g < 4; ++g) {
+                        const int lr = a * 32 + 8 * g + tq;
+                        const float4 q = (full || wrow + lr < p.R) ? *(const float4*)(hw + (long)lr * NC + b * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        hh[4 * g] = q.x; hh[4 * g + 1] = q.y; hh[4 * g + 2] = q.z; hh[4 * g + 3] = q.w;
                     }
+                    quad_transpose(hh, lane);
                 }
+                f32x16 t;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int lr = a * 32 + acc_row(r, h);
@@ -468,8 +487,14 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                     if (ok) {
                         if (EPI == 1) { s1 += v; s2 += v * v; }
                         if (EPI == 2) { s1 += v; s2 += v * (hh[r] - emu) * eiv; }
-                        cw[(long)lr * NC + b * 32] = v;
                     }
+                    t[r] = v;
+                }
+                quad_transpose(t, lane);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int lr = a * 32 + 8 * g + tq;
+                    if (full || wrow + lr < p.R) *(float4*)(cw + (long)lr * NC + b * 32) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
                 }
             }
             if (EPI != 0) {

@@ -402,11 +402,52 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][rr][r] = (acc[t][rr][r] + red[0][t][rr][r][lane]) + (red[1][t][rr][r][lane] + red[2][t][rr][r][lane]);
     }
+    auto activate = [&](float v) {
+        if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
+        else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        return v;
+    };
+    const bool wide = !(p.ldy & 3) && !(p.Cy & 3) && !(((size_t)p.y) & 15);
 #pragma unroll
     for (int t = 0; t < NCO; ++t) {
     const int co = (nf + t) * 32 + i - p.nf0 * 32;
+    const float bias = (p.bias && co < p.Cy) ? p.bias[co] : 0.f;
+    if (wide) {
+        // 16 B per lane in the quad-transposed layout (ptta_common.h quad_transpose): a quarter of the store instructions
+        const int c4 = (nf + t) * 32 - p.nf0 * 32 + 4 * (i >> 2);
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int y = ybase + rr;
+            if (y >= Hout) break;
+            f32x16 tt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tt[r] = acc[t][rr][r] + bias;
+            quad_transpose(tt, lane);
+            float* yrow = p.y + ((size_t)b * Hout + y) * Wout * p.ldy + c4;
+            bool ok[4]; size_t xo[4]; float4 old[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int xl = x0 + (i & 3) + 8 * g + 4 * h;
+                const int x = MODE == 2 ? 2 * xl + xpar : xl;
+                ok[g] = c4 < p.Cy && xl < Wt && x < Wout;
+                xo[g] = (size_t)(ok[g] ? x : 0) * p.ldy;
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) old[g] = ok[g] ? *(const float4*)(yrow + xo[g]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = make_float4(tt[4 * g], tt[4 * g + 1], tt[4 * g + 2], tt[4 * g + 3]);
+                if (p.accumulate) { v.x += old[g].x; v.y += old[g].y; v.z += old[g].z; v.w += old[g].w; }
+                v.x = activate(v.x); v.y = activate(v.y); v.z = activate(v.z); v.w = activate(v.w);
+                if (ok[g]) *(float4*)(yrow + xo[g]) = v;
+            }
+        }
+        continue;
+    }
     if (co >= p.Cy) continue;
-    const float bias = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
     for (int rr = 0; rr < R; ++rr) {
         const int y = ybase + rr;
@@ -421,10 +462,7 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
             float* dst = yrow + (size_t)x * p.ldy;
             float v = acc[t][rr][r] + bias;
             if (p.accumulate) v += *dst;
-            if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
-            else if (p.act == GACT_LRELU) v = v > 0.f ? v : 0.2f * v;
-            else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-            *dst = v;
+            *dst = activate(v);
         }
     }
     }

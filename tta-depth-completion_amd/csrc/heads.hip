@@ -12,6 +12,7 @@
 // the backward the ReLU mask / BatchNorm-backward reductions are fused the same way.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -326,8 +327,11 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
 // blocks per CU: 85 / 92 / 95 us per 26752x512x512 GEMM; ablations (profiles/r02_gemm_ablation.txt): stores 20 us, loads 16 us,
 // MFMAs 16 us, everything else 34 us and nothing overlaps across the block's single K loop -> the shape is bound by
 // per-block latency chains, not by the matrix cores.
-template <int PRO, int EPI>
+#define GSTAMP(v) do { if (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
+template <int PRO, int EPI, bool TIMING = false>
 __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
+    unsigned long long T0 = 0, Ta = 0, Tb = 0, Tc = 0, Td = 0, dStore = 0, dLoad = 0, dBar = 0, dMfma = 0, Tloop = 0, Tend = 0;
+    GSTAMP(T0);
     constexpr int BM = 128, BN = 256, TM = 2, TN = 4;
     constexpr int STAGE = (2 * BM + 2 * BN) * X3_ROW;         // 61,440 B
     const GemmP& p = q.g;
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
     if (wave >= 4) {
         // ================= staging waves =================
         const int tid = threadIdx.x - 256;
-        struct Regs { float4 a[2][2]; uint4 bh[4], bl[4]; };          // one K slice in flight: [item][half], B hi / lo
+        struct Regs { float4 a[2][2]; uint4 bh[4], bl[4]; float4 sc[2], sh[2]; };   // one K slice in flight: [item][half], B hi / lo, prologue scale / shift
         Regs r0, r1;
         auto load_slice = [&](int sl, Regs& rr) {
             const int k0 = sl << 5;
@@ -355,6 +359,12 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 const float* src = (const float*)p.A + gr * p.K + k0 + 8 * (idx & 3);
                 rr.a[it][0] = *(const float4*)src; rr.a[it][1] = *(const float4*)(src + 4);
             }
+            if (PRO == 1) {     // fetched WITH the slice (both items of a thread share the 8 columns): a load inside store_slice is the
+                                // youngest one there and waiting for it (vmcnt(0)) drains the prefetch of the next slice as well
+                const int k = k0 + 8 * (tid & 3);
+                rr.sc[0] = *(const float4*)(p.pscale + k); rr.sc[1] = *(const float4*)(p.pscale + k + 4);
+                rr.sh[0] = *(const float4*)(p.pshift + k); rr.sh[1] = *(const float4*)(p.pshift + k + 4);
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = tid + 256 * it;
@@ -363,19 +373,16 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 rr.bl[it] = *(const uint4*)(q.Wil + off + 32);
             }
         };
-        auto store_slice = [&](int sl, const Regs& rr) {
-            unsigned char* const Ahi = sm + (sl & 1) * STAGE; unsigned char* const Alo = Ahi + BM * X3_ROW;
+        auto store_slice = [&](int stage, const Regs& rr) {
+            unsigned char* const Ahi = sm + stage * STAGE; unsigned char* const Alo = Ahi + BM * X3_ROW;
             unsigned char* const Bhi = Alo + BM * X3_ROW; unsigned char* const Blo = Bhi + BN * X3_ROW;
-            const int k0 = sl << 5;
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int idx = tid + 256 * it;
                 const int row = stage_row(idx), kq = idx & 3;
-                const int k = k0 + 8 * kq;
                 float v[8] = {rr.a[it][0].x, rr.a[it][0].y, rr.a[it][0].z, rr.a[it][0].w, rr.a[it][1].x, rr.a[it][1].y, rr.a[it][1].z, rr.a[it][1].w};
                 if (PRO == 1) {
-                    const float4 s0 = *(const float4*)(p.pscale + k), s1 = *(const float4*)(p.pscale + k + 4);
-                    const float4 t0 = *(const float4*)(p.pshift + k), t1 = *(const float4*)(p.pshift + k + 4);
+                    const float4 s0 = rr.sc[0], s1 = rr.sc[1], t0 = rr.sh[0], t1 = rr.sh[1];
                     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
@@ -394,20 +401,38 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 *(uint4*)(Blo + row * X3_ROW + 16 * kq) = rr.bl[it];
             }
         };
+        // Every load and every store below is UNCONDITIONAL (slice indices past the end are clamped to the last slice; the extra
+        // stores go to the stage nobody reads): with `if (sl + 3 < nslices) load_slice(...)` the compiler must pick one s_waitcnt
+        // immediate that is valid on both paths and falls back to vmcnt(0) at the top of every store_slice, which drained the
+        // prefetch of the following slice each time (in-kernel stamps: 70 % of the staging waves' loop was that wait).
+        const int last = nslices - 1;
         load_slice(0, r0);
-        if (nslices > 1) load_slice(1, r1);
+        load_slice(min(1, last), r1);
         store_slice(0, r0);
-        if (nslices > 2) load_slice(2, r0);
+        load_slice(min(2, last), r0);
         lds_barrier();                                              // slice 0 staged
-        for (int sl = 0; sl < nslices; sl += 2) {
-            // during the MFMAs of slice sl: stage slice sl+1 (registers ring 1), refill ring 1 with slice sl+3
-            if (sl + 1 < nslices) { store_slice(sl + 1, r1); if (sl + 3 < nslices) load_slice(sl + 3, r1); }
+        GSTAMP(Tloop);
+        for (int sl = 0; sl + 1 < nslices; sl += 2) {
+            // during the MFMAs of slice sl: stage slice sl+1 (ring 1), refill ring 1 with slice sl+3
+            GSTAMP(Ta);
+            store_slice(1, r1); GSTAMP(Tb); load_slice(min(sl + 3, last), r1);
+            GSTAMP(Tc);
             lds_barrier();
-            if (sl + 1 >= nslices) break;
+            GSTAMP(Td);
+            dStore += Tb - Ta; dLoad += Tc - Tb; dBar += Td - Tc;
             // during the MFMAs of slice sl+1: stage slice sl+2 (ring 0), refill ring 0 with slice sl+4
-            if (sl + 2 < nslices) { store_slice(sl + 2, r0); if (sl + 4 < nslices) load_slice(sl + 4, r0); }
+            GSTAMP(Ta);
+            store_slice(0, r0); GSTAMP(Tb); load_slice(min(sl + 4, last), r0);
+            GSTAMP(Tc);
             lds_barrier();
+            GSTAMP(Td);
+            dStore += Tb - Ta; dLoad += Tc - Tb; dBar += Td - Tc;
         }
+        if (nslices & 1) lds_barrier();                             // odd slice count: the last slice's hand-back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the clamped tail loads land before the registers die
+        GSTAMP(Tend);
+        if (TIMING && (blockIdx.y == 50 || blockIdx.y == 150) && blockIdx.x == 0 && lane == 0)
+            printf("stg blk %d wave %d: life %llu pro %llu loop %llu | store(+vmwait) %llu loadissue %llu barrier %llu\n", blockIdx.y, wave, Tend - T0, Tloop - T0, Tend - Tloop, dStore, dLoad, dBar);
     } else {
         // ================= MFMA waves =================
         const int wm = wave >> 1, wn = wave & 1;
@@ -419,7 +444,9 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
         lds_barrier();                                              // slice 0 staged
+        GSTAMP(Tloop);
         for (int sl = 0; sl < nslices; ++sl) {
+            GSTAMP(Ta);
             const unsigned char* Ahi = sm + (sl & 1) * STAGE; const unsigned char* Alo = Ahi + BM * X3_ROW;
             const unsigned char* Bhi = Alo + BM * X3_ROW; const unsigned char* Blo = Bhi + BN * X3_ROW;
 #pragma unroll
@@ -444,8 +471,12 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                     }
                 }
             }
+            GSTAMP(Tb);
             lds_barrier();          // hand the stage back; the other stage is complete
+            GSTAMP(Tc);
+            dMfma += Tb - Ta; dBar += Tc - Tb;
         }
+        GSTAMP(Td);
         // ---- epilogue (MFMA waves only): N = 512 is a compile-time row stride, one base pointer per wave, and a block that
         // lies fully inside the R rows (always, when R is a multiple of 128) stores without per-element bounds branches ----
         constexpr int NC = 512;
@@ -457,51 +488,74 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
         const int tq = (i & 3) + 4 * h, tc = 4 * (i >> 2);           // row offset within a group of eight, first of four columns
         float* const cw = p.C + wrow * NC + n0 + wn * TN * 32 + tc;
         const float* const hw = EPI == 2 ? p.eH + wrow * NC + n0 + wn * TN * 32 + tc : nullptr;
+        // per-column constants of all four column tiles are fetched before the first store, and a block that lies fully inside the
+        // R rows runs a branch-free body: a load behind a store (or any branch around either) makes the compiler wait vmcnt(0),
+        // i.e. for the stores of the previous tile to be acknowledged -- the epilogue was 25-30 % of an MFMA wave's life that way
+        float bias_[TN], esc_[TN], esh_[TN], emu_[TN], eiv_[TN];
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const int cl = (wn * TN + b) * 32 + i;
-            const int col = n0 + cl;
-            const float bias = p.bias ? p.bias[col] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-            float esc = 0.f, esh = 0.f, emu = 0.f, eiv = 0.f;
-            if (EPI == 2) { esc = p.escale[col]; esh = p.eshift[col]; emu = p.emean[col]; eiv = p.einv[col]; }
+            const int col = n0 + (wn * TN + b) * 32 + i;
+            bias_[b] = p.bias ? p.bias[col] : 0.f;
+            esc_[b] = esh_[b] = emu_[b] = eiv_[b] = 0.f;
+            if (EPI == 2) { esc_[b] = p.escale[col]; esh_[b] = p.eshift[col]; emu_[b] = p.emean[col]; eiv_[b] = p.einv[col]; }
+        }
+        auto load_h = [&](auto fullc, int ab, f32x16& hh) {
+            constexpr bool FULL = decltype(fullc)::value;
+            const int b = ab / TM, a = ab % TM;
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                f32x16 hh;
-                if (EPI == 2) {
+            for (int g = 0; g < 4; ++g) {
+                const int lr = a * 32 + 8 * g + tq;
+                const float4 q = (FULL || wrow + lr < p.R) ? *(const float4*)(hw + (long)lr * NC + b * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+                hh[4 * g] = q.x; hh[4 * g + 1] = q.y; hh[4 * g + 2] = q.z; hh[4 * g + 3] = q.w;
+            }
+        };
+        auto epilogue = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
+            f32x16 hnext;
+            if (EPI == 2) load_h(fullc, 0, hnext);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int cl = (wn * TN + b) * 32 + i;
+                const float bias = bias_[b], esc = esc_[b], esh = esh_[b], emu = emu_[b], eiv = eiv_[b];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    f32x16 hh;
+                    if (EPI == 2) {
+                        hh = hnext;
+                        if (b * TM + a + 1 < TN * TM) load_h(fullc, b * TM + a + 1, hnext);     // next tile's mask input ahead of this tile's stores
+                        quad_transpose(hh, lane);
+                    }
+                    f32x16 t;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lr = a * 32 + acc_row(r, h);
+                        const bool ok = FULL || wrow + lr < p.R;
+                        float v = acc[a][b][r] + bias;
+                        if (EPI == 2) v = (fmaf(hh[r], esc, esh) > 0.f) ? v : 0.f;
+                        if (ok) {
+                            if (EPI == 1) { s1 += v; s2 += v * v; }
+                            if (EPI == 2) { s1 += v; s2 += v * (hh[r] - emu) * eiv; }
+                        }
+                        t[r] = v;
+                    }
+                    quad_transpose(t, lane);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int lr = a * 32 + 8 * g + tq;
-                        const float4 q = (full || wrow + lr < p.R) ? *(const float4*)(hw + (long)lr * NC + b * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        hh[4 * g] = q.x; hh[4 * g + 1] = q.y; hh[4 * g + 2] = q.z; hh[4 * g + 3] = q.w;
+                        if (FULL || wrow + lr < p.R) *(float4*)(cw + (long)lr * NC + b * 32) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
                     }
-                    quad_transpose(hh, lane);
                 }
-                f32x16 t;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lr = a * 32 + acc_row(r, h);
-                    const bool ok = full || wrow + lr < p.R;
-                    float v = acc[a][b][r] + bias;
-                    if (EPI == 2) v = (fmaf(hh[r], esc, esh) > 0.f) ? v : 0.f;
-                    if (ok) {
-                        if (EPI == 1) { s1 += v; s2 += v * v; }
-                        if (EPI == 2) { s1 += v; s2 += v * (hh[r] - emu) * eiv; }
-                    }
-                    t[r] = v;
-                }
-                quad_transpose(t, lane);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int lr = a * 32 + 8 * g + tq;
-                    if (full || wrow + lr < p.R) *(float4*)(cw + (long)lr * NC + b * 32) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+                if (EPI != 0) {
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    if (h == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
                 }
             }
-            if (EPI != 0) {
-                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (h == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
-            }
-        }
+        };
+        if (full) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        GSTAMP(Tend);
+        if (TIMING && (blockIdx.y == 50 || blockIdx.y == 150) && blockIdx.x == 0 && lane == 0)
+            printf("mma blk %d wave %d: life %llu pro %llu loop %llu epi %llu | mfma %llu barrier %llu\n", blockIdx.y, wave, Tend - T0, Tloop - T0, Td - Tloop, Tend - Td, dMfma, dBar);
     }
     if (EPI != 0) {
         __syncthreads();
@@ -549,6 +603,8 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
         if (a.N == 512 && a.Wil && a.pro != 2) {
             dim3 grid(2, (a.R + 127) / 128);
 #define GS_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_ws_kernel<PRO, EPI>), grid, dim3(512), 0, s, q)
+            static const int stamps = getenv("PTTA_GEMM_STAMPS") ? atoi(getenv("PTTA_GEMM_STAMPS")) : 0;   // diagnostic: in-kernel phase stamps
+            if (stamps && key3 == 10) { hipLaunchKernelGGL((gemm_x3_ws_kernel<1, 0, true>), grid, dim3(512), 0, s, q); PTTA_CHECK_LAUNCH(); return 0; }
             switch (key3) {
                 case 0: GS_(0, 0); break; case 1: GS_(0, 1); break; case 2: GS_(0, 2); break;
                 case 10: GS_(1, 0); break; case 11: GS_(1, 1); break;

@@ -131,6 +131,10 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
         for (int r = 0; r < 16; ++r) acc[rr][r] = 0.f;
 
     issue_loads(0);
+    // fetched here, not in the epilogue: there its L2 round trip sat between the last MFMA and the first store (in-kernel stamps)
+    const int co = nf * 32 + i - p.nf0 * 32;          // channel inside the output view
+    const bool cok = co < p.Cy;
+    const float bias = (cok && p.bias) ? p.bias[co] : 0.f;
     unsigned long long Tpro = 0; STAMP(Tpro);
     for (int q = 0; q < nq; ++q) {
         STAMP(ta);
@@ -188,9 +192,6 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
         dA += tb - ta; dW += tc - tb; dS += td - tc; dL += te - td; dB += tf - te; dM += tg - tf;
     }
     unsigned long long Tloop = 0; STAMP(Tloop);
-    const int co = nf * 32 + i - p.nf0 * 32;          // channel inside the output view
-    const bool cok = co < p.Cy;
-    const float bias = (cok && p.bias) ? p.bias[co] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     auto activate = [&](float v) {
         if (p.act == GACT_RELU) v = v > 0.f ? v : 0.f;
@@ -198,31 +199,49 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
         else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
         return v;
     };
+    // selects only (the compiler if-converts `activate` and then evaluates expf and the division for every element of every launch:
+    // 6k of a wave's 36k cycles by the in-kernel stamps); the sigmoid (one layer of the network) runs in its own uniform branch
+    auto activate_cheap = [&](float v) {
+        const float neg = p.act == GACT_LRELU ? 0.2f * v : (p.act == GACT_RELU ? 0.f : v);
+        return v > 0.f ? v : neg;
+    };
     // The accumulator layout (lane = channel, register = pixel) would store one dword per lane, 32 store instructions per wave, and
     // the vector-memory instruction path is what this kernel is bound by (in-kernel stamps: the epilogue was 35-40 % of a wave's
     // life).  Transposed through the wave's own 8 KB of the (now idle) tile buffers -- [row 2][pixel 32][channel 32] floats, written
     // conflict-free one pixel per half-wave, read back as float4 -- every lane stores 16 B: 8 store instructions per wave, each
     // covering eight pixels x 128 contiguous bytes.  Bias / activation / statistics stay in the register layout (per-lane channel);
     // a launch that accumulates adds the old values as float4 after the transpose and activates there.
-    const bool wide = !(p.accumulate && p.stat_part) && !(p.ldy & 3) && !(p.Cy & 3) && !(((size_t)p.y) & 15);
+    const bool sig = p.act == GACT_SIGMOID;
+    const bool wide = !(p.accumulate && (p.stat_part || sig)) && !(p.ldy & 3) && !(p.Cy & 3) && !(((size_t)p.y) & 15);
+    unsigned long long E1 = 0, E2 = 0, E3 = 0;
     if (wide) {
         lds_barrier();                                    // every wave is done with the tile buffers
+        STAMP(E1);
         float* const tw = (float*)lds + wave * 2048;
+        float bias_w = bias;
+        if (sig) {                                        // uniform
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rr][r] = 1.f / (1.f + expf(-(acc[rr][r] + bias)));
+            bias_w = 0.f;
+        }
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const bool yok = y0 + 2 * wave + rr < H;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int px = acc_row(r, h);
-                float v = acc[rr][r] + bias;
+                float v = sig ? acc[rr][r] : acc[rr][r] + bias_w;
                 if (!p.accumulate) {
-                    v = activate(v);
+                    v = sig ? v : activate_cheap(v);
                     if (yok && cok && x0 + px < W) { s1 += v; s2 += v * v; }
                 }
                 tw[(rr * 32 + px) * 32 + i] = v;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // wave-local: a wave's LDS operations execute in order
+        STAMP(E2);
         const int c4 = (lane & 7) * 4, pl = lane >> 3;
         const int cbase = nf * 32 - p.nf0 * 32 + c4;
         if (cbase < p.Cy) {
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
                 float* dst = p.y + (((size_t)b * H + y) * W + x) * p.ldy + cbase;
                 if (p.accumulate) {
                     const float4 o = *(const float4*)dst;
-                    v.x = activate(v.x + o.x); v.y = activate(v.y + o.y); v.z = activate(v.z + o.z); v.w = activate(v.w + o.w);
+                    v.x = activate_cheap(v.x + o.x); v.y = activate_cheap(v.y + o.y); v.z = activate_cheap(v.z + o.z); v.w = activate_cheap(v.w + o.w);
                 }
                 *(float4*)dst = v;
             }
@@ -259,6 +278,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
         }
     }
     }
+    STAMP(E3);
     if (p.stat_part) {
         // fused BatchNorm statistics of this tile: lane halves, then the four waves through LDS (fixed order)
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
@@ -277,8 +297,8 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
     if constexpr (TIMING) {
         unsigned long long Tend = 0; STAMP(Tend);
         if ((blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x / 3) && lane == 0)
-            printf("blk %u/%u wave %d nq %d: life %llu pro %llu loop %llu epi %llu | barA %llu vmwait %llu split %llu issue %llu barB %llu mfma %llu\n", blockIdx.x, gridDim.x, wave, nq,
-                   Tend - T0, Tpro - T0, Tloop - Tpro, Tend - Tloop, dA, dW, dS, dL, dB, dM);
+            printf("blk %u/%u wave %d nq %d: life %llu pro %llu loop %llu epi %llu (barrier %llu transpose-write %llu read+store %llu stats %llu) | barA %llu vmwait %llu split %llu issue %llu barB %llu mfma %llu\n", blockIdx.x, gridDim.x, wave, nq,
+                   Tend - T0, Tpro - T0, Tloop - Tpro, Tend - Tloop, E1 - Tloop, E2 - E1, E3 - E2, Tend - E3, dA, dW, dS, dL, dB, dM);
     }
 }
 
@@ -408,7 +428,11 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
         else if (p.act == GACT_SIGMOID) v = 1.f / (1.f + expf(-v));
         return v;
     };
-    const bool wide = !(p.ldy & 3) && !(p.Cy & 3) && !(((size_t)p.y) & 15);
+    auto activate_cheap = [&](float v) {                 // selects only; the sigmoid takes the scalar path below
+        const float neg = p.act == GACT_LRELU ? 0.2f * v : (p.act == GACT_RELU ? 0.f : v);
+        return v > 0.f ? v : neg;
+    };
+    const bool wide = p.act != GACT_SIGMOID && !(p.ldy & 3) && !(p.Cy & 3) && !(((size_t)p.y) & 15);
 #pragma unroll
     for (int t = 0; t < NCO; ++t) {
     const int co = (nf + t) * 32 + i - p.nf0 * 32;
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
             for (int g = 0; g < 4; ++g) {
                 float4 v = make_float4(tt[4 * g], tt[4 * g + 1], tt[4 * g + 2], tt[4 * g + 3]);
                 if (p.accumulate) { v.x += old[g].x; v.y += old[g].y; v.z += old[g].z; v.w += old[g].w; }
-                v.x = activate(v.x); v.y = activate(v.y); v.z = activate(v.z); v.w = activate(v.w);
+                v.x = activate_cheap(v.x); v.y = activate_cheap(v.y); v.z = activate_cheap(v.z); v.w = activate_cheap(v.w);
                 if (ok[g]) *(float4*)(yrow + xo[g]) = v;
             }
         }

@@ -173,8 +173,11 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 // at the 144-B stride their hi/lo footprints then fall on disjoint banks
 __device__ __forceinline__ int x3_stage_pix(int idx) { return ((idx >> 5) << 3) + (((idx >> 2) & 1) << 2) + ((idx >> 3) & 3); }
 
-template <bool RELU, bool UP, bool MASK, bool ADD>
+#define CSTAMP(v) do { if (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
+template <bool RELU, bool UP, bool MASK, bool ADD, bool TIMING = false>
 __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) {
+    unsigned long long T0 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0, dW = 0, dS = 0, dI = 0, dB1 = 0, dM = 0, dE = 0, dB2 = 0, Tpro = 0; int ntl = 0;
+    CSTAMP(T0);
     // one LDS array: [halo tile | lo weight fragments | (UP) half-resolution source window of the bilinear skip]
     constexpr int UPH = 6, UPW = 18;                      // an 8x32 output tile reads <= 5x17 source pixels
     __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * X3_STRIDE + 18 * 64 * 16 + (UP ? UPH * UPW * 128 : 0)];
@@ -217,7 +220,9 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
             }
         }
     };
+    unsigned long long P1 = 0, P2 = 0, F1 = 0;
     if (PREFETCH && blockIdx.x < ntiles) issue_loads(blockIdx.x);
+    CSTAMP(P1);
     // hi weight fragments stay in registers (72 VGPRs), lo fragments in LDS (read once per use).  Loaded AFTER the
     // first tile's loads were issued so that the two L2 round trips overlap (the small low-resolution launches are
     // one tile per block: their duration is this latency chain).
@@ -229,13 +234,18 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+        CSTAMP(P2);
         for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
     }
 
+    CSTAMP(Tpro);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
         if (!PREFETCH) issue_loads(tile);
+        CSTAMP(ta);
+        if (TIMING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CSTAMP(tb);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
@@ -251,7 +261,9 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
                 *(uint4*)(dst + 64) = lo;
             }
         }
+        CSTAMP(tc);
         if (PREFETCH && tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x);
+        CSTAMP(td);
         // bilinear x2 skip: stage the source window once per tile as whole 128-B lines (clamped at the
         // borders; only indices the lerp actually produces are ever read back)
         int uy0 = 0, ux0 = 0;
@@ -267,9 +279,11 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
             }
         }
         lds_barrier();          // LDS-only: the next tile's global loads (issued above) stay in flight during the MFMAs
+        CSTAMP(te);
         // ---- two output rows per wave ------------------------------------------------------------
 #pragma unroll 1
         for (int rr = 0; rr < 2; ++rr) {
+            unsigned long long m0 = 0, m1 = 0, m2 = 0; CSTAMP(m0);
             const int row = 2 * wave + rr;
             const int y = y0 + row;
             if (y >= H) break;                                      // wave-uniform
@@ -292,6 +306,8 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
                 }
                 if (kx == 2) __builtin_amdgcn_sched_barrier(0);      // bound the ds_read prefetch depth (VGPR pressure)
             }
+            if (TIMING) { float sink = acc[0]; asm volatile("v_mov_b32 %0, %0" : "+v"(sink) :: "memory"); acc[0] = sink; }   // MFMA results landed
+            CSTAMP(m1);
             if (UP) {
                 // (conv + bias) + bilinear, in the reference's order; the skip comes from LDS (lane = channel:
                 // consecutive banks), then the generic epilogue runs without bias / gather
@@ -311,8 +327,20 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
             } else {
                 epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
             }
+            CSTAMP(m2);
+            dM += m1 - m0; dE += m2 - m1;
         }
+        CSTAMP(tf);
         lds_barrier();          // LDS reuse only: do not wait for this tile's stores (nor the prefetch) to drain
+        CSTAMP(tg);
+        dW += tb - ta; dS += tc - tb; dI += td - tc; dB1 += te - td; dB2 += tg - tf; ++ntl;
+        if (ntl == 1) F1 = tg - ta;
+    }
+    if (TIMING) {
+        unsigned long long Tend = 0; CSTAMP(Tend);
+        if ((blockIdx.x == 100 || blockIdx.x == 300) && lane == 0)
+            printf("blk %u wave %d tiles %d: life %llu pro %llu (issue0 %llu whloads %llu wl->lds %llu) first tile %llu | per tile: vmwait %llu split+write %llu issue %llu barrier1 %llu mfma %llu epilogue %llu barrier2 %llu\n", blockIdx.x, wave, ntl,
+                   Tend - T0, Tpro - T0, P1 - T0, P2 - P1, Tpro - P2, F1, dW / ntl, dS / ntl, dI / ntl, dB1 / ntl, dM / ntl, dE / ntl, dB2 / ntl);
     }
 }
 
@@ -494,6 +522,14 @@ static void launch_mfma(const Conv32P<T>& p, int flags, int blocks, hipStream_t 
 }
 template <bool RELU>
 static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_t s) {
+    static const int stamps = getenv("PTTA_S1_STAMPS") ? atoi(getenv("PTTA_S1_STAMPS")) : 0;      // diagnostic (tools/exp_c32_stamps.sh)
+    if (stamps && blocks == 512 && flags == stamps - 1) {
+        if (flags == 0) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, false, true>), dim3(blocks), dim3(256), 0, s, p);
+        else if (flags == 2) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p);
+        else if (flags == 1) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, true, false, false, true>), dim3(blocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, true, true>), dim3(blocks), dim3(256), 0, s, p);
+        return;
+    }
 #define K_(U, M, A) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
     switch (flags) {
         case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;

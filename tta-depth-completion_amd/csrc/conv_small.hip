@@ -337,6 +337,85 @@ __global__ __launch_bounds__(256) void conv_out1_kernel(const T* __restrict__ in
     }
 }
 
+// LDS-staged form for fp32 storage (the shipped one): a block owns an 8 x 32 output tile and stages its (8+2) x (32+2) x 32-channel
+// window ONCE as whole 128-B pixel lines (zero padding and the input ReLU applied while staging), so every input pixel crosses the
+// vector-memory path 1.33 times instead of the 4.5 times of the strip kernel above (18 float4 loads per lane and 4 x 8 outputs).
+// Same lane roles (8 lanes per pixel, 4 channels each), same tap order and the same xor-shuffle reduction: bit-identical sums.
+// The 32 results of an output row are collected into one half-wave (lane quad index = pass) and leave as ONE 128-B store.
+template <bool RELU>
+__global__ __launch_bounds__(256) void conv_out1_lds_kernel(const float* __restrict__ in, int in_nb, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ add,
+                                                            int add_nb, float* __restrict__ out, int B, int H, int W) {
+    constexpr int TH = 8, PW = 34, PH = TH + 2, NV = PH * PW * 8, NIT = (NV + 255) / 256;
+    __shared__ float4 tile[NV];
+    const int tid = threadIdx.x, lane = tid & 63, pl = lane >> 3, cq = lane & 7;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    float4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = *(const float4*)(w + t * 32 + 4 * cq);
+    const float b0 = bias ? bias[0] : 0.f;
+    const int ntx = (W + 31) >> 5, nty = (H + TH - 1) / TH;
+    const long ntiles = (long)B * ntx * nty;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        long t_ = t;
+        const int ty = (int)(t_ % nty); t_ /= nty;
+        const int tx = (int)(t_ % ntx);
+        const int b = (int)(t_ / ntx);
+        const int y0 = ty * TH, x0 = tx << 5;
+        const float* inb = in + (size_t)(b % in_nb) * H * W * 32;
+        // all loads of the window first (unconditional, clamped), zero padding / ReLU afterwards
+        float4 v[NIT];
+        unsigned okm = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = min(tid + 256 * it, NV - 1);
+            const int q = idx & 7, pix = idx >> 3;
+            const int py = pix / PW, px = pix - py * PW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            okm |= (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (1u << it) : 0u;
+            v[it] = *(const float4*)(inb + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 32 + 4 * q);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            float4 a = v[it];
+            if (!((okm >> it) & 1u)) a = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (RELU) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            if (idx < NV) tile[idx] = a;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr, y = y0 + row;
+            const int xs = x0 + cq * 8 + pl;                  // the pixel this lane stores (lanes with cq < 4)
+            const bool sok = cq < 4 && y < H && xs < W;
+            const size_t o = (size_t)min(y, H - 1) * W + min(xs, W - 1);
+            float addv = 0.f;
+            if (add) addv = add[(size_t)(b % add_nb) * H * W + o];
+            float res = 0.f;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const float4* base = tile + (row * PW + pass * 8 + pl) * 8 + cq;
+                float acc = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float4 a = base[((tap / 3) * PW + tap % 3) * 8];
+                    acc = fmaf(a.x, wt[tap].x, acc); acc = fmaf(a.y, wt[tap].y, acc);
+                    acc = fmaf(a.z, wt[tap].z, acc); acc = fmaf(a.w, wt[tap].w, acc);
+                }
+                acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+                res = cq == pass ? acc : res;
+            }
+            if (sok) {
+                float r = res + b0;
+                if (add) r += addv;
+                out[(size_t)b * H * W + o] = r;
+            }
+        }
+        lds_barrier();
+    }
+}
+
 __global__ void pack_conv_out1_kernel(const float* __restrict__ src, int cin_total, int cin_index, int from_conv_in, float* w) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= 288) return;
@@ -354,8 +433,15 @@ int ptta_launch_conv_out1(const ConvOut1Args& a, hipStream_t s) {
     const int add_nb = a.add_nb > 0 ? a.add_nb : 1;
 #define LAUNCH_(T, R) hipLaunchKernelGGL((conv_out1_kernel<T, R>), dim3(blocks), dim3(256), 0, s, (const T*)a.in, a.in_nb, \
                                          a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W)
+    static const int strip = getenv("PTTA_OUT1_STRIP") ? atoi(getenv("PTTA_OUT1_STRIP")) : 0;      // A/B switch: the strip kernel for fp32 too
     if (a.bf16) { if (a.relu_in) LAUNCH_(bf16_t, true); else LAUNCH_(bf16_t, false); }
-    else { if (a.relu_in) LAUNCH_(float, true); else LAUNCH_(float, false); }
+    else if (strip) { if (a.relu_in) LAUNCH_(float, true); else LAUNCH_(float, false); }
+    else {
+        const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8);
+        const int tb = (int)(tiles < 768 ? tiles : 768);                                            // three 43.5-KB blocks per CU
+        if (a.relu_in) hipLaunchKernelGGL((conv_out1_lds_kernel<true>), dim3(tb), dim3(256), 0, s, (const float*)a.in, a.in_nb, a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W);
+        else hipLaunchKernelGGL((conv_out1_lds_kernel<false>), dim3(tb), dim3(256), 0, s, (const float*)a.in, a.in_nb, a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W);
+    }
 #undef LAUNCH_
     PTTA_CHECK_LAUNCH();
     return 0;

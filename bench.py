@@ -138,6 +138,43 @@ def nlspn_cpu_baseline(inner_iter=3):
             'sample': '1 TTA step of the same 352x1216 workload after one eval forward (PyTorch-CPU oracle, fp32, %.1f s/step; %d steps/frame)' % (dt, inner_iter)}
 
 
+def two_streams_workload(steps=100, nstreams=2):
+    """Beside the metric, never `value`: the config-4 sharding (independent frame streams, each with its own adapted parameters and
+    Adam state) applied INSIDE one GPU -- two handles, two hipGraphs, two HIP streams.  What the second stream gains is the share of
+    the single-stream step that is latency (small launches, serial chains), not bandwidth."""
+    from proxytta import synth
+    from proxytta.engine import Engine
+    engs, keep = [], []
+    for _ in range(nstreams):
+        eng = Engine(1, H, W, dtype='fp32', **HP)
+        sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
+        eng.load_state_dict(sd)
+        for name in eng.adapted:
+            keep.append((sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name])))
+            eng.bind_adapted(name, *keep[-1])
+        engs.append(eng)
+    streams = [torch.cuda.Stream() for _ in range(nstreams)]
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(900 + i, H, W, 1)] for i in range(4)]
+
+    def run(k):
+        for it in range(k):
+            for e, st in zip(engs, streams):
+                with torch.cuda.stream(st):
+                    info, _ = e.step(*frames[it % 4])
+        return info
+    run(10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    info = run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {'workload': '%d independent MSG_CHN 1layer frame streams on one GPU (own parameters / Adam state / hipGraph each), 352x1216, batch 1' % nstreams,
+           'frames_per_s': steps * nstreams / dt, 'ms_per_frame': 1e3 * dt / (steps * nstreams), 'finite': bool(torch.isfinite(info).all().item())}
+    for e in engs:
+        e.close()
+    return out
+
+
 def nlspn_workload(frames=3, inner_iter=3):
     """BASELINE config 3 (not the headline metric): NLSPN backbone, 352x1216, 3 TTA steps per frame + the scored eval
     forward, adapt_mode meta_bn (88 adapted tensors), batch 1, inputs resident in HBM.  Reported beside the metric."""
@@ -535,7 +572,7 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_nlspn:
             out['other_workloads'] = {'msg_chn_2layers': msgchn_2layers_workload(), 'nlspn': nlspn_workload(), 'costdcnet': costdcnet_workload(),
-                                      'head_stage2': head_stage2_workload()}
+                                      'head_stage2': head_stage2_workload(), 'msg_chn_two_streams_per_gpu': two_streams_workload()}
             if not args.no_cpu_baseline:
                 out['other_workloads']['nlspn']['cpu_baseline'] = nlspn_cpu_baseline()
                 out['other_workloads']['costdcnet']['cpu_baseline'] = costdcnet_cpu_baseline()

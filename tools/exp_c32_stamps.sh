@@ -1,6 +1,6 @@
 #!/bin/bash
 # in-kernel s_memtime stamps of the MSG_CHN stride-1 conv (TIMING variant): PTTA_S1_STAMPS = 1 + flags (1 plain, 2 bilinear skip, 3 mask, 5 add),
-# full-resolution launches (512 blocks) only
+# PTTA_S1_STAMPS_BLOCKS selects the launch size (default 512 = full resolution; 418 / 220 / 110 = the 1/2, 1/4, 1/8 maps)
 cd $GRAFT_REPO_ROOT
 for F in "$@"; do
   echo "== flags $((F-1))"

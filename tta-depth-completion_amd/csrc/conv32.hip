@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     }
     if (TIMING) {
         unsigned long long Tend = 0; CSTAMP(Tend);
-        if ((blockIdx.x == 100 || blockIdx.x == 300) && lane == 0)
+        if ((blockIdx.x == gridDim.x / 5 || blockIdx.x == (3 * gridDim.x) / 5) && lane == 0)
             printf("blk %u wave %d tiles %d: life %llu pro %llu (issue0 %llu whloads %llu wl->lds %llu) first tile %llu | per tile: vmwait %llu split+write %llu issue %llu barrier1 %llu mfma %llu epilogue %llu barrier2 %llu\n", blockIdx.x, wave, ntl,
                    Tend - T0, Tpro - T0, P1 - T0, P2 - P1, Tpro - P2, F1, dW / ntl, dS / ntl, dI / ntl, dB1 / ntl, dM / ntl, dE / ntl, dB2 / ntl);
     }
@@ -523,7 +523,8 @@ static void launch_mfma(const Conv32P<T>& p, int flags, int blocks, hipStream_t 
 template <bool RELU>
 static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_t s) {
     static const int stamps = getenv("PTTA_S1_STAMPS") ? atoi(getenv("PTTA_S1_STAMPS")) : 0;      // diagnostic (tools/exp_c32_stamps.sh)
-    if (stamps && blocks == 512 && flags == stamps - 1) {
+    static const int stamp_blocks = getenv("PTTA_S1_STAMPS_BLOCKS") ? atoi(getenv("PTTA_S1_STAMPS_BLOCKS")) : 512;
+    if (stamps && blocks == stamp_blocks && flags == stamps - 1) {
         if (flags == 0) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, false, true>), dim3(blocks), dim3(256), 0, s, p);
         else if (flags == 2) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p);
         else if (flags == 1) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, true, false, false, true>), dim3(blocks), dim3(256), 0, s, p);

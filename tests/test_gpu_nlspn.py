@@ -311,7 +311,9 @@ def test_shared_parameter_step_nlspn():
     assert torch.allclose(info1, info2, rtol=1e-5)
     assert e2.adam_step_count() == 1
     for k in ad1:
-        assert rel_mae(ad2[k][0], ad1[k][0]) < 1e-5, k
+        # two FUSED steps on identical engines already differ by 0.4e-5 .. 2.6e-5 on conv5.0.bn1.bias (tools/exp_nlspn_noise.py:
+        # the propagation gradient's float atomics + Adam's sign-like first step), so 1e-5 was inside the run-to-run noise
+        assert rel_mae(ad2[k][0], ad1[k][0]) < 1e-4, k
     e1.close(); e2.close()
 
 

@@ -562,10 +562,11 @@ __device__ __forceinline__ void wsplit8(const float* v, uint4& hi, uint4& lo) {
     gsplit2(v[4], v[5], hi.z, lo.z); gsplit2(v[6], v[7], hi.w, lo.w);
 }
 // single = 1 (Ci, Co <= 32): one tile pair; the four waves take different items instead and write a partial each.
-__global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int nitems_x, int single, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int nitems_x, int single, int ncib, float* __restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, hg = lane >> 5;
-    const int cob = single ? 0 : wave >> 1, cib = single ? 0 : wave & 1;
+    // the four waves of a block = the four (ci tile, co tile) pairs: 2 x 2 (<= 64 x 64 channels), 1 x 4 (32 -> 128) or 4 x 1 (128 -> 32)
+    const int cob = single ? 0 : wave / ncib, cib = single ? 0 : wave % ncib;
     const int H = x.H, W = x.W;
     const int co = cob * 32 + c, ci = cib * 32 + c;
     const bool cov = co < gy.C, civ = ci < x.C;
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int n
         mma(r1);
         item = n2;
     }
-    float* out = part + ((long)blockIdx.x * 4 + wave) * GWG_PART;      // pair index = cob * 2 + cib = wave (ncib = 2); single: chunk index
+    float* out = part + ((long)blockIdx.x * 4 + wave) * GWG_PART;      // pair index = cob * ncib + cib = wave; single: chunk index
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -738,18 +739,21 @@ long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co) {
     return a > b ? a : b;
 }
 int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s) {
-    if (x.C <= 64 && gy.C <= 64 && x.C > 16) {
-        // bf16x3 form: blocks of four waves; > 32 channels: partials [block][4 pairs] (the reducer sees ncib = 2, ncob = 2);
-        // <= 32 channels: one pair, the waves split the items, partials [block * 4 + wave]
+    const bool sq = x.C <= 64 && gy.C <= 64, wide_out = x.C <= 32 && gy.C <= 128, wide_in = x.C <= 128 && gy.C <= 32;
+    if ((sq || wide_out || wide_in) && x.C > 16) {
+        // bf16x3 form: blocks of four waves = four 32x32 channel-tile pairs (2 x 2, or 1 x 4 / 4 x 1 for the 32 <-> 128 layers of the
+        // 2layers meta block), partials [block][4 pairs]; <= 32 x 32 channels: one pair, the waves split the items, partials
+        // [block * 4 + wave]
         const int nx = (x.W + 15) / 16;
         const long nitems = (long)x.B * x.H * nx;
         const int single = (x.C <= 32 && gy.C <= 32) ? 1 : 0;
+        const int kcib = sq ? 2 : (wide_out ? 1 : 4);
         const long cap = single ? 64 : 256;
         const int nblk = (int)(nitems < cap ? nitems : cap);
-        hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, part);
+        hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
         const long n = 9L * x.C * gy.C + gy.C;
         if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb);
-        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk, 4, 2, x.C, gy.C, gw, gb);
+        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk, 4, kcib, x.C, gy.C, gw, gb);
         PTTA_CHECK_LAUNCH();
         return 0;
     }

@@ -656,22 +656,38 @@ __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int n
 }
 
 // one wave per output element group: 64 lanes sum the chunk partials of one (tap, co, ci) in a fixed order
+// Fixed-order second stage.  A block owns 64 consecutive elements; thread (e = tid & 63, g = tid >> 6) sums the chunks g, g+4, ... of
+// its element in fp64 -- the 64 lanes of a wave read 64 consecutive floats of one partial tile (ci is the fastest index of both the
+// element order and the tile), where the wave-per-element form touched 64 different cache lines per load -- and the four group sums
+// are combined in a fixed order through LDS.
 __global__ __launch_bounds__(256) void gwgrad_mfma_reduce_kernel(const float* __restrict__ part, int nchunks, int npairs, int ncib, int Ci, int Co,
                                                                  float* __restrict__ gw, float* __restrict__ gb) {
-    const int lane = threadIdx.x & 63;
-    const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ double red[4][64];
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + el;
     const long nw = 9L * Co * Ci;
-    if (e >= nw + Co) return;
-    int tap = 0, co, ci = 0;
-    if (e < nw) { tap = (int)(e / ((long)Co * Ci)); const int r = (int)(e % ((long)Co * Ci)); co = r / Ci; ci = r % Ci; }
-    else co = (int)(e - nw);
+    const bool live = e < nw + Co;
+    int tap = 0, co = 0, ci = 0;
+    if (live) {
+        if (e < nw) { tap = (int)(e / ((long)Co * Ci)); const int r = (int)(e % ((long)Co * Ci)); co = r / Ci; ci = r % Ci; }
+        else co = (int)(e - nw);
+    }
     const int pair = (co >> 5) * ncib + (e < nw ? (ci >> 5) : 0);
     const long off = e < nw ? ((long)tap * 32 + (co & 31)) * 32 + (ci & 31) : 9 * 1024 + (co & 31);
     double s = 0.0;
-    for (int k = lane; k < nchunks; k += 64) s += (double)part[((long)k * npairs + pair) * GWG_PART + off];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-    if (lane) return;
+    if (live) {
+        int k = g;
+        for (; k + 12 < nchunks; k += 16) {                 // four independent loads in flight
+            const float a0 = part[((long)k * npairs + pair) * GWG_PART + off], a1 = part[((long)(k + 4) * npairs + pair) * GWG_PART + off];
+            const float a2 = part[((long)(k + 8) * npairs + pair) * GWG_PART + off], a3 = part[((long)(k + 12) * npairs + pair) * GWG_PART + off];
+            s += (double)a0; s += (double)a1; s += (double)a2; s += (double)a3;
+        }
+        for (; k < nchunks; k += 4) s += (double)part[((long)k * npairs + pair) * GWG_PART + off];
+    }
+    red[g][el] = s;
+    __syncthreads();
+    if (g || !live) return;
+    s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
     if (e < nw) gw[((long)co * Ci + ci) * 9 + tap] = (float)s;
     else if (gb) gb[co] = (float)s;
 }
@@ -752,8 +768,8 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
         const int nblk = (int)(nitems < cap ? nitems : cap);
         hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
         const long n = 9L * x.C * gy.C + gy.C;
-        if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb);
-        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblk, 4, kcib, x.C, gy.C, gw, gb);
+        if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb);
+        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nblk, 4, kcib, x.C, gy.C, gw, gb);
         PTTA_CHECK_LAUNCH();
         return 0;
     }
@@ -761,7 +777,7 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
     const int ncib = (x.C + 31) / 32, ncob = (gy.C + 31) / 32, npairs = ncib * ncob;
     hipLaunchKernelGGL(gwgrad_mfma_kernel, dim3(nchunks, npairs), dim3(64), 0, s, x, gy, nchunks, ncib, part);
     const long n = 9L * x.C * gy.C + gy.C;
-    hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nchunks, npairs, ncib, x.C, gy.C, gw, gb);
+    hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nchunks, npairs, ncib, x.C, gy.C, gw, gb);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

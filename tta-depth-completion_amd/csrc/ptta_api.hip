@@ -789,12 +789,11 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     RUN(ptta_launch_gemm(g, s));
     RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
     RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
-    GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = c->g_feat_f32; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;
+    GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = c->bf16 ? c->g_feat_f32 : (float*)c->g_feat; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;   // fp32 storage: straight into the gradient map (no copy launch)
     g2.pscale = c->bnb_gscale; g2.pmean = bn.mean; g2.pinv = bn.inv; g2.pc1 = c->bnb_c1; g2.pc2 = c->bnb_c2;
     g2.x3 = c->x3; g2.Whi = l0.Wthi; g2.Wlo = l0.Wtlo;
     RUN(ptta_launch_gemm(g2, s));
     if (c->bf16) hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(c->Rg * 32)), dim3(256), 0, s, c->g_feat_f32, (bf16_t*)c->g_feat, c->Rg * 32);
-    else HIPCHK(hipMemcpyAsync(c->g_feat, c->g_feat_f32, (size_t)c->Rg * 32 * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
 

@@ -439,6 +439,117 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
     }
 }
 
+// ---- stride-2 convolution, LDS-staged (fp32 storage, bf16x3): the (2*4+1) x (2*32+1) input window of a 4 x 32 output tile is read
+// ONCE as whole pixel lines (every input pixel crosses the vector-memory path 1.14 times, 64 B per load pair) instead of as
+// per-tap fragment loads (1.8 times, 32 B used of every 128-B line touched per instruction).  Same structure as the stride-1
+// kernel with two differences: the K loop is split into the two 16-channel k-steps (the window of all 32 channels would not fit
+// two blocks per CU), and a wave owns one output row whose A fragments are read from LDS with a two-pixel stride.  Accumulation
+// order: k-step outer, tap inner.  The next stage's loads are issued before the current stage's MFMAs (one register set; a
+// two-set ring with loads two stages ahead needed 254-256 VGPRs, spilled in the mask / add variants and measured slower:
+// 34.4 vs 33.7 us at full resolution, 9.9 vs 8.8 us at 1/8).
+#define S2_TH 4
+#define S2_PH (2 * S2_TH + 1)
+#define S2_PW 65
+#define S2_STR 80                                      // per pixel and k-step: hi 32 B | lo 32 B | pad 16 B
+template <bool RELU, bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<float> p) {
+    constexpr int NPIX = S2_PH * S2_PW, NIT = (NPIX * 2 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * S2_STR + 18 * 64 * 16];
+    unsigned char* const wl_lds = lds + NPIX * S2_STR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hin = p.Hin, Win = p.Win, Ho = p.Hout, Wo = p.Wout;
+    const int ntx = (Wo + 31) >> 5, nty = (Ho + S2_TH - 1) / S2_TH;
+    const long nstages = 2L * p.B * ntx * nty;                      // (tile, k-step) pairs
+    float4 v0[NIT], v1[NIT];
+    auto coords = [&](long tile, int& b, int& oy0, int& ox0) {
+        long t_ = tile;
+        const int ty = (int)(t_ % nty); t_ /= nty;
+        const int tx = (int)(t_ % ntx);
+        b = (int)(t_ / ntx); oy0 = ty * S2_TH; ox0 = tx << 5;
+    };
+    auto issue_loads = [&](long stage) {
+        int b, oy0, ox0;
+        coords(stage >> 1, b, oy0, ox0);
+        const float* inb = p.in + (size_t)(b % p.in_nb) * Hin * Win * 32 + 16 * (int)(stage & 1);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int g = idx & 1, pix = idx >> 1;
+            const int py = pix / S2_PW, px = pix - py * S2_PW;
+            const int gy = 2 * oy0 - 1 + py, gx = 2 * ox0 - 1 + px;
+            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
+            if (pix < NPIX && gy >= 0 && gy < Hin && gx >= 0 && gx < Win) {
+                const float* src = inb + ((size_t)gy * Win + gx) * 32 + 8 * g;
+                v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
+            }
+        }
+    };
+    const long first = 2L * blockIdx.x, sstride = 2L * gridDim.x;       // this block's stages: 2t, 2t+1 of its tiles
+    if (first < nstages) issue_loads(first);
+    uint4 wh[9][2];
+    {
+        const uint4* ph = (const uint4*)p.wpack;
+        const uint4* pl = (const uint4*)p.wpack2;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+    }
+    f32x16 acc;
+    bool started = false;
+    for (long base = first; base < nstages; base += sstride) {
+        int b, oy0, ox0;
+        coords(base >> 1, b, oy0, ox0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (started) lds_barrier();                  // the previous stage's MFMAs are done with the window
+            started = true;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + 256 * it;
+                const int pix = idx >> 1;
+                if (pix < NPIX) {
+                    float4 a0 = v0[it], a1 = v1[it];
+                    if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
+                    uint4 hi, lo;
+                    split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);
+                    split2(a1.x, a1.y, hi.z, lo.z); split2(a1.z, a1.w, hi.w, lo.w);
+                    unsigned char* dst = lds + pix * S2_STR + 16 * (idx & 1);
+                    *(uint4*)dst = hi;
+                    *(uint4*)(dst + 32) = lo;
+                }
+            }
+            {   // next stage's loads: the other k-step of this tile, or the first k-step of the block's next tile
+                const long nxt = q == 0 ? base + 1 : base + sstride;
+                if (nxt < nstages) issue_loads(nxt);
+            }
+            lds_barrier();                               // LDS-only: the loads just issued stay in flight during the MFMAs
+            if (q == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
+            if (oy0 + wave < Ho) {                       // wave-uniform
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    const unsigned char* a = lds + ((2 * wave + ky) * S2_PW + 2 * i + kx) * S2_STR + 16 * h;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][q]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + q) * 64 + lane) * 16));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+                if (q == 1) epi_tile<float, false, MASK, ADD>(p.epi, b, oy0 + wave, Ho, Wo, i, acc, ox0, h, Wo, 1, 0, 0.f, 0.f);
+            }
+        }
+    }
+}
+
 // ---- reference-style direct kernel (one thread per output element), same epilogue ------------
 // Selected with PTTA_CONV_IMPL=naive: keeps the whole pipeline testable independently of the MFMA
 // fragment packing.  Weights in canonical float layout Wc[tap][cin][cout].
@@ -586,6 +697,18 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
         long blocks = (items + 3) / 4; if (blocks > 512) blocks = 512;
         const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
+        static const int s2_direct = getenv("PTTA_S2_DIRECT") ? atoi(getenv("PTTA_S2_DIRECT")) : 0;      // A/B: keep the direct-load form
+        if (MODE == CONV_S2 && !(flags & 1) && !s2_direct) {
+            const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + S2_TH - 1) / S2_TH);
+            const int tb = (int)(tiles < 512 ? tiles : 512);
+#define KS2_(R, M, A) hipLaunchKernelGGL((conv32_s2_lds_kernel<R, M, A>), dim3(tb), dim3(256), 0, s, pf)
+            const bool m_ = flags & 2, a_ = flags & 4;
+            if (a.relu_in) { if (m_) { if (a_) KS2_(true, true, true); else KS2_(true, true, false); } else { if (a_) KS2_(true, false, true); else KS2_(true, false, false); } }
+            else { if (m_) { if (a_) KS2_(false, true, true); else KS2_(false, true, false); } else { if (a_) KS2_(false, false, true); else KS2_(false, false, false); } }
+#undef KS2_
+            PTTA_CHECK_LAUNCH();
+            return 0;
+        }
         if (a.relu_in) launch_direct_x3<MODE, true>(pf, flags, (int)blocks, s); else launch_direct_x3<MODE, false>(pf, flags, (int)blocks, s);
         PTTA_CHECK_LAUNCH();
         return 0;

@@ -17,8 +17,12 @@ MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
 STD = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
 MAX_DEPTH = 8.0
 HP = dict(lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=None)
-# 'naive': direct fp32 kernels (exact arithmetic); 'default': bf16x3 matrix-core convolutions
-TOL = {'naive': dict(depth=1e-4, emb=1e-3, grad=2e-2, param=2e-3), 'default': dict(depth=1e-3, emb=5e-3, grad=6e-2, param=4e-3)}
+# 'naive': direct fp32 kernels (exact arithmetic); 'default': matrix-core convolutions, bf16x6 forward for the real frames
+# (three-way operand split, fp32-grade products), bf16x3 for the proxy frames and the data gradients.
+# Bounds = 2x the worst figure measured on MI355X (tools/costdc_report.py, round 3): depth 1.5e-6 / 2.4e-6, gradients 5.0e-3 /
+# 5.1e-3 (rel. MAE of the worst of the 32 tensors; post-step parameters 9.3e-5; the reference's own fp32 gradients sit 1.8e-3 from an fp64 evaluation,
+# tests/golden/costdcnet_fp64.npz), post-update eval depth 2.5e-4 / 6.0e-4.
+TOL = {'naive': dict(depth=1e-5, emb=1e-3, grad=1e-2, param=2e-4, eval=1e-3), 'default': dict(depth=1e-5, emb=5e-3, grad=1e-2, param=2e-4, eval=1e-3)}
 MODES = ['naive', 'default']
 
 
@@ -108,10 +112,10 @@ def test_step_matches_golden(golden_dir, name, impl):
         info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
         p = 's%d/' % s
         if s > 0:
-            # Adam's FIRST update moves every entry by +-lr (3e-3 in the CostDCNet scripts) whatever the gradient's size, so
-            # the handful of entries whose near-zero gradients differ in sign sit 2*lr apart afterwards (the fp32 CPU
-            # reference is as arbitrary there as this path): later steps are held to a bound, not to the tight tolerance
-            assert rel_mae(depth, g[p + 'depth_train']) < 5e-3, (name, s)
+            # Adam's FIRST update moves every entry by lr * g / (|g| + eps) (lr = 3e-3 in the CostDCNet scripts): entries whose
+            # gradient is near zero move by a sign- and size-dependent amount (exact arithmetic: 3.5e-2 of the mean parameter
+            # at 64x96), so the SECOND step is held to the north-star tolerance only (measured 6.1e-4, exact mode 6.8e-4)
+            assert rel_mae(depth, g[p + 'depth_train']) < 1.5e-3, (name, s)
             continue
         assert rel_mae(depth, g[p + 'depth_train']) < tol['depth'], (name, s)
         np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2e-3, atol=1e-7)
@@ -122,13 +126,13 @@ def test_step_matches_golden(golden_dir, name, impl):
         for k in g.files:                       # tracked BatchNorm buffers (BatchNorm3d, heads, sparse encoder)
             if k.startswith(p + 'buf/'):
                 assert rel_mae(sd[k[len(p) + 4:]], g[k]) < 2e-3, k
-        assert rel_mae(eng.forward_eval(image1, sparse), g[p + 'depth_eval']) < 5e-3
+        assert rel_mae(eng.forward_eval(image1, sparse), g[p + 'depth_eval']) < tol['eval']        # the scored tensor, after this path's OWN update
         # the eval path itself, from the REFERENCE's post-step parameters (the tracked running statistics are this
         # engine's own, updated by the training forward above): tight
         keep = {k: adapted[k][0].clone() for k in names}
         for k in names:
             adapted[k][0].copy_(torch.from_numpy(g[p + 'param/' + k]))
-        assert rel_mae(eng.forward_eval(image1, sparse), g[p + 'depth_eval']) < (1e-5 if impl == 'naive' else 2e-4)
+        assert rel_mae(eng.forward_eval(image1, sparse), g[p + 'depth_eval']) < 1e-5            # measured 1.2e-6 (both modes)
         for k in names:
             adapted[k][0].copy_(keep[k])
     assert eng.adam_step_count() == steps
@@ -147,15 +151,26 @@ def test_full_size_step_matches_reference(golden_dir, name):
     eng, sd, adapted = make_costdc(n, h, w, hp)
     raw, image1, sparse = [torch.from_numpy(x).cuda() for x in costdc_frame(0, h, w, n, float(g['density']))]
     info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
-    _check_map(depth, g, 's0/depth_train', 1e-3)
-    np.testing.assert_allclose(info.cpu().numpy(), g['s0/loss_info'], rtol=2e-3, atol=1e-7)
+    _check_map(depth, g, 's0/depth_train', 1e-5)                                            # measured 2.4e-6
+    np.testing.assert_allclose(info.cpu().numpy(), g['s0/loss_info'], rtol=1e-4, atol=1e-7)
     for k in eng.adapted:
         assert rel_mae(eng.grad(k, adapted[k][0]), g['s0/grad/' + k]) < TOL['default']['grad'], k
         assert np.abs(adapted[k][0].cpu().numpy() - g['s0/param/' + k]).max() <= 2.0 * lr * 1.01, k
-    _check_map(eng.forward_eval(image1, sparse), g, 's0/depth_eval', 5e-3)                 # after this path's own Adam step (+-lr sign noise)
+    # the scored tensor (src/tta_main.py:729-736): eval depth after this path's OWN Adam step, north_star tolerance 1e-3
+    # (measured 1.1e-6 at 320x400, 6.0e-4 at 480x640; exact-arithmetic mode 1.0e-6 / 2.6e-4)
+    d_eval = eng.forward_eval(image1, sparse)
+    _check_map(d_eval, g, 's0/depth_eval', 1e-3)
+    # ... and against the fp64 evaluation of the same step (tests/golden/costdcnet_fp64.npz): the reference's own fp32 result is
+    # 9.9e-5 / 2.9e-4 away from it (one near-zero gradient entry takes the opposite first step); this path may be at most 1e-3
+    g64 = np.load(os.path.join(golden_dir, 'costdcnet_fp64.npz'))
+    e64 = g64[name + '/depth_eval_pix']
+    mine = d_eval.detach().cpu().numpy().reshape(-1)[g['pix_idx']].astype(np.float64)
+    ref_noise = float(g64[name + '/reference_vs_fp64'][1])
+    err64 = float(np.abs(mine - e64).mean() / np.abs(e64).mean())
+    assert err64 < 1e-3, (err64, ref_noise)
     for k in eng.adapted:                                                                  # the eval path from the reference's parameters
         adapted[k][0].copy_(torch.from_numpy(g['s0/param/' + k]))
-    _check_map(eng.forward_eval(image1, sparse), g, 's0/depth_eval', 2e-4)
+    _check_map(eng.forward_eval(image1, sparse), g, 's0/depth_eval', 1e-5)                  # measured 1.1e-6
     eng.close()
 
 
@@ -204,14 +219,14 @@ def test_external_model_adapt_facade_costdcnet(golden_dir):
     opt.zero_grad()
     loss.backward()
     opt.step()
-    assert rel_mae(depth, g['s0/depth_train']) < 1e-3
+    assert rel_mae(depth, g['s0/depth_train']) < 1e-5
     assert abs(float(loss.detach()) - g['s0/loss_info'][0]) < 2e-3 * abs(g['s0/loss_info'][0])
     for k, prm in zip(names, params):
         assert rel_mae(prm.grad, g['s0/grad/' + k]) < TOL['default']['grad'], k
     model.eval()
     with torch.no_grad():
         d_eval = model.forward(image=image1, sparse_depth=sparse, loss_type=CANONICAL_LOSS_TYPE)
-    assert rel_mae(d_eval, g['s0/depth_eval']) < 5e-3
+    assert rel_mae(d_eval, g['s0/depth_eval']) < 1e-3            # measured 2.3e-4
     # the checkpoint carries the reference's key set (ResBlock.norm3 listed twice) and the updated running statistics
     sd = model.model.state_dict()
     assert list(sd.keys()) == [k for k, _ in synth.costdcnet_keys()]

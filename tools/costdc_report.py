@@ -24,7 +24,7 @@ for name in sys.argv[1:] or ['costdcnet_64x96', 'costdcnet_64x64_n2', 'costdcnet
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, md = [float(x) for x in g['hp']]
     hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=None)
     sampled = 'pix_idx' in g.files
-    for impl in (['default'] if sampled else ['naive', 'default']):
+    for impl in (os.environ['IMPLS'].split(',') if os.environ.get('IMPLS') else (['default'] if sampled else ['naive', 'default'])):
         eng, sd, ad = make_costdc(n, h, w, hp, impl=impl)
         for s in range(steps):
             raw, im, sp = [torch.from_numpy(x).cuda() for x in costdc_frame(s, h, w, n, float(g['density']))]

@@ -343,6 +343,7 @@ GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth
     e->hp = *hp; e->max_depth = max_depth; e->z_step = (float)((double)max_depth / 15.0);
     const char* impl = getenv("PTTA_CONV_IMPL");
     e->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
+    { const char* x6 = getenv("PTTA_X6"); e->x6 = e->naive ? 0 : (x6 ? (atoi(x6) ? 1 : 0) : 1); }      // default ON: DESIGN.md section 10 (parity of the post-update depth)
     e->build();
     if (e->oom || !e->step_dev) { delete e; *rc = -12; return nullptr; }
     if (e->upload_hparams(nullptr)) { delete e; *rc = -5; return nullptr; }

@@ -36,11 +36,23 @@ __device__ __forceinline__ void gsplit2(float a, float b, unsigned& hi, unsigned
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
 
+// three-way split a = h + m + l (8 + 8 + 8 significant bits): h and m are the two-way split's (hi, lo); l2 is what that split drops
+__device__ __forceinline__ void gsplit3(float a, float b, unsigned& hi, unsigned& lo, unsigned& l2) {
+    float2_t v = {a, b};
+    const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    hi = __builtin_bit_cast(unsigned, h);
+    float2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
+    const bf16x2_t m = __builtin_convertvector(r, bf16x2_t);
+    lo = __builtin_bit_cast(unsigned, m);
+    float2_t r2 = {r[0] - __uint_as_float(lo << 16), r[1] - __uint_as_float(lo & 0xffff0000u)};
+    l2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2_t));
+}
+
 #define GX_TH 8
 
 // fragment (nf, chunk, tap, kk): lane l holds column co = 32 nf + (l & 31), rows ci = 32 chunk + 16 kk + 8 (l >> 5) + e
 __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1,
-                                  int Co, int nchunks, int nf_total, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+                                  int Co, int nchunks, int nf_total, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, bf16_t* __restrict__ l2) {
     const long total = (long)nf_total * nchunks * KK * 2 * 64 * 8;
     const int nch0 = (C0 + 31) / 32;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -56,7 +68,10 @@ __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, lon
         float v = 0.f;
         if (cl < Cs && co < Co) v = canon[(long)t * wts + (long)((s == 0 ? c0_0 : c0_1) + cl) * wld + co];
         const bf16_t h = f2bf(v);
-        hi[idx] = h; lo[idx] = f2bf(v - bf2f(h));
+        const float r = v - bf2f(h);
+        const bf16_t m = f2bf(r);
+        hi[idx] = h; lo[idx] = m;
+        if (l2) l2[idx] = f2bf(r - bf2f(m));
     }
 }
 
@@ -66,17 +81,21 @@ __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, lon
 // TIMING: s_memtime stamps around the phases of one block's K loop, printed by two blocks of the launch (diagnostic builds of the
 // launcher select it with PTTA_S1_STAMPS=<grid size in blocks>; the shipped instantiation has no stamps)
 #define STAMP(v) do { if constexpr (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
-template <int KS, bool VERT, bool TIMING = false>
-__global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
+// SIX: three operand planes (GX3Args::six_B): 112 B of LDS per pixel, three weight planes, two blocks per CU; blocks of images
+// >= six_B (the proxy frames) skip the three extra products
+template <int KS, bool VERT, bool TIMING = false, bool SIX = false>
+__global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p) {
     unsigned long long T0 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0;
     unsigned long long dA = 0, dW = 0, dS = 0, dL = 0, dB = 0, dM = 0;
     STAMP(T0);
     constexpr int PAD = KS / 2, PADX = VERT ? 0 : PAD, KKX = VERT ? 1 : KS, PH = GX_TH + 2 * PAD, PW = 32 + 2 * PADX, KK = KS * KKX;
     constexpr int NPIX = PH * PW;
     constexpr int NIT = (NPIX * 2 + 255) / 256;          // (pixel, 8-channel group) items per thread
-    constexpr int NWF = KK * 64 * 2;                     // weight uint4 per sub-chunk: [hi | lo][tap][lane]
+    constexpr int NPL = SIX ? 3 : 2;                     // operand planes
+    constexpr int STR = SIX ? 112 : GX_STR16;            // LDS bytes per pixel: hi 32 | lo 32 [| l2 32] | pad 16 (an odd number of 16-B slots)
+    constexpr int NWF = KK * 64 * NPL;                   // weight uint4 per sub-chunk: [hi | lo | l2][tap][lane]
     constexpr int NW = (NWF + 255) / 256;
-    constexpr int ACT = NPIX * GX_STR16;
+    constexpr int ACT = NPIX * STR;
     constexpr int LDSB = ACT + NWF * 16 > 32768 ? ACT + NWF * 16 : 32768;     // the epilogue stages 4 x 8 KB through it
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDSB + 1024];
     uint4* const wlds = (uint4*)(lds + ACT);
@@ -95,6 +114,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
     const int nf = p.nf0 + nfl;
     const int nch0 = (p.C0 + 31) >> 5;
     const int nq = 2 * p.nchunks;
+    const bool six = SIX && b < p.six_B;                 // block-uniform
 
     float4 v0[NIT], v1[NIT];
     uint4 wr[NW];
@@ -121,7 +141,7 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
         for (int j = 0; j < NW; ++j) {
             const int idx = tid + 256 * j;                // [hl][tap][lane]
             const int hl = idx / (KK * 64), r = idx - hl * (KK * 64);
-            wr[j] = idx < NWF ? (hl ? p.wlo : p.whi)[wbase + (r >> 6) * 128 + (r & 63)] : make_uint4(0, 0, 0, 0);
+            wr[j] = idx < NWF ? (hl == 0 ? p.whi : (hl == 1 ? p.wlo : p.wl2))[wbase + (r >> 6) * 128 + (r & 63)] : make_uint4(0, 0, 0, 0);
         }
     };
     f32x16 acc[2];
@@ -149,9 +169,16 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             if (pix < NPIX) {
                 const float4 a0 = v0[it], a1 = v1[it];
                 uint4 hi, lo;
-                gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
-                gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
-                unsigned char* dst = lds + pix * GX_STR16 + 16 * (idx & 1);
+                unsigned char* dst = lds + pix * STR + 16 * (idx & 1);
+                if constexpr (SIX) {
+                    uint4 l2;
+                    gsplit3(a0.x, a0.y, hi.x, lo.x, l2.x); gsplit3(a0.z, a0.w, hi.y, lo.y, l2.y);
+                    gsplit3(a1.x, a1.y, hi.z, lo.z, l2.z); gsplit3(a1.z, a1.w, hi.w, lo.w, l2.w);
+                    *(uint4*)(dst + 64) = l2;
+                } else {
+                    gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
+                    gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
+                }
                 *(uint4*)dst = hi;
                 *(uint4*)(dst + 32) = lo;
             }
@@ -176,9 +203,22 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
             bf16x8 ah[2], al[2];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const unsigned char* a = lds + ((2 * wave + rr + ky) * PW + i + kx) * GX_STR16 + 16 * h;
+                const unsigned char* a = lds + ((2 * wave + rr + ky) * PW + i + kx) * STR + 16 * h;
                 ah[rr] = __builtin_bit_cast(bf16x8, *(const uint4*)a);
                 al[rr] = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
+            }
+            if constexpr (SIX) if (six) {                 // the 2^-16 terms first: l.h, h.l, m.m
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, wlds[2 * KK * 64 + tap * 64 + lane]);
+                bf16x8 a2[2];
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+                    a2[rr] = __builtin_bit_cast(bf16x8, *(const uint4*)(lds + ((2 * wave + rr + ky) * PW + i + kx) * STR + 16 * h + 64));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[0], bh, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[1], bh, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], b2, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], b2, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bl, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bl, acc[1], 0, 0, 0);
             }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh, acc[1], 0, 0, 0);
@@ -312,7 +352,8 @@ __global__ __launch_bounds__(256, 3) void gconv_x3_s1_kernel(GX3Args p) {
 //   MODE 2 (T2): y[oy][ox] = sum over taps with (oy+pad-ky), (ox+pad-kx) even of x[(oy+pad-ky)/2][(ox+pad-kx)/2] w[tap]
 // NCO = output-channel tiles (of 32) per wave: with two, every A fragment (uncoalesced 32-B pieces of strided pixels, split to
 // bf16 in registers) feeds two weight fragments
-template <int MODE, int KS, int KSPLIT, int NCO>
+// SIX: bf16x6 for the images below p.six_B (GX3Args), the third operand planes split in registers / streamed like the other two
+template <int MODE, int KS, int KSPLIT, int NCO, bool SIX = false>
 __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin, int Win) {
     constexpr int PAD = KS / 2, KK = KS * KS;
     // stride 2: two output rows per wave, tap-outer / row-inner, so the A loads of both rows are in flight before the
@@ -342,6 +383,7 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
     const int b = (int)(t_ / nseg);
     const int x0 = seg << 5, ybase = yg * R;
     const bool lane_in = (x0 + i) < Wt;
+    const bool six = SIX && b < p.six_B;                 // wave-uniform
     f32x16 acc[NCO][R];
 #pragma unroll
     for (int t = 0; t < NCO; ++t)
@@ -356,6 +398,7 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
         const float* inb = src + (size_t)b * Hin * Win * ld + cb + 8 * h;
         const uint4* ph = p.whi + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + lane;
         const uint4* pl = p.wlo + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + lane;
+        const uint4* p2 = SIX ? p.wl2 + ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + lane : nullptr;
         const size_t tstride = (size_t)p.nchunks * (KK * 2 * 64);                 // next output-channel tile
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
@@ -367,13 +410,14 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                bf16x8 bh[NCO], bl[NCO];
+                bf16x8 bh[NCO], bl[NCO], b2[NCO];
 #pragma unroll
                 for (int t = 0; t < NCO; ++t) {
                     bh[t] = __builtin_bit_cast(bf16x8, ph[t * tstride + (tap * 2 + k) * 64]);
                     bl[t] = __builtin_bit_cast(bf16x8, pl[t * tstride + (tap * 2 + k) * 64]);
+                    if constexpr (SIX) b2[t] = __builtin_bit_cast(bf16x8, p2[t * tstride + (tap * 2 + k) * 64]);
                 }
-                bf16x8 ah[R], al[R];
+                bf16x8 ah[R], al[R], a2[R];
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) {
                     const int y = ybase + rr;
@@ -388,9 +432,26 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
                     float4 a0 = *(const float4*)q, a1 = *(const float4*)(q + 4);
                     if (!ok) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
                     uint4 hi, lo;
-                    gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
-                    gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
+                    if constexpr (SIX) {
+                        uint4 l2;
+                        gsplit3(a0.x, a0.y, hi.x, lo.x, l2.x); gsplit3(a0.z, a0.w, hi.y, lo.y, l2.y);
+                        gsplit3(a1.x, a1.y, hi.z, lo.z, l2.z); gsplit3(a1.z, a1.w, hi.w, lo.w, l2.w);
+                        a2[rr] = __builtin_bit_cast(bf16x8, l2);
+                    } else {
+                        gsplit2(a0.x, a0.y, hi.x, lo.x); gsplit2(a0.z, a0.w, hi.y, lo.y);
+                        gsplit2(a1.x, a1.y, hi.z, lo.z); gsplit2(a1.z, a1.w, hi.w, lo.w);
+                    }
                     ah[rr] = __builtin_bit_cast(bf16x8, hi); al[rr] = __builtin_bit_cast(bf16x8, lo);
+                }
+                if constexpr (SIX) if (six) {
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+                        for (int t = 0; t < NCO; ++t) {
+                            acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[rr], bh[t], acc[t][rr], 0, 0, 0);
+                            acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], b2[t], acc[t][rr], 0, 0, 0);
+                            acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bl[t], acc[t][rr], 0, 0, 0);
+                        }
                 }
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr)
@@ -695,11 +756,11 @@ __global__ __launch_bounds__(256) void gwgrad_mfma_reduce_kernel(const float* __
 }  // namespace
 
 void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
-                     hipStream_t s) {
+                     hipStream_t s, bf16_t* l2) {
     const int nchunks = (C0 + 31) / 32 + (C1 + 31) / 32, nf_total = (Co + 31) / 32;
     const long total = (long)nf_total * nchunks * KK * 2 * 64 * 8;
     long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gfrag_pack_kernel, dim3((int)blocks), dim3(256), 0, s, canon, wld, wts, KK, C0, C1, c0_0, c0_1, Co, nchunks, nf_total, hi, lo);
+    hipLaunchKernelGGL(gfrag_pack_kernel, dim3((int)blocks), dim3(256), 0, s, canon, wld, wts, KK, C0, C1, c0_0, c0_1, Co, nchunks, nf_total, hi, lo, l2);
 }
 long ptta_gfrag_elems(int KK, int C0, int C1, int Co) {
     return (long)((Co + 31) / 32) * ((C0 + 31) / 32 + (C1 + 31) / 32) * KK * 2 * 64 * 8;
@@ -714,6 +775,15 @@ int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
     const long blocks = tiles * a.nnf;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
     static const int exp_t = getenv("PTTA_S1_STAMPS") ? atoi(getenv("PTTA_S1_STAMPS")) : 0;   // diagnostic: in-kernel phase stamps (tools/exp_s1_stamps.sh)
+    if (a.six_B > 0) {
+        if (!a.wl2) return -22;
+        if (ks == 3 && a.vert) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else if (ks == 1) hipLaunchKernelGGL((gconv_x3_s1_kernel<1, false, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else return -22;
+        PTTA_CHECK_LAUNCH();
+        return 0;
+    }
     if (ks == 3 && a.vert) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else if (ks == 3 && exp_t && blocks == exp_t) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
@@ -738,12 +808,15 @@ int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, in
     const int ngrp = a.nnf / nco;
     const long blocks = (split ? nitems : (nitems + 3) / 4) * ngrp;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
-#define L_(M, K) do { if (nco == 2) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); \
-                      else if (split) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 4, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); \
-                      else hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); } while (0)
+    if (a.six_B > 0 && !a.wl2) return -22;
+#define L__(M, K, S) do { if (nco == 2) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 1, 2, S>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); \
+                      else if (split) hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 4, 1, S>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); \
+                      else hipLaunchKernelGGL((gconv_x3_direct_kernel<M, K, 1, 1, S>), dim3((unsigned)blocks), dim3(256), 0, s, a, hin, win); } while (0)
+#define L_(M, K) do { if (a.six_B > 0) L__(M, K, true); else L__(M, K, false); } while (0)
     if (mode == 1) { if (ks == 3) L_(1, 3); else L_(1, 1); }
     else { if (ks == 3) L_(2, 3); else L_(2, 1); }
 #undef L_
+#undef L__
     PTTA_CHECK_LAUNCH();
     return 0;
 }

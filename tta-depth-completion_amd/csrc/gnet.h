@@ -57,6 +57,7 @@ struct GConvW {            // convolution weights, packed at load time (frozen) 
     int vcol = 0;                                         // 3x1x1 Conv3d stored as a 3x3 filter with only the middle column set
     float* gpad = nullptr;                                // zero-padded copy of the output gradient (Co_pad channels)
     bf16_t *ff_hi = nullptr, *ff_lo = nullptr, *fb_hi = nullptr, *fb_lo = nullptr;     // bf16x3 MFMA fragments (forward / data gradient)
+    bf16_t* ff_l2 = nullptr;                              // third operand plane of the forward fragments (GNet::x6)
     bf16_t *fb1_hi = nullptr, *fb1_lo = nullptr;          // data-gradient fragments of the SECOND source when its channel offset is not a multiple of 32
     bool mf = false, mb = false;                          // matrix-core kernel usable for forward / data gradient
     bool loaded = false, has_bias = false;
@@ -126,6 +127,10 @@ struct GNet {
     float *depth = nullptr, *gdepth = nullptr;     // (Nu,1,Hu,Wu): network output / its gradient
     int t_emb = -1, t_ref = -1;
     int naive = 0;
+    // bf16x6 forward for the real frames (GX3Args::six_B): the two-way operand split's 2^-17 representation error reaches the depth
+    // map as ~2e-5 relative, enough to flip the sign of near-zero gradient entries -- and Adam's first step turns a sign into +-lr
+    // (CostDCNet: post-update eval depth 1.6e-3 from the reference with bf16x3).  PTTA_X6=0/1 overrides.
+    int x6 = 0;
     int norm_on = 0; float norm_div = 1.f, norm_mean[3] = {0, 0, 0}, norm_std[3] = {1, 1, 1};
     bool fwd_valid = false;
     int max_bn_C = 16;
@@ -177,6 +182,18 @@ struct GNet {
         v.B = (int)(pix / ((long)rH * rW)); v.H = rH; v.W = rW;
     }
 
+    static bool exact_listed(const char* var, const std::string& wname) {
+        const char* e = getenv(var);
+        if (!e || !*e) return false;
+        std::string l(e); size_t a = 0;
+        while (a <= l.size()) {
+            size_t b = l.find(',', a); if (b == std::string::npos) b = l.size();
+            const std::string pre = l.substr(a, b - a);
+            if (pre == "*" || (!pre.empty() && wname.compare(0, pre.size(), pre) == 0)) return true;
+            a = b + 1;
+        }
+        return false;
+    }
     // ---- program construction --------------------------------------------------------------------------------------
     int add_adapted(const std::string& name, long n) {
         Adapted a; a.name = name; a.n = n; a.goff = gall_n; gall_n += n;
@@ -194,6 +211,10 @@ struct GNet {
         cw.C0 = T[x0].C; cw.C1 = x1 >= 0 ? T[x1].C : 0;
         cw.mf = !naive && (stride == 1 && !transposed ? (cw.C0 % 8) == 0 && (cw.C1 % 8) == 0 : (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0);
         cw.mb = !naive && ((cw.Co % 16) == 0 || (stride == 1 && !transposed));
+        // diagnostics: PTTA_EXACT_FWD / PTTA_EXACT_BWD = comma-separated layer-name prefixes ("*" = every layer) whose forward /
+        // data gradient runs on the direct fp32 kernels (needs the activation's real channel count: not the zero-padded inputs)
+        if (exact_listed("PTTA_EXACT_FWD", wname) && wname != "enc2d.conv1" && wname != "conv1_rgb.0" && wname != "conv1_dep.0") cw.mf = false;
+        if (exact_listed("PTTA_EXACT_BWD", wname)) cw.mb = false;
         cw.Co_pad = (cw.Co + 15) / 16 * 16;               // data gradient of a conv with < 16 output channels: gy is zero-padded
         const long pix = (long)T[y].per * T[y].H * T[y].W;
         if (pix > cw.gpad_pix) cw.gpad_pix = pix;
@@ -271,7 +292,8 @@ struct GNet {
         for (auto& kv : convs) {
             GConvW& cw = kv.second;
             const int KK = cw.k * cw.k;
-            if (cw.mf) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.C0, cw.C1, cw.Co); cw.ff_hi = (bf16_t*)dalloc(n * 2); cw.ff_lo = (bf16_t*)dalloc(n * 2); }
+            if (cw.mf) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.C0, cw.C1, cw.Co); cw.ff_hi = (bf16_t*)dalloc(n * 2); cw.ff_lo = (bf16_t*)dalloc(n * 2);
+                         if (x6) cw.ff_l2 = (bf16_t*)dalloc(n * 2); }
             if (cw.mb && !cw.Ci_real && cw.Co_pad != cw.Co) cw.gpad = falloc((size_t)cw.gpad_pix * cw.Co_pad);
             if (cw.mb && !cw.Ci_real) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.Ci); cw.fb_hi = (bf16_t*)dalloc(n * 2); cw.fb_lo = (bf16_t*)dalloc(n * 2); }
             if (cw.mb && !cw.Ci_real && cw.C1 > 0 && (cw.C0 % 32) != 0) { const size_t n = (size_t)ptta_gfrag_elems(KK, cw.Co, 0, cw.C1); cw.fb1_hi = (bf16_t*)dalloc(n * 2); cw.fb1_lo = (bf16_t*)dalloc(n * 2); }
@@ -285,13 +307,13 @@ struct GNet {
         if (cw.vcol) {
             // 3x1x1 Conv3d: the matrix-core kernel's VERT form takes the three vertical taps only (canonical taps 1, 4, 7)
             const long ts = (long)cw.Ci * cw.Co;
-            if (cw.mf) ptta_gfrag_pack(cw.wf + ts, cw.Co, 3 * ts, 3, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);
+            if (cw.mf) ptta_gfrag_pack(cw.wf + ts, cw.Co, 3 * ts, 3, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s, cw.ff_l2);
             if (cw.mb) ptta_gfrag_pack(cw.wb + ts, cw.Ci, 3 * ts, 3, cw.Co, 0, 0, 0, cw.Ci, cw.fb_hi, cw.fb_lo, s);
             return;
         }
         const int KK = cw.k * cw.k;
-        if (cw.mf && cw.Ci_real) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci_real * cw.Co, KK, cw.Ci_real, 0, 0, 0, cw.Co, cw.ff_hi, cw.ff_lo, s);
-        else if (cw.mf) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci * cw.Co, KK, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s);
+        if (cw.mf && cw.Ci_real) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci_real * cw.Co, KK, cw.Ci_real, 0, 0, 0, cw.Co, cw.ff_hi, cw.ff_lo, s, cw.ff_l2);
+        else if (cw.mf) ptta_gfrag_pack(cw.wf, cw.Co, (long)cw.Ci * cw.Co, KK, cw.C0, cw.C1, 0, cw.C0, cw.Co, cw.ff_hi, cw.ff_lo, s, cw.ff_l2);
         if (cw.mb && !cw.Ci_real) ptta_gfrag_pack(cw.wb, cw.Ci, (long)cw.Co * cw.Ci, KK, cw.Co, 0, 0, 0, cw.Ci, cw.fb_hi, cw.fb_lo, s);
         // second source at a channel offset that is not a tile boundary: its own fragment set (columns C0.. of the packed matrix)
         if (cw.fb1_hi) ptta_gfrag_pack(cw.wb + cw.C0, cw.Ci, (long)cw.Co * cw.Ci, KK, cw.Co, 0, 0, 0, cw.C1, cw.fb1_hi, cw.fb1_lo, s);

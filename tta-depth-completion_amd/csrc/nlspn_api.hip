@@ -292,6 +292,7 @@ GNet* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int legacy_offse
     e->N = e->Nu = n; e->H = e->Hu = h; e->W = e->Wu = w; e->hp = *hp; e->legacy = (legacy_offset & 1) ? 1 : 0; e->heads_adapted = (legacy_offset & 2) ? 1 : 0;
     const char* impl = getenv("PTTA_CONV_IMPL");
     e->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;          // direct fp32 kernels everywhere (validation)
+    { const char* x6 = getenv("PTTA_X6"); e->x6 = (!e->naive && x6 && atoi(x6)) ? 1 : 0; }             // default OFF (matrix-core bound; parity holds without)
     e->build();
     if (e->oom || !e->step_dev) { delete e; *rc = -12; return nullptr; }
     const float one[1] = {4.0f};                                  // affinity_gamma * num = 0.5 * 8 (nlspnmodel_adapt.py:231-233)

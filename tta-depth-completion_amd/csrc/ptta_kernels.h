@@ -230,9 +230,13 @@ struct GX3Args {
     // {sum y, sum y^2} per channel, layout [pass][tile][2][stat_C]; stat_npass equal slices of the batch
     float* stat_part = nullptr; int stat_C = 0, stat_npass = 1;
     int vert = 0;                                             // stride-1 3x3 only: fragments hold the three vertical taps (3x1x1 Conv3d)
+    // bf16x6: the first six_B images of the batch (the real frames of a [real | proxy] launch) are computed with a three-way operand
+    // split x = h + m + l, w = h + m + l and the six products down to 2^-16 (hh, hm, mh, mm, hl, lh): fp32-grade products where the
+    // two-way split's 2^-17 operand error is too much (CostDCNet: gradient signs after the first Adam step); wl2 = the weights' l plane
+    const uint4* wl2 = nullptr; int six_B = 0;
 };
 void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
-                     hipStream_t s);
+                     hipStream_t s, bf16_t* l2 = nullptr);
 long ptta_gfrag_elems(int KK, int C0, int C1, int Co);
 int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s);
 int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, int win, hipStream_t s);

@@ -265,8 +265,16 @@ def costdcnet_shared(args, rank, world, dist):
     for k in eng.adapted:
         keep.append((sd[k].clone().contiguous(), torch.zeros_like(sd[k]), torch.zeros_like(sd[k])))
         eng.bind_adapted(k, *keep[-1])
+    mode = 'single rank'
     if world > 1:
-        eng.enable_stat_sync()
+        if dist.get_backend() == 'nccl':
+            # the library's own RCCL communicator: BatchNorm statistics exchange + the gradient all-reduce are enqueued by
+            # the library inside ONE fused step (include/ptta.h ptta_set_stat_sync_rccl / ptta_set_grad_sync_rccl)
+            eng.enable_rccl_sync()
+            mode = 'library-owned RCCL communicator (ncclAllReduce enqueued by libptta_hip on the step stream)'
+        else:
+            eng.enable_stat_sync()
+            mode = 'torch.distributed callback (%s)' % dist.get_backend()
     frames = costdcnet_frames(2, h, w)                          # every rank its own two frames of the stream
     data = [[torch.from_numpy(np.roll(x, 7 * rank, axis=-1)).cuda() for x in f] for f in frames]
 
@@ -295,9 +303,11 @@ def costdcnet_shared(args, rank, world, dist):
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 storage, bf16x3 MFMA arithmetic (fp32 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': 'CostDCNet, 480x640 VOID-shaped synthetic (1500 points), global batch = n_gpus frames, 1 TTA step, meta_bn (32 tensors)',
+            'config': {'workload': 'CostDCNet, 480x640 VOID-shaped synthetic (1500 points), global batch = n_gpus frames, 1 TTA step, meta_bn with the 32-tensor '
+                                   'single-GPU adapted list (NOT the reference\'s DDP parameter set: after convert_syncbn the reference adapts every '
+                                   'BatchNorm incl. BatchNorm3d / BatchNorm1d / the sparse encoder\'s, src/costdcnet_model_adapt.py:364-366)',
                        'parallelism': 'dp%d: SyncBatchNorm statistics exchange per BatchNorm + one flat gradient all-reduce (5,200 floats) per step' % world,
-                       'finite': finite}}))
+                       'exchange': mode, 'finite': finite}}))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,4 +1,4 @@
-/* libptta_hip — C ABI of the MI355X-native ProxyTTA test-time-adaptation step (MSG_CHN and NLSPN backbones).
+/* libptta_hip — C ABI of the MI355X-native ProxyTTA test-time-adaptation step (MSG_CHN, NLSPN and CostDCNet backbones).
  *
  * This is the drop-in boundary for the hot path of seobbro/TTA-depth-completion.  The reference
  * has no FFI for this path (it is Python calling ATen); each entry point below names the Python
@@ -32,7 +32,8 @@ typedef void* ptta_stream;              /* hipStream_t */
 /* PTTA_BACKBONE_NLSPN: ExternalModel_Adapt(model_name='nlspn') -- src/nlspn_model_adapt.py:13-128 ->
  * NLSPNModel_Adapt._rgbd_meta_contrast (external_src/NLSPN/src/model/nlspnmodel_adapt.py:850-944), adapter settings of
  * src/nlspn_model_adapt.py:56-68, adapt_parameters('meta_bn') (:322-337).  meta_mode must be PTTA_META_1LAYER (optionally | PTTA_NLSPN_LEGACY_OFFSET), dtype
- * PTTA_DTYPE_F32, height and width multiples of 16.  Differences from the MSG_CHN handle: embeddings are (rows, 1024)
+ * PTTA_DTYPE_F32, any height and width >= 16 (sizes that are not multiples of 16 follow the reference's ceil-halving encoder
+ * maps and decoder crops, nlspnmodel_adapt.py:474-490).  Differences from the MSG_CHN handle: embeddings are (rows, 1024)
  * with rows = n*(H/16)*(W/16); ptta_adapted_count() is 88 (conv1_rgb_meta + every BatchNorm2d weight/bias, in the
  * reference's order) and every one of them must be bound; ptta_load_weights ignores BatchNorm running statistics
  * (dropped by 'meta_bn') and the values of adapted tensors (the bound tensors are read instead);
@@ -49,7 +50,7 @@ typedef void* ptta_stream;              /* hipStream_t */
  * 'meta_bn'); the other remarks of PTTA_BACKBONE_NLSPN apply. */
 enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1, PTTA_BACKBONE_COSTDCNET = 2 };
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
-enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };
+enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };   /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
 /* NLSPN only, OR-ed into meta_mode: ExternalModel_Adapt(..., offset=True) -> args.legacy (src/nlspn_model_adapt.py:62):
  * the confidence gathers add each tap's own (dy, dx) to the learned offset (nlspnmodel_adapt.py:297-302).
  * src/tta_main.py:309-317 always constructs the model this way. */
@@ -58,7 +59,7 @@ enum { PTTA_NLSPN_LEGACY_OFFSET = 0x100,
         * SyncBatchNorm BEFORE adapt_parameters('meta_bn') (:339), whose isinstance test (src/nlspn_model_adapt.py:329-331) then
         * also matches the heads' three BatchNorm1d: 94 adapted tensors (proj.1, proj_t.1, pred.1 weight/bias appended in
         * module order) instead of 88.  proj / pred feed the detached embedding: their gradients stay zero. */
-       PTTA_NLSPN_SYNCBN_ADAPT = 0x200 };  /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
+       PTTA_NLSPN_SYNCBN_ADAPT = 0x200 };
 
 /* Hyper-parameters of the step.  Reference: src/tta.py:10-160 flags learning_rates,
  * optimizer_betas, optimizer_epsilon, w_weight_decay, w_loss_sparse_depth, w_loss_smoothness,
@@ -225,10 +226,27 @@ int ptta_crop_flip(const float* src, float* dst, int n, int channels, int height
  * float64, caller-owned, `capacity` elements >= 2 * 2 * widest BatchNorm), calls `fn(user, exchange_buf, count, stream)`
  * -- which must SUM the first `count` elements over the ranks in place, ordered on `stream` (torch.distributed.all_reduce
  * on RCCL does exactly that) -- and finalises with world_size x the local row count (equal local batches).  Gradients of
- * adapted BatchNorm parameters come out already averaged over the ranks.  world_size 1 switches the exchange off.
- * MSG_CHN handles replay no hipGraph while it is on. */
+ * adapted BatchNorm parameters come out already averaged over the ranks.  world_size 1 switches the exchange off (and
+ * restores graph replay / the second stream).  MSG_CHN handles replay no hipGraph while the CALLBACK form is on. */
 typedef int (*ptta_allreduce_fn)(void* user, double* exchange_buf, long long count, ptta_stream s);
 int ptta_set_stat_sync(ptta_handle h, ptta_allreduce_fn fn, void* user, double* exchange_buf, int64_t capacity, int world_size);
+
+/* The same exchange on an RCCL communicator owned by the library (the reference's backend: dist.init_process_group('nccl'),
+ * src/tta_main.py:101-111): rank 0 calls ptta_rccl_unique_id, the caller broadcasts the 128 bytes, every rank calls
+ * ptta_rccl_comm_create (ncclCommInitRank) and ptta_set_stat_sync_rccl.  The library enqueues ncclAllReduce itself on the
+ * step's stream: no host callback, and the collectives are captured into the step's hipGraph (MSG_CHN handles keep replaying).
+ * comm == NULL switches the exchange off.  ptta_rccl_allreduce_mean_f32 is the ONE gradient collective of a shared-parameter step
+ * (the adapted gradients only, instead of DDP's all-reduce of every gradient: src/msg_chn_model_adapt.py:476-480).
+ * librccl is resolved at run time (the process's own copy first); -38 when it cannot be loaded; ptta_rccl_last_error() for RCCL errors. */
+int ptta_rccl_unique_id(void* id128_host);
+int ptta_rccl_comm_create(const void* id128_host, int rank, int world_size, void** comm_out_host);
+int ptta_rccl_comm_destroy(void* comm);
+int ptta_rccl_allreduce_mean_f32(void* comm, float* buf, int64_t count, ptta_stream s);
+const char* ptta_rccl_last_error(void);
+int ptta_set_stat_sync_rccl(ptta_handle h, void* comm, double* exchange_buf, int64_t capacity, int world_size);
+/* DistributedDataParallel's gradient averaging inside the fused ptta_step (src/tta_main.py:354,631-633): between backward and
+ * Adam the adapted gradients are averaged over the communicator with one ncclAllReduce on the step's stream.  NULL: off. */
+int ptta_set_grad_sync_rccl(ptta_handle h, void* comm);
 
 int ptta_set_graph(ptta_handle h, int enable);
 

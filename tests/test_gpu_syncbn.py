@@ -108,3 +108,75 @@ def test_costdcnet_forward_with_global_batch_statistics():
     assert rel_mae(np.concatenate([r0['depth'], r1['depth']], 0), g['s0/depth_train']) < 1e-3
     assert np.array_equal(r0['buf'], r1['buf'])
     assert rel_mae(r0['buf'], g['s0/buf/unet3d.inc.double_conv.0.bn1.running_mean']) < 2e-3
+
+
+# ---- the library-owned RCCL communicator (ptta_rccl_*, ptta_set_stat_sync_rccl, ptta_set_grad_sync_rccl) ----------------------------
+# One GPU = one rank: the communicator has ONE rank (RCCL refuses two ranks on one device), so these tests pin the plumbing --
+# librccl resolves, the communicator initialises, the collectives are enqueued by the library on the step's stream, the MSG_CHN
+# step keeps replaying its hipGraph with the exchange on -- and that a sum / mean over one rank leaves the results unchanged.
+# The N > 1 exchange protocol itself is pinned by the two-rank gloo tests above; N > 1 RCCL remains unmeasured on hardware.
+def test_rccl_one_rank_msg_chn_step_replays_graph_and_matches():
+    from proxytta import distributed as D
+    from proxytta import synth
+    from tests.util import golden_hp, make_engine
+    g = np.load(os.path.join(GOLD, 'msgchn_1layer_32x48_n2.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    comm, world = D.rccl_communicator()
+    assert comm and world == 1
+    out = []
+    for sync in (False, True):
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, None)
+        if sync:
+            eng.enable_rccl_sync()
+            eng._chk(eng.lib.ptta_set_graph(eng.handle, 1), 'ptta_set_graph')      # graph replay is NOT refused with the RCCL exchange
+        for s in range(steps):
+            image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)]
+            info, depth = D.shared_parameter_step(eng, image, sparse) if sync else eng.step(image, sparse, want_depth=True)
+        torch.cuda.synchronize()
+        out.append((info.cpu().numpy(), depth.cpu().numpy(), {k: v[0].cpu().numpy().copy() for k, v in adapted.items()},
+                    sd['proj.1.running_mean'].cpu().numpy().copy()))
+        eng.close()
+    (i0, d0, p0, b0), (i1, d1, p1, b1) = out
+    # the exchange re-expresses a BatchNorm's partial sums as one double per channel: same statistics to fp32 rounding
+    np.testing.assert_allclose(i1, i0, rtol=1e-5)
+    assert np.abs(d1 - d0).mean() / np.abs(d0).mean() < 1e-6
+    for k in p0:
+        assert np.abs(p1[k] - p0[k]).max() < 1e-6, k
+    np.testing.assert_allclose(b1, b0, rtol=1e-5, atol=1e-7)
+    # the reference's batch-2 vectors, with the exchange on
+    ref = g['s%d/depth_train' % (steps - 1)]
+    assert np.abs(d1 - ref).mean() / np.abs(ref).mean() < 1e-3
+
+
+@pytest.mark.parametrize('backbone', ['costdcnet', 'nlspn'])
+def test_rccl_one_rank_generic_engine(backbone):
+    """The op-list engine (CostDCNet: one collective per BatchNorm incl. the sparse encoder's voxel BatchNorm; NLSPN) with the
+    library's RCCL exchange and the in-step gradient all-reduce: unchanged results on one rank."""
+    from proxytta import distributed as D
+    res = []
+    for sync in (False, True):
+        if backbone == 'costdcnet':
+            from tests.test_gpu_costdcnet import costdc_frame, make_costdc
+            n, h, w = 1, 64, 64
+            eng, sd, adapted = make_costdc(n, h, w)
+            raw, image1, sparse = [torch.from_numpy(x).cuda() for x in costdc_frame(0, h, w, n)]
+        else:
+            from tests.test_gpu_nlspn import make_nlspn, nlspn_frame
+            n, h, w = 1, 32, 64
+            eng, sd, adapted = make_nlspn(n, h, w)
+            raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+        if sync:
+            eng.enable_rccl_sync()
+        info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+        torch.cuda.synchronize()
+        res.append((info.cpu().numpy(), depth.cpu().numpy(), {k: v[0].cpu().numpy().copy() for k, v in adapted.items()}))
+        eng.close()
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-4)
+    assert np.abs(res[1][1] - res[0][1]).mean() / np.abs(res[0][1]).mean() < 1e-5
+    # Adam's first step is +-lr: compare where the two runs agree on the sign (a sum re-expressed in double moves near-zero gradients)
+    tot = same = 0
+    for k in res[0][2]:
+        d = np.abs(res[1][2][k] - res[0][2][k])
+        tot += d.size; same += int((d < 1e-6).sum())
+    assert same >= 0.995 * tot, (same, tot)

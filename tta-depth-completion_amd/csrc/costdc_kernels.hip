@@ -481,11 +481,11 @@ int cd_launch_sparse_bn(const CdSparse& q, const float* f, const float* res, int
     if (C > 64) return -22;
     if (train) hipLaunchKernelGGL(cd_sbn_stats_kernel, dim3(SBN_BLOCKS), dim3(64), 0, s, f, q.cnt + level, C, q.bn_part);
     const double* gsum = nullptr;
-    if (train && sync && sync->fn && sync->world > 1) {
+    if (train && sync && sync->on()) {
         if (2 * C + 1 > sync->cap) return -22;
         hipLaunchKernelGGL(cd_sbn_collapse_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, sync->buf);
-        const int rc = sync->fn(sync->user, sync->buf, 2 * C + 1, (void*)s);
-        if (rc) return rc < 0 ? rc : -rc;
+        const int rc = sync->exchange(2 * C + 1, s);
+        if (rc) return rc;
         gsum = sync->buf;
     }
     hipLaunchKernelGGL(cd_sbn_finalize_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, gamma, beta, rm, rv, nbt, train, repeats, q.bn_st, gsum);

@@ -110,17 +110,19 @@ __global__ void stat_expand_kernel(const double* __restrict__ in, int nblocks, i
         const int b = (int)(t_ % nblocks); const int pass = (int)(t_ / nblocks);
         const double v = in[((long)pass * 2 + which) * C + c];
         const float hi = (float)v;
+        // hi part in block 0, the double -> float correction in block 1; a single-block BatchNorm keeps the rounded sum only
+        // (2^-24 relative: below the fp32 statistics it replaces)
         part[i] = b == 0 ? hi : (b == 1 ? (float)(v - (double)hi) : 0.f);
     }
 }
 int ptta_stat_sync(const PttaStatSync* sy, float* part, int nblocks, int C, int npass, hipStream_t s) {
-    if (!sy || !sy->fn || sy->world <= 1) return 0;
+    if (!sy || !sy->on()) return 0;
     const long n = (long)npass * 2 * C;
     if (n > sy->cap) return -22;
     hipLaunchKernelGGL(stat_collapse_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, part, nblocks, C, npass, sy->buf);
     if (hipGetLastError() != hipSuccess) return -5;
-    const int rc = sy->fn(sy->user, sy->buf, (long long)n, (void*)s);       // SUM over the ranks, in place, ordered on `s`
-    if (rc) return rc < 0 ? rc : -rc;
+    const int rc = sy->exchange((long long)n, s);                            // SUM over the ranks, in place, ordered on `s`
+    if (rc) return rc;
     const long total = (long)npass * nblocks * 2 * C;
     long blocks = (total + 255) / 256; if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(stat_expand_kernel, dim3((int)blocks), dim3(256), 0, s, sy->buf, nblocks, C, npass, part);
@@ -187,7 +189,7 @@ int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, in
     if (fused_blocks > 0) blocks = fused_blocks;
     else hipLaunchKernelGGL((gbn_stats_kernel<0>), dim3(blocks, npass), dim3(256), lds, s, x, x, x, npass, 0, 0, nullptr, nullptr, part);
     long Rg = R;
-    if (sync && sync->world > 1) { const int rc = ptta_stat_sync(sync, part, blocks, C, npass, s); if (rc) return rc; Rg = R * sync->world; }
+    if (sync && sync->on()) { const int rc = ptta_stat_sync(sync, part, blocks, C, npass, s); if (rc) return rc; Rg = R * sync->world; }
     hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, Rg, eps, gamma, beta, st);
     if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
     const long total = (long)x.B * x.H * x.W * (C >> 2);
@@ -279,7 +281,7 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
     const float* fshift = (act_first && res_relu) ? st + 3L * npass * C : nullptr;
     hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, fscale, fshift);
     long Rg = R; float gsc = 1.f;
-    if (sync && sync->world > 1) { const int rc = ptta_stat_sync(sync, part, blocks, C, 1, s); if (rc) return rc; Rg = R * sync->world; gsc = 1.f / (float)sync->world; }
+    if (sync && sync->on()) { const int rc = ptta_stat_sync(sync, part, blocks, C, 1, s); if (rc) return rc; Rg = R * sync->world; gsc = 1.f / (float)sync->world; }
     hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, C, Rg, gamma, inv, dgamma, dbeta, bw, gsc);
     if ((C & 3) || (x.ld & 3) || (g.ld & 3) || (y.ld & 3) || (gx.ld & 3) || (gres.p && (gres.ld & 3))) return -22;
     const long total = R * (C >> 2);

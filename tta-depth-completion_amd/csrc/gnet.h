@@ -135,6 +135,7 @@ struct GNet {
     bool fwd_valid = false;
     int max_bn_C = 16;
     PttaStatSync stat_sync;               // SyncBatchNorm exchange (ptta_set_stat_sync); world == 1: off
+    void* grad_comm = nullptr;            // RCCL communicator of the gradient all-reduce inside step() (ptta_set_grad_sync_rccl)
 
     virtual ~GNet() { for (void* p : allocs) if (p) (void)hipFree(p); }
     // ---- backbone-specific ------------------------------------------------------------------------------------------

@@ -254,6 +254,7 @@ int GNet::step(const float* image, const float* loss_image, const float* sparse,
                                   Wu, loss_ws, gdepth, T[t_ref].g, s, hyper + 5, loss_info)) return fail("loss backward failed", -5);
     rc = backward(s);
     if (rc) return rc;
+    if (grad_comm && ptta_rccl_allreduce_mean_f32(grad_comm, gall, gall_n, (ptta_stream)s)) return fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
     rc = adam_step(s);
     if (rc) return rc;
     if (depth_out && hipMemcpyAsync(depth_out, depth, (size_t)NP * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("memcpy failed", -5);

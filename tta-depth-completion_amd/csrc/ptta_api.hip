@@ -97,6 +97,9 @@ struct ptta_ctx {
     // hipGraph replay of the whole step (inputs are first copied to fixed staging buffers so that
     // the captured pointers never change); one graph per (validity given, separate loss image)
     int use_graph = 1;
+    void* grad_comm = nullptr;       // RCCL communicator of the gradient all-reduce inside ptta_step (ptta_set_grad_sync_rccl)
+    float* grad_arena = nullptr; long grad_arena_n = 0;
+    int pre_sync_graph = -1, pre_sync_aux = -1;      // use_graph / use_aux as they were before ptta_set_stat_sync switched them off (-1: untouched)
     hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
     hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t cap_stream = nullptr;    // private stream to capture on (the caller's may be the un-capturable null stream)
@@ -350,7 +353,11 @@ void build_workspace(ptta_ctx* c) {
                      {std::string(p2) + "1.weight", 32L * 128 * 9}, {std::string(p2) + "1.bias", 32}, {std::string(p2) + "2.weight", 32},
                      {std::string(p2) + "2.bias", 32}};
         else names = {{"conv1_rgb_meta.weight", 9216}, {"conv1_rgb_meta.bias", 32}};
-        for (auto& nm : names) { ptta_ctx::Adapted ad; ad.name = nm.first; ad.n = nm.second; ad.g = c->falloc(nm.second); c->adapted.push_back(ad); }
+        // one arena for every adapted gradient: the shared-parameter step all-reduces it as ONE message (ptta_set_grad_sync_rccl)
+        long gtot = 0; for (auto& nm : names) gtot += (nm.second + 3) & ~3L;
+        c->grad_arena = c->falloc((size_t)gtot); c->grad_arena_n = gtot;
+        long goff = 0;
+        for (auto& nm : names) { ptta_ctx::Adapted ad; ad.name = nm.first; ad.n = nm.second; ad.g = c->grad_arena + goff; goff += (nm.second + 3) & ~3L; c->adapted.push_back(ad); }
         if (c->meta_mode == PTTA_META_2LAYERS) {
             auto& m2 = c->m2;
             for (int g = 0; g < 4; ++g) {
@@ -1284,6 +1291,8 @@ static int step_body(ptta_handle c, const float* image, const float* loss_image,
     RUN(ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
                                   c->N, c->H, c->W, c->loss_ws, c->g_final, c->gref_buf, s, c->hyper + 5, c->loss_info));
     RUN(ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_));
+    // shared-parameter run (the reference's DDP, src/tta_main.py:354,631-633): mean of the adapted gradients over the ranks, one message
+    if (c->grad_comm && ptta_rccl_allreduce_mean_f32(c->grad_comm, c->grad_arena, c->grad_arena_n, s_)) return c->fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
     RUN(ptta_adam_step(c, nullptr, nullptr, s_));
     return 0;
 }
@@ -1560,7 +1569,43 @@ int ptta_set_stat_sync(ptta_handle c, ptta_allreduce_fn fn, void* user, double* 
     if (world_size > 1 && c->meta_mode == PTTA_META_2LAYERS && !c->m2.generic) return c->fail("SyncBatchNorm needs the default arithmetic for the 2layers meta layer", -38);
     c->stat_sync = sy;
     c->drop_graphs();
-    if (world_size > 1) { c->use_graph = 0; c->use_aux = 0; }      // the step contains host-driven collectives: no graph replay, one stream
+    if (world_size > 1) {               // the step contains host-driven collectives: no graph replay, one stream
+        if (c->pre_sync_graph < 0) { c->pre_sync_graph = c->use_graph; c->pre_sync_aux = c->use_aux; }
+        c->use_graph = 0; c->use_aux = 0;
+    } else if (c->pre_sync_graph >= 0) {     // exchange switched off again: back to the replayed, two-stream step
+        c->use_graph = c->pre_sync_graph; c->use_aux = c->pre_sync_aux; c->pre_sync_graph = c->pre_sync_aux = -1;
+    }
+    return 0;
+}
+
+// The same exchange on the library's own RCCL communicator (rccl_sync.hip): the collectives are enqueued by the library on the
+// step's stream, so they are captured into the step's hipGraph like any kernel -- graph replay stays on; only the second stream
+// is given up (collectives of one communicator are kept in one stream order).  comm == NULL or world_size == 1 with comm == NULL: off.
+int ptta_set_stat_sync_rccl(ptta_handle c, void* comm, double* exchange_buf, int64_t capacity, int world_size) {
+    if (!c || world_size < 1 || (comm && (!exchange_buf || capacity < 2 * 1024))) return -22;
+    PttaStatSync sy; sy.comm = comm; sy.buf = exchange_buf; sy.cap = (long)capacity; sy.world = world_size;
+    if (c->nl) { c->err.clear(); c->nl->stat_sync = sy; return 0; }
+    if (comm && c->meta_mode == PTTA_META_2LAYERS && !c->m2.generic) return c->fail("SyncBatchNorm needs the default arithmetic for the 2layers meta layer", -38);
+    c->stat_sync = sy;
+    c->drop_graphs();
+    if (comm) {
+        if (c->pre_sync_graph < 0) { c->pre_sync_graph = c->use_graph; c->pre_sync_aux = c->use_aux; }
+        else c->use_graph = c->pre_sync_graph;         // coming from the callback mode: the graph is available again
+        c->use_aux = 0;
+    } else if (c->pre_sync_graph >= 0) {
+        c->use_graph = c->pre_sync_graph; c->use_aux = c->pre_sync_aux; c->pre_sync_graph = c->pre_sync_aux = -1;
+    }
+    return 0;
+}
+
+// DistributedDataParallel's gradient averaging (src/msg_chn_model_adapt.py:476-480) for the fused ptta_step: between backward and
+// Adam the adapted gradients (one arena: 37 KB for MSG_CHN 1layer) are averaged over the communicator's ranks with ONE
+// ncclAllReduce enqueued on the step's stream (captured into the hipGraph).  comm == NULL: off.
+int ptta_set_grad_sync_rccl(ptta_handle c, void* comm) {
+    if (!c) return -1;
+    if (c->nl) { c->nl->grad_comm = comm; return 0; }
+    c->grad_comm = comm;
+    c->drop_graphs();
     return 0;
 }
 
@@ -1568,7 +1613,7 @@ int ptta_set_graph(ptta_handle c, int enable) {
     if (c && c->nl) return c->fail("not available for the NLSPN / CostDCNet backbones: use ptta_step / ptta_forward_*", -38);
 
     if (!c) return -1;
-    if (enable && c->stat_sync.world > 1) return c->fail("graph replay is not available with SyncBatchNorm exchange (ptta_set_stat_sync)", -38);
+    if (enable && c->stat_sync.on() && !c->stat_sync.comm) return c->fail("graph replay is not available with SyncBatchNorm exchange (ptta_set_stat_sync)", -38);
     c->use_graph = enable ? 1 : 0;
     if (!enable) c->drop_graphs();
     return 0;

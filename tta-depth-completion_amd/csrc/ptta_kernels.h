@@ -74,7 +74,18 @@ int ptta_launch_outlier_removal(const float* sparse, const float* validity, floa
 // block 0 (+ a low-order correction in block 1) so that the unchanged finalize kernels see GLOBAL sums; the row count they
 // divide by is multiplied by the world size (equal local batches, as DistributedSampler + drop_last give).
 typedef int (*ptta_allreduce_cb)(void* user, double* dev_buf, long long count, void* stream);
-struct PttaStatSync { ptta_allreduce_cb fn = nullptr; void* user = nullptr; double* buf = nullptr; long cap = 0; int world = 1; };
+int ptta_rccl_sum_f64(void* comm, double* buf, long long count, hipStream_t s);                                // rccl_sync.hip
+struct PttaStatSync {
+    ptta_allreduce_cb fn = nullptr; void* user = nullptr;     // caller's collective (torch.distributed: gloo or RCCL through Python) ...
+    void* comm = nullptr;                                     // ... or the library's own RCCL communicator (ptta_set_stat_sync_rccl): enqueued here, capturable
+    double* buf = nullptr; long cap = 0; int world = 1;
+    bool on() const { return (fn || comm) && (world > 1 || comm); }       // a communicator of ONE rank still exchanges (plumbing test)
+    int exchange(long long count, hipStream_t s) const {                // SUM over the ranks of buf[0..count), in place, ordered on s
+        if (comm) return ptta_rccl_sum_f64(comm, buf, count, s);
+        const int rc = fn(user, buf, count, (void*)s);
+        return rc ? (rc < 0 ? rc : -rc) : 0;
+    }
+};
 int ptta_stat_sync(const PttaStatSync* sy, float* part, int nblocks, int C, int npass, hipStream_t s);      // gbn.hip
 
 // ---- heads.hip --------------------------------------------------------------------------------

@@ -66,6 +66,13 @@ SIGNATURES = [
     ('ptta_head_get_grad', c_int, [_P, c_char_p, _P, c_int64, POINTER(c_int), _P]),
     ('ptta_crop_flip', c_int, [_P, _P] + [c_int] * 6 + [_P] * 5),
     ('ptta_set_stat_sync', c_int, [_P, _P, _P, _P, c_int64, c_int]),
+    ('ptta_rccl_unique_id', c_int, [_P]),
+    ('ptta_rccl_comm_create', c_int, [_P, c_int, c_int, POINTER(c_void_p)]),
+    ('ptta_rccl_comm_destroy', c_int, [_P]),
+    ('ptta_rccl_allreduce_mean_f32', c_int, [_P, _P, c_int64, _P]),
+    ('ptta_rccl_last_error', c_char_p, []),
+    ('ptta_set_stat_sync_rccl', c_int, [_P, _P, _P, c_int64, c_int]),
+    ('ptta_set_grad_sync_rccl', c_int, [_P, _P]),
     ('ptta_set_graph', c_int, [_P, c_int]),
     ('ptta_profile', c_int, [_P, c_int]),
     ('ptta_profile_read', c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),

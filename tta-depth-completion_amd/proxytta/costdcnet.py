@@ -72,6 +72,19 @@ class CostDCNetModel_Adapt(MsgChnModel_Adapt):
         params = dict(self.model.named_parameters())
         return nn.ParameterList([params[k] for k in self.adapted])
 
+    def convert_syncbn(self, apex=False):
+        """SyncBatchNorm.convert_sync_batchnorm (src/costdcnet_model_adapt.py:535-546).  KNOWN DIFFERENCE from the reference's DDP
+        run: the reference converts BEFORE adapt_parameters('meta_bn') (src/tta_main.py:326,339), after which its isinstance test
+        (src/costdcnet_model_adapt.py:364-366) also matches UNet3D's BatchNorm3d, the heads' BatchNorm1d and the BatchNorm1d inside
+        every MinkowskiBatchNorm: ALL of them become adapted and lose their running statistics.  This mirror keeps the 32-tensor
+        single-GPU list (Encoder2D's BatchNorm2d + conv1_rgb_meta) with tracked running statistics elsewhere and exchanges the
+        statistics of every BatchNorm; the sparse encoder has no backward here.  A warning says so once."""
+        import warnings
+        warnings.warn('CostDCNetModel_Adapt.convert_syncbn: the reference\'s DDP run adapts EVERY BatchNorm after the SyncBatchNorm '
+                      'conversion (src/tta_main.py:326,339; src/costdcnet_model_adapt.py:364-366); this path keeps the 32-tensor '
+                      'single-GPU adapted list -- statistics are exchanged, the adapted set differs from the reference\'s')
+        super().convert_syncbn(apex)
+
     def state_dict(self):
         """The reference's state_dict lists ResBlock.norm3 a second time as downsample.1 (same tensors)."""
         sd = self.model.state_dict()

@@ -39,6 +39,39 @@ def allreduce_adapted_grads(grads, group=None):
     return grads
 
 
+_rccl = {}
+
+
+def rccl_communicator(group=None):
+    """(comm handle, world size) of the library-owned RCCL communicator of this process (include/ptta.h ptta_rccl_*): rank 0
+    draws the unique id, torch.distributed (any backend: it only carries 128 bytes, once) broadcasts it, every rank joins.
+    Without an initialised process group: a one-rank communicator."""
+    import ctypes
+    from . import _lib
+    key = id(group)
+    if key in _rccl:
+        return _rccl[key]
+    lib = _lib.load()
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    ident = ctypes.create_string_buffer(128)
+    if rank == 0:
+        rc = lib.ptta_rccl_unique_id(ident)
+        if rc:
+            raise RuntimeError('ptta_rccl_unique_id failed (%d): %s' % (rc, lib.ptta_rccl_last_error().decode()))
+    if world > 1:
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = ctypes.create_string_buffer(box[0], 128)
+    comm = ctypes.c_void_p()
+    rc = lib.ptta_rccl_comm_create(ident, rank, world, ctypes.byref(comm))
+    if rc:
+        raise RuntimeError('ptta_rccl_comm_create failed (%d): %s' % (rc, lib.ptta_rccl_last_error().decode()))
+    _rccl[key] = (comm.value, world)
+    return _rccl[key]
+
+
 _warned = []
 
 
@@ -46,6 +79,9 @@ def shared_parameter_step(engine, image, sparse, validity=None, loss_image=None,
     """Batched TTA across ranks with shared adapted parameters: local forward / loss / backward
     through the library, one gradient all-reduce, fused Adam with the reduced gradients.
     `w` = (w_sparse_depth, w_smoothness, w_cos); default: the engine's hyper-parameters."""
+    if getattr(engine, '_rccl_grads', False) and w is None:
+        # library-owned RCCL communicator: statistics exchange, gradient all-reduce and Adam are all inside ONE fused step
+        return engine.step(image, sparse, validity=validity, loss_image=loss_image, want_depth=True)
     if w is None:
         w = (engine.hp.w_sparse_depth, engine.hp.w_smoothness, engine.hp.w_cos)
     if (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and not _warned

@@ -276,6 +276,30 @@ class Engine:
         self._chk(self.lib.ptta_set_stat_sync(self.handle, ctypes.cast(cb, c_void_p), None, c_void_p(buf.data_ptr()), buf.numel(), world),
                   'ptta_set_stat_sync')
 
+    def enable_rccl_sync(self, comm=None, world=None, stats=True, grads=True):
+        """The reference's DDP + SyncBatchNorm run (src/tta_main.py:326-354) on the library's own RCCL communicator: the
+        BatchNorm statistics exchange (`stats`) and the mean all-reduce of the adapted gradients between backward and Adam of the
+        fused step (`grads`) are enqueued by the library on the step's stream -- no Python frame per collective, and the MSG_CHN
+        step keeps replaying its hipGraph.  `comm`: a handle from proxytta.distributed.rccl_communicator() (default: the
+        process-wide one).  None/None with no process group = a one-rank communicator (plumbing test)."""
+        from . import distributed as D
+        if comm is None:
+            comm, world = D.rccl_communicator()
+        self._keep['rccl'] = comm
+        if stats:
+            buf = torch.zeros(4 * 2 * 1024, device=self.device, dtype=torch.float64)
+            self._keep['stat_sync'] = (buf, None)
+            self._chk(self.lib.ptta_set_stat_sync_rccl(self.handle, c_void_p(comm), c_void_p(buf.data_ptr()), buf.numel(), int(world)), 'ptta_set_stat_sync_rccl')
+        if grads:
+            self._chk(self.lib.ptta_set_grad_sync_rccl(self.handle, c_void_p(comm)), 'ptta_set_grad_sync_rccl')
+        self._rccl_grads = bool(grads)
+
+    def disable_rccl_sync(self):
+        self._chk(self.lib.ptta_set_stat_sync_rccl(self.handle, None, None, 0, 1), 'ptta_set_stat_sync_rccl')
+        self._chk(self.lib.ptta_set_grad_sync_rccl(self.handle, None), 'ptta_set_grad_sync_rccl')
+        self._rccl_grads = False
+        self._keep.pop('stat_sync', None)
+
     # ---- stage-2 head trainer (include/ptta.h "Stage-2 head trainer"; src/head_main.py:464-480) ------------
     def bind_head(self, name, param, exp_avg=None, exp_avg_sq=None):
         ts = [t for t in (param, exp_avg, exp_avg_sq) if t is not None]

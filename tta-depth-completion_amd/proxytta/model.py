@@ -257,8 +257,19 @@ class MsgChnModel_Adapt(object):
                 eng.bind_head(k, params[k].data)
             hp = getattr(self, '_head_hp', None) or dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, tau=0.999)
             eng.set_head_hparams(adam_step=getattr(self, '_head_t', 0), **hp)
+            eng._head_t = getattr(self, '_head_t', 0)
             eng._heads_bound = True
         return eng
+
+    def _sync_head_step(self, eng):
+        """Counterpart of _sync_adam_step for the stage-2 heads: every (batch, height, width) engine has its own device-side
+        step count, torch.optim.Adam has ONE `step` per parameter -- a second engine (the last short batch of a loader) must
+        continue the bias correction where the first one stands."""
+        t = getattr(self, '_head_t', 0)
+        if getattr(eng, '_head_t', None) != t:
+            hp = getattr(self, '_head_hp', None) or dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, tau=0.999)
+            eng.set_head_hparams(adam_step=t, **hp)
+            eng._head_t = t
 
     def head_forward(self, image, sparse_depth, loss_type):
         """forward(loss_type='head_selfsup_seq_ema[_reverse]') in training mode: (None, embedding, reference)
@@ -283,8 +294,17 @@ class MsgChnModel_Adapt(object):
     def head_step(self, image, sparse_depth, loss_type):
         """Fused stage-2 step (head_main.py:464-480): EMA, forward, prepare loss, backward, Adam -- one library call."""
         eng = self._head_engine(image)
-        loss = eng.head_step(image, sparse_depth, 'reverse' in loss_type)
+        # the library keeps ONE step count for the head tensors, torch.optim.Adam one per parameter: in `reverse` mode only
+        # `pred` steps, so a run that switches between the two loss types would give proj pred's count -> refused
+        rev = 'reverse' in loss_type
+        if getattr(self, '_head_mode', rev) != rev and getattr(self, '_head_t', 0) > 0:
+            raise NotImplementedError('head_step: switching between reverse and non-reverse loss types inside one run is not supported '
+                                      '(per-parameter Adam step counts would diverge)')
+        self._head_mode = rev
+        self._sync_head_step(eng)
+        loss = eng.head_step(image, sparse_depth, rev)
         self._head_t = getattr(self, '_head_t', 0) + 1
+        eng._head_t = self._head_t
         live = self._head_names if 'reverse' not in loss_type else [k for k in self._head_names if k.startswith('pred')]
         for k in live:
             st = self._head_state[k]

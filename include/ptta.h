@@ -218,6 +218,26 @@ int ptta_head_get_grad(ptta_handle h, const char* name, float* dst, int64_t capa
 int ptta_crop_flip(const float* src, float* dst, int n, int channels, int height, int width, int crop_height, int crop_width,
                    const int32_t* start_y, const int32_t* start_x, const uint8_t* hflip, const uint8_t* vflip, ptta_stream s);
 
+/* The other augmentations the adapt scripts enable (bash/adapt/adapt_msgchn_vkitti.sh:34-41; applied in every step,
+ * src/tta_main.py:595-605).  The reference implements them with torchvision.transforms.functional 0.10.1 (third party, absent
+ * from the reference tree: parity unpinned); each call restates torchvision's tensor algorithm.  All handle-free, enqueue only,
+ * per-sample decisions as device arrays (uint8 flags; a sample whose flag is 0 is copied), dst must not alias src.
+ *   ptta_rotate         Transforms.rotate (src/transforms.py:1036-1070): functional.rotate(image, angle[b] degrees, interpolation,
+ *                       expand=False): affine grid about the image centre + grid_sample(align_corners=False, zeros);
+ *                       bilinear = 0 nearest (depth, validity, ground truth), 1 bilinear (image)  (src/tta_main.py:471-473)
+ *   ptta_resize_crop    Transforms.resize_and_crop (:1222-1283): functional.resize to (resize_height[b], resize_width[b]) then the crop
+ *                       [start_y[b] : +height, start_x[b] : +width] back to the input size; scale_depth = resize_scaling_depth
+ *   ptta_photometric    brightness -> contrast -> saturation (:714-838, :236-311) on uint8-valued 3-channel images (the reference casts
+ *                       float images to uint8 first); any do_* pointer may be NULL (transform not configured); scratch: 256*n doubles */
+int ptta_rotate(const float* src, float* dst, int n, int channels, int height, int width, const uint8_t* do_rotate, const float* angle_deg,
+                int bilinear, ptta_stream s);
+int ptta_resize_crop(const float* src, float* dst, int n, int channels, int height, int width, const uint8_t* do_resize,
+                     const int32_t* resize_height, const int32_t* resize_width, const int32_t* start_y, const int32_t* start_x,
+                     int bilinear, int scale_depth, ptta_stream s);
+int ptta_photometric(const float* src, float* dst, int n, int height, int width, const uint8_t* do_brightness, const float* f_brightness,
+                     const uint8_t* do_contrast, const float* f_contrast, const uint8_t* do_saturation, const float* f_saturation,
+                     double* scratch, ptta_stream s);
+
 /* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
  * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
 /* model.convert_syncbn() (src/tta_main.py:326 -> SyncBatchNorm.convert_sync_batchnorm, src/msg_chn_model_adapt.py:547-556)

@@ -71,13 +71,142 @@ def test_crop_flip_full_size_against_index_arithmetic(shape):
 
 def test_transforms_refuse_what_is_not_built():
     with pytest.raises(NotImplementedError):
-        Transforms(random_brightness=[0.5, 1.5])
+        Transforms(random_gamma=[0.5, 1.5])
+    with pytest.raises(NotImplementedError):
+        Transforms(random_hue=[-0.1, 0.1])
     with pytest.raises(NotImplementedError):
         Transforms(normalized_image_range=[0, 1])
     with pytest.raises(NotImplementedError):
-        Transforms(random_rotate_max=10)
+        Transforms(random_crop_and_pad=[0.5, 1.0])
     with pytest.raises(ValueError):
         Transforms(random_crop_to_shape=[1, 2, 3])
+
+
+# ---- rotation / resize-and-crop / photometric jitter (torchvision calls in the reference: parity unpinned; oracle = torchvision's
+# ---- tensor algorithms on torch's own grid_sample / interpolate) ------------------------------------------------------------------
+def _img(n, c, H, W, seed, integer=False):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, c, H, W), dtype=np.float32) * 255.0
+    return np.floor(x) if integer else x
+
+
+@pytest.mark.parametrize('shape', [(2, 37, 53), (2, 352, 1216), (1, 480, 640)])
+def test_rotate_matches_torchvision_algorithm(shape):
+    n, H, W = shape
+    x = _img(n, 3, H, W, 11)
+    do = torch.tensor([1] + [0] * (n - 1) if n > 1 else [1], dtype=torch.uint8)
+    ang = torch.tensor([4.3, -2.0][:n], dtype=torch.float64)
+    t = Transforms(random_rotate_max=5)
+    d = {'crop': None, 'hflip': None, 'vflip': None, 'rotate': (do, ang), 'resize': None}
+    xg = torch.from_numpy(x).cuda()
+    for mode in ('nearest', 'bilinear'):
+        [y] = t.apply([xg], d, [mode])
+        ref = TO.rotate(torch.from_numpy(x), do.tolist(), ang.tolist(), mode == 'bilinear').numpy()
+        got = y.cpu().numpy()
+        if mode == 'nearest':
+            # a pixel whose source coordinate sits within float rounding of a half-integer may pick the neighbour: < 0.1 % of them
+            assert (got != ref).mean() < 1e-3
+        else:
+            assert np.abs(got - ref).max() < 0.05 and np.abs(got - ref).mean() < 1e-3          # 0-255 scale
+        if n > 1:
+            np.testing.assert_array_equal(got[1], x[1])            # coin said no: untouched
+    # angle 0 = identity (nearest: exactly)
+    d0 = dict(d, rotate=(torch.ones(n, dtype=torch.uint8), torch.zeros(n, dtype=torch.float64)))
+    assert torch.equal(t.apply([xg], d0, ['nearest'])[0], xg)
+    assert float((t.apply([xg], d0, ['bilinear'])[0] - xg).abs().max()) < 0.1          # float32 grid coordinates (as torchvision): 1e-4 px x 255
+    # 4 degrees forth and back: the interior comes back (bilinear smoothing aside), the corners were rotated out to zero
+    ds = dict(d, rotate=(torch.ones(n, dtype=torch.uint8), torch.full((n,), 4.0, dtype=torch.float64)))
+    [r1] = t.apply([xg], ds, ['nearest'])
+    assert float(r1[:, :, 0, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('shape', [(2, 37, 53), (2, 352, 1216), (1, 480, 640)])
+def test_resize_and_crop_matches_torchvision_algorithm(shape):
+    n, H, W = shape
+    x = _img(n, 3, H, W, 12)
+    sd = _img(n, 1, H, W, 13)
+    do = torch.tensor(([1, 0] * n)[:n], dtype=torch.uint8)
+    rh = torch.tensor([int(1.27 * H), int(1.1 * H)][:n], dtype=torch.int32)
+    rw = torch.tensor([int(1.41 * W), int(1.2 * W)][:n], dtype=torch.int32)
+    sy = torch.tensor([(int(1.27 * H) - H) // 2, 1][:n], dtype=torch.int32)
+    sx = torch.tensor([int(1.41 * W) - W, 0][:n], dtype=torch.int32)
+    t = Transforms(random_resize_and_crop=[1.0, 1.5])
+    d = {'crop': None, 'hflip': None, 'vflip': None, 'rotate': None, 'resize': (do, rh, rw, sy, sx, H, W)}
+    im, dep = t.apply([torch.from_numpy(x).cuda(), torch.from_numpy(sd).cuda()], d, ['bilinear', 'nearest'])
+    ref_im = TO.resize_and_crop(torch.from_numpy(x), do.tolist(), rh, rw, sy, sx, True).numpy()
+    ref_dep = TO.resize_and_crop(torch.from_numpy(sd), do.tolist(), rh, rw, sy, sx, False).numpy()
+    assert np.abs(im.cpu().numpy() - ref_im).max() < 0.05 and np.abs(im.cpu().numpy() - ref_im).mean() < 1e-3
+    assert (dep.cpu().numpy() != ref_dep).mean() < 1e-3
+    # scale 1 with a zero offset = identity, both modes
+    one = {'crop': None, 'hflip': None, 'vflip': None, 'rotate': None,
+           'resize': (torch.ones(n, dtype=torch.uint8), torch.full((n,), H, dtype=torch.int32), torch.full((n,), W, dtype=torch.int32),
+                      torch.zeros(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int32), H, W)}
+    a, b = t.apply([torch.from_numpy(x).cuda(), torch.from_numpy(sd).cuda()], one, ['bilinear', 'nearest'])
+    assert torch.equal(b.cpu(), torch.from_numpy(sd)) and float((a.cpu() - torch.from_numpy(x)).abs().max()) < 1e-3
+    # resize_scaling_depth divides the non-image tensors by rw / W
+    ts = Transforms(random_resize_and_crop=[1.0, 1.5], resize_scaling_depth=True)
+    _, dep2 = ts.apply([torch.from_numpy(x).cuda(), torch.from_numpy(sd).cuda()], d, ['bilinear', 'nearest'])
+    np.testing.assert_allclose(dep2.cpu().numpy()[0], dep.cpu().numpy()[0] / (float(rw[0]) / W), rtol=1e-6)
+
+
+@pytest.mark.parametrize('shape', [(2, 37, 53), (2, 352, 1216)])
+def test_photometric_matches_torchvision_algorithm(shape):
+    n, H, W = shape
+    x = _img(n, 3, H, W, 14)                                           # fractional values: the uint8 cast truncates
+    on = torch.ones(n, dtype=torch.uint8)
+    off = torch.zeros(n, dtype=torch.uint8)
+    t = Transforms(random_brightness=[0.6, 1.4], random_contrast=[0.6, 1.4], random_saturation=[0.6, 1.4])
+    fb, fc, fs = torch.tensor([1.31, 0.7][:n]), torch.tensor([0.64, 1.38][:n]), torch.tensor([1.22, 0.61][:n])
+    for bb, cc, ss in ((on, on, on), (on, off, off), (off, on, off), (off, off, on), (off, off, off)):
+        d = {'crop': None, 'hflip': None, 'vflip': None, 'rotate': None, 'resize': None, 'brightness': (bb, fb), 'contrast': (cc, fc), 'saturation': (ss, fs)}
+        [y] = t.apply([torch.from_numpy(x).cuda()], d)
+        ref = TO.photometric(torch.from_numpy(x), (bb, fb), (cc, fc), (ss, fs)).numpy()
+        got = y.cpu().numpy()
+        assert np.abs(got - ref).max() <= 1.0 and (got != ref).mean() < 2e-3       # a product within float rounding of an integer may truncate one level lower
+        assert np.array_equal(got, np.floor(got)) and got.min() >= 0 and got.max() <= 255
+    # factor 1 everywhere = the uint8 cast alone
+    one = torch.ones(n)
+    d = {'crop': None, 'hflip': None, 'vflip': None, 'rotate': None, 'resize': None, 'brightness': (on, one), 'contrast': (on, one), 'saturation': (on, one)}
+    np.testing.assert_array_equal(t.apply([torch.from_numpy(x).cuda()], d)[0].cpu().numpy(), np.floor(x))
+
+
+def test_adapt_script_flags_construct_and_run():
+    """Transforms(**flags of bash/adapt/adapt_msgchn_vkitti.sh:34-41) as src/tta_main.py:446-462 builds its two objects, one call
+    each as :595-605: same seed -> the oracle's draw-by-draw restatement gives the same tensors; intrinsics follow :447-451, :493-497."""
+    n, H, W = 2, 96, 160
+    geo = Transforms(random_crop_to_shape=[-1, -1], random_flip_type=['horizontal'], random_rotate_max=5,
+                     random_crop_and_pad=[-1, -1], random_resize_and_pad=[-1, -1], random_resize_and_crop=[1.0, 1.5])
+    pho = Transforms(normalized_image_range=None, random_brightness=[0.6, 1.4], random_contrast=[0.6, 1.4], random_gamma=[-1, -1],
+                     random_hue=[-1, -1], random_saturation=[0.6, 1.4], random_noise_type='none', random_noise_spread=-1)
+    image = torch.from_numpy(_img(n, 3, H, W, 21, integer=True)).cuda()
+    sparse = torch.from_numpy((_img(n, 1, H, W, 22) * (np.random.default_rng(5).random((n, 1, H, W)) < 0.05)).astype(np.float32)).cuda()
+    K = torch.tensor([[[100., 0., 80.], [0., 110., 48.], [0., 0., 1.]]] * n).cuda()
+    seen = 0
+    for seed in range(6):
+        torch.manual_seed(seed); np.random.seed(seed)
+        [im, sd], [K2] = geo.transform(images_arr=[image, sparse], intrinsics_arr=[K], interpolation_modes=[2, 0], random_transform_probability=1.0)
+        d = geo.last_draw
+        [im1] = pho.transform(images_arr=[im], random_transform_probability=1.0)
+        dp = pho.last_draw
+        assert im.shape == image.shape and sd.shape == sparse.shape and im1.shape == image.shape
+        # the oracle, fed the same decisions
+        x, s_ = image.cpu(), sparse.cpu()
+        hf = d['hflip'].bool().numpy()
+        dd = {'crop': None, 'hflip': hf, 'vflip': np.zeros(n, bool)}
+        x, s_ = torch.from_numpy(TO.apply(x.numpy(), dd)), torch.from_numpy(TO.apply(s_.numpy(), dd))
+        x, s_ = TO.rotate(x, d['rotate'][0].tolist(), d['rotate'][1].tolist(), True), TO.rotate(s_, d['rotate'][0].tolist(), d['rotate'][1].tolist(), False)
+        do, rh, rw, sy, sx, nh, nw = d['resize']
+        x, s_ = TO.resize_and_crop(x, do.tolist(), rh, rw, sy, sx, True), TO.resize_and_crop(s_, do.tolist(), rh, rw, sy, sx, False)
+        assert np.abs(im.cpu().numpy() - x.numpy()).mean() < 1e-3 and (sd.cpu().numpy() != s_.numpy()).mean() < 2e-3
+        ref1 = TO.photometric(im.cpu(), dp['brightness'], dp['contrast'], dp['saturation'])
+        assert (im1.cpu() - ref1).abs().max() <= 1.0
+        Kr = K.cpu().clone()
+        for b in range(n):                                              # every sample, whatever its coin (as the reference)
+            Kr[b, 0, 0] *= float(rw[b]) / nw; Kr[b, 0, 2] = Kr[b, 0, 2] * (float(rw[b]) / nw) - float(rw[b] - nw)
+            Kr[b, 1, 1] *= float(rh[b]) / nh; Kr[b, 1, 2] = Kr[b, 1, 2] * (float(rh[b]) / nh) - float(rh[b] - nh)
+        np.testing.assert_allclose(K2.cpu().numpy(), Kr.numpy(), rtol=1e-6)
+        seen += int(d['rotate'][0].sum()) + int(do.sum())
+    assert seen > 0
 
 
 def test_flipped_frame_gives_flipped_free_step():

@@ -33,3 +33,170 @@ extern "C" int ptta_crop_flip(const float* src, float* dst, int n, int channels,
                        crop_height, crop_width, start_y, start_x, hflip, vflip);
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
+
+// ---- rotation, resize-and-crop, photometric jitter: the augmentations every adapt script enables (bash/adapt/adapt_msgchn_vkitti.sh:
+// 34-41: rotate <= 5 degrees, resize_and_crop 1.0-1.5, brightness / contrast / saturation 0.6-1.4), applied inside every step
+// (src/tta_main.py:595-605).  The reference implements them with torchvision.transforms.functional (absent from this image and from
+// the reference tree: PARITY UNPINNED); the kernels restate torchvision 0.10.1's published tensor algorithms, and the oracle
+// (oracle/transforms_oracle.py) restates them with the torch primitives torchvision itself calls (grid_sample, interpolate).
+
+// Transforms.rotate (src/transforms.py:1036-1070) -> functional.rotate(image, angle, interpolation, expand=False) on a tensor:
+// inverse matrix [cos a, -sin a, 0; sin a, cos a, 0] about the image centre, affine grid over pixel centres
+// (x_c = ox + 0.5 - W/2), grid_sample(align_corners=False, padding zeros), nearest (round half to even) or bilinear.
+__global__ void rotate_kernel(const float* __restrict__ src, float* __restrict__ dst, int c, int H, int W,
+                              const unsigned char* __restrict__ do_rotate, const float* __restrict__ angle_deg, int bilinear) {
+    const int b = blockIdx.z;
+    const long plane = (long)H * W;
+    const bool on = do_rotate[b] != 0;
+    float m0 = 1.f, m1 = 0.f, m3 = 0.f, m4 = 1.f;
+    if (on) {
+        const double a = (double)angle_deg[b] * 3.14159265358979323846 / 180.0;     // math.radians / math.cos / math.sin (double), then float32 theta
+        m0 = (float)cos(a); m1 = (float)(-sin(a)); m3 = (float)sin(a); m4 = (float)cos(a);
+    }
+    const float t00 = m0 / (0.5f * W), t10 = m1 / (0.5f * W), t01 = m3 / (0.5f * H), t11 = m4 / (0.5f * H);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        const int oy = (int)(i / W), ox = (int)(i - (long)oy * W);
+        if (!on) { for (int ch = 0; ch < c; ++ch) dst[((long)b * c + ch) * plane + i] = src[((long)b * c + ch) * plane + i]; continue; }
+        const float xc = -0.5f * W + 0.5f + ox, yc = -0.5f * H + 0.5f + oy;
+        const float gx = xc * t00 + yc * t10, gy = xc * t01 + yc * t11;
+        const float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+        if (!bilinear) {
+            const float rx = nearbyintf(ix), ry = nearbyintf(iy);
+            const bool ok = rx >= 0.f && rx <= (float)(W - 1) && ry >= 0.f && ry <= (float)(H - 1);
+            const long si = ok ? (long)ry * W + (long)rx : 0;
+            for (int ch = 0; ch < c; ++ch) dst[((long)b * c + ch) * plane + i] = ok ? src[((long)b * c + ch) * plane + si] : 0.f;
+        } else {
+            const float fx = floorf(ix), fy = floorf(iy);
+            const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+            const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+            const bool okx0 = x0 >= 0 && x0 < W, okx1 = x1 >= 0 && x1 < W, oky0 = y0 >= 0 && y0 < H, oky1 = y1 >= 0 && y1 < H;
+            for (int ch = 0; ch < c; ++ch) {
+                const float* s = src + ((long)b * c + ch) * plane;
+                float v = 0.f;                                   // grid_sample's order: nw, ne, sw, se
+                if (oky0 && okx0) v += s[(long)y0 * W + x0] * (wx0 * wy0);
+                if (oky0 && okx1) v += s[(long)y0 * W + x1] * (wx1 * wy0);
+                if (oky1 && okx0) v += s[(long)y1 * W + x0] * (wx0 * wy1);
+                if (oky1 && okx1) v += s[(long)y1 * W + x1] * (wx1 * wy1);
+                dst[((long)b * c + ch) * plane + i] = v;
+            }
+        }
+    }
+}
+
+// Transforms.resize_and_crop (src/transforms.py:1222-1283): functional.resize(image, (rh, rw), interpolation) = F.interpolate
+// (nearest: src = min(floor(dst * in/out), in-1); bilinear, align_corners=False: src = max((dst + 0.5) * in/out - 0.5, 0)), then the
+// crop [sy : sy+H, sx : sx+W] back to the original size -- fused: only the cropped window of the resized image is ever computed.
+// depth_div: the reference's resize_scaling_depth (image /= rw / W for the non-image tensors).
+__global__ void resize_crop_kernel(const float* __restrict__ src, float* __restrict__ dst, int c, int H, int W,
+                                   const unsigned char* __restrict__ do_it, const int* __restrict__ rh_, const int* __restrict__ rw_,
+                                   const int* __restrict__ sy_, const int* __restrict__ sx_, int bilinear, int depth_div) {
+    const int b = blockIdx.z;
+    const long plane = (long)H * W;
+    const bool on = do_it[b] != 0;
+    const int rh = rh_[b], rw = rw_[b], sy = sy_[b], sx = sx_[b];
+    const float scy = (float)H / (float)rh, scx = (float)W / (float)rw;
+    const float div = depth_div ? (float)rw / (float)W : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        if (!on) { for (int ch = 0; ch < c; ++ch) dst[((long)b * c + ch) * plane + i] = src[((long)b * c + ch) * plane + i]; continue; }
+        const int oy = (int)(i / W), ox = (int)(i - (long)oy * W);
+        const int Y = oy + sy, X = ox + sx;                       // pixel of the resized image
+        if (!bilinear) {
+            const int yy = min((int)floorf((float)Y * scy), H - 1), xx = min((int)floorf((float)X * scx), W - 1);
+            for (int ch = 0; ch < c; ++ch) { const float v = src[((long)b * c + ch) * plane + (long)yy * W + xx]; dst[((long)b * c + ch) * plane + i] = depth_div ? v / div : v; }
+        } else {
+            float fy = scy * ((float)Y + 0.5f) - 0.5f, fx = scx * ((float)X + 0.5f) - 0.5f;
+            fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float ly1 = fy - (float)y0, ly0 = 1.f - ly1, lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+            for (int ch = 0; ch < c; ++ch) {
+                const float* s = src + ((long)b * c + ch) * plane;
+                const float v = ly0 * (lx0 * s[(long)y0 * W + x0] + lx1 * s[(long)y0 * W + x1]) + ly1 * (lx0 * s[(long)y1 * W + x0] + lx1 * s[(long)y1 * W + x1]);
+                dst[((long)b * c + ch) * plane + i] = depth_div ? v / div : v;
+            }
+        }
+    }
+}
+
+// Photometric jitter on uint8-valued images (Transforms.transform casts float images to uint8 first, src/transforms.py:236-241):
+// brightness -> contrast -> saturation, each torchvision's _blend(img1, img2, ratio) = (ratio * img1 + (1 - ratio) * img2).clamp(0, 255)
+// truncated back to uint8; img2 = 0 (brightness), the sample's mean of the uint8 grayscale (contrast), the uint8 grayscale (saturation);
+// grayscale = trunc(0.2989 r + 0.587 g + 0.114 b).  Contrast needs a per-sample mean of the brightness-adjusted image: two passes.
+__device__ __forceinline__ float u8trunc(float v) { v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v); return floorf(v); }
+__device__ __forceinline__ float gray_u8(float r, float g, float bl) { return floorf(0.2989f * r + 0.587f * g + 0.114f * bl); }
+#define PH_BLOCKS 256
+__global__ __launch_bounds__(256) void photo_pass1_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W,
+                                                          const unsigned char* __restrict__ do_b, const float* __restrict__ f_b,
+                                                          double* __restrict__ part) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    const long plane = (long)H * W;
+    const bool on = do_b && do_b[b];
+    const float f = on ? f_b[b] : 1.f;
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        float v[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float x = u8trunc(src[((long)b * 3 + ch) * plane + i]);                 // .to(torch.uint8)
+            if (on) x = u8trunc(f * x);                                              // _blend(img, zeros, f)
+            v[ch] = x; dst[((long)b * 3 + ch) * plane + i] = x;
+        }
+        acc += (double)gray_u8(v[0], v[1], v[2]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)b * PH_BLOCKS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void photo_pass2_kernel(float* __restrict__ img, int H, int W, const double* __restrict__ part,
+                                                          const unsigned char* __restrict__ do_c, const float* __restrict__ f_c,
+                                                          const unsigned char* __restrict__ do_s, const float* __restrict__ f_s) {
+    const int b = blockIdx.y;
+    const long plane = (long)H * W;
+    const bool oc = do_c && do_c[b], os = do_s && do_s[b];
+    if (!oc && !os) return;
+    float mean = 0.f;
+    if (oc) { double s = 0.0; for (int k = 0; k < PH_BLOCKS; ++k) s += part[(long)b * PH_BLOCKS + k]; mean = (float)(s / (double)plane); }
+    const float fc = oc ? f_c[b] : 1.f, gc = (float)(1.0 - (double)fc);
+    const float fs = os ? f_s[b] : 1.f, gs = (float)(1.0 - (double)fs);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += (long)gridDim.x * blockDim.x) {
+        float v[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { v[ch] = img[((long)b * 3 + ch) * plane + i]; if (oc) v[ch] = u8trunc(fc * v[ch] + gc * mean); }
+        if (os) { const float g = gray_u8(v[0], v[1], v[2]);
+#pragma unroll
+                  for (int ch = 0; ch < 3; ++ch) v[ch] = u8trunc(fs * v[ch] + gs * g); }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) img[((long)b * 3 + ch) * plane + i] = v[ch];
+    }
+}
+
+extern "C" int ptta_rotate(const float* src, float* dst, int n, int channels, int height, int width, const uint8_t* do_rotate,
+                           const float* angle_deg, int bilinear, ptta_stream stream) {
+    if (!src || !dst || src == dst || !do_rotate || !angle_deg || n <= 0 || n > 65535 || channels <= 0 || height <= 0 || width <= 0) return -22;
+    long blocks = ((long)height * width + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rotate_kernel, dim3((unsigned)blocks, 1, n), dim3(256), 0, (hipStream_t)stream, src, dst, channels, height, width, do_rotate, angle_deg, bilinear ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+extern "C" int ptta_resize_crop(const float* src, float* dst, int n, int channels, int height, int width, const uint8_t* do_resize,
+                                const int32_t* resize_height, const int32_t* resize_width, const int32_t* start_y, const int32_t* start_x,
+                                int bilinear, int scale_depth, ptta_stream stream) {
+    if (!src || !dst || src == dst || !do_resize || !resize_height || !resize_width || !start_y || !start_x || n <= 0 || n > 65535 ||
+        channels <= 0 || height <= 0 || width <= 0) return -22;
+    long blocks = ((long)height * width + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(resize_crop_kernel, dim3((unsigned)blocks, 1, n), dim3(256), 0, (hipStream_t)stream, src, dst, channels, height, width, do_resize,
+                       resize_height, resize_width, start_y, start_x, bilinear ? 1 : 0, scale_depth ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+extern "C" int ptta_photometric(const float* src, float* dst, int n, int height, int width, const uint8_t* do_brightness, const float* f_brightness,
+                                const uint8_t* do_contrast, const float* f_contrast, const uint8_t* do_saturation, const float* f_saturation,
+                                double* scratch, ptta_stream stream) {
+    if (!src || !dst || !scratch || n <= 0 || n > 65535 || height <= 0 || width <= 0) return -22;
+    if ((do_brightness && !f_brightness) || (do_contrast && !f_contrast) || (do_saturation && !f_saturation)) return -22;
+    hipLaunchKernelGGL(photo_pass1_kernel, dim3(PH_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, src, dst, height, width, do_brightness, f_brightness, scratch);
+    if (do_contrast || do_saturation)
+        hipLaunchKernelGGL(photo_pass2_kernel, dim3(PH_BLOCKS, n), dim3(256), 0, (hipStream_t)stream, dst, height, width, scratch, do_contrast, f_contrast, do_saturation, f_saturation);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
+}

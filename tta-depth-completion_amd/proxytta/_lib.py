@@ -65,6 +65,9 @@ SIGNATURES = [
     ('ptta_head_step', c_int, [_P, _P, _P, c_int, _P, _P]),
     ('ptta_head_get_grad', c_int, [_P, c_char_p, _P, c_int64, POINTER(c_int), _P]),
     ('ptta_crop_flip', c_int, [_P, _P] + [c_int] * 6 + [_P] * 5),
+    ('ptta_rotate', c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    ('ptta_resize_crop', c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    ('ptta_photometric', c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     ('ptta_set_stat_sync', c_int, [_P, _P, _P, _P, c_int64, c_int]),
     ('ptta_rccl_unique_id', c_int, [_P]),
     ('ptta_rccl_comm_create', c_int, [_P, c_int, c_int, POINTER(c_void_p)]),

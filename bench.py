@@ -175,7 +175,7 @@ def two_streams_workload(steps=100, nstreams=2):
     return out
 
 
-def nlspn_workload(frames=3, inner_iter=3):
+def nlspn_workload(frames=10, inner_iter=3):
     """BASELINE config 3 (not the headline metric): NLSPN backbone, 352x1216, 3 TTA steps per frame + the scored eval
     forward, adapt_mode meta_bn (88 adapted tensors), batch 1, inputs resident in HBM.  Reported beside the metric."""
     from proxytta import synth
@@ -218,7 +218,7 @@ def nlspn_workload(frames=3, inner_iter=3):
     return out
 
 
-def head_stage2_workload(steps=20):
+def head_stage2_workload(steps=30):
     """Stage-2 head trainer step (src/head_main.py:464-480) at the headline shape, both loss types; beside the metric."""
     from proxytta import synth
     from proxytta.engine import HEAD_PARAMS, HEAD_TARGETS, Engine
@@ -376,7 +376,13 @@ def costdcnet_frames(count, h, w):
     return out
 
 
-def costdcnet_workload(frames=6):
+# one CostDCNet TTA step at 480x640 with 1500 points, counted with forward hooks on the REAL reference by tools/costdcnet_count.py
+# (SURVEY.md section 8d's rule: per conv / linear / sparse-conv layer input + output + weight elements; minimal backward)
+COSTDC_ALG = {'forward_elements': 1079523516, 'forward_gmac': 212.040342912, 'backward_min_elements': 517284352, 'backward_min_gmac': 105.2539392,
+              'eval_forward_elements': 538339550, 'eval_forward_gmac': 105.838309056}
+
+
+def costdcnet_workload(frames=30):
     """BASELINE config 5's per-GPU work (not the headline metric): CostDCNet, 480x640 VOID-shaped frame with 1500 sparse points,
     1 TTA step per frame (bash/adapt/adapt_costdc_*.sh: inner_iter 1) + the scored eval forward, adapt_mode meta_bn (32 adapted
     tensors), batch 1, inputs resident in HBM."""
@@ -407,6 +413,17 @@ def costdcnet_workload(frames=6):
                        '1 TTA step/frame, meta_bn (32 adapted tensors), batch 1',
            'ms_per_step': 1e3 * t_step, 'frames_per_s': 1.0 / t_step, 'eval_forward_ms': 1e3 * t_eval,
            'finite': bool(torch.isfinite(info).all().item() and torch.isfinite(d).all().item())}
+    alg_bytes = 4.0 * (COSTDC_ALG['forward_elements'] + COSTDC_ALG['backward_min_elements'])
+    alg_gmac = COSTDC_ALG['forward_gmac'] + COSTDC_ALG['backward_min_gmac']
+    out['step_roofline'] = {
+        'bound': 'hbm', 'alg_bytes_per_step': alg_bytes, 'alg_gmac_per_step': alg_gmac, 'achieved': alg_bytes / t_step / 1e9, 'peak': HBM_PEAK / 1e9,
+        'unit': 'GB/s', 'frac': alg_bytes / t_step / HBM_PEAK,
+        'eval_forward': {'alg_bytes': 4.0 * COSTDC_ALG['eval_forward_elements'], 'alg_gmac': COSTDC_ALG['eval_forward_gmac'],
+                         'frac': 4.0 * COSTDC_ALG['eval_forward_elements'] / t_eval / HBM_PEAK},
+        'mfma_frac_useful': 2e9 * alg_gmac / t_step / MFMA_BF16_PEAK,
+        'note': 'algorithmic bytes / MACs measured with forward hooks on the reference (tools/costdcnet_count.py, SURVEY 8d rule: BatchNorm / ELU / '
+                'pooling / fusion traffic counted as fused = 0); arithmetic: bf16x6 forward for the real frames, bf16x3 elsewhere; '
+                'AI = 99 FLOP/B < ridge 312: HBM is the binding roof'}
     eng.close()
     return out
 

@@ -38,7 +38,9 @@ typedef void* ptta_stream;              /* hipStream_t */
  * reference's order) and every one of them must be bound; ptta_load_weights ignores BatchNorm running statistics
  * (dropped by 'meta_bn') and the values of adapted tensors (the bound tensors are read instead);
  * ptta_backward ignores its two output pointers (read the 88 gradients with ptta_get_grad) and ptta_adam_step takes
- * NULL gradients (it uses the internal ones); ptta_set_graph and ptta_profile return -38. */
+ * NULL gradients (it uses the internal ones); after ptta_set_graph(h, 1) (or PTTA_GRAPH=1) ptta_step and ptta_forward_eval replay
+ * captured hipGraphs from their second call on (default off for these handles: measured no faster than plain launches);
+ * ptta_profile returns -38. */
 /* PTTA_BACKBONE_COSTDCNET: ExternalModel_Adapt(model_name='costdcnet') -- src/costdcnet_model_adapt.py:31-114 ->
  * CostDCNet._rgbd_meta_contrast (external_src/costdcnet/CostDCNet_adapt.py:207-256), res = 16 planes, up_scale = 4
  * (src/costdcnet_model_adapt.py:47-52), adapt_parameters('meta_bn') (:357-378).  meta_mode PTTA_META_1LAYER, dtype

@@ -231,3 +231,25 @@ def test_external_model_adapt_facade_costdcnet(golden_dir):
     sd = model.model.state_dict()
     assert list(sd.keys()) == [k for k, _ in synth.costdcnet_keys()]
     assert rel_mae(sd['unet3d.inc.double_conv.0.bn1.running_mean'], g['s0/buf/unet3d.inc.double_conv.0.bn1.running_mean']) < 2e-3
+
+
+def test_graph_replay_equals_kernel_by_kernel_launches():
+    """ptta_step / ptta_forward_eval replay captured hipGraphs from their second call on (the op-list engine): three steps and
+    two eval forwards with replay give bit-identical parameters, statistics and depth maps to PTTA_GRAPH=0."""
+    n, h, w = 1, 64, 96
+    res = []
+    for graph in (0, 1):
+        eng, sd, ad = make_costdc(n, h, w)
+        eng._chk(eng.lib.ptta_set_graph(eng.handle, graph), 'ptta_set_graph')
+        for s in range(3):
+            raw, image1, sparse = [torch.from_numpy(x).cuda() for x in costdc_frame(s, h, w, n)]
+            info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+            d_eval = eng.forward_eval(image1, sparse)
+        torch.cuda.synchronize()
+        res.append((info.clone(), depth.clone(), d_eval.clone(), {k: v[0].clone() for k, v in ad.items()},
+                    sd['unet3d.inc.double_conv.0.bn1.running_mean'].clone()))
+        eng.close()
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k

@@ -344,6 +344,9 @@ GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth
     const char* impl = getenv("PTTA_CONV_IMPL");
     e->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
     { const char* x6 = getenv("PTTA_X6"); e->x6 = e->naive ? 0 : (x6 ? (atoi(x6) ? 1 : 0) : 1); }      // default ON: DESIGN.md section 10 (parity of the post-update depth)
+    // hipGraph replay of the step / eval forward: built and bit-identical (tests), but measured 0.3 - 2 % SLOWER than kernel-by-kernel
+    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: PTTA_GRAPH=1 / ptta_set_graph(h, 1)
+    { const char* gr = getenv("PTTA_GRAPH"); e->use_graph = (gr && strcmp(gr, "1") == 0) ? 1 : 0; }
     e->build();
     if (e->oom || !e->step_dev) { delete e; *rc = -12; return nullptr; }
     if (e->upload_hparams(nullptr)) { delete e; *rc = -5; return nullptr; }

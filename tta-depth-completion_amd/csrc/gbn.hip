@@ -129,21 +129,47 @@ int ptta_stat_sync(const PttaStatSync* sy, float* part, int nblocks, int C, int 
     return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-// forward finalize: per (pass, c): mean, inv, scale = gamma*inv, shift = beta - mean*scale   (st = [4][npass][C])
+// forward finalize: per (pass, c): mean, inv, scale = gamma*inv, shift = beta - mean*scale   (st = [4][npass][C]).  One wave per channel,
+// the passes in order.  TRACKED BatchNorm (rm != null; CostDCNet's BatchNorm3d / BatchNorm1d): the momentum update of the running
+// statistics -- one per pass in order, `repeats` times each, exactly gbn_running_update_kernel's arithmetic -- and the eval-mode affine
+// of the UPDATED statistics (st_eval = [mean, inv, scale, shift][C]) come out of the same launch (two launches per BatchNorm fewer
+// per step + eval forward).
+struct GbnTrack { float* rm; float* rv; long long* nbt; float momentum; int repeats; float* st_eval; };
 __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* __restrict__ part, int nblocks, int npass, int C, long R, float eps,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ st) {
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (idx >= npass * C) return;
-    const int pass = idx / C, c = idx % C;
-    double s1, s2;
-    gbn_sum_partials(part + ((long)pass * nblocks * 2) * C, nblocks, C, c, s1, s2);
-    if (threadIdx.x & 63) return;
-    const double m = s1 / (double)R;
-    double var = s2 / (double)R - m * m; if (var < 0.0) var = 0.0;
-    const float iv = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * iv;
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ st,
+                                                           GbnTrack tr) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
     const int n = npass * C;
-    st[idx] = (float)m; st[n + idx] = iv; st[2 * n + idx] = sc; st[3 * n + idx] = beta[c] - (float)m * sc;
+    float m_run = 0.f, v_run = 0.f;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    if (tr.rm && lane0) { m_run = tr.rm[c]; v_run = tr.rv[c]; }
+    for (int pass = 0; pass < npass; ++pass) {
+        double s1, s2;
+        gbn_sum_partials(part + ((long)pass * nblocks * 2) * C, nblocks, C, c, s1, s2);
+        if (!lane0) continue;
+        const double m = s1 / (double)R;
+        double var = s2 / (double)R - m * m; if (var < 0.0) var = 0.0;
+        const float iv = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * iv;
+        const int idx = pass * C + c;
+        st[idx] = (float)m; st[n + idx] = iv; st[2 * n + idx] = sc; st[3 * n + idx] = beta[c] - (float)m * sc;
+        if (tr.rm) {
+            double v2 = 1.0 / ((double)iv * (double)iv) - (double)eps;          // as gbn_running_update_kernel (from the stored inv)
+            if (v2 < 0.0) v2 = 0.0;
+            const float unb = (float)(R > 1 ? v2 * (double)R / (double)(R - 1) : v2);
+            const float mu = (float)m;
+            for (int k = 0; k < tr.repeats; ++k) { m_run = (1.f - tr.momentum) * m_run + tr.momentum * mu; v_run = (1.f - tr.momentum) * v_run + tr.momentum * unb; }
+        }
+    }
+    if (tr.rm && lane0) {
+        tr.rm[c] = m_run; tr.rv[c] = v_run;
+        if (c == 0 && tr.nbt) *tr.nbt += (long long)npass * tr.repeats;
+        if (tr.st_eval) {
+            const float iv = 1.f / sqrtf(v_run + eps), sc = gamma[c] * iv;
+            tr.st_eval[c] = m_run; tr.st_eval[C + c] = iv; tr.st_eval[2 * C + c] = sc; tr.st_eval[3 * C + c] = beta[c] - m_run * sc;
+        }
+    }
 }
 
 // y = act(x*scale+shift) ; with res: y = relu(x*scale+shift + res)   (BasicBlock.forward, nlspnmodel_adapt.py:98-116)
@@ -181,7 +207,8 @@ __global__ void gbn_apply_kernel(GView x, GView res, GView y, int npass, int act
 // fused_blocks > 0: `part` was already filled by the producing convolution's epilogue ([pass][fused_blocks][2][C]), skip the
 // statistics pass
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
-                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks, int act_first, const PttaStatSync* sync) {
+                            const float* beta, float* part, float* st, hipStream_t s, int fused_blocks, int act_first, const PttaStatSync* sync,
+                            float* rm, float* rv, long long* nbt, float momentum, int repeats, float* st_eval) {
     const int C = x.C, CT = C < 256 ? C : 256, nsub = 256 / CT;
     const size_t lds = (size_t)nsub * 2 * CT * sizeof(float);
     const long R = (long)(x.B / npass) * x.H * x.W;
@@ -190,7 +217,8 @@ int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, in
     else hipLaunchKernelGGL((gbn_stats_kernel<0>), dim3(blocks, npass), dim3(256), lds, s, x, x, x, npass, 0, 0, nullptr, nullptr, part);
     long Rg = R;
     if (sync && sync->on()) { const int rc = ptta_stat_sync(sync, part, blocks, C, npass, s); if (rc) return rc; Rg = R * sync->world; }
-    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((npass * C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, Rg, eps, gamma, beta, st);
+    const GbnTrack tr{rm, rv, nbt, momentum, repeats, st_eval};
+    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, Rg, eps, gamma, beta, st, tr);
     if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
     const long total = (long)x.B * x.H * x.W * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;

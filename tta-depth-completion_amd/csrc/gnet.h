@@ -89,6 +89,8 @@ struct Op {
     bool act_first = false;           // with a residual: y = relu(act(bn(x)) + res) instead of relu(bn(x) + res)
     int stat_repeats = 1;             // the reference runs this layer `repeats` times per training forward on the same input
     float *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
+    float* st_eval = nullptr;         // tracked: eval-mode affine [mean, inv, scale, shift][C] of the running statistics
+    mutable bool st_eval_valid = false;   // written by the last training forward's finalize (or an eval forward); cleared by every load()
     // func: fx = tensors whose gradient buffers the backward closure writes (first_x[k] tells it to overwrite or accumulate)
     int fx[2] = {-1, -1};
     std::function<int(bool, hipStream_t)> ffwd;
@@ -137,7 +139,34 @@ struct GNet {
     PttaStatSync stat_sync;               // SyncBatchNorm exchange (ptta_set_stat_sync); world == 1: off
     void* grad_comm = nullptr;            // RCCL communicator of the gradient all-reduce inside step() (ptta_set_grad_sync_rccl)
 
-    virtual ~GNet() { for (void* p : allocs) if (p) (void)hipFree(p); }
+    // ---- hipGraph replay of the fused step and of the eval forward (fixed shapes, ~450 / ~200 launches): the caller's frames are staged
+    // at fixed addresses, everything else the launches read is handle-owned or bound memory.  The FIRST call of each kind runs eagerly
+    // (lazy one-time work must not happen under capture); graphs are dropped whenever a pointer or a baked-in constant changes.
+    int use_graph = 1;
+    bool eager_step_done = false, eager_eval_done = false;
+    hipGraph_t graph[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};          // step: key = (own loss image) | 2 (caller's validity); 4 = eval forward
+    hipGraphExec_t gexec[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t cap_stream = nullptr;
+    hipEvent_t ev_replay = nullptr;
+    float *gi_image = nullptr, *gi_loss = nullptr, *gi_sparse = nullptr, *gi_valid = nullptr;
+    void drop_graphs() {
+        if (ev_replay) (void)hipEventSynchronize(ev_replay);
+        for (int k = 0; k < 5; ++k) {
+            if (gexec[k]) { (void)hipGraphExecDestroy(gexec[k]); gexec[k] = nullptr; }
+            if (graph[k]) { (void)hipGraphDestroy(graph[k]); graph[k] = nullptr; }
+        }
+    }
+    bool graph_ok() const { return use_graph && !(stat_sync.on() && !stat_sync.comm); }       // a host callback inside the step cannot be captured
+    int stage_inputs(const float* image, const float* loss_image, const float* sparse, const float* validity, hipStream_t s);
+    int replay(int key, std::function<int(hipStream_t)> body, hipStream_t s);
+    int step_body(const float* image, const float* loss_image, const float* sparse, const float* validity, hipStream_t s);
+
+    virtual ~GNet() {
+        drop_graphs();
+        if (ev_replay) (void)hipEventDestroy(ev_replay);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        for (void* p : allocs) if (p) (void)hipFree(p);
+    }
     // ---- backbone-specific ------------------------------------------------------------------------------------------
     virtual int forward(const float* image, const float* sparse, bool train, hipStream_t s) = 0;    // fills `depth`
     virtual int backward(hipStream_t s) = 0;                    // consumes gdepth and T[t_ref].g
@@ -231,7 +260,7 @@ struct GNet {
         if (C > max_bn_C) max_bn_C = C;
         if (frozen) frozen_bn[bname] = std::make_pair(falloc(C), falloc(C));
         else { o.ad_g = add_adapted(bname + ".weight", C); o.ad_beta = add_adapted(bname + ".bias", C); }
-        o.st = falloc((size_t)4 * 2 * C);
+        o.st = falloc((size_t)4 * 2 * C); o.st_eval = falloc((size_t)4 * C);
         // statistics fused into the producing convolution's epilogue when that is the stride-1 matrix-core kernel
         for (int k = (int)ops.size() - 1; k >= 0; --k) {
             Op& pr = ops[k];
@@ -374,7 +403,7 @@ struct GNet {
     }
 
     // ---- the C-ABI entry points (ptta_api.hip forwards to these) ---------------------------------------------------------
-    int set_hparams(const ptta_hparams* h, hipStream_t s) { hp = *h; return upload_hparams(s); }
+    int set_hparams(const ptta_hparams* h, hipStream_t s) { if (h->max_input_depth != hp.max_input_depth) drop_graphs(); hp = *h; return upload_hparams(s); }
     int set_image_norm(float div, const float* mean, const float* stdv);
     int bind_adapted(const char* name, float* p, float* m, float* v);
     int adapted_count() const { return (int)adapted.size(); }
@@ -400,4 +429,5 @@ struct GNet {
                       int64_t rows_, float* grad_depth_out, float* grad_ref_out, hipStream_t s);
     int backward_from(const float* grad_depth, const float* grad_ref, hipStream_t s);
     int adam_step(hipStream_t s);
+    int upload_adam_table(hipStream_t s);
 };

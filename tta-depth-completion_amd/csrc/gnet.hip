@@ -21,6 +21,8 @@ __global__ void gnet_validity_kernel(const float* __restrict__ sp, float* __rest
 int GNet::load(const char* name_c, const void* tensor_, const int64_t* shape, int ndim, hipStream_t s) {
     const std::string name(name_c);
     const float* src = (const float*)tensor_;
+    for (Op& o : ops) o.st_eval_valid = false;                        // any load may change an affine parameter or a running statistic
+    drop_graphs();                                                    // ... or re-bind a running-statistics pointer
     if (aid.count(name)) return 0;                                   // adapted: the bound tensor is authoritative
     const size_t dot = name.rfind('.');
     if (dot == std::string::npos) return load_extra(name, src, shape, ndim, s);
@@ -112,20 +114,22 @@ int GNet::run_bn_fwd(const Op& o, bool train, hipStream_t s) {
     const int npass = (o.xw[0] == W_BOTH && train) ? 2 : 1;
     if (o.tracked && !train) {                              // eval mode: running statistics
         if (!o.rm || !o.rv) return fail("running statistics of " + o.bname + " not loaded", -3);
-        if (ptta_launch_gbn_eval_affine(bn_gamma(o), bn_beta(o), o.rm, o.rv, BN_EPS, x.C, o.st, s) ||
-            ptta_launch_gbn_apply(x, res, y, 1, o.act, o.st, 1, s, o.act_first ? 1 : 0))
+        // the affine of the running statistics is left behind by the training forward's finalize; computed here only after a load()
+        if (!o.st_eval_valid) {
+            if (ptta_launch_gbn_eval_affine(bn_gamma(o), bn_beta(o), o.rm, o.rv, BN_EPS, x.C, o.st_eval, s)) return fail("batch-norm " + o.bname + " (eval) launch failed", -5);
+            o.st_eval_valid = true;
+        }
+        if (ptta_launch_gbn_apply(x, res, y, 1, o.act, o.st_eval, 1, s, o.act_first ? 1 : 0))
             return fail("batch-norm " + o.bname + " (eval) launch failed", -5);
         return 0;
     }
     GView xt = x; review(xt, o.rH, o.rW);
     const int fused = o.fused_from >= 0 ? ptta_gconv_x3_tiles(xt.B / npass, xt.H, xt.W) : 0;
-    if (ptta_launch_gbn_forward(x, res, y, npass, o.act, BN_EPS, bn_gamma(o), bn_beta(o), fused ? o.part : bn_part, o.st, s, fused, o.act_first ? 1 : 0, &stat_sync))
+    const bool upd = o.tracked && train && o.rm && o.rv;      // running statistics + eval affine out of the finalize launch
+    if (ptta_launch_gbn_forward(x, res, y, npass, o.act, BN_EPS, bn_gamma(o), bn_beta(o), fused ? o.part : bn_part, o.st, s, fused, o.act_first ? 1 : 0, &stat_sync,
+                                upd ? o.rm : nullptr, upd ? o.rv : nullptr, upd ? o.nbt : nullptr, 0.1f, o.stat_repeats, upd ? o.st_eval : nullptr))
         return fail("batch-norm " + o.bname + " launch failed", -5);
-    if (o.tracked && train && o.rm && o.rv) {
-        const long R = (long)(x.B / npass) * x.H * x.W * (stat_sync.world > 1 ? stat_sync.world : 1);
-        if (ptta_launch_gbn_running_update(o.st, npass, x.C, R, 0.1f, BN_EPS, o.rm, o.rv, o.nbt, o.stat_repeats, s))
-            return fail("running statistics of " + o.bname + " failed", -5);
-    }
+    if (upd) o.st_eval_valid = true;
     return 0;
 }
 
@@ -201,6 +205,7 @@ int GNet::set_image_norm(float div, const float* mean, const float* stdv) {
     if (!(div > 0.f)) return fail("ptta_set_image_norm: divisor must be positive", -22);
     norm_div = div;
     for (int k = 0; k < 3; ++k) { norm_mean[k] = mean ? mean[k] : 0.f; norm_std[k] = stdv ? stdv[k] : 1.f; if (!(norm_std[k] > 0.f)) return fail("std must be positive", -22); }
+    drop_graphs();                                 // the constants are kernel arguments of the captured launches
     norm_on = !(div == 1.f && norm_mean[0] == 0.f && norm_mean[1] == 0.f && norm_mean[2] == 0.f && norm_std[0] == 1.f &&
                 norm_std[1] == 1.f && norm_std[2] == 1.f);
     return 0;
@@ -209,6 +214,7 @@ int GNet::bind_adapted(const char* name, float* p, float* m, float* v) {
     auto it = aid.find(name ? name : "");
     if (it == aid.end()) return fail(std::string("not an adapted parameter: ") + (name ? name : "(null)"), -2);
     Adapted& a = adapted[it->second];
+    if (a.p != p || a.m != m || a.v != v) drop_graphs();
     a.p = p; a.m = m; a.v = v;
     adam_tab_dirty = true;
     return 0;
@@ -222,30 +228,89 @@ int GNet::forward_train(const float* image, const float* sparse, float* depth_ou
     if (ref && hipMemcpyAsync(ref, T[t_ref].p, eb, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("memcpy failed", -5);
     return 0;
 }
+int GNet::stage_inputs(const float* image, const float* loss_image, const float* sparse, const float* validity, hipStream_t s) {
+    const size_t ib = (size_t)Nu * 3 * Hu * Wu * sizeof(float), pb = (size_t)Nu * Hu * Wu * sizeof(float);
+    if (!gi_image) {                                     // once, outside any capture
+        gi_image = falloc((size_t)Nu * 3 * Hu * Wu); gi_loss = falloc((size_t)Nu * 3 * Hu * Wu);
+        gi_sparse = falloc((size_t)Nu * Hu * Wu); gi_valid = falloc((size_t)Nu * Hu * Wu);
+        if (oom) return fail("out of device memory (graph input staging)", -12);
+    }
+    NCHK(hipMemcpyAsync(gi_image, image, ib, hipMemcpyDeviceToDevice, s));
+    NCHK(hipMemcpyAsync(gi_sparse, sparse, pb, hipMemcpyDeviceToDevice, s));
+    if (loss_image && loss_image != image) NCHK(hipMemcpyAsync(gi_loss, loss_image, ib, hipMemcpyDeviceToDevice, s));
+    if (validity) NCHK(hipMemcpyAsync(gi_valid, validity, pb, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+int GNet::replay(int key, std::function<int(hipStream_t)> body, hipStream_t s) {
+    if (!gexec[key]) {
+        if (!cap_stream) NCHK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        NCHK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = body(cap_stream);
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(cap_stream, &g);
+        if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (e != hipSuccess || !g) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e), -100 - (int)e);
+        graph[key] = g;
+        NCHK(hipGraphInstantiate(&gexec[key], g, nullptr, nullptr, 0));
+    }
+    NCHK(hipGraphLaunch(gexec[key], s));
+    if (!ev_replay) NCHK(hipEventCreateWithFlags(&ev_replay, hipEventDisableTiming));
+    NCHK(hipEventRecord(ev_replay, s));
+    return 0;
+}
 int GNet::forward_eval(const float* image, const float* sparse, float* depth_out, hipStream_t s) {
-    const int rc = forward(image, sparse, false, s);
+    int rc;
+    if (graph_ok() && eager_eval_done) {
+        rc = stage_inputs(image, nullptr, sparse, nullptr, s);
+        if (rc) return rc;
+        rc = replay(4, [this](hipStream_t cs) { return forward(gi_image, gi_sparse, false, cs); }, s);
+        fwd_valid = false;
+    } else {
+        rc = forward(image, sparse, false, s);
+        eager_eval_done = true;
+    }
     if (rc) return rc;
     if (depth_out && hipMemcpyAsync(depth_out, depth, (size_t)Nu * Hu * Wu * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("memcpy failed", -5);
     return 0;
 }
+int GNet::upload_adam_table(hipStream_t s) {           // after ptta_bind_adapted only: pointer table of every adapted tensor
+    adam_host.resize(adapted.size());
+    long off = 0;
+    for (size_t k = 0; k < adapted.size(); ++k) { const Adapted& ad = adapted[k]; adam_host[k] = PttaAdamEntry{ad.p, ad.m, ad.v, gall + ad.goff, ad.n, off}; off += ad.n; }
+    NCHK(hipMemcpyAsync(adam_tab, adam_host.data(), adam_host.size() * sizeof(PttaAdamEntry), hipMemcpyHostToDevice, s));
+    adam_tab_dirty = false;
+    return 0;
+}
 int GNet::adam_step(hipStream_t s) {
     for (auto& ad : adapted) if (!ad.p || !ad.m || !ad.v) return fail("Adam state of " + ad.name + " not bound", -3);
-    if (adam_tab_dirty) {              // after ptta_bind_adapted only: pointer table of every adapted tensor
-        adam_host.resize(adapted.size());
-        long off = 0;
-        for (size_t k = 0; k < adapted.size(); ++k) { const Adapted& ad = adapted[k]; adam_host[k] = PttaAdamEntry{ad.p, ad.m, ad.v, gall + ad.goff, ad.n, off}; off += ad.n; }
-        NCHK(hipMemcpyAsync(adam_tab, adam_host.data(), adam_host.size() * sizeof(PttaAdamEntry), hipMemcpyHostToDevice, s));
-        adam_tab_dirty = false;
-    }
+    if (adam_tab_dirty) { const int rc = upload_adam_table(s); if (rc) return rc; }
     if (ptta_launch_adam_multi(adam_tab, (int)adapted.size(), gall_n, hyper, step_dev, adam_ticket, s)) return fail("adam failed", -5);
     return 0;
 }
 int GNet::step(const float* image, const float* loss_image, const float* sparse, const float* validity, float* depth_out, float* loss_info_out, hipStream_t s) {
-    for (auto& ad : adapted) if (!ad.m || !ad.v) return fail("Adam state of " + ad.name + " not bound", -3);
+    for (auto& ad : adapted) if (!ad.p || !ad.m || !ad.v) return fail("Adam state of " + ad.name + " not bound", -3);
     if (!loss_image) loss_image = image;
-    int rc = forward(image, sparse, true, s);
+    int rc;
+    if (graph_ok() && eager_step_done) {
+        const int key = (loss_image != image ? 1 : 0) | (validity ? 2 : 0);
+        rc = stage_inputs(image, loss_image, sparse, validity, s);
+        if (rc) return rc;
+        if (adam_tab_dirty) { rc = upload_adam_table(s); if (rc) return rc; }          // a host -> device copy: never under capture
+        rc = replay(key, [this, key](hipStream_t cs) { return step_body(gi_image, (key & 1) ? gi_loss : gi_image, gi_sparse, (key & 2) ? gi_valid : nullptr, cs); }, s);
+    } else {
+        rc = step_body(image, loss_image, sparse, validity, s);
+        eager_step_done = true;
+    }
     if (rc) return rc;
     const long NP = (long)Nu * Hu * Wu;
+    if (depth_out && hipMemcpyAsync(depth_out, depth, (size_t)NP * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("memcpy failed", -5);
+    if (loss_info_out && hipMemcpyAsync(loss_info_out, loss_info, 4 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("memcpy failed", -5);
+    fwd_valid = false;
+    return 0;
+}
+int GNet::step_body(const float* image, const float* loss_image, const float* sparse, const float* validity, hipStream_t s) {
+    int rc = forward(image, sparse, true, s);
+    if (rc) return rc;
     const float* emb = T[t_emb].p; const float* ref = T[t_ref].p;
     // validity == NULL: evaluated inside the loss kernels; the finalisation runs inside the two gradient kernels
     if (ptta_launch_loss_forward(depth, loss_image, sparse, validity, hp.max_input_depth, emb, ref, rows(), emb_dim(), hyper + 5,
@@ -255,12 +320,7 @@ int GNet::step(const float* image, const float* loss_image, const float* sparse,
     rc = backward(s);
     if (rc) return rc;
     if (grad_comm && ptta_rccl_allreduce_mean_f32(grad_comm, gall, gall_n, (ptta_stream)s)) return fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
-    rc = adam_step(s);
-    if (rc) return rc;
-    if (depth_out && hipMemcpyAsync(depth_out, depth, (size_t)NP * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("memcpy failed", -5);
-    if (loss_info_out && hipMemcpyAsync(loss_info_out, loss_info, 4 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return fail("memcpy failed", -5);
-    fwd_valid = false;
-    return 0;
+    return adam_step(s);
 }
 int GNet::get_grad(const char* name, float* dst, int64_t capacity, hipStream_t s) {
     auto it = aid.find(name ? name : "");

@@ -107,13 +107,16 @@ struct ptta_ctx {
     // the first decoder-3 gradients (backward); fork/join with events (graph edges under capture)
     int use_aux = 1;
     hipStream_t aux_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_real = nullptr;
+    int split_fwd = 0;               // PTTA_SPLIT_FWD bit 0: real and proxy frames of the training forward as two concurrent launch chains; bit 1: the
+                                     // depth-only head of the stage-1 encoder beside the RGB encoder (both measured SLOWER inside one graph: DESIGN.md section 8)
     hipStream_t aux(hipStream_t) {
         if (!use_aux || prof_on) return nullptr;
         if (!aux_stream) {
             if (hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
             if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; return nullptr; }
+                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_real, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; return nullptr; }
         }
         return aux_stream;
     }
@@ -640,89 +643,125 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     // ---- RGB encoder (RGBEncoder.forward :252-264) + meta layer (:481-482) ----
     // train: the proxy half of c0..c4 (zero image through frozen weights) is a constant of the handle, computed once by
     // ensure_proxy_rgb(); only the real frames go through the encoder here
-    RUN(rgb_encoder(c, image, Nn, 0, Nn, s));
-    RUN(meta_forward(c, train, B2, s));
-
-    // ---- stage 1/4 (:487-489): depth-only encoder shared by both passes ----
-    {
+    // Its first three launches need nothing from the RGB branch: with a second stream they run BESIDE the RGB encoder
+    // (forked before it, below); the fourth adds c3 and waits for the join.
+    auto enc1_head = [&](hipStream_t st) -> int {
         const LIn& li = c->lin_in["depth_encoder1.init.0"];
         ConvInArgs a; a.cin = 1; a.pl[0].p = c->d14; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H4 * W4;
         a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e1_0a;
         a.B = Nn; a.H = H4; a.W = W4; a.bf16 = c->bf16; a.naive = c->naive;
-        RUN(ptta_launch_conv_in(a, s));
+        RUN(ptta_launch_conv_in(a, st));
+        RUN(conv32(c, st, "depth_encoder1.init.2", false, CONV_S1, c->e1_0a, Nn, Nn, H4, W4, true, e_raw(c->e1_0)));
+        RUN(conv32(c, st, "depth_encoder1.enc1.1", false, CONV_S2, c->e1_0, Nn, Nn, H4, W4, true, e_raw(c->e1_1a)));
+        return 0;
+    };
+    const bool early = train && s2 && (c->split_fwd & 2);
+    if (early) {                  // depth-only head of the stage-1 encoder beside the RGB encoder
+        HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+        RUN(enc1_head(s2));
+        HIPCHK(hipEventRecord(c->ev_join, s2));
     }
-    CV("depth_encoder1.init.2", false, CONV_S1, c->e1_0a, Nn, Nn, H4, W4, true, e_raw(c->e1_0));
-    CV("depth_encoder1.enc1.1", false, CONV_S2, c->e1_0, Nn, Nn, H4, W4, true, e_raw(c->e1_1a));
+    RUN(rgb_encoder(c, image, Nn, 0, Nn, s));
+    RUN(meta_forward(c, train, B2, s));
+
+    // ---- stage 1/4 (:487-489): depth-only encoder shared by both passes ----
+    if (early) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); else RUN(enc1_head(s));
     { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
       CV("depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, B2, H8, W8, true, e); }
     CV("depth_encoder1.enc2.1", false, CONV_S2, c->e1_1, B2, Nn, H8, W8, true, e_raw(c->e1_2a));
     { E e; e.sum = c->y2; e.add1 = c->c4; e.add1_nb = B2;                                         // y2 = e1_2 + c4
       CV("depth_encoder1.enc2.3", false, CONV_S1, c->e1_2a, Nn, B2, H16, W16, true, e); }
-    // decoder 1 (DepthDecoder.forward :296-311)
-    CV("depth_decoder1.dec2.1", false, CONV_T2, c->y2, B2, B2, H16, W16, true, e_raw(c->t1));
-    { E e; e.raw = c->y3; e.sum = c->s1_1; e.add1 = c->y1; e.add1_nb = B2;
-      CV("depth_decoder1.dec2.3", false, CONV_S1, c->t1, B2, B2, H8, W8, true, e); }
-    CV("depth_decoder1.dec1.1", false, CONV_T2, c->s1_1, B2, B2, H8, W8, true, e_raw(c->u1));
-    { E e; e.raw = c->y4; e.sum = c->s0_1; e.add1 = c->e1_0; e.add1_nb = Nn; e.add2 = c->m; e.add2_nb = B2;
-      CV("depth_decoder1.dec1.3", false, CONV_S1, c->u1, B2, B2, H4, W4, true, e); }
-    CV("depth_decoder1.prdct.1", false, CONV_S1, c->s0_1, B2, B2, H4, W4, true, e_raw(c->v1));
-    {
-        const LOut& lo = c->lout["depth_decoder1.prdct.3"];
-        ConvOut1Args a; a.in = c->v1; a.in_nb = B2; a.w = lo.w; a.bias = lo.bias; a.out = c->out1;
-        a.B = B2; a.H = H4; a.W = W4; a.relu_in = 1; a.bf16 = c->bf16;
-        RUN(ptta_launch_conv_out1(a, s));
-    }
-    // ---- stage 1/2 (:491-498) ----
-    RUN(ptta_launch_up2_1ch(c->out1, c->p12, B2, H4, W4, s));
-    {
-        const LIn& li = c->lin_in["depth_encoder2.init.0"];
-        ConvInArgs a; a.cin = 2;
-        a.pl[0].p = c->d12; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H2 * W2;
-        a.pl[1].p = c->p12; a.pl[1].nb = B2; a.pl[1].bstride = (long)H2 * W2;
-        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e2_0a;
-        a.B = B2; a.H = H2; a.W = W2; a.bf16 = c->bf16; a.naive = c->naive;
-        RUN(ptta_launch_conv_in(a, s));
-    }
-    { E e; e.raw = c->e2_0; e.up = c->y4; e.up_nb = B2; CV("depth_encoder2.init.2", false, CONV_S1, c->e2_0a, B2, B2, H2, W2, true, e); }
-    CV("depth_encoder2.enc1.1", false, CONV_S2, c->e2_0, B2, B2, H2, W2, true, e_raw(c->e2_1a));
-    { E e; e.raw = c->e2_1; e.up = c->y3; e.up_nb = B2; CV("depth_encoder2.enc1.3", false, CONV_S1, c->e2_1a, B2, B2, H4, W4, true, e); }
-    CV("depth_encoder2.enc2.1", false, CONV_S2, c->e2_1, B2, B2, H4, W4, true, e_raw(c->e2_2a));
-    { E e; e.sum = c->z2; e.up = c->y2; e.up_nb = B2; e.add1 = c->c3; e.add1_nb = B2;            // z2 = e2_2 + c3
-      CV("depth_encoder2.enc2.3", false, CONV_S1, c->e2_2a, B2, B2, H8, W8, true, e); }
-    CV("depth_decoder2.dec2.1", false, CONV_T2, c->z2, B2, B2, H8, W8, true, e_raw(c->t2));
-    { E e; e.raw = c->z3; e.sum = c->s1_2; e.add1 = c->e2_1; e.add1_nb = B2; e.add2 = c->m; e.add2_nb = B2;
-      CV("depth_decoder2.dec2.3", false, CONV_S1, c->t2, B2, B2, H4, W4, true, e); }
-    CV("depth_decoder2.dec1.1", false, CONV_T2, c->s1_2, B2, B2, H4, W4, true, e_raw(c->u2));
-    { E e; e.raw = c->z4; e.sum = c->s0_2; e.add1 = c->e2_0; e.add1_nb = B2; e.add2 = c->c1; e.add2_nb = B2;
-      CV("depth_decoder2.dec1.3", false, CONV_S1, c->u2, B2, B2, H2, W2, true, e); }
-    CV("depth_decoder2.prdct.1", false, CONV_S1, c->s0_2, B2, B2, H2, W2, true, e_raw(c->v2));
-    {
-        const LOut& lo = c->lout["depth_decoder2.prdct.3"];
-        ConvOut1Args a; a.in = c->v2; a.in_nb = B2; a.w = lo.w; a.bias = lo.bias; a.add = c->p12; a.add_nb = B2; a.out = c->q;
-        a.B = B2; a.H = H2; a.W = W2; a.relu_in = 1; a.bf16 = c->bf16;                           // q = out2 + p12
-        RUN(ptta_launch_conv_out1(a, s));
-    }
-    // ---- stage 1/1 (:500-506) ----
-    RUN(ptta_launch_up2_1ch(c->q, c->p11, B2, H2, W2, s));
-    {
-        const LIn& li = c->lin_in["depth_encoder3.init.0"];
-        ConvInArgs a; a.cin = 2;
-        a.pl[0].p = c->dclamp; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H1 * W1;
-        a.pl[1].p = c->p11; a.pl[1].nb = B2; a.pl[1].bstride = (long)H1 * W1;
-        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e3_0a;
-        a.B = B2; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
-        RUN(ptta_launch_conv_in(a, s));
-    }
-    { E e; e.raw = c->e3_0; e.up = c->z4; e.up_nb = B2; CV("depth_encoder3.init.2", false, CONV_S1, c->e3_0a, B2, B2, H1, W1, true, e); }
-    CV("depth_encoder3.enc1.1", false, CONV_S2, c->e3_0, B2, B2, H1, W1, true, e_raw(c->e3_1a));
-    { E e; e.raw = c->e3_1; e.up = c->z3; e.up_nb = B2; CV("depth_encoder3.enc1.3", false, CONV_S1, c->e3_1a, B2, B2, H2, W2, true, e); }
-    CV("depth_encoder3.enc2.1", false, CONV_S2, c->e3_1, B2, B2, H2, W2, true, e_raw(c->e3_2a));
-    { E e; e.raw = c->feat; e.sum = c->w2; e.up = c->z2; e.up_nb = B2; e.add1 = c->m; e.add1_nb = B2;   // w2 = feat + m
-      CV("depth_encoder3.enc2.3", false, CONV_S1, c->e3_2a, B2, B2, H4, W4, true, e); }
-    if (train && s2) {
+
+    // ---- decoder 1, stage 1/2, encoder of stage 1/1: `Bl` frames starting at batch index b0 of the [real | proxy] batch.
+    // One pass over the whole batch (b0 = 0, Bl = B2), or -- training step with a second stream -- the real frames on `s` and
+    // the proxy frames on the auxiliary stream: the two halves are independent until the loss, and most of these 30 launches are
+    // 1/4 ... 1/16-resolution layers that leave the chip half empty.  Tensors that hold the batch once
+    // (e1_0, d12, dclamp: depth-only) are indexed modulo their own batch count and take no offset.
+    auto region = [&](hipStream_t st, int b0, int Bl) -> int {
+        auto A = [&](void* p_, int h, int w) { return (void*)((char*)p_ + (size_t)b0 * h * w * 32 * c->es); };
+        auto P1 = [&](float* p_, int h, int w) { return p_ + (size_t)b0 * h * w; };
+        auto raw = [](void* r) { E e; e.raw = r; return e; };
+#define CR(...) RUN(conv32(c, st, __VA_ARGS__))
+        // decoder 1 (DepthDecoder.forward :296-311)
+        CR("depth_decoder1.dec2.1", false, CONV_T2, A(c->y2, H16, W16), Bl, Bl, H16, W16, true, raw(A(c->t1, H8, W8)));
+        { E e; e.raw = A(c->y3, H8, W8); e.sum = A(c->s1_1, H8, W8); e.add1 = A(c->y1, H8, W8); e.add1_nb = Bl;
+          CR("depth_decoder1.dec2.3", false, CONV_S1, A(c->t1, H8, W8), Bl, Bl, H8, W8, true, e); }
+        CR("depth_decoder1.dec1.1", false, CONV_T2, A(c->s1_1, H8, W8), Bl, Bl, H8, W8, true, raw(A(c->u1, H4, W4)));
+        { E e; e.raw = A(c->y4, H4, W4); e.sum = A(c->s0_1, H4, W4); e.add1 = c->e1_0; e.add1_nb = Nn; e.add2 = A(c->m, H4, W4); e.add2_nb = Bl;
+          CR("depth_decoder1.dec1.3", false, CONV_S1, A(c->u1, H4, W4), Bl, Bl, H4, W4, true, e); }
+        CR("depth_decoder1.prdct.1", false, CONV_S1, A(c->s0_1, H4, W4), Bl, Bl, H4, W4, true, raw(A(c->v1, H4, W4)));
+        {
+            const LOut& lo = c->lout["depth_decoder1.prdct.3"];
+            ConvOut1Args a; a.in = A(c->v1, H4, W4); a.in_nb = Bl; a.w = lo.w; a.bias = lo.bias; a.out = P1(c->out1, H4, W4);
+            a.B = Bl; a.H = H4; a.W = W4; a.relu_in = 1; a.bf16 = c->bf16;
+            RUN(ptta_launch_conv_out1(a, st));
+        }
+        // ---- stage 1/2 (:491-498) ----
+        RUN(ptta_launch_up2_1ch(P1(c->out1, H4, W4), P1(c->p12, H2, W2), Bl, H4, W4, st));
+        {
+            const LIn& li = c->lin_in["depth_encoder2.init.0"];
+            ConvInArgs a; a.cin = 2;
+            a.pl[0].p = c->d12; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H2 * W2;
+            a.pl[1].p = P1(c->p12, H2, W2); a.pl[1].nb = Bl; a.pl[1].bstride = (long)H2 * W2;
+            a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = A(c->e2_0a, H2, W2);
+            a.B = Bl; a.H = H2; a.W = W2; a.bf16 = c->bf16; a.naive = c->naive;
+            RUN(ptta_launch_conv_in(a, st));
+        }
+        { E e; e.raw = A(c->e2_0, H2, W2); e.up = A(c->y4, H4, W4); e.up_nb = Bl; CR("depth_encoder2.init.2", false, CONV_S1, A(c->e2_0a, H2, W2), Bl, Bl, H2, W2, true, e); }
+        CR("depth_encoder2.enc1.1", false, CONV_S2, A(c->e2_0, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->e2_1a, H4, W4)));
+        { E e; e.raw = A(c->e2_1, H4, W4); e.up = A(c->y3, H8, W8); e.up_nb = Bl; CR("depth_encoder2.enc1.3", false, CONV_S1, A(c->e2_1a, H4, W4), Bl, Bl, H4, W4, true, e); }
+        CR("depth_encoder2.enc2.1", false, CONV_S2, A(c->e2_1, H4, W4), Bl, Bl, H4, W4, true, raw(A(c->e2_2a, H8, W8)));
+        { E e; e.sum = A(c->z2, H8, W8); e.up = A(c->y2, H16, W16); e.up_nb = Bl; e.add1 = A(c->c3, H8, W8); e.add1_nb = Bl;            // z2 = e2_2 + c3
+          CR("depth_encoder2.enc2.3", false, CONV_S1, A(c->e2_2a, H8, W8), Bl, Bl, H8, W8, true, e); }
+        CR("depth_decoder2.dec2.1", false, CONV_T2, A(c->z2, H8, W8), Bl, Bl, H8, W8, true, raw(A(c->t2, H4, W4)));
+        { E e; e.raw = A(c->z3, H4, W4); e.sum = A(c->s1_2, H4, W4); e.add1 = A(c->e2_1, H4, W4); e.add1_nb = Bl; e.add2 = A(c->m, H4, W4); e.add2_nb = Bl;
+          CR("depth_decoder2.dec2.3", false, CONV_S1, A(c->t2, H4, W4), Bl, Bl, H4, W4, true, e); }
+        CR("depth_decoder2.dec1.1", false, CONV_T2, A(c->s1_2, H4, W4), Bl, Bl, H4, W4, true, raw(A(c->u2, H2, W2)));
+        { E e; e.raw = A(c->z4, H2, W2); e.sum = A(c->s0_2, H2, W2); e.add1 = A(c->e2_0, H2, W2); e.add1_nb = Bl; e.add2 = A(c->c1, H2, W2); e.add2_nb = Bl;
+          CR("depth_decoder2.dec1.3", false, CONV_S1, A(c->u2, H2, W2), Bl, Bl, H2, W2, true, e); }
+        CR("depth_decoder2.prdct.1", false, CONV_S1, A(c->s0_2, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->v2, H2, W2)));
+        {
+            const LOut& lo = c->lout["depth_decoder2.prdct.3"];
+            ConvOut1Args a; a.in = A(c->v2, H2, W2); a.in_nb = Bl; a.w = lo.w; a.bias = lo.bias; a.add = P1(c->p12, H2, W2); a.add_nb = Bl; a.out = P1(c->q, H2, W2);
+            a.B = Bl; a.H = H2; a.W = W2; a.relu_in = 1; a.bf16 = c->bf16;                           // q = out2 + p12
+            RUN(ptta_launch_conv_out1(a, st));
+        }
+        // ---- stage 1/1 (:500-506) ----
+        RUN(ptta_launch_up2_1ch(P1(c->q, H2, W2), P1(c->p11, H1, W1), Bl, H2, W2, st));
+        {
+            const LIn& li = c->lin_in["depth_encoder3.init.0"];
+            ConvInArgs a; a.cin = 2;
+            a.pl[0].p = c->dclamp; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H1 * W1;
+            a.pl[1].p = P1(c->p11, H1, W1); a.pl[1].nb = Bl; a.pl[1].bstride = (long)H1 * W1;
+            a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = A(c->e3_0a, H1, W1);
+            a.B = Bl; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
+            RUN(ptta_launch_conv_in(a, st));
+        }
+        { E e; e.raw = A(c->e3_0, H1, W1); e.up = A(c->z4, H2, W2); e.up_nb = Bl; CR("depth_encoder3.init.2", false, CONV_S1, A(c->e3_0a, H1, W1), Bl, Bl, H1, W1, true, e); }
+        CR("depth_encoder3.enc1.1", false, CONV_S2, A(c->e3_0, H1, W1), Bl, Bl, H1, W1, true, raw(A(c->e3_1a, H2, W2)));
+        { E e; e.raw = A(c->e3_1, H2, W2); e.up = A(c->z3, H4, W4); e.up_nb = Bl; CR("depth_encoder3.enc1.3", false, CONV_S1, A(c->e3_1a, H2, W2), Bl, Bl, H2, W2, true, e); }
+        CR("depth_encoder3.enc2.1", false, CONV_S2, A(c->e3_1, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->e3_2a, H4, W4)));
+        { E e; e.raw = A(c->feat, H4, W4); e.sum = A(c->w2, H4, W4); e.up = A(c->z2, H8, W8); e.up_nb = Bl; e.add1 = A(c->m, H4, W4); e.add1_nb = Bl;   // w2 = feat + m
+          CR("depth_encoder3.enc2.3", false, CONV_S1, A(c->e3_2a, H4, W4), Bl, Bl, H4, W4, true, e); }
+#undef CR
+        return 0;
+    };
+    const bool split = train && s2 && (c->split_fwd & 1);
+    if (split) {
+        // real frames on s, proxy frames on s2; the heads (both halves' depth_encoder3 outputs) follow on s2 beside decoder 3
         HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+        RUN(region(s, 0, Nn));
+        RUN(region(s2, Nn, Nn));
+        HIPCHK(hipEventRecord(c->ev_real, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_real, 0));
         RUN(heads_forward(c, s2));
         HIPCHK(hipEventRecord(c->ev_join, s2));
+    } else {
+        RUN(region(s, 0, B2));
+        if (train && s2) {
+            HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+            RUN(heads_forward(c, s2));
+            HIPCHK(hipEventRecord(c->ev_join, s2));
+        }
     }
     // decoder 3: real frames only (the proxy pass stops at depth_encoder3, :509-532); the stage-2 head forward stops at
     // depth_encoder3 for both passes (:652,:676)
@@ -973,6 +1012,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     c->use_graph = (gr && strcmp(gr, "0") == 0) ? 0 : 1;
     const char* ax = getenv("PTTA_AUX_STREAM");
     c->use_aux = (ax && strcmp(ax, "0") == 0) ? 0 : 1;
+    { const char* sf = getenv("PTTA_SPLIT_FWD"); c->split_fwd = sf ? atoi(sf) : 0; }
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
     c->x3 = (arith && strcmp(arith, "exact") == 0) ? 0 : 1;
     c->hp = *hp;
@@ -991,7 +1031,7 @@ void ptta_destroy(ptta_handle h) {
     h->drop_graphs();
     if (h->ev_replay) (void)hipEventDestroy(h->ev_replay);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-    if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); }
+    if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_real); }
     for (void* p : h->allocs) if (p) (void)hipFree(p);
     for (auto& pc : h->prof) for (auto& e : pc.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete h;
@@ -1565,7 +1605,7 @@ int ptta_set_image_norm(ptta_handle c, float divisor, const float* mean, const f
 int ptta_set_stat_sync(ptta_handle c, ptta_allreduce_fn fn, void* user, double* exchange_buf, int64_t capacity, int world_size) {
     if (!c || world_size < 1 || (world_size > 1 && (!fn || !exchange_buf || capacity < 2 * 1024))) return -22;
     PttaStatSync sy; sy.fn = (ptta_allreduce_cb)fn; sy.user = user; sy.buf = exchange_buf; sy.cap = (long)capacity; sy.world = world_size;
-    if (c->nl) { c->err.clear(); c->nl->stat_sync = sy; return 0; }
+    if (c->nl) { c->err.clear(); c->nl->drop_graphs(); c->nl->stat_sync = sy; return 0; }
     if (world_size > 1 && c->meta_mode == PTTA_META_2LAYERS && !c->m2.generic) return c->fail("SyncBatchNorm needs the default arithmetic for the 2layers meta layer", -38);
     c->stat_sync = sy;
     c->drop_graphs();
@@ -1584,7 +1624,7 @@ int ptta_set_stat_sync(ptta_handle c, ptta_allreduce_fn fn, void* user, double* 
 int ptta_set_stat_sync_rccl(ptta_handle c, void* comm, double* exchange_buf, int64_t capacity, int world_size) {
     if (!c || world_size < 1 || (comm && (!exchange_buf || capacity < 2 * 1024))) return -22;
     PttaStatSync sy; sy.comm = comm; sy.buf = exchange_buf; sy.cap = (long)capacity; sy.world = world_size;
-    if (c->nl) { c->err.clear(); c->nl->stat_sync = sy; return 0; }
+    if (c->nl) { c->err.clear(); c->nl->drop_graphs(); c->nl->stat_sync = sy; return 0; }
     if (comm && c->meta_mode == PTTA_META_2LAYERS && !c->m2.generic) return c->fail("SyncBatchNorm needs the default arithmetic for the 2layers meta layer", -38);
     c->stat_sync = sy;
     c->drop_graphs();
@@ -1603,14 +1643,14 @@ int ptta_set_stat_sync_rccl(ptta_handle c, void* comm, double* exchange_buf, int
 // ncclAllReduce enqueued on the step's stream (captured into the hipGraph).  comm == NULL: off.
 int ptta_set_grad_sync_rccl(ptta_handle c, void* comm) {
     if (!c) return -1;
-    if (c->nl) { c->nl->grad_comm = comm; return 0; }
+    if (c->nl) { c->nl->drop_graphs(); c->nl->grad_comm = comm; return 0; }
     c->grad_comm = comm;
     c->drop_graphs();
     return 0;
 }
 
 int ptta_set_graph(ptta_handle c, int enable) {
-    if (c && c->nl) return c->fail("not available for the NLSPN / CostDCNet backbones: use ptta_step / ptta_forward_*", -38);
+    if (c && c->nl) { c->nl->use_graph = enable ? 1 : 0; if (!enable) c->nl->drop_graphs(); return 0; }
 
     if (!c) return -1;
     if (enable && c->stat_sync.on() && !c->stat_sync.comm) return c->fail("graph replay is not available with SyncBatchNorm exchange (ptta_set_stat_sync)", -38);

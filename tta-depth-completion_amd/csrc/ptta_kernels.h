@@ -210,7 +210,10 @@ int ptta_launch_gwgrad(const GView& x, const GView& gy, float* part, float* gw, 
 int ptta_gbn_part_floats(int C, int npass);
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,
                             const float* beta, float* part, float* st, hipStream_t s, int fused_blocks = 0, int act_first = 0,
-                            const PttaStatSync* sync = nullptr);
+                            const PttaStatSync* sync = nullptr,
+                            // tracked BatchNorm: running statistics updated (and the eval-mode affine written) by the finalize launch
+                            float* rm = nullptr, float* rv = nullptr, long long* nbt = nullptr, float momentum = 0.1f, int repeats = 1,
+                            float* st_eval = nullptr);
 int ptta_gconv_x3_tiles(int B, int H, int W);
 int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int npass, int act, const float* st, int res_relu, hipStream_t s,
                           int act_first = 0);

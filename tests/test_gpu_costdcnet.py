@@ -253,3 +253,26 @@ def test_graph_replay_equals_kernel_by_kernel_launches():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[4], b[4])
     for k in a[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.parametrize('shape', [(64, 96), (72, 100)])
+def test_fused_image_normalisation(shape):
+    """Engine.set_image_norm([mean, std]) fuses Transforms.normalize_images (src/transforms.py:668-710) into the input staging -- or,
+    for sizes that are not multiples of 16, into the dual-corner padding (the reference normalises before it pads: the padding stays
+    zero): a step on the RAW image equals a step on the pre-normalised image bit for bit."""
+    n = 1
+    h, w = shape
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in costdc_frame(0, h, w, n)]
+    res = []
+    for fused in (False, True):
+        eng, sd, ad = make_costdc(n, h, w)
+        if fused:
+            eng.set_image_norm([tuple(float(v) for v in MEAN.reshape(-1)), tuple(float(v) for v in STD.reshape(-1))])
+        info, depth = eng.step(raw if fused else image1, sparse, loss_image=raw, want_depth=True)
+        d_eval = eng.forward_eval(raw if fused else image1, sparse)
+        torch.cuda.synchronize()
+        res.append((info.clone(), depth.clone(), d_eval.clone()))
+        eng.close()
+    # (v / 255 - mean) / std on the host (numpy) and on the device are the same three float32 operations
+    assert rel_mae(res[1][1], res[0][1]) < 1e-6 and rel_mae(res[1][2], res[0][2]) < 1e-6
+    np.testing.assert_allclose(res[1][0].cpu().numpy(), res[0][0].cpu().numpy(), rtol=1e-5)

@@ -16,6 +16,11 @@ def _oracle():
     return O.MsgChnOracle(synth.formula_state_dict(ONE), ONE, max_input_depth=80.0, lr=1e-3, w_sd=1.0, w_sm=2.0, w_cos=0.1)
 
 
+# post-update eval depth after this path's OWN Adam step, against the oracle's: the north_star tolerance (measured on MI355X, round 3:
+# 2.9e-4 at 256x320, 5.6e-4 at 480x640, 9.7e-5 at 3 x 48x80)
+EVAL_TOL = 1e-3
+
+
 @pytest.mark.parametrize('shape', [(1, 256, 320), (1, 480, 640), (3, 48, 80)])
 def test_other_config_shapes_against_oracle(shape):
     """BASELINE.json configs[0] (320x256 VOID frame), the 640x480 VOID shape and an odd batch."""
@@ -33,7 +38,15 @@ def test_other_config_shapes_against_oracle(shape):
     # update, and the tight check from the ORACLE's post-step parameters
     ref_eval = o.forward_eval(torch.from_numpy(image), torch.from_numpy(sparse))
     d_eval = eng.forward_eval(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())
-    assert rel_mae(d_eval, ref_eval) < 3e-3
+    assert rel_mae(d_eval, ref_eval) < EVAL_TOL, rel_mae(d_eval, ref_eval)
+    # this path's OWN update in parameter space: wherever the gradient is clear of the sign-flip noise floor (|g| > 1e-3 of the
+    # tensor's largest entry) Adam's first step is -lr * sign(g) on both sides: identical parameters to 1e-3 of one step
+    for k, (prm, m, v) in adapted.items():
+        gref = r['grads'][k]
+        clear = gref.abs() > 1e-3 * gref.abs().max()
+        assert float(clear.float().mean()) > 0.9, k
+        dp = (prm.cpu() - o.P[k].detach()).abs()
+        assert float(dp[clear].max()) < 1e-3 * HP['lr'], (k, float(dp[clear].max()))
     for k, (prm, m, v) in adapted.items():
         prm.copy_(o.P[k].detach())
     d_eval = eng.forward_eval(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())

@@ -53,8 +53,9 @@ def test_full_size_matches_reference(golden_dir, name, meta):
             if np.abs(gref).max() < 1e-6:                      # conv bias in front of a BatchNorm: analytically zero
                 assert float(got.abs().max()) < 1e-4
                 continue
-            # sums of sign() functions over 428k pixels: measured 5e-4 (1layer) at this size
-            assert rel_mae(got, gref) < 1e-2, (k, s, rel_mae(got, gref))
+            # sums of sign() functions over 82k - 428k pixels; measured (tools/grad_report.py, round 3): 1layer 7.6e-4 / 9.1e-4 (first /
+            # second step, 256x320), 3.2e-4 / 4.7e-4 (352x1216); 2layers (BatchNorm affine gradients) 8.9e-3 / 7.4e-3 -> bounds = 2x
+            assert rel_mae(got, gref) < (1.8e-2 if meta == '2layers' else 1.9e-3), (k, s, rel_mae(got, gref))
             assert rel_mae(prm, g[p + 'param/' + k]) < 2e-3, k
             if p + 'exp_avg/' + k in g.files:
                 assert rel_mae(m, g[p + 'exp_avg/' + k]) < 1e-2

@@ -15,8 +15,17 @@ from tests.util import ONE, TWO
 pytestmark = pytest.mark.gpu
 
 
-def make_head_engine(n, h, w, hp, tau, bind_target=True):
-    eng = Engine(n, h, w, dtype='fp32', max_input_depth=80.0)
+MODES = ['exact', 'default']          # PTTA_ARITH=exact: fp32 matrix-core arithmetic everywhere (v_mfma_f32_32x32x2_f32); default: bf16x3
+
+
+def make_head_engine(n, h, w, hp, tau, bind_target=True, mode='default'):
+    os.environ.pop('PTTA_ARITH', None)
+    if mode == 'exact':
+        os.environ['PTTA_ARITH'] = 'exact'
+    try:
+        eng = Engine(n, h, w, dtype='fp32', max_input_depth=80.0)
+    finally:
+        os.environ.pop('PTTA_ARITH', None)
     sd_np = synth.formula_state_dict(ONE, 1.0)
     sd_np.update(perturbed_target(sd_np))
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in sd_np.items()}
@@ -45,42 +54,50 @@ def _check(z, key, value, rtol, atol, what):
     assert abs(value.sum(dtype=np.float64) - s[0]) <= rtol * s[1] + atol * value.size, what
 
 
-def _grad_close(mine, want, first, what):
-    """Gradients are sums over thousands of rows through a ReLU: a pre-activation within rounding of zero flips its mask
-    under any other summation order and moves single entries by one row's contribution (~1e-5 here).  So: every entry
-    within 2.5 % of the tensor's largest entry, and the MEAN error 2.5e-3 of the mean magnitude (first step).  Measured at the
-    second test shape with either accumulation order of the stride-2 conv: largest entry error 1.99 % (tap-major direct form) /
-    2.01 % (k-step-major LDS-staged form) on pred.0.weight, mean error 1.99e-3 / 2.02e-3 on proj.0.weight -- the former bounds of
-    2 % and 2e-3 sat exactly on the measured values.  Later steps also carry Adam's first-step sign noise."""
+# Gradient bounds = 2x the worst figure measured on MI355X (tools/grad_report.py, round 3), per arithmetic mode:
+#   (worst |entry error| / largest |entry|,  mean |error| / mean |entry|)          first step          later steps
+#   exact    (fp32 products): the kernels themselves                               5.7e-6 / 3.6e-6     3.8e-3 / 3.7e-5
+#   default  (bf16x3 products, 2^-17 operand error)                                2.0e-2 / 2.4e-3     1.6e-2 / 7.8e-3
+# The reference's own fp32 gradients sit 1e-6 from an fp64 evaluation of the same step (well conditioned), so the exact-mode bound
+# is the regression detector for linear_wgrad_kernel / the fused BatchNorm-backward transforms: a defect of a few 1e-5 fails it.
+# The default-mode figures are ReLU-mask flips: a hidden pre-activation within 1e-5 of zero changes side under the two-way
+# operand split, and with 192 - 720 embedding rows one flipped row moves an entry of that hidden unit's gradient by up to 1/rows of
+# its magnitude (at 352x1216 there are 26,752 rows).  Later steps also carry Adam's first-step sign noise on near-zero entries.
+GRAD_TOL = {'exact': {True: (1.2e-5, 8e-6), False: (8e-3, 8e-5)}, 'default': {True: (4e-2, 5e-3), False: (4e-2, 1.6e-2)}}
+
+
+def _grad_close(mine, want, first, what, mode='default'):
     mine, want = np.asarray(mine, np.float64), np.asarray(want, np.float64)
     if np.abs(want).max() < 1e-8:
         # mathematically ZERO gradient (a bias in front of a BatchNorm: pred.0.bias, proj.0.bias, and proj.3.bias which only
         # shifts pred's pre-BatchNorm hidden): the reference holds rounding noise
         assert np.abs(mine).max() < 1e-6, what
         return
+    tmax, tmean = GRAD_TOL[mode][bool(first)]
     d = np.abs(mine - want)
-    assert d.max() <= 0.025 * np.abs(want).max() + 1e-12, (what, d.max(), np.abs(want).max())
-    assert d.mean() <= (2.5e-3 if first else 2e-2) * np.abs(want).mean() + 1e-12, (what, d.mean(), np.abs(want).mean())
+    assert d.max() <= tmax * np.abs(want).max() + 1e-12, (what, d.max(), np.abs(want).max())
+    assert d.mean() <= tmean * np.abs(want).mean() + 1e-12, (what, d.mean(), np.abs(want).mean())
 
 
-def _grad_check(z, key, g, first, what):
+def _grad_check(z, key, g, first, what, mode='default'):
     g = g.detach().cpu().numpy()
     if key in z.files:
-        _grad_close(g, z[key], first, what)
+        _grad_close(g, z[key], first, what, mode)
         return
     idx = np.linspace(0, g.shape[0] - 1, 24).astype(np.int64)
-    _grad_close(g[idx], z[key + '#rows'], first, what)
+    _grad_close(g[idx], z[key + '#rows'], first, what, mode)
     s = z[key + '#sum']
-    assert abs(g.sum(dtype=np.float64) - s[0]) <= (2e-3 if first else 2e-2) * s[1], what
+    assert abs(g.sum(dtype=np.float64) - s[0]) <= GRAD_TOL[mode][bool(first)][1] * s[1], what
 
 
+@pytest.mark.parametrize('mode', MODES)
 @pytest.mark.parametrize('name', ['head_reverse_32x48_n2', 'head_forward_32x48_n2', 'head_reverse_64x96'])
-def test_head_trainer_reproduces_reference(golden_dir, name):
+def test_head_trainer_reproduces_reference(golden_dir, name, mode):
     z = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps = (int(v) for v in z['meta'])
     lr, b1, b2, eps, wd, tau = (float(v) for v in z['hp'])
     reverse = 'reverse' in str(z['loss_type'])
-    eng, sd, _, _ = make_head_engine(n, h, w, dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd), tau)
+    eng, sd, _, _ = make_head_engine(n, h, w, dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd), tau, mode=mode)
     for s in range(steps):
         image, sparse = (torch.from_numpy(a).cuda() for a in synth.synthetic_frame(s, h, w, n))
         emb, ref = eng.head_forward(image, sparse, reverse)
@@ -95,7 +112,7 @@ def test_head_trainer_reproduces_reference(golden_dir, name):
             assert bool(z[p + 'has_grad/' + k]) == (g is not None), k
             if g is None:
                 continue
-            _grad_check(z, p + 'grad/' + k, g, s == 0, k)
+            _grad_check(z, p + 'grad/' + k, g, s == 0, k, mode)
         eng.head_adam_step()
     torch.cuda.synchronize()
     last = 's%d/after/' % (steps - 1)
@@ -120,12 +137,13 @@ def test_head_trainer_reproduces_reference(golden_dir, name):
             _check(z, last + k, sd[k], 1e-5, 1e-6, k)
 
 
-def test_head_trainer_against_oracle_other_shape():
-    """A shape and batch the fixtures do not hold, 2 steps each mode, incl. the EMA and the step counter."""
+@pytest.mark.parametrize('mode', MODES)
+def test_head_trainer_against_oracle_other_shape(mode):
+    """A shape and batch the fixtures do not hold, 2 steps each loss type, incl. the EMA and the step counter."""
     n, h, w = 3, 48, 80
     hp = dict(lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
     for loss_type in ('head_selfsup_seq_ema_reverse', 'head_selfsup_seq_ema'):
-        eng, sd, sd_np, _ = make_head_engine(n, h, w, hp, 0.99)
+        eng, sd, sd_np, _ = make_head_engine(n, h, w, hp, 0.99, mode=mode)
         o = HO.HeadTrainerOracle(sd_np, loss_type, max_input_depth=80.0, tau=0.99, **hp)
         for s in range(2):
             image, sparse = synth.synthetic_frame(10 + s, h, w, n)
@@ -135,7 +153,7 @@ def test_head_trainer_against_oracle_other_shape():
             assert abs(float(loss) - r['loss']) < (2e-5 if s == 0 else 1e-4)
             for k, g in r['grads'].items():
                 mine = eng.head_grad(k, sd[k]).cpu()
-                _grad_close(mine.numpy(), g.numpy(), s == 0, k)
+                _grad_close(mine.numpy(), g.numpy(), s == 0, k, mode)
             eng.head_adam_step()
         for k in HEAD_TARGETS:
             np.testing.assert_allclose(sd[k].cpu().numpy(), o.P[k].detach().numpy(), rtol=1e-5, atol=0.01 * 2.5 * 5e-4 * 4 + 1e-7, err_msg=k)

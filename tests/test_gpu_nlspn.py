@@ -25,9 +25,13 @@ def nlspn_frame(idx, h, w, n):
 
 
 # 'naive': direct fp32 kernels everywhere (exact arithmetic, tight bounds); 'default': bf16x3 matrix-core convolutions
-# (each product carries ~2^-17 relative error, through ~40 normalised layers)
-TOL = {'naive': dict(feat=1e-4, depth=1e-4, emb=1e-3, grad=3e-2, param=2e-3),
-       'default': dict(feat=1e-3, depth=1e-3, emb=5e-3, grad=8e-2, param=4e-3)}
+# (each product carries ~2^-17 relative error, through ~40 normalised layers).
+# Gradient bounds = 2x the worst figure measured on MI355X over every fixture incl. 352x1216 (tools/grad_report.py, round 3):
+#   worst full-gradient rel. MAE of an adapted tensor: naive 6.8e-3, default 2.1e-2 (conv3.0.downsample.1.*: the deep BatchNorm
+#   affine gradients are ill-conditioned -- the fp32 CPU reference itself sits 1.3e-2 from an fp64 evaluation of the same graph);
+#   worst gradient-NORM error over the 88 tensors: naive 2.1e-3, default 4.4e-3;  depth: naive 3.9e-7, default 2.6e-6.
+TOL = {'naive': dict(feat=1e-4, depth=1e-5, emb=1e-3, grad=1.4e-2, gnorm=5e-3, param=2e-3),
+       'default': dict(feat=1e-3, depth=1e-4, emb=5e-3, grad=4.2e-2, gnorm=9e-3, param=4e-3)}
 MODES = ['naive', 'default']
 
 
@@ -113,7 +117,7 @@ def test_step_matches_golden(golden_dir, name, impl):
         raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(s, h, w, n)]
         info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
         p = 's%d/' % s
-        assert rel_mae(depth, g[p + 'depth_train']) < 1e-3            # north_star: 1e-3 relative MAE on depth
+        assert rel_mae(depth, g[p + 'depth_train']) < (tol['depth'] if s == 0 else 1e-3)     # first step: 2.6e-6 measured; north_star 1e-3
         np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2e-3)
         if s == 0:
             # Gradients of the deep BatchNorm affine parameters are ill-conditioned: the fp32 CPU reference itself sits
@@ -121,7 +125,7 @@ def test_step_matches_golden(golden_dir, name, impl):
             # first update Adam turns that noise into +-lr parameter moves, so later steps are pinned on depth and loss
             # here and on gradients by test_second_step_from_oracle_state.
             gn = np.array([float(eng.grad(k, adapted[k][0]).double().norm()) for k in names])
-            np.testing.assert_allclose(gn, g[p + 'grad_norms'], rtol=tol['grad'], atol=1e-6)
+            np.testing.assert_allclose(gn, g[p + 'grad_norms'], rtol=tol['gnorm'], atol=1e-6)
             for key in g.files:
                 if key.startswith(p + 'grad/'):
                     k = key[len(p + 'grad/'):]
@@ -311,7 +315,7 @@ def test_shared_parameter_step_nlspn():
     assert torch.allclose(info1, info2, rtol=1e-5)
     assert e2.adam_step_count() == 1
     for k in ad1:
-        # two FUSED steps on identical engines already differ by 0.4e-5 .. 2.6e-5 on conv5.0.bn1.bias (tools/exp_nlspn_noise.py:
+        # two FUSED steps on identical engines already differ by 0.4e-5 .. 2.6e-5 on conv5.0.bn1.bias (measured in round 2:
         # the propagation gradient's float atomics + Adam's sign-like first step), so 1e-5 was inside the run-to-run noise
         assert rel_mae(ad2[k][0], ad1[k][0]) < 1e-4, k
     e1.close(); e2.close()
@@ -331,10 +335,10 @@ def test_full_size_step_matches_reference(golden_dir, name):
     names = [str(x) for x in g['adapted_names']]
     raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
     info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
-    _check_map(depth, g, 's0/depth_train', 1e-3)                       # north_star: 1e-3 relative MAE
+    _check_map(depth, g, 's0/depth_train', 1e-4)                       # measured 2.6e-6 (north_star: 1e-3 relative MAE)
     np.testing.assert_allclose(info.cpu().numpy(), g['s0/loss_info'], rtol=2e-3)
     gn = np.array([float(eng.grad(k, adapted[k][0]).double().norm()) for k in names])
-    np.testing.assert_allclose(gn, g['s0/grad_norms'], rtol=TOL['default']['grad'], atol=1e-6)
+    np.testing.assert_allclose(gn, g['s0/grad_norms'], rtol=TOL['default']['gnorm'], atol=1e-6)
     for key in g.files:
         if key.startswith('s0/grad/'):
             k = key[len('s0/grad/'):]
@@ -419,5 +423,40 @@ def test_graph_replay_equals_kernel_by_kernel_launches():
     tot = same = 0
     for k in a[3]:
         d = (a[3][k] - b[3][k]).abs()
-        tot += d.numel(); same += int((d < 1e-6).sum())
-    assert same >= 0.97 * tot, (same, tot)
+        tot += d.numel(); same += int((d < 1e-4).sum())          # lr = 1e-3: an entry that took the opposite Adam step would differ by 2e-3
+    assert same >= 0.99 * tot, (same, tot)                     # measured 0.995 (two kernel-by-kernel runs: 0.998)
+
+
+def test_eval_forward_fills_holes_like_the_reference(golden_dir):
+    """src/nlspn_model_adapt.py:124-127: the eval forward's exact zeros (the clamp at nlspnmodel_adapt.py:371) are filled by
+    biharmonic inpainting on the host.  At 228x304 the reference's eval output holds one hole (tests/golden/nlspn_228x304_legacy.npz:
+    n_zero_eval, taken before its skimage call): the façade returns a map without zeros that equals the raw network output everywhere
+    else; `fill_holes = False` gives the raw output (what the fixtures pin)."""
+    from proxytta.model import ExternalModel_Adapt
+    g = np.load(os.path.join(golden_dir, 'nlspn_228x304_legacy.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
+    model = ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=mid, offset=True, device=torch.device('cuda'))
+    model._prepare_head('meta_selfsup_seq_1layer_ema')
+    model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict_nlspn().items()})
+    params = model.adapt_parameters(mode='meta_bn')
+    opt = torch.optim.Adam(params, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    model.model.bind_optimizer(opt)
+    model.model.set_hparams(w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos)
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+    model.train()
+    model.step(image1, sparse, loss_image=raw)
+    model.eval()
+    model.model.fill_holes = False
+    d_raw = model.forward(image1, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
+    model.model.fill_holes = True
+    d_fill = model.forward(image1, sparse, loss_type='adapt_meta_selfsup_seq_ema_reverse')
+    holes = d_raw == 0
+    assert int(holes.sum()) == int(g['s0/n_zero_eval']) >= 1
+    assert not bool((d_fill == 0).any())
+    assert torch.equal(d_fill[~holes], d_raw[~holes])
+    ys, xs = torch.where(holes[0, 0])
+    for y, x in zip(ys.tolist(), xs.tolist()):
+        nb = d_raw[0, 0, max(y - 2, 0):y + 3, max(x - 2, 0):x + 3]
+        nb = nb[nb > 0]
+        assert float(nb.min()) * 0.5 <= float(d_fill[0, 0, y, x]) <= float(nb.max()) * 1.5

@@ -106,10 +106,12 @@ def test_op_conv32_bf16():
 
 
 def _run_golden(name, impl, golden_dir):
-    # gradients of the L1 / total-variation terms are sums of sign() functions: a 1e-5 perturbation
-    # of the depth map (bf16x3 arithmetic, different summation order) flips a few signs, so the
-    # gradient tolerance is looser than the depth tolerance; exact-fp32 modes hold 1e-3
-    gtol, ptol = (1e-3, 5e-5) if impl in ('naive', 'exact') else (3e-2, 1e-3)
+    # gradients of the L1 / total-variation terms are sums of sign() functions: a 1e-5 perturbation of the depth map (bf16x3
+    # arithmetic) flips a few signs, so the default-mode gradient tolerance is looser than the depth tolerance.  Bounds = 2x the worst
+    # figure measured on MI355X over these fixtures (tools/grad_report.py, round 3): gradients, first step: exact 2.1e-6, default
+    # 5.2e-3; later steps (they also carry Adam's sign-like first update): exact 6.8e-4 (the w_cos = 1 fixture; 1.2e-6 elsewhere),
+    # default 9.3e-3; post-step parameters: exact 2.3e-5, default 3.6e-4
+    gtol1, gtol, ptol = (5e-6, 1.4e-3, 5e-5) if impl in ('naive', 'exact') else (1.1e-2, 1.9e-2, 7.5e-4)
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
@@ -134,8 +136,8 @@ def _run_golden(name, impl, golden_dir):
         assert rel_mae(depth2, g[p + 'depth_train']) < 1e-4
         np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=1e-4)
         gw, gb = eng.debug_tensor('gW').view(32, 32, 3, 3), eng.debug_tensor('gB')
-        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < gtol, (name, s)
-        assert rel_mae(gb, g[p + 'grad/conv1_rgb_meta.bias']) < gtol
+        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < (gtol1 if s == 0 else gtol), (name, s)
+        assert rel_mae(gb, g[p + 'grad/conv1_rgb_meta.bias']) < (gtol1 if s == 0 else gtol)
         for k, (prm, m, v) in adapted.items():
             assert rel_mae(prm, g[p + 'param/' + k]) < ptol, k
             assert rel_mae(m, g[p + 'exp_avg/' + k]) < gtol
@@ -233,7 +235,7 @@ def test_facade_reference_style_driver(golden_dir, mode, fixture):
         for k, prm in zip(names, params):
             if np.abs(g[p + 'grad/' + k]).max() < 1e-6:
                 continue                          # analytically-zero gradient, see test_2layers_...
-            assert rel_mae(prm.grad, g[p + 'grad/' + k]) < 5e-2, k
+            assert rel_mae(prm.grad, g[p + 'grad/' + k]) < 3.2e-2, k        # measured <= 1.56e-2 (2layers, second step)
             assert rel_mae(prm, g[p + "param/" + k]) < 2e-3, k
         model.eval()
         with torch.no_grad():
@@ -272,7 +274,8 @@ def test_2layers_meta_layer_matches_reference_golden(golden_dir, impl):
     h, w, n, steps = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
     eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, impl, meta='2layers')
-    gtol = 2e-3 if impl == 'exact' else 5e-2
+    # measured (tools/grad_report.py): exact 2.0e-6 both steps; default 2.5e-3 first step, 1.56e-2 second step
+    gtol = 1e-5 if impl == 'exact' else 3.2e-2
     for s in range(steps):
         image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)]
         p = 's%d/' % s

@@ -93,3 +93,35 @@ def test_costdcnet_key_table_and_adapted_list():
     assert sum(int(np.prod(shapes[k])) for k in names) == 5200
     sd = synth.formula_state_dict_costdcnet()
     assert np.array_equal(sd['enc2d.layer2.0.downsample.1.weight'], sd['enc2d.layer2.0.norm3.weight'])      # one module, two names
+
+
+def test_biharmonic_hole_filling_properties():
+    """proxytta/inpaint.py restates skimage.restoration.inpaint_biharmonic (absent here: parity unpinned) for the NLSPN adapter's
+    eval-time hole filling (src/nlspn_model_adapt.py:124-127, src/data_utils.py:327-354).  Size-independent properties: the interior
+    stencil annihilates cubic surfaces (holes in one are restored to rounding), known pixels are never touched, a map without holes
+    comes back as the same object's values, results stay inside the known range, independent regions do not interact."""
+    from proxytta.inpaint import inpaint_biharmonic, inpainting
+    H, W = 48, 64
+    y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+    f = (2 + 0.03 * x + 0.02 * y + 0.001 * x * y + 1e-4 * x ** 2 * y - 2e-5 * y ** 3).astype(np.float32)
+    d = np.stack([f, f])[:, None].copy()
+    d[0, 0, 10:13, 20:24] = 0; d[0, 0, 30, 40] = 0; d[1, 0, 5, 5] = 0; d[1, 0, 0, 0] = 0; d[1, 0, 47, 5:8] = 0
+    holes = d == 0
+    out = inpainting(d.copy())
+    assert not (out == 0).any()
+    np.testing.assert_array_equal(out[~holes], d[~holes])
+    np.testing.assert_allclose(out[0, 0, 10:13, 20:24], f[10:13, 20:24], rtol=1e-6)       # interior: exact for a cubic
+    np.testing.assert_allclose(out[0, 0, 30, 40], f[30, 40], rtol=1e-6)
+    np.testing.assert_allclose(out[1, 0, 5, 5], f[5, 5], rtol=1e-6)
+    assert abs(out[1, 0, 0, 0] - f[0, 0]) < 0.05 and np.abs(out[1, 0, 47, 5:8] - f[47, 5:8]).max() < 0.05      # borders: reflect stencil
+    assert out.min() >= f.min() and out.max() <= f.max()
+    clean = np.stack([f])[:, None].copy()
+    assert inpainting(clean) is clean
+    # two regions solved independently = both solved together when they are far apart
+    m = np.zeros((H, W), bool); m[10:12, 10:12] = True; m[30:33, 50] = True
+    a = inpaint_biharmonic(np.where(m, 0, f), m)
+    m1 = np.zeros_like(m); m1[10:12, 10:12] = True
+    b = inpaint_biharmonic(np.where(m1, 0, f), m1)
+    np.testing.assert_array_equal(a[10:12, 10:12], b[10:12, 10:12])
+    with pytest.raises(ValueError):
+        inpaint_biharmonic(f, m[:-1])

@@ -14,7 +14,8 @@ struct CdSparse {
     float *bn_part = nullptr, *bn_st = nullptr;
 };
 
-int cd_launch_pad_dual(const float* src, float* dst, int N, int C, int H, int W, int Hp, int Wp, int pt, int pr, hipStream_t s);
+int cd_launch_pad_dual(const float* src, float* dst, int N, int C, int H, int W, int Hp, int Wp, int pt, int pr, hipStream_t s, int norm = 0, float div = 1.f,
+                       const float* mean = nullptr, const float* stdv = nullptr);
 int cd_launch_crop_avg(const float* net, float* out, int N, int H, int W, int Hp, int Wp, int pt, int pr, hipStream_t s);
 int cd_launch_scatter_dual_grad(const float* g, float* gnet, int N, int H, int W, int Hp, int Wp, int pt, int pr, hipStream_t s);
 int cd_launch_stage(const float* image, const float* sparse, float* out, int N, int passes, int H, int W, int C, int norm, float div, const float* mean,

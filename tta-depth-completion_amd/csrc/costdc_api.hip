@@ -311,15 +311,16 @@ struct costdc_engine : GNet {
         for (auto& ad : adapted) if (!ad.p) return fail("adapted parameter " + ad.name + " not bound (ptta_bind_adapted)", -3);
         const float* img = image; const float* spp = sparse;
         if (dual) {
-            if (cd_launch_pad_dual(image, img_pad, Nu, 3, Hu, Wu, H, W, pt, pr, s) || cd_launch_pad_dual(sparse, sp_pad, Nu, 1, Hu, Wu, H, W, pt, pr, s))
+            // the fused image normalisation happens while padding (in-frame pixels only: the padding stays zero, as in the reference)
+            if (cd_launch_pad_dual(image, img_pad, Nu, 3, Hu, Wu, H, W, pt, pr, s, norm_on, norm_div, norm_mean, norm_std) ||
+                cd_launch_pad_dual(sparse, sp_pad, Nu, 1, Hu, Wu, H, W, pt, pr, s))
                 return fail("padding failed", -5);
             img = img_pad; spp = sp_pad;
         }
         // clamp (src/external_model_adapt.py:108) and cat([image | zeros, sparse]) staging; the reference normalises the image
         // before it pads, so padded pixels must stay zero: normalisation is applied to the caller's frame region only
         if (cd_launch_clamp(spp, sp_clamp, (long)N * H * W, hp.max_input_depth, s)) return fail("clamp failed", -5);
-        if (dual && norm_on) return fail("fused image normalisation with dual-corner padding is not supported: pass normalised images", -38);
-        if (cd_launch_stage(img, sp_clamp, T[t_in].p, N, train ? 2 : 1, H, W, T[t_in].C, norm_on, norm_div, norm_mean, norm_std, s)) return fail("input staging failed", -5);
+        if (cd_launch_stage(img, sp_clamp, T[t_in].p, N, train ? 2 : 1, H, W, T[t_in].C, dual ? 0 : norm_on, norm_div, norm_mean, norm_std, s)) return fail("input staging failed", -5);
         repack_adapted(s);
         const int rc = run_ops_fwd(train, s);
         if (rc) return rc;

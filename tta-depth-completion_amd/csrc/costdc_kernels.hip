@@ -17,7 +17,10 @@ inline int nbk(long total, int cap = 16384) { long b = (total + 255) / 256; if (
 #define GRID_STRIDE(i, n) for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
 // ---- dual-corner zero padding (src/costdcnet_model_adapt.py:134-185): item k=0 pads top/right, k=1 bottom/left ----------
-__global__ void cd_pad_dual_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W, int Hp, int Wp, int pt, int pr) {
+// norm: Transforms.normalize_images fused into the padding (the reference normalises BEFORE it pads, src/tta_main.py:602 then
+// src/costdcnet_model_adapt.py:134-210: padded pixels stay exactly zero, in-frame pixels become (v / div - mean[c]) / std[c])
+struct CdNorm { int on; float div; float mean[3]; float stdv[3]; };
+__global__ void cd_pad_dual_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int W, int Hp, int Wp, int pt, int pr, CdNorm nm) {
     const long total = (long)2 * N * C * Hp * Wp;
     GRID_STRIDE(idx, total) {
         const int x = (int)(idx % Wp); long t_ = idx / Wp;
@@ -25,7 +28,12 @@ __global__ void cd_pad_dual_kernel(const float* __restrict__ src, float* __restr
         const int ch = (int)(t_ % C); t_ /= C;
         const int n = (int)(t_ % N); const int k = (int)(t_ / N);
         const int sy = k == 0 ? y - pt : y, sx = k == 0 ? x : x - pr;
-        dst[idx] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? src[(((long)n * C + ch) * H + sy) * W + sx] : 0.f;
+        float v = 0.f;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            v = src[(((long)n * C + ch) * H + sy) * W + sx];
+            if (nm.on) v = (v / nm.div - nm.mean[ch]) / nm.stdv[ch];
+        }
+        dst[idx] = v;
     }
 }
 __global__ void cd_crop_avg_kernel(const float* __restrict__ net, float* __restrict__ out, int N, int H, int W, int Hp, int Wp, int pt, int pr) {
@@ -436,8 +444,11 @@ __global__ void cd_rows_bwd_kernel(const float* __restrict__ grows, float* __res
 
 #define LAUNCH_OK() do { if (hipGetLastError() != hipSuccess) return -5; return 0; } while (0)
 
-int cd_launch_pad_dual(const float* src, float* dst, int N, int C, int H, int W, int Hp, int Wp, int pt, int pr, hipStream_t s) {
-    hipLaunchKernelGGL(cd_pad_dual_kernel, dim3(nbk((long)2 * N * C * Hp * Wp)), dim3(256), 0, s, src, dst, N, C, H, W, Hp, Wp, pt, pr); LAUNCH_OK();
+int cd_launch_pad_dual(const float* src, float* dst, int N, int C, int H, int W, int Hp, int Wp, int pt, int pr, hipStream_t s, int norm, float div,
+                       const float* mean, const float* stdv) {
+    CdNorm nm{0, 1.f, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+    if (norm && C == 3) { nm.on = 1; nm.div = div; for (int k = 0; k < 3; ++k) { nm.mean[k] = mean[k]; nm.stdv[k] = stdv[k]; } }
+    hipLaunchKernelGGL(cd_pad_dual_kernel, dim3(nbk((long)2 * N * C * Hp * Wp)), dim3(256), 0, s, src, dst, N, C, H, W, Hp, Wp, pt, pr, nm); LAUNCH_OK();
 }
 int cd_launch_crop_avg(const float* net, float* out, int N, int H, int W, int Hp, int Wp, int pt, int pr, hipStream_t s) {
     hipLaunchKernelGGL(cd_crop_avg_kernel, dim3(nbk((long)N * H * W)), dim3(256), 0, s, net, out, N, H, W, Hp, Wp, pt, pr); LAUNCH_OK();

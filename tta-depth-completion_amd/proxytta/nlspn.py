@@ -58,6 +58,7 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
         self.sync_bn = False
         self.hparams = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0)
         self.total_time = self.train_time = self.eval_time = 0.0
+        self.fill_holes = True            # eval forward: biharmonic hole filling like the reference (False: the raw network output)
         self.to(device)
 
     @staticmethod
@@ -125,7 +126,14 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
             params = dict(self.model.named_parameters())
             return self._timed(lambda: _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted]), loss_type)
         with torch.no_grad():
-            return self._timed(lambda: self._engine(image).forward_eval(image, sparse_depth), loss_type)
+            out = self._timed(lambda: self._engine(image).forward_eval(image, sparse_depth), loss_type)
+        # Fill in any holes with inpainting (src/nlspn_model_adapt.py:124-127): exact zeros left by the final clamp are filled by
+        # biharmonic interpolation on the host, as in the reference (scikit-image there; proxytta/inpaint.py restates it on scipy).
+        # One flag comes back first: a map without holes -- the usual case -- never leaves the device.
+        if self.fill_holes and 'head' not in loss_type and bool((out == 0).any()):
+            from .inpaint import inpainting
+            out = torch.from_numpy(inpainting(out.detach().cpu().numpy())).to(out.device)
+        return out
 
     def save_model(self, checkpoint_path, step, optimizer, meanvar=None):
         ckpt = {'net': self.model.state_dict(), 'optimizer': optimizer.state_dict() if optimizer else {}, 'train_step': step}

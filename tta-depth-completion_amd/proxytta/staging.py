@@ -8,7 +8,7 @@ slot being refilled was consumed two steps ago), which is also the loop's backpr
 The pageable -> pinned copy is a single-threaded numpy copy ON PURPOSE: torch's `Tensor.copy_` fans a 5 MB copy out over
 every core it sees (256 on the GPU box) and the spinning OpenMP team exhausts the container's CPU quota (cgroup cpu.max =
 16 CPUs) within a few frames -- the process is then throttled for the rest of the 100 ms period, measured as an 80-100 ms
-stall every ~5 frames (tools/exp_stager3.py: 21.8 ms/frame with torch's copy, 2.35 ms/frame with one thread).
+stall every ~5 frames (measured in round 2: 21.8 ms/frame with torch's copy, 2.35 ms/frame with one thread).
 
     stager.submit(image_k1, sparse_k1)        # host memcpy into pinned slot, async H2D on the copy stream
     image, sparse = stager.acquire()          # host waits for that slot's H2D (submitted a step ago: already there)

@@ -344,6 +344,127 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     }
 }
 
+// ---- the same convolution for SMALL maps (at most ~256 tiles of 8x32: the 1/4 ... 1/16-resolution layers, 18 launches of a step) ----
+// Those launches are one tile per block and their duration is a latency chain, not bandwidth (in-kernel stamps of the kernel above on a
+// one-tile launch: 26k cycles = weights -> LDS 5.9k + first loads 3.7k + split 2.6k + 108 MFMAs with LDS-fed lo fragments 6.1k + epilogue
+// 2.6k).  This form shortens the chain: a 4x32 tile (one output row per wave: 54 MFMAs, twice the blocks -- the chip is mostly idle at
+// these sizes), BOTH weight fragment sets in registers (144 VGPRs: no global -> LDS -> barrier hop for the lo half; one block per SIMD
+// row, occupancy is irrelevant here), every global load of the block -- halo, 36 weight fragments, bilinear window -- issued before the
+// first wait.  Same products in the same order as conv32_s1_x3_kernel: bit-identical outputs.
+#define X3S_TH 4
+#define X3S_PH 6
+template <bool RELU, bool UP, bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> p) {
+    constexpr int UPH = 4, UPW = 18;                      // a 4x32 output tile reads <= 3x17 source pixels of the half-resolution map
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3S_PH * X3_PW * X3_STRIDE + (UP ? UPH * UPW * 128 : 0)];
+    float* const up_lds = (float*)(lds + X3S_PH * X3_PW * X3_STRIDE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.Hout, W = p.Wout;
+    const int ntx = (W + 31) >> 5, nty = (H + X3S_TH - 1) / X3S_TH;
+    const int ntiles = p.B * ntx * nty;
+    const float sy = up_scale(H >> 1, H), sx = up_scale(W >> 1, W);
+    constexpr int NPIX = X3S_PH * X3_PW;                  // 204 halo pixels
+    constexpr int NIT = (((NPIX + 7) / 8) * 32 + 255) / 256;      // (pixel, 8-channel group) items per thread
+    uint4 wh[9][2], wl[9][2];
+    bool wloaded = false;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ty = tile % nty, tx = (tile / nty) % ntx, b = tile / (nty * ntx);
+        const int y0 = ty * X3S_TH, x0 = tx << 5;
+        const float* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
+        float4 v0[NIT], v1[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int g = idx & 3, pix = x3_stage_pix(idx);
+            const int py = pix / X3_PW, px = pix - py * X3_PW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
+            if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const float* src = inb + ((size_t)gy * W + gx) * 32 + 8 * g;
+                v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
+            }
+        }
+        if (!wloaded) {                                   // block-uniform; in flight together with the halo
+            const uint4* ph = (const uint4*)p.wpack;
+            const uint4* pl = (const uint4*)p.wpack2;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { wh[t][k] = ph[(t * 2 + k) * 64 + lane]; wl[t][k] = pl[(t * 2 + k) * 64 + lane]; }
+            wloaded = true;
+        }
+        int uy0 = 0, ux0 = 0;
+        if (UP) {
+            const int Hu = H >> 1, Wu = W >> 1;
+            uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
+            const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
+            for (int idx = tid; idx < UPH * UPW * 8; idx += 256) {
+                const int q = idx & 7, pix = idx >> 3;
+                const int r = pix / UPW, cc = pix - r * UPW;
+                const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
+                *(float4*)(up_lds + pix * 32 + 4 * q) = *(const float4*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            const int pix = x3_stage_pix(idx);
+            if (pix < NPIX) {
+                float4 a0 = v0[it], a1 = v1[it];
+                if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
+                uint4 hi, lo;
+                split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);
+                split2(a1.x, a1.y, hi.z, lo.z); split2(a1.z, a1.w, hi.w, lo.w);
+                unsigned char* dst = lds + pix * X3_STRIDE + 16 * (idx & 3);
+                *(uint4*)dst = hi;
+                *(uint4*)(dst + 64) = lo;
+            }
+        }
+        lds_barrier();
+        const int y = y0 + wave;
+        if (y < H) {                                      // wave-uniform
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const unsigned char* a = lds + ((wave + ky) * X3_PW + i + kx) * X3_STRIDE + 16 * h;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, wl[tap][k]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first (as conv32_s1_x3_kernel)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+            }
+            if (UP) {
+                const float bias = (p.epi.bias ? p.epi.bias : kZeroBias)[i];
+                const Lerp ly = lerp_coef(y, H >> 1, sy);
+                const float* r0 = up_lds + (ly.i0 - uy0) * UPW * 32 + i;
+                const float* r1 = up_lds + (ly.i1 - uy0) * UPW * 32 + i;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = min(x0 + acc_row(r, h), W - 1);
+                    const Lerp lx = lerp_coef(px, W >> 1, sx);
+                    const int c0 = (lx.i0 - ux0) * 32, c1 = (lx.i1 - ux0) * 32;
+                    acc[r] = (acc[r] + bias) + (ly.l0 * (lx.l0 * r0[c0] + lx.l1 * r0[c1]) + ly.l1 * (lx.l0 * r1[c0] + lx.l1 * r1[c1]));
+                }
+                Epi<float> e2 = p.epi; e2.bias = nullptr; e2.up = nullptr;
+                epi_tile<float, false, MASK, ADD>(e2, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+            } else {
+                epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+            }
+        }
+        if (tile + (int)gridDim.x < ntiles) lds_barrier();   // LDS reuse by the next tile
+    }
+}
+
 // ---- stride-2 / transposed geometries, fp32 storage, bf16x3 arithmetic, direct loads ----------
 // Same per-wave tiling as conv32_mfma_kernel (32 outputs of one row / one x-parity), but each A
 // fragment (8 fp32 channels of one input pixel) is split into bf16 hi/lo in registers and fed to
@@ -641,6 +762,24 @@ static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_
         else if (flags == 1) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, true, false, false, true>), dim3(blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, true, true>), dim3(blocks), dim3(256), 0, s, p);
         return;
+    }
+    // small maps: the latency-chain form (conv32_s1_small_kernel), one 4x32 tile per block
+    static const int small_off = getenv("PTTA_S1_SMALL") ? (atoi(getenv("PTTA_S1_SMALL")) == 0) : 0;
+    {
+        const long tiles8 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
+        if (!small_off && tiles8 <= 256) {
+            const long t4 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3S_TH - 1) / X3S_TH);
+            const int nb4 = (int)(t4 > 1024 ? 1024 : t4);
+#define KS_(U, M, A) hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, U, M, A>), dim3(nb4), dim3(256), 0, s, p)
+            switch (flags) {
+                case 0: KS_(false, false, false); break; case 1: KS_(true, false, false); break;
+                case 2: KS_(false, true, false); break;  case 3: KS_(true, true, false); break;
+                case 4: KS_(false, false, true); break;  case 5: KS_(true, false, true); break;
+                case 6: KS_(false, true, true); break;   default: KS_(true, true, true); break;
+            }
+#undef KS_
+            return;
+        }
     }
 #define K_(U, M, A) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
     switch (flags) {

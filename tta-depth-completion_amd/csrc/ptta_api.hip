@@ -415,6 +415,12 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     a.add1 = e.add1; a.add1_nb = e.add1_nb; a.add2 = e.add2; a.add2_nb = e.add2_nb;
     a.out_raw = e.raw; a.out_sum = e.sum;
     a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = c->bf16; a.naive = c->naive; a.x3 = c->x3;
+    {   // TIMING ablation only (results are garbage): PTTA_ABLATE bit 0 skips the 32->32 convolutions at <= 1/4 resolution, bit 1 those above
+        static const int abl = getenv("PTTA_ABLATE") ? atoi(getenv("PTTA_ABLATE")) : 0;
+        const bool small = (long)Hin * Win <= (long)c->H4 * c->W4 * (mode == CONV_S2 ? 4 : 1);
+        if ((abl & 1) && small) return 0;
+        if ((abl & 2) && !small) return 0;
+    }
     if (!c->prof_on) return ptta_launch_conv32(a, s);
     // bracket this launch with events on ITS stream; algorithmic bytes = input + output + weight
     // elements x element size, MACs = output pixels x 9 x 32 x 32 (SURVEY.md 8d counting rule)
@@ -806,6 +812,7 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
 }
 
 int heads_forward(ptta_ctx* c, hipStream_t s) {
+    { static const int abl = getenv("PTTA_ABLATE") ? atoi(getenv("PTTA_ABLATE")) : 0; if (abl & 4) return 0; }      // timing ablation only
     const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
     const void* feat_zero = (const char*)c->feat + half;
     if (c->head_swap) {
@@ -827,6 +834,7 @@ int heads_forward(ptta_ctx* c, hipStream_t s) {
 
 // d ref -> d feat through proj = Linear(32,512) - BN1d - ReLU - Linear(512,512)
 int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
+    { static const int abl = getenv("PTTA_ABLATE") ? atoi(getenv("PTTA_ABLATE")) : 0; if (abl & 4) return 0; }      // timing ablation only
     const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
     const int R = (int)c->Rg;
     GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;

@@ -90,6 +90,27 @@ __device__ __forceinline__ void gbn_sum_partials(const float* __restrict__ part,
     s1 = a1; s2 = a2;
 }
 
+// the same with all 256 threads of a block on ONE (pass, channel): thread t takes blocks t, t + 256, ... (four loads in flight), waves
+// combine through LDS in a fixed order.  The sums are fp64 of fp32 partials: exact to 2^-53, so the order is immaterial for the fp32
+// statistics -- and a full-resolution layer has 3,344 tile partials per channel, 52 dependent iterations for a single wave (22 us).
+__device__ __forceinline__ void gbn_sum_partials_block(const float* __restrict__ part, int nblocks, int C, int c, double& s1, double& s2) {
+    __shared__ double red[8];
+    double a1 = 0.0, a2 = 0.0;
+    int b = threadIdx.x;
+    for (; b + 768 < nblocks; b += 1024) {
+        const float* o0 = part + ((long)b * 2) * C; const float* o1 = o0 + 512L * C; const float* o2 = o1 + 512L * C; const float* o3 = o2 + 512L * C;
+        const float x0 = o0[c], y0 = o0[C + c], x1 = o1[c], y1 = o1[C + c], x2 = o2[c], y2 = o2[C + c], x3 = o3[c], y3 = o3[C + c];
+        a1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3); a2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+    }
+    for (; b < nblocks; b += 256) { const float* o = part + ((long)b * 2) * C; a1 += (double)o[c]; a2 += (double)o[C + c]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { a1 += __shfl_xor(a1, m); a2 += __shfl_xor(a2, m); }
+    __syncthreads();                                     // red[] may still be read by the previous call's thread 0
+    if ((threadIdx.x & 63) == 0) { red[(threadIdx.x >> 6) * 2] = a1; red[(threadIdx.x >> 6) * 2 + 1] = a2; }
+    __syncthreads();
+    s1 = (red[0] + red[2]) + (red[4] + red[6]); s2 = (red[1] + red[3]) + (red[5] + red[7]);
+}
+
 // ---- SyncBatchNorm exchange (ptta_kernels.h: PttaStatSync) ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void stat_collapse_kernel(const float* __restrict__ part, int nblocks, int C, int npass, double* __restrict__ out) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);               // (pass, which, c): one wave each
@@ -138,15 +159,17 @@ struct GbnTrack { float* rm; float* rv; long long* nbt; float momentum; int repe
 __global__ __launch_bounds__(256) void gbn_finalize_kernel(const float* __restrict__ part, int nblocks, int npass, int C, long R, float eps,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ st,
                                                            GbnTrack tr) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    // untracked: one block per (pass, channel); tracked: one block per channel walks the passes in order (the momentum updates chain)
+    const int unit = blockIdx.x;
+    const int c = tr.rm ? unit : unit % C;
+    const int pfirst = tr.rm ? 0 : unit / C, plast = tr.rm ? npass : pfirst + 1;
     const int n = npass * C;
     float m_run = 0.f, v_run = 0.f;
-    const bool lane0 = (threadIdx.x & 63) == 0;
+    const bool lane0 = threadIdx.x == 0;
     if (tr.rm && lane0) { m_run = tr.rm[c]; v_run = tr.rv[c]; }
-    for (int pass = 0; pass < npass; ++pass) {
+    for (int pass = pfirst; pass < plast; ++pass) {
         double s1, s2;
-        gbn_sum_partials(part + ((long)pass * nblocks * 2) * C, nblocks, C, c, s1, s2);
+        gbn_sum_partials_block(part + ((long)pass * nblocks * 2) * C, nblocks, C, c, s1, s2);
         if (!lane0) continue;
         const double m = s1 / (double)R;
         double var = s2 / (double)R - m * m; if (var < 0.0) var = 0.0;
@@ -218,7 +241,7 @@ int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, in
     long Rg = R;
     if (sync && sync->on()) { const int rc = ptta_stat_sync(sync, part, blocks, C, npass, s); if (rc) return rc; Rg = R * sync->world; }
     const GbnTrack tr{rm, rv, nbt, momentum, repeats, st_eval};
-    hipLaunchKernelGGL(gbn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, npass, C, Rg, eps, gamma, beta, st, tr);
+    hipLaunchKernelGGL(gbn_finalize_kernel, dim3(rm ? C : npass * C), dim3(256), 0, s, part, blocks, npass, C, Rg, eps, gamma, beta, st, tr);
     if ((C & 3) || (x.ld & 3) || (y.ld & 3) || (res.p && (res.ld & 3))) return -22;
     const long total = (long)x.B * x.H * x.W * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
@@ -244,11 +267,10 @@ int ptta_launch_gbn_apply(const GView& x, const GView& res, const GView& y, int 
 __global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, int C, long R, const float* __restrict__ gamma,
                                                                const float* __restrict__ inv, float* dgamma, float* dbeta, float* __restrict__ bw,
                                                                float grad_scale = 1.f) {
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    const int c = blockIdx.x;
     double s1, s2;
-    gbn_sum_partials(part, nblocks, C, c, s1, s2);
-    if (threadIdx.x & 63) return;
+    gbn_sum_partials_block(part, nblocks, C, c, s1, s2);
+    if (threadIdx.x) return;
     // with SyncBatchNorm the sums are global: 1/world of them = the DDP-averaged local parameter gradients
     if (dbeta) dbeta[c] = (float)s1 * grad_scale;
     if (dgamma) dgamma[c] = (float)s2 * grad_scale;
@@ -310,7 +332,7 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
     hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, fscale, fshift);
     long Rg = R; float gsc = 1.f;
     if (sync && sync->on()) { const int rc = ptta_stat_sync(sync, part, blocks, C, 1, s); if (rc) return rc; Rg = R * sync->world; gsc = 1.f / (float)sync->world; }
-    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, blocks, C, Rg, gamma, inv, dgamma, dbeta, bw, gsc);
+    hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, part, blocks, C, Rg, gamma, inv, dgamma, dbeta, bw, gsc);
     if ((C & 3) || (x.ld & 3) || (g.ld & 3) || (y.ld & 3) || (gx.ld & 3) || (gres.p && (gres.ld & 3))) return -22;
     const long total = R * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;

@@ -49,7 +49,14 @@ typedef void* ptta_stream;              /* hipStream_t */
  * ptta_adapted_count() is 32 (conv1_rgb_meta + every BatchNorm2d weight/bias of Encoder2D, the reference's order);
  * ptta_load_weights BINDS the running statistics of BatchNorm3d / BatchNorm1d / the sparse encoder's BatchNorm
  * (updated in place by training forwards, read by the eval forward) and ignores those of BatchNorm2d (dropped by
- * 'meta_bn'); the other remarks of PTTA_BACKBONE_NLSPN apply. */
+ * 'meta_bn'); the other remarks of PTTA_BACKBONE_NLSPN apply.
+ * meta_mode | PTTA_SYNCBN_ADAPT: the adapted set of the reference's DDP run (src/tta_main.py:326 convert_syncbn() BEFORE :339
+ * adapt_parameters): EVERY BatchNorm of the model -- Encoder2D's, the BatchNorm1d inside the sparse encoder's nine MinkowskiBatchNorm
+ * (`enc3d.<layer>.bn.weight/bias`), UNet3D's 28 BatchNorm3d, the heads' three BatchNorm1d -- is adapted and has lost its running
+ * statistics (batch statistics in train AND eval mode; ptta_load_weights ignores every running_* key).  ptta_adapted_count() is 114
+ * unique tensors in the reference's order; the reference's list has 116 entries because enc2d.layer{2,3}.0.norm3.{weight,bias} sit
+ * behind two SyncBatchNorm modules (norm3 and downsample[1]) and are listed -- and updated by Adam -- twice per step:
+ * ptta_adapted_repeat() is 2 for them, 0 for proj.1 / pred.1 (listed, never given a gradient), 1 otherwise. */
 enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1, PTTA_BACKBONE_COSTDCNET = 2 };
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
 enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };   /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
@@ -61,7 +68,8 @@ enum { PTTA_NLSPN_LEGACY_OFFSET = 0x100,
         * SyncBatchNorm BEFORE adapt_parameters('meta_bn') (:339), whose isinstance test (src/nlspn_model_adapt.py:329-331) then
         * also matches the heads' three BatchNorm1d: 94 adapted tensors (proj.1, proj_t.1, pred.1 weight/bias appended in
         * module order) instead of 88.  proj / pred feed the detached embedding: their gradients stay zero. */
-       PTTA_NLSPN_SYNCBN_ADAPT = 0x200 };
+       PTTA_NLSPN_SYNCBN_ADAPT = 0x200,
+       PTTA_SYNCBN_ADAPT = 0x200 };        /* the same switch for PTTA_BACKBONE_COSTDCNET (see there) */
 
 /* Hyper-parameters of the step.  Reference: src/tta.py:10-160 flags learning_rates,
  * optimizer_betas, optimizer_epsilon, w_weight_decay, w_loss_sparse_depth, w_loss_smoothness,
@@ -136,6 +144,9 @@ int ptta_get_grad(ptta_handle h, const char* name, float* dst, int64_t capacity,
 int ptta_set_grad(ptta_handle h, const char* name, const float* src, int64_t numel, ptta_stream s);
 int ptta_adapted_count(ptta_handle h);
 const char* ptta_adapted_name(ptta_handle h, int index, int64_t* numel_host);
+/* How many times the reference's parameter list names this tensor = the Adam updates it receives per optimizer.step()
+ * (torch.optim.Adam walks the list; a tensor listed twice is stepped twice with the same gradient).  1 except under PTTA_SYNCBN_ADAPT. */
+int ptta_adapted_repeat(ptta_handle h, int index);
 
 /* optimizer.step() for the bound parameters with explicit gradients (src/tta_main.py:633). */
 int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* grad_meta_bias, ptta_stream s);

@@ -34,6 +34,10 @@ def _bn2d(P, pre, x):
 def _bn_tracked(P, pre, x, training):
     """BatchNorm3d / BatchNorm1d that keep their running statistics: batch statistics + momentum-0.1 update in train mode,
     running statistics in eval mode."""
+    if P.get('__syncbn_adapted__', False):
+        # the DDP run (adapted_names(P, syncbn=True)): converted to SyncBatchNorm and caught by adapt_parameters('meta_bn'), the layer
+        # lost its running statistics -> batch statistics in train AND eval mode, nothing to update (AD:364-372)
+        return F.batch_norm(x, None, None, P[pre + '.weight'], P[pre + '.bias'], True, 0.1, BN_EPS)
     if training:
         P[pre + '.num_batches_tracked'] += 1
     return F.batch_norm(x, P[pre + '.running_mean'], P[pre + '.running_var'], P[pre + '.weight'], P[pre + '.bias'],
@@ -195,15 +199,26 @@ def model_forward(P, image, sparse_depth, training, max_depth, max_input_depth=N
     return (depth, out[1], out[2]) if training else depth
 
 
-def adapted_names(P):
+def adapted_names(P, syncbn=False):
     """adapt_parameters('meta_bn') (AD:357-378): parameters whose name contains 'meta', then weight / bias of every
     BatchNorm2d in module order (Encoder2D only: BatchNorm3d / BatchNorm1d / MinkowskiBatchNorm are not BatchNorm2d);
-    ResBlock.norm3 also sits inside `downsample` but a module is visited once."""
-    names = [k for k in P if 'meta' in k]
+    ResBlock.norm3 also sits inside `downsample` but a module is visited once.
+    syncbn: the reference's DDP run calls convert_syncbn() first (src/tta_main.py:326,339): every BatchNorm is a SyncBatchNorm by then and
+    matches the isinstance test -- Encoder2D's, the BatchNorm1d inside every MinkowskiBatchNorm, UNet3D's BatchNorm3d, the heads' BatchNorm1d --
+    116 entries in module order.  convert_sync_batchnorm builds one new module per visited ATTRIBUTE, so ResBlock.norm3 and its alias
+    downsample[1] become two modules sharing one Parameter: that parameter is listed twice (and Adam updates it twice per step)."""
+    names = [k for k in P if 'meta' in k and not k.startswith('__')]
     for k in P:
-        if k.startswith('enc2d.') and k.endswith('.running_mean') and '.downsample.1.' not in k:
-            pre = k[:-len('.running_mean')]
-            names += [pre + '.weight', pre + '.bias']
+        if not k.endswith('.running_mean'):
+            continue
+        pre = k[:-len('.running_mean')]
+        if not syncbn:
+            if k.startswith('enc2d.') and '.downsample.1.' not in k:
+                names += [pre + '.weight', pre + '.bias']
+            continue
+        if pre.startswith('enc2d.') and '.downsample.1' in pre:
+            pre = pre.replace('.downsample.1', '.norm3')          # the alias: same tensors, second listing
+        names += [pre + '.weight', pre + '.bias']
     return names
 
 
@@ -211,13 +226,16 @@ class CostDcnOracle:
     """model + Adam; ``step()`` = src/tta_main.py:583-633, ``forward_eval`` = :729-736."""
 
     def __init__(self, state_dict, max_depth=8.0, max_input_depth=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 w_sd=1.0, w_sm=1.0, w_cos=1.0):
+                 w_sd=1.0, w_sm=1.0, w_cos=1.0, syncbn=False):
         self.P = {k: torch.as_tensor(v).clone() for k, v in state_dict.items()}
+        self.syncbn = syncbn
         for k in list(self.P):          # one BatchNorm behind two names (ResBlock.norm3 / downsample.1)
             if k.startswith('enc2d.') and '.downsample.1.' in k:
                 self.P[k] = self.P[k.replace('.downsample.1.', '.norm3.')]
         self.max_depth, self.max_input_depth = max_depth, max_input_depth
-        self.names = adapted_names(self.P)
+        self.names = adapted_names(self.P, syncbn)
+        if syncbn:
+            self.P['__syncbn_adapted__'] = True
         for k in self.names:
             self.P[k].requires_grad_(True)
         self.opt = AdamState([self.P[k] for k in self.names], lr, betas, eps, weight_decay)

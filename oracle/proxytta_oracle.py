@@ -235,16 +235,24 @@ class AdamState:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.t = 0
-        self.m = [torch.zeros_like(p) for p in params]
-        self.v = [torch.zeros_like(p) for p in params]
+        # torch keys its state by parameter: a tensor listed twice (the CostDCNet DDP list names ResBlock.norm3 twice) shares ONE
+        # (exp_avg, exp_avg_sq, step) and is updated once per occurrence, each with its own step count
+        self._state = {}
+        for p in params:
+            self._state.setdefault(id(p), [torch.zeros_like(p), torch.zeros_like(p), 0])
+        self.m = [self._state[id(p)][0] for p in params]
+        self.v = [self._state[id(p)][1] for p in params]
 
     def step(self, params, grads):
         b1, b2 = self.betas
         self.t += 1
-        bc1 = 1 - b1 ** self.t
-        bc2 = 1 - b2 ** self.t
         with torch.no_grad():
-            for p, g, m, v in zip(params, grads, self.m, self.v):
+            for p, g in zip(params, grads):
+                st = self._state[id(p)]
+                m, v = st[0], st[1]
+                st[2] += 1
+                bc1 = 1 - b1 ** st[2]
+                bc2 = 1 - b2 ** st[2]
                 if self.wd != 0:
                     g = g + self.wd * p
                 m.mul_(b1).add_(g, alpha=1 - b1)

@@ -44,17 +44,42 @@ def costdc_frame(idx, h, w, n, density):
     return raw, ((raw / np.float32(255.0) - MEAN) / STD).astype(np.float32), sparse
 
 
-def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False):
+def install_cpu_syncbn():
+    """Harness-side shim (like the `.cuda()` no-ops): torch.nn.SyncBatchNorm refuses CPU tensors.  In a single process without a
+    process group it never synchronises anyway (`need_sync` is false): its forward reduces to F.batch_norm with the module's own
+    training / running-statistics rules (torch/nn/modules/batchnorm.py SyncBatchNorm.forward), which is what this replacement runs."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    def forward(self, input):
+        bn_training = True if self.training else (self.running_mean is None and self.running_var is None)
+        eaf = 0.0 if self.momentum is None else self.momentum
+        use = not self.training or self.track_running_stats
+        return F.batch_norm(input, self.running_mean if use else None, self.running_var if use else None, self.weight, self.bias, bn_training, eaf, self.eps)
+    nn.SyncBatchNorm.forward = forward
+
+
+def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False, syncbn=False):
+    """syncbn: the reference's DDP run converts every BatchNorm to SyncBatchNorm BEFORE adapt_parameters('meta_bn') (src/tta_main.py:326,339):
+    the isinstance test of src/costdcnet_model_adapt.py:364-366 then matches every BatchNorm of the model (116 entries; ResBlock.norm3 and its
+    alias inside `downsample` become two modules sharing one Parameter, which therefore appears TWICE in the list and gets two Adam updates
+    per step) and all of them lose their running statistics."""
     model = ema.ExternalModel_Adapt('costdcnet', 0.1, MAX_DEPTH, max_input_depth=None, device=torch.device('cpu'))
     model._prepare_head(PREPARE)
     net = model.model.model
     sd = synth.formula_state_dict_costdcnet(PREPARE)
     assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(np.shape(v))) for k, v in sd.items()], 'key table drifted'
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    if syncbn:
+        install_cpu_syncbn()
+        model.convert_syncbn()
     params = model.adapt_parameters(mode='meta_bn')
     pnames = {id(p): k for k, p in net.named_parameters()}
     names = [pnames[id(p)] for p in params]
-    opt = torch.optim.Adam(params, lr=HP['lr'], betas=HP['betas'], eps=HP['eps'], weight_decay=HP['weight_decay'])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')                 # syncbn: "optimizer contains a parameter group with duplicate parameters"
+        opt = torch.optim.Adam(params, lr=HP['lr'], betas=HP['betas'], eps=HP['eps'], weight_decay=HP['weight_decay'])
     out = {'meta': np.array([h, w, n, steps], dtype=np.int64), 'density': np.array(density),
            'hp': np.array([HP['lr'], HP['betas'][0], HP['betas'][1], HP['eps'], HP['weight_decay'], HP['w_sd'], HP['w_sm'], HP['w_cos'],
                            MAX_DEPTH], dtype=np.float64),
@@ -74,7 +99,7 @@ def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False):
         opt.zero_grad()
         loss.backward()
         grads = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
-        assert all(k in grads for k in names), 'an adapted tensor got no gradient'
+        assert syncbn or all(k in grads for k in names), 'an adapted tensor got no gradient'
         opt.step()
         model.eval()
         with torch.no_grad():
@@ -93,11 +118,11 @@ def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False):
         out[p + 'emb_shape'] = np.array(e.shape)
         out[p + 'loss_info'] = np.array([float(torch.as_tensor(info[k]).detach()) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')])
         named = dict(net.named_parameters())
-        state = opt.state_dict()['state']
         for i, k in enumerate(names):
-            out[p + 'grad/' + k] = grads[k].numpy()
+            out[p + 'grad/' + k] = grads[k].numpy() if k in grads else np.zeros(tuple(named[k].shape), np.float32)     # syncbn: proj / pred BatchNorm1d get no gradient
             out[p + 'param/' + k] = named[k].detach().numpy().copy()
-            out[p + 'exp_avg/' + k] = state[i]['exp_avg'].numpy().copy()
+            if named[k] in opt.state and 'exp_avg' in opt.state[named[k]]:
+                out[p + 'exp_avg/' + k] = opt.state[named[k]]['exp_avg'].numpy().copy()
         for k, v in net.state_dict().items():          # buffers that the eval forward reads / save_model writes
             if k.endswith(('running_mean', 'running_var')) and not k.startswith(('enc2d.', 'proj_t.')):
                 out[p + 'buf/' + k] = v.numpy().copy()
@@ -113,6 +138,7 @@ CASES = {
     'costdcnet_64x64_n2': lambda e: run_case(e, 'costdcnet_64x64_n2', 64, 64, 2, 1),
     'costdcnet_72x100_pad': lambda e: run_case(e, 'costdcnet_72x100_pad', 72, 100, 1, 1),       # dual-corner padding, odd pooled sizes
     'costdcnet_320x400': lambda e: run_case(e, 'costdcnet_320x400', 320, 400, 1, 1, density=0.012, sampled=True),   # the ScanNet script's frame
+    'costdcnet_64x64_n2_syncbn': lambda e: run_case(e, 'costdcnet_64x64_n2_syncbn', 64, 64, 2, 2, syncbn=True),      # the DDP run's adapted set (116 entries)
     'costdcnet_480x640': lambda e: run_case(e, 'costdcnet_480x640', 480, 640, 1, 1, density=1500.0 / (480 * 640), sampled=True),  # config 5
 }
 

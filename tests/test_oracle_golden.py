@@ -282,6 +282,44 @@ def test_costdcnet_oracle_matches_reference(golden_dir, name):
         assert rel_mae(o.forward_eval(image1, sparse), g[p + 'depth_eval']) < 1e-5
 
 
+def test_costdcnet_oracle_syncbn_adapted_matches_reference(golden_dir):
+    """The adapted set of the reference's DDP run: convert_syncbn() BEFORE adapt_parameters('meta_bn') (src/tta_main.py:326,339) ->
+    116 entries (every BatchNorm incl. UNet3D's, the heads' and the sparse encoder's; ResBlock.norm3 listed twice and stepped twice by
+    Adam), no running statistics anywhere: batch statistics in the eval forward too.  Fixture = the real reference with a CPU shim for
+    SyncBatchNorm.forward (single process: it never synchronises), two steps."""
+    from oracle import costdcnet_oracle as CO
+    g = np.load(os.path.join(golden_dir, 'costdcnet_64x64_n2_syncbn.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, max_depth = [float(x) for x in g['hp']]
+    torch.set_num_threads(4)
+    o = CO.CostDcnOracle(synth.formula_state_dict_costdcnet(), max_depth=max_depth, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd,
+                         w_sd=w_sd, w_sm=w_sm, w_cos=w_cos, syncbn=True)
+    ref_names = [str(x).replace('.bn.', '.bn.') for x in g['adapted_names']]
+    assert o.names == ref_names and len(o.names) == 116 and sum(o.P[k].numel() for k in o.names) == 12336
+    assert o.names.count('enc2d.layer2.0.norm3.weight') == 2 and o.names.count('enc2d.layer3.0.norm3.bias') == 2
+    for s in range(steps):
+        raw, image1, sparse = [torch.from_numpy(x) for x in costdc_frame(s, h, w, n, float(g['density']))]
+        r = o.step(image1, sparse, loss_image=raw)
+        p = 's%d/' % s
+        assert rel_mae(r['depth'], g[p + 'depth_train']) < (1e-5 if s == 0 else 1e-3), s
+        li = r['loss_info']
+        np.testing.assert_allclose([li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], g[p + 'loss_info'],
+                                   rtol=2e-5 if s == 0 else 1e-3, atol=1e-8)
+        if s == 0:
+            for k in set(o.names):
+                gref = g[p + 'grad/' + k]
+                if np.abs(gref).max() == 0:
+                    assert float(r['grads'][k].abs().max()) == 0, k          # proj / pred BatchNorm1d: the detached branch
+                else:
+                    assert rel_mae(r['grads'][k], gref) < 2e-3, k
+                assert rel_mae(o.P[k].detach(), g[p + 'param/' + k]) < 1e-4, k
+            # the doubly listed tensors moved by TWO Adam steps (first step: -lr sign(g) each)
+            k = 'enc2d.layer2.0.norm3.weight'
+            moved = np.abs(o.P[k].detach().numpy() - synth.formula_state_dict_costdcnet()[k])
+            assert np.median(moved) > 1.9 * lr
+        assert rel_mae(o.forward_eval(image1, sparse), g[p + 'depth_eval']) < (1e-5 if s == 0 else 1e-3)
+
+
 def test_minkowski_lite_matches_dense_convolution():
     """The sparse-convolution stand-in on a FULLY occupied grid equals a dense zero-padded Conv3d with the kernel taps in
     the documented order (first spatial axis fastest), and a stride-(1,2,2) convolution equals the dense strided one."""

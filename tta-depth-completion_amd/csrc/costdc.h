@@ -24,7 +24,11 @@ int cd_launch_clamp(const float* src, float* dst, long n, float maxd, hipStream_
 int cd_sparse_levels_build(const CdSparse& q, const float* sparse, float z_step, hipStream_t s);
 int cd_launch_sparse_conv(const CdSparse& q, const float* fin, int lin, int lout, const float* Wk, int ksize, int Ci, int Co, float* fout, hipStream_t s);
 int cd_launch_sparse_bn(const CdSparse& q, const float* f, const float* res, int level, int C, const float* gamma, const float* beta, float* rm, float* rv,
-                        long long* nbt, int train, int repeats, int relu, float* out, hipStream_t s, const PttaStatSync* sync = nullptr);
+                        long long* nbt, int train, int repeats, int relu, float* out, hipStream_t s, const PttaStatSync* sync = nullptr, float* st = nullptr);
+int cd_launch_sparse_conv_bwd(const CdSparse& q, const float* gy, int lin, int lout, const float* Wk, int ksize, int Ci, int Co, float* gx, int acc, hipStream_t s);
+int cd_launch_sparse_bn_bwd(const CdSparse& q, const float* f, const float* y, const float* g, int level, int C, const float* gamma, const float* st, int relu,
+                            float* dgamma, float* dbeta, float* gx, float* gres, int acc_res, float* bw, hipStream_t s, const PttaStatSync* sync = nullptr);
+int cd_launch_densify_bwd(const CdSparse& q, const float* gvol, int ldv, int c0, int C, float* g, hipStream_t s);
 int cd_launch_densify(const CdSparse& q, const float* f, int C, float* dense, hipStream_t s);
 int cd_launch_fusion_fwd(const float* feat2d, const float* feat3d, float* vol, float* maskw, int N, int passes, int h, int w, hipStream_t s);
 int cd_launch_fusion_bwd(const float* gvol, const float* maskw, float* gfeat2d, int N, int h, int w, hipStream_t s);

@@ -35,7 +35,14 @@ struct costdc_engine : GNet {
     CdSparse sp;
     float* sbuf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     struct SConv { float* w = nullptr; int K = 0, Ci = 0, Co = 0; bool loaded = false; };
-    struct SBn { float *g = nullptr, *b = nullptr, *rm = nullptr, *rv = nullptr; long long* nbt = nullptr; int C = 0; };
+    struct SBn { float *g = nullptr, *b = nullptr, *rm = nullptr, *rv = nullptr; long long* nbt = nullptr; int C = 0;
+                 int ad_g = -1, ad_b = -1; float *f = nullptr, *y = nullptr, *st = nullptr; };      // sync_adapt: adapted + saved for the backward
+    // the adapted set of the reference's DDP run (PTTA_SYNCBN_ADAPT): convert_syncbn() runs before adapt_parameters('meta_bn')
+    // (src/tta_main.py:326,339), so every BatchNorm of the model is adapted and has lost its running statistics (AD:364-372)
+    int sync_adapt = 0;
+    std::map<std::string, std::pair<int, int>> sbn_ad;
+    float* sgrad[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* sp_bw = nullptr;
     std::map<std::string, SConv> sconv;
     std::map<std::string, SBn> sbn;
 
@@ -48,10 +55,10 @@ struct costdc_engine : GNet {
         const int r1 = tensor(name + ".r1", 2 * per, h, w, cout, true, per), a1 = tensor(name + ".a1", 2 * per, h, w, cout, true, per);
         const int r2 = tensor(name + ".r2", 2 * per, h, w, cout, true, per), a2 = tensor(name + ".a2", 2 * per, h, w, cout, true, per);
         conv(name + ".conv1", x0, x1, r1, 3, 1, 0, GACT_NONE, W_BOTH, W_BOTH);
-        bn(name + ".bn1", r1, a1, -1, GACT_ELU, W_BOTH, true).tracked = true;
+        bn(name + ".bn1", r1, a1, -1, GACT_ELU, W_BOTH, !sync_adapt).tracked = !sync_adapt;
         { Op& c2 = conv(name + ".conv2", a1, -1, r2, 3, 1, 0, GACT_NONE, W_BOTH, W_BOTH); c2.rH = D; c2.rW = h * w; }
         convs[name + ".conv2"].vcol = 1;
-        bn(name + ".bn2", r2, a2, -1, GACT_ELU, W_BOTH, true).tracked = true;
+        bn(name + ".bn2", r2, a2, -1, GACT_ELU, W_BOTH, !sync_adapt).tracked = !sync_adapt;
         return a2;
     }
     int double_conv(const std::string& pre, int x0, int x1, int mid, int cout, int D, int h, int w) {
@@ -100,10 +107,28 @@ struct costdc_engine : GNet {
         conv("enc2d.conv2", cur, -1, f16, 1, 1, 0, GACT_NONE, W_BOTH, W_BOTH);
         t_feat2d = tensor("feat2d", N2, h4, w4, 16, true);
         { Op& m = conv("conv1_rgb_meta", f16, -1, t_feat2d, 3, 1, 0, GACT_NONE, W_BOTH, W_BOTH); m.ad_w = ad_mw; m.ad_b = ad_mb; }
+        if (sync_adapt) {
+            // convert_sync_batchnorm makes one new module per visited attribute: ResBlock.norm3 and its alias downsample[1] become two
+            // SyncBatchNorm modules sharing one Parameter, which adapt_parameters then lists twice -> two Adam updates per step
+            for (const char* b : {"enc2d.layer2.0.norm3", "enc2d.layer3.0.norm3"})
+                for (const char* l : {".weight", ".bias"}) adapted[aid[std::string(b) + l]].rep = 2;
+            // module order: enc2d, enc3d (the BatchNorm1d inside each MinkowskiBatchNorm is called `bn`), unet3d, proj, proj_t, pred
+            const char* sn[9] = {"bn0", "block1.0.norm1", "block1.0.norm2", "block2.0.norm1", "block2.0.norm2", "block2.0.downsample.1",
+                                 "block3.0.norm1", "block3.0.norm2", "block3.0.downsample.1"};
+            const int sc_[9] = {32, 32, 32, 48, 48, 48, 64, 64, 64};
+            for (int k = 0; k < 9; ++k) {
+                const std::string b = std::string("enc3d.") + sn[k];
+                const int ig = add_adapted(b + ".bn.weight", sc_[k]), ib = add_adapted(b + ".bn.bias", sc_[k]);
+                sbn_ad[b] = std::make_pair(ig, ib);
+            }
+        }
         // fusion (CD:390-406); the sparse encoder runs inside its forward closure
         t_vol = tensor("vol", N2 * 16, h4, w4, 32, true, N * 16);
         func([this](bool train, hipStream_t s) { return fusion_fwd(train, s); },
-             [this](hipStream_t s) { return cd_launch_fusion_bwd(T[t_vol].g, maskw, T[t_feat2d].g, N, h4, w4, s) ? fail("fusion gradient failed", -5) : 0; },
+             [this](hipStream_t s) {
+                 if (cd_launch_fusion_bwd(T[t_vol].g, maskw, T[t_feat2d].g, N, h4, w4, s)) return fail("fusion gradient failed", -5);
+                 return sync_adapt ? sparse_backward(s) : 0;
+             },
              t_feat2d);
         // UNet3D (unet3d.py:7-47), f_maps = [32, 48, 64, 80]
         const int f[4] = {32, 48, 64, 80};
@@ -169,10 +194,16 @@ struct costdc_engine : GNet {
             const int r = tensor(std::string(name) + ".h", N, fh, fw, 512, bwd), a = tensor(std::string(name) + ".a", N, fh, fw, 512, bwd);
             const int o = tensor(std::string(name) + ".out", N, fh, fw, 512, bwd);
             conv(std::string(name) + ".0", xin, -1, r, 1, 1, 0, GACT_NONE, W_GRAD, W_GRAD, true, bwd);
-            bn(std::string(name) + ".1", r, a, -1, GACT_RELU, W_GRAD, true, true, bwd).tracked = true;
+            bn(std::string(name) + ".1", r, a, -1, GACT_RELU, W_GRAD, !sync_adapt, true, bwd).tracked = !sync_adapt;
             conv(std::string(name) + ".3", a, -1, o, 1, 1, 0, GACT_NONE, W_GRAD, W_GRAD, true, bwd);
             return o;
         };
+        if (sync_adapt)            // module order proj, proj_t, pred; proj / pred only feed the detached embedding: never given a gradient
+            for (const char* b : {"proj.1", "proj_t.1", "pred.1"})
+                for (const char* l : {".weight", ".bias"}) {
+                    const int i = add_adapted(std::string(b) + l, 512);
+                    if (strcmp(b, "proj_t.1") != 0) adapted[i].rep = 0;
+                }
         const int pz = mlp("proj", t_rows_p, false);
         t_emb = mlp("pred", pz, false); tid["emb"] = t_emb;
         t_ref = mlp("proj_t", t_rows, true); tid["ref"] = t_ref;
@@ -197,10 +228,18 @@ struct costdc_engine : GNet {
         sp.cnt = (int*)dalloc(4 * sizeof(int));
         sp.rowcnt = (int*)dalloc((size_t)N * 16 * H * sizeof(int)); sp.rowoff = (int*)dalloc((size_t)N * 16 * H * sizeof(int));
         sp.feat_in = falloc((size_t)cap);
-        sp.bn_part = falloc((size_t)256 * 2 * 64); sp.bn_st = falloc(2 * 64);
+        sp.bn_part = falloc((size_t)256 * 2 * 64); sp.bn_st = falloc(4 * 64);
         for (int k = 0; k < 5; ++k) sbuf[k] = falloc((size_t)cap * 64);
         auto sc = [&](const std::string& n, int K, int Ci, int Co) { SConv c; c.K = K; c.Ci = Ci; c.Co = Co; c.w = falloc((size_t)K * Ci * Co); sconv[n] = c; };
-        auto sb = [&](const std::string& n, int C) { SBn b; b.C = C; b.g = falloc(C); b.b = falloc(C); sbn[n] = b; };
+        auto sb = [&](const std::string& n, int C) {
+            SBn b; b.C = C; b.g = falloc(C); b.b = falloc(C);
+            if (sync_adapt) {                    // adapted, and everything the backward needs is kept: input, output, [scale, shift, mean, inv]
+                b.ad_g = sbn_ad[n].first; b.ad_b = sbn_ad[n].second;
+                b.f = falloc((size_t)cap * C); b.y = falloc((size_t)cap * C); b.st = falloc((size_t)4 * C);
+            }
+            sbn[n] = b;
+        };
+        if (sync_adapt) { for (int k = 0; k < 4; ++k) sgrad[k] = falloc((size_t)cap * 64); sp_bw = falloc(3 * 64); }
         sc("enc3d.conv1", 27, 1, 32); sb("enc3d.bn0", 32);
         int inpl = 32; const int pl[3] = {32, 48, 64};
         for (int b = 0; b < 3; ++b) {
@@ -219,12 +258,72 @@ struct costdc_engine : GNet {
     }
     int sbn_run(const std::string& n, const float* f, const float* res, int level, bool train, int relu, float* out, hipStream_t s) {
         SBn& b = sbn[n];
+        if (sync_adapt)      // no running statistics: batch statistics in train AND eval mode (synchronised over the ranks in train mode only)
+            return cd_launch_sparse_bn(sp, f, res, level, b.C, adapted[b.ad_g].p, adapted[b.ad_b].p, nullptr, nullptr, nullptr, 1, 1, relu, out, s,
+                                       train ? &stat_sync : nullptr, b.st) ? fail("sparse batch-norm " + n + " failed", -5) : 0;
         if (!train && (!b.rm || !b.rv)) return fail("running statistics of " + n + " not loaded", -3);
         // train: the reference evaluates the sparse encoder once per pass on the same input (CD:216, :237): two updates
         return cd_launch_sparse_bn(sp, f, res, level, b.C, b.g, b.b, b.rm, b.rv, b.nbt, train ? 1 : 0, 2, relu, out, s, &stat_sync) ? fail("sparse batch-norm " + n + " failed", -5) : 0;
     }
+    // sync_adapt: the same network with every BatchNorm's input and output kept, then its backward (BatchNorm gamma / beta gradients only)
+    int sparse_encoder_adapt(bool train, hipStream_t s) {
+        NRUN(sconv_run("enc3d.conv1", sp.feat_in, 0, 0, sbn["enc3d.bn0"].f, s));
+        NRUN(sbn_run("enc3d.bn0", sbn["enc3d.bn0"].f, nullptr, 0, train, 1, sbn["enc3d.bn0"].y, s));
+        const float* x = sbn["enc3d.bn0"].y;
+        for (int blk = 1; blk <= 3; ++blk) {
+            const std::string P = "enc3d.block" + std::to_string(blk) + ".0";
+            const int lin = blk == 1 ? 0 : blk - 2, lout = blk - 1;
+            SBn &n1 = sbn[P + ".norm1"], &n2 = sbn[P + ".norm2"];
+            NRUN(sconv_run(P + ".conv1", x, lin, lout, n1.f, s));
+            NRUN(sbn_run(P + ".norm1", n1.f, nullptr, lout, train, 1, n1.y, s));
+            NRUN(sconv_run(P + ".conv2", n1.y, lout, lout, n2.f, s));
+            const float* res = x;
+            if (blk > 1) {
+                SBn& ds = sbn[P + ".downsample.1"];
+                NRUN(sconv_run(P + ".downsample.0", x, lin, lout, ds.f, s));
+                NRUN(sbn_run(P + ".downsample.1", ds.f, nullptr, lout, train, 0, ds.y, s));
+                res = ds.y;
+            }
+            NRUN(sbn_run(P + ".norm2", n2.f, res, lout, train, 1, n2.y, s));
+            x = n2.y;
+        }
+        NRUN(sconv_run("enc3d.conv2", x, 2, 2, sbuf[0], s));
+        if (cd_launch_densify(sp, sbuf[0], 16, feat3d, s)) return fail("densify failed", -5);
+        return 0;
+    }
+    int sconv_bwd(const std::string& n, const float* gy, int lin, int lout, float* gx, int acc, hipStream_t s) {
+        const SConv& c = sconv[n];
+        return cd_launch_sparse_conv_bwd(sp, gy, lin, lout, c.w, c.K == 27 ? 3 : 1, c.Ci, c.Co, gx, acc, s) ? fail("sparse conv gradient " + n + " failed", -5) : 0;
+    }
+    int sbn_bwd(const std::string& n, const float* g, int level, int relu, float* gx, float* gres, hipStream_t s) {
+        SBn& b = sbn[n];
+        return cd_launch_sparse_bn_bwd(sp, b.f, b.y, g, level, b.C, adapted[b.ad_g].p, b.st, relu, gall + adapted[b.ad_g].goff, gall + adapted[b.ad_b].goff,
+                                       gx, gres, 0, sp_bw, s, &stat_sync) ? fail("sparse batch-norm gradient " + n + " failed", -5) : 0;
+    }
+    int sparse_backward(hipStream_t s) {
+        float *G0 = sgrad[0], *G1 = sgrad[1], *G2 = sgrad[2], *G3 = sgrad[3];
+        // the real pass's half of the fused volume's gradient, channels 16..31 (fusion concatenates [feat2d * mask | feat3d])
+        if (cd_launch_densify_bwd(sp, T[t_vol].g, 32, 16, 16, G0, s)) return fail("densify gradient failed", -5);
+        NRUN(sconv_bwd("enc3d.conv2", G0, 2, 2, G1, 0, s));                              // G1 = d block3 output
+        for (int blk = 3; blk >= 1; --blk) {
+            const std::string P = "enc3d.block" + std::to_string(blk) + ".0";
+            const int lin = blk == 1 ? 0 : blk - 2, lout = blk - 1;
+            NRUN(sbn_bwd(P + ".norm2", G1, lout, 1, G0, G2, s));                         // G0 = d conv2 out, G2 = d residual branch
+            NRUN(sconv_bwd(P + ".conv2", G0, lout, lout, G3, 0, s));
+            NRUN(sbn_bwd(P + ".norm1", G3, lout, 1, G0, nullptr, s));
+            if (blk > 1) {
+                NRUN(sconv_bwd(P + ".conv1", G0, lin, lout, G1, 0, s));                  // G1 = d block input
+                NRUN(sbn_bwd(P + ".downsample.1", G2, lout, 0, G0, nullptr, s));
+                NRUN(sconv_bwd(P + ".downsample.0", G0, lin, lout, G1, 1, s));
+            } else {
+                NRUN(sconv_bwd(P + ".conv1", G0, lin, lout, G2, 1, s));                  // identity residual: G2 already holds its share
+            }
+        }
+        return sbn_bwd("enc3d.bn0", G2, 0, 1, G0, nullptr, s);
+    }
     int sparse_encoder(bool train, hipStream_t s) {
         if (cd_sparse_levels_build(sp, sp_clamp, z_step, s)) return fail("depth2MDP failed", -5);
+        if (sync_adapt) return sparse_encoder_adapt(train, s);
         float *a = sbuf[0], *b = sbuf[1], *c = sbuf[2], *d = sbuf[3], *e = sbuf[4];
         NRUN(sconv_run("enc3d.conv1", sp.feat_in, 0, 0, a, s));
         NRUN(sbn_run("enc3d.bn0", a, nullptr, 0, train, 1, b, s));                       // out_p1 = b
@@ -288,6 +387,7 @@ struct costdc_engine : GNet {
             SBn& b = it->second;
             if (leaf == "weight") { NCHK(hipMemcpyAsync(b.g, src, (size_t)b.C * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0; }
             if (leaf == "bias") { NCHK(hipMemcpyAsync(b.b, src, (size_t)b.C * sizeof(float), hipMemcpyDeviceToDevice, s)); return 0; }
+            if (sync_adapt && leaf != "weight" && leaf != "bias") return 0;         // running statistics dropped with the SyncBatchNorm conversion
             if (leaf == "running_mean") { b.rm = (float*)src; return 0; }           // bound, updated in place
             if (leaf == "running_var") { b.rv = (float*)src; return 0; }
             if (leaf == "num_batches_tracked") { b.nbt = (long long*)src; return 0; }
@@ -298,6 +398,7 @@ struct costdc_engine : GNet {
         // BatchNorm2d running statistics are dropped by adapt_parameters('meta_bn') (AD:370-372)
         if (name.rfind("enc2d.", 0) == 0 && (ends("running_mean") || ends("running_var") || ends("num_batches_tracked"))) return 0;
         if (ends("running_mean") || ends("running_var") || ends("num_batches_tracked")) {
+            if (sync_adapt) return 0;
             for (Op& o : ops)
                 if (o.kind == K_BN && o.tracked && o.bname == base) {
                     if (leaf == "running_mean") o.rm = (float*)src; else if (leaf == "running_var") o.rv = (float*)src; else o.nbt = (long long*)src;
@@ -333,7 +434,7 @@ struct costdc_engine : GNet {
     }
 };
 
-GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth, int* rc) {
+GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth, int flags, int* rc) {
     *rc = 0;
     if (n < 1 || h < 32 || w < 32 || !hp || !(max_depth > 0.f)) { *rc = -22; return nullptr; }
     costdc_engine* e = new costdc_engine();
@@ -348,6 +449,7 @@ GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth
     // hipGraph replay of the step / eval forward: built and bit-identical (tests), but measured 0.3 - 2 % SLOWER than kernel-by-kernel
     // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: PTTA_GRAPH=1 / ptta_set_graph(h, 1)
     { const char* gr = getenv("PTTA_GRAPH"); e->use_graph = (gr && strcmp(gr, "1") == 0) ? 1 : 0; }
+    e->sync_adapt = (flags & 1) ? 1 : 0;
     e->build();
     if (e->oom || !e->step_dev) { delete e; *rc = -12; return nullptr; }
     if (e->upload_hparams(nullptr)) { delete e; *rc = -5; return nullptr; }

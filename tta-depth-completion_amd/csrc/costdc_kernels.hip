@@ -246,8 +246,9 @@ __global__ void cd_sbn_finalize_kernel(const float* __restrict__ part, const int
             rm[c] = a; rv[c] = b2;
         }
     } else { mu = rm[c]; var = rv[c]; }
-    const float sc = gamma[c] / sqrtf(var + 1e-5f);
-    st[c] = sc; st[C + c] = beta[c] - mu * sc;
+    const float iv = 1.f / sqrtf(var + 1e-5f);
+    const float sc = gamma[c] * iv;
+    st[c] = sc; st[C + c] = beta[c] - mu * sc; st[2 * C + c] = mu; st[3 * C + c] = iv;      // [scale, shift, mean, inv][C]
 }
 __global__ void cd_sbn_apply_kernel(const float* __restrict__ f, const float* __restrict__ res, const int* __restrict__ cnt, int C, const float* __restrict__ st,
                                     int relu, float* __restrict__ out) {
@@ -267,6 +268,101 @@ __global__ void cd_densify_kernel(const float* __restrict__ f, const int4* __res
         const int c = (int)(i % C); const int4 q = coords[i / C];
         const int y = q.z >> 2, x = q.w >> 2;
         if (q.y < 16 && y < h4 && x < w4) dense[((((long)q.x * 16 + q.y) * h4 + y) * w4 + x) * C + c] = f[i];
+    }
+}
+
+// ---- backward through the sparse encoder: only the shared-parameter (DDP) run needs it -- after convert_syncbn() the reference's
+// adapt_parameters('meta_bn') adapts the BatchNorm1d inside every MinkowskiBatchNorm too (src/costdcnet_model_adapt.py:364-372), so
+// their gamma / beta gradients flow back from the fused volume through densify, the 1x1x1 head and the three BasicBlocks.
+// Transposed generalized sparse convolution: gx[j] = sum_k W[k] gy[u] over the output voxels u that read input voxel j with offset k,
+// i.e. u = j - off_k * ts_in when that coordinate lies on the output grid and exists.  One block per input voxel, thread = input channel.
+__global__ __launch_bounds__(64) void cd_sparse_conv_bwd_kernel(const float* __restrict__ gy, const int* __restrict__ vol_out, int sh_in, int sh_out, int Hout, int Wout,
+                                                                const int4* __restrict__ coords_in, const int* __restrict__ cnt_in,
+                                                                const float* __restrict__ Wk, int ksize, int Ci, int Co, float* __restrict__ gx, int acc) {
+    const int ci = threadIdx.x;
+    const int nk = ksize == 3 ? 27 : 1;
+    const int ts_in = 1 << sh_in, mask_out = (1 << sh_out) - 1;
+    for (int j = blockIdx.x; j < *cnt_in; j += gridDim.x) {
+        const int4 c = coords_in[j];
+        float a = 0.f;
+        for (int k = 0; k < nk; ++k) {
+            int dz = 0, dy = 0, dx = 0;
+            if (ksize == 3) { dz = k % 3 - 1; dy = (k / 3) % 3 - 1; dx = k / 9 - 1; }
+            const int z = c.y - dz, y = c.z - dy * ts_in, x = c.w - dx * ts_in;        // the output voxel's coordinate
+            if (z < 0 || z > 15 || y < 0 || x < 0 || (y & mask_out) || (x & mask_out)) continue;
+            const int yo = y >> sh_out, xo = x >> sh_out;
+            if (yo >= Hout || xo >= Wout) continue;
+            const int u = vol_out[(((long)c.x * 16 + z) * Hout + yo) * Wout + xo];
+            if (u < 0) continue;
+            if (ci < Ci) {
+                const float* g = gy + (long)u * Co;
+                const float* w = Wk + ((long)k * Ci + ci) * Co;
+                for (int co = 0; co < Co; ++co) a = fmaf(g[co], w[co], a);
+            }
+        }
+        if (ci < Ci) { float* o = gx + (long)j * Ci + ci; *o = acc ? *o + a : a; }
+    }
+}
+// BatchNorm over voxels, backward: y = relu?(bn(f) + res?); g1 = g * (y > 0) when relu; partial {sum g1, sum g1 xhat}
+__global__ __launch_bounds__(64) void cd_sbn_bwd_stats_kernel(const float* __restrict__ f, const float* __restrict__ y, const float* __restrict__ g,
+                                                              const int* __restrict__ cnt, int C, const float* __restrict__ st, int relu, float* __restrict__ part) {
+    const int c = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float mu = st[2 * C + c], iv = st[3 * C + c];
+        for (int u = blockIdx.x; u < *cnt; u += gridDim.x) {
+            float gv = g[(long)u * C + c];
+            if (relu && !(y[(long)u * C + c] > 0.f)) gv = 0.f;
+            s1 += gv; s2 += gv * (f[(long)u * C + c] - mu) * iv;
+        }
+        part[((long)blockIdx.x * 2) * C + c] = s1; part[((long)blockIdx.x * 2 + 1) * C + c] = s2;
+    }
+}
+__global__ void cd_sbn_bwd_collapse_kernel(const float* __restrict__ part, const int* __restrict__ cnt, int C, double* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) out[2 * C] = (double)(*cnt);
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < SBN_BLOCKS; ++b) { s1 += (double)part[((long)b * 2) * C + c]; s2 += (double)part[((long)b * 2 + 1) * C + c]; }
+    out[c] = s1; out[C + c] = s2;
+}
+// dgamma, dbeta (scaled by 1 / world under SyncBatchNorm: the DDP-averaged local gradients, as gbn.hip) and bw = [gamma * inv, c1, c2][C]
+__global__ void cd_sbn_bwd_finalize_kernel(const float* __restrict__ part, const int* __restrict__ cnt, int C, const float* __restrict__ gamma,
+                                           const float* __restrict__ st, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ bw,
+                                           const double* __restrict__ gsum, float grad_scale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0, R;
+    if (gsum) { s1 = gsum[c]; s2 = gsum[C + c]; R = gsum[2 * C] > 0.0 ? gsum[2 * C] : 1.0; }
+    else {
+        for (int b = 0; b < SBN_BLOCKS; ++b) { s1 += (double)part[((long)b * 2) * C + c]; s2 += (double)part[((long)b * 2 + 1) * C + c]; }
+        R = (double)(*cnt > 0 ? *cnt : 1);
+    }
+    dbeta[c] = (float)s1 * grad_scale; dgamma[c] = (float)s2 * grad_scale;
+    bw[c] = gamma[c] * st[3 * C + c]; bw[C + c] = (float)(s1 / R); bw[2 * C + c] = (float)(s2 / R);
+}
+// gx (+)= gamma inv (g1 - c1 - xhat c2);  gres (+)= g1
+__global__ void cd_sbn_bwd_apply_kernel(const float* __restrict__ f, const float* __restrict__ y, const float* __restrict__ g, const int* __restrict__ cnt, int C,
+                                        const float* __restrict__ st, const float* __restrict__ bw, int relu, float* __restrict__ gx, float* __restrict__ gres,
+                                        int acc_res) {
+    const long total = (long)(*cnt) * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C);
+        float gv = g[i];
+        if (relu && !(y[i] > 0.f)) gv = 0.f;
+        const float xh = (f[i] - st[2 * C + c]) * st[3 * C + c];
+        gx[i] = bw[c] * (gv - bw[C + c] - xh * bw[2 * C + c]);
+        if (gres) gres[i] = acc_res ? gres[i] + gv : gv;
+    }
+}
+// gradient of densify: g[u][c] = gvol[(frame, plane, y/4, x/4)][c0 + c] at the level-2 voxels (gvol has `ldv` channels per voxel of the volume)
+__global__ void cd_densify_bwd_kernel(const float* __restrict__ gvol, int ldv, int c0, const int4* __restrict__ coords, const int* __restrict__ cnt, int C, int h4, int w4,
+                                      float* __restrict__ g) {
+    const long total = (long)(*cnt) * C;
+    GRID_STRIDE(i, total) {
+        const int c = (int)(i % C); const int4 q = coords[i / C];
+        const int y = q.z >> 2, x = q.w >> 2;
+        g[i] = (q.y < 16 && y < h4 && x < w4) ? gvol[((((long)q.x * 16 + q.y) * h4 + y) * w4 + x) * ldv + c0 + c] : 0.f;
     }
 }
 
@@ -488,8 +584,9 @@ int cd_launch_sparse_conv(const CdSparse& q, const float* fin, int lin, int lout
                        Ci, Co, fout); LAUNCH_OK();
 }
 int cd_launch_sparse_bn(const CdSparse& q, const float* f, const float* res, int level, int C, const float* gamma, const float* beta, float* rm, float* rv,
-                        long long* nbt, int train, int repeats, int relu, float* out, hipStream_t s, const PttaStatSync* sync) {
+                        long long* nbt, int train, int repeats, int relu, float* out, hipStream_t s, const PttaStatSync* sync, float* st) {
     if (C > 64) return -22;
+    if (!st) st = q.bn_st;
     if (train) hipLaunchKernelGGL(cd_sbn_stats_kernel, dim3(SBN_BLOCKS), dim3(64), 0, s, f, q.cnt + level, C, q.bn_part);
     const double* gsum = nullptr;
     if (train && sync && sync->on()) {
@@ -499,8 +596,32 @@ int cd_launch_sparse_bn(const CdSparse& q, const float* f, const float* res, int
         if (rc) return rc;
         gsum = sync->buf;
     }
-    hipLaunchKernelGGL(cd_sbn_finalize_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, gamma, beta, rm, rv, nbt, train, repeats, q.bn_st, gsum);
-    hipLaunchKernelGGL(cd_sbn_apply_kernel, dim3(2048), dim3(256), 0, s, f, res, q.cnt + level, C, q.bn_st, relu, out); LAUNCH_OK();
+    hipLaunchKernelGGL(cd_sbn_finalize_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, gamma, beta, rm, rv, nbt, train, repeats, st, gsum);
+    hipLaunchKernelGGL(cd_sbn_apply_kernel, dim3(2048), dim3(256), 0, s, f, res, q.cnt + level, C, st, relu, out); LAUNCH_OK();
+}
+int cd_launch_sparse_conv_bwd(const CdSparse& q, const float* gy, int lin, int lout, const float* Wk, int ksize, int Ci, int Co, float* gx, int acc, hipStream_t s) {
+    if (Ci > 64) return -22;
+    hipLaunchKernelGGL(cd_sparse_conv_bwd_kernel, dim3(4096), dim3(64), 0, s, gy, q.vol[lout], lin, lout, q.H >> lout, q.W >> lout, q.coords[lin], q.cnt + lin, Wk,
+                       ksize, Ci, Co, gx, acc); LAUNCH_OK();
+}
+// y = relu?(bn(f) [+ res]) with the forward's saved st = [scale, shift, mean, inv][C]: dgamma, dbeta, gx (written), gres (the residual branch, optional)
+int cd_launch_sparse_bn_bwd(const CdSparse& q, const float* f, const float* y, const float* g, int level, int C, const float* gamma, const float* st, int relu,
+                            float* dgamma, float* dbeta, float* gx, float* gres, int acc_res, float* bw, hipStream_t s, const PttaStatSync* sync) {
+    if (C > 64) return -22;
+    hipLaunchKernelGGL(cd_sbn_bwd_stats_kernel, dim3(SBN_BLOCKS), dim3(64), 0, s, f, y, g, q.cnt + level, C, st, relu, q.bn_part);
+    const double* gsum = nullptr; float gsc = 1.f;
+    if (sync && sync->on()) {
+        if (2 * C + 1 > sync->cap) return -22;
+        hipLaunchKernelGGL(cd_sbn_bwd_collapse_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, sync->buf);
+        const int rc = sync->exchange(2 * C + 1, s);
+        if (rc) return rc;
+        gsum = sync->buf; gsc = 1.f / (float)sync->world;
+    }
+    hipLaunchKernelGGL(cd_sbn_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, q.bn_part, q.cnt + level, C, gamma, st, dgamma, dbeta, bw, gsum, gsc);
+    hipLaunchKernelGGL(cd_sbn_bwd_apply_kernel, dim3(2048), dim3(256), 0, s, f, y, g, q.cnt + level, C, st, bw, relu, gx, gres, acc_res); LAUNCH_OK();
+}
+int cd_launch_densify_bwd(const CdSparse& q, const float* gvol, int ldv, int c0, int C, float* g, hipStream_t s) {
+    hipLaunchKernelGGL(cd_densify_bwd_kernel, dim3(2048), dim3(256), 0, s, gvol, ldv, c0, q.coords[2], q.cnt + 2, C, q.H >> 2, q.W >> 2, g); LAUNCH_OK();
 }
 int cd_launch_densify(const CdSparse& q, const float* f, int C, float* dense, hipStream_t s) {
     const int h4 = q.H >> 2, w4 = q.W >> 2;

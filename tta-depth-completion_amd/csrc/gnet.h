@@ -97,7 +97,7 @@ struct Op {
     std::function<int(hipStream_t)> fbwd;
 };
 
-struct Adapted { std::string name; long n = 0, goff = 0; float *p = nullptr, *m = nullptr, *v = nullptr; };
+struct Adapted { std::string name; long n = 0, goff = 0; float *p = nullptr, *m = nullptr, *v = nullptr; int rep = 1; };
 
 __global__ void gnet_pad_channels_kernel(const float* __restrict__ src, int lds_, int C, float* __restrict__ dst, int Cp, long npix);
 inline int nb(long total) { long b = (total + 255) / 256; if (b > 16384) b = 16384; if (b < 1) b = 1; return (int)b; }
@@ -259,7 +259,10 @@ struct GNet {
         const int C = T[x].C;
         if (C > max_bn_C) max_bn_C = C;
         if (frozen) frozen_bn[bname] = std::make_pair(falloc(C), falloc(C));
-        else { o.ad_g = add_adapted(bname + ".weight", C); o.ad_beta = add_adapted(bname + ".bias", C); }
+        else {      // a backbone may have reserved the entries already (to fix their place in the adapted list)
+            o.ad_g = aid.count(bname + ".weight") ? aid[bname + ".weight"] : add_adapted(bname + ".weight", C);
+            o.ad_beta = aid.count(bname + ".bias") ? aid[bname + ".bias"] : add_adapted(bname + ".bias", C);
+        }
         o.st = falloc((size_t)4 * 2 * C); o.st_eval = falloc((size_t)4 * C);
         // statistics fused into the producing convolution's epilogue when that is the stride-1 matrix-core kernel
         for (int k = (int)ops.size() - 1; k >= 0; --k) {
@@ -407,6 +410,7 @@ struct GNet {
     int set_image_norm(float div, const float* mean, const float* stdv);
     int bind_adapted(const char* name, float* p, float* m, float* v);
     int adapted_count() const { return (int)adapted.size(); }
+    int adapted_repeat(int index) const { return (index < 0 || index >= (int)adapted.size()) ? 0 : adapted[index].rep; }
     const char* adapted_name(int index, int64_t* numel) const {
         if (index < 0 || index >= (int)adapted.size()) return nullptr;
         if (numel) *numel = adapted[index].n;

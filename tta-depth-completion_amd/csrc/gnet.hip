@@ -276,7 +276,7 @@ int GNet::forward_eval(const float* image, const float* sparse, float* depth_out
 int GNet::upload_adam_table(hipStream_t s) {           // after ptta_bind_adapted only: pointer table of every adapted tensor
     adam_host.resize(adapted.size());
     long off = 0;
-    for (size_t k = 0; k < adapted.size(); ++k) { const Adapted& ad = adapted[k]; adam_host[k] = PttaAdamEntry{ad.p, ad.m, ad.v, gall + ad.goff, ad.n, off}; off += ad.n; }
+    for (size_t k = 0; k < adapted.size(); ++k) { const Adapted& ad = adapted[k]; adam_host[k] = PttaAdamEntry{ad.p, ad.m, ad.v, gall + ad.goff, ad.n, off, ad.rep}; off += ad.n; }
     NCHK(hipMemcpyAsync(adam_tab, adam_host.data(), adam_host.size() * sizeof(PttaAdamEntry), hipMemcpyHostToDevice, s));
     adam_tab_dirty = false;
     return 0;

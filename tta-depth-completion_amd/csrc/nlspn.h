@@ -4,4 +4,4 @@
 #include "gnet.h"
 
 GNet* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int legacy_offset, int* rc);         // nlspn_api.hip
-GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth, int* rc);          // costdc_api.hip
+GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth, int flags, int* rc);          // costdc_api.hip

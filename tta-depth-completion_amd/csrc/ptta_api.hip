@@ -998,9 +998,9 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
         return 0;
     }
     if (backbone_id == PTTA_BACKBONE_COSTDCNET) {
-        if (meta_mode != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32 || !hp) return -38;
+        if ((meta_mode & ~PTTA_SYNCBN_ADAPT) != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32 || !hp) return -38;
         int rc = 0;
-        GNet* e = costdc_create(n, height, width, hp, hp->max_predict_depth, &rc);
+        GNet* e = costdc_create(n, height, width, hp, hp->max_predict_depth, (meta_mode & PTTA_SYNCBN_ADAPT) ? 1 : 0, &rc);
         if (!e) return rc ? rc : -12;
         ptta_ctx* c = new ptta_ctx();
         c->nl = e; c->N = n; c->H = height; c->W = width; c->hp = *hp;
@@ -1168,6 +1168,11 @@ const char* ptta_adapted_name(ptta_handle c, int index, int64_t* numel) {
     if (!c || index < 0 || index >= (int)c->adapted.size()) return nullptr;
     if (numel) *numel = c->adapted[index].n;
     return c->adapted[index].name.c_str();
+}
+int ptta_adapted_repeat(ptta_handle c, int index) {
+    if (!c) return 0;
+    if (c->nl) return c->nl->adapted_repeat(index);
+    return (index >= 0 && index < (int)c->adapted.size()) ? 1 : 0;
 }
 int ptta_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity, ptta_stream s) {
     NLFWD(c->nl->get_grad(name, dst, capacity, (hipStream_t)s));

@@ -156,7 +156,9 @@ int ptta_launch_adam(float* p, float* m, float* v, const float* g, long n, const
                      const int* step_dev, hipStream_t s);
 int ptta_launch_step_inc(int* step_dev, hipStream_t s);
 // every adapted tensor in one launch; also increments the step count (torch.optim.Adam's state['step'])
-struct PttaAdamEntry { float *p, *m, *v; const float* g; long n, off; };
+// rep: how many times the optimizer's parameter list names this tensor (torch.optim.Adam updates a parameter once per occurrence, each
+// with its own step count: occurrence r of step t uses (t - 1) * rep + r + 1); 0 / 1 = the usual single update
+struct PttaAdamEntry { float *p, *m, *v; const float* g; long n, off; int rep = 1; };
 int ptta_launch_adam_multi(const PttaAdamEntry* tab_dev, int nt, long total, const float* hyper, int* step_dev, unsigned* ticket_dev, hipStream_t s);
 int ptta_launch_set_floats(float* dst, const float* host_src, int n /*<= 8*/, hipStream_t s);   // by kernel argument: no sync
 int ptta_launch_set_int(int* dst, int v, hipStream_t s);

@@ -134,14 +134,29 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const PttaAdamEntry* __
         int lo = 0, hi = nt - 1;
         while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].off <= idx) lo = mid; else hi = mid - 1; }
         const PttaAdamEntry e = tab[lo];
+        if (e.rep == 0) continue;                           // listed, never given a gradient (torch.optim.Adam skips grad = None)
         const long k = idx - e.off;
-        float gg = e.g[k];
-        const float pk = e.p[k];
-        if (wd != 0.f) gg = fmaf(wd, pk, gg);
-        const float mk = b1 * e.m[k] + (1.f - b1) * gg;
-        const float vk = b2 * e.v[k] + (1.f - b2) * gg * gg;
-        e.m[k] = mk; e.v[k] = vk;
-        e.p[k] = pk - step_size * (mk / (sqrtf(vk) / bc2s + eps));
+        const float g0 = e.g[k];
+        float pk = e.p[k], mk = e.m[k], vk = e.v[k];
+        if (e.rep <= 1) {
+            float gg = g0;
+            if (wd != 0.f) gg = fmaf(wd, pk, gg);
+            mk = b1 * mk + (1.f - b1) * gg;
+            vk = b2 * vk + (1.f - b2) * gg * gg;
+            pk = pk - step_size * (mk / (sqrtf(vk) / bc2s + eps));
+        } else {
+            // a tensor listed `rep` times: `rep` consecutive updates with the same gradient, step counts (t - 1) * rep + 1 ... t * rep
+            for (int r = 0; r < e.rep; ++r) {
+                const int tt = (t - 1) * e.rep + r + 1;
+                const double c1 = 1.0 - pow((double)b1, (double)tt), c2 = 1.0 - pow((double)b2, (double)tt);
+                float gg = g0;
+                if (wd != 0.f) gg = fmaf(wd, pk, gg);
+                mk = b1 * mk + (1.f - b1) * gg;
+                vk = b2 * vk + (1.f - b2) * gg * gg;
+                pk = pk - (float)((double)lr / c1) * (mk / (sqrtf(vk) / (float)sqrt(c2) + eps));
+            }
+        }
+        e.m[k] = mk; e.v[k] = vk; e.p[k] = pk;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -15,6 +15,7 @@ PTTA_BACKBONE_NLSPN = 1
 PTTA_BACKBONE_COSTDCNET = 2
 PTTA_NLSPN_LEGACY_OFFSET = 0x100
 PTTA_NLSPN_SYNCBN_ADAPT = 0x200
+PTTA_SYNCBN_ADAPT = 0x200
 PTTA_META_1LAYER = 0
 PTTA_META_2LAYERS = 1
 PTTA_DTYPE_F32 = 0
@@ -49,6 +50,7 @@ SIGNATURES = [
     ('ptta_get_grad', c_int, [_P, c_char_p, _P, c_int64, _P]),
     ('ptta_adapted_count', c_int, [_P]),
     ('ptta_adapted_name', c_char_p, [_P, c_int, POINTER(c_int64)]),
+    ('ptta_adapted_repeat', c_int, [_P, c_int]),
     ('ptta_adam_step', c_int, [_P, _P, _P, _P]),
     ('ptta_step', c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     ('ptta_outlier_removal', c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),

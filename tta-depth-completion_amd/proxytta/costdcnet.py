@@ -18,16 +18,37 @@ from .model import MsgChnModel_Adapt, _ForwardFn, _init_tensor, _Tree
 _BUFFERS = ('running_mean', 'running_var', 'num_batches_tracked')
 
 
-def costdcnet_adapted_names(keys):
+def costdcnet_adapted_names(keys, syncbn=False):
     """adapt_parameters('meta_bn') (src/costdcnet_model_adapt.py:357-378): parameters whose name contains 'meta', then
     weight / bias of every BatchNorm2d in module order = Encoder2D's (BatchNorm3d, BatchNorm1d and the sparse encoder's
-    MinkowskiBatchNorm are not BatchNorm2d; ResBlock.norm3 also sits inside `downsample` but a module is visited once)."""
+    MinkowskiBatchNorm are not BatchNorm2d; ResBlock.norm3 also sits inside `downsample` but a module is visited once).
+    syncbn: the list of the reference's DDP run.  convert_syncbn() runs BEFORE adapt_parameters (src/tta_main.py:326,339), every
+    BatchNorm is a SyncBatchNorm by then and passes the isinstance test (:364-366): Encoder2D's, the BatchNorm1d inside each
+    MinkowskiBatchNorm (`enc3d.<layer>.bn`), UNet3D's BatchNorm3d and the heads' BatchNorm1d -- 116 entries.
+    convert_sync_batchnorm builds one new module per visited attribute, so ResBlock.norm3 and its alias downsample[1] are two
+    modules around ONE Parameter: enc2d.layer{2,3}.0.norm3.{weight,bias} are listed twice (and stepped twice by Adam)."""
     names = [k for k in keys if 'meta' in k]
     for k in keys:
-        if k.startswith('enc2d.') and k.endswith('.running_mean') and '.downsample.1.' not in k:
-            pre = k[:-len('.running_mean')]
-            names += [pre + '.weight', pre + '.bias']
+        if not k.endswith('.running_mean'):
+            continue
+        pre = k[:-len('.running_mean')]
+        if not syncbn:
+            if k.startswith('enc2d.') and '.downsample.1.' not in k:
+                names += [pre + '.weight', pre + '.bias']
+            continue
+        if pre.startswith('enc2d.'):
+            pre = pre.replace('.downsample.1', '.norm3')
+        names += [pre + '.weight', pre + '.bias']
     return names
+
+
+def _unique(names):
+    seen, out = set(), []
+    for k in names:
+        if k not in seen:
+            seen.add(k)
+            out.append(k)
+    return out
 
 
 class CostDCNetModel_Adapt(MsgChnModel_Adapt):
@@ -63,27 +84,31 @@ class CostDCNetModel_Adapt(MsgChnModel_Adapt):
         for k, s in synth.costdcnet_keys(mode):
             if k.startswith(('proj', 'pred', 'conv1_rgb_meta')):
                 self.model._leaf(k, _init_tensor(k, s).to(self.device), not k.endswith(_BUFFERS))
-        self.adapted = costdcnet_adapted_names([k for k, _ in synth.costdcnet_keys(mode)])
+        self._set_adapted()
+
+    def _set_adapted(self):
+        # adapted_listed: the reference's parameter list (duplicates included); adapted: the tensors behind it, as the library binds them
+        self.adapted_listed = costdcnet_adapted_names([k for k, _ in synth.costdcnet_keys(self.prepare_mode)], self.sync_bn)
+        self.adapted = _unique(self.adapted_listed)
+        # proj / pred feed the detached embedding (CD:249): their BatchNorm parameters never get a gradient, torch.optim.Adam skips them
+        self._never_stepped = {k for k in self.adapted if k.startswith(('proj.1.', 'pred.1.'))} if self.sync_bn else set()
         self._clear_engines()
 
     def adapt_parameters(self, mode=None):
         if mode != 'meta_bn':
             raise NotImplementedError("adapt_mode %r: only 'meta_bn' (the CostDCNet scripts' mode) is on the accelerated path" % mode)
         params = dict(self.model.named_parameters())
-        return nn.ParameterList([params[k] for k in self.adapted])
+        # the DDP list names four tensors twice: torch.optim.Adam then steps them twice per step(), like the reference's
+        return nn.ParameterList([params[k] for k in self.adapted_listed])
 
     def convert_syncbn(self, apex=False):
-        """SyncBatchNorm.convert_sync_batchnorm (src/costdcnet_model_adapt.py:535-546).  KNOWN DIFFERENCE from the reference's DDP
-        run: the reference converts BEFORE adapt_parameters('meta_bn') (src/tta_main.py:326,339), after which its isinstance test
-        (src/costdcnet_model_adapt.py:364-366) also matches UNet3D's BatchNorm3d, the heads' BatchNorm1d and the BatchNorm1d inside
-        every MinkowskiBatchNorm: ALL of them become adapted and lose their running statistics.  This mirror keeps the 32-tensor
-        single-GPU list (Encoder2D's BatchNorm2d + conv1_rgb_meta) with tracked running statistics elsewhere and exchanges the
-        statistics of every BatchNorm; the sparse encoder has no backward here.  A warning says so once."""
-        import warnings
-        warnings.warn('CostDCNetModel_Adapt.convert_syncbn: the reference\'s DDP run adapts EVERY BatchNorm after the SyncBatchNorm '
-                      'conversion (src/tta_main.py:326,339; src/costdcnet_model_adapt.py:364-366); this path keeps the 32-tensor '
-                      'single-GPU adapted list -- statistics are exchanged, the adapted set differs from the reference\'s')
+        """SyncBatchNorm.convert_sync_batchnorm (src/costdcnet_model_adapt.py:535-546).  The reference converts BEFORE
+        adapt_parameters('meta_bn') (src/tta_main.py:326,339): from here on every BatchNorm of the model is adapted and normalises
+        with batch statistics in train AND eval mode (its running statistics are dropped, :364-372) -- the library's
+        PTTA_SYNCBN_ADAPT engine, whose sparse encoder has a backward for its BatchNorm gamma / beta."""
         super().convert_syncbn(apex)
+        if self.prepare_mode is not None:
+            self._set_adapted()
 
     def state_dict(self):
         """The reference's state_dict lists ResBlock.norm3 a second time as downsample.1 (same tensors)."""
@@ -109,7 +134,9 @@ class CostDCNetModel_Adapt(MsgChnModel_Adapt):
         if eng is None:
             if self.prepare_mode is None:
                 raise RuntimeError('_prepare_head(mode) must be called before forward (tta_main.py:322)')
-            eng = Engine(n, h, w, backbone='costdcnet', max_input_depth=self.max_input_depth, max_predict_depth=self.max_depth, **self.hparams)
+            eng = Engine(n, h, w, backbone='costdcnet', max_input_depth=self.max_input_depth, max_predict_depth=self.max_depth,
+                         syncbn_adapted=self.sync_bn, **self.hparams)
+            assert all(self.adapted_listed.count(k) == max(eng.adapted_repeat[k], 1) for k in eng.adapted), 'listing counts drifted'
             assert eng.adapted == self.adapted, 'adapted parameter list drifted from the library'
             eng.load_state_dict(self.model.state_dict())      # running statistics are bound by pointer and updated in place
             params = dict(self.model.named_parameters())

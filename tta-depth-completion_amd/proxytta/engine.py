@@ -73,7 +73,7 @@ class Engine:
                                   {'nlspn': _lib.PTTA_BACKBONE_NLSPN, 'costdcnet': _lib.PTTA_BACKBONE_COSTDCNET}.get(backbone, _lib.PTTA_BACKBONE_MSG_CHN),
                                   (_lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER) |
                                   (_lib.PTTA_NLSPN_LEGACY_OFFSET if (legacy_offset and backbone == 'nlspn') else 0) |
-                                  (_lib.PTTA_NLSPN_SYNCBN_ADAPT if (syncbn_adapted and backbone == 'nlspn') else 0),
+                                  (_lib.PTTA_SYNCBN_ADAPT if (syncbn_adapted and backbone in ('nlspn', 'costdcnet')) else 0),
                                   self.n, self.h, self.w, code, byref(self.hp))
         if rc != 0:
             why = {-19: 'no HIP device', -12: 'out of device memory', -22: 'invalid size / argument',
@@ -83,12 +83,14 @@ class Engine:
         self.rows = int(self.lib.ptta_embedding_rows(self.handle))
         # adapted tensors in the reference's order, from the library (MSG_CHN 1layer: 2, 2layers: 7, NLSPN meta_bn: 88,
         # src/nlspn_model_adapt.py:322-337)
-        names, self.adapted_numel = [], {}
+        names, self.adapted_numel, self.adapted_repeat = [], {}, {}
         for i in range(int(self.lib.ptta_adapted_count(self.handle))):
             n = c_int64(0)
             name = self.lib.ptta_adapted_name(self.handle, i, byref(n)).decode()
             names.append(name)
             self.adapted_numel[name] = int(n.value)
+            # entries of the reference's parameter list behind this tensor (CostDCNet's DDP list names four tensors twice: include/ptta.h)
+            self.adapted_repeat[name] = int(self.lib.ptta_adapted_repeat(self.handle, i))
         if backbone in ('nlspn', 'costdcnet'):
             self.adapted = names
         else:

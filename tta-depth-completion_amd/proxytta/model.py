@@ -432,7 +432,8 @@ class MsgChnModel_Adapt(object):
                 st['exp_avg'] = torch.zeros_like(p.data)
                 st['exp_avg_sq'] = torch.zeros_like(p.data)
             self._opt_state[name] = st
-            self._adam_t = int(float(st['step']))
+        # the library keeps ONE count of optimizer.step() calls; a tensor the list names twice shows twice that in torch's state
+        self._adam_t = int(float(optimizer.state[params[self.adapted[0]]]['step']))
         self._clear_engines()
         self._optimizer = optimizer
 
@@ -458,8 +459,10 @@ class MsgChnModel_Adapt(object):
         eng._t = self._adam_t
         opt = getattr(self, '_optimizer', None)
         if opt is not None:
-            for p in opt.param_groups[0]['params']:
-                if 'step' in opt.state[p]:
+            never = getattr(self, '_never_stepped', None)
+            skip = {id(p) for k, p in self.model.named_parameters() if k in never} if never else ()
+            for p in opt.param_groups[0]['params']:             # as listed: a tensor named twice is stepped twice
+                if 'step' in opt.state[p] and id(p) not in skip:
                     opt.state[p]['step'] += 1
         return info, depth
 

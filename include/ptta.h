@@ -53,7 +53,7 @@ typedef void* ptta_stream;              /* hipStream_t */
  * meta_mode | PTTA_SYNCBN_ADAPT: the adapted set of the reference's DDP run (src/tta_main.py:326 convert_syncbn() BEFORE :339
  * adapt_parameters): EVERY BatchNorm of the model -- Encoder2D's, the BatchNorm1d inside the sparse encoder's nine MinkowskiBatchNorm
  * (`enc3d.<layer>.bn.weight/bias`), UNet3D's 28 BatchNorm3d, the heads' three BatchNorm1d -- is adapted and has lost its running
- * statistics (batch statistics in train AND eval mode; ptta_load_weights ignores every running_* key).  ptta_adapted_count() is 114
+ * statistics (batch statistics in train AND eval mode; ptta_load_weights ignores every running_* key).  ptta_adapted_count() is 112
  * unique tensors in the reference's order; the reference's list has 116 entries because enc2d.layer{2,3}.0.norm3.{weight,bias} sit
  * behind two SyncBatchNorm modules (norm3 and downsample[1]) and are listed -- and updated by Adam -- twice per step:
  * ptta_adapted_repeat() is 2 for them, 0 for proj.1 / pred.1 (listed, never given a gradient), 1 otherwise. */

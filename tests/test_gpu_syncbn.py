@@ -52,6 +52,22 @@ def _worker(rank, world, port, backbone, out):
             for k in ('proj.1.running_mean', 'pred.1.running_var'):
                 res['s%d/buf/%s' % (s, k)] = sd[k].cpu().numpy().copy()
             res['s%d/eval' % s] = eng.forward_eval(image, sparse).cpu().numpy()
+    elif backbone == 'costdcnet_ddp':
+        # the reference's DDP run: every BatchNorm adapted (PTTA_SYNCBN_ADAPT), statistics + gradients over both ranks
+        from tests.test_gpu_costdcnet import costdc_frame
+        from tests.test_gpu_costdcnet_syncbn import golden_hp as hp_of, make as make_ddp
+        g = np.load(os.path.join(GOLD, 'costdcnet_64x64_n2_syncbn.npz'))
+        h, w, n, steps = [int(x) for x in g['meta']]
+        eng, sd, adapted = make_ddp(1, h, w, hp_of(g))
+        eng.enable_stat_sync()
+        raw, image1, sparse = [torch.from_numpy(x[rank:rank + 1]).cuda() for x in costdc_frame(0, h, w, n, float(g['density']))]
+        info, depth = D.shared_parameter_step(eng, image1, sparse, loss_image=raw)
+        res['depth'] = depth.cpu().numpy()
+        res['info'] = info.cpu().numpy()
+        for k, (prm, m, v) in adapted.items():
+            res['param/' + k] = prm.cpu().numpy().copy()
+            res['grad/' + k] = eng.grad(k, prm).cpu().numpy()
+        res['eval'] = eng.forward_eval(image1, sparse).cpu().numpy()
     else:
         from tests.test_gpu_costdcnet import costdc_frame, make_costdc
         g = np.load(os.path.join(GOLD, 'costdcnet_64x64_n2.npz'))
@@ -108,6 +124,31 @@ def test_costdcnet_forward_with_global_batch_statistics():
     assert rel_mae(np.concatenate([r0['depth'], r1['depth']], 0), g['s0/depth_train']) < 1e-3
     assert np.array_equal(r0['buf'], r1['buf'])
     assert rel_mae(r0['buf'], g['s0/buf/unet3d.inc.double_conv.0.bn1.running_mean']) < 2e-3
+
+
+def test_costdcnet_two_ranks_reproduce_the_ddp_adapted_run():
+    """Two ranks with one frame each, every BatchNorm adapted and synchronised (forward statistics AND the backward's two sums, the
+    sparse encoder's with its per-rank voxel counts): the batch-2 run of the reference with the DDP adapted list."""
+    from tests.util import rel_mae
+    r0, r1 = _run('costdcnet_ddp')
+    g = np.load(os.path.join(GOLD, 'costdcnet_64x64_n2_syncbn.npz'))
+    assert rel_mae(np.concatenate([r0['depth'], r1['depth']], 0), g['s0/depth_train']) < 1e-4
+    names = [k[len('grad/'):] for k in r0 if k.startswith('grad/')]
+    assert len(names) == 112
+    worst = 0.0
+    for k in names:
+        assert np.array_equal(r0['param/' + k], r1['param/' + k]), k              # identical update on every rank
+        if k.startswith(('proj.1.', 'pred.1.')):
+            continue
+        # after shared_parameter_step the stored gradient IS the mean over the ranks = the batch-2 gradient (measured 1.2e-4, as the
+        # single-process run of tests/test_gpu_costdcnet_syncbn.py: bound 2x)
+        e = rel_mae(r0['grad/' + k], g['s0/grad/' + k])
+        worst = max(worst, e)
+        assert e < 2.5e-4, (k, e)
+        assert rel_mae(r0['param/' + k], g['s0/param/' + k]) < 1.5e-5, k
+    print('worst gradient deviation', worst)
+    # the eval forward normalises with LOCAL batch statistics (SyncBatchNorm only synchronises in training mode): each rank's frame
+    # alone differs from the batch-2 eval of the golden run, so only the training-side quantities are compared
 
 
 # ---- the library-owned RCCL communicator (ptta_rccl_*, ptta_set_stat_sync_rccl, ptta_set_grad_sync_rccl) ----------------------------

@@ -1,4 +1,1 @@
-#!/bin/bash
-cd $GRAFT_REPO_ROOT
-timeout 1800 python -m pytest tests/test_gpu_costdcnet.py tests/test_gpu_nlspn.py tests/test_gpu_syncbn.py tests/test_gpu_parity.py -x -q > gpurun_out/t.txt 2>&1
-grep -a "passed\|failed\|Error" gpurun_out/t.txt | tail -5
+python -m pytest tests/test_gpu_syncbn.py tests/test_gpu_costdcnet_syncbn.py -x -q -s  2>&1 | grep -v "Gloo\|socket\|amdgpu.ids" | tail -30

@@ -252,13 +252,15 @@ def head_stage2_workload(steps=30):
 def costdcnet_shared(args, rank, world, dist):
     """BASELINE config 5: CostDCNet, 480x640, batched TTA with SHARED adapted parameters -- every rank adapts its own frame of
     the global batch, BatchNorm statistics are those of the global batch (SyncBatchNorm, src/tta_main.py:326), ONE flat
-    all-reduce of the 32 adapted gradients per step (RCCL over xGMI on a multi-GPU node), identical Adam on every rank.
+    all-reduce of the 112 adapted gradients of the DDP list per step (RCCL over xGMI on a multi-GPU node), identical Adam on every rank.
     Optional workload (`--workload costdcnet-shared`); the headline metric stays the default one."""
     from proxytta import synth
     from proxytta.distributed import shared_parameter_step
     from proxytta.engine import Engine
     h, w = 480, 640
-    eng = Engine(1, h, w, backbone='costdcnet', max_predict_depth=8.0, lr=3e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1)
+    # syncbn_adapted: the adapted list of the reference's DDP run (convert_syncbn before adapt_parameters, src/tta_main.py:326,339):
+    # every BatchNorm adapted, 116 listed entries = 112 tensors, the sparse encoder with its backward
+    eng = Engine(1, h, w, backbone='costdcnet', max_predict_depth=8.0, lr=3e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, syncbn_adapted=True)
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_costdcnet().items()}
     eng.load_state_dict(sd)
     keep = []
@@ -301,12 +303,13 @@ def costdcnet_shared(args, rank, world, dist):
         print(json.dumps({
             'metric': 'TTA frames/sec (fwd+loss+bwd+Adam), CostDCNet 480x640, shared adapted parameters', 'value': world * args.steps / elapsed,
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 storage, bf16x3 MFMA arithmetic (fp32 accumulate)',
-            'data': 'synthetic',
-            'config': {'workload': 'CostDCNet, 480x640 VOID-shaped synthetic (1500 points), global batch = n_gpus frames, 1 TTA step, meta_bn with the 32-tensor '
-                                   'single-GPU adapted list (NOT the reference\'s DDP parameter set: after convert_syncbn the reference adapts every '
-                                   'BatchNorm incl. BatchNorm3d / BatchNorm1d / the sparse encoder\'s, src/costdcnet_model_adapt.py:364-366)',
-                       'parallelism': 'dp%d: SyncBatchNorm statistics exchange per BatchNorm + one flat gradient all-reduce (5,200 floats) per step' % world,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 storage, bf16x6 (forward of the real frames) / bf16x3 MFMA arithmetic (fp32 accumulate)', 'data': 'synthetic',
+            'config': {'workload': 'CostDCNet, 480x640 VOID-shaped synthetic (1500 points), global batch = n_gpus frames, 1 TTA step, meta_bn with the '
+                                   'adapted list of the reference\'s DDP run (convert_syncbn before adapt_parameters: every BatchNorm incl. BatchNorm3d / '
+                                   'BatchNorm1d / the sparse encoder\'s, 116 listed entries = 112 tensors, src/costdcnet_model_adapt.py:364-366)',
+                       'parallelism': 'dp%d: SyncBatchNorm statistics exchange per BatchNorm (forward and backward) + one flat gradient all-reduce '
+                                      '(11,888 floats) per step' % world,
                        'exchange': mode, 'finite': finite}}))
     if dist is not None:
         dist.destroy_process_group()

@@ -98,7 +98,9 @@ class CostDCNetModel_Adapt(MsgChnModel_Adapt):
         if mode != 'meta_bn':
             raise NotImplementedError("adapt_mode %r: only 'meta_bn' (the CostDCNet scripts' mode) is on the accelerated path" % mode)
         params = dict(self.model.named_parameters())
-        # the DDP list names four tensors twice: torch.optim.Adam then steps them twice per step(), like the reference's
+        # the DDP list names four tensors twice: torch.optim.Adam then steps them twice per step(), like the reference's.  The reference
+        # pins torch 1.10.1 (README.md:74: one entry at a time, two complete consecutive updates -- what step() does on device); with
+        # torch >= 2.0 build the optimizer with foreach=False to get the same from optimizer.step()
         return nn.ParameterList([params[k] for k in self.adapted_listed])
 
     def convert_syncbn(self, apex=False):

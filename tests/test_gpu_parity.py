@@ -205,6 +205,29 @@ def test_against_oracle_midsize():
     eng.close()
 
 
+def test_merged_head_linears_equal_the_two_layer_form():
+    """emb = pred(proj(feat_zero)): proj.3 and pred.0 have nothing between them and run as ONE GEMM with W' = W_pred0 W_proj3 (derived in
+    double when the weights are loaded).  Same embedding as the layer-by-layer form to fp32 rounding; the BatchNorm buffers likewise."""
+    import os
+    n, h, w = 1, 128, 256
+    image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(7, h, w, n)]
+    out = {}
+    for fuse in ('1', '0'):
+        os.environ['PTTA_FUSE_HEADS'] = fuse
+        try:
+            eng, sd, adapted = make_engine(n, h, w, 'fp32')
+        finally:
+            os.environ.pop('PTTA_FUSE_HEADS', None)
+        depth, emb, ref = eng.forward_train(image, sparse)
+        out[fuse] = (emb.clone(), ref.clone(), sd['pred.1.running_mean'].clone(), sd['pred.1.running_var'].clone(), sd['proj.1.running_var'].clone())
+        eng.close()
+    # measured 8.6e-6 = the size of either form's own bf16x3 deviation from fp32 arithmetic (dropped lo*lo terms, 2^-16 per product)
+    assert rel_mae(out['1'][0], out['0'][0]) < 2e-5
+    assert torch.equal(out['1'][1], out['0'][1])
+    for k in (2, 3, 4):
+        assert rel_mae(out['1'][k], out['0'][k]) < 2e-5
+
+
 @pytest.mark.parametrize('mode,fixture', [(ONE, 'msgchn_1layer_32x48'), (TWO, 'msgchn_2layers_32x48')])
 def test_facade_reference_style_driver(golden_dir, mode, fixture):
     """tta_main-style loop (forward / compute_loss / zero_grad / backward / optimizer.step) through the

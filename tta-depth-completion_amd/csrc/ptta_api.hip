@@ -90,6 +90,9 @@ struct ptta_ctx {
     bool fwd_valid = false;
     PttaStatSync stat_sync;          // SyncBatchNorm exchange across ranks (ptta_set_stat_sync); world == 1: off
     bool proxy_rgb_valid = false;   // proxy half of c0..c4 holds the zero-image encoder outputs for the current weights
+    // emb = pred(proj(feat_zero)): proj.3 and pred.0 are two Linear layers with nothing between them (network_exp_msg_chn_adapt.py:551-554)
+    // -> ONE 512x512 GEMM with W' = W_pred0 W_proj3, b' = W_pred0 b_proj3 + b_pred0 (both frozen during TTA; derived in double on load)
+    Lin fused_pp; bool fused_pp_valid = false; int fuse_heads = 1;
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
     struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double bytes = 0, macs = 0; };
     bool prof_on = false;
@@ -294,6 +297,10 @@ void build_registry(ptta_ctx* c) {
             l->Wil = (bf16_t*)c->dalloc(ne * 4); l->Wtil = (bf16_t*)c->dalloc(ne * 4);
         }
         c->fc[std::string(p) + ".0"] = a; c->fc[std::string(p) + ".3"] = b;
+        if (std::string(p) == "proj") {
+            Lin& f = c->fused_pp; f.N = 512; f.K = 512; f.W = c->falloc(512 * 512); f.bias = c->falloc(512);
+            f.Whi = (bf16_t*)c->dalloc(512 * 512 * 2); f.Wlo = (bf16_t*)c->dalloc(512 * 512 * 2); f.Wil = (bf16_t*)c->dalloc(512 * 512 * 4);
+        }
         BNorm n; n.gamma = c->falloc(512); n.beta = c->falloc(512);
         n.mean = c->falloc(512); n.inv = c->falloc(512); n.scale = c->falloc(512); n.shift = c->falloc(512);
         c->bn[std::string(p) + ".1"] = n;
@@ -631,7 +638,31 @@ int rgb_encoder(ptta_ctx* c, const float* image, int nb, int boff, int zero_from
 // The proxy pass feeds torch.zeros_like(rgb) through the frozen RGB encoder (:509-515): its c0..c4 depend only on the
 // encoder weights and the frame size, so they are computed ONCE per (handle, weights) into the proxy half of the
 // buffers instead of in every step (the eval forward only writes the real half).  Never runs inside a graph capture.
+__global__ void fuse_linear_kernel(const float* __restrict__ Wb, const float* __restrict__ bb, const float* __restrict__ Wa, const float* __restrict__ ba,
+                                   float* __restrict__ W, float* __restrict__ bias, int N, int M, int K) {
+    // y = (x Wa^T + ba) Wb^T + bb = x (Wb Wa)^T + (Wb ba + bb);  Wb: [N][M], Wa: [M][K] -> W: [N][K]
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (k >= K) return;
+    double acc = 0.0;
+    for (int m = 0; m < M; ++m) acc += (double)Wb[(long)n * M + m] * (double)Wa[(long)m * K + k];
+    W[(long)n * K + k] = (float)acc;
+    if (k == 0) {
+        double b = (double)bb[n];
+        for (int m = 0; m < M; ++m) b += (double)Wb[(long)n * M + m] * (double)ba[m];
+        bias[n] = (float)b;
+    }
+}
+int ensure_fused_heads(ptta_ctx* c, hipStream_t s) {
+    if (c->fused_pp_valid || !c->fuse_heads) return 0;
+    Lin& f = c->fused_pp; const Lin& a = c->fc["proj.3"]; const Lin& b = c->fc["pred.0"];
+    hipLaunchKernelGGL(fuse_linear_kernel, dim3(2, 512), dim3(256), 0, s, b.W, b.bias, a.W, a.bias, f.W, f.bias, 512, 512, 512);
+    ptta_split_weight(f.W, f.Whi, f.Wlo, f.Wil, 512L * 512, 512, s);
+    c->fused_pp_valid = true;
+    return 0;
+}
+
 int ensure_proxy_rgb(ptta_ctx* c, const float* any_image, hipStream_t s) {
+    RUN(ensure_fused_heads(c, s));
     if (c->proxy_rgb_valid) return 0;
     RUN(rgb_encoder(c, any_image, c->Nn, c->Nn, 0, s));
     c->proxy_rgb_valid = true;
@@ -826,8 +857,28 @@ int heads_forward(ptta_ctx* c, hipStream_t s) {
         RUN(mlp_forward(c, "proj", feat_zero, c->bf16, 32, c->h1z, c->ref, s));
         return 0;
     }
-    RUN(mlp_forward(c, "proj", feat_zero, c->bf16, 32, c->h1z, c->pz, s));
-    RUN(mlp_forward(c, "pred", c->pz, 0, 512, c->h2, c->emb, s));
+    if (c->fuse_heads && c->fused_pp_valid && c->x3 && !c->bf16 && !c->skip_dec3) {      // (the stage-2 head trainer needs proj's output itself)
+        // emb = pred.3(relu(bn(pred.0(proj.3(relu(bn(proj.0 x))))))) with proj.3 / pred.0 merged into one GEMM (ptta_ctx::fused_pp)
+        const Lin& l0 = c->fc["proj.0"]; const Lin& lf = c->fused_pp; const Lin& l3 = c->fc["pred.3"];
+        BNorm& b1 = c->bn["proj.1"]; BNorm& b2 = c->bn["pred.1"];
+        const int R = (int)c->Rg, Rw = R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1);
+        GemmArgs g; g.A = feat_zero; g.a_bf16 = 0; g.W = l0.W; g.bias = l0.bias; g.C = c->h1z; g.R = R; g.K = 32; g.N = 512; g.epi = 1; g.part = c->bn_part;
+        g.x3 = 1; g.Whi = l0.Whi; g.Wlo = l0.Wlo; g.Wil = l0.Wil;
+        RUN(ptta_launch_gemm(g, s));
+        RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
+        RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(g), Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
+        GemmArgs gf; gf.A = c->h1z; gf.W = lf.W; gf.bias = lf.bias; gf.C = c->h2; gf.R = R; gf.K = 512; gf.N = 512; gf.pro = 1; gf.epi = 1; gf.part = c->bn_part;
+        gf.pscale = b1.scale; gf.pshift = b1.shift; gf.x3 = 1; gf.Whi = lf.Whi; gf.Wlo = lf.Wlo; gf.Wil = lf.Wil;
+        RUN(ptta_launch_gemm(gf, s));
+        RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(gf), 512, 1, s));
+        RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(gf), Rw, 512, b2.gamma, b2.beta, 1e-5f, 0.1f, b2.rm, b2.rv, b2.nbt, b2.mean, b2.inv, b2.scale, b2.shift, s));
+        GemmArgs g3; g3.A = c->h2; g3.W = l3.W; g3.bias = l3.bias; g3.C = c->emb; g3.R = R; g3.K = 512; g3.N = 512; g3.pro = 1;
+        g3.pscale = b2.scale; g3.pshift = b2.shift; g3.x3 = 1; g3.Whi = l3.Whi; g3.Wlo = l3.Wlo; g3.Wil = l3.Wil;
+        RUN(ptta_launch_gemm(g3, s));
+    } else {
+        RUN(mlp_forward(c, "proj", feat_zero, c->bf16, 32, c->h1z, c->pz, s));
+        RUN(mlp_forward(c, "pred", c->pz, 0, 512, c->h2, c->emb, s));
+    }
     RUN(mlp_forward(c, "proj", c->feat, c->bf16, 32, c->h1, c->ref, s));     // last: its BN statistics are kept for backward
     return 0;
 }
@@ -1021,6 +1072,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     const char* ax = getenv("PTTA_AUX_STREAM");
     c->use_aux = (ax && strcmp(ax, "0") == 0) ? 0 : 1;
     { const char* sf = getenv("PTTA_SPLIT_FWD"); c->split_fwd = sf ? atoi(sf) : 0; }
+    { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
     c->x3 = (arith && strcmp(arith, "exact") == 0) ? 0 : 1;
     c->hp = *hp;
@@ -1061,7 +1113,7 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
 
     if (!c || !name_ || !tensor) return -1;
     c->drop_graphs();
-    c->proxy_rgb_valid = false;
+    c->proxy_rgb_valid = false; c->fused_pp_valid = false;
     hipStream_t s = (hipStream_t)s_;
     const std::string name(name_);
     const long numel = shape_numel(shape, ndim);
@@ -1430,6 +1482,7 @@ static int head_init(ptta_ctx* c) {
 static int head_reload(ptta_ctx* c, int k, hipStream_t s) {
     const auto& e = c->head.prm[k];
     if (!e.p) return 0;
+    c->fused_pp_valid = false;
     const std::string name = e.name, base = name.substr(0, name.rfind('.'));
     const bool is_w = name.size() > 7 && name.compare(name.size() - 7, 7, ".weight") == 0;
     if (c->fc.count(base)) {

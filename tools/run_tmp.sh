@@ -1,1 +1,1 @@
-python -m pytest tests/test_gpu_parity.py -x -q -k merged 2>&1 | tail -3
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_edge_cases.py tests/test_gpu_head_trainer.py -x -q 2>&1 | tail -3

@@ -174,7 +174,8 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 __device__ __forceinline__ int x3_stage_pix(int idx) { return ((idx >> 5) << 3) + (((idx >> 2) & 1) << 2) + ((idx >> 3) & 3); }
 
 #define CSTAMP(v) do { if (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
-template <bool RELU, bool UP, bool MASK, bool ADD, bool TIMING = false>
+// ABL (diagnostic instantiations only, PTTA_S1_ABL): 1 = no stores, 2 = no global loads, 4 = no MFMAs (LDS reads kept), 8 = no LDS reads either
+template <bool RELU, bool UP, bool MASK, bool ADD, bool TIMING = false, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) {
     unsigned long long T0 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0, dW = 0, dS = 0, dI = 0, dB1 = 0, dM = 0, dE = 0, dB2 = 0, Tpro = 0; int ntl = 0;
     CSTAMP(T0);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     // registers to spare, so the NEXT tile's global loads are issued before this tile's MFMAs and
     // land while the matrix cores work (software prefetch across the persistent tile loop).
     constexpr int NIT = (((X3_PH * X3_PW + 7) / 8) * 32 + 255) / 256;
-    constexpr bool PREFETCH = !UP;
+    constexpr bool PREFETCH = !UP;       // (the bilinear epilogue leaves no registers for it: 13 spills and no gain when forced)
     float4 v0[NIT], v1[NIT];
     auto tile_coords = [&](long tile, int& b, int& y0, int& x0) {
         long t_ = tile;
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
             const int py = pix / X3_PW, px = pix - py * X3_PW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
+            if (ABL & 2) { v0[it] = make_float4((float)gy, (float)gx, 1.f, (float)it); v1[it] = v0[it]; continue; }
             if (pix < X3_PH * X3_PW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
                 const float* src = inb + ((size_t)gy * W + gx) * 32 + 8 * g;
                 v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
@@ -242,6 +244,27 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
+        int uy0 = 0, ux0 = 0;
+        if (UP) {
+            // bilinear x2 skip: the source window goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, one 1-KB piece =
+            // 8 source pixels per wave instruction, lane-linear image [pixel][32 floats], clamped at the borders), issued FIRST so that
+            // it flies while this tile's halo is split and written; drained before the next tile's register prefetch is issued
+            // (vmcnt is in order: a later wait for the window would also wait for that prefetch)
+            const int Hu = H >> 1, Wu = W >> 1;
+            uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
+            const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
+#pragma unroll
+            for (int k = 0; k < (UPH * UPW * 8 + 255) / 256; ++k) {
+                const int idx = tid + 256 * k;
+                if (idx < UPH * UPW * 8) {
+                    const int q = idx & 7, pix = idx >> 3;
+                    const int r = pix / UPW, cc = pix - r * UPW;
+                    const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q),
+                                                     (__attribute__((address_space(3))) void*)(up_lds + (size_t)(256 * k + 64 * wave) * 4), 16, 0, 0);
+                }
+            }
+        }
         if (!PREFETCH) issue_loads(tile);
         CSTAMP(ta);
         if (TIMING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -261,23 +284,12 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
                 *(uint4*)(dst + 64) = lo;
             }
         }
+        if (UP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the window has landed (and this tile's halo loads before it)
         CSTAMP(tc);
         if (PREFETCH && tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x);
         CSTAMP(td);
         // bilinear x2 skip: stage the source window once per tile as whole 128-B lines (clamped at the
         // borders; only indices the lerp actually produces are ever read back)
-        int uy0 = 0, ux0 = 0;
-        if (UP) {
-            const int Hu = H >> 1, Wu = W >> 1;
-            uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
-            const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
-            for (int idx = tid; idx < UPH * UPW * 8; idx += 256) {
-                const int q = idx & 7, pix = idx >> 3;
-                const int r = pix / UPW, cc = pix - r * UPW;
-                const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
-                *(float4*)(up_lds + pix * 32 + 4 * q) = *(const float4*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q);
-            }
-        }
         lds_barrier();          // LDS-only: the next tile's global loads (issued above) stay in flight during the MFMAs
         CSTAMP(te);
         // ---- two output rows per wave ------------------------------------------------------------
@@ -294,8 +306,14 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
                 const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * X3_STRIDE + 16 * h;
+                if (ABL & 8) { acc[tap] += __uint_as_float(wh[tap][0].x); continue; }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
+                    if (ABL & 4) {
+                        const uint4 qa = *(const uint4*)(a + 32 * k), qb = *(const uint4*)(a + 32 * k + 64), qc = *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
+                        acc[tap] += __uint_as_float(qa.x ^ qb.y ^ qc.z ^ wh[tap][k].w);
+                        continue;
+                    }
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
                     const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
@@ -309,23 +327,11 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
             if (TIMING) { float sink = acc[0]; asm volatile("v_mov_b32 %0, %0" : "+v"(sink) :: "memory"); acc[0] = sink; }   // MFMA results landed
             CSTAMP(m1);
             if (UP) {
-                // (conv + bias) + bilinear, in the reference's order; the skip comes from LDS (lane = channel:
-                // consecutive banks), then the generic epilogue runs without bias / gather
-                const float bias = (p.epi.bias ? p.epi.bias : kZeroBias)[i];
-                const Lerp ly = lerp_coef(y, H >> 1, sy);
-                const float* r0 = up_lds + (ly.i0 - uy0) * UPW * 32 + i;
-                const float* r1 = up_lds + (ly.i1 - uy0) * UPW * 32 + i;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int px = min(x0 + acc_row(r, h), W - 1);
-                    const Lerp lx = lerp_coef(px, W >> 1, sx);
-                    const int c0 = (lx.i0 - ux0) * 32, c1 = (lx.i1 - ux0) * 32;
-                    acc[r] = (acc[r] + bias) + (ly.l0 * (lx.l0 * r0[c0] + lx.l1 * r0[c1]) + ly.l1 * (lx.l0 * r1[c0] + lx.l1 * r1[c1]));
-                }
-                Epi<float> e2 = p.epi; e2.bias = nullptr; e2.up = nullptr;
-                epi_tile<float, false, MASK, ADD>(e2, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+                // (conv + bias) + bilinear, in the reference's order; the skip comes from the LDS window, added after the quad
+                // transpose (four channels of one pixel per lane: ptta_common.h epi_tile UPL)
+                epi_tile<float, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
             } else {
-                epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+                if (!(ABL & 1) || acc[0] == 1.2345e-30f) epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
             }
             CSTAMP(m2);
             dM += m1 - m0; dE += m2 - m1;
@@ -444,19 +450,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
                 }
             }
             if (UP) {
-                const float bias = (p.epi.bias ? p.epi.bias : kZeroBias)[i];
-                const Lerp ly = lerp_coef(y, H >> 1, sy);
-                const float* r0 = up_lds + (ly.i0 - uy0) * UPW * 32 + i;
-                const float* r1 = up_lds + (ly.i1 - uy0) * UPW * 32 + i;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int px = min(x0 + acc_row(r, h), W - 1);
-                    const Lerp lx = lerp_coef(px, W >> 1, sx);
-                    const int c0 = (lx.i0 - ux0) * 32, c1 = (lx.i1 - ux0) * 32;
-                    acc[r] = (acc[r] + bias) + (ly.l0 * (lx.l0 * r0[c0] + lx.l1 * r0[c1]) + ly.l1 * (lx.l0 * r1[c0] + lx.l1 * r1[c1]));
-                }
-                Epi<float> e2 = p.epi; e2.bias = nullptr; e2.up = nullptr;
-                epi_tile<float, false, MASK, ADD>(e2, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+                epi_tile<float, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
             } else {
                 epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
             }
@@ -762,6 +756,12 @@ static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_
         else if (flags == 1) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, true, false, false, true>), dim3(blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, true, true>), dim3(blocks), dim3(256), 0, s, p);
         return;
+    }
+    static const int abl = getenv("PTTA_S1_ABL") ? atoi(getenv("PTTA_S1_ABL")) : 0;              // diagnostic: resource ablation of the plain variant
+    if (abl && flags == 0) {
+#define KA_(N) case N: hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, false, false, N>), dim3(blocks), dim3(256), 0, s, p); return
+        switch (abl) { KA_(1); KA_(2); KA_(3); KA_(4); KA_(5); KA_(6); KA_(7); KA_(8); KA_(9); KA_(10); KA_(11); default: break; }
+#undef KA_
     }
     // small maps: the latency-chain form (conv32_s1_small_kernel), one 4x32 tile per block
     static const int small_off = getenv("PTTA_S1_SMALL") ? (atoi(getenv("PTTA_S1_SMALL")) == 0) : 0;

@@ -124,9 +124,14 @@ __device__ __forceinline__ void quad_transpose(f32x16& t, int lane) {
 // per element makes hipcc branch around each load and wait vmcnt(0) 100+ times per tile:
 // cdna_hip_programming.md §5 "Three .s-level traps" (c)).  Out-of-range pixels load from a
 // clamped address and are simply not stored.
-template <typename T, bool UP, bool MASK, bool ADD>
+// UPL (fp32 storage only): the bilinear x2 skip comes from an LDS window `upw` = [row][UPLW columns][32 floats] of the half-resolution
+// source whose origin is (uy0, ux0), and is added AFTER the quad transpose: a lane then holds four consecutive channels of one pixel,
+// so one row costs it 4 coefficient pairs and 16 ds_read_b128 instead of 16 pairs and 64 ds_read_b32 -- the same expression per
+// element as the accumulator-layout form, (conv + bias) + (ly.l0 (lx.l0 v00 + lx.l1 v01) + ly.l1 (lx.l0 v10 + lx.l1 v11)).
+template <typename T, bool UP, bool MASK, bool ADD, bool UPL = false, int UPLW = 18>
 __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, int W, int ch, const f32x16& acc,
-                                         int x0, int h, int Wt, int xstep, int xoff, float sy, float sx) {
+                                         int x0, int h, int Wt, int xstep, int xoff, float sy, float sx,
+                                         const float* upw = nullptr, int uy0 = 0, int ux0 = 0) {
     const float* bp = e.bias ? e.bias : kZeroBias;       // pointer select, not a branch around the load
     const float bias = bp[ch];
     float v[16];
@@ -168,6 +173,24 @@ __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, i
             const int px = x0 + (ch & 3) + 8 * g + 4 * h;
             okg[g] = px < Wt;
             xq[g] = ((size_t)((okg[g] ? px : Wt - 1) * xstep + xoff) + rowoff) * 32 + j4;
+        }
+        if constexpr (UPL) {
+            const Lerp ly = lerp_coef(y, H >> 1, sy);
+            const float* r0 = upw + (ly.i0 - uy0) * UPLW * 32 + j4;
+            const float* r1 = upw + (ly.i1 - uy0) * UPLW * 32 + j4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int px = min(x0 + (ch & 3) + 8 * g + 4 * h, W - 1);
+                const Lerp lx = lerp_coef(px, W >> 1, sx);
+                const int c0 = (lx.i0 - ux0) * 32, c1 = (lx.i1 - ux0) * 32;
+                const float4 v00 = *(const float4*)(r0 + c0), v01 = *(const float4*)(r0 + c1);
+                const float4 v10 = *(const float4*)(r1 + c0), v11 = *(const float4*)(r1 + c1);
+                t[4 * g] = t[4 * g] + (ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x));
+                t[4 * g + 1] = t[4 * g + 1] + (ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y));
+                t[4 * g + 2] = t[4 * g + 2] + (ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z));
+                t[4 * g + 3] = t[4 * g + 3] + (ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w));
+                __builtin_amdgcn_sched_barrier(0);                   // four ds_read_b128 in flight at a time (VGPR budget)
+            }
         }
         // every auxiliary load of the row is issued before the first store (a store between them would order them)
         float4 mk[4], t1[4], t2[4];

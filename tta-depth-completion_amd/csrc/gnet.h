@@ -224,6 +224,20 @@ struct GNet {
         }
         return false;
     }
+    // layers whose real-frame forward keeps the third operand plane (x6): the backbone's list (x6_layers, comma-separated name prefixes,
+    // empty = every layer), or PTTA_X6_LAYERS ("*" = every layer)
+    std::string x6_layers;
+    bool x6_layer(const std::string& wname) const {
+        if (getenv("PTTA_X6_LAYERS")) return exact_listed("PTTA_X6_LAYERS", wname);
+        if (x6_layers.empty()) return true;
+        size_t a = 0;
+        while (a <= x6_layers.size()) {
+            size_t b = x6_layers.find(',', a); if (b == std::string::npos) b = x6_layers.size();
+            if (b > a && wname.compare(0, b - a, x6_layers, a, b - a) == 0) return true;
+            a = b + 1;
+        }
+        return false;
+    }
     // ---- program construction --------------------------------------------------------------------------------------
     int add_adapted(const std::string& name, long n) {
         Adapted a; a.name = name; a.n = n; a.goff = gall_n; gall_n += n;

@@ -82,7 +82,7 @@ int GNet::run_conv_fwd(const Op& o, bool train, hipStream_t s) {
         a.whi = (const uint4*)cw.ff_hi; a.wlo = (const uint4*)cw.ff_lo;
         a.nchunks = (a.C0 + 31) / 32 + (a.C1 + 31) / 32; a.nf0 = 0; a.nnf = (cw.Co + 31) / 32;
         a.y = y.p; a.ldy = y.ld; a.Cy = y.C; a.bias = bias; a.act = o.act; a.vert = cw.vcol;
-        if (cw.ff_l2 && o.yw != W_PROXY) {               // bf16x6 for the real frames (they come first in a [real | proxy] batch)
+        if (cw.ff_l2 && o.yw != W_PROXY && x6_layer(o.wname)) {               // bf16x6 for the real frames (they come first in a [real | proxy] batch)
             a.wl2 = (const uint4*)cw.ff_l2; a.six_B = (o.yw == W_BOTH && train) ? y.B / 2 : y.B;
         }
         if (o.stat_to >= 0 && (train || !ops[o.stat_to].tracked)) {

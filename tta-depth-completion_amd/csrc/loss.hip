@@ -9,6 +9,7 @@
 // Reductions are wave-shuffle + LDS per block, then a fixed-order second stage (bitwise
 // reproducible, no float atomics).  Gradients w.r.t. the depth map and w.r.t. `reference`
 // replace autograd's backward through these ops (src/tta_main.py:632).
+#include <cstdlib>
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -44,18 +45,18 @@ __device__ __forceinline__ float edge_w(const float* img, size_t plane, size_t a
     return expf(-m);
 }
 
-__global__ __launch_bounds__(256) void loss_depth_reduce_kernel(const float* __restrict__ depth, const float* __restrict__ image,
-                                                                const float* __restrict__ sparse, const float* __restrict__ validity,
-                                                                float max_d, int H, int W, float* __restrict__ part) {
+// bx / nbx: this block's index and the block count of the reduction (the merged launches below give each loss its own block range)
+__device__ __forceinline__ void depth_reduce_body(int bx, int nbx, int n, const float* __restrict__ depth, const float* __restrict__ image,
+                                                  const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                  float max_d, int H, int W, float* __restrict__ part) {
     __shared__ float red[4][4];
-    const int n = blockIdx.y;
     const size_t plane = (size_t)H * W;
     const float* D = depth + n * plane;
     const float* S = sparse + n * plane;
     const float* V = validity ? validity + n * plane : nullptr;
     const float* I = image + (size_t)n * 3 * plane;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = (size_t)bx * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)nbx * blockDim.x) {
         const int x = (int)(idx % W), y = (int)(idx / W);
         const float d = D[idx], w = valid_w(V, S, idx);
         a0 += w * fabsf(clampd(S[idx], max_d) - d);
@@ -68,17 +69,22 @@ __global__ __launch_bounds__(256) void loss_depth_reduce_kernel(const float* __r
     if ((threadIdx.x & 63) == 0) { red[wave][0] = a0; red[wave][1] = a1; red[wave][2] = a2; red[wave][3] = a3; }
     __syncthreads();
     if (threadIdx.x < 4)
-        part[((size_t)n * LOSS_PB + blockIdx.x) * 4 + threadIdx.x] =
+        part[((size_t)n * LOSS_PB + bx) * 4 + threadIdx.x] =
             red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void loss_depth_reduce_kernel(const float* __restrict__ depth, const float* __restrict__ image,
+                                                                const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                                float max_d, int H, int W, float* __restrict__ part) {
+    depth_reduce_body(blockIdx.x, gridDim.x, blockIdx.y, depth, image, sparse, validity, max_d, H, W, part);
 }
 
 // one wave per row of `emb`/`ref` (D = 512: 8 values per lane)
-__global__ __launch_bounds__(256) void cos_rows_kernel(const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
-                                                       float* __restrict__ rowstats, float* __restrict__ part) {
+__device__ __forceinline__ void cos_rows_body(int bx, int nbx, const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+                                              float* __restrict__ rowstats, float* __restrict__ part) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc = 0.f;
-    for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
+    for (long row = (long)bx * 4 + wave; row < R; row += (long)nbx * 4) {
         const float* e = emb + row * D;
         const float* r = ref + row * D;
         float ee = 0.f, rr = 0.f, er = 0.f;
@@ -96,7 +102,22 @@ __global__ __launch_bounds__(256) void cos_rows_kernel(const float* __restrict__
     }
     if (lane == 0) red[wave] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) part[bx] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void cos_rows_kernel(const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+                                                       float* __restrict__ rowstats, float* __restrict__ part) {
+    cos_rows_body(blockIdx.x, gridDim.x, emb, ref, R, D, rowstats, part);
+}
+// both reductions of the step in ONE launch: blocks [0, N * LOSS_PB) the depth terms (latency-bound: 1.7 MB per frame), the rest the cosine
+// rows (bandwidth-bound: 110 MB) -- the short one hides inside the long one, and one launch less on the critical path
+__global__ __launch_bounds__(256) void loss_forward_merged_kernel(const float* __restrict__ depth, const float* __restrict__ image,
+                                                                  const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                                  float max_d, int N, int H, int W, float* __restrict__ dpart,
+                                                                  const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+                                                                  float* __restrict__ rowstats, float* __restrict__ cpart) {
+    const int nd = N * LOSS_PB;
+    if ((int)blockIdx.x < nd) depth_reduce_body(blockIdx.x % LOSS_PB, LOSS_PB, blockIdx.x / LOSS_PB, depth, image, sparse, validity, max_d, H, W, dpart);
+    else cos_rows_body(blockIdx.x - nd, gridDim.x - nd, emb, ref, R, D, rowstats, cpart);
 }
 
 // one block: parallel fixed-shape reductions of the partials (deterministic), then thread 0 finishes
@@ -195,11 +216,17 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
                              float max_input_depth, const float* emb, const float* ref, long R, int D,
                              const float* w3_dev, int N, int H, int W,
                              float* ws, float* loss_info, hipStream_t s, int defer_finalize) {
-    hipLaunchKernelGGL(loss_depth_reduce_kernel, dim3(LOSS_PB, N), dim3(256), 0, s, depth, image, sparse, validity,
-                       max_input_depth, H, W, ws + ws_depth_off(N));
     const int has_cos = (emb && ref) ? 1 : 0;
-    if (has_cos)
-        hipLaunchKernelGGL(cos_rows_kernel, dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+    static const int merge_off = getenv("PTTA_LOSS_MERGE") ? (atoi(getenv("PTTA_LOSS_MERGE")) == 0) : 0;     // A/B switch
+    if (has_cos && !merge_off) {
+        hipLaunchKernelGGL(loss_forward_merged_kernel, dim3(N * LOSS_PB + LOSS_CB), dim3(256), 0, s, depth, image, sparse, validity, max_input_depth,
+                           N, H, W, ws + ws_depth_off(N), emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+    } else {
+        hipLaunchKernelGGL(loss_depth_reduce_kernel, dim3(LOSS_PB, N), dim3(256), 0, s, depth, image, sparse, validity,
+                           max_input_depth, H, W, ws + ws_depth_off(N));
+        if (has_cos)
+            hipLaunchKernelGGL(cos_rows_kernel, dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+    }
     // defer_finalize (fused step, N <= LOSS_FIN_MAXN): ptta_launch_loss_backward(..., w3_dev, loss_info) finalises inside its kernels
     if (!defer_finalize || N > LOSS_FIN_MAXN)
         hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, ws, N, H, W, R, has_cos, w3_dev, loss_info);
@@ -207,17 +234,17 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
     return 0;
 }
 
-__global__ __launch_bounds__(256) void loss_depth_grad_kernel(const float* __restrict__ depth, const float* __restrict__ image,
-                                                              const float* __restrict__ sparse, const float* __restrict__ validity,
-                                                              float max_d, int N, int H, int W, float* __restrict__ ws,
-                                                              float* __restrict__ g, long R, int has_cos, const float* __restrict__ w3,
-                                                              float* __restrict__ loss_info) {
+__device__ __forceinline__ void depth_grad_body(int bx, int nbx, const float* __restrict__ depth, const float* __restrict__ image,
+                                                const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                float max_d, int N, int H, int W, float* __restrict__ ws,
+                                                float* __restrict__ g, long R, int has_cos, const float* __restrict__ w3,
+                                                float* __restrict__ loss_info) {
     __shared__ float fin[3 + LOSS_FIN_MAXN];
     const size_t plane = (size_t)H * W;
     const size_t total = (size_t)N * plane;
-    if (w3) loss_finalize_block(ws, N, H, W, R, has_cos, w3, fin, blockIdx.x == 0 ? loss_info : nullptr, ws);       // fused step
+    if (w3) loss_finalize_block(ws, N, H, W, R, has_cos, w3, fin, bx == 0 ? loss_info : nullptr, ws);       // fused step
     const float cx = w3 ? fin[1] : ws[WS_SCAL + 1], cy = w3 ? fin[2] : ws[WS_SCAL + 2];
-    for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (size_t)gridDim.x * blockDim.x) {
+    for (size_t gi = (size_t)bx * blockDim.x + threadIdx.x; gi < total; gi += (size_t)nbx * blockDim.x) {
         const int n = (int)(gi / plane);
         const size_t idx = gi % plane;
         const int x = (int)(idx % W), y = (int)(idx / W);
@@ -234,15 +261,22 @@ __global__ __launch_bounds__(256) void loss_depth_grad_kernel(const float* __res
         g[gi] = v + cx * tx + cy * ty;
     }
 }
+__global__ __launch_bounds__(256) void loss_depth_grad_kernel(const float* __restrict__ depth, const float* __restrict__ image,
+                                                              const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                              float max_d, int N, int H, int W, float* __restrict__ ws,
+                                                              float* __restrict__ g, long R, int has_cos, const float* __restrict__ w3,
+                                                              float* __restrict__ loss_info) {
+    depth_grad_body(blockIdx.x, gridDim.x, depth, image, sparse, validity, max_d, N, H, W, ws, g, R, has_cos, w3, loss_info);
+}
 
-__global__ __launch_bounds__(256) void cos_grad_kernel(const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
-                                                       const float* __restrict__ ws, const float* __restrict__ rowstats,
-                                                       float* __restrict__ gref, int N, int H, int W, const float* __restrict__ w3) {
+__device__ __forceinline__ void cos_grad_body(int bx, int nbx, const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+                                              const float* __restrict__ ws, const float* __restrict__ rowstats,
+                                              float* __restrict__ gref, int N, int H, int W, const float* __restrict__ w3) {
     __shared__ float fin[3 + LOSS_FIN_MAXN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (w3) loss_finalize_block(ws, N, H, W, R, 1, w3, fin, nullptr, nullptr);
     const float coef = w3 ? fin[0] : ws[WS_SCAL + 0];
-    for (long row = (long)blockIdx.x * 4 + wave; row < R; row += (long)gridDim.x * 4) {
+    for (long row = (long)bx * 4 + wave; row < R; row += (long)nbx * 4) {
         const float ne = rowstats[3 * row], nr = rowstats[3 * row + 1], c = rowstats[3 * row + 2];
         const float ie = 1.f / ne, ir = 1.f / nr;
         // d(r/max(|r|,eps))/dr = (I - rhat rhat^T)/|r| above eps, I/eps below it
@@ -258,6 +292,20 @@ __global__ __launch_bounds__(256) void cos_grad_kernel(const float* __restrict__
         }
     }
 }
+__global__ __launch_bounds__(256) void cos_grad_kernel(const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+                                                       const float* __restrict__ ws, const float* __restrict__ rowstats,
+                                                       float* __restrict__ gref, int N, int H, int W, const float* __restrict__ w3) {
+    cos_grad_body(blockIdx.x, gridDim.x, emb, ref, R, D, ws, rowstats, gref, N, H, W, w3);
+}
+// both gradients in ONE launch (see loss_forward_merged_kernel): blocks [0, db) the depth gradient, the rest the cosine gradient
+__global__ __launch_bounds__(256) void loss_backward_merged_kernel(const float* __restrict__ depth, const float* __restrict__ image,
+                                                                   const float* __restrict__ sparse, const float* __restrict__ validity,
+                                                                   float max_d, int N, int H, int W, float* __restrict__ ws, float* __restrict__ g,
+                                                                   const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+                                                                   float* __restrict__ gref, const float* __restrict__ w3, float* __restrict__ loss_info, int db) {
+    if ((int)blockIdx.x < db) depth_grad_body(blockIdx.x, db, depth, image, sparse, validity, max_d, N, H, W, ws, g, R, 1, w3, loss_info);
+    else cos_grad_body(blockIdx.x - db, gridDim.x - db, emb, ref, R, D, ws, ws + ws_rows_off(N), gref, N, H, W, w3);
+}
 
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
@@ -267,6 +315,15 @@ int ptta_launch_loss_backward(const float* depth, const float* image, const floa
     if (w3_fused && N > LOSS_FIN_MAXN) w3_fused = nullptr;          // the forward launched the finalize kernel in that case
     int blocks = (int)((total + 255) / 256); if (blocks > (w3_fused ? 1024 : 4096)) blocks = w3_fused ? 1024 : 4096;
     const int has_cos = (emb && ref) ? 1 : 0;
+    static const int merge_off = getenv("PTTA_LOSS_MERGE") ? (atoi(getenv("PTTA_LOSS_MERGE")) == 0) : 0;     // A/B switch
+    if (emb && ref && gref && w3_fused && !merge_off) {
+        long cb = (R + 3) / 4; if (cb > 1024) cb = 1024;
+        if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(loss_backward_merged_kernel, dim3(blocks + (int)cb), dim3(256), 0, s, depth, image, sparse, validity, max_input_depth, N, H, W,
+                           ws, gdepth, emb, ref, R, D, gref, w3_fused, loss_info_fused, blocks);
+        PTTA_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(loss_depth_grad_kernel, dim3(blocks), dim3(256), 0, s, depth, image, sparse, validity,
                        max_input_depth, N, H, W, ws, gdepth, R, has_cos, w3_fused, loss_info_fused);
     if (emb && ref && gref) {

@@ -14,10 +14,11 @@ cp $O/trace_graph/x_kernel_stats.csv $O/r03_fp32_kernel_stats.csv
 # 2
 PTTA_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_step -o x -- python3 $BENCH > /dev/null 2> $O/trace_step.log
 python3 tools/trace_step.py $O/trace_step/x_kernel_trace.csv 120 > $O/r03_fp32_step_trace_summary.txt
+python3 tools/trace_sequence.py $O/trace_graph/x_kernel_trace.csv > $O/r03_fp32_step_sequence_graph.txt
 # 3
 PTTA_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o x -- python3 bench.py --steps 8 --warmup 2 --no-nlspn --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.log
 PTTA_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o x -- python3 bench.py --steps 8 --warmup 2 --no-nlspn --no-cpu-baseline > /dev/null 2> $O/pmc_write.log
-python3 tools/traffic_from_pmc.py $O/pmc_fetch/x_counter_collection.csv $O/pmc_write/x_counter_collection.csv "conv32_s1_x3_kernel<true" $O/traffic_fp32.json > /dev/null
+python3 tools/traffic_from_pmc.py $O/pmc_fetch/x_counter_collection.csv $O/pmc_write/x_counter_collection.csv "conv32_s1_(x3|small)_kernel<true" $O/traffic_fp32.json > /dev/null
 python3 tools/pmc_summary.py "$O/pmc_fetch/x_counter_collection.csv" "$O/pmc_write/x_counter_collection.csv" > $O/r03_fp32_pmc_fetch_write_per_kernel.txt
 PTTA_GRAPH=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
   --output-format csv -d $O/pmc_sq -o x -- python3 bench.py --steps 4 --warmup 2 --no-nlspn --no-cpu-baseline > /dev/null 2> $O/pmc_sq.log

@@ -2,11 +2,11 @@
 """HBM traffic per launch of the dominant kernel class from two rocprofv3 --pmc passes
 (FETCH_SIZE and WRITE_SIZE collected separately: they do not fit one pass on gfx950).
 Units/corrections per MI355X_MICROARCH.md §HBM: counters are in KiB; FETCH_SIZE reports half the bytes of
-wide (16 B/lane) coalesced reads on gfx950 -> doubled; WRITE_SIZE is taken as is (our epilogue stores are
-4 B/lane, an access width the guide calls uncalibrated, so the write half is indicative).
-usage: traffic_from_pmc.py <fetch_csv> <write_csv> <kernel-name-substring> <out.json>"""
+wide (16 B/lane) coalesced reads on gfx950 -> doubled; WRITE_SIZE is taken as is (the epilogues store float4 since round 2).
+usage: traffic_from_pmc.py <fetch_csv> <write_csv> <kernel-name regular expression> <out.json>"""
 import csv
 import json
+import re
 import sys
 
 fetch_csv, write_csv, pat, out = sys.argv[1:5]
@@ -15,7 +15,7 @@ fetch_csv, write_csv, pat, out = sys.argv[1:5]
 def total(path, counter):
     s, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if pat in r['Kernel_Name'] and r['Counter_Name'] == counter:
+        if re.search(pat, r['Kernel_Name']) and r['Counter_Name'] == counter:
             s += float(r['Counter_Value']); n += 1
     return s, n
 

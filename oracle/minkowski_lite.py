@@ -13,7 +13,10 @@ Semantics restated
   * generalized sparse convolution: out[u] = sum_{i in N(u, K)} W_i x[u + i * tensor_stride] over EXISTING inputs only;
     stride-1 convolutions keep the input coordinates, a stride-s convolution has output coordinates
     unique(floor(c / (ts*s)) * (ts*s)) and tensor stride ts*s; odd kernels are centred.
-  * kernel offsets are enumerated with the first spatial axis fastest: k = (d0+1) + 3*(d1+1) + 9*(d2+1)  [choice];
+  * kernel offsets are enumerated with the first spatial axis fastest: k = (d0+1) + 3*(d1+1) + 9*(d2+1)  [pinned by the reference's
+    PRETRAINED weights: with external_src/costdcnet/weights/*.pth the real network completes a synthetic indoor scene to 7.5 mm MAE
+    under this order, 99 mm under the opposite one, 125 mm with the offsets shuffled -- tools/costdcnet_kernel_order.py,
+    tests/test_oracle_golden.py::test_sparse_kernel_order_matches_pretrained_weights];
     kernel tensor (K, Cin, Cout), or (Cin, Cout) when kernel volume = 1 and stride = 1 (the layout of the shipped
     external_src/costdcnet/weights/enc3d.pth: conv2.kernel (64,16), downsample.0.kernel (1,32,48)); no bias.
   * a kernel_size-1, stride-s convolution only sees inputs that sit exactly on an output coordinate.
@@ -89,7 +92,7 @@ def kernel_offsets(kernel_size):
     if kernel_size == 1:
         return [(0, 0, 0)]
     r = range(-(kernel_size // 2), kernel_size // 2 + 1)
-    return [(d0, d1, d2) for d2 in r for d1 in r for d0 in r]          # first axis fastest [choice]
+    return [(d0, d1, d2) for d2 in r for d1 in r for d0 in r]          # first axis fastest (pinned: module docstring)
 
 
 def sparse_conv(x, kernel, kernel_size, stride):

@@ -552,11 +552,8 @@ def main():
         eng.step(*frames[i % nframes])
     torch.cuda.synchronize()
     instrumented_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-    ms_raw, abytes, macs, launches = eng.profile_read(1)      # class 1 = stride-1, relu-in
+    ms, abytes, macs, launches = eng.profile_read(1)      # class 1 = stride-1, relu-in
     eng.profile(False)
-    # an event pair brackets the launch's own latency too (rocprofv3's kernel duration does not): calibrated on an empty kernel, subtracted
-    pair_us = eng.profile_overhead()
-    ms = max(ms_raw - launches * pair_us * 1e-3, 1e-9)
     if dist is not None:
         t = torch.tensor([elapsed], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -578,9 +575,8 @@ def main():
                     'frac': achieved / (HBM_PEAK / 1e9)}
         roof.update({'kernel': ('stride-1 3x3 32->32 convolutions with ReLU on load: conv32_s1_x3_kernel<true, *> (large maps) + conv32_s1_small_kernel<true, *> '
                                 '(maps of <= 256 tiles)' if es == 4 else 'conv32_mfma_kernel<bf16, CONV_S1, relu, *>'),
-                     'measured': 'hipEvents around each launch, same K steps re-run without the graph (%.3f ms/step); the bracket of an empty '
-                                 'kernel (event pair + launch latency, %.2f us) subtracted per launch' % (instrumented_ms, pair_us),
-                     'launches': launches, 'avg_launch_us': 1e3 * ms / max(launches, 1), 'avg_launch_us_with_event_pair': 1e3 * ms_raw / max(launches, 1),
+                     'measured': 'hipEvents around each launch, same K steps re-run without the graph (%.3f ms/step)' % instrumented_ms,
+                     'launches': launches, 'avg_launch_us': 1e3 * ms / max(launches, 1),
                      'alg_bytes_per_launch': abytes / max(launches, 1), 'traffic': None})
         tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.dtype)
         if os.path.exists(tpath):       # HBM bytes per launch from the separate rocprofv3 --pmc passes

@@ -290,9 +290,6 @@ int ptta_set_graph(ptta_handle h, int enable);
 int ptta_profile(ptta_handle h, int enable);
 int ptta_profile_read(ptta_handle h, int klass, double* ms_total_host, double* alg_bytes_host, double* macs_host,
                       int64_t* launches_host, ptta_stream s);
-/* Mean bracket, in microseconds, of an EMPTY kernel between two events on `s` (what the event pair and the launch itself add to every
- * bracketed launch of ptta_profile): subtract launches x this from ptta_profile_read's total to compare with a profiler's kernel durations. */
-int ptta_profile_overhead(ptta_handle h, double* us_per_launch, ptta_stream s);
 
 /* Test / debug hooks (not on the hot path). */
 int ptta_debug_tensor(ptta_handle h, const char* name, float* dst, int64_t capacity, int64_t* numel_host, ptta_stream s);

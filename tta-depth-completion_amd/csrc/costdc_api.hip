@@ -449,7 +449,8 @@ GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth
     // ... on the layers that decide it (measured layer by layer, tools/costdc_report.py with PTTA_X6_LAYERS): Encoder2D, the meta convolution
     // and the first two levels of the UNet3D give the post-update depth of bf16x6 everywhere (5.5e-6 / 6.0e-4 at 320x400 / 480x640); any
     // smaller set leaves it at 0.8 - 1.3e-3
-    e->x6_layers = "enc2d,conv1_rgb_meta,unet3d.inc,unet3d.down1";
+    // (the DDP adapted set adapts the UNet3D's own BatchNorm too: every layer keeps the third plane there)
+    e->x6_layers = (flags & 1) ? "" : "enc2d,conv1_rgb_meta,unet3d.inc,unet3d.down1";
     // hipGraph replay of the step / eval forward: built and bit-identical (tests), but measured 0.3 - 2 % SLOWER than kernel-by-kernel
     // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: PTTA_GRAPH=1 / ptta_set_graph(h, 1)
     { const char* gr = getenv("PTTA_GRAPH"); e->use_graph = (gr && strcmp(gr, "1") == 0) ? 1 : 0; }

@@ -1794,30 +1794,6 @@ int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_by
     return 0;
 }
 
-__global__ void prof_empty_kernel() {}
-// What an event pair adds around a launch (event processing + the launch's own latency): the bracket of an EMPTY kernel, mean of 64.  The
-// profiler's kernel duration has neither, so ptta_profile_read's total minus launches x this is what agrees with rocprofv3 --kernel-trace.
-int ptta_profile_overhead(ptta_handle c, double* us_per_launch, ptta_stream s_) {
-    if (!c || !us_per_launch) return -1;
-    hipStream_t s = (hipStream_t)s_;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -12;
-    double tot = 0; int n = 0;
-    for (int k = 0; k < 72; ++k) {
-        (void)hipEventRecord(e0, s);
-        hipLaunchKernelGGL(prof_empty_kernel, dim3(1), dim3(64), 0, s);
-        (void)hipEventRecord(e1, s);
-        if (hipStreamSynchronize(s) != hipSuccess) break;
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) break;
-        if (k >= 8) { tot += t; ++n; }                     // first launches warm the code object up
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (!n) return c->fail("event timing failed", -5);
-    *us_per_launch = 1e3 * tot / n;
-    return 0;
-}
-
 int ptta_debug_tensor(ptta_handle c, const char* name, float* dst, int64_t capacity, int64_t* numel_host, ptta_stream s_) {
     NLFWD(c->nl->debug_tensor(name, dst, capacity, numel_host, (hipStream_t)s_));
 

@@ -80,7 +80,6 @@ SIGNATURES = [
     ('ptta_set_grad_sync_rccl', c_int, [_P, _P]),
     ('ptta_set_graph', c_int, [_P, c_int]),
     ('ptta_profile', c_int, [_P, c_int]),
-    ('ptta_profile_overhead', c_int, [_P, POINTER(ctypes.c_double), _P]),
     ('ptta_profile_read', c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                   POINTER(c_int64), _P]),
     ('ptta_debug_tensor', c_int, [_P, c_char_p, _P, c_int64, POINTER(c_int64), _P]),

@@ -363,12 +363,6 @@ class Engine:
                   'ptta_profile_read')
         return ms.value, by.value, mc.value, n.value
 
-    def profile_overhead(self):
-        """Microseconds an event pair adds around one launch (bracket of an empty kernel): see include/ptta.h."""
-        us = ctypes.c_double(0)
-        self._chk(self.lib.ptta_profile_overhead(self.handle, byref(us), _stream()), 'ptta_profile_overhead')
-        return us.value
-
     def debug_tensor(self, name):
         n = c_int64(0)
         self._chk(self.lib.ptta_debug_tensor(self.handle, name.encode(), None, 0, byref(n), _stream()), 'ptta_debug_tensor')

@@ -475,55 +475,65 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {
-        const uint4* ph = (const uint4*)p.wpack;
-        const uint4* pl = (const uint4*)p.wpack2;
-        for (int idx = tid; idx < 18 * 64; idx += 256) { *(uint4*)(wl_lds + idx * 16) = ph[idx]; *(uint4*)(wl_lds + (18 * 64 + idx) * 16) = pl[idx]; }
-    }
-    __syncthreads();
     const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
     const int nseg = (Wt + 31) >> 5;
     const int npar = (MODE == CONV_T2) ? 2 : 1;
     const long nitems = (long)p.B * nseg * npar * p.Hout;
     const float sy = up_scale(p.Hout >> 1, p.Hout), sx = up_scale(p.Wout >> 1, p.Wout);
 
-    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+    // item state (one item = 32 outputs of one row / x parity), decoded before its first loads
+    int y = 0, xpar = 0, b = 0, x0 = 0;
+    bool lane_in = false;
+    const float* inb = p.in;
+    auto decode = [&](long item) __attribute__((always_inline)) {
         long t_ = item;
-        const int y = (int)(t_ % p.Hout); t_ /= p.Hout;
-        int xpar = 0;
+        y = (int)(t_ % p.Hout); t_ /= p.Hout;
+        xpar = 0;
         if (MODE == CONV_T2) { xpar = (int)(t_ & 1); t_ >>= 1; }
         const int seg = (int)(t_ % nseg);
-        const int b = (int)(t_ / nseg);
-        const int x0 = seg << 5;
-        const bool lane_in = (x0 + i) < Wt;
-        const float* inb = p.in + (size_t)(b % p.in_nb) * p.Hin * p.Win * 32;
+        b = (int)(t_ / nseg);
+        x0 = seg << 5;
+        lane_in = (x0 + i) < Wt;
+        inb = p.in + (size_t)(b % p.in_nb) * p.Hin * p.Win * 32;
+    };
+    // Loads are UNCONDITIONAL (clamped address + select) and issued three taps ahead of their MFMAs: with a per-load
+    // `if (ok)` every one of the 36 loads of an item waited for the previous one (s_waitcnt behind each exec branch), which
+    // at the 1/8 and 1/16-resolution layers -- one item per wave -- was the whole kernel: 12.3 us whatever the size.
+    float4 v[9][4];
+    bool act[9], okl[9];
+    auto fetch = [&](int tap) __attribute__((always_inline)) {
+        const int ky = tap / 3, kx = tap % 3;
+        bool active = true;
+        int yi, xi;
+        if (MODE == CONV_S1) { yi = y + ky - 1; xi = x0 + i + kx - 1; }
+        else if (MODE == CONV_S2) { yi = 2 * y + ky - 1; xi = 2 * (x0 + i) + kx - 1; }
+        else {
+            const int ty = y + 1 - ky, tx = xpar + 1 - kx;
+            active = ((ty & 1) == 0) && ((tx & 1) == 0);
+            yi = ty >> 1; xi = x0 + i + (tx >> 1);
+        }
+        active = active && (yi >= 0) && (yi < p.Hin);
+        act[tap] = active;                                          // wave-uniform
+        okl[tap] = active && lane_in && (xi >= 0) && (xi < p.Win);
+        if (!active) return;
+        const float* src = inb + ((size_t)yi * p.Win + (okl[tap] ? xi : 0)) * 32 + 8 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[tap][q] = *(const float4*)(src + 16 * (q >> 1) + 4 * (q & 1));      // q = 2*kstep + half-of-8
+    };
+    long item = (long)blockIdx.x * 4 + wave;
+    // the first item's loads go out BEFORE the weight fragments are staged: one memory round trip for both instead of two in a row
+    // (the 1/8 and 1/16-resolution launches are one item per wave: their duration is this latency chain)
+    if (item < nitems) { decode(item); fetch(0); fetch(1); fetch(2); fetch(3); fetch(4); fetch(5); }
+    {
+        const uint4* ph = (const uint4*)p.wpack;
+        const uint4* pl = (const uint4*)p.wpack2;
+        for (int idx = tid; idx < 18 * 64; idx += 256) { *(uint4*)(wl_lds + idx * 16) = ph[idx]; *(uint4*)(wl_lds + (18 * 64 + idx) * 16) = pl[idx]; }
+    }
+    lds_barrier();
+    while (item < nitems) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        // Loads are UNCONDITIONAL (clamped address + select) and issued three taps ahead of their MFMAs: with a per-load
-        // `if (ok)` every one of the 36 loads of an item waited for the previous one (s_waitcnt behind each exec branch), which
-        // at the 1/8 and 1/16-resolution layers -- one item per wave -- was the whole kernel: 12.3 us whatever the size.
-        float4 v[9][4];
-        bool act[9], okl[9];
-        auto fetch = [&](int tap) __attribute__((always_inline)) {
-            const int ky = tap / 3, kx = tap % 3;
-            bool active = true;
-            int yi, xi;
-            if (MODE == CONV_S1) { yi = y + ky - 1; xi = x0 + i + kx - 1; }
-            else if (MODE == CONV_S2) { yi = 2 * y + ky - 1; xi = 2 * (x0 + i) + kx - 1; }
-            else {
-                const int ty = y + 1 - ky, tx = xpar + 1 - kx;
-                active = ((ty & 1) == 0) && ((tx & 1) == 0);
-                yi = ty >> 1; xi = x0 + i + (tx >> 1);
-            }
-            active = active && (yi >= 0) && (yi < p.Hin);
-            act[tap] = active;                                          // wave-uniform
-            okl[tap] = active && lane_in && (xi >= 0) && (xi < p.Win);
-            if (!active) return;
-            const float* src = inb + ((size_t)yi * p.Win + (okl[tap] ? xi : 0)) * 32 + 8 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[tap][q] = *(const float4*)(src + 16 * (q >> 1) + 4 * (q & 1));      // q = 2*kstep + half-of-8
-        };
         auto compute = [&](int tap) __attribute__((always_inline)) {
             if (!act[tap]) return;
 #pragma unroll
@@ -544,13 +554,13 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
             }
         };
-        fetch(0); fetch(1); fetch(2);
-        fetch(3); fetch(4); fetch(5);
         compute(0); compute(1); compute(2);
         fetch(6); fetch(7); fetch(8);
         compute(3); compute(4); compute(5);
         compute(6); compute(7); compute(8);
         epi_tile<float, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx);
+        item += (long)gridDim.x * 4;
+        if (item < nitems) { decode(item); fetch(0); fetch(1); fetch(2); fetch(3); fetch(4); fetch(5); }
     }
 }
 

@@ -499,13 +499,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A STREAM of frames: every call names the frame the next call will pass, and the part of that frame's forward that does not depend on
+    # the adapted parameters (sparse-depth pooling, the frozen RGB encoder, the depth-only head of the stage-1 encoder) runs on its own
+    # stream beside this frame's step (ptta_step_pipelined; identical results, tests/test_gpu_staging_augment.py).  K timed calls = K such
+    # prefixes + K remainders: the first timed frame's prefix is started by the last warm-up call, the last call starts one for frame K+1.
+    pipe = os.environ.get('PTTA_PIPELINE', '1') != '0'
+
+    def nxt(i):
+        return frames[(i + 1) % nframes] if pipe else None
     for i in range(args.warmup):
-        eng.step(*frames[i % nframes])
+        eng.step(*frames[i % nframes], next_frame=nxt(i))
+    if args.warmup == 0 and pipe:
+        pass                        # the first timed call then computes its own prefix in line
     barrier()
     t0 = time.perf_counter()
     info = None
     for i in range(args.steps):
-        info, _ = eng.step(*frames[i % nframes])
+        info, _ = eng.step(*frames[(args.warmup + i) % nframes], next_frame=nxt(args.warmup + i))
     barrier()
     elapsed = time.perf_counter() - t0
     # Second figure: the same K steps with every frame starting in PAGEABLE HOST memory, as the reference's

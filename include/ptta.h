@@ -148,6 +148,16 @@ const char* ptta_adapted_name(ptta_handle h, int index, int64_t* numel_host);
  * (torch.optim.Adam walks the list; a tensor listed twice is stepped twice with the same gradient).  1 except under PTTA_SYNCBN_ADAPT. */
 int ptta_adapted_repeat(ptta_handle h, int index);
 
+/* ptta_step for a STREAM of frames (MSG_CHN handles; others forward to ptta_step): besides the step on (image, sparse) it starts, on a stream
+ * of its own, the part of the NEXT frame's forward that does not depend on the adapted parameters -- clamp / pooling of the sparse depth, the
+ * frozen RGB encoder, the depth-only head of the stage-1 encoder (everything upstream of conv1_rgb_meta) -- so that it runs beside this
+ * frame's step instead of at the head of the next one.  Results are those of ptta_step, call by call (the prefix's outputs exist twice).
+ * next_image / next_sparse: the frame the FOLLOWING call will pass (same device pointers -- that is how the prepared prefix is recognised;
+ * a different frame just recomputes it), valid and unchanged until that call; NULL: nothing is prepared.  The reference's loop knows its next
+ * frame from the data loader (src/tta_main.py:519-523).  ptta_forward_eval / ptta_forward_train between two calls are fine. */
+int ptta_step_pipelined(ptta_handle h, const float* image, const float* loss_image, const float* sparse_depth, const float* validity_map,
+                        const float* next_image, const float* next_sparse_depth, float* depth_out, float* loss_info_out, ptta_stream s);
+
 /* optimizer.step() for the bound parameters with explicit gradients (src/tta_main.py:633). */
 int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* grad_meta_bias, ptta_stream s);
 

@@ -276,3 +276,33 @@ def test_staged_sequence_equals_resident_sequence():
     assert torch.equal(ia, ib)
     for k in pa:
         assert torch.equal(pa[k], pb[k]), k
+
+
+def test_pipelined_steps_equal_plain_steps():
+    """ptta_step_pipelined: the parameter-independent prefix of frame k+1 (sparse-depth pooling, frozen RGB encoder, depth-only head of the
+    stage-1 encoder) runs on its own stream beside the step of frame k.  Same parameters, losses and depths as ptta_step, call by call --
+    also with an eval forward between two calls, an unannounced frame (prefix recomputed in line) and a plain step in the middle."""
+    from tests.util import make_engine
+    n, h, w = 1, 64, 128
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(20 + i, h, w, n)] for i in range(7)]
+    out = {}
+    for mode in ('plain', 'pipelined'):
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0))
+        rec = []
+        for i in range(6):
+            nxt = frames[i + 1] if mode == 'pipelined' else None
+            if i == 3:
+                nxt = None if mode == 'plain' else frames[6]               # announce the WRONG frame once: step 4 recomputes its prefix
+            if i == 5 and mode == 'pipelined':
+                nxt = None                                                   # a plain ptta_step in the middle of the stream
+            info, depth = eng.step(frames[i][0], frames[i][1], want_depth=True, next_frame=nxt)
+            ev = eng.forward_eval(frames[i][0], frames[i][1]) if i in (1, 2) else None     # the scored forward between two steps
+            rec.append((info.clone(), depth.clone(), None if ev is None else ev.clone(), {k: v[0].clone() for k, v in adapted.items()}))
+        torch.cuda.synchronize()
+        out[mode] = rec
+        eng.close()
+    for a, b in zip(out['plain'], out['pipelined']):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert (a[2] is None) == (b[2] is None) and (a[2] is None or torch.equal(a[2], b[2]))
+        for k in a[3]:
+            assert torch.equal(a[3][k], b[3][k]), k

@@ -106,6 +106,25 @@ struct ptta_ctx {
     hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
     hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t cap_stream = nullptr;    // private stream to capture on (the caller's may be the un-capturable null stream)
+    // ---- frame pipelining (ptta_step_pipelined) ----
+    // Everything UPSTREAM of the adapted layer -- clamp / pooling of the sparse depth, the frozen RGB encoder, the depth-only head of the
+    // stage-1 encoder -- does not depend on the parameters the previous frame's Adam step writes, so the prefix of frame k+1 runs on its own
+    // stream BESIDE the rest of frame k.  Its outputs (and the staged inputs) exist twice; a set's pointers are swapped into the members the
+    // launches read, and every graph is captured once per set.
+    struct PreSet {
+        void *c0 = nullptr, *c1 = nullptr, *c2 = nullptr, *c3 = nullptr, *c4 = nullptr, *e1_0a = nullptr, *e1_0 = nullptr, *e1_1a = nullptr;
+        void *e1_1 = nullptr, *y1 = nullptr, *e1_2a = nullptr, *y2 = nullptr, *t1 = nullptr, *y3 = nullptr, *s1_1 = nullptr, *u1 = nullptr;
+        float *dclamp = nullptr, *d12 = nullptr, *d14 = nullptr, *in_image = nullptr, *in_loss_image = nullptr, *in_sparse = nullptr, *in_validity = nullptr;
+        bool proxy_valid = false, prepared = false, rest_recorded = false;
+        const float *prep_image = nullptr, *prep_sparse = nullptr;
+    };
+    PreSet pset[2];
+    int cur_set = 0, pipe_cur = 0, pipe_last = 0;        // set in the members now / of the next pipelined frame / of the last processed frame
+    bool pipe_ready = false, pipe_active = false, skip_prefix = false;
+    hipStream_t pre_stream = nullptr;
+    hipEvent_t ev_prefix[2] = {nullptr, nullptr}, ev_rest[2] = {nullptr, nullptr}, ev_entry = nullptr;
+    hipGraph_t pgraph[2] = {nullptr, nullptr}, rgraph[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    hipGraphExec_t pexec[2] = {nullptr, nullptr}, rexec[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     // intra-step concurrency: the MLP heads run on a second stream beside decoder 3 (forward) and beside
     // the first decoder-3 gradients (backward); fork/join with events (graph edges under capture)
     int use_aux = 1;
@@ -127,9 +146,19 @@ struct ptta_ctx {
     hipEvent_t ev_replay = nullptr;      // recorded after every hipGraphLaunch: a graph is only destroyed once its last replay is done
     void drop_graphs() {
         if (ev_replay) (void)hipEventSynchronize(ev_replay);
+        if (pre_stream) (void)hipStreamSynchronize(pre_stream);
         for (int k = 0; k < 4; ++k) {
             if (gexec[k]) { (void)hipGraphExecDestroy(gexec[k]); gexec[k] = nullptr; }
             if (graph[k]) { (void)hipGraphDestroy(graph[k]); graph[k] = nullptr; }
+            for (int p = 0; p < 2; ++p) {
+                if (rexec[k][p]) { (void)hipGraphExecDestroy(rexec[k][p]); rexec[k][p] = nullptr; }
+                if (rgraph[k][p]) { (void)hipGraphDestroy(rgraph[k][p]); rgraph[k][p] = nullptr; }
+            }
+        }
+        for (int p = 0; p < 2; ++p) {
+            if (pexec[p]) { (void)hipGraphExecDestroy(pexec[p]); pexec[p] = nullptr; }
+            if (pgraph[p]) { (void)hipGraphDestroy(pgraph[p]); pgraph[p] = nullptr; }
+            pset[p].prepared = false;
         }
     }
 
@@ -601,6 +630,8 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
 }
 
 int heads_forward(ptta_ctx* c, hipStream_t s);
+static int pipe_quiesce(ptta_ctx* c);
+static void pipe_use(ptta_ctx* c, int p);
 
 // RGBEncoder.forward (:252-264) on `nb` frames written at batch offset `boff` of the c0..c4 buffers; frames with index
 // >= zero_from_b see a zero image (the proxy pass's torch.zeros_like(rgb), :511).
@@ -669,6 +700,36 @@ int ensure_proxy_rgb(ptta_ctx* c, const float* any_image, hipStream_t s) {
     return 0;
 }
 
+// The depth-only head of the stage-1 encoder (DepthEncoder.forward :218-232 up to the first skip addition): nothing of the RGB branch in it
+int enc1_head_fn(ptta_ctx* c, hipStream_t st) {
+    const int Nn = c->Nn, H4 = c->H4, W4 = c->W4;
+    const LIn& li = c->lin_in["depth_encoder1.init.0"];
+    ConvInArgs a; a.cin = 1; a.pl[0].p = c->d14; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H4 * W4;
+    a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e1_0a;
+    a.B = Nn; a.H = H4; a.W = W4; a.bf16 = c->bf16; a.naive = c->naive;
+    RUN(ptta_launch_conv_in(a, st));
+    { E e; e.raw = c->e1_0; RUN(conv32(c, st, "depth_encoder1.init.2", false, CONV_S1, c->e1_0a, Nn, Nn, H4, W4, true, e)); }
+    { E e; e.raw = c->e1_1a; RUN(conv32(c, st, "depth_encoder1.enc1.1", false, CONV_S2, c->e1_0, Nn, Nn, H4, W4, true, e)); }
+    return 0;
+}
+
+// The rest of the stage-1/4 cascade that the adapted layer does not reach: the encoder's two skip additions with the RGB features
+// (:487-489) and decoder 1 down to its last transposed convolution (DepthDecoder.forward :296-305) -- conv1_rgb_meta's output enters
+// at dec1.3.  B2 = images per launch ([real | proxy] in a training forward).
+int stage1_independent(ptta_ctx* c, int B2, hipStream_t s) {
+    const int Nn = c->Nn, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
+    { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
+      RUN(conv32(c, s, "depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, B2, H8, W8, true, e)); }
+    { E e; e.raw = c->e1_2a; RUN(conv32(c, s, "depth_encoder1.enc2.1", false, CONV_S2, c->e1_1, B2, Nn, H8, W8, true, e)); }
+    { E e; e.sum = c->y2; e.add1 = c->c4; e.add1_nb = B2;                                         // y2 = e1_2 + c4
+      RUN(conv32(c, s, "depth_encoder1.enc2.3", false, CONV_S1, c->e1_2a, Nn, B2, H16, W16, true, e)); }
+    { E e; e.raw = c->t1; RUN(conv32(c, s, "depth_decoder1.dec2.1", false, CONV_T2, c->y2, B2, B2, H16, W16, true, e)); }
+    { E e; e.raw = c->y3; e.sum = c->s1_1; e.add1 = c->y1; e.add1_nb = B2;
+      RUN(conv32(c, s, "depth_decoder1.dec2.3", false, CONV_S1, c->t1, B2, B2, H8, W8, true, e)); }
+    { E e; e.raw = c->u1; RUN(conv32(c, s, "depth_decoder1.dec1.1", false, CONV_T2, c->s1_1, B2, B2, H8, W8, true, e)); }
+    return 0;
+}
+
 // One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half;
 // the MLP heads (which only need depth_encoder3's output) run on the auxiliary stream beside decoder 3.
 int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
@@ -682,32 +743,27 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     // ensure_proxy_rgb(); only the real frames go through the encoder here
     // Its first three launches need nothing from the RGB branch: with a second stream they run BESIDE the RGB encoder
     // (forked before it, below); the fourth adds c3 and waits for the join.
-    auto enc1_head = [&](hipStream_t st) -> int {
-        const LIn& li = c->lin_in["depth_encoder1.init.0"];
-        ConvInArgs a; a.cin = 1; a.pl[0].p = c->d14; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H4 * W4;
-        a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e1_0a;
-        a.B = Nn; a.H = H4; a.W = W4; a.bf16 = c->bf16; a.naive = c->naive;
-        RUN(ptta_launch_conv_in(a, st));
-        RUN(conv32(c, st, "depth_encoder1.init.2", false, CONV_S1, c->e1_0a, Nn, Nn, H4, W4, true, e_raw(c->e1_0)));
-        RUN(conv32(c, st, "depth_encoder1.enc1.1", false, CONV_S2, c->e1_0, Nn, Nn, H4, W4, true, e_raw(c->e1_1a)));
-        return 0;
-    };
-    const bool early = train && s2 && (c->split_fwd & 2);
+    auto enc1_head = [&](hipStream_t st) -> int { return enc1_head_fn(c, st); };
+    const bool early = train && s2 && (c->split_fwd & 2) && !c->skip_prefix;
     if (early) {                  // depth-only head of the stage-1 encoder beside the RGB encoder
         HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
         RUN(enc1_head(s2));
         HIPCHK(hipEventRecord(c->ev_join, s2));
     }
-    RUN(rgb_encoder(c, image, Nn, 0, Nn, s));
+    if (!c->skip_prefix) RUN(rgb_encoder(c, image, Nn, 0, Nn, s));
     RUN(meta_forward(c, train, B2, s));
 
     // ---- stage 1/4 (:487-489): depth-only encoder shared by both passes ----
-    if (early) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); else RUN(enc1_head(s));
-    { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
-      CV("depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, B2, H8, W8, true, e); }
-    CV("depth_encoder1.enc2.1", false, CONV_S2, c->e1_1, B2, Nn, H8, W8, true, e_raw(c->e1_2a));
-    { E e; e.sum = c->y2; e.add1 = c->c4; e.add1_nb = B2;                                         // y2 = e1_2 + c4
-      CV("depth_encoder1.enc2.3", false, CONV_S1, c->e1_2a, Nn, B2, H16, W16, true, e); }
+    if (early) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); else if (!c->skip_prefix) RUN(enc1_head(s));
+    const bool split = train && s2 && (c->split_fwd & 1);
+    if (!c->skip_prefix && !split) RUN(stage1_independent(c, B2, s));
+    if (split) {                     // (diagnostic split of the two passes: the head of decoder 1 stays inside each pass's chain)
+        { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
+          CV("depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, B2, H8, W8, true, e); }
+        CV("depth_encoder1.enc2.1", false, CONV_S2, c->e1_1, B2, Nn, H8, W8, true, e_raw(c->e1_2a));
+        { E e; e.sum = c->y2; e.add1 = c->c4; e.add1_nb = B2;                                         // y2 = e1_2 + c4
+          CV("depth_encoder1.enc2.3", false, CONV_S1, c->e1_2a, Nn, B2, H16, W16, true, e); }
+    }
 
     // ---- decoder 1, stage 1/2, encoder of stage 1/1: `Bl` frames starting at batch index b0 of the [real | proxy] batch.
     // One pass over the whole batch (b0 = 0, Bl = B2), or -- training step with a second stream -- the real frames on `s` and
@@ -719,11 +775,13 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         auto P1 = [&](float* p_, int h, int w) { return p_ + (size_t)b0 * h * w; };
         auto raw = [](void* r) { E e; e.raw = r; return e; };
 #define CR(...) RUN(conv32(c, st, __VA_ARGS__))
-        // decoder 1 (DepthDecoder.forward :296-311)
+        // decoder 1 (DepthDecoder.forward :296-311); its first three launches are in stage1_independent() unless the passes are split
+        if (Bl != B2) {
         CR("depth_decoder1.dec2.1", false, CONV_T2, A(c->y2, H16, W16), Bl, Bl, H16, W16, true, raw(A(c->t1, H8, W8)));
         { E e; e.raw = A(c->y3, H8, W8); e.sum = A(c->s1_1, H8, W8); e.add1 = A(c->y1, H8, W8); e.add1_nb = Bl;
           CR("depth_decoder1.dec2.3", false, CONV_S1, A(c->t1, H8, W8), Bl, Bl, H8, W8, true, e); }
         CR("depth_decoder1.dec1.1", false, CONV_T2, A(c->s1_1, H8, W8), Bl, Bl, H8, W8, true, raw(A(c->u1, H4, W4)));
+        }
         { E e; e.raw = A(c->y4, H4, W4); e.sum = A(c->s0_1, H4, W4); e.add1 = c->e1_0; e.add1_nb = Nn; e.add2 = A(c->m, H4, W4); e.add2_nb = Bl;
           CR("depth_decoder1.dec1.3", false, CONV_S1, A(c->u1, H4, W4), Bl, Bl, H4, W4, true, e); }
         CR("depth_decoder1.prdct.1", false, CONV_S1, A(c->s0_1, H4, W4), Bl, Bl, H4, W4, true, raw(A(c->v1, H4, W4)));
@@ -783,7 +841,6 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
 #undef CR
         return 0;
     };
-    const bool split = train && s2 && (c->split_fwd & 1);
     if (split) {
         // real frames on s, proxy frames on s2; the heads (both halves' depth_encoder3 outputs) follow on s2 beside decoder 3
         HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
@@ -994,8 +1051,10 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
         hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * c->Hp * c->Wp)), dim3(256), 0, s, sparse, c->sp_pad, c->N, 1, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
         img = c->img_pad; sp = c->sp_pad;
     }
-    if (train) RUN(ensure_proxy_rgb(c, img, s));
-    RUN(ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
+    if (!c->skip_prefix) {                     // (ptta_step_pipelined ran this part ahead, beside the previous frame's step)
+        if (train) RUN(ensure_proxy_rgb(c, img, s));
+        RUN(ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
+    }
     if (c->meta_mode == PTTA_META_2LAYERS && c->m2.generic) {
         auto& m2 = c->m2;
         const float* W1 = c->adapted[0].p; const float* W2 = c->adapted[3].p;       // (128,32,3,3), (32,128,3,3)
@@ -1091,6 +1150,10 @@ void ptta_destroy(ptta_handle h) {
     h->drop_graphs();
     if (h->ev_replay) (void)hipEventDestroy(h->ev_replay);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->pre_stream) {
+        (void)hipStreamDestroy(h->pre_stream); (void)hipEventDestroy(h->ev_entry);
+        for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(h->ev_prefix[p]); (void)hipEventDestroy(h->ev_rest[p]); }
+    }
     if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_real); }
     for (void* p : h->allocs) if (p) (void)hipFree(p);
     for (auto& pc : h->prof) for (auto& e : pc.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1113,7 +1176,8 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
 
     if (!c || !name_ || !tensor) return -1;
     c->drop_graphs();
-    c->proxy_rgb_valid = false; c->fused_pp_valid = false;
+    RUN(pipe_quiesce(c));
+    c->proxy_rgb_valid = false; c->fused_pp_valid = false; c->pset[0].proxy_valid = false; c->pset[1].proxy_valid = false;
     hipStream_t s = (hipStream_t)s_;
     const std::string name(name_);
     const long numel = shape_numel(shape, ndim);
@@ -1274,6 +1338,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
 
     if (!c || !image || !sparse) return -1;
     hipStream_t s = (hipStream_t)s_;
+    if (c->pipe_active && !c->skip_prefix) pipe_use(c, c->pipe_last);       // never the buffer set a prefix may be writing (ptta_step_pipelined)
     c->fwd_valid = false; c->head.fwd_ok = false;
     RUN(forward_common(c, image, sparse, true, s));      // includes the heads (beside decoder 3)
     const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
@@ -1289,6 +1354,7 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
 
     if (!c || !image || !sparse || !depth_out) return -1;
     hipStream_t s = (hipStream_t)s_;
+    if (c->pipe_active) pipe_use(c, c->pipe_last);       // never the buffer set a prefix may be writing (ptta_step_pipelined)
     c->fwd_valid = false; c->head.fwd_ok = false;        // the eval pass overwrites the saved activations
     RUN(forward_common(c, image, sparse, false, s));
     HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, hipMemcpyDeviceToDevice, s));
@@ -1406,6 +1472,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
               float* depth_out, float* loss_info_out, ptta_stream s_) {
     if (!c || !image || !sparse) return -1;
     if (c->nl) return c->nl->step(image, loss_image, sparse, validity, depth_out, loss_info_out, (hipStream_t)s_);
+    RUN(pipe_quiesce(c));
     hipStream_t s = (hipStream_t)s_;
     if (!loss_image) loss_image = image;
     const size_t ibytes = (size_t)c->N * 3 * c->H * c->W * 4, pbytes = (size_t)c->N * c->H * c->W * 4;
@@ -1439,6 +1506,154 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
     }
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
     if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---- frame pipelining -------------------------------------------------------------------------------------------------------
+namespace {
+static void pipe_save(ptta_ctx* c, ptta_ctx::PreSet& P) {
+    P.c0 = c->c0; P.c1 = c->c1; P.c2 = c->c2; P.c3 = c->c3; P.c4 = c->c4; P.e1_0a = c->e1_0a; P.e1_0 = c->e1_0; P.e1_1a = c->e1_1a;
+    P.e1_1 = c->e1_1; P.y1 = c->y1; P.e1_2a = c->e1_2a; P.y2 = c->y2; P.t1 = c->t1; P.y3 = c->y3; P.s1_1 = c->s1_1; P.u1 = c->u1;
+    P.dclamp = c->dclamp; P.d12 = c->d12; P.d14 = c->d14;
+    P.in_image = c->in_image; P.in_loss_image = c->in_loss_image; P.in_sparse = c->in_sparse; P.in_validity = c->in_validity;
+    P.proxy_valid = c->proxy_rgb_valid;
+}
+static void pipe_use(ptta_ctx* c, int p) {
+    if (p == c->cur_set) return;
+    pipe_save(c, c->pset[c->cur_set]);
+    const ptta_ctx::PreSet& P = c->pset[p];
+    c->c0 = P.c0; c->c1 = P.c1; c->c2 = P.c2; c->c3 = P.c3; c->c4 = P.c4; c->e1_0a = P.e1_0a; c->e1_0 = P.e1_0; c->e1_1a = P.e1_1a;
+    c->e1_1 = P.e1_1; c->y1 = P.y1; c->e1_2a = P.e1_2a; c->y2 = P.y2; c->t1 = P.t1; c->y3 = P.y3; c->s1_1 = P.s1_1; c->u1 = P.u1;
+    c->dclamp = P.dclamp; c->d12 = P.d12; c->d14 = P.d14;
+    c->in_image = P.in_image; c->in_loss_image = P.in_loss_image; c->in_sparse = P.in_sparse; c->in_validity = P.in_validity;
+    c->proxy_rgb_valid = P.proxy_valid;
+    c->cur_set = p;
+}
+static int pipe_init(ptta_ctx* c) {
+    if (c->pipe_ready) return 0;
+    const int Nn = c->Nn, B2 = 2 * Nn, H1 = c->Hp, W1 = c->Wp;
+    const size_t es = c->es;
+    auto A = [&](int nb, int h, int w) { return c->dalloc((size_t)nb * h * w * 32 * es); };
+    pipe_save(c, c->pset[c->cur_set]);                       // the set the handle was built with (0)
+    ptta_ctx::PreSet& Q = c->pset[1];
+    Q.c0 = A(B2, H1, W1); Q.c1 = A(B2, c->H2, c->W2); Q.c2 = A(B2, c->H4, c->W4); Q.c3 = A(B2, c->H8, c->W8); Q.c4 = A(B2, c->H16, c->W16);
+    Q.e1_0a = A(Nn, c->H4, c->W4); Q.e1_0 = A(Nn, c->H4, c->W4); Q.e1_1a = A(Nn, c->H8, c->W8);
+    Q.e1_1 = A(B2, c->H8, c->W8); Q.y1 = A(B2, c->H8, c->W8); Q.e1_2a = A(Nn, c->H16, c->W16); Q.y2 = A(B2, c->H16, c->W16);
+    Q.t1 = A(B2, c->H8, c->W8); Q.y3 = A(B2, c->H8, c->W8); Q.s1_1 = A(B2, c->H8, c->W8); Q.u1 = A(B2, c->H4, c->W4);
+    Q.dclamp = c->falloc((size_t)Nn * H1 * W1); Q.d12 = c->falloc((size_t)Nn * c->H2 * c->W2); Q.d14 = c->falloc((size_t)Nn * c->H4 * c->W4);
+    Q.in_image = c->falloc((size_t)c->N * 3 * c->H * c->W); Q.in_loss_image = c->falloc((size_t)c->N * 3 * c->H * c->W);
+    Q.in_sparse = c->falloc((size_t)c->N * c->H * c->W); Q.in_validity = c->falloc((size_t)c->N * c->H * c->W);
+    if (c->oom) return c->fail("out of device memory (second prefix buffer set)", -12);
+    HIPCHK(hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking));
+    for (int p = 0; p < 2; ++p) {
+        HIPCHK(hipEventCreateWithFlags(&c->ev_prefix[p], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_rest[p], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming));
+    c->pipe_ready = true;
+    return 0;
+}
+// any entry point that is not ptta_step_pipelined: wait for a prefix in flight, forget it, go back to buffer set 0
+static int pipe_quiesce(ptta_ctx* c) {
+    if (!c->pipe_active) return 0;
+    HIPCHK(hipStreamSynchronize(c->pre_stream));
+    for (int p = 0; p < 2; ++p) c->pset[p].prepared = false;
+    pipe_use(c, 0);
+    c->pipe_cur = 0; c->pipe_last = 0; c->pipe_active = false;
+    return 0;
+}
+static int prefix_body(ptta_ctx* c, const float* image, const float* sparse, hipStream_t s) {
+    RUN(ptta_launch_prep(sparse, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
+    RUN(rgb_encoder(c, image, c->Nn, 0, c->Nn, s));
+    RUN(enc1_head_fn(c, s));
+    return stage1_independent(c, 2 * c->Nn, s);
+}
+template <class F>
+static int pipe_capture(ptta_ctx* c, hipGraph_t* g_out, hipGraphExec_t* e_out, F body) {
+    if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = body(c->cap_stream);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(c->cap_stream, &g);
+    if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) return c->fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e), -100 - (int)e);
+    *g_out = g;
+    HIPCHK(hipGraphInstantiate(e_out, g, nullptr, nullptr, 0));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// One TTA step on (image, sparse) AND, beside it, the parameter-independent prefix of the NEXT frame (next_image, next_sparse; NULL: none).
+// Same results as ptta_step call by call.  The frame passed as `next` must be the frame of the following call (same device pointers:
+// that is how the prepared prefix is recognised; otherwise the prefix is simply recomputed) and its buffers must stay unchanged until then.
+int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
+                        const float* next_image, const float* next_sparse, float* depth_out, float* loss_info_out, ptta_stream s_) {
+    if (!c || !image || !sparse) return -1;
+    if (c->nl || !c->use_graph || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive)
+        return ptta_step(c, image, loss_image, sparse, validity, depth_out, loss_info_out, s_);
+    hipStream_t s = (hipStream_t)s_;
+    if (!loss_image) loss_image = image;
+    RUN(pipe_init(c));
+    c->pipe_active = true;
+    const size_t ibytes = (size_t)c->N * 3 * c->H * c->W * 4, pbytes = (size_t)c->N * c->H * c->W * 4;
+    const int p = c->pipe_cur, q = 1 - p;
+    const int key = (validity ? 2 : 0) | (loss_image != image ? 1 : 0);
+    HIPCHK(hipEventRecord(c->ev_entry, s));                   // what the caller queued before this call (the next frame's data, too)
+    pipe_use(c, p);
+    if (!c->proxy_rgb_valid) RUN(ensure_proxy_rgb(c, c->in_image, s));
+    RUN(ensure_adam_table(c, s));
+    ptta_ctx::PreSet& P = c->pset[p];
+    if (P.prepared && P.prep_image == image && P.prep_sparse == sparse) {
+        HIPCHK(hipStreamWaitEvent(s, c->ev_prefix[p], 0));
+    } else {                                                  // first call, or the caller did not announce this frame: prefix in line
+        HIPCHK(hipStreamSynchronize(c->pre_stream));          // (a prefix of another frame may still be writing this set)
+        HIPCHK(hipMemcpyAsync(c->in_image, image, ibytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(c->in_sparse, sparse, pbytes, hipMemcpyDeviceToDevice, s));
+        if (!c->pexec[p]) RUN(pipe_capture(c, &c->pgraph[p], &c->pexec[p], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));
+        HIPCHK(hipGraphLaunch(c->pexec[p], s));
+    }
+    P.prepared = false;
+    if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
+    if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
+    if (!c->rexec[key][p]) {
+        c->skip_prefix = true;
+        const int rc = pipe_capture(c, &c->rgraph[key][p], &c->rexec[key][p], [&](hipStream_t cs) {
+            return step_body(c, c->in_image, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse, (key & 2) ? c->in_validity : nullptr, (ptta_stream)cs);
+        });
+        c->skip_prefix = false;
+        if (rc) return rc;
+    }
+    HIPCHK(hipGraphLaunch(c->rexec[key][p], s));
+    HIPCHK(hipEventRecord(c->ev_rest[p], s));
+    P.rest_recorded = true; c->pipe_last = p;
+    if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->ev_replay, s));
+    c->fwd_valid = true;
+    if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
+    if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
+    if (next_image && next_sparse) {
+        // the next frame's prefix into the other set, on its own stream: after the caller's data is there and after the step that last read
+        // that set (two calls ago) is done with it
+        pipe_use(c, q);
+        ptta_ctx::PreSet& Q = c->pset[q];
+        hipStream_t ps = c->pre_stream;
+        HIPCHK(hipStreamWaitEvent(ps, c->ev_entry, 0));
+        if (Q.rest_recorded) HIPCHK(hipStreamWaitEvent(ps, c->ev_rest[q], 0));
+        if (!c->proxy_rgb_valid) { HIPCHK(hipStreamSynchronize(ps)); RUN(ensure_proxy_rgb(c, c->in_image, s)); HIPCHK(hipStreamSynchronize(s)); }   // once per set
+        HIPCHK(hipMemcpyAsync(c->in_image, next_image, ibytes, hipMemcpyDeviceToDevice, ps));
+        HIPCHK(hipMemcpyAsync(c->in_sparse, next_sparse, pbytes, hipMemcpyDeviceToDevice, ps));
+        if (!c->pexec[q]) RUN(pipe_capture(c, &c->pgraph[q], &c->pexec[q], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));
+        HIPCHK(hipGraphLaunch(c->pexec[q], ps));
+        HIPCHK(hipEventRecord(c->ev_prefix[q], ps));
+        Q.prepared = true; Q.prep_image = next_image; Q.prep_sparse = next_sparse;
+        c->pipe_cur = q;
+        pipe_use(c, p);                                       // the members point at the frame just processed (what final_depth etc. read)
+    }
     return 0;
 }
 

@@ -229,13 +229,23 @@ class Engine:
     def adam_step(self, gw=None, gb=None):
         self._chk(self.lib.ptta_adam_step(self.handle, ptr(gw), ptr(gb), _stream()), 'ptta_adam_step')
 
-    def step(self, image, sparse, validity=None, loss_image=None, want_depth=False):
+    def step(self, image, sparse, validity=None, loss_image=None, want_depth=False, next_frame=None):
         """forward + loss + backward + Adam in one enqueue (src/tta_main.py:610-633).
-        Returns (loss_info[4] device tensor, depth or None)."""
+        Returns (loss_info[4] device tensor, depth or None).
+        next_frame = (image, sparse) of the frame the NEXT call will pass (the same tensors, kept alive and unchanged until then): the part of
+        its forward upstream of the adapted layer then runs beside this step (ptta_step_pipelined, include/ptta.h); same results."""
         image = self._f32(image, (self.n, 3, self.h, self.w))
         sparse = self._f32(sparse, (self.n, 1, self.h, self.w))
         info = torch.empty(4, device=image.device, dtype=torch.float32)
         depth = torch.empty((self.n, 1, self.h, self.w), device=image.device, dtype=torch.float32) if want_depth else None
+        if next_frame is not None:
+            nimg = self._f32(next_frame[0], (self.n, 3, self.h, self.w))
+            nsp = self._f32(next_frame[1], (self.n, 1, self.h, self.w))
+            self._keep['next_frame'] = (nimg, nsp, image, sparse)
+            self._chk(self.lib.ptta_step_pipelined(self.handle, ptr(image), ptr(None if loss_image is None else loss_image.contiguous()),
+                                                   ptr(sparse), ptr(None if validity is None else validity.contiguous()),
+                                                   ptr(nimg), ptr(nsp), ptr(depth), ptr(info), _stream()), 'ptta_step_pipelined')
+            return info, depth
         self._chk(self.lib.ptta_step(self.handle, ptr(image), ptr(None if loss_image is None else loss_image.contiguous()),
                                      ptr(sparse), ptr(None if validity is None else validity.contiguous()),
                                      ptr(depth), ptr(info), _stream()), 'ptta_step')

@@ -295,6 +295,10 @@ def test_pipelined_steps_equal_plain_steps():
                 nxt = None if mode == 'plain' else frames[6]               # announce the WRONG frame once: step 4 recomputes its prefix
             if i == 5 and mode == 'pipelined':
                 nxt = None                                                   # a plain ptta_step in the middle of the stream
+            if i == 0 and mode == 'pipelined':                               # two steps on the same frame (inner_iter 2): the prefix is reused
+                eng.step(frames[0][0], frames[0][1], next_frame=frames[0])
+            elif i == 0:
+                eng.step(frames[0][0], frames[0][1])
             info, depth = eng.step(frames[i][0], frames[i][1], want_depth=True, next_frame=nxt)
             ev = eng.forward_eval(frames[i][0], frames[i][1]) if i in (1, 2) else None     # the scored forward between two steps
             rec.append((info.clone(), depth.clone(), None if ev is None else ev.clone(), {k: v[0].clone() for k, v in adapted.items()}))

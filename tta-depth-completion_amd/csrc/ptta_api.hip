@@ -1636,7 +1636,11 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     c->fwd_valid = true;
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
     if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
-    if (next_image && next_sparse) {
+    if (next_image == image && next_sparse == sparse) {
+        // another step on the SAME frame (inner_iter > 1): its prefix is the one just used -- nothing in the step writes those tensors
+        HIPCHK(hipEventRecord(c->ev_prefix[p], s));
+        P.prepared = true; P.prep_image = image; P.prep_sparse = sparse;
+    } else if (next_image && next_sparse) {
         // the next frame's prefix into the other set, on its own stream: after the caller's data is there and after the step that last read
         // that set (two calls ago) is done with it
         pipe_use(c, q);

@@ -451,10 +451,14 @@ class MsgChnModel_Adapt(object):
         with torch.no_grad():
             return self._timed(lambda: self._engine(image).forward_eval(image, sparse_depth), loss_type)
 
-    def step(self, image, sparse_depth, validity_map=None, loss_image=None, want_depth=False):
+    def step(self, image, sparse_depth, validity_map=None, loss_image=None, want_depth=False, next_frame=None):
+        """The fused step.  next_frame = (image, sparse_depth) of the frame the NEXT call will pass (the data loader's look-ahead): the part of
+        its forward upstream of the adapted layer then runs beside this step (Engine.step / ptta_step_pipelined); same results."""
         eng = self._engine(image)
         self._sync_adam_step(eng)
-        info, depth = eng.step(image, sparse_depth, validity_map, loss_image, want_depth)
+        if next_frame is not None and (getattr(eng, 'backbone', 'msg_chn') != 'msg_chn' or tuple(next_frame[0].shape) != tuple(image.shape)):
+            next_frame = None                       # other backbones have nothing upstream of their adapted layers; a new shape is a new engine
+        info, depth = eng.step(image, sparse_depth, validity_map, loss_image, want_depth, **({'next_frame': next_frame} if next_frame is not None else {}))
         self._adam_t += 1
         eng._t = self._adam_t
         opt = getattr(self, '_optimizer', None)
@@ -560,16 +564,22 @@ class ExternalModel_Adapt(object):
     def set_image_norm(self, normalized_image_range):
         self.model.set_image_norm(normalized_image_range)
 
-    def step(self, image, sparse_depth, validity_map=None, loss_image=None, want_depth=False):
-        """One TTA step (src/tta_main.py:610-633) in one library call; returns (loss_info[4], depth)."""
+    def step(self, image, sparse_depth, validity_map=None, loss_image=None, want_depth=False, next_frame=None):
+        """One TTA step (src/tta_main.py:610-633) in one library call; returns (loss_info[4], depth).  next_frame: see the adapter's step."""
+        if next_frame is not None and isinstance(self.model, MsgChnModel_Adapt) and type(self.model) is MsgChnModel_Adapt:
+            return self.model.step(image, sparse_depth, validity_map, loss_image, want_depth, next_frame=next_frame)
         return self.model.step(image, sparse_depth, validity_map, loss_image, want_depth)
 
-    def adapt(self, image, sparse_depth, inner_iter=1, validity_map=None, loss_image=None):
+    def adapt(self, image, sparse_depth, inner_iter=1, validity_map=None, loss_image=None, next_frame=None):
         """Per-frame adaptation = inner_iter steps then the scored eval forward
-        (src/tta_main.py:579-636 and :729-736).  Returns (depth, loss_info of the last step)."""
+        (src/tta_main.py:579-636 and :729-736).  Returns (depth, loss_info of the last step).
+        next_frame = (image, sparse_depth) the next call will pass: announced to the LAST step of this frame (frame pipelining)."""
         info = None
         self.model.train()
-        for _ in range(inner_iter):
+        for it in range(inner_iter):
+            if it == inner_iter - 1 and next_frame is not None:
+                info, _ = self.step(image, sparse_depth, validity_map, loss_image, next_frame=next_frame)
+                continue
             info, _ = self.model.step(image, sparse_depth, validity_map, loss_image)
         self.model.eval()
         depth = self.model.forward(image, sparse_depth, loss_type=CANONICAL_LOSS_TYPE)

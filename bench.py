@@ -545,7 +545,8 @@ def main():
             for i in range(count):
                 st.submit(*host_frames[(i + 1) % nframes])
                 im, sp = st.acquire()
-                eng.step(im, sp)
+                # frame pipelining on top of the staging: the next slot's H2D copy is ordered on the library's prefix stream
+                eng.step(im, sp, next_frame=st.peek_next(eng.prefix_stream()) if pipe else None)
                 st.release()
         torch.cuda.synchronize()
         host_elapsed = time.perf_counter() - th

@@ -157,6 +157,9 @@ int ptta_adapted_repeat(ptta_handle h, int index);
  * frame from the data loader (src/tta_main.py:519-523).  ptta_forward_eval / ptta_forward_train between two calls are fine. */
 int ptta_step_pipelined(ptta_handle h, const float* image, const float* loss_image, const float* sparse_depth, const float* validity_map,
                         const float* next_image, const float* next_sparse_depth, float* depth_out, float* loss_info_out, ptta_stream s);
+/* The stream the next frame's prefix runs on: when that frame is still arriving (an asynchronous H2D copy), make THIS stream wait for the
+ * copy's event before the call that announces the frame -- not the caller's stream, which would delay the current step. */
+int ptta_pipeline_stream(ptta_handle h, ptta_stream* stream_out);
 
 /* optimizer.step() for the bound parameters with explicit gradients (src/tta_main.py:633). */
 int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* grad_meta_bias, ptta_stream s);

@@ -264,7 +264,9 @@ def test_staged_sequence_equals_resident_sequence():
                 if k + 1 < 5:
                     st.submit(*frames[k + 1])
                 im, sd = st.acquire()
-                infos.append(eng.step(im, sd)[0])
+                # 'pipelined': the next slot (its copy still in flight) is announced, ordered on the library's prefix stream
+                nxt = st.peek_next(eng.prefix_stream()) if staged == 'pipelined' else None
+                infos.append(eng.step(im, sd, next_frame=nxt)[0])
                 st.release()
         else:
             for k in range(5):
@@ -272,10 +274,11 @@ def test_staged_sequence_equals_resident_sequence():
         torch.cuda.synchronize()
         return torch.stack(infos).cpu(), {k: v[0].detach().cpu().clone() for k, v in adapted.items()}
     ia, pa = run(False)
-    ib, pb = run(True)
-    assert torch.equal(ia, ib)
-    for k in pa:
-        assert torch.equal(pa[k], pb[k]), k
+    for mode in (True, 'pipelined'):
+        ib, pb = run(mode)
+        assert torch.equal(ia, ib), mode
+        for k in pa:
+            assert torch.equal(pa[k], pb[k]), (mode, k)
 
 
 def test_pipelined_steps_equal_plain_steps():

@@ -1588,6 +1588,16 @@ static int pipe_capture(ptta_ctx* c, hipGraph_t* g_out, hipGraphExec_t* e_out, F
 
 extern "C" {
 
+// The stream ptta_step_pipelined runs the next frame's prefix on (created on first use): a host that produces that frame asynchronously
+// (an H2D copy on its own stream) orders the copy's event on THIS stream instead of delaying the current frame's step with it.
+int ptta_pipeline_stream(ptta_handle c, ptta_stream* out) {
+    if (!c || !out) return -1;
+    if (c->nl) return c->fail("frame pipelining is built for MSG_CHN handles", -38);
+    RUN(pipe_init(c));
+    *out = (ptta_stream)c->pre_stream;
+    return 0;
+}
+
 // One TTA step on (image, sparse) AND, beside it, the parameter-independent prefix of the NEXT frame (next_image, next_sparse; NULL: none).
 // Same results as ptta_step call by call.  The frame passed as `next` must be the frame of the following call (same device pointers:
 // that is how the prepared prefix is recognised; otherwise the prefix is simply recomputed) and its buffers must stay unchanged until then.

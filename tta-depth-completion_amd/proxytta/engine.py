@@ -251,6 +251,15 @@ class Engine:
                                      ptr(depth), ptr(info), _stream()), 'ptta_step')
         return info, depth
 
+    def prefix_stream(self):
+        """torch view of the stream the next frame's prefix runs on (ptta_pipeline_stream): order an asynchronous producer of that frame
+        (FrameStager's H2D copy) on it with `.wait_event(...)` before the step call that announces the frame."""
+        if getattr(self, '_prefix_stream', None) is None:
+            sp = c_void_p()
+            self._chk(self.lib.ptta_pipeline_stream(self.handle, byref(sp)), 'ptta_pipeline_stream')
+            self._prefix_stream = torch.cuda.ExternalStream(sp.value, device=self.device)
+        return self._prefix_stream
+
     def set_image_norm(self, normalized_image_range):
         """Fuse Transforms.normalize_images (src/transforms.py:668-710) into the first convolution: the
         engine then takes RAW images.  Accepts the reference's `normalized_image_range` values: [0, 1],

@@ -74,6 +74,15 @@ class FrameStager:
         self.held = True
         return self.dev[k]
 
+    def peek_next(self, stream=None):
+        """Device tensors of the frame AFTER the acquired one (already submitted; None otherwise) for frame pipelining
+        (Engine.step(..., next_frame=...)).  No host wait: `stream` (the engine's prefix_stream()) is made to wait for that slot's copy."""
+        if not self.held or self.tail + 1 >= self.head:
+            return None
+        k = (self.tail + 1) % self.slots
+        (torch.cuda.current_stream() if stream is None else stream).wait_event(self.ready[k])
+        return self.dev[k]
+
     def release(self):
         """Mark the acquired slot reusable once everything enqueued so far on the current stream has run."""
         if not self.held:

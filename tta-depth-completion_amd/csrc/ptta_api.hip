@@ -1604,7 +1604,7 @@ int ptta_pipeline_stream(ptta_handle c, ptta_stream* out) {
 int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
                         const float* next_image, const float* next_sparse, float* depth_out, float* loss_info_out, ptta_stream s_) {
     if (!c || !image || !sparse) return -1;
-    if (c->nl || !c->use_graph || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive)
+    if (c->nl || !c->use_graph || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16 || c->split_fwd)
         return ptta_step(c, image, loss_image, sparse, validity, depth_out, loss_info_out, s_);
     hipStream_t s = (hipStream_t)s_;
     if (!loss_image) loss_image = image;

@@ -77,15 +77,16 @@ def msgchn_2layers_workload(steps=30):
     for name in eng.adapted:
         eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(i, H, W, 1)] for i in range(4)]
+    pipe = os.environ.get('PTTA_PIPELINE', '1') != '0'           # frames as a stream, like the headline loop
     for i in range(5):
-        eng.step(*frames[i % 4])
+        eng.step(*frames[i % 4], next_frame=frames[(i + 1) % 4] if pipe else None)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        info, _ = eng.step(*frames[i % 4])
+        info, _ = eng.step(*frames[(5 + i) % 4], next_frame=frames[(6 + i) % 4] if pipe else None)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    out = {'workload': 'MSG_CHN 2layers meta (Res_Conv(32,128), 7 adapted tensors), 352x1216, 1 TTA step/frame, batch 1',
+    out = {'workload': 'MSG_CHN 2layers meta (Res_Conv(32,128), 7 adapted tensors), 352x1216, 1 TTA step/frame, batch 1, frame pipelining ' + ('on' if pipe else 'off'),
            'ms_per_step': 1e3 * dt, 'frames_per_s': 1.0 / dt, 'finite': bool(torch.isfinite(info).all().item())}
     eng.close()
     return out

@@ -281,7 +281,8 @@ def test_staged_sequence_equals_resident_sequence():
             assert torch.equal(pa[k], pb[k]), (mode, k)
 
 
-def test_pipelined_steps_equal_plain_steps():
+@pytest.mark.parametrize('meta', ['1layer', '2layers'])
+def test_pipelined_steps_equal_plain_steps(meta):
     """ptta_step_pipelined: the parameter-independent prefix of frame k+1 (sparse-depth pooling, frozen RGB encoder, depth-only head of the
     stage-1 encoder) runs on its own stream beside the step of frame k.  Same parameters, losses and depths as ptta_step, call by call --
     also with an eval forward between two calls, an unannounced frame (prefix recomputed in line) and a plain step in the middle."""
@@ -290,7 +291,7 @@ def test_pipelined_steps_equal_plain_steps():
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(20 + i, h, w, n)] for i in range(7)]
     out = {}
     for mode in ('plain', 'pipelined'):
-        eng, sd, adapted = make_engine(n, h, w, 'fp32', dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0))
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0), meta=meta)
         rec = []
         for i in range(6):
             nxt = frames[i + 1] if mode == 'pipelined' else None

@@ -92,6 +92,37 @@ def msgchn_2layers_workload(steps=30):
     return out
 
 
+def msgchn_adapt_loop_workload(frames_n=60):
+    """The per-frame loop of the reference (src/tta_main.py:579-636 + :729-736): ONE TTA step, then the scored eval forward of the same frame,
+    frames fed as a stream (frame pipelining; the eval forward reuses the adapted frame's prefix).  Reported beside the metric."""
+    from proxytta import synth
+    from proxytta.engine import ADAPTED, Engine
+    eng = Engine(1, H, W, **HP)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict('meta_selfsup_seq_1layer_ema').items()}
+    eng.load_state_dict(sd)
+    for name in ADAPTED:
+        eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(i, H, W, 1)] for i in range(4)]
+    out = {'workload': 'MSG_CHN 1layer, 352x1216, per frame: 1 TTA step + the scored eval forward, batch 1'}
+    for mode in ('pipelined', 'call_by_call'):
+        for phase, count in (('warm', 5), ('timed', frames_n)):
+            if phase == 'timed':
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            for i in range(count):
+                if mode == 'pipelined':
+                    eng.step(*frames[i % 4], next_frame=frames[(i + 1) % 4])
+                    d = eng.forward_eval_last()
+                else:
+                    eng.step(*frames[i % 4])
+                    d = eng.forward_eval(*frames[i % 4])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / frames_n
+        out[mode] = {'ms_per_frame': 1e3 * dt, 'frames_per_s': 1.0 / dt, 'finite': bool(torch.isfinite(d).all().item())}
+    eng.close()
+    return out
+
+
 def nlspn_macs(h, w, n=1):
     """Multiply-accumulates of one NLSPN TTA step from the architecture (nlspnmodel_adapt.py:385-452, ResNet34
     BasicBlocks :70-116): (training forward incl. the proxy pass and the heads, eval forward, minimal backward).
@@ -630,7 +661,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_nlspn:
             out['other_workloads'] = {'msg_chn_2layers': msgchn_2layers_workload(), 'nlspn': nlspn_workload(), 'costdcnet': costdcnet_workload(),
-                                      'head_stage2': head_stage2_workload(), 'msg_chn_two_streams_per_gpu': two_streams_workload()}
+                                      'head_stage2': head_stage2_workload(), 'msg_chn_two_streams_per_gpu': two_streams_workload(),
+                                      'msg_chn_step_plus_scored_eval': msgchn_adapt_loop_workload()}
             if not args.no_cpu_baseline:
                 out['other_workloads']['nlspn']['cpu_baseline'] = nlspn_cpu_baseline()
                 out['other_workloads']['costdcnet']['cpu_baseline'] = costdcnet_cpu_baseline()

@@ -160,6 +160,9 @@ int ptta_step_pipelined(ptta_handle h, const float* image, const float* loss_ima
 /* The stream the next frame's prefix runs on: when that frame is still arriving (an asynchronous H2D copy), make THIS stream wait for the
  * copy's event before the call that announces the frame -- not the caller's stream, which would delay the current step. */
 int ptta_pipeline_stream(ptta_handle h, ptta_stream* stream_out);
+/* The scored eval forward (src/tta_main.py:729-736) of the frame the last ptta_step_pipelined call adapted, without recomputing that
+ * frame's parameter-independent prefix (it is still in the handle).  -3 when no such frame is held (e.g. after ptta_load_weights). */
+int ptta_forward_eval_last(ptta_handle h, float* depth_out, ptta_stream s);
 
 /* optimizer.step() for the bound parameters with explicit gradients (src/tta_main.py:633). */
 int ptta_adam_step(ptta_handle h, const float* grad_meta_weight, const float* grad_meta_bias, ptta_stream s);

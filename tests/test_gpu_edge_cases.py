@@ -233,3 +233,31 @@ def test_get_time_hook():
     model.forward(image, sparse, loss_type=CANONICAL_LOSS_TYPE)           # not timed
     total, train, evalt = model.forward(image, sparse, loss_type='get_time')
     assert train > 0 and evalt > 0 and abs(total - train - evalt) < 1e-9
+
+
+def test_adapt_loop_with_look_ahead_equals_the_plain_loop():
+    """ExternalModel_Adapt.adapt (one TTA step + the scored eval forward per frame, src/tta_main.py:579-636, :729-736) with the data loader's
+    look-ahead frame announced: same depths and parameters as without it, also across a shape change (new engine: no pipelining there)."""
+    from proxytta.model import ExternalModel_Adapt
+    shapes = [(1, 32, 48), (1, 32, 48), (1, 32, 48), (1, 48, 64), (1, 48, 64)]
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(70 + i, h, w, n)] for i, (n, h, w) in enumerate(shapes)]
+    out = {}
+    for ahead in (False, True):
+        model = ExternalModel_Adapt('msg_chn', 0.0, 80.0, max_input_depth=80.0, device=torch.device('cuda'))
+        model._prepare_head(ONE)
+        model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.formula_state_dict(ONE).items()})
+        params = model.adapt_parameters(mode='meta')
+        opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        model.model.set_hparams(w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1)
+        model.model.bind_optimizer(opt)
+        rec = []
+        for i, (image, sparse) in enumerate(frames):
+            nxt = frames[i + 1] if (ahead and i + 1 < len(frames)) else None
+            depth, info = model.adapt(image, sparse, inner_iter=1, next_frame=nxt)
+            rec.append((depth.clone(), info.clone(), [p.detach().clone() for p in params]))
+        torch.cuda.synchronize()
+        out[ahead] = rec
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for pa, pb in zip(a[2], b[2]):
+            assert torch.equal(pa, pb)

@@ -304,7 +304,9 @@ def test_pipelined_steps_equal_plain_steps(meta):
             elif i == 0:
                 eng.step(frames[0][0], frames[0][1])
             info, depth = eng.step(frames[i][0], frames[i][1], want_depth=True, next_frame=nxt)
+            evl = eng.forward_eval_last() if (i == 2 and mode == 'pipelined') else None   # the scored forward from the adapted frame's own prefix
             ev = eng.forward_eval(frames[i][0], frames[i][1]) if i in (1, 2) else None     # the scored forward between two steps
+            assert evl is None or torch.equal(evl, ev)
             rec.append((info.clone(), depth.clone(), None if ev is None else ev.clone(), {k: v[0].clone() for k, v in adapted.items()}))
         torch.cuda.synchronize()
         out[mode] = rec

@@ -116,7 +116,8 @@ struct ptta_ctx {
         void *e1_1 = nullptr, *y1 = nullptr, *e1_2a = nullptr, *y2 = nullptr, *t1 = nullptr, *y3 = nullptr, *s1_1 = nullptr, *u1 = nullptr;
         float *dclamp = nullptr, *d12 = nullptr, *d14 = nullptr, *in_image = nullptr, *in_loss_image = nullptr, *in_sparse = nullptr, *in_validity = nullptr;
         bool proxy_valid = false, prepared = false, rest_recorded = false;
-        const float *prep_image = nullptr, *prep_sparse = nullptr;
+        const float *prep_image = nullptr, *prep_sparse = nullptr;      // the frame whose prefix has been started into this set
+        const float *last_image = nullptr, *last_sparse = nullptr;      // the frame whose step last ran from this set (prefix still valid)
     };
     PreSet pset[2];
     int cur_set = 0, pipe_cur = 0, pipe_last = 0;        // set in the members now / of the next pipelined frame / of the last processed frame
@@ -158,7 +159,7 @@ struct ptta_ctx {
         for (int p = 0; p < 2; ++p) {
             if (pexec[p]) { (void)hipGraphExecDestroy(pexec[p]); pexec[p] = nullptr; }
             if (pgraph[p]) { (void)hipGraphDestroy(pgraph[p]); pgraph[p] = nullptr; }
-            pset[p].prepared = false;
+            pset[p].prepared = false; pset[p].last_image = pset[p].last_sparse = nullptr;
         }
     }
 
@@ -1361,6 +1362,23 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
     return 0;
 }
 
+// The scored forward (src/tta_main.py:729-736) of the frame the last ptta_step_pipelined call adapted: the parameter-independent prefix of
+// that frame is still in its buffer set (nothing in the step writes those tensors), so only the part downstream of the adapted layer runs.
+int ptta_forward_eval_last(ptta_handle c, float* depth_out, ptta_stream s_) {
+    if (!c || !depth_out) return -1;
+    if (c->nl) return c->fail("ptta_forward_eval_last follows ptta_step_pipelined (MSG_CHN handles)", -38);
+    if (!c->pipe_active || !c->pset[c->pipe_last].last_image) return c->fail("ptta_forward_eval_last: no frame adapted by ptta_step_pipelined since the last reset", -3);
+    hipStream_t s = (hipStream_t)s_;
+    pipe_use(c, c->pipe_last);
+    c->fwd_valid = false; c->head.fwd_ok = false;
+    c->skip_prefix = true;
+    const int rc = forward_common(c, c->in_image, c->in_sparse, false, s);
+    c->skip_prefix = false;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 int ptta_loss_forward(ptta_handle c, const float* loss_image, const float* depth, const float* sparse, const float* validity,
                       const float* emb, const float* ref, int64_t rows, float w_sd, float w_sm, float w_cos,
                       float* loss_info_out, ptta_stream s_) {
@@ -1559,7 +1577,7 @@ static int pipe_init(ptta_ctx* c) {
 static int pipe_quiesce(ptta_ctx* c) {
     if (!c->pipe_active) return 0;
     HIPCHK(hipStreamSynchronize(c->pre_stream));
-    for (int p = 0; p < 2; ++p) c->pset[p].prepared = false;
+    for (int p = 0; p < 2; ++p) { c->pset[p].prepared = false; c->pset[p].last_image = c->pset[p].last_sparse = nullptr; }
     pipe_use(c, 0);
     c->pipe_cur = 0; c->pipe_last = 0; c->pipe_active = false;
     return 0;
@@ -1640,7 +1658,7 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     }
     HIPCHK(hipGraphLaunch(c->rexec[key][p], s));
     HIPCHK(hipEventRecord(c->ev_rest[p], s));
-    P.rest_recorded = true; c->pipe_last = p;
+    P.rest_recorded = true; c->pipe_last = p; P.last_image = image; P.last_sparse = sparse;
     if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));
     HIPCHK(hipEventRecord(c->ev_replay, s));
     c->fwd_valid = true;
@@ -1664,7 +1682,7 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         if (!c->pexec[q]) RUN(pipe_capture(c, &c->pgraph[q], &c->pexec[q], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));
         HIPCHK(hipGraphLaunch(c->pexec[q], ps));
         HIPCHK(hipEventRecord(c->ev_prefix[q], ps));
-        Q.prepared = true; Q.prep_image = next_image; Q.prep_sparse = next_sparse;
+        Q.prepared = true; Q.prep_image = next_image; Q.prep_sparse = next_sparse; Q.last_image = Q.last_sparse = nullptr;
         c->pipe_cur = q;
         pipe_use(c, p);                                       // the members point at the frame just processed (what final_depth etc. read)
     }

@@ -55,6 +55,7 @@ SIGNATURES = [
     ('ptta_step', c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     ('ptta_step_pipelined', c_int, [_P] * 10),
     ('ptta_pipeline_stream', c_int, [_P, POINTER(c_void_p)]),
+    ('ptta_forward_eval_last', c_int, [_P, _P, _P]),
     ('ptta_outlier_removal', c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
     ('ptta_eval_metrics', c_int, [_P, _P, c_int64, c_float, c_float, _P, _P, _P]),
     ('ptta_mdconv_forward', c_int, [_P] * 6 + [c_int] * 15 + [_P]),

@@ -251,6 +251,13 @@ class Engine:
                                      ptr(depth), ptr(info), _stream()), 'ptta_step')
         return info, depth
 
+    def forward_eval_last(self):
+        """The scored eval forward of the frame the last step(..., next_frame=...) call adapted, reusing that frame's parameter-independent
+        prefix (ptta_forward_eval_last)."""
+        depth = torch.empty((self.n, 1, self.h, self.w), device=self.device, dtype=torch.float32)
+        self._chk(self.lib.ptta_forward_eval_last(self.handle, ptr(depth), _stream()), 'ptta_forward_eval_last')
+        return depth
+
     def prefix_stream(self):
         """torch view of the stream the next frame's prefix runs on (ptta_pipeline_stream): order an asynchronous producer of that frame
         (FrameStager's H2D copy) on it with `.wait_event(...)` before the step call that announces the frame."""

@@ -471,6 +471,11 @@ class MsgChnModel_Adapt(object):
         return info, depth
 
 
+def eng_is_padded(eng):
+    """Frame sizes not divisible by 16 run the dual-corner padding and the plain step (no pipelining state to reuse)."""
+    return (eng.h % 16) != 0 or (eng.w % 16) != 0
+
+
 class ExternalModel_Adapt(object):
     """Counterpart of src/external_model_adapt.py:29 (model_name 'msg_chn', 'nlspn', 'costdcnet')."""
 
@@ -576,12 +581,18 @@ class ExternalModel_Adapt(object):
         next_frame = (image, sparse_depth) the next call will pass: announced to the LAST step of this frame (frame pipelining)."""
         info = None
         self.model.train()
+        piped = False
         for it in range(inner_iter):
             if it == inner_iter - 1 and next_frame is not None:
                 info, _ = self.step(image, sparse_depth, validity_map, loss_image, next_frame=next_frame)
+                piped = type(self.model) is MsgChnModel_Adapt and tuple(next_frame[0].shape) == tuple(image.shape)
                 continue
             info, _ = self.model.step(image, sparse_depth, validity_map, loss_image)
         self.model.eval()
+        if piped:                    # the scored forward from the adapted frame's own prefix (ptta_forward_eval_last)
+            eng = self.model._engine(image)
+            if getattr(eng.lib, 'ptta_forward_eval_last', None) is not None and not eng_is_padded(eng):
+                return eng.forward_eval_last(), info
         depth = self.model.forward(image, sparse_depth, loss_type=CANONICAL_LOSS_TYPE)
         return depth, info
 

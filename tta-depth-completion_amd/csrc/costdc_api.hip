@@ -43,6 +43,15 @@ struct costdc_engine : GNet {
     std::map<std::string, std::pair<int, int>> sbn_ad;
     float* sgrad[4] = {nullptr, nullptr, nullptr, nullptr};
     float* sp_bw = nullptr;
+    // The sparse encoder needs only the clamped sparse depth: it runs on a stream of its own BESIDE Encoder2D (its launches are small and
+    // latency-bound, Encoder2D's are the step's largest) and joins at the fusion.  Not under SyncBatchNorm: the ranks must issue their
+    // exchanges in one order.  PTTA_SPARSE_ASYNC=0 keeps it in line (A/B).
+    hipStream_t sp_stream = nullptr;
+    hipEvent_t ev_sp_fork = nullptr, ev_sp_done = nullptr;
+    bool sp_async = true, sp_inflight = false;
+    ~costdc_engine() {
+        if (sp_stream) { (void)hipStreamSynchronize(sp_stream); (void)hipStreamDestroy(sp_stream); (void)hipEventDestroy(ev_sp_fork); (void)hipEventDestroy(ev_sp_done); }
+    }
     std::map<std::string, SConv> sconv;
     std::map<std::string, SBn> sbn;
 
@@ -349,8 +358,8 @@ struct costdc_engine : GNet {
         return 0;
     }
     int fusion_fwd(bool train, hipStream_t s) {
-        const int rc = sparse_encoder(train, s);
-        if (rc) return rc;
+        if (sp_inflight) { NCHK(hipStreamWaitEvent(s, ev_sp_done, 0)); sp_inflight = false; }
+        else { const int rc = sparse_encoder(train, s); if (rc) return rc; }
         return cd_launch_fusion_fwd(T[t_feat2d].p, feat3d, T[t_vol].p, maskw, N, train ? 2 : 1, h4, w4, s) ? fail("fusion failed", -5) : 0;
     }
     int regress_fwd(hipStream_t s) {
@@ -422,6 +431,20 @@ struct costdc_engine : GNet {
         // before it pads, so padded pixels must stay zero: normalisation is applied to the caller's frame region only
         if (cd_launch_clamp(spp, sp_clamp, (long)N * H * W, hp.max_input_depth, s)) return fail("clamp failed", -5);
         if (cd_launch_stage(img, sp_clamp, T[t_in].p, N, train ? 2 : 1, H, W, T[t_in].C, dual ? 0 : norm_on, norm_div, norm_mean, norm_std, s)) return fail("input staging failed", -5);
+        sp_inflight = false;
+        if (sp_async && !stat_sync.on()) {
+            if (!sp_stream) {
+                NCHK(hipStreamCreateWithFlags(&sp_stream, hipStreamNonBlocking));
+                NCHK(hipEventCreateWithFlags(&ev_sp_fork, hipEventDisableTiming));
+                NCHK(hipEventCreateWithFlags(&ev_sp_done, hipEventDisableTiming));
+            }
+            NCHK(hipEventRecord(ev_sp_fork, s));                      // the clamped sparse depth is ready
+            NCHK(hipStreamWaitEvent(sp_stream, ev_sp_fork, 0));
+            const int rcs = sparse_encoder(train, sp_stream);
+            if (rcs) return rcs;
+            NCHK(hipEventRecord(ev_sp_done, sp_stream));
+            sp_inflight = true;
+        }
         repack_adapted(s);
         const int rc = run_ops_fwd(train, s);
         if (rc) return rc;
@@ -455,6 +478,7 @@ GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth
     // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: PTTA_GRAPH=1 / ptta_set_graph(h, 1)
     { const char* gr = getenv("PTTA_GRAPH"); e->use_graph = (gr && strcmp(gr, "1") == 0) ? 1 : 0; }
     e->sync_adapt = (flags & 1) ? 1 : 0;
+    { const char* sa = getenv("PTTA_SPARSE_ASYNC"); e->sp_async = !(sa && strcmp(sa, "0") == 0); }
     e->build();
     if (e->oom || !e->step_dev) { delete e; *rc = -12; return nullptr; }
     if (e->upload_hparams(nullptr)) { delete e; *rc = -5; return nullptr; }

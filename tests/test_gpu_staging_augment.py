@@ -303,7 +303,9 @@ def test_pipelined_steps_equal_plain_steps(meta, n):
                 eng.step(frames[0][0], frames[0][1], next_frame=frames[0])
             elif i == 0:
                 eng.step(frames[0][0], frames[0][1])
-            info, depth = eng.step(frames[i][0], frames[i][1], want_depth=True, next_frame=nxt)
+            # steps 2 and 4 with an explicit validity map and a separate loss image (other graph keys, staged per buffer set)
+            extra = dict(validity=(frames[i][1] > 0).float(), loss_image=frames[i][0] * 0.5 + 0.1) if i in (2, 4) else {}
+            info, depth = eng.step(frames[i][0], frames[i][1], want_depth=True, next_frame=nxt, **extra)
             evl = eng.forward_eval_last() if (i == 2 and mode == 'pipelined') else None   # the scored forward from the adapted frame's own prefix
             ev = eng.forward_eval(frames[i][0], frames[i][1]) if i in (1, 2) else None     # the scored forward between two steps
             assert evl is None or torch.equal(evl, ev)

@@ -13,9 +13,12 @@
  *   - all work is enqueued on the hipStream_t argument (pass torch.cuda.current_stream()); nothing
  *     is allocated after ptta_create and no call on the path synchronises (host constants travel as
  *     kernel arguments).  The only calls that wait for the stream are the ones that RETURN a host
- *     value (ptta_get_adam_step, ptta_profile_read) and the ones that destroy a captured graph
+ *     value (ptta_get_adam_step, ptta_profile_read), the ones that destroy a captured graph
  *     (they wait for its last replay: ptta_load_weights, ptta_bind_adapted, ptta_set_image_norm,
- *     ptta_set_graph(0), a changed max_input_depth in ptta_set_hparams).
+ *     ptta_set_graph(0), a changed max_input_depth in ptta_set_hparams), ptta_step_pipelined when it
+ *     is handed a frame it was NOT told about by the previous call (it waits for its own prefix
+ *     stream once before computing that frame's prefix in line; an announced frame costs no wait),
+ *     and any other entry point called while a prefix is in flight (it waits for the prefix stream).
  *   - return value 0 = ok, <0 = error; ptta_last_error() returns a message.  Nothing is printed.
  *   - one handle per (process, GPU); a handle is not thread-safe.
  */
@@ -152,16 +155,26 @@ int ptta_adapted_repeat(ptta_handle h, int index);
  * of its own, the part of the NEXT frame's forward that does not depend on the adapted parameters -- clamp / pooling of the sparse depth, the
  * frozen RGB encoder, the depth-only head of the stage-1 encoder (everything upstream of conv1_rgb_meta) -- so that it runs beside this
  * frame's step instead of at the head of the next one.  Results are those of ptta_step, call by call (the prefix's outputs exist twice).
- * next_image / next_sparse: the frame the FOLLOWING call will pass (same device pointers -- that is how the prepared prefix is recognised;
- * a different frame just recomputes it), valid and unchanged until that call; NULL: nothing is prepared.  The reference's loop knows its next
- * frame from the data loader (src/tta_main.py:519-523).  ptta_forward_eval / ptta_forward_train between two calls are fine. */
+ * Frames are named by TOKENS the caller chooses: non-zero, and a NEW one whenever the frame CONTENT is new (a counter).  next_image /
+ * next_sparse / next_token: the frame the FOLLOWING call will pass as (image, sparse, frame_token); it is copied into the handle when it is
+ * announced, so the caller's buffers only have to hold it until this call's work on the prefix stream has run.  The prepared prefix is used
+ * iff the following call's frame_token equals the announced next_token -- never by pointer identity: refilling one staging buffer with another
+ * frame is safe as long as the new content gets a new token (tests/test_gpu_staging_augment.py).  next_token == frame_token: another step
+ * on the same frame (inner_iter > 1), its prefix is kept.  A token of 0 = unnamed: frame_token 0 never matches (prefix computed in line),
+ * next_token 0 / NULL pointers prepare nothing.  The reference's loop knows its next frame from the data loader (src/tta_main.py:519-523).
+ * ptta_forward_eval / ptta_forward_train between two calls are fine (they run in, and invalidate, the buffer set of the last processed frame).
+ * Host synchronisation: none when the frame was announced; an UNANNOUNCED frame (first call, token mismatch) waits for the prefix stream
+ * on the host once before computing its prefix in line. */
 int ptta_step_pipelined(ptta_handle h, const float* image, const float* loss_image, const float* sparse_depth, const float* validity_map,
-                        const float* next_image, const float* next_sparse_depth, float* depth_out, float* loss_info_out, ptta_stream s);
+                        uint64_t frame_token, const float* next_image, const float* next_sparse_depth, uint64_t next_token,
+                        float* depth_out, float* loss_info_out, ptta_stream s);
 /* The stream the next frame's prefix runs on: when that frame is still arriving (an asynchronous H2D copy), make THIS stream wait for the
  * copy's event before the call that announces the frame -- not the caller's stream, which would delay the current step. */
 int ptta_pipeline_stream(ptta_handle h, ptta_stream* stream_out);
 /* The scored eval forward (src/tta_main.py:729-736) of the frame the last ptta_step_pipelined call adapted, without recomputing that
- * frame's parameter-independent prefix (it is still in the handle).  -3 when no such frame is held (e.g. after ptta_load_weights). */
+ * frame's parameter-independent prefix (it is still in the handle).  When that call ran as a plain ptta_step (no graph replay, profiling,
+ * SyncBatchNorm / gradient exchange, padded sizes, bf16 storage) this is a full ptta_forward_eval of its frame, read from the caller's
+ * buffers of that call (which must still hold it).  -3 when no such frame is held (e.g. after ptta_load_weights or a ptta_forward_eval). */
 int ptta_forward_eval_last(ptta_handle h, float* depth_out, ptta_stream s);
 
 /* optimizer.step() for the bound parameters with explicit gradients (src/tta_main.py:633). */

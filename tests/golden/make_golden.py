@@ -63,7 +63,7 @@ def sample_rows(x, k=24):
     return idx, x[idx]
 
 
-def run_case(ema, name, prepare_mode, h, w, n, steps, w_cos=None, gain=1.0):
+def run_case(ema, name, prepare_mode, h, w, n, steps, w_cos=None, gain=1.0, head_bias=0.0):
     hp = dict(HP)
     if w_cos is not None:
         hp['w_cos'] = w_cos
@@ -71,7 +71,7 @@ def run_case(ema, name, prepare_mode, h, w, n, steps, w_cos=None, gain=1.0):
                                     device=torch.device('cpu'))
     model._prepare_head(prepare_mode)
     net = model.model.model
-    sd = synth.formula_state_dict(prepare_mode, gain)
+    sd = synth.formula_state_dict(prepare_mode, gain, head_bias)
     assert list(sd.keys()) == list(net.state_dict().keys()), 'key table drifted from reference'
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     params = model.adapt_parameters(mode='meta')
@@ -80,7 +80,8 @@ def run_case(ema, name, prepare_mode, h, w, n, steps, w_cos=None, gain=1.0):
     out = {'meta': np.array([h, w, n, steps], dtype=np.int64),
            'hp': np.array([hp['lr'], hp['betas'][0], hp['betas'][1], hp['eps'], hp['weight_decay'],
                            hp['w_sd'], hp['w_sm'], hp['w_cos'], hp['max_input_depth'], gain],
-                          dtype=np.float64)}
+                          dtype=np.float64),
+           'head_bias': np.array(head_bias, dtype=np.float64)}
     names = [k for k, _ in net.named_parameters() if 'meta' in k]
     for s in range(steps):
         image_np, sparse_np = synth.synthetic_frame(s, h, w, n)
@@ -172,6 +173,13 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     ema, net_utils = import_reference()
     one, two = 'meta_selfsup_seq_1layer_ema', 'meta_selfsup_seq_2layers_ema'
+    if len(sys.argv) > 1 and sys.argv[1] == 'gate':
+        # whole steps on both sides of the `loss_cos < 0.3` gate (src/external_model_adapt.py:424-425): the heads' output biases are one
+        # large common vector (synth.formula_state_dict head_bias), L_cos = 0.2 (gate fires: the cosine term drops out of loss and
+        # gradients -- the branch trained heads take) and 0.37 (just above: it stays); w_cos = 300 so that the cosine term is ~8 % of the adapted gradient when it is on
+        run_case(ema, 'msgchn_1layer_64x96_gate_below', one, 64, 96, 1, 3, w_cos=300.0, head_bias=5.0)
+        run_case(ema, 'msgchn_1layer_64x96_gate_above', one, 64, 96, 1, 3, w_cos=300.0, head_bias=3.5)
+        raise SystemExit(0)
     run_case(ema, 'msgchn_1layer_32x48', one, 32, 48, 1, 3)
     run_case(ema, 'msgchn_1layer_64x96', one, 64, 96, 1, 3)
     run_case(ema, 'msgchn_1layer_36x52_pad', one, 36, 52, 1, 2)        # dual-corner padding path

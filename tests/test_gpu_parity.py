@@ -357,3 +357,50 @@ def test_eval_metrics_on_device():
     ref = O.eval_metrics(out, gt, 0.5, 80.0)
     got = eval_metrics(out.cuda(), gt.cuda(), 0.5, 80.0).cpu()
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5)
+
+
+GATE_CASES = ['msgchn_1layer_64x96_gate_below', 'msgchn_1layer_64x96_gate_above']
+
+
+@pytest.mark.parametrize('path', ['graph', 'pipelined', 'eager'])
+@pytest.mark.parametrize('impl', ['exact', None])
+@pytest.mark.parametrize('name', GATE_CASES)
+def test_fused_step_on_both_sides_of_the_cosine_gate(golden_dir, name, impl, path):
+    """The `loss_cos < 0.3 => w_loss_cos = 0` gate (src/external_model_adapt.py:424-425) INSIDE the fused step -- loss_finalize_block
+    run by the two gradient kernels -- through graph replay (ptta_step), the frame-pipelined call (ptta_step_pipelined) and kernel by
+    kernel (PTTA_GRAPH=0), against whole steps of the REAL reference on either side of the gate (L_cos = 0.20: the branch trained heads
+    take, the cosine term drops out of loss and gradients; L_cos = 0.37: it stays and, with w_cos = 300, is ~8 % of the adapted gradient,
+    so a gate taken the wrong way fails every bound below)."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    if path == 'eager':
+        os.environ['PTTA_GRAPH'] = '0'
+    try:
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, impl, head_bias=float(g['head_bias']))
+    finally:
+        os.environ.pop('PTTA_GRAPH', None)
+    gtol1, gtol, ptol = (5e-6, 1.4e-3, 5e-5) if impl == 'exact' else (1.1e-2, 1.9e-2, 7.5e-4)
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)] for s in range(steps + 1)]
+    below = 'below' in name
+    for s in range(steps):
+        image, sparse = frames[s]
+        p = 's%d/' % s
+        info, depth = eng.step(image, sparse, want_depth=True, next_frame=frames[s + 1] if path == 'pipelined' else None)
+        torch.cuda.synchronize()
+        li = info.cpu().numpy()
+        np.testing.assert_allclose(li, g[p + 'loss_info'], rtol=1e-4)
+        assert (li[3] < 0.3) == below
+        dense = hp['w_sparse_depth'] * li[2] + hp['w_smoothness'] * li[1]
+        assert abs(li[0] - dense) < 1e-4 * li[0] if below else li[0] > dense + 100.0
+        assert rel_mae(depth, g[p + 'depth_train']) < 1e-4
+        gw, gb = eng.debug_tensor('gW').view(32, 32, 3, 3), eng.debug_tensor('gB')
+        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < (gtol1 if s == 0 else gtol), (name, s)
+        assert rel_mae(gb, g[p + 'grad/conv1_rgb_meta.bias']) < (gtol1 if s == 0 else gtol)
+        for k, (prm, m, v) in adapted.items():
+            assert rel_mae(prm, g[p + 'param/' + k]) < ptol, k
+            assert rel_mae(m, g[p + 'exp_avg/' + k]) < gtol
+            assert rel_mae(v, g[p + 'exp_avg_sq/' + k]) < 2 * gtol
+        d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-4
+    eng.close()

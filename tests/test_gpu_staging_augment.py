@@ -318,3 +318,83 @@ def test_pipelined_steps_equal_plain_steps(meta, n):
         assert (a[2] is None) == (b[2] is None) and (a[2] is None or torch.equal(a[2], b[2]))
         for k in a[3]:
             assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_refilled_buffer_gets_a_fresh_prefix():
+    """The prepared prefix is recognised by a frame TOKEN, not by pointer identity (include/ptta.h ptta_step_pipelined): a caller that
+    refills the SAME device buffers with another frame between the announcing and the consuming call -- what a fixed staging slot or a
+    caching allocator does -- gets that frame's own prefix, not the stale one.  Also at the C-ABI with explicit tokens."""
+    from tests.util import make_engine
+    n, h, w = 1, 64, 128
+    hp = dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
+    A, B, C = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(40 + i, h, w, n)] for i in range(3)]
+    out = {}
+    for mode in ('plain', 'refill', 'refill_tokens', 'stale_token'):
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp)
+        slot = [B[0].clone(), B[1].clone()]
+        if mode == 'plain':
+            eng.step(*A)
+            info, depth = eng.step(*C, want_depth=True)
+        else:
+            tok = dict(frame_token=11, next_token=12) if mode != 'refill' else {}
+            eng.step(*A, next_frame=slot, **tok)                   # announces B (in `slot`)
+            torch.cuda.synchronize()                               # B's prefix has been computed from the handle's copy of it
+            slot[0].copy_(C[0]); slot[1].copy_(C[1])               # the same buffers now hold C
+            tok = dict(refill={}, refill_tokens=dict(frame_token=13, next_token=14), stale_token=dict(frame_token=12, next_token=14))[mode]
+            info, depth = eng.step(*slot, want_depth=True, next_frame=A, **tok)
+        torch.cuda.synchronize()
+        out[mode] = (info.clone(), depth.clone(), {k: v[0].clone() for k, v in adapted.items()})
+        eng.close()
+    for mode in ('refill', 'refill_tokens'):
+        assert torch.equal(out['plain'][0], out[mode][0]) and torch.equal(out['plain'][1], out[mode][1]), mode
+        for k in out['plain'][2]:
+            assert torch.equal(out['plain'][2][k], out[mode][2][k]), (mode, k)
+    # the contract, seen from the other side: a caller that passes the OLD token for new content asked for the prefix of B and gets it
+    assert not torch.equal(out['plain'][1], out['stale_token'][1])
+
+
+@pytest.mark.parametrize('why', ['no_graph', 'profiling'])
+def test_eval_last_after_a_step_that_fell_back_to_the_plain_path(why):
+    """ptta_step_pipelined runs as a plain ptta_step when graph replay is off (PTTA_GRAPH=0), under profiling, with SyncBatchNorm / gradient
+    exchange, padded sizes or bf16 storage; ptta_forward_eval_last must then still return the scored forward of the frame just adapted
+    (round-3 advisor finding: it raised), and ExternalModel_Adapt.adapt(..., next_frame=...) must run."""
+    import os
+    from tests.util import make_engine
+    n, h, w = 1, 64, 96
+    hp = dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(60 + i, h, w, n)] for i in range(3)]
+    if why == 'no_graph':
+        os.environ['PTTA_GRAPH'] = '0'
+    try:
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp)
+    finally:
+        os.environ.pop('PTTA_GRAPH', None)
+    if why == 'profiling':
+        eng.profile(True)
+    for i in range(2):
+        eng.step(*frames[i], next_frame=frames[i + 1])
+        a = eng.forward_eval_last()
+        b = eng.forward_eval(*frames[i])
+        assert torch.equal(a, b)
+    eng.close()
+
+
+def test_eval_forward_between_two_steps_on_one_frame_invalidates_the_kept_prefix():
+    """inner_iter > 1: the prefix of a frame is kept for its next step (next_token == frame_token).  A full eval forward of ANOTHER frame in
+    between overwrites that buffer set (round-3 advisor finding: the following step silently reused the wrong prefix)."""
+    from tests.util import make_engine
+    n, h, w = 1, 64, 96
+    hp = dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
+    f0, f1 = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(80 + i, h, w, n)] for i in range(2)]
+    out = {}
+    for mode in ('plain', 'pipelined'):
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp)
+        nxt = dict(next_frame=f0) if mode == 'pipelined' else {}
+        eng.step(*f0, **nxt)
+        ev = eng.forward_eval(*f1)
+        info, depth = eng.step(*f0, want_depth=True, **nxt)
+        torch.cuda.synchronize()
+        out[mode] = (ev.clone(), info.clone(), depth.clone())
+        eng.close()
+    for a, b in zip(out['plain'], out['pipelined']):
+        assert torch.equal(a, b)

@@ -14,7 +14,10 @@ CASES = [('msgchn_1layer_32x48', 'meta_selfsup_seq_1layer_ema'),
          ('msgchn_1layer_36x52_pad', 'meta_selfsup_seq_1layer_ema'),
          ('msgchn_1layer_32x48_n2', 'meta_selfsup_seq_1layer_ema'),
          ('msgchn_1layer_32x48_wcos1', 'meta_selfsup_seq_1layer_ema'),
-         ('msgchn_2layers_32x48', 'meta_selfsup_seq_2layers_ema')]
+         ('msgchn_2layers_32x48', 'meta_selfsup_seq_2layers_ema'),
+         # whole steps on both sides of the `loss_cos < 0.3` gate (external_model_adapt.py:424-425): L_cos = 0.20 / 0.37
+         ('msgchn_1layer_64x96_gate_below', 'meta_selfsup_seq_1layer_ema'),
+         ('msgchn_1layer_64x96_gate_above', 'meta_selfsup_seq_1layer_ema')]
 
 
 def rel_mae(a, b):
@@ -30,7 +33,8 @@ def test_oracle_matches_reference(golden_dir, name, mode):
     h, w, n, steps = [int(x) for x in g['meta']]
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid, gain = [float(x) for x in g['hp']]
     torch.set_num_threads(4)
-    o = O.MsgChnOracle(synth.formula_state_dict(mode, gain), mode, max_input_depth=mid, lr=lr,
+    head_bias = float(g['head_bias']) if 'head_bias' in g.files else 0.0
+    o = O.MsgChnOracle(synth.formula_state_dict(mode, gain, head_bias), mode, max_input_depth=mid, lr=lr,
                        betas=(b1, b2), eps=eps, weight_decay=wd, w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
     # 2layers: the noise-driven bias (see below) leaks into the next BN's running mean and into
     # the eval forward, which uses running statistics
@@ -47,6 +51,10 @@ def test_oracle_matches_reference(golden_dir, name, mode):
         li = r['loss_info']
         got = [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']]
         np.testing.assert_allclose(got, g[p + 'loss_info'], rtol=2e-5)
+        if 'gate_below' in name:
+            assert li['loss_cos'] < 0.3 and abs(li['loss'] - (w_sd * li['loss_sparse_depth'] + w_sm * li['loss_smooth'])) < 1e-4 * li['loss']
+        if 'gate_above' in name:
+            assert li['loss_cos'] >= 0.3 and li['loss'] > w_sd * li['loss_sparse_depth'] + w_sm * li['loss_smooth'] + 100.0
         for k in o.names:
             assert rel_mae(r['grads'][k], g[p + 'grad/' + k]) < 2e-4, k
             if np.abs(g[p + 'grad/' + k]).max() < 1e-6:
@@ -187,7 +195,8 @@ def test_oracle_matches_reference_full_size(golden_dir, name, mode, max_steps):
     h, w, n, steps, frame0 = [int(x) for x in g['meta']]
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid, gain = [float(x) for x in g['hp']]
     torch.set_num_threads(8)
-    o = O.MsgChnOracle(synth.formula_state_dict(mode, gain), mode, max_input_depth=mid, lr=lr, betas=(b1, b2), eps=eps,
+    head_bias = float(g['head_bias']) if 'head_bias' in g.files else 0.0
+    o = O.MsgChnOracle(synth.formula_state_dict(mode, gain, head_bias), mode, max_input_depth=mid, lr=lr, betas=(b1, b2), eps=eps,
                        weight_decay=wd, w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
     eval_tol = 2e-4 if '2layers' in mode else 2e-5
     for s in range(min(steps, max_steps)):

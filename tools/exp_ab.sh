@@ -1,10 +1,13 @@
 #!/bin/bash
 # A/B of environment switches on ONE box: bash tools/exp_ab.sh "VAR=a" "VAR=b" ...   (3 interleaved repeats each, graph replay)
+# prints the pipelined (headline) and the call-by-call step time of every variant
 cd $GRAFT_REPO_ROOT
+REPS=${REPS:-3}
 rm -f gpurun_out/ab.txt
-for rep in 1 2 3; do
+for rep in $(seq 1 $REPS); do
   for V in "$@"; do
     env $V python3 bench.py --steps 100 --warmup 10 --no-nlspn --no-cpu-baseline 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$V rep $rep ms_per_step', round(d['ms_per_step'],4))" >> gpurun_out/ab.txt
+import json,sys; d=json.loads(sys.stdin.read()); print('$V rep $rep ms_per_step', round(d['ms_per_step'],4), 'plain', round(d['config']['ms_per_step_without_frame_pipelining'] or 0,4))" >> gpurun_out/ab.txt
   done
 done
+cat gpurun_out/ab.txt

@@ -130,9 +130,11 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// The same finalisation as loss_finalize_kernel, run redundantly by EVERY block of the two gradient kernels of the fused
-// step (a few KB of partials from L2 per block) instead of as a 1-block launch between them: one ~20 us latency-bound
-// kernel less on the step's critical path.  fin: [0] coef_cos [1] cx [2] cy [3..3+N) per-sample sparse-depth coefficient.
+// The ONE finalisation of the loss (sparse-depth / smoothness / cosine terms, the gate of external_model_adapt.py:424-425, the gradient
+// coefficients).  The fused step runs it redundantly in EVERY block of its two gradient kernels (a few KB of partials from L2 per block)
+// instead of as a 1-block launch between them: one ~20 us latency-bound kernel less on the step's critical path; the split API
+// (ptta_loss_forward) runs it as loss_finalize_kernel below.  fin (LDS): [0] coef_cos [1] cx [2] cy [3..3+N) per-sample sparse-depth
+// coefficient (first LOSS_FIN_MAXN samples); with `loss_info` given, the scalars and the coefficients also go to the workspace.
 #define LOSS_FIN_MAXN 16
 __device__ void loss_finalize_block(const float* __restrict__ ws, int N, int H, int W, long R, int has_cos, const float* __restrict__ w3,
                                     float* __restrict__ fin, float* __restrict__ loss_info, float* __restrict__ ws_out) {
@@ -146,8 +148,12 @@ __device__ void loss_finalize_block(const float* __restrict__ ws, int N, int H, 
         if (t < LOSS_PB) { const float* q = dp + ((size_t)n * LOSS_PB + t) * 4; q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; }
         const double num = block_sum_d(q0, red), den = block_sum_d(q1, red);
         smx += block_sum_d(q2, red); smy += block_sum_d(q3, red);
-        l_sd += num / den;
-        if (t == 0) fin[3 + n] = (float)((double)w_sd / ((double)N * den));
+        l_sd += num / den;                                   // NaN if a sample has no valid point, as the reference
+        if (t == 0) {
+            const float sdn = (float)((double)w_sd / ((double)N * den));
+            if (n < LOSS_FIN_MAXN) fin[3 + n] = sdn;
+            if (loss_info) ws_out[WS_SD + n] = sdn;
+        }
     }
     l_sd /= N;
     const double cntx = (double)N * H * (W - 1), cnty = (double)N * (H - 1) * W;
@@ -169,7 +175,6 @@ __device__ void loss_finalize_block(const float* __restrict__ ws, int N, int H, 
             loss_info[0] = (float)(w_sd * l_sd + w_sm * l_sm + (double)wc * l_cos);
             loss_info[1] = (float)l_sm; loss_info[2] = (float)l_sd; loss_info[3] = (float)l_cos;
             ws_out[WS_SCAL + 0] = fin[0]; ws_out[WS_SCAL + 1] = fin[1]; ws_out[WS_SCAL + 2] = fin[2];
-            for (int n = 0; n < N; ++n) ws_out[WS_SD + n] = fin[3 + n];
         }
     }
     __syncthreads();
@@ -177,39 +182,8 @@ __device__ void loss_finalize_block(const float* __restrict__ ws, int N, int H, 
 
 __global__ __launch_bounds__(256) void loss_finalize_kernel(float* __restrict__ ws, int N, int H, int W, long R, int has_cos,
                                                             const float* __restrict__ w3, float* __restrict__ loss_info) {
-    __shared__ double red[4];
-    const float w_sd = w3[0], w_sm = w3[1], w_cos = w3[2];
-    const float* dp = ws + ws_depth_off(N);
-    const int t = threadIdx.x;
-    double l_sd = 0.0, smx = 0.0, smy = 0.0;
-    for (int n = 0; n < N; ++n) {
-        double q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-        if (t < LOSS_PB) { const float* q = dp + ((size_t)n * LOSS_PB + t) * 4; q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; }
-        const double num = block_sum_d(q0, red), den = block_sum_d(q1, red);
-        smx += block_sum_d(q2, red); smy += block_sum_d(q3, red);
-        l_sd += num / den;                                   // NaN if a sample has no valid point, as the reference
-        if (t == 0) ws[WS_SD + n] = (float)((double)w_sd / ((double)N * den));
-    }
-    l_sd /= N;
-    const double cntx = (double)N * H * (W - 1), cnty = (double)N * (H - 1) * W;
-    const double l_sm = smx / cntx + smy / cnty;
-    double l_cos = 0.0;
-    float wc = w_cos;
-    if (has_cos) {
-        const float* cp = ws + ws_cos_off(N);
-        double a = 0.0;
-        for (int b = t; b < LOSS_CB; b += 256) a += cp[b];
-        l_cos = block_sum_d(a, red) / (double)R;
-        if ((float)l_cos < 0.3f) wc = 0.f;                   // external_model_adapt.py:424-425
-    }
-    if (t != 0) return;
-    ws[WS_SCAL + 0] = has_cos ? (float)(-2.0 * wc / (double)R) : 0.f;
-    ws[WS_SCAL + 1] = (float)(w_sm / cntx);
-    ws[WS_SCAL + 2] = (float)(w_sm / cnty);
-    loss_info[0] = (float)(w_sd * l_sd + w_sm * l_sm + (double)wc * l_cos);
-    loss_info[1] = (float)l_sm;
-    loss_info[2] = (float)l_sd;
-    loss_info[3] = (float)l_cos;
+    __shared__ float fin[3 + LOSS_FIN_MAXN];
+    loss_finalize_block(ws, N, H, W, R, has_cos, w3, fin, loss_info, ws);
 }
 
 int ptta_launch_loss_forward(const float* depth, const float* image, const float* sparse, const float* validity,

@@ -43,6 +43,7 @@ struct ptta_ctx {
     GNet* nl = nullptr;              // backbones on the generic layer-graph engine (NLSPN, CostDCNet): every entry point forwards to it
     int N = 1, H = 0, W = 0, Hp = 0, Wp = 0, pt = 0, pr = 0, dual = 0, Nn = 1;
     int bf16 = 0, naive = 0, es = 4, x3 = 1;
+    int ablate = 0;                  // PTTA_ABLATE (diagnostic): groups of launches skipped for timing, results garbage; announced on stderr by ptta_create
     ptta_hparams hp{};
     std::string err;
     std::vector<void*> allocs;
@@ -113,15 +114,19 @@ struct ptta_ctx {
     // launches read, and every graph is captured once per set.
     struct PreSet {
         void *c0 = nullptr, *c1 = nullptr, *c2 = nullptr, *c3 = nullptr, *c4 = nullptr, *e1_0a = nullptr, *e1_0 = nullptr, *e1_1a = nullptr;
+        void *c0a = nullptr, *c1a = nullptr, *c2a = nullptr, *c3a = nullptr, *c4a = nullptr;     // the RGB encoder's intermediates: a prefix on pre_stream writes them too
         void *e1_1 = nullptr, *y1 = nullptr, *e1_2a = nullptr, *y2 = nullptr, *t1 = nullptr, *y3 = nullptr, *s1_1 = nullptr, *u1 = nullptr;
         float *dclamp = nullptr, *d12 = nullptr, *d14 = nullptr, *in_image = nullptr, *in_loss_image = nullptr, *in_sparse = nullptr, *in_validity = nullptr;
         bool proxy_valid = false, prepared = false, rest_recorded = false;
-        const float *prep_image = nullptr, *prep_sparse = nullptr;      // the frame whose prefix has been started into this set
-        const float *last_image = nullptr, *last_sparse = nullptr;      // the frame whose step last ran from this set (prefix still valid)
+        // Frames are recognised by the caller's TOKEN (ptta.h: non-zero, one per frame content), never by pointer identity: a caller that
+        // refills one staging buffer gives the new content a new token and gets a fresh prefix.
+        uint64_t prep_token = 0;        // the frame whose prefix has been started into this set (0: none)
+        uint64_t last_token = 0;        // the frame whose step last ran from this set: its prefix is still valid (0: none / overwritten)
     };
     PreSet pset[2];
     int cur_set = 0, pipe_cur = 0, pipe_last = 0;        // set in the members now / of the next pipelined frame / of the last processed frame
     bool pipe_ready = false, pipe_active = false, skip_prefix = false;
+    const float *fb_image = nullptr, *fb_sparse = nullptr;   // frame of the last ptta_step_pipelined call that fell back to ptta_step (ptta_forward_eval_last)
     hipStream_t pre_stream = nullptr;
     hipEvent_t ev_prefix[2] = {nullptr, nullptr}, ev_rest[2] = {nullptr, nullptr}, ev_entry = nullptr;
     hipGraph_t pgraph[2] = {nullptr, nullptr}, rgraph[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
@@ -159,7 +164,7 @@ struct ptta_ctx {
         for (int p = 0; p < 2; ++p) {
             if (pexec[p]) { (void)hipGraphExecDestroy(pexec[p]); pexec[p] = nullptr; }
             if (pgraph[p]) { (void)hipGraphDestroy(pgraph[p]); pgraph[p] = nullptr; }
-            pset[p].prepared = false; pset[p].last_image = pset[p].last_sparse = nullptr;
+            pset[p].prepared = false; pset[p].prep_token = pset[p].last_token = 0;
         }
     }
 
@@ -453,7 +458,7 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     a.out_raw = e.raw; a.out_sum = e.sum;
     a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = c->bf16; a.naive = c->naive; a.x3 = c->x3;
     {   // TIMING ablation only (results are garbage): PTTA_ABLATE bit 0 skips the 32->32 convolutions at <= 1/4 resolution, bit 1 those above
-        static const int abl = getenv("PTTA_ABLATE") ? atoi(getenv("PTTA_ABLATE")) : 0;
+        const int abl = c->ablate;
         const bool small = (long)Hin * Win <= (long)c->H4 * c->W4 * (mode == CONV_S2 ? 4 : 1);
         if ((abl & 1) && small) return 0;
         if ((abl & 2) && !small) return 0;
@@ -633,6 +638,14 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
 int heads_forward(ptta_ctx* c, hipStream_t s);
 static int pipe_quiesce(ptta_ctx* c);
 static void pipe_use(ptta_ctx* c, int p);
+// a full forward (ptta_forward_eval / ptta_forward_train) has written an arbitrary frame's prefix into set p: whatever was prepared into it
+// or adapted from it is gone.  (Set p is pipe_last; when a prefix of the SAME frame was kept there for another step -- inner_iter > 1 --
+// the step that follows recomputes it in line.)
+static void pipe_overwritten(ptta_ctx* c, int p) {
+    ptta_ctx::PreSet& P = c->pset[p];
+    if (c->pipe_cur == p) { P.prepared = false; P.prep_token = 0; }
+    P.last_token = 0;
+}
 
 // RGBEncoder.forward (:252-264) on `nb` frames written at batch offset `boff` of the c0..c4 buffers; frames with index
 // >= zero_from_b see a zero image (the proxy pass's torch.zeros_like(rgb), :511).
@@ -901,7 +914,7 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
 }
 
 int heads_forward(ptta_ctx* c, hipStream_t s) {
-    { static const int abl = getenv("PTTA_ABLATE") ? atoi(getenv("PTTA_ABLATE")) : 0; if (abl & 4) return 0; }      // timing ablation only
+    if (c->ablate & 4) return 0;      // timing ablation only
     const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
     const void* feat_zero = (const char*)c->feat + half;
     if (c->head_swap) {
@@ -943,7 +956,7 @@ int heads_forward(ptta_ctx* c, hipStream_t s) {
 
 // d ref -> d feat through proj = Linear(32,512) - BN1d - ReLU - Linear(512,512)
 int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
-    { static const int abl = getenv("PTTA_ABLATE") ? atoi(getenv("PTTA_ABLATE")) : 0; if (abl & 4) return 0; }      // timing ablation only
+    if (c->ablate & 4) return 0;      // timing ablation only
     const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
     const int R = (int)c->Rg;
     GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;
@@ -1133,6 +1146,8 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     c->use_aux = (ax && strcmp(ax, "0") == 0) ? 0 : 1;
     { const char* sf = getenv("PTTA_SPLIT_FWD"); c->split_fwd = sf ? atoi(sf) : 0; }
     { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
+    { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
+      if (c->ablate) fprintf(stderr, "libptta_hip: PTTA_ABLATE=%d -- TIMING ABLATION: launches are skipped, every result of this handle is GARBAGE\n", c->ablate); }
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
     c->x3 = (arith && strcmp(arith, "exact") == 0) ? 0 : 1;
     c->hp = *hp;
@@ -1339,7 +1354,10 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
 
     if (!c || !image || !sparse) return -1;
     hipStream_t s = (hipStream_t)s_;
-    if (c->pipe_active && !c->skip_prefix) pipe_use(c, c->pipe_last);       // never the buffer set a prefix may be writing (ptta_step_pipelined)
+    if (c->pipe_active && !c->skip_prefix) {              // never the buffer set a prefix may be writing (ptta_step_pipelined) ...
+        pipe_use(c, c->pipe_last);
+        pipe_overwritten(c, c->pipe_last);               // ... and the set it DOES overwrite no longer holds the frame it was prepared for / adapted from
+    }
     c->fwd_valid = false; c->head.fwd_ok = false;
     RUN(forward_common(c, image, sparse, true, s));      // includes the heads (beside decoder 3)
     const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
@@ -1355,7 +1373,7 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
 
     if (!c || !image || !sparse || !depth_out) return -1;
     hipStream_t s = (hipStream_t)s_;
-    if (c->pipe_active) pipe_use(c, c->pipe_last);       // never the buffer set a prefix may be writing (ptta_step_pipelined)
+    if (c->pipe_active) { pipe_use(c, c->pipe_last); pipe_overwritten(c, c->pipe_last); }       // as ptta_forward_train
     c->fwd_valid = false; c->head.fwd_ok = false;        // the eval pass overwrites the saved activations
     RUN(forward_common(c, image, sparse, false, s));
     HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, hipMemcpyDeviceToDevice, s));
@@ -1367,7 +1385,13 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
 int ptta_forward_eval_last(ptta_handle c, float* depth_out, ptta_stream s_) {
     if (!c || !depth_out) return -1;
     if (c->nl) return c->fail("ptta_forward_eval_last follows ptta_step_pipelined (MSG_CHN handles)", -38);
-    if (!c->pipe_active || !c->pset[c->pipe_last].last_image) return c->fail("ptta_forward_eval_last: no frame adapted by ptta_step_pipelined since the last reset", -3);
+    if (!c->pipe_active) {
+        // the last ptta_step_pipelined call ran as a plain ptta_step (no graph replay, profiling, SyncBatchNorm / gradient exchange, padded
+        // sizes, bf16 storage ...): no prefix is held, so this is a full eval forward of that call's frame (its buffers are still the caller's)
+        if (!c->fb_image || !c->fb_sparse) return c->fail("ptta_forward_eval_last: no frame adapted by ptta_step_pipelined since the last reset", -3);
+        return ptta_forward_eval(c, c->fb_image, c->fb_sparse, depth_out, s_);
+    }
+    if (!c->pset[c->pipe_last].last_token) return c->fail("ptta_forward_eval_last: no frame adapted by ptta_step_pipelined since the last reset", -3);
     hipStream_t s = (hipStream_t)s_;
     pipe_use(c, c->pipe_last);
     c->fwd_valid = false; c->head.fwd_ok = false;
@@ -1491,6 +1515,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
     if (!c || !image || !sparse) return -1;
     if (c->nl) return c->nl->step(image, loss_image, sparse, validity, depth_out, loss_info_out, (hipStream_t)s_);
     RUN(pipe_quiesce(c));
+    c->fb_image = c->fb_sparse = nullptr;
     hipStream_t s = (hipStream_t)s_;
     if (!loss_image) loss_image = image;
     const size_t ibytes = (size_t)c->N * 3 * c->H * c->W * 4, pbytes = (size_t)c->N * c->H * c->W * 4;
@@ -1533,6 +1558,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
 namespace {
 static void pipe_save(ptta_ctx* c, ptta_ctx::PreSet& P) {
     P.c0 = c->c0; P.c1 = c->c1; P.c2 = c->c2; P.c3 = c->c3; P.c4 = c->c4; P.e1_0a = c->e1_0a; P.e1_0 = c->e1_0; P.e1_1a = c->e1_1a;
+    P.c0a = c->c0a; P.c1a = c->c1a; P.c2a = c->c2a; P.c3a = c->c3a; P.c4a = c->c4a;
     P.e1_1 = c->e1_1; P.y1 = c->y1; P.e1_2a = c->e1_2a; P.y2 = c->y2; P.t1 = c->t1; P.y3 = c->y3; P.s1_1 = c->s1_1; P.u1 = c->u1;
     P.dclamp = c->dclamp; P.d12 = c->d12; P.d14 = c->d14;
     P.in_image = c->in_image; P.in_loss_image = c->in_loss_image; P.in_sparse = c->in_sparse; P.in_validity = c->in_validity;
@@ -1543,6 +1569,7 @@ static void pipe_use(ptta_ctx* c, int p) {
     pipe_save(c, c->pset[c->cur_set]);
     const ptta_ctx::PreSet& P = c->pset[p];
     c->c0 = P.c0; c->c1 = P.c1; c->c2 = P.c2; c->c3 = P.c3; c->c4 = P.c4; c->e1_0a = P.e1_0a; c->e1_0 = P.e1_0; c->e1_1a = P.e1_1a;
+    c->c0a = P.c0a; c->c1a = P.c1a; c->c2a = P.c2a; c->c3a = P.c3a; c->c4a = P.c4a;
     c->e1_1 = P.e1_1; c->y1 = P.y1; c->e1_2a = P.e1_2a; c->y2 = P.y2; c->t1 = P.t1; c->y3 = P.y3; c->s1_1 = P.s1_1; c->u1 = P.u1;
     c->dclamp = P.dclamp; c->d12 = P.d12; c->d14 = P.d14;
     c->in_image = P.in_image; c->in_loss_image = P.in_loss_image; c->in_sparse = P.in_sparse; c->in_validity = P.in_validity;
@@ -1557,6 +1584,7 @@ static int pipe_init(ptta_ctx* c) {
     pipe_save(c, c->pset[c->cur_set]);                       // the set the handle was built with (0)
     ptta_ctx::PreSet& Q = c->pset[1];
     Q.c0 = A(B2, H1, W1); Q.c1 = A(B2, c->H2, c->W2); Q.c2 = A(B2, c->H4, c->W4); Q.c3 = A(B2, c->H8, c->W8); Q.c4 = A(B2, c->H16, c->W16);
+    Q.c0a = A(B2, H1, W1); Q.c1a = A(B2, c->H2, c->W2); Q.c2a = A(B2, c->H4, c->W4); Q.c3a = A(B2, c->H8, c->W8); Q.c4a = A(B2, c->H16, c->W16);
     Q.e1_0a = A(Nn, c->H4, c->W4); Q.e1_0 = A(Nn, c->H4, c->W4); Q.e1_1a = A(Nn, c->H8, c->W8);
     Q.e1_1 = A(B2, c->H8, c->W8); Q.y1 = A(B2, c->H8, c->W8); Q.e1_2a = A(Nn, c->H16, c->W16); Q.y2 = A(B2, c->H16, c->W16);
     Q.t1 = A(B2, c->H8, c->W8); Q.y3 = A(B2, c->H8, c->W8); Q.s1_1 = A(B2, c->H8, c->W8); Q.u1 = A(B2, c->H4, c->W4);
@@ -1577,7 +1605,7 @@ static int pipe_init(ptta_ctx* c) {
 static int pipe_quiesce(ptta_ctx* c) {
     if (!c->pipe_active) return 0;
     HIPCHK(hipStreamSynchronize(c->pre_stream));
-    for (int p = 0; p < 2; ++p) { c->pset[p].prepared = false; c->pset[p].last_image = c->pset[p].last_sparse = nullptr; }
+    for (int p = 0; p < 2; ++p) { c->pset[p].prepared = false; c->pset[p].prep_token = c->pset[p].last_token = 0; }
     pipe_use(c, 0);
     c->pipe_cur = 0; c->pipe_last = 0; c->pipe_active = false;
     return 0;
@@ -1617,13 +1645,18 @@ int ptta_pipeline_stream(ptta_handle c, ptta_stream* out) {
 }
 
 // One TTA step on (image, sparse) AND, beside it, the parameter-independent prefix of the NEXT frame (next_image, next_sparse; NULL: none).
-// Same results as ptta_step call by call.  The frame passed as `next` must be the frame of the following call (same device pointers:
-// that is how the prepared prefix is recognised; otherwise the prefix is simply recomputed) and its buffers must stay unchanged until then.
-int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
-                        const float* next_image, const float* next_sparse, float* depth_out, float* loss_info_out, ptta_stream s_) {
+// Same results as ptta_step call by call.  Frames are named by caller-chosen TOKENS (non-zero, a new one for every new frame CONTENT): the
+// prefix prepared for `next_token` is used by the following call iff that call's `frame_token` equals it -- never by pointer identity, so a
+// caller that refills one staging buffer is safe as long as the refill gets a new token.  The announced frame is copied to the handle's own
+// staging buffers when it is announced: the caller's buffers only have to hold it until this call's copies have run on the prefix stream.
+int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity, uint64_t frame_token,
+                        const float* next_image, const float* next_sparse, uint64_t next_token, float* depth_out, float* loss_info_out, ptta_stream s_) {
     if (!c || !image || !sparse) return -1;
-    if (c->nl || !c->use_graph || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16 || c->split_fwd)
-        return ptta_step(c, image, loss_image, sparse, validity, depth_out, loss_info_out, s_);
+    if (c->nl || !c->use_graph || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16 || c->split_fwd) {
+        const int rc = ptta_step(c, image, loss_image, sparse, validity, depth_out, loss_info_out, s_);
+        if (!c->nl) { c->fb_image = rc ? nullptr : image; c->fb_sparse = rc ? nullptr : sparse; }       // for ptta_forward_eval_last
+        return rc;
+    }
     hipStream_t s = (hipStream_t)s_;
     if (!loss_image) loss_image = image;
     RUN(pipe_init(c));
@@ -1633,19 +1666,20 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     const int key = (validity ? 2 : 0) | (loss_image != image ? 1 : 0);
     HIPCHK(hipEventRecord(c->ev_entry, s));                   // what the caller queued before this call (the next frame's data, too)
     pipe_use(c, p);
+    RUN(ensure_fused_heads(c, s));                            // (ptta_head_reload / ptta_head_step invalidate the merged head GEMM only)
     if (!c->proxy_rgb_valid) RUN(ensure_proxy_rgb(c, c->in_image, s));
     RUN(ensure_adam_table(c, s));
     ptta_ctx::PreSet& P = c->pset[p];
-    if (P.prepared && P.prep_image == image && P.prep_sparse == sparse) {
+    if (P.prepared && frame_token != 0 && P.prep_token == frame_token) {
         HIPCHK(hipStreamWaitEvent(s, c->ev_prefix[p], 0));
     } else {                                                  // first call, or the caller did not announce this frame: prefix in line
-        HIPCHK(hipStreamSynchronize(c->pre_stream));          // (a prefix of another frame may still be writing this set)
+        HIPCHK(hipStreamSynchronize(c->pre_stream));          // (a prefix of another frame may still be writing this set) -- the ONE host wait of this path
         HIPCHK(hipMemcpyAsync(c->in_image, image, ibytes, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(c->in_sparse, sparse, pbytes, hipMemcpyDeviceToDevice, s));
         if (!c->pexec[p]) RUN(pipe_capture(c, &c->pgraph[p], &c->pexec[p], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));
         HIPCHK(hipGraphLaunch(c->pexec[p], s));
     }
-    P.prepared = false;
+    P.prepared = false; P.prep_token = 0;
     if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
     if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
     if (!c->rexec[key][p]) {
@@ -1658,17 +1692,17 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     }
     HIPCHK(hipGraphLaunch(c->rexec[key][p], s));
     HIPCHK(hipEventRecord(c->ev_rest[p], s));
-    P.rest_recorded = true; c->pipe_last = p; P.last_image = image; P.last_sparse = sparse;
+    P.rest_recorded = true; c->pipe_last = p; P.last_token = frame_token ? frame_token : ~(uint64_t)0;      // (an unnamed frame is still the one ptta_forward_eval_last scores)
     if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));
     HIPCHK(hipEventRecord(c->ev_replay, s));
     c->fwd_valid = true;
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
     if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
-    if (next_image == image && next_sparse == sparse) {
+    if (next_token != 0 && next_token == frame_token) {
         // another step on the SAME frame (inner_iter > 1): its prefix is the one just used -- nothing in the step writes those tensors
         HIPCHK(hipEventRecord(c->ev_prefix[p], s));
-        P.prepared = true; P.prep_image = image; P.prep_sparse = sparse;
-    } else if (next_image && next_sparse) {
+        P.prepared = true; P.prep_token = frame_token;
+    } else if (next_image && next_sparse && next_token != 0) {
         // the next frame's prefix into the other set, on its own stream: after the caller's data is there and after the step that last read
         // that set (two calls ago) is done with it
         pipe_use(c, q);
@@ -1682,7 +1716,7 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         if (!c->pexec[q]) RUN(pipe_capture(c, &c->pgraph[q], &c->pexec[q], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));
         HIPCHK(hipGraphLaunch(c->pexec[q], ps));
         HIPCHK(hipEventRecord(c->ev_prefix[q], ps));
-        Q.prepared = true; Q.prep_image = next_image; Q.prep_sparse = next_sparse; Q.last_image = Q.last_sparse = nullptr;
+        Q.prepared = true; Q.prep_token = next_token; Q.last_token = 0;
         c->pipe_cur = q;
         pipe_use(c, p);                                       // the members point at the frame just processed (what final_depth etc. read)
     }

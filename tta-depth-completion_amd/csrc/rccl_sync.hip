@@ -31,12 +31,17 @@ struct RcclApi {
 RcclApi g_api;
 std::once_flag g_once;
 thread_local char g_err[256] = "";
+char g_load_err[192] = "";              // dlerror() of the last failed dlopen, captured right behind it (a later dl* call resets it)
 
 void load_api() {
     const char* names[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : names) if (!g_api.lib) g_api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);      // the process's own copy first
     const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : paths) if (!g_api.lib) g_api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    for (const char* n : paths)
+        if (!g_api.lib) {
+            g_api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!g_api.lib) { const char* e = dlerror(); snprintf(g_load_err, sizeof(g_load_err), "%s", e ? e : "dlopen failed"); }
+        }
     if (!g_api.lib) return;
 #define SYM(field, name) g_api.field = (decltype(g_api.field))dlsym(g_api.lib, name)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
@@ -44,7 +49,7 @@ void load_api() {
 #undef SYM
     g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce;
 }
-int api() { std::call_once(g_once, load_api); if (!g_api.ok) { snprintf(g_err, sizeof(g_err), "librccl could not be loaded: %s", dlerror() ? dlerror() : "symbols missing"); return -38; } return 0; }
+int api() { std::call_once(g_once, load_api); if (!g_api.ok) { snprintf(g_err, sizeof(g_err), "librccl could not be loaded: %s", g_api.lib ? "symbols missing" : g_load_err); return -38; } return 0; }
 int chk(ncclResult_t r, const char* what) {
     if (r == ncclSuccess) return 0;
     snprintf(g_err, sizeof(g_err), "%s: %s", what, g_api.GetErrorString ? g_api.GetErrorString(r) : "RCCL error");

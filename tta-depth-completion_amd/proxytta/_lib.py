@@ -5,7 +5,7 @@ module raises, and every call that needs a GPU raises when no HIP device is pres
 """
 import ctypes
 import os
-from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int64, c_void_p
+from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libptta_hip.so')
@@ -53,7 +53,7 @@ SIGNATURES = [
     ('ptta_adapted_repeat', c_int, [_P, c_int]),
     ('ptta_adam_step', c_int, [_P, _P, _P, _P]),
     ('ptta_step', c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
-    ('ptta_step_pipelined', c_int, [_P] * 10),
+    ('ptta_step_pipelined', c_int, [_P] * 5 + [c_uint64] + [_P] * 2 + [c_uint64] + [_P] * 3),
     ('ptta_pipeline_stream', c_int, [_P, POINTER(c_void_p)]),
     ('ptta_forward_eval_last', c_int, [_P, _P, _P]),
     ('ptta_outlier_removal', c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P]),

@@ -39,18 +39,32 @@ def allreduce_adapted_grads(grads, group=None):
     return grads
 
 
-_rccl = {}
+import atexit
+import weakref
+
+_rccl_default = []                          # communicator of the default process group (group=None)
+_rccl_groups = weakref.WeakKeyDictionary()  # keyed on the group OBJECT: a collected group's id() can be reused by another one
+
+
+def _rccl_destroy(comm):
+    from . import _lib
+    try:
+        _lib.load().ptta_rccl_comm_destroy(comm)
+    except Exception:
+        pass
 
 
 def rccl_communicator(group=None):
     """(comm handle, world size) of the library-owned RCCL communicator of this process (include/ptta.h ptta_rccl_*): rank 0
     draws the unique id, torch.distributed (any backend: it only carries 128 bytes, once) broadcasts it, every rank joins.
-    Without an initialised process group: a one-rank communicator."""
+    Without an initialised process group: a one-rank communicator.  One communicator per process group, destroyed when the
+    group object is collected or at interpreter exit."""
     import ctypes
     from . import _lib
-    key = id(group)
-    if key in _rccl:
-        return _rccl[key]
+    if group is None and _rccl_default:
+        return _rccl_default[0]
+    if group is not None and group in _rccl_groups:
+        return _rccl_groups[group]
     lib = _lib.load()
     on = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if on else 1
@@ -68,8 +82,14 @@ def rccl_communicator(group=None):
     rc = lib.ptta_rccl_comm_create(ident, rank, world, ctypes.byref(comm))
     if rc:
         raise RuntimeError('ptta_rccl_comm_create failed (%d): %s' % (rc, lib.ptta_rccl_last_error().decode()))
-    _rccl[key] = (comm.value, world)
-    return _rccl[key]
+    entry = (comm.value, world)
+    if group is None:
+        _rccl_default.append(entry)
+        atexit.register(_rccl_destroy, comm.value)
+    else:
+        _rccl_groups[group] = entry
+        weakref.finalize(group, _rccl_destroy, comm.value)
+    return entry
 
 
 _warned = []

@@ -229,11 +229,19 @@ class Engine:
     def adam_step(self, gw=None, gb=None):
         self._chk(self.lib.ptta_adam_step(self.handle, ptr(gw), ptr(gb), _stream()), 'ptta_adam_step')
 
-    def step(self, image, sparse, validity=None, loss_image=None, want_depth=False, next_frame=None):
+    @staticmethod
+    def _frame_key(image, sparse):
+        # what identifies a frame's CONTENT on the torch side: the storage and torch's in-place modification counters (a staging slot that is
+        # refilled with `copy_` keeps its address and gets a new version)
+        return (image.data_ptr(), image._version, sparse.data_ptr(), sparse._version)
+
+    def step(self, image, sparse, validity=None, loss_image=None, want_depth=False, next_frame=None, frame_token=None, next_token=None):
         """forward + loss + backward + Adam in one enqueue (src/tta_main.py:610-633).
         Returns (loss_info[4] device tensor, depth or None).
-        next_frame = (image, sparse) of the frame the NEXT call will pass (the same tensors, kept alive and unchanged until then): the part of
-        its forward upstream of the adapted layer then runs beside this step (ptta_step_pipelined, include/ptta.h); same results."""
+        next_frame = (image, sparse) of the frame the NEXT call will pass: the part of its forward upstream of the adapted layer then runs
+        beside this step (ptta_step_pipelined, include/ptta.h); same results.  The library recognises the announced frame by a TOKEN, which
+        this wrapper derives from the tensors (address + torch's in-place version counter: a refilled staging buffer is a new frame); a
+        caller that writes device buffers behind torch's back passes explicit non-zero `frame_token` / `next_token` integers instead."""
         image = self._f32(image, (self.n, 3, self.h, self.w))
         sparse = self._f32(sparse, (self.n, 1, self.h, self.w))
         info = torch.empty(4, device=image.device, dtype=torch.float32)
@@ -241,15 +249,27 @@ class Engine:
         if next_frame is not None:
             nimg = self._f32(next_frame[0], (self.n, 3, self.h, self.w))
             nsp = self._f32(next_frame[1], (self.n, 1, self.h, self.w))
+            key, nkey = self._frame_key(image, sparse), self._frame_key(nimg, nsp)
+            ann = getattr(self, '_announced', None)
+            if frame_token is None:
+                frame_token = ann[0] if (ann is not None and ann[1] == key) else self._new_token()
+            if next_token is None:
+                next_token = frame_token if nkey == key else self._new_token()
+            self._announced = (next_token, nkey)
             self._keep['next_frame'] = (nimg, nsp, image, sparse)
             self._chk(self.lib.ptta_step_pipelined(self.handle, ptr(image), ptr(None if loss_image is None else loss_image.contiguous()),
-                                                   ptr(sparse), ptr(None if validity is None else validity.contiguous()),
-                                                   ptr(nimg), ptr(nsp), ptr(depth), ptr(info), _stream()), 'ptta_step_pipelined')
+                                                   ptr(sparse), ptr(None if validity is None else validity.contiguous()), int(frame_token),
+                                                   ptr(nimg), ptr(nsp), int(next_token), ptr(depth), ptr(info), _stream()), 'ptta_step_pipelined')
             return info, depth
+        self._announced = None
         self._chk(self.lib.ptta_step(self.handle, ptr(image), ptr(None if loss_image is None else loss_image.contiguous()),
                                      ptr(sparse), ptr(None if validity is None else validity.contiguous()),
                                      ptr(depth), ptr(info), _stream()), 'ptta_step')
         return info, depth
+
+    def _new_token(self):
+        self._token = getattr(self, '_token', 0) + 1
+        return self._token
 
     def forward_eval_last(self):
         """The scored eval forward of the frame the last step(..., next_frame=...) call adapted, reusing that frame's parameter-independent

@@ -160,8 +160,16 @@ def formula_tensor(name, shape, gain=1.0):
     return v.reshape(shape).astype(np.float32)
 
 
-def formula_state_dict(prepare_mode='meta_selfsup_seq_1layer_ema', gain=1.0):
-    return {k: formula_tensor(k, s, gain) for k, s in msg_chn_keys(prepare_mode)}
+def formula_state_dict(prepare_mode='meta_selfsup_seq_1layer_ema', gain=1.0, head_bias=0.0):
+    """head_bias != 0: the output biases of `proj` and `pred` become the SAME vector of that scale, so every embedding / reference
+    row is dominated by one direction and L_cos is small -- the side of the `loss_cos < 0.3` gate (src/external_model_adapt.py:424-425)
+    that trained heads sit on; plain formula weights give L_cos ~ 2."""
+    sd = {k: formula_tensor(k, s, gain) for k, s in msg_chn_keys(prepare_mode)}
+    if head_bias:
+        v = (head_bias * (hash_uniform('head_bias', 512) * 2.0 - 1.0)).astype(np.float32)
+        sd['proj.3.bias'] = v.copy()
+        sd['pred.3.bias'] = v.copy()
+    return sd
 
 
 def synthetic_frame(frame_idx, height, width, n=1, density=0.05, dmin=1.0, dmax=80.0):

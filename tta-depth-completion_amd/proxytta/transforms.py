@@ -147,7 +147,8 @@ class Transforms(object):
     def apply(self, images_arr, draw, interpolation_modes=('nearest',)):
         """Every N x C x H x W cuda tensor of images_arr through the decisions `draw`, in the reference's order: photometric jitter
         (three-channel tensors only make sense there), crop + flip, rotation, resize-and-crop.  interpolation_modes: one of
-        'nearest' / 'bilinear' (or the reference's PIL enums 0 / 2) per tensor, the last one repeated (:1058-1060)."""
+        'nearest' / 'bilinear' (or the reference's PIL enums 0 / 2) per tensor; rotation repeats the last one for further tensors (:1058-1060),
+        resize-and-crop leaves further tensors untouched (:1252), both as the reference."""
         lib = _lib.load()
         dev = images_arr[0].device
         n, _, H, W = images_arr[0].shape
@@ -209,6 +210,11 @@ class Transforms(object):
             do, rh, rw, ry, rx = [up(a) for a in draw['resize'][:5]]
             res = []
             for i, (t, b_) in enumerate(zip(out, bil)):
+                if i >= len(interpolation_modes):
+                    # the reference's resize_and_crop zips images_arr with the list AS GIVEN (src/transforms.py:1252; only rotate extends
+                    # it, :1058-1060): tensors beyond it are left unresized there, so they are here (tta_main passes one mode per tensor)
+                    res.append(t)
+                    continue
                 o = torch.empty_like(t)
                 rc = lib.ptta_resize_crop(ptr(t), ptr(o), n, t.shape[1], ch, cw, ptr(do), ptr(rh), ptr(rw), ptr(ry), ptr(rx), int(b_),
                                           int(bool(self.resize_scaling_depth) and i != 0), stream)

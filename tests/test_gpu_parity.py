@@ -380,7 +380,10 @@ def test_fused_step_on_both_sides_of_the_cosine_gate(golden_dir, name, impl, pat
         eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, impl, head_bias=float(g['head_bias']))
     finally:
         os.environ.pop('PTTA_GRAPH', None)
-    gtol1, gtol, ptol = (5e-6, 1.4e-3, 5e-5) if impl == 'exact' else (1.1e-2, 1.9e-2, 7.5e-4)
+    # bounds = 2x the worst figure measured on MI355X on these two fixtures (tools/gate_report.py, round 4): first-step gradients exact 9.1e-7 /
+    # default 5.6e-3; later steps exact 2.0e-3 (one ReLU decision after Adam's sign-like first update, w_cos = 300) / default 1.2e-2;
+    # post-step parameters exact 2.7e-5 / default 6.0e-4.  A gate taken the wrong way moves the first-step gradient by ~8e-2.
+    gtol1, gtol, ptol = (5e-6, 4.1e-3, 6e-5) if impl == 'exact' else (1.2e-2, 2.5e-2, 1.2e-3)
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)] for s in range(steps + 1)]
     below = 'below' in name
     for s in range(steps):

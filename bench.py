@@ -10,10 +10,14 @@ N > 1: one process per GPU (torch.distributed.run), independent frame streams sh
 ranks, no data-path collective ("weak" scaling); barrier + max-over-ranks timing.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     dominant kernel = conv32_mfma_kernel<S1, relu> (stride-1 3x3 32->32 conv):
+  roofline     dominant kernel class = the stride-1 3x3 32->32 convolutions with ReLU on load
+               (conv32_s1_x3_kernel<true, ...> on large maps + conv32_s1_small_kernel<true, ...>):
                algorithmic bytes/MACs of its launches (SURVEY.md §8d counting rule: input + output +
                weight elements per layer) / their duration measured with hipEvents on the launch
-               stream inside the timed region (ptta_profile).
+               stream (ptta_profile); roofline_by_class: the same for every launch class of the step.
+  timing       SURVEY.md §8d / BASELINE.md §4: whatever --steps says, >= 10 blocks of K steps so that
+               >= 200 steps are timed (each block bracketed by barrier + synchronize, MAX over ranks);
+               ms_per_step = MEDIAN over the blocks, min / max beside it.
   cpu_baseline the oracle (PyTorch CPU restatement, oracle/proxytta_oracle.py) timed on this
                box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -48,21 +52,53 @@ HP = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_dept
           w_cos=0.1, max_input_depth=80.0)
 
 
-def cpu_baseline(steps=3):
+def cpu_model_string():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(warm=3, steps=10):
+    """the PyTorch-CPU restatement (pinned to the reference by tests/golden) on this box's host cores,
+    3 warm-up + 10 timed steps, forward / loss / backward / Adam split."""
     from oracle import proxytta_oracle as O
     from proxytta import synth
     # PyTorch's CPU convolutions at batch 1 stop scaling (and then regress badly) past a few dozen
-    # threads; 16 is where the oracle is fastest on the GPU box's host (99 s/step with all 256)
+    # threads; 16 is where the oracle is fastest on the GPU box's host (99 s/step with all 256; the container's cgroup quota is 16 CPUs)
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     o = O.MsgChnOracle(synth.formula_state_dict(MODE), MODE, max_input_depth=80.0, lr=1e-3, w_sd=1.0, w_sm=2.0, w_cos=0.1)
     frames = [[torch.from_numpy(x) for x in synth.synthetic_frame(i, H, W, 1)] for i in range(2)]
-    o.step(*frames[0])                                   # warm-up
-    t0 = time.time()
-    for i in range(steps):
-        o.step(*frames[i % 2])
-    dt = (time.time() - t0) / steps
+    split = {'forward': 0.0, 'loss': 0.0, 'backward': 0.0, 'adam': 0.0}
+    per_step = []
+    for i in range(warm + steps):
+        image, sparse = frames[i % 2]
+        validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
+        t0 = time.perf_counter()
+        depth, emb, ref = o.forward_train(image, sparse)
+        t1 = time.perf_counter()
+        loss, _ = O.adapt_loss(image, depth, sparse, validity, emb, ref, *o.w, max_input_depth=o.max_input_depth)
+        t2 = time.perf_counter()
+        params = [o.P[k] for k in o.names]
+        grads = torch.autograd.grad(loss, params, allow_unused=True)
+        t3 = time.perf_counter()
+        o.opt.step(params, [torch.zeros_like(p) if g is None else g for p, g in zip(params, grads)])
+        t4 = time.perf_counter()
+        if i >= warm:
+            for k, dt in zip(split, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                split[k] += dt / steps
+            per_step.append(t4 - t0)
+    dt = float(np.median(per_step))
     return {'value': 1.0 / dt, 'unit': 'frames/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d steps of the same 352x1216 workload after 1 warm-up (PyTorch-CPU oracle, fp32, %.2f s/step)' % (steps, dt)}
+            'cpu_model': cpu_model_string(), 'host_cpus_visible': os.cpu_count(),
+            'threads_reason': 'torch CPU convolutions at batch 1 are fastest at 16 threads on this host (all cores: ~99 s/step; cgroup quota 16 CPUs)',
+            's_per_step_median': dt, 's_per_step_min': float(min(per_step)), 's_per_step_max': float(max(per_step)),
+            'split_s': {k: round(v, 4) for k, v in split.items()},
+            'sample': '%d timed steps of the same 352x1216 workload after %d warm-up steps (PyTorch-CPU oracle, fp32, %.2f s/step median; the '
+                      'oracle runs autograd only into the adapted tensors)' % (steps, warm, dt)}
 
 
 def msgchn_2layers_workload(steps=30):
@@ -486,6 +522,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--single-block', action='store_true', help='time ONE block of --steps steps (quick A/B runs) instead of >= 10 blocks / >= 200 steps')
     ap.add_argument('--no-nlspn', action='store_true', help='skip the side measurements (2layers, NLSPN, CostDCNet)')
     ap.add_argument('--workload', default='msg_chn', choices=['msg_chn', 'costdcnet-shared'],
                     help="'costdcnet-shared': BASELINE config 5 (shared adapted parameters, all-reduce + SyncBatchNorm) instead of the headline metric")
@@ -541,26 +578,40 @@ def main():
         return frames[(i + 1) % nframes] if pipe else None
     for i in range(args.warmup):
         eng.step(*frames[i % nframes], next_frame=nxt(i))
-    if args.warmup == 0 and pipe:
-        pass                        # the first timed call then computes its own prefix in line
-    barrier()
-    t0 = time.perf_counter()
+    # >= 10 blocks of K steps, >= 200 timed steps in all; every block is the contract's timed region: barrier + synchronize on
+    # both sides, MAX over ranks; the reported figure is the MEDIAN block.  (With --warmup 0 the first timed call computes its own prefix in line.)
+    nblocks = 1 if args.single_block else max(10, -(-200 // max(args.steps, 1)))
+    block_s = []
     info = None
-    for i in range(args.steps):
-        info, _ = eng.step(*frames[(args.warmup + i) % nframes], next_frame=nxt(args.warmup + i))
-    barrier()
-    elapsed = time.perf_counter() - t0
+    it = args.warmup
+    for blk in range(nblocks):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            info, _ = eng.step(*frames[it % nframes], next_frame=nxt(it))
+            it += 1
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        block_s.append(dt)
+    elapsed = float(np.median(block_s))
     # the same K steps call by call with no next frame announced (plain ptta_step): reported beside the metric
     plain_ms = None
     if pipe and world == 1:
         for i in range(3):
             eng.step(*frames[i % nframes])
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for i in range(args.steps):
-            eng.step(*frames[i % nframes])
-        torch.cuda.synchronize()
-        plain_ms = 1e3 * (time.perf_counter() - tp) / args.steps
+        pb = []
+        for blk in range(nblocks):
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for i in range(args.steps):
+                eng.step(*frames[i % nframes])
+            torch.cuda.synchronize()
+            pb.append(1e3 * (time.perf_counter() - tp) / args.steps)
+        plain_ms = float(np.median(pb))
     # Second figure: the same K steps with every frame starting in PAGEABLE HOST memory, as the reference's
     # dataloader hands it over (src/tta_main.py:519-523): pinned triple buffer + copy stream, frame k+1 travels while frame k
     # is adapted.  Never `value` (that one is HBM-resident by contract).
@@ -606,12 +657,10 @@ def main():
         eng.step(*frames[i % nframes])
     torch.cuda.synchronize()
     instrumented_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-    ms, abytes, macs, launches = eng.profile_read(1)      # class 1 = stride-1, relu-in
+    CLASSES = ['s1_relu_large', 's1_relu_small', 's1_plain_large', 's1_plain_small', 'strided_large', 'strided_small', 'heads', 'in_out_convs', 'rest']
+    prof = [eng.profile_read(k) for k in range(len(CLASSES))]
+    ms, abytes, macs, launches = [sum(x) for x in zip(prof[0], prof[1])]      # dominant class = stride-1, ReLU on load (large + small maps)
     eng.profile(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     finite = bool(torch.isfinite(info).all().item())
 
     if rank == 0:
@@ -633,8 +682,20 @@ def main():
                      'launches': launches, 'avg_launch_us': 1e3 * ms / max(launches, 1),
                      'alg_bytes_per_launch': abytes / max(launches, 1), 'traffic': None})
         tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.dtype)
-        if os.path.exists(tpath):       # HBM bytes per launch from the separate rocprofv3 --pmc passes
-            roof['traffic'] = json.load(open(tpath)).get('hbm_bytes_per_launch')
+        if os.path.exists(tpath):       # HBM bytes per launch from the separate rocprofv3 --pmc passes: NOT measured in this run
+            tj = json.load(open(tpath))
+            roof['traffic'] = tj.get('hbm_bytes_per_launch')
+            roof['traffic_provenance'] = {'file': 'profiles/traffic_%s.json' % args.dtype, 'measured_in_this_run': False,
+                                          'source': tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/traffic_from_pmc.py)'),
+                                          'commit': tj.get('commit'), 'round': tj.get('round')}
+        by_class = {}
+        for name, (cms, cby, cmc, cn) in zip(CLASSES, prof):
+            per = args.steps
+            by_class[name] = {'launches_per_step': cn / per, 'us_per_step': 1e3 * cms / per, 'alg_bytes_per_step': cby / per,
+                              'hbm_frac': (cby / (cms * 1e-3) / HBM_PEAK) if cms > 0 else None,
+                              'mfma_bf16x3_frac': (3 * 2.0 * cmc / (cms * 1e-3) / MFMA_BF16_PEAK) if cms > 0 else None}
+        by_class['_note'] = ('hipEvent leg (kernel by kernel, one stream, every launch bracketed): us_per_step sums the bracketed launches of the class; '
+                             'algorithmic bytes by SURVEY 8d (0 for rest); heads priced as the 6 + 2 linear layers the reference executes')
         out = {
             'metric': 'TTA frames/sec (fwd+loss+bwd+Adam) at 352x1216', 'value': steps_per_s, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
@@ -652,6 +713,10 @@ def main():
                               'hbm_frac_per_gpu': (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * es * (steps_per_s / world) / HBM_PEAK,
                               'mfma_frac_per_gpu': (3 if es == 4 else 1) * ALG_FLOP_PER_STEP * (steps_per_s / world) / MFMA_BF16_PEAK},
             'roofline': roof,
+            'roofline_by_class': by_class,
+            'timing': {'protocol': '%d blocks x %d steps, each block bracketed by barrier + synchronize, MAX over ranks; ms_per_step = median block' % (nblocks, args.steps),
+                       'blocks': nblocks, 'steps_timed': nblocks * args.steps, 'ms_per_step_median': 1e3 * elapsed / args.steps,
+                       'ms_per_step_min': 1e3 * min(block_s) / args.steps, 'ms_per_step_max': 1e3 * max(block_s) / args.steps},
         }
         if from_host is not None:
             out['from_host_memory'] = from_host

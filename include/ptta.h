@@ -312,10 +312,13 @@ int ptta_set_grad_sync_rccl(ptta_handle h, void* comm);
 
 int ptta_set_graph(ptta_handle h, int enable);
 
-/* Measurement hook for bench.py: while enabled, every launch of the 3x3 32->32 convolution kernel
- * is bracketed by hipEvents on its own stream.  klass = geometry*2 + relu_in (geometry 0 = stride 1,
- * 1 = stride 2, 2 = transposed); read returns the summed duration (ms), the algorithmic bytes and
- * MACs (SURVEY.md 8d counting rule) and the launch count since enable, after synchronising s. */
+/* Measurement hook for bench.py: while enabled, the step runs kernel by kernel on one stream and EVERY launch is bracketed by hipEvents
+ * on that stream, accounted to one of nine classes:  0 / 1 stride-1 3x3 32->32 convolution with ReLU on load, maps above / up to 1/4
+ * resolution (together: the dominant kernel class of bench.py's `roofline`);  2 / 3 the same without ReLU (data gradients);  4 / 5 stride-2
+ * and transposed convolutions;  6 the MLP heads (GEMMs + BatchNorm finalize);  7 first-layer / prediction convolutions (Cin <= 3 or
+ * Cout = 1) and their data gradients;  8 everything else (resampling, loss, weight gradient, Adam, packing).  read returns the summed
+ * duration (ms), the algorithmic bytes and MACs (SURVEY.md 8d counting rule: input + output + weight elements per conv / linear layer,
+ * 0 for class 8) and the launch count since enable, after synchronising s. */
 int ptta_profile(ptta_handle h, int enable);
 int ptta_profile_read(ptta_handle h, int klass, double* ms_total_host, double* alg_bytes_host, double* macs_host,
                       int64_t* launches_host, ptta_stream s);

@@ -126,7 +126,7 @@ def sample_rows(x, k=24):
     return idx, x[idx]
 
 
-def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False):
+def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_frame=False):
     model = ema.ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], offset=offset, device=torch.device('cpu'))
     model._prepare_head(PREPARE)
     net = model.model.model
@@ -140,12 +140,12 @@ def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False):
     out = {'meta': np.array([h, w, n, steps], dtype=np.int64),
            'hp': np.array([hp['lr'], hp['betas'][0], hp['betas'][1], hp['eps'], hp['weight_decay'], hp['w_sd'], hp['w_sm'],
                            hp['w_cos'], hp['max_input_depth']], dtype=np.float64),
-           'adapted_names': np.array(names), 'legacy': np.array(int(offset))}
+           'adapted_names': np.array(names), 'legacy': np.array(int(offset)), 'same_frame': np.array(int(same_frame))}
     # a subset of the 88 adapted tensors is stored per step (first/last layers, one per stage)
     keep = [k for k in names if k.startswith(('conv1_rgb_meta', 'conv2.0.bn1', 'conv3.0.downsample.1', 'conv5.2.bn2', 'conv6.1',
                                               'dec5.1', 'dec2.1', 'id_dec1.1', 'gd_dec1.1', 'cf_dec1.1'))]
     for s in range(steps):
-        raw, image1, sparse_np = nlspn_frame(s, h, w, n)
+        raw, image1, sparse_np = nlspn_frame(0 if same_frame else s, h, w, n)        # same_frame: adapt(inner_iter=steps) on ONE frame
         image, sparse, loss_image = torch.from_numpy(image1), torch.from_numpy(sparse_np), torch.from_numpy(raw)
         validity = torch.where(sparse > 0, torch.ones_like(sparse), sparse)
         model.train()
@@ -207,6 +207,10 @@ def main():
         # what src/tta_main.py runs: legacy offsets; the canonical script's loss weights (adapt_nlspn_vkitti.sh) + a smoothness term
         if h * w < 20000:       # small sizes NOT divisible by 16 (decoder crops of nlspnmodel_adapt.py:474-490): full maps, batch 2
             run_case(ema, 'nlspn_%dx%d_n2_legacy' % (h, w), h, w, 2, 2, dict(hp, lr=3e-4), offset=True)
+            return
+        if len(sys.argv) > 2 and sys.argv[2] == 'inner3':
+            # BASELINE config 3 as stated: 3 TTA steps on the SAME frame (inner_iter 3, src/tta_main.py:579-636), scored forward after each
+            run_case(ema, 'nlspn_%dx%d_legacy_inner3' % (h, w), h, w, 1, 3, dict(hp, lr=3e-4), offset=True, sampled=True, same_frame=True)
             return
         run_case(ema, 'nlspn_%dx%d_legacy' % (h, w), h, w, 1, 1, dict(hp, lr=3e-4), offset=True, sampled=True)
         return

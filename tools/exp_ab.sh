@@ -6,7 +6,7 @@ REPS=${REPS:-3}
 rm -f gpurun_out/ab.txt
 for rep in $(seq 1 $REPS); do
   for V in "$@"; do
-    env $V python3 bench.py --steps 100 --warmup 10 --no-nlspn --no-cpu-baseline 2>/dev/null | python3 -c "
+    env $V python3 bench.py --steps 50 --warmup 10 --no-nlspn --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$V rep $rep ms_per_step', round(d['ms_per_step'],4), 'plain', round(d['config']['ms_per_step_without_frame_pipelining'] or 0,4))" >> gpurun_out/ab.txt
   done
 done

@@ -95,9 +95,13 @@ struct ptta_ctx {
     // -> ONE 512x512 GEMM with W' = W_pred0 W_proj3, b' = W_pred0 b_proj3 + b_pred0 (both frozen during TTA; derived in double on load)
     Lin fused_pp; bool fused_pp_valid = false; int fuse_heads = 1;
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
-    struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double bytes = 0, macs = 0; };
+    // classes (include/ptta.h PTTA_PROF_*): 0/1 stride-1 32->32 conv with ReLU on load, maps above / up to 1/4 resolution; 2/3 the same
+    // without ReLU (data gradients); 4/5 stride-2 / transposed; 6 the MLP heads; 7 first-layer / prediction convs (Cin <= 3 or Cout = 1)
+    // and their gradients; 8 everything else (resampling, loss, weight gradient, Adam, packing: 0 algorithmic bytes by SURVEY 8d's rule)
+    struct ProfClass { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t used = 0; double bytes = 0, macs = 0; long launches = 0; };
     bool prof_on = false;
-    ProfClass prof[6];
+    static constexpr int NPROF = 9;
+    ProfClass prof[NPROF];
     // hipGraph replay of the whole step (inputs are first copied to fixed staging buffers so that
     // the captured pointers never change); one graph per (validity given, separate loss image)
     int use_graph = 1;
@@ -442,6 +446,35 @@ void build_workspace(ptta_ctx* c) {
 #undef M_
 }
 
+// one bracketed group of launches of the profiling leg (ptta_profile): events on the launch stream, nothing when profiling is off
+struct ProfScope {
+    ptta_ctx::ProfClass* pc = nullptr; hipStream_t s;
+    ProfScope(ptta_ctx* c, int klass, hipStream_t s_, double bytes, double macs, int launches) : s(s_) {
+        if (!c->prof_on) return;
+        pc = &c->prof[klass];
+        if (pc->used == pc->ev.size()) {
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { pc = nullptr; return; }
+            pc->ev.push_back({e0, e1});
+        }
+        pc->bytes += bytes; pc->macs += macs; pc->launches += launches;
+        (void)hipEventRecord(pc->ev[pc->used].first, s);
+    }
+    ~ProfScope() { if (pc) { (void)hipEventRecord(pc->ev[pc->used].second, s); pc->used++; } }
+};
+// first-layer / prediction convolutions (class 7): Cin <= 3 -> 32 and 32 -> 1, forward and as each other's data gradient
+int conv_in_p(ptta_ctx* c, const ConvInArgs& a, hipStream_t s) {
+    const double px = (double)a.B * a.H * a.W;
+    ProfScope ps(c, 7, s, (px * (a.cin + 32) + 9.0 * a.cin * 32) * c->es, px * 9.0 * a.cin * 32, 1);
+    return ptta_launch_conv_in(a, s);
+}
+int conv_out1_p(ptta_ctx* c, const ConvOut1Args& a, hipStream_t s) {
+    const double px = (double)a.B * a.H * a.W;
+    ProfScope ps(c, 7, s, (px * 33 + 288) * c->es, px * 288.0, 1);
+    return ptta_launch_conv_out1(a, s);
+}
+#define REST_(s_, call) do { ProfScope ps_(c, 8, (s_), 0, 0, 1); RUN(call); } while (0)
+
 struct E { const void* up = nullptr; int up_nb = 1; const void* mask = nullptr; int mask_nb = 1;
            const void* add1 = nullptr; int add1_nb = 1; const void* add2 = nullptr; int add2_nb = 1;
            void* raw = nullptr; void* sum = nullptr; };
@@ -463,24 +496,14 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
         if ((abl & 1) && small) return 0;
         if ((abl & 2) && !small) return 0;
     }
-    if (!c->prof_on) return ptta_launch_conv32(a, s);
-    // bracket this launch with events on ITS stream; algorithmic bytes = input + output + weight
+    // profiling leg (bench.py roofline): bracket this launch with events on ITS stream; algorithmic bytes = input + output + weight
     // elements x element size, MACs = output pixels x 9 x 32 x 32 (SURVEY.md 8d counting rule)
-    ptta_ctx::ProfClass& pc = c->prof[mode * 2 + (relu ? 1 : 0)];
-    if (pc.used == pc.ev.size()) {
-        hipEvent_t e0, e1;
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -12;
-        pc.ev.push_back({e0, e1});
-    }
     const long pin = (long)B * Hin * Win;
     const long pout = mode == CONV_S1 ? pin : (mode == CONV_S2 ? pin / 4 : pin * 4);
-    pc.bytes += (double)((pin + pout) * 32 + 9216) * c->es;
-    pc.macs += (double)(mode == CONV_T2 ? pin : pout) * 9.0 * 32.0 * 32.0;
-    (void)hipEventRecord(pc.ev[pc.used].first, s);
-    const int rc = ptta_launch_conv32(a, s);
-    (void)hipEventRecord(pc.ev[pc.used].second, s);
-    pc.used++;
-    return rc;
+    const bool small = (long)Hin * Win <= (long)c->H4 * c->W4 * (mode == CONV_S2 ? 4 : 1);
+    ProfScope ps(c, (mode == CONV_S1 ? (relu ? 0 : 2) : 4) + (small ? 1 : 0), s, (double)((pin + pout) * 32 + 9216) * c->es,
+                 (double)(mode == CONV_T2 ? pin : pout) * 9.0 * 32.0 * 32.0, 1);
+    return ptta_launch_conv32(a, s);
 }
 
 int conv32w(ptta_ctx* c, hipStream_t s, const ConvW* w, const float* bias, const void* in, int in_nb, int B, int H, int W, const E& e) {
@@ -665,7 +688,7 @@ int rgb_encoder(ptta_ctx* c, const float* image, int nb, int boff, int zero_from
         }
         a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = at(c->c0a, H1, W1);
         a.B = nb; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
-        RUN(ptta_launch_conv_in(a, s));
+        RUN(conv_in_p(c, a, s));
     }
     CV("rgb_encoder.init.2", false, CONV_S1, at(c->c0a, H1, W1), nb, nb, H1, W1, true, e_raw(at(c->c0, H1, W1)));
     CV("rgb_encoder.enc1.1", false, CONV_S2, at(c->c0, H1, W1), nb, nb, H1, W1, true, e_raw(at(c->c1a, H2, W2)));
@@ -721,7 +744,7 @@ int enc1_head_fn(ptta_ctx* c, hipStream_t st) {
     ConvInArgs a; a.cin = 1; a.pl[0].p = c->d14; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H4 * W4;
     a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = c->e1_0a;
     a.B = Nn; a.H = H4; a.W = W4; a.bf16 = c->bf16; a.naive = c->naive;
-    RUN(ptta_launch_conv_in(a, st));
+    RUN(conv_in_p(c, a, st));
     { E e; e.raw = c->e1_0; RUN(conv32(c, st, "depth_encoder1.init.2", false, CONV_S1, c->e1_0a, Nn, Nn, H4, W4, true, e)); }
     { E e; e.raw = c->e1_1a; RUN(conv32(c, st, "depth_encoder1.enc1.1", false, CONV_S2, c->e1_0, Nn, Nn, H4, W4, true, e)); }
     return 0;
@@ -803,10 +826,10 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
             const LOut& lo = c->lout["depth_decoder1.prdct.3"];
             ConvOut1Args a; a.in = A(c->v1, H4, W4); a.in_nb = Bl; a.w = lo.w; a.bias = lo.bias; a.out = P1(c->out1, H4, W4);
             a.B = Bl; a.H = H4; a.W = W4; a.relu_in = 1; a.bf16 = c->bf16;
-            RUN(ptta_launch_conv_out1(a, st));
+            RUN(conv_out1_p(c, a, st));
         }
         // ---- stage 1/2 (:491-498) ----
-        RUN(ptta_launch_up2_1ch(P1(c->out1, H4, W4), P1(c->p12, H2, W2), Bl, H4, W4, st));
+        REST_(st, ptta_launch_up2_1ch(P1(c->out1, H4, W4), P1(c->p12, H2, W2), Bl, H4, W4, st));
         {
             const LIn& li = c->lin_in["depth_encoder2.init.0"];
             ConvInArgs a; a.cin = 2;
@@ -814,7 +837,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
             a.pl[1].p = P1(c->p12, H2, W2); a.pl[1].nb = Bl; a.pl[1].bstride = (long)H2 * W2;
             a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = A(c->e2_0a, H2, W2);
             a.B = Bl; a.H = H2; a.W = W2; a.bf16 = c->bf16; a.naive = c->naive;
-            RUN(ptta_launch_conv_in(a, st));
+            RUN(conv_in_p(c, a, st));
         }
         { E e; e.raw = A(c->e2_0, H2, W2); e.up = A(c->y4, H4, W4); e.up_nb = Bl; CR("depth_encoder2.init.2", false, CONV_S1, A(c->e2_0a, H2, W2), Bl, Bl, H2, W2, true, e); }
         CR("depth_encoder2.enc1.1", false, CONV_S2, A(c->e2_0, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->e2_1a, H4, W4)));
@@ -833,10 +856,10 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
             const LOut& lo = c->lout["depth_decoder2.prdct.3"];
             ConvOut1Args a; a.in = A(c->v2, H2, W2); a.in_nb = Bl; a.w = lo.w; a.bias = lo.bias; a.add = P1(c->p12, H2, W2); a.add_nb = Bl; a.out = P1(c->q, H2, W2);
             a.B = Bl; a.H = H2; a.W = W2; a.relu_in = 1; a.bf16 = c->bf16;                           // q = out2 + p12
-            RUN(ptta_launch_conv_out1(a, st));
+            RUN(conv_out1_p(c, a, st));
         }
         // ---- stage 1/1 (:500-506) ----
-        RUN(ptta_launch_up2_1ch(P1(c->q, H2, W2), P1(c->p11, H1, W1), Bl, H2, W2, st));
+        REST_(st, ptta_launch_up2_1ch(P1(c->q, H2, W2), P1(c->p11, H1, W1), Bl, H2, W2, st));
         {
             const LIn& li = c->lin_in["depth_encoder3.init.0"];
             ConvInArgs a; a.cin = 2;
@@ -844,7 +867,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
             a.pl[1].p = P1(c->p11, H1, W1); a.pl[1].nb = Bl; a.pl[1].bstride = (long)H1 * W1;
             a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = A(c->e3_0a, H1, W1);
             a.B = Bl; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
-            RUN(ptta_launch_conv_in(a, st));
+            RUN(conv_in_p(c, a, st));
         }
         { E e; e.raw = A(c->e3_0, H1, W1); e.up = A(c->z4, H2, W2); e.up_nb = Bl; CR("depth_encoder3.init.2", false, CONV_S1, A(c->e3_0a, H1, W1), Bl, Bl, H1, W1, true, e); }
         CR("depth_encoder3.enc1.1", false, CONV_S2, A(c->e3_0, H1, W1), Bl, Bl, H1, W1, true, raw(A(c->e3_1a, H2, W2)));
@@ -885,7 +908,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         const LOut& lo = c->lout["depth_decoder3.prdct.3"];
         ConvOut1Args a; a.in = c->v3; a.in_nb = Nn; a.w = lo.w; a.bias = lo.bias; a.add = c->p11; a.add_nb = B2; a.out = c->depth_net;
         a.B = Nn; a.H = H1; a.W = W1; a.relu_in = 1; a.bf16 = c->bf16;                           // output = out3 + p11 (:506)
-        RUN(ptta_launch_conv_out1(a, s));
+        RUN(conv_out1_p(c, a, s));
     }
     }
 #undef CV
@@ -915,6 +938,9 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
 
 int heads_forward(ptta_ctx* c, hipStream_t s) {
     if (c->ablate & 4) return 0;      // timing ablation only
+    // profiling class 6: 3 applications of Linear(32,512) / Linear(512,512) pairs (proj on both passes, pred on the proxy pass; proj.3 and
+    // pred.0 run merged) = per row 2 x (32 + 512) + 4 x (512 + 512) elements by SURVEY 8d's rule as the REFERENCE executes it (6 linears)
+    ProfScope ps_(c, 6, s, ((double)c->Rg * (2 * 544 + 4 * 1024) + 2 * 16384.0 + 4 * 262144.0) * 4, (double)c->Rg * (2 * 16384.0 + 4 * 262144.0), 8);
     const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
     const void* feat_zero = (const char*)c->feat + half;
     if (c->head_swap) {
@@ -957,6 +983,7 @@ int heads_forward(ptta_ctx* c, hipStream_t s) {
 // d ref -> d feat through proj = Linear(32,512) - BN1d - ReLU - Linear(512,512)
 int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     if (c->ablate & 4) return 0;      // timing ablation only
+    ProfScope ps_(c, 6, s, ((double)c->Rg * (1024 + 544) + 16384.0 + 262144.0) * 4, (double)c->Rg * (16384.0 + 262144.0), 3);   // data gradient through proj once
     const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
     const int R = (int)c->Rg;
     GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;
@@ -983,13 +1010,13 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
         ConvInArgs a; a.cin = 1; a.pl[0].p = g; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H * W;
         a.wfrag = lo.bfrag; a.wcanon = lo.bcanon; a.mask = mask; a.mask_nb = B2; a.out_raw = out;
         a.B = Nn; a.H = H; a.W = W; a.bf16 = c->bf16; a.naive = c->naive;
-        return ptta_launch_conv_in(a, s);
+        return conv_in_p(c, a, s);
     };
     auto dgrad_in_ch1 = [&](const std::string& layer, const void* g, const float* add, float* out, int H, int W) -> int {
         const LIn& li = c->lin_in[layer];
         ConvOut1Args a; a.in = g; a.in_nb = Nn; a.w = li.bw; a.add = add; a.add_nb = Nn; a.out = out;
         a.B = Nn; a.H = H; a.W = W; a.relu_in = 0; a.bf16 = c->bf16;
-        return ptta_launch_conv_out1(a, s);
+        return conv_out1_p(c, a, s);
     };
     auto em = [](void* raw, const void* mask, int mask_nb) { E e; e.raw = raw; e.mask = mask; e.mask_nb = mask_nb; return e; };
     // ---- decoder 3 ----
@@ -1002,7 +1029,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     { E e; e.raw = c->dw2; e.mask = c->w2; e.mask_nb = B2; e.sum = c->dfeat_tot; e.add1 = c->g_feat; e.add1_nb = Nn;
       CV("depth_decoder3.dec2.1", true, CONV_S2, c->dt3, Nn, Nn, H2, W2, false, e); }
     // ---- encoder 3 ----
-    RUN(ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, c->bf16, s));
+    REST_(s, ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, c->bf16, s));
     CV("depth_encoder3.enc2.3", true, CONV_S1, c->dfeat_tot, Nn, Nn, H4, W4, false, em(c->de3_2a, c->e3_2a, B2));
     { E e; e.sum = c->de3_1; e.mask = c->e3_1; e.mask_nb = B2; e.add1 = c->ds1_3; e.add1_nb = Nn;
       CV("depth_encoder3.enc2.1", true, CONV_T2, c->de3_2a, Nn, Nn, H4, W4, false, e); }
@@ -1011,14 +1038,14 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
       CV("depth_encoder3.enc1.1", true, CONV_T2, c->de3_1a, Nn, Nn, H2, W2, false, e); }
     CV("depth_encoder3.init.2", true, CONV_S1, c->de3_0, Nn, Nn, H1, W1, false, em(c->de3_0a, c->e3_0a, B2));
     RUN(dgrad_in_ch1("depth_encoder3.init.0", c->de3_0a, g_net, c->dp11, H1, W1));       // d p11 = conv^T + d output
-    RUN(ptta_launch_up2T_1ch(c->dp11, c->dq, Nn, H2, W2, s));                              // d(out2 + p12)
+    REST_(s, ptta_launch_up2T_1ch(c->dp11, c->dq, Nn, H2, W2, s));                              // d(out2 + p12)
     // ---- decoder 2 ----
     RUN(dgrad_out1("depth_decoder2.prdct.3", c->dq, c->v2, c->dv2, H2, W2));
     CV("depth_decoder2.prdct.1", true, CONV_S1, c->dv2, Nn, Nn, H2, W2, false, em(c->ds0_2, c->s0_2, B2));
-    RUN(ptta_launch_up2T_32(c->de3_0, c->ds0_2, c->dz4, Nn, H2, W2, c->bf16, s));         // d z4 = d s0_2 + up2^T(d e3_0)
+    REST_(s, ptta_launch_up2T_32(c->de3_0, c->ds0_2, c->dz4, Nn, H2, W2, c->bf16, s));         // d z4 = d s0_2 + up2^T(d e3_0)
     CV("depth_decoder2.dec1.3", true, CONV_S1, c->dz4, Nn, Nn, H2, W2, false, em(c->du2, c->u2, B2));
     CV("depth_decoder2.dec1.1", true, CONV_S2, c->du2, Nn, Nn, H2, W2, false, em(c->ds1_2, c->s1_2, B2));
-    RUN(ptta_launch_up2T_32(c->de3_1, c->ds1_2, c->dz3, Nn, H4, W4, c->bf16, s));         // d z3 = d s1_2 + up2^T(d e3_1)
+    REST_(s, ptta_launch_up2T_32(c->de3_1, c->ds1_2, c->dz3, Nn, H4, W4, c->bf16, s));         // d z3 = d s1_2 + up2^T(d e3_1)
     CV("depth_decoder2.dec2.3", true, CONV_S1, c->dz3, Nn, Nn, H4, W4, false, em(c->dt2, c->t2, B2));
     { E e; e.sum = c->dz2; e.mask = c->z2; e.mask_nb = B2; e.add1 = c->dz2_up; e.add1_nb = Nn;
       CV("depth_decoder2.dec2.1", true, CONV_S2, c->dt2, Nn, Nn, H4, W4, false, e); }
@@ -1031,7 +1058,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
       CV("depth_encoder2.enc1.1", true, CONV_T2, c->de2_1a, Nn, Nn, H4, W4, false, e); }
     CV("depth_encoder2.init.2", true, CONV_S1, c->de2_0, Nn, Nn, H2, W2, false, em(c->de2_0a, c->e2_0a, B2));
     RUN(dgrad_in_ch1("depth_encoder2.init.0", c->de2_0a, c->dq, c->dp12, H2, W2));       // d p12 = conv^T + d q
-    RUN(ptta_launch_up2T_1ch(c->dp12, c->dout1, Nn, H4, W4, s));
+    REST_(s, ptta_launch_up2T_1ch(c->dp12, c->dout1, Nn, H4, W4, s));
     // ---- decoder 1: only the prediction head reaches the meta layer (y0 = e1_0 + m) ----
     RUN(dgrad_out1("depth_decoder1.prdct.3", c->dout1, c->v1, c->dv1, H4, W4));
     { E e; e.sum = c->dm_total; e.mask = c->s0_1; e.mask_nb = B2; e.add1 = c->dw2; e.add1_nb = Nn; e.add2 = c->ds1_2; e.add2_nb = Nn;
@@ -1043,10 +1070,10 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
         // default arithmetic: the bf16x3 reduction-GEMM form (gconv_mfma.hip gwgrad_x3_kernel, single-pair mode)
         GView xv; xv.p = (float*)c->c2; xv.B = Nn; xv.H = H4; xv.W = W4; xv.C = 32; xv.ld = 32;
         GView gv; gv.p = (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
-        RUN(ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s));
+        REST_(s, ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s));
         return 0;
     }
-    RUN(ptta_launch_wgrad32(c->c2, c->dm_total, c->bf16, Nn, H4, W4, c->wgrad_part, c->gW, c->gB, s));
+    REST_(s, ptta_launch_wgrad32(c->c2, c->dm_total, c->bf16, Nn, H4, W4, c->wgrad_part, c->gW, c->gB, s));
     return 0;
 }
 
@@ -1067,7 +1094,7 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
     }
     if (!c->skip_prefix) {                     // (ptta_step_pipelined ran this part ahead, beside the previous frame's step)
         if (train) RUN(ensure_proxy_rgb(c, img, s));
-        RUN(ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
+        REST_(s, ptta_launch_prep(sp, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
     }
     if (c->meta_mode == PTTA_META_2LAYERS && c->m2.generic) {
         auto& m2 = c->m2;
@@ -1086,7 +1113,7 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
         }
     } else {
         const L32& ml = c->l32["conv1_rgb_meta"];
-        ptta_pack_conv32(c->meta_w, ml.f, 0, 0, s);
+        { ProfScope ps_(c, 8, s, 0, 0, 1); ptta_pack_conv32(c->meta_w, ml.f, 0, 0, s); }
     }
     RUN(backbone(c, img, train, s));
     if (c->dual)
@@ -1480,7 +1507,7 @@ int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream 
     if (!gw && !gb) {                       // the internal gradients: every adapted tensor + the step count in one launch
         RUN(ensure_adam_table(c, s));
         long total = 0; for (auto& ad : c->adapted) total += ad.n;
-        RUN(ptta_launch_adam_multi(c->adam_tab, (int)c->adapted.size(), total, c->hyper, c->step_dev, c->adam_ticket, s));
+        REST_(s, ptta_launch_adam_multi(c->adam_tab, (int)c->adapted.size(), total, c->hyper, c->step_dev, c->adam_ticket, s));
         return 0;
     }
     RUN(ptta_launch_step_inc(c->step_dev, s));
@@ -1499,10 +1526,10 @@ static int step_body(ptta_handle c, const float* image, const float* loss_image,
     RUN(ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_));
     // validity == NULL: where(sparse > 0, 1, sparse) is evaluated inside the loss kernels; the loss finalisation runs inside
     // the two gradient kernels (no 1-block launch between forward and backward)
-    RUN(ptta_launch_loss_forward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
-                                 c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info, s, 1));
-    RUN(ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
-                                  c->N, c->H, c->W, c->loss_ws, c->g_final, c->gref_buf, s, c->hyper + 5, c->loss_info));
+    REST_(s, ptta_launch_loss_forward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
+                                      c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info, s, 1));
+    REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
+                                       c->N, c->H, c->W, c->loss_ws, c->g_final, c->gref_buf, s, c->hyper + 5, c->loss_info));
     RUN(ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_));
     // shared-parameter run (the reference's DDP, src/tta_main.py:354,631-633): mean of the adapted gradients over the ranks, one message
     if (c->grad_comm && ptta_rccl_allreduce_mean_f32(c->grad_comm, c->grad_arena, c->grad_arena_n, s_)) return c->fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
@@ -2052,14 +2079,14 @@ int ptta_profile(ptta_handle c, int enable) {
 
     if (!c) return -1;
     c->prof_on = enable != 0;
-    for (auto& pc : c->prof) { pc.used = 0; pc.bytes = 0; pc.macs = 0; }
+    for (auto& pc : c->prof) { pc.used = 0; pc.bytes = 0; pc.macs = 0; pc.launches = 0; }
     return 0;
 }
 
 int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_bytes, double* macs, int64_t* launches, ptta_stream s_) {
     if (c && c->nl) return c->fail("not available for the NLSPN / CostDCNet backbones: use ptta_step / ptta_forward_*", -38);
 
-    if (!c || klass < 0 || klass >= 6) return -1;
+    if (!c || klass < 0 || klass >= ptta_ctx::NPROF) return -1;
     HIPCHK(hipStreamSynchronize((hipStream_t)s_));
     ptta_ctx::ProfClass& pc = c->prof[klass];
     double ms = 0;
@@ -2071,7 +2098,7 @@ int ptta_profile_read(ptta_handle c, int klass, double* ms_total, double* alg_by
     if (ms_total) *ms_total = ms;
     if (alg_bytes) *alg_bytes = pc.bytes;
     if (macs) *macs = pc.macs;
-    if (launches) *launches = (int64_t)pc.used;
+    if (launches) *launches = (int64_t)pc.launches;
     return 0;
 }
 

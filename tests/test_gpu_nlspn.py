@@ -481,10 +481,10 @@ def test_three_steps_on_one_full_size_frame_match_the_reference(golden_dir):
         info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
         # measured on MI355X (round 4, tools/nlspn_inner3_report.py): training depth 2.6e-6 / 6.3e-6 / 7.7e-6, eval depth 6.3e-6 / 7.7e-6 / 8.8e-6
         # over the three steps, loss terms to 1.5e-6
-        _check_map(depth, g, p + 'depth_train', 2e-5)
+        _check_map(depth, g, p + 'depth_train', 3e-5)
         np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2e-5)
         if s == 0:
             gn = np.array([float(eng.grad(k, adapted[k][0]).double().norm()) for k in names])
             np.testing.assert_allclose(gn, g[p + 'grad_norms'], rtol=TOL['default']['gnorm'], atol=1e-6)
-        _check_map(eng.forward_eval(image1, sparse), g, p + 'depth_eval', 2e-5)          # (north_star bound on the scored tensor: 1e-3)
+        _check_map(eng.forward_eval(image1, sparse), g, p + 'depth_eval', 3e-5)          # (north_star bound on the scored tensor: 1e-3)
     eng.close()

@@ -223,7 +223,9 @@ def test_merged_head_linears_equal_the_two_layer_form():
         eng.close()
     # measured 8.6e-6 = the size of either form's own bf16x3 deviation from fp32 arithmetic (dropped lo*lo terms, 2^-16 per product)
     assert rel_mae(out['1'][0], out['0'][0]) < 2e-5
-    assert torch.equal(out['1'][1], out['0'][1])
+    # ref: bit-identical while proj's hidden was materialised in both forms; heads v2 (default, with the merged form) recomputes it inside the
+    # GEMM from analytic BatchNorm statistics (measured 5e-6)
+    assert rel_mae(out['1'][1], out['0'][1]) < 2e-5
     for k in (2, 3, 4):
         assert rel_mae(out['1'][k], out['0'][k]) < 2e-5
 

@@ -164,7 +164,12 @@ struct GemmX3P {
     GemmP g;
     const bf16_t* Whi; const bf16_t* Wlo;
     const bf16_t* Wil;           // interleaved [n][k/32][hi 32 | lo 32] (wide kernel)
+    // heads v2 (GemmArgs): PRO 3 / EPI 3 of the wave-specialised kernel
+    const float* X; const uint4* W0frag; const float* b0;
+    const bf16_t* W0hi; const bf16_t* W0lo; const bf16_t* W0thi; const bf16_t* W0tlo;
+    float* P;
 };
+#define DY_ROW 272           // bytes per row of the EPI 3 gradient planes: 128 bf16 + 16 pad (conflict-free ds_read_b128)
 
 template <int WGM, int WGN, int TM, int TN, int PRO, int EPI>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
@@ -336,6 +341,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
     constexpr int STAGE = (2 * BM + 2 * BN) * X3_ROW;         // 61,440 B
     const GemmP& p = q.g;
     __shared__ __attribute__((aligned(16))) unsigned char sm[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float cst[PRO == 3 ? 3 * 512 : 4];       // PRO 3: BatchNorm scale | shift | first Linear's bias, per hidden unit
     float* red = (float*)sm;                                  // [2][2][BN], used after the K loop
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -347,10 +353,32 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
     if (wave >= 4) {
         // ================= staging waves =================
         const int tid = threadIdx.x - 256;
-        struct Regs { float4 a[2][2]; uint4 bh[4], bl[4]; float4 sc[2], sh[2]; };   // one K slice in flight: [item][half], B hi / lo, prologue scale / shift
+        // one K slice in flight: [item][half] (PRO 3: the four W0 fragments), B hi / lo, prologue scale / shift (PRO 3: + the first Linear's bias)
+        struct Regs { float4 a[2][2]; uint4 bh[4], bl[4]; float4 sc[2], sh[2]; };
         Regs r0, r1;
+        // PRO 3: A[row][k] = relu(bn(x[row] . W0[k] + b0[k])) is COMPUTED here, on the matrix cores, as the 32 x 32 tile D = W0[slice] x^T
+        // (M = hidden unit, N = row, K = 32 input channels: 2 k-steps x 3 bf16 products): this wave owns rows 32 (wave - 4) ... + 31, its x
+        // fragments (B operand: lane = row, 8 consecutive channels) are split once per block; a lane then holds 4 x 4 consecutive hidden
+        // units of ONE row -> BatchNorm + ReLU -> split -> 8-byte LDS stores.  The 55-MB hidden map is neither written nor read.
+        uint4 xh[2], xl[2];
+        if (PRO == 3) {
+            long gr = row0 + 32 * (wave - 4) + i;
+            if (gr >= p.R) gr = p.R - 1;
+            const float* xs = q.X + gr * 32 + 8 * h;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const float4 x0 = *(const float4*)(xs + 16 * ks), x1 = *(const float4*)(xs + 16 * ks + 4);
+                hsplit2(x0.x, x0.y, xh[ks].x, xl[ks].x); hsplit2(x0.z, x0.w, xh[ks].y, xl[ks].y);
+                hsplit2(x1.x, x1.y, xh[ks].z, xl[ks].z); hsplit2(x1.z, x1.w, xh[ks].w, xl[ks].w);
+            }
+        }
         auto load_slice = [&](int sl, Regs& rr) {
             const int k0 = sl << 5;
+            if (PRO == 3) {
+                const uint4* wf = q.W0frag + (size_t)sl * 256 + lane;               // [slice][kstep][hi, lo][lane]
+                rr.a[0][0] = __builtin_bit_cast(float4, wf[0]); rr.a[0][1] = __builtin_bit_cast(float4, wf[64]);
+                rr.a[1][0] = __builtin_bit_cast(float4, wf[128]); rr.a[1][1] = __builtin_bit_cast(float4, wf[192]);
+            } else {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int idx = tid + 256 * it;
@@ -358,6 +386,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 if (gr >= p.R) gr = p.R - 1;                                  // clamped (rows beyond R are never stored)
                 const float* src = (const float*)p.A + gr * p.K + k0 + 8 * (idx & 3);
                 rr.a[it][0] = *(const float4*)src; rr.a[it][1] = *(const float4*)(src + 4);
+            }
             }
             if (PRO == 1) {     // fetched WITH the slice (both items of a thread share the 8 columns): a load inside store_slice is the
                                 // youngest one there and waiting for it (vmcnt(0)) drains the prefetch of the next slice as well
@@ -373,9 +402,48 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 rr.bl[it] = *(const uint4*)(q.Wil + off + 32);
             }
         };
-        auto store_slice = [&](int stage, const Regs& rr) {
+        auto store_slice = [&](int stage, const Regs& rr, int sl_ = 0) {
             unsigned char* const Ahi = sm + stage * STAGE; unsigned char* const Alo = Ahi + BM * X3_ROW;
             unsigned char* const Bhi = Alo + BM * X3_ROW; unsigned char* const Blo = Bhi + BN * X3_ROW;
+            if (PRO == 3) {
+                // per-hidden-unit constants from LDS (cst: [scale | shift | b0][512]); accumulator rows 4 j ... 4 j + 3 = hidden units k0 + 8 j + 4 h ...
+                // two independent accumulation chains (one per k-step, added afterwards): the producer's MFMAs queue behind the MFMA wave's
+                // stream on this SIMD, and a dependent chain of six would wait for each one's full latency
+                f32x16 hacc, hac2;
+                float4 csc[4], csh[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = (sl_ << 5) + 8 * j + 4 * h;
+                    const float4 b0v = *(const float4*)(cst + 1024 + k);
+                    csc[j] = *(const float4*)(cst + k); csh[j] = *(const float4*)(cst + 512 + k);
+                    hacc[4 * j] = b0v.x; hacc[4 * j + 1] = b0v.y; hacc[4 * j + 2] = b0v.z; hacc[4 * j + 3] = b0v.w;
+                    hac2[4 * j] = 0.f; hac2[4 * j + 1] = 0.f; hac2[4 * j + 2] = 0.f; hac2[4 * j + 3] = 0.f;
+                }
+                {
+                    const bf16x8 wh0 = __builtin_bit_cast(bf16x8, rr.a[0][0]), wl0 = __builtin_bit_cast(bf16x8, rr.a[0][1]);
+                    const bf16x8 wh1 = __builtin_bit_cast(bf16x8, rr.a[1][0]), wl1 = __builtin_bit_cast(bf16x8, rr.a[1][1]);
+                    const bf16x8 xh0 = __builtin_bit_cast(bf16x8, xh[0]), xl0 = __builtin_bit_cast(bf16x8, xl[0]);
+                    const bf16x8 xh1 = __builtin_bit_cast(bf16x8, xh[1]), xl1 = __builtin_bit_cast(bf16x8, xl[1]);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl0, xh0, hacc, 0, 0, 0);      // small terms first
+                    hac2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl1, xh1, hac2, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh0, xl0, hacc, 0, 0, 0);
+                    hac2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh1, xl1, hac2, 0, 0, 0);
+                    hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh0, xh0, hacc, 0, 0, 0);
+                    hac2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh1, xh1, hac2, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hacc[r] += hac2[r];
+                }
+                const int row = 32 * (wave - 4) + i;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v0 = fmaxf(fmaf(hacc[4 * j], csc[j].x, csh[j].x), 0.f), v1 = fmaxf(fmaf(hacc[4 * j + 1], csc[j].y, csh[j].y), 0.f);
+                    const float v2 = fmaxf(fmaf(hacc[4 * j + 2], csc[j].z, csh[j].z), 0.f), v3 = fmaxf(fmaf(hacc[4 * j + 3], csc[j].w, csh[j].w), 0.f);
+                    uint2 hi, lo;
+                    hsplit2(v0, v1, hi.x, lo.x); hsplit2(v2, v3, hi.y, lo.y);
+                    *(uint2*)(Ahi + row * X3_ROW + 16 * j + 8 * h) = hi;
+                    *(uint2*)(Alo + row * X3_ROW + 16 * j + 8 * h) = lo;
+                }
+            } else {
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int idx = tid + 256 * it;
@@ -393,6 +461,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 *(uint4*)(Ahi + row * X3_ROW + 16 * kq) = hi;
                 *(uint4*)(Alo + row * X3_ROW + 16 * kq) = lo;
             }
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = tid + 256 * it;
@@ -408,21 +477,25 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
         const int last = nslices - 1;
         load_slice(0, r0);
         load_slice(min(1, last), r1);
-        store_slice(0, r0);
+        if (PRO == 3) {
+            for (int idx = tid; idx < 512; idx += 256) { cst[idx] = p.pscale[idx]; cst[512 + idx] = p.pshift[idx]; cst[1024 + idx] = q.b0[idx]; }
+            lds_barrier();                                          // (matched by the MFMA waves' extra barrier at their start)
+        }
+        store_slice(0, r0, 0);
         load_slice(min(2, last), r0);
         lds_barrier();                                              // slice 0 staged
         GSTAMP(Tloop);
         for (int sl = 0; sl + 1 < nslices; sl += 2) {
             // during the MFMAs of slice sl: stage slice sl+1 (ring 1), refill ring 1 with slice sl+3
             GSTAMP(Ta);
-            store_slice(1, r1); GSTAMP(Tb); load_slice(min(sl + 3, last), r1);
+            store_slice(1, r1, min(sl + 1, last)); GSTAMP(Tb); load_slice(min(sl + 3, last), r1);
             GSTAMP(Tc);
             lds_barrier();
             GSTAMP(Td);
             dStore += Tb - Ta; dLoad += Tc - Tb; dBar += Td - Tc;
             // during the MFMAs of slice sl+1: stage slice sl+2 (ring 0), refill ring 0 with slice sl+4
             GSTAMP(Ta);
-            store_slice(0, r0); GSTAMP(Tb); load_slice(min(sl + 4, last), r0);
+            store_slice(0, r0, min(sl + 2, last)); GSTAMP(Tb); load_slice(min(sl + 4, last), r0);
             GSTAMP(Tc);
             lds_barrier();
             GSTAMP(Td);
@@ -430,6 +503,45 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
         }
         if (nslices & 1) lds_barrier();                             // odd slice count: the last slice's hand-back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the clamped tail loads land before the registers die
+        if (EPI == 3) {
+            // The MFMA waves hand over, in two passes of 128 columns, the masked gradient x gamma x invstd of this block as bf16 hi / lo
+            // planes [row][column]; this wave contracts its 32 rows with W0 over those columns: P[row][ch] += dy[row][j] W0[j][ch]
+            // (A = the LDS plane, B = W0^T fragments from L2: lane = channel, 8 consecutive hidden units), 24 MFMAs per pass.
+            unsigned char* const DYhi = sm + 4096; unsigned char* const DYlo = DYhi + BM * DY_ROW;
+            const int sw = wave - 4;
+            f32x16 pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                uint4 th[8], tl[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int j0 = n0 + (kk >= 4 ? 128 : 0) + pass * 64 + 16 * (kk & 3) + 8 * h;
+                    th[kk] = *(const uint4*)(q.W0thi + (size_t)i * 512 + j0);
+                    tl[kk] = *(const uint4*)(q.W0tlo + (size_t)i * 512 + j0);
+                }
+                lds_barrier();                                          // this pass's planes are complete
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int off = (32 * sw + i) * DY_ROW + 32 * kk + 16 * h;
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(DYhi + off));
+                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(DYlo + off));
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, th[kk]), bl = __builtin_bit_cast(bf16x8, tl[kk]);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, pacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, pacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, pacc, 0, 0, 0);
+                }
+                lds_barrier();                                          // the planes may be overwritten
+            }
+            quad_transpose(pacc, lane);
+            const int tq = (i & 3) + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const long row = row0 + 32 * sw + 8 * g + tq;
+                if (row < p.R) *(float4*)(q.P + ((size_t)blockIdx.x * p.R + row) * 32 + 4 * (i >> 2)) = make_float4(pacc[4 * g], pacc[4 * g + 1], pacc[4 * g + 2], pacc[4 * g + 3]);
+            }
+        }
         GSTAMP(Tend);
         if (TIMING && (blockIdx.y == 50 || blockIdx.y == 150) && blockIdx.x == 0 && lane == 0)
             printf("stg blk %d wave %d: life %llu pro %llu loop %llu | store(+vmwait) %llu loadissue %llu barrier %llu\n", blockIdx.y, wave, Tend - T0, Tloop - T0, Tend - Tloop, dStore, dLoad, dBar);
@@ -443,6 +555,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        if (PRO == 3) lds_barrier();                                // the staging waves' constants are in LDS
         lds_barrier();                                              // slice 0 staged
         GSTAMP(Tloop);
         for (int sl = 0; sl < nslices; ++sl) {
@@ -497,7 +610,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
             const int col = n0 + (wn * TN + b) * 32 + i;
             bias_[b] = p.bias ? p.bias[col] : 0.f;
             esc_[b] = esh_[b] = emu_[b] = eiv_[b] = 0.f;
-            if (EPI == 2) { esc_[b] = p.escale[col]; esh_[b] = p.eshift[col]; emu_[b] = p.emean[col]; eiv_[b] = p.einv[col]; }
+            if (EPI >= 2) { esc_[b] = p.escale[col]; esh_[b] = p.eshift[col]; emu_[b] = p.emean[col]; eiv_[b] = p.einv[col]; }
         }
         auto load_h = [&](auto fullc, int ab, f32x16& hh) {
             constexpr bool FULL = decltype(fullc)::value;
@@ -534,16 +647,18 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                         float v = acc[a][b][r] + bias;
                         if (EPI == 2) v = (fmaf(hh[r], esc, esh) > 0.f) ? v : 0.f;
                         if (ok) {
-                            if (EPI == 1) { s1 += v; s2 += v * v; }
+                            if (EPI == 1 || EPI == 4) { s1 += v; s2 += v * v; }
                             if (EPI == 2) { s1 += v; s2 += v * (hh[r] - emu) * eiv; }
                         }
                         t[r] = v;
                     }
+                    if (EPI != 4) {
                     quad_transpose(t, lane);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int lr = a * 32 + 8 * g + tq;
                         if (FULL || wrow + lr < p.R) *(float4*)(cw + (long)lr * NC + b * 32) = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+                    }
                     }
                 }
                 if (EPI != 0) {
@@ -552,7 +667,87 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 }
             }
         };
+        if (EPI == 3) {
+            // ---- data gradient through proj.3 WITHOUT the stored hidden: h = x W0^T + b0 of this wave's 64 x 128 outputs is recomputed on
+            // the matrix cores in the accumulator layout (A = x rows, B = W0 rows of the column tile: K = 32), the ReLU mask and the two
+            // BatchNorm-backward column sums are taken as in EPI 2, and the masked gradient x gamma x invstd goes to the LDS planes the
+            // staging waves contract with W0 (above) instead of to a [R][512] tensor ----
+            unsigned char* const DYhi = sm + 4096; unsigned char* const DYlo = DYhi + BM * DY_ROW;
+            uint4 xh[TM][2], xl[TM][2];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                long gr = wrow + 32 * a + i;
+                if (gr >= p.R) gr = p.R - 1;
+                const float* xs = q.X + gr * 32 + 8 * h;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const float4 x0 = *(const float4*)(xs + 16 * ks), x1 = *(const float4*)(xs + 16 * ks + 4);
+                    hsplit2(x0.x, x0.y, xh[a][ks].x, xl[a][ks].x); hsplit2(x0.z, x0.w, xh[a][ks].y, xl[a][ks].y);
+                    hsplit2(x1.x, x1.y, xh[a][ks].z, xl[a][ks].z); hsplit2(x1.z, x1.w, xh[a][ks].w, xl[a][ks].w);
+                }
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int b = 2 * pass + bb;
+                    const int cl = (wn * TN + b) * 32 + i, col = n0 + cl;
+                    uint4 wh[2], wl[2];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        wh[ks] = *(const uint4*)(q.W0hi + (size_t)col * 32 + 16 * ks + 8 * h);
+                        wl[ks] = *(const uint4*)(q.W0lo + (size_t)col * 32 + 16 * ks + 8 * h);
+                    }
+                    const float b0c = q.b0[col], esc = esc_[b], esh = esh_[b], emu = emu_[b], eiv = eiv_[b];
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        f32x16 hh, hh2;                               // (the forward's association: one chain per k-step, bias in the first, then added)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { hh[r] = b0c; hh2[r] = 0.f; }
+                        {
+                            const bf16x8 axh0 = __builtin_bit_cast(bf16x8, xh[a][0]), axl0 = __builtin_bit_cast(bf16x8, xl[a][0]);
+                            const bf16x8 axh1 = __builtin_bit_cast(bf16x8, xh[a][1]), axl1 = __builtin_bit_cast(bf16x8, xl[a][1]);
+                            const bf16x8 bwh0 = __builtin_bit_cast(bf16x8, wh[0]), bwl0 = __builtin_bit_cast(bf16x8, wl[0]);
+                            const bf16x8 bwh1 = __builtin_bit_cast(bf16x8, wh[1]), bwl1 = __builtin_bit_cast(bf16x8, wl[1]);
+                            hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh0, bwl0, hh, 0, 0, 0);
+                            hh2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh1, bwl1, hh2, 0, 0, 0);
+                            hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axl0, bwh0, hh, 0, 0, 0);
+                            hh2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axl1, bwh1, hh2, 0, 0, 0);
+                            hh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh0, bwh0, hh, 0, 0, 0);
+                            hh2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(axh1, bwh1, hh2, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) hh[r] += hh2[r];
+                        }
+                        f32x16 t;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = a * 32 + acc_row(r, h);
+                            const bool ok = full || wrow + lr < p.R;
+                            float v = acc[a][b][r];
+                            v = (fmaf(hh[r], esc, esh) > 0.f) ? v : 0.f;
+                            if (ok) { s1 += v; s2 += v * (hh[r] - emu) * eiv; }
+                            t[r] = v * esc;                                  // x gamma x invstd (escale = gamma * invstd)
+                        }
+                        quad_transpose(t, lane);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int row = (wm * TM + a) * 32 + 8 * g + tq, cp = wn * 64 + bb * 32 + tc;
+                            uint2 hi, lo;
+                            hsplit2(t[4 * g], t[4 * g + 1], hi.x, lo.x); hsplit2(t[4 * g + 2], t[4 * g + 3], hi.y, lo.y);
+                            *(uint2*)(DYhi + row * DY_ROW + 2 * cp) = hi;
+                            *(uint2*)(DYlo + row * DY_ROW + 2 * cp) = lo;
+                        }
+                    }
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    if (h == 0) { red[(wm * 2 + 0) * BN + cl] = s1; red[(wm * 2 + 1) * BN + cl] = s2; }
+                }
+                lds_barrier();                                          // planes complete: the staging waves contract them
+                lds_barrier();                                          // ... and are done with them
+            }
+        } else {
         if (full) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        }
         GSTAMP(Tend);
         if (TIMING && (blockIdx.y == 50 || blockIdx.y == 150) && blockIdx.x == 0 && lane == 0)
             printf("mma blk %d wave %d: life %llu pro %llu loop %llu epi %llu | mfma %llu barrier %llu\n", blockIdx.y, wave, Tend - T0, Tloop - T0, Td - Tloop, Tend - Td, dMfma, dBar);
@@ -585,6 +780,182 @@ void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, bf16_t* il, long 
     hipLaunchKernelGGL(split_weight_kernel, dim3((int)b), dim3(256), 0, s, w, hi, lo, il, n, K);
 }
 
+// ---- heads v2: support kernels ------------------------------------------------------------------------------------------------
+__global__ void pack_w0_frag_kernel(const float* __restrict__ W0, uint4* __restrict__ frag) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // ((slice * 2 + kstep) * 2 + hl) * 64 + lane
+    if (idx >= 16 * 2 * 2 * 64) return;
+    const int lane = idx & 63, hl = (idx >> 6) & 1, ks = (idx >> 7) & 1, sl = idx >> 8;
+    const float* src = W0 + (size_t)(32 * sl + (lane & 31)) * 32 + 16 * ks + 8 * (lane >> 5);
+    unsigned w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned hi, lo;
+        hsplit2(src[2 * e], src[2 * e + 1], hi, lo);
+        w[e] = hl ? lo : hi;
+    }
+    frag[idx] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+void ptta_pack_w0_frag(const float* W0, void* frag, hipStream_t s) {
+    hipLaunchKernelGGL(pack_w0_frag_kernel, dim3(16), dim3(256), 0, s, W0, (uint4*)frag);
+}
+
+// Batch statistics of h = X W0^T + b0 from the second moments of X: one block per HM_ROWS rows and pass, fp64 throughout on
+// v_mfma_f64_16x16x4_f64 (A: lane = (m = lane & 15, k = lane >> 4), B: (n = lane & 15, k = lane >> 4), C/D: col = lane & 15,
+// row = (lane >> 4) + 4 reg).  Phase 1: S = X^T X (32 x 32 = 2 x 2 tiles, K = rows) and the column sums, the block's rows split over
+// the 8 waves, per-wave partials reduced through LDS in a fixed order.  Phase 2: T = W0 S (M = hidden unit: 32 tiles, 4 per wave), then
+// per hidden unit sum h^2 = sum_b T[j][b] w_j[b] + 2 b_j (w_j . sx) + n b_j^2 and sum h = n b_j + w_j . sx.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+#define HM_ROWS 256
+int ptta_head_moment_blocks(long R) { return (int)((R + HM_ROWS - 1) / HM_ROWS); }
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m); }
+__global__ __launch_bounds__(512) void head_moments_kernel(const float* __restrict__ X, long R, const float* __restrict__ W0,
+                                                           const float* __restrict__ b0, float* __restrict__ part) {
+    __shared__ double Sw[8][32][32];                  // per-wave partial second moments
+    __shared__ double sxw[8][32];
+    __shared__ double S[32][33];                      // S[a][b] = sum x_a x_b, S[a][32] = sum x_a
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nb = gridDim.x, blk = blockIdx.x, pass = blockIdx.y;
+    const float* Xp = X + (size_t)pass * R * 32;
+    const long r0 = (long)blk * HM_ROWS, r1 = min(r0 + (long)HM_ROWS, R);
+    d4_t c00 = {0, 0, 0, 0}, c01 = c00, c10 = c00, c11 = c00;
+    double sa0 = 0.0, sa1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < HM_ROWS / 8 / 4; ++s) {
+        const long row = r0 + (HM_ROWS / 8) * wave + 4 * s + lk;
+        const bool ok = row < r1;
+        const float* xr = Xp + (size_t)(ok ? row : r0) * 32;
+        const double x0 = ok ? (double)xr[li] : 0.0, x1 = ok ? (double)xr[16 + li] : 0.0;
+        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, c11, 0, 0, 0);
+        sa0 += x0; sa1 += x1;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        Sw[wave][lk + 4 * v][li] = c00[v]; Sw[wave][lk + 4 * v][16 + li] = c01[v];
+        Sw[wave][16 + lk + 4 * v][li] = c10[v]; Sw[wave][16 + lk + 4 * v][16 + li] = c11[v];
+    }
+    sa0 += shfl_xor_d(sa0, 16); sa0 += shfl_xor_d(sa0, 32); sa1 += shfl_xor_d(sa1, 16); sa1 += shfl_xor_d(sa1, 32);
+    if (lk == 0) { sxw[wave][li] = sa0; sxw[wave][16 + li] = sa1; }
+    __syncthreads();
+    for (int e = t; e < 1024; e += 512) {
+        const int a = e >> 5, b = e & 31;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += Sw[w][a][b];
+        S[a][b] = v;
+    }
+    if (t < 32) { double v = 0.0; for (int w = 0; w < 8; ++w) v += sxw[w][t]; S[t][32] = v; }
+    __syncthreads();
+    const double n = (double)(r1 - r0);
+    float* out = part + ((size_t)(pass * nb + blk) * 2) * 512;
+#pragma unroll 1
+    for (int qd = 0; qd < 4; ++qd) {
+        const int j0 = 16 * (4 * wave + qd);
+        d4_t T0 = {0, 0, 0, 0}, T1 = T0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const double aw = (double)W0[(size_t)(j0 + li) * 32 + 4 * s + lk];
+            T0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, S[4 * s + lk][li], T0, 0, 0, 0);
+            T1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aw, S[4 * s + lk][16 + li], T1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int jj = j0 + lk + 4 * v;
+            const double w0 = (double)W0[(size_t)jj * 32 + li], w1 = (double)W0[(size_t)jj * 32 + 16 + li];
+            double q = T0[v] * w0 + T1[v] * w1, wsx = w0 * S[li][32] + w1 * S[16 + li][32];
+#pragma unroll
+            for (int m = 1; m < 16; m <<= 1) { q += shfl_xor_d(q, m); wsx += shfl_xor_d(wsx, m); }
+            if (li == 0) {
+                const double bj = (double)b0[jj];
+                out[jj] = (float)(n * bj + wsx);
+                out[512 + jj] = (float)(q + 2.0 * bj * wsx + n * bj * bj);
+            }
+        }
+    }
+}
+int ptta_launch_head_moments(const float* X, long R, int npass, const float* W0, const float* b0, float* part, hipStream_t s) {
+    if (!X || !W0 || !b0 || !part || R < 1 || npass < 1) return -22;
+    hipLaunchKernelGGL(head_moments_kernel, dim3(ptta_head_moment_blocks(R), npass), dim3(512), 0, s, X, R, W0, b0, part);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+// dX = sum_j gs_j (dy_j - c1_j - xhat_j c2_j) w_j with xhat_j = (x . w_j + b_j - mu_j) inv_j
+//    = P - u - x M,   M[a][ch] = sum_j k2_j w_j[a] w_j[ch] (k2 = gs c2 inv),   u[ch] = sum_j (gs_j c1_j + k2_j (b_j - mu_j)) w_j[ch]
+// (P = sum_j gs_j dy_j w_j comes out of the epi-3 GEMM in two column-block halves).  One launch: every block of 128 rows derives M and u
+// itself (32 x 32 x 512 on v_mfma_f64_16x16x4_f64, the 512 hidden units split over the 8 waves, fixed-order reduction through LDS:
+// identical in every block) and applies them to its rows.
+__global__ __launch_bounds__(512) void head_bwd_finish_kernel(const double* __restrict__ k12, const float* __restrict__ W0, const float* __restrict__ P,
+                                                              const float* __restrict__ X, long R, float* __restrict__ dX) {
+    __shared__ double Mw[8][32][32];
+    __shared__ double uw[8][32];
+    __shared__ float Ms[32][33];
+    __shared__ float us[32];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int ch = t & 31;
+    const long base = (long)blockIdx.x * 128;
+    // this thread's rows of the apply phase, fetched up front (in flight during the M / u phase)
+    float xv[8], pv[8];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const long row = base + 16 * ps + (t >> 5);
+        const long rr = row < R ? row : R - 1;
+        xv[ps] = X[rr * 32 + ch];
+        pv[ps] = P[rr * 32 + ch] + P[(R + rr) * 32 + ch];
+    }
+    d4_t m00 = {0, 0, 0, 0}, m01 = m00, m10 = m00, m11 = m00;
+    double u0 = 0.0, u1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int j = 64 * wave + 4 * s + lk;
+        const double k1 = k12[j], k2 = k12[512 + j];
+        const double x0 = (double)W0[(size_t)j * 32 + li], x1 = (double)W0[(size_t)j * 32 + 16 + li];
+        m00 = __builtin_amdgcn_mfma_f64_16x16x4f64(k2 * x0, x0, m00, 0, 0, 0);
+        m01 = __builtin_amdgcn_mfma_f64_16x16x4f64(k2 * x0, x1, m01, 0, 0, 0);
+        m10 = __builtin_amdgcn_mfma_f64_16x16x4f64(k2 * x1, x0, m10, 0, 0, 0);
+        m11 = __builtin_amdgcn_mfma_f64_16x16x4f64(k2 * x1, x1, m11, 0, 0, 0);
+        u0 += k1 * x0; u1 += k1 * x1;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        Mw[wave][lk + 4 * v][li] = m00[v]; Mw[wave][lk + 4 * v][16 + li] = m01[v];
+        Mw[wave][16 + lk + 4 * v][li] = m10[v]; Mw[wave][16 + lk + 4 * v][16 + li] = m11[v];
+    }
+    u0 += shfl_xor_d(u0, 16); u0 += shfl_xor_d(u0, 32); u1 += shfl_xor_d(u1, 16); u1 += shfl_xor_d(u1, 32);
+    if (lk == 0) { uw[wave][li] = u0; uw[wave][16 + li] = u1; }
+    __syncthreads();
+    for (int e = t; e < 1024; e += 512) {
+        const int a = e >> 5, b = e & 31;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += Mw[w][a][b];
+        Ms[a][b] = (float)v;
+    }
+    if (t < 32) { double v = 0.0; for (int w = 0; w < 8; ++w) v += uw[w][t]; us[t] = (float)v; }
+    __syncthreads();
+    float mc[32];
+#pragma unroll
+    for (int a = 0; a < 32; ++a) mc[a] = Ms[a][ch];
+    const float uc = us[ch];
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const long row = base + 16 * ps + (t >> 5);                // rows come in multiples of 16 (H/4 x W/4 of sizes divisible by 16)
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 32; ++a) acc = fmaf(__shfl(xv[ps], (lane & 32) + a, 64), mc[a], acc);
+        if (row < R) dX[row * 32 + ch] = pv[ps] - acc - uc;
+    }
+}
+int ptta_launch_head_bwd_finish(const double* k12, const float* W0, const float* P, const float* X, long R, float* dX, hipStream_t s) {
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3((int)((R + 127) / 128)), dim3(512), 0, s, k12, W0, P, X, R, dX);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
 int ptta_gemm_row_blocks(int R) { return (R + GEMM_BM - 1) / GEMM_BM; }
 // number of row-block partials the launch of `a` writes (every kernel here uses 128-row blocks)
 int ptta_gemm_part_blocks(const GemmArgs& a) { return ptta_gemm_row_blocks(a.R); }
@@ -597,7 +968,11 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     p.eH = a.eH; p.escale = a.escale; p.eshift = a.eshift; p.emean = a.emean; p.einv = a.einv; p.part = a.part;
     if (a.x3 && !a.a_bf16) {
         GemmX3P q; q.g = p; q.Whi = a.Whi; q.Wlo = a.Wlo; q.Wil = a.Wil;
+        q.X = a.X; q.W0frag = (const uint4*)a.W0frag; q.b0 = a.b0; q.W0hi = a.W0hi; q.W0lo = a.W0lo; q.W0thi = a.W0thi; q.W0tlo = a.W0tlo; q.P = a.P;
         const int key3 = a.pro * 10 + a.epi;
+        if ((a.pro == 3 && (!a.X || !a.W0frag || !a.b0 || !a.pscale || !a.pshift)) ||
+            (a.epi == 3 && (!a.X || !a.b0 || !a.W0hi || !a.W0lo || !a.W0thi || !a.W0tlo || !a.P || !a.escale || !a.part))) return -22;
+        if ((a.pro == 3 || a.epi == 3) && !(a.N == 512 && a.K == 512 && a.Wil)) return -22;
         // (K = 32, the first Linear of proj: routed to the 128x128-tile kernel instead, the step is unchanged within noise --
         //  2.317 vs 2.318 ms A/B on one box: that launch is bound by its 55 MB of fp32 stores, not by the tiling)
         if (a.N == 512 && a.Wil && a.pro != 2) {
@@ -608,6 +983,8 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
             switch (key3) {
                 case 0: GS_(0, 0); break; case 1: GS_(0, 1); break; case 2: GS_(0, 2); break;
                 case 10: GS_(1, 0); break; case 11: GS_(1, 1); break;
+                case 30: GS_(3, 0); break; case 31: GS_(3, 1); break; case 3: GS_(0, 3); break;       // heads v2
+                case 4: GS_(0, 4); break;                                                              // column statistics only (no C)
                 default: return -22;
             }
 #undef GS_
@@ -708,7 +1085,8 @@ int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, con
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int row_blocks, int R, int N,
                                        const float* __restrict__ gamma, const float* __restrict__ invstd,
-                                       float* gscale, float* c1, float* c2, float* dgamma, float* dbeta) {
+                                       float* gscale, float* c1, float* c2, float* dgamma, float* dbeta,
+                                       double* k12 = nullptr, const float* __restrict__ b0 = nullptr, const float* __restrict__ mean = nullptr) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= N) return;
@@ -722,12 +1100,18 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     c1[c] = (float)(s1 / R); c2[c] = (float)(s2 / R);
     gscale[c] = gamma[c] * invstd[c];
     if (dgamma) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }     // d gamma = sum g * xhat, d beta = sum g (stage-2 head trainer)
+    if (k12) {      // heads v2 (head_bwd_finish_kernel): k2 = gs c2 inv, k1 = gs c1 + k2 (b0 - mean), in double
+        const double gs = (double)gamma[c] * (double)invstd[c];
+        const double k2 = gs * (s2 / R) * (double)invstd[c];
+        k12[c] = gs * (s1 / R) + k2 * ((double)b0[c] - (double)mean[c]); k12[N + c] = k2;
+    }
 }
 
 int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
-                                float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma, float* dbeta) {
+                                float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma, float* dbeta,
+                                double* k12, const float* b0, const float* mean) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + 3) / 4), dim3(256), 0, s, part, row_blocks, R, N, gamma,
-                       invstd, gscale, c1, c2, dgamma, dbeta);
+                       invstd, gscale, c1, c2, dgamma, dbeta, k12, b0, mean);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -94,6 +94,11 @@ struct ptta_ctx {
     // emb = pred(proj(feat_zero)): proj.3 and pred.0 are two Linear layers with nothing between them (network_exp_msg_chn_adapt.py:551-554)
     // -> ONE 512x512 GEMM with W' = W_pred0 W_proj3, b' = W_pred0 b_proj3 + b_pred0 (both frozen during TTA; derived in double on load)
     Lin fused_pp; bool fused_pp_valid = false; int fuse_heads = 1;
+    // heads v2 (PTTA_HEADS_V2=0 restores the materialised form): proj's 512-wide hidden is never written -- its BatchNorm statistics come
+    // from the second moments of the 32-channel input, the hidden is recomputed inside the 512x512 GEMMs (forward: A-operand producer;
+    // backward: mask / BatchNorm-backward sums + the contraction with W0 inside the block)
+    int heads_v2 = 1;
+    void* w0frag = nullptr; float *hm_part = nullptr, *headP = nullptr; double* head_k12 = nullptr;
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
     // classes (include/ptta.h PTTA_PROF_*): 0/1 stride-1 32->32 conv with ReLU on load, maps above / up to 1/4 resolution; 2/3 the same
     // without ReLU (data gradients); 4/5 stride-2 / transposed; 6 the MLP heads; 7 first-layer / prediction convs (Cin <= 3 or Cout = 1)
@@ -340,6 +345,7 @@ void build_registry(ptta_ctx* c) {
             Lin& f = c->fused_pp; f.N = 512; f.K = 512; f.W = c->falloc(512 * 512); f.bias = c->falloc(512);
             f.Whi = (bf16_t*)c->dalloc(512 * 512 * 2); f.Wlo = (bf16_t*)c->dalloc(512 * 512 * 2); f.Wil = (bf16_t*)c->dalloc(512 * 512 * 4);
         }
+        if (std::string(p) == "proj") c->w0frag = c->dalloc(16 * 2 * 2 * 64 * 16);
         BNorm n; n.gamma = c->falloc(512); n.beta = c->falloc(512);
         n.mean = c->falloc(512); n.inv = c->falloc(512); n.scale = c->falloc(512); n.shift = c->falloc(512);
         c->bn[std::string(p) + ".1"] = n;
@@ -378,6 +384,8 @@ void build_workspace(ptta_ctx* c) {
     c->dbg["h1"] = Dbg{c->h1, (long)RD, 0}; c->dbg["gmask"] = Dbg{c->gmask, (long)RD, 0}; c->dbg["gref"] = Dbg{c->gref_buf, (long)RD, 0};
     c->bn_part = c->falloc((size_t)ptta_gemm_row_blocks((int)c->Rg) * 2 * 512);
     c->bnb_gscale = c->falloc(512); c->bnb_c1 = c->falloc(512); c->bnb_c2 = c->falloc(512);
+    c->hm_part = c->falloc((size_t)2 * ptta_gemm_row_blocks((int)c->Rg) * 2 * 512);       // statistics partials of proj.0's output, [real | proxy] rows
+    c->headP = c->falloc((size_t)2 * c->Rg * 32); c->head_k12 = (double*)c->dalloc(1024 * sizeof(double));
     c->loss_ws = c->falloc((size_t)ptta_loss_ws_floats(c->N, c->H, c->W, c->Rg));
     c->loss_info = c->falloc(4);
     M_(g_final, c->N, c->H, c->W); M_(g_net, Nn, H1, W1);
@@ -919,6 +927,10 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     return 0;
 }
 
+static bool heads_v2_on(const ptta_ctx* c) {
+    return c->heads_v2 && c->fuse_heads && c->fused_pp_valid && c->x3 && !c->bf16 && !c->naive && !c->skip_dec3 && !c->head_swap;
+}
+
 // proj / pred heads (:551-554): emb = pred(proj(feat_zero)), ref = proj(feat); BN1d in train mode.
 int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16, int K, float* hidden, float* out, hipStream_t s) {
     const Lin& l0 = c->fc[name + ".0"]; const Lin& l3 = c->fc[name + ".3"]; BNorm& bn = c->bn[name + ".1"];
@@ -940,7 +952,7 @@ int heads_forward(ptta_ctx* c, hipStream_t s) {
     if (c->ablate & 4) return 0;      // timing ablation only
     // profiling class 6: 3 applications of Linear(32,512) / Linear(512,512) pairs (proj on both passes, pred on the proxy pass; proj.3 and
     // pred.0 run merged) = per row 2 x (32 + 512) + 4 x (512 + 512) elements by SURVEY 8d's rule as the REFERENCE executes it (6 linears)
-    ProfScope ps_(c, 6, s, ((double)c->Rg * (2 * 544 + 4 * 1024) + 2 * 16384.0 + 4 * 262144.0) * 4, (double)c->Rg * (2 * 16384.0 + 4 * 262144.0), 8);
+    ProfScope ps_(c, 6, s, ((double)c->Rg * (2 * 544 + 4 * 1024) + 2 * 16384.0 + 4 * 262144.0) * 4, (double)c->Rg * (2 * 16384.0 + 4 * 262144.0), heads_v2_on(c) ? 7 : 8);
     const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
     const void* feat_zero = (const char*)c->feat + half;
     if (c->head_swap) {
@@ -952,6 +964,46 @@ int heads_forward(ptta_ctx* c, hipStream_t s) {
         for (int k = 0; k < 4; ++k) HIPCHK(hipMemcpyAsync(dst[k], src[k], 512 * 4, hipMemcpyDeviceToDevice, s));
         RUN(mlp_forward(c, "pred", c->pz, 0, 512, c->h2, c->emb, s));
         RUN(mlp_forward(c, "proj", feat_zero, c->bf16, 32, c->h1z, c->ref, s));
+        return 0;
+    }
+    if (heads_v2_on(c)) {
+        // heads v2: emb = pred.3(relu(bn(fused_pp(relu(bn(proj.0 x_zero)))))), ref = proj.3(relu(bn(proj.0 x))) with proj.0's output never
+        // materialised.  BatchNorm1d batch statistics of Linear(32,512) are analytic in the input's second moments (one fp64 pass over the
+        // 26,752 x 32 features of both passes); the 512x512 GEMMs compute their A operand relu(bn(x W0^T + b0)) on the fly.
+        const Lin& l0 = c->fc["proj.0"]; const Lin& lf = c->fused_pp; const Lin& lp3 = c->fc["pred.3"]; const Lin& l3 = c->fc["proj.3"];
+        BNorm& b1 = c->bn["proj.1"]; BNorm& b2 = c->bn["pred.1"];
+        const int R = (int)c->Rg, Rw = R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), nbm = ptta_gemm_row_blocks(R);
+        {   // BatchNorm1d batch statistics of proj.0's output for BOTH passes: the K = 32 GEMM with its column sums and NO store -- one launch
+            // over rows [0, R) = real frames, [R, 2R) = proxy frames when the 128-row blocks do not straddle the two, else one per pass
+            GemmArgs g; g.A = c->feat; g.W = l0.W; g.bias = l0.bias; g.R = 2 * R; g.K = 32; g.N = 512; g.epi = 4; g.part = c->hm_part;
+            g.x3 = 1; g.Whi = l0.Whi; g.Wlo = l0.Wlo; g.Wil = l0.Wil;
+            if (R % 128 == 0) RUN(ptta_launch_gemm(g, s));
+            else {
+                g.R = R; RUN(ptta_launch_gemm(g, s));
+                g.A = feat_zero; g.part = c->hm_part + (size_t)nbm * 2 * 512; RUN(ptta_launch_gemm(g, s));
+            }
+        }
+        float* part_real = c->hm_part; float* part_zero = c->hm_part + (size_t)nbm * 2 * 512;
+        auto gemm_h = [&](const void* x, const Lin& w, float* out, int epi) {
+            GemmArgs g; g.X = (const float*)x; g.W0frag = c->w0frag; g.b0 = l0.bias; g.pscale = b1.scale; g.pshift = b1.shift; g.pro = 3;
+            g.W = w.W; g.bias = w.bias; g.C = out; g.R = R; g.K = 512; g.N = 512; g.epi = epi; g.part = c->bn_part;
+            g.x3 = 1; g.Whi = w.Whi; g.Wlo = w.Wlo; g.Wil = w.Wil;
+            return g;
+        };
+        // proxy pass first: the running statistics are updated in the reference's order (proj(feat_zero), then proj(feat), :551-554)
+        RUN(ptta_stat_sync(&c->stat_sync, part_zero, nbm, 512, 1, s));
+        RUN(ptta_launch_bn_finalize(part_zero, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
+        const GemmArgs gf = gemm_h(feat_zero, lf, c->h2, 1);
+        RUN(ptta_launch_gemm(gf, s));
+        RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(gf), 512, 1, s));
+        RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(gf), Rw, 512, b2.gamma, b2.beta, 1e-5f, 0.1f, b2.rm, b2.rv, b2.nbt, b2.mean, b2.inv, b2.scale, b2.shift, s));
+        GemmArgs g3; g3.A = c->h2; g3.W = lp3.W; g3.bias = lp3.bias; g3.C = c->emb; g3.R = R; g3.K = 512; g3.N = 512; g3.pro = 1;
+        g3.pscale = b2.scale; g3.pshift = b2.shift; g3.x3 = 1; g3.Whi = lp3.Whi; g3.Wlo = lp3.Wlo; g3.Wil = lp3.Wil;
+        RUN(ptta_launch_gemm(g3, s));
+        // real pass last: its BatchNorm statistics are the ones the backward needs
+        RUN(ptta_stat_sync(&c->stat_sync, part_real, nbm, 512, 1, s));
+        RUN(ptta_launch_bn_finalize(part_real, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
+        RUN(ptta_launch_gemm(gemm_h(c->feat, l3, c->ref, 0), s));
         return 0;
     }
     if (c->fuse_heads && c->fused_pp_valid && c->x3 && !c->bf16 && !c->skip_dec3) {      // (the stage-2 head trainer needs proj's output itself)
@@ -986,6 +1038,21 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     ProfScope ps_(c, 6, s, ((double)c->Rg * (1024 + 544) + 16384.0 + 262144.0) * 4, (double)c->Rg * (16384.0 + 262144.0), 3);   // data gradient through proj once
     const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
     const int R = (int)c->Rg;
+    if (heads_v2_on(c)) {
+        // d ref -> d feat without the stored hidden: the GEMM recomputes h = x W0^T + b0 for the ReLU mask and the BatchNorm-backward sums and
+        // contracts the masked gradient (x gamma x invstd) with W0 inside the block (P: [column block 2][R][32]); the BatchNorm-backward
+        // correction terms are linear in x: d x = P[0] + P[1] - x M - u (heads.hip head_bwd_mat_kernel)
+        GemmArgs g; g.A = gref; g.W = l3.Wt; g.R = R; g.K = 512; g.N = 512; g.epi = 3;
+        g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part;
+        g.x3 = 1; g.Whi = l3.Wthi; g.Wlo = l3.Wtlo; g.Wil = l3.Wtil;
+        g.X = (const float*)c->feat; g.b0 = l0.bias; g.W0hi = l0.Whi; g.W0lo = l0.Wlo; g.W0thi = l0.Wthi; g.W0tlo = l0.Wtlo; g.P = c->headP;
+        RUN(ptta_launch_gemm(g, s));
+        RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
+        RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s,
+                                        nullptr, nullptr, c->head_k12, l0.bias, bn.mean));
+        RUN(ptta_launch_head_bwd_finish(c->head_k12, l0.W, c->headP, (const float*)c->feat, R, (float*)c->g_feat, s));
+        return 0;
+    }
     GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;
     g.eH = c->h1; g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part;
     g.x3 = c->x3; g.Whi = l3.Wthi; g.Wlo = l3.Wtlo; g.Wil = l3.Wtil;
@@ -1173,6 +1240,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     c->use_aux = (ax && strcmp(ax, "0") == 0) ? 0 : 1;
     { const char* sf = getenv("PTTA_SPLIT_FWD"); c->split_fwd = sf ? atoi(sf) : 0; }
     { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
+    { const char* hv = getenv("PTTA_HEADS_V2"); c->heads_v2 = (hv && strcmp(hv, "0") == 0) ? 0 : 1; }
     { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
       if (c->ablate) fprintf(stderr, "libptta_hip: PTTA_ABLATE=%d -- TIMING ABLATION: launches are skipped, every result of this handle is GARBAGE\n", c->ablate); }
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
@@ -1287,6 +1355,7 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
             hipLaunchKernelGGL(transpose_kernel, dim3(nblk(numel)), dim3(256), 0, s, src, l.Wt, l.N, l.K);
             ptta_split_weight(l.W, l.Whi, l.Wlo, l.Wil, numel, l.K, s);            // [N][K]
             ptta_split_weight(l.Wt, l.Wthi, l.Wtlo, l.Wtil, numel, l.N, s);        // transposed: [K][N]
+            if (base == "proj.0") ptta_pack_w0_frag(l.W, c->w0frag, s);
         } else if (is_b) { HIPCHK(hipMemcpyAsync(l.bias, src, (size_t)l.N * 4, hipMemcpyDeviceToDevice, s)); }
         else return c->fail("unknown key " + name, -2);
         return 0;
@@ -1800,6 +1869,7 @@ static int head_reload(ptta_ctx* c, int k, hipStream_t s) {
             hipLaunchKernelGGL(transpose_kernel, dim3(nblk(e.n)), dim3(256), 0, s, (const float*)e.p, l.Wt, l.N, l.K);
             ptta_split_weight(l.W, l.Whi, l.Wlo, l.Wil, e.n, l.K, s);
             ptta_split_weight(l.Wt, l.Wthi, l.Wtlo, l.Wtil, e.n, l.N, s);
+            if (base == "proj.0") ptta_pack_w0_frag(l.W, c->w0frag, s);
         } else HIPCHK(hipMemcpyAsync(l.bias, e.p, (size_t)e.n * 4, hipMemcpyDeviceToDevice, s));
     } else {
         BNorm& b = c->bn[base];

@@ -106,7 +106,26 @@ struct GemmArgs {
     float* part = nullptr;                     // [row_blocks][2][N] partial column statistics
     int x3 = 0; const bf16_t* Whi = nullptr; const bf16_t* Wlo = nullptr;   // bf16x3 arithmetic: pre-split [N][K] weight
     const bf16_t* Wil = nullptr;               // the same, interleaved per 32-k slice (one 128-B line per row and slice)
+    // ---- heads v2: the 512-wide hidden of proj = Linear(32,512) is never materialised (N = 512 kernel only) ----
+    // pro 3: A[r][k] = relu(bn(X[r][:] . W0[k][:] + b0[k])) computed by the staging waves on the matrix cores (K = 512 hidden units)
+    // epi 3: data gradient through proj.3 with the hidden RECOMPUTED for the ReLU mask / BatchNorm-backward sums, and the masked gradient
+    //        (x gamma x invstd) contracted with W0 inside the block: P[col block][r][32] instead of a 55-MB [R][512] store
+    const float* X = nullptr;                  // [R][32] fp32 input rows of the first Linear
+    const void* W0frag = nullptr;              // pro 3: W0 in MFMA A-fragment order (ptta_pack_w0_frag)
+    const float* b0 = nullptr;                 // [512] bias of the first Linear
+    const bf16_t* W0hi = nullptr; const bf16_t* W0lo = nullptr;       // epi 3: [512][32] bf16 planes
+    const bf16_t* W0thi = nullptr; const bf16_t* W0tlo = nullptr;     // epi 3: [32][512] bf16 planes (transposed)
+    float* P = nullptr;                        // epi 3: [2][R][32]
 };
+// W0 [512][32] fp32 -> [slice 16][kstep 2][hi, lo][lane 64] uint4 fragments (8 bf16: hidden unit 32*slice + (lane & 31), channels 16*kstep + 8*(lane >> 5) ...)
+void ptta_pack_w0_frag(const float* W0, void* frag, hipStream_t s);
+// Train-mode BatchNorm1d statistics of h = X W0^T + b0 WITHOUT computing h: per 256-row block the second moments of X (fp64), then per hidden
+// unit sum h = n b + w . sum x and sum h^2 = w^T S w + 2 b w . sum x + n b^2 -> partials in the layout ptta_launch_bn_finalize reduces
+// ([pass][block][2][512]); X holds `npass` consecutive groups of R rows.
+int ptta_head_moment_blocks(long R);
+int ptta_launch_head_moments(const float* X, long R, int npass, const float* W0, const float* b0, float* part, hipStream_t s);
+// after the epi-3 GEMM + ptta_launch_bn_bwd_finalize: dX = P[0] + P[1] - X M - u (M, u from the BatchNorm-backward means, derived per block in fp64)
+int ptta_launch_head_bwd_finish(const double* k12, const float* W0, const float* P, const float* X, long R, float* dX, hipStream_t s);
 void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, bf16_t* il, long n, int K, hipStream_t s);
 int ptta_gemm_row_blocks(int R);
 int ptta_gemm_part_blocks(const GemmArgs& a);
@@ -116,7 +135,8 @@ int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, con
                             float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
                             float* mean, float* invstd, float* scale, float* shift, hipStream_t s);
 int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
-                                float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr);
+                                float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr,
+                                double* k12 = nullptr, const float* b0 = nullptr, const float* mean = nullptr);    // k12: [k1 512 | k2 512] for ptta_launch_head_bwd_finish
 
 // ---- loss.hip ---------------------------------------------------------------------------------
 struct LossScalars;      // device-resident scalars, see loss.hip

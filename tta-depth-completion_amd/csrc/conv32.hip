@@ -30,7 +30,18 @@ struct Conv32P {
     const void* wpack2;          // lo fragments (bf16x3 arithmetic)
     Epi<T> epi;
     int B, Hin, Win, Hout, Wout;
+    int stagger;                 // persistent kernels, full grids (two resident blocks per CU): shader cycles by which the second half of the
+                                 // grid starts late, so that the two blocks of a CU run their memory and matrix phases in anti-phase
 };
+// Blocks of a persistent full-chip launch all start together and then stay in lock-step (load, split, MFMA, store): the memory system idles
+// during the matrix phases and the matrix cores during the memory phases.  Workgroups are dealt to the CUs in index
+// order, so block b and block b + gridDim/2 share a CU: the upper half waits `cycles` before its first load.
+__device__ __forceinline__ void stagger_start(int cycles) {
+    if (cycles > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)cycles) __builtin_amdgcn_s_sleep(16);
+    }
+}
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef float4 A; };
@@ -179,6 +190,7 @@ template <bool RELU, bool UP, bool MASK, bool ADD, bool TIMING = false, int ABL 
 __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) {
     unsigned long long T0 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0, dW = 0, dS = 0, dI = 0, dB1 = 0, dM = 0, dE = 0, dB2 = 0, Tpro = 0; int ntl = 0;
     CSTAMP(T0);
+    stagger_start(p.stagger);
     // one LDS array: [halo tile | lo weight fragments | (UP) half-resolution source window of the bilinear skip]
     constexpr int UPH = 6, UPW = 18;                      // an 8x32 output tile reads <= 5x17 source pixels
     __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * X3_STRIDE + 18 * 64 * 16 + (UP ? UPH * UPW * 128 : 0)];
@@ -472,6 +484,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
 template <int MODE, bool RELU, bool UP, bool MASK, bool ADD>
 __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float> p) {
     __shared__ __attribute__((aligned(16))) unsigned char wl_lds[2 * 18 * 64 * 16];     // [hi | lo][tap][k][lane] weight fragments
+    stagger_start(p.stagger);
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -579,6 +592,7 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
 template <bool RELU, bool MASK, bool ADD>
 __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<float> p) {
     constexpr int NPIX = S2_PH * S2_PW, NIT = (NPIX * 2 + 255) / 256;
+    stagger_start(p.stagger);
     __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * S2_STR + 18 * 64 * 16];
     unsigned char* const wl_lds = lds + NPIX * S2_STR;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -823,7 +837,7 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     p.epi.add1 = (const T*)a.add1; p.epi.add1_nb = a.add1_nb > 0 ? a.add1_nb : 1;
     p.epi.add2 = (const T*)a.add2; p.epi.add2_nb = a.add2_nb > 0 ? a.add2_nb : 1;
     p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = (T*)a.out_sum;
-    p.B = a.B; p.Hin = a.Hin; p.Win = a.Win;
+    p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.stagger = 0;
     if (MODE == CONV_S1) { p.Hout = a.Hin; p.Wout = a.Win; }
     else if (MODE == CONV_S2) { p.Hout = a.Hin / 2; p.Wout = a.Win / 2; }
     else { p.Hout = a.Hin * 2; p.Wout = a.Win * 2; }
@@ -835,6 +849,8 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
         static const int cap = getenv("PTTA_S1_BLOCKS") ? atoi(getenv("PTTA_S1_BLOCKS")) : 512;
         const int blocks = (int)(tiles > cap ? cap : tiles);     // 2 resident blocks per CU, persistent
+        static const int stag = getenv("PTTA_STAGGER") ? atoi(getenv("PTTA_STAGGER")) : 8000;      // measured on one box: 0 -> 8000 cycles: step -15 us
+        if (blocks == 512) p.stagger = stag;
         const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
         if (a.relu_in) launch_x3<true>(pf, flags, blocks, s); else launch_x3<false>(pf, flags, blocks, s);
         PTTA_CHECK_LAUNCH();
@@ -850,7 +866,9 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         if (MODE == CONV_S2 && !(flags & 1) && !s2_direct) {
             const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + S2_TH - 1) / S2_TH);
             const int tb = (int)(tiles < 512 ? tiles : 512);
-#define KS2_(R, M, A) hipLaunchKernelGGL((conv32_s2_lds_kernel<R, M, A>), dim3(tb), dim3(256), 0, s, pf)
+            static const int stag2 = getenv("PTTA_STAGGER_S2") ? atoi(getenv("PTTA_STAGGER_S2")) : 0;
+            Conv32P<float> pf2 = pf; if (tb == 512) pf2.stagger = stag2;
+#define KS2_(R, M, A) hipLaunchKernelGGL((conv32_s2_lds_kernel<R, M, A>), dim3(tb), dim3(256), 0, s, pf2)
             const bool m_ = flags & 2, a_ = flags & 4;
             if (a.relu_in) { if (m_) { if (a_) KS2_(true, true, true); else KS2_(true, true, false); } else { if (a_) KS2_(true, false, true); else KS2_(true, false, false); } }
             else { if (m_) { if (a_) KS2_(false, true, true); else KS2_(false, true, false); } else { if (a_) KS2_(false, false, true); else KS2_(false, false, false); } }
@@ -858,7 +876,9 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
             PTTA_CHECK_LAUNCH();
             return 0;
         }
-        if (a.relu_in) launch_direct_x3<MODE, true>(pf, flags, (int)blocks, s); else launch_direct_x3<MODE, false>(pf, flags, (int)blocks, s);
+        static const int stagd = getenv("PTTA_STAGGER_D") ? atoi(getenv("PTTA_STAGGER_D")) : 0;
+        Conv32P<float> pfd = pf; if (blocks == 512) pfd.stagger = stagd;
+        if (a.relu_in) launch_direct_x3<MODE, true>(pfd, flags, (int)blocks, s); else launch_direct_x3<MODE, false>(pfd, flags, (int)blocks, s);
         PTTA_CHECK_LAUNCH();
         return 0;
     }

@@ -20,6 +20,7 @@
 // register sets and unconditional loads keeps 11 loads in flight across the MFMAs, needs 234 VGPRs (two blocks per CU) and
 // measures the same: 25.73 vs 25.66 ms per NLSPN step, A/B on one box -- three non-overlapping blocks hide as much as two
 // overlapping ones, and neither is bound by the loads.)
+#include <cstdlib>
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
@@ -837,7 +838,8 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
         const long nitems = (long)x.B * x.H * nx;
         const int single = (x.C <= 32 && gy.C <= 32) ? 1 : 0;
         const int kcib = sq ? 2 : (wide_out ? 1 : 4);
-        const long cap = single ? 64 : 256;
+        static const int cap1 = getenv("PTTA_WGRAD_BLOCKS") ? atoi(getenv("PTTA_WGRAD_BLOCKS")) : 64;
+        const long cap = single ? (cap1 < 1 ? 1 : (cap1 > 256 ? 256 : cap1)) : 256;
         const int nblk = (int)(nitems < cap ? nitems : cap);
         hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
         const long n = 9L * x.C * gy.C + gy.C;

@@ -362,6 +362,185 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     }
 }
 
+// ---- the first two layers of an encoder stage in ONE launch: Conv2d(cin <= 3, 32) - ReLU - Conv2d(32, 32) (RGBEncoder.init / DepthEncoder.init,
+// network_exp_msg_chn_adapt.py:172-176, :218-222) ----
+// The 32-channel map between the two convolutions never makes a round trip through HBM as the second convolution's INPUT: a block
+// stages the (8 + 4) x (32 + 4) window of the cin input planes (<= 5 KB instead of a 43.5-KB 32-channel halo), computes the first
+// convolution for its (8 + 2) x (32 + 2) halo on the matrix cores exactly as conv_in_lds_kernel does (v_mfma_f32_32x32x2_f32 over
+// k = 9 cin, the same k order: bit-identical values, 1.33 x recomputed), applies the zero padding of the SECOND convolution, ReLU and the
+// bf16 hi / lo split on the accumulators (lane-quad transpose: four channels of one pixel per lane, 8-byte LDS stores) and then runs the
+// body of conv32_s1_x3_kernel on that LDS tile.  The pre-activation map is still written for the frames whose backward needs it as a
+// ReLU mask (`a_out`, frames b < a_nb: the real frames; not at all for the RGB encoder).  The input-plane window lives in the LDS
+// region of the bilinear-skip window (dead until the matrix phase); the next tile's window is prefetched into registers.
+struct FirstP {
+    Plane pl[3]; int zero_from_b;
+    const float* w1;             // [14][64] fp32 MFMA fragments of the first convolution (ptta_pack_conv_in)
+    const float* bias1;
+    float* a_out; int a_nb;
+};
+template <int CIN, bool UP>
+__global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> p, FirstP f) {
+    constexpr int UPH = 6, UPW = 18;
+    constexpr int K1 = 9 * CIN, NS = (K1 + 1) / 2;
+    constexpr int PL_W = 36, PL_H = 12, PLANE = PL_H * PL_W;
+    constexpr int PLSZ = (CIN * PLANE + 4) * 4, USZ = UP ? UPH * UPW * 128 : 0, AUX = USZ > PLSZ ? USZ : PLSZ;
+    constexpr int NPL = (CIN * PLANE + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * X3_STRIDE + 18 * 64 * 16 + AUX];
+    unsigned char* const wl_lds = lds + X3_PH * X3_PW * X3_STRIDE;
+    float* const up_lds = (float*)(wl_lds + 18 * 64 * 16);
+    float* const planes = up_lds;
+    stagger_start(p.stagger);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.Hout, W = p.Wout;
+    const int ntx = (W + 31) >> 5, nty = (H + X3_TH - 1) / X3_TH;
+    const long ntiles = (long)p.B * ntx * nty;
+    const float sy = up_scale(H >> 1, H), sx = up_scale(W >> 1, W);
+    auto tile_coords = [&](long tile, int& b, int& y0, int& x0) {
+        long t_ = tile;
+        const int ty = (int)(t_ % nty); t_ /= nty;
+        const int tx = (int)(t_ % ntx);
+        b = (int)(t_ / ntx); y0 = ty * X3_TH; x0 = tx << 5;
+    };
+    float pv[NPL];
+    auto load_planes = [&](long tile) {
+        int b, y0, x0;
+        tile_coords(tile, b, y0, x0);
+        const bool live = b < f.zero_from_b;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int idx = tid + 256 * k;
+            const int ci = idx / PLANE, r = idx - ci * PLANE;
+            const int py = r / PL_W, px = r - py * PL_W;
+            const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+            float v = 0.f;
+            if (idx < CIN * PLANE && live && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const Plane& pl = f.pl[ci];
+                v = pl.p[(size_t)(b % pl.nb) * pl.bstride + (size_t)gy * W + gx];
+                if (pl.norm) v = (v / pl.div - pl.mean) / pl.stdv;
+            }
+            pv[k] = v;
+        }
+    };
+    if (blockIdx.x < ntiles) load_planes(blockIdx.x);
+    uint4 wh[9][2];
+    float w1[NS];
+    {
+        const uint4* ph = (const uint4*)p.wpack;
+        const uint4* pl = (const uint4*)p.wpack2;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+#pragma unroll
+        for (int s_ = 0; s_ < NS; ++s_) w1[s_] = f.w1[s_ * 64 + lane];
+        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+    }
+    const float b1 = f.bias1[i];
+    const int tq = (i & 3) + 4 * h, c4 = 4 * (i >> 2);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b, y0, x0;
+        tile_coords(tile, b, y0, x0);
+        // ---- the input-plane window (prefetched) -> LDS ----
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) { const int idx = tid + 256 * k; if (idx < CIN * PLANE) planes[idx] = pv[k]; }
+        if (tid == 0) planes[CIN * PLANE] = 0.f;                       // the padded k of an odd 9 cin reads this word
+        lds_barrier();
+        // ---- first convolution on the halo: pixel p = 34 py + px of the (8 + 2) x (32 + 2) halo, 32 pixels per MFMA group ----
+        const bool amap = f.a_out != nullptr && b < f.a_nb;
+#pragma unroll 1
+        for (int g = wave; g < (X3_PH * X3_PW + 31) / 32; g += 4) {
+            const int pm = min(32 * g + i, X3_PH * X3_PW - 1);
+            const float* base = planes + (pm / X3_PW) * PL_W + (pm % X3_PW);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < NS; ++s_) {
+                const int k0 = 2 * s_, k1 = 2 * s_ + 1;
+                const int o0 = (k0 % CIN) * PLANE + ((k0 / CIN) / 3) * PL_W + (k0 / CIN) % 3;
+                const int o1 = (k1 < K1) ? (k1 % CIN) * PLANE + ((k1 / CIN) / 3) * PL_W + (k1 / CIN) % 3 : -1;
+                const float a = h ? (o1 >= 0 ? base[o1] : planes[CIN * PLANE]) : base[o0];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1[s_], acc, 0, 0, 0);
+            }
+            f32x16 t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t[r] = acc[r] + b1;
+            quad_transpose(t, lane);                                   // lane: channels c4 ... c4 + 3 of pixel 8 j + tq of the group
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pp = 32 * g + 8 * j + tq;
+                const int py = pp / X3_PW, px = pp - py * X3_PW;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                const bool inimg = pp < X3_PH * X3_PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                float4 v = make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
+                if (amap && inimg && py >= 1 && py <= X3_TH && px >= 1 && px <= 32)
+                    *(float4*)(f.a_out + (((size_t)b * H + gy) * W + gx) * 32 + c4) = v;
+                v = inimg ? relu4(v) : make_float4(0.f, 0.f, 0.f, 0.f);            // the second convolution's zero padding
+                uint2 hi, lo;
+                split2(v.x, v.y, hi.x, lo.x); split2(v.z, v.w, hi.y, lo.y);
+                if (pp < X3_PH * X3_PW) {
+                    *(uint2*)(lds + pp * X3_STRIDE + 2 * c4) = hi;
+                    *(uint2*)(lds + pp * X3_STRIDE + 64 + 2 * c4) = lo;
+                }
+            }
+        }
+        lds_barrier();                                                  // halo complete; the plane window is dead
+        if (tile + gridDim.x < ntiles) load_planes(tile + gridDim.x);
+        int uy0 = 0, ux0 = 0;
+        if (UP) {
+            const int Hu = H >> 1, Wu = W >> 1;
+            uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
+            const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
+#pragma unroll
+            for (int k = 0; k < (UPH * UPW * 8 + 255) / 256; ++k) {
+                const int idx = tid + 256 * k;
+                if (idx < UPH * UPW * 8) {
+                    const int q = idx & 7, pix = idx >> 3;
+                    const int r = pix / UPW, cc = pix - r * UPW;
+                    const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q),
+                                                     (__attribute__((address_space(3))) void*)(up_lds + (size_t)(256 * k + 64 * wave) * 4), 16, 0, 0);
+                }
+            }
+        }
+        // ---- second convolution, two rows per wave; the bilinear window lands during the first row's MFMAs and is awaited (by every
+        // wave: the barrier sits outside the row test) before the first epilogue ----
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr, y = y0 + row;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (y < H) {                                                // wave-uniform
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * X3_STRIDE + 16 * h;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first (as conv32_s1_x3_kernel)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                    }
+                    if (kx == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (UP && rr == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); }      // every wave's pieces of the window have landed
+            if (y < H) {
+                if (UP) epi_tile<float, false, false, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
+                else epi_tile<float, false, false, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+            }
+        }
+        lds_barrier();          // LDS reuse by the next tile (plane window over the bilinear window, halo)
+    }
+}
+
 // ---- the same convolution for SMALL maps (at most ~256 tiles of 8x32: the 1/4 ... 1/16-resolution layers, 18 launches of a step) ----
 // Those launches are one tile per block and their duration is a latency chain, not bandwidth (in-kernel stamps of the kernel above on a
 // one-tile launch: 26k cycles = weights -> LDS 5.9k + first loads 3.7k + split 2.6k + 108 MFMAs with LDS-fed lo fragments 6.1k + epilogue
@@ -897,6 +1076,35 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         if (blocks > cap) blocks = cap;
         if (a.relu_in) launch_mfma<T, MODE, true>(p, flags, (int)blocks, s); else launch_mfma<T, MODE, false>(p, flags, (int)blocks, s);
     }
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
+// Conv2d(cin, 32) - ReLU - Conv2d(32, 32) in one launch (conv32_s1_first_kernel): `a` describes the SECOND convolution as for
+// ptta_launch_conv32 (its `in` is ignored), `f` the first one as for ptta_launch_conv_in (its outputs are ignored); a_out: where the
+// first convolution's pre-activation map is still written (frames b < a_nb), or null.  Returns 1 when this form does not apply
+// (the caller then launches the two kernels): other storage / arithmetic modes, epilogues other than the bilinear skip, small maps.
+int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_out, int a_nb, hipStream_t s) {
+    if (a.bf16 || a.naive || !a.x3 || a.mode != CONV_S1 || !a.relu_in || a.mask || a.add1 || a.add2 || a.out_sum || f.bf16 || f.naive) return 1;
+    if (f.cin < 1 || f.cin > 3 || f.up || f.mask || f.add1 || f.B != a.B || f.H != a.Hin || f.W != a.Win) return 1;
+    const long tiles = (long)a.B * ((a.Win + 31) / 32) * ((a.Hin + X3_TH - 1) / X3_TH);
+    if (tiles <= 256) return 1;
+    Conv32P<float> p;
+    p.in = nullptr; p.in_nb = 1; p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
+    p.epi.bias = a.bias; p.epi.up = (const float*)a.up; p.epi.up_nb = a.up_nb > 0 ? a.up_nb : 1;
+    p.epi.mask = nullptr; p.epi.mask_nb = 1; p.epi.add1 = nullptr; p.epi.add1_nb = 1; p.epi.add2 = nullptr; p.epi.add2_nb = 1;
+    p.epi.out_raw = (float*)a.out_raw; p.epi.out_sum = nullptr;
+    p.B = a.B; p.Hin = p.Hout = a.Hin; p.Win = p.Wout = a.Win;
+    static const int stag = getenv("PTTA_STAGGER") ? atoi(getenv("PTTA_STAGGER")) : 8000;
+    const int blocks = (int)(tiles > 512 ? 512 : tiles);
+    p.stagger = blocks == 512 ? stag : 0;
+    FirstP q;
+    for (int c = 0; c < 3; ++c) { q.pl[c] = f.pl[c]; if (q.pl[c].nb < 1) q.pl[c].nb = 1; }
+    q.zero_from_b = f.zero_from_b; q.w1 = f.wfrag; q.bias1 = f.bias; q.a_out = (float*)a_out; q.a_nb = a_nb;
+#define KF_(C) do { if (a.up) hipLaunchKernelGGL((conv32_s1_first_kernel<C, true>), dim3(blocks), dim3(256), 0, s, p, q); \
+                    else hipLaunchKernelGGL((conv32_s1_first_kernel<C, false>), dim3(blocks), dim3(256), 0, s, p, q); } while (0)
+    if (f.cin == 1) KF_(1); else if (f.cin == 2) KF_(2); else KF_(3);
+#undef KF_
     PTTA_CHECK_LAUNCH();
     return 0;
 }

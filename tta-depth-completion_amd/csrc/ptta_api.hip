@@ -98,6 +98,7 @@ struct ptta_ctx {
     // from the second moments of the 32-channel input, the hidden is recomputed inside the 512x512 GEMMs (forward: A-operand producer;
     // backward: mask / BatchNorm-backward sums + the contraction with W0 inside the block)
     int heads_v2 = 1;
+    int fuse_first = 1;              // PTTA_FUSE_FIRST=0: the first two convolutions of an encoder stage as two launches
     void* w0frag = nullptr; float *hm_part = nullptr, *headP = nullptr; double* head_k12 = nullptr;
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
     // classes (include/ptta.h PTTA_PROF_*): 0/1 stride-1 32->32 conv with ReLU on load, maps above / up to 1/4 resolution; 2/3 the same
@@ -522,6 +523,28 @@ int conv32w(ptta_ctx* c, hipStream_t s, const ConvW* w, const float* bias, const
     return ptta_launch_conv32(a, s);
 }
 
+// Conv2d(cin <= 3, 32) - ReLU - Conv2d(32, 32) of an encoder stage's `init` block: ONE launch where the fused form applies
+// (conv32.hip conv32_s1_first_kernel; PTTA_FUSE_FIRST=0 or any other mode: the two launches).  `f`: the first convolution (out_raw = where
+// its pre-activation map goes), a_nb: how many leading frames of that map are still needed (the backward's ReLU mask), 0: none.
+int conv32_first(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvInArgs& f, int a_nb, int B, int H, int W, const E& e) {
+    auto it = c->l32.find(layer);
+    if (it == c->l32.end()) return c->fail("unknown 32->32 layer " + layer, -2);
+    const long tiles = (long)B * ((W + 31) / 32) * ((H + 7) / 8);
+    if (c->fuse_first >= (f.cin == 3 ? 2 : 1) && !(c->ablate & 3) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && !e.mask && !e.add1 && !e.add2 && !e.sum) {
+        Conv32Args a;
+        a.in = nullptr; a.in_nb = B; a.w = &it->second.f; a.bias = it->second.bias;
+        a.up = e.up; a.up_nb = e.up_nb; a.out_raw = e.raw;
+        a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 1; a.bf16 = 0; a.naive = 0; a.x3 = 1;
+        const double px = (double)B * H * W;
+        // (both layers' algorithmic bytes and MACs: the launch executes both)
+        ProfScope ps(c, 0, s, (px * (f.cin + 32) + 9.0 * f.cin * 32 + px * 64 + 9216) * c->es, px * 9.0 * (f.cin * 32 + 1024), 1);
+        const int rc = ptta_launch_conv32_first(a, f, a_nb > 0 ? f.out_raw : nullptr, a_nb, s);
+        return rc == 1 ? c->fail("conv32_first: fused form refused a case its caller accepted", -22) : rc;
+    }
+    RUN(conv_in_p(c, f, s));
+    return conv32(c, s, layer, false, CONV_S1, f.out_raw, B, B, H, W, true, e);
+}
+
 inline float* st_ptr(float* base, int C, int pass, int kind) { return base + ((size_t)pass * 4 + kind) * C; }   // kind: 0 mean 1 inv 2 scale 3 shift
 
 // conv1_rgb_meta forward.  1layer: one conv (:1065-1071).  2layers: Res_Conv(32,128) (:28-36); in training
@@ -696,9 +719,8 @@ int rgb_encoder(ptta_ctx* c, const float* image, int nb, int boff, int zero_from
         }
         a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = at(c->c0a, H1, W1);
         a.B = nb; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
-        RUN(conv_in_p(c, a, s));
+        RUN(conv32_first(c, s, "rgb_encoder.init.2", a, 0, nb, H1, W1, e_raw(at(c->c0, H1, W1))));       // (nothing reads the map in between)
     }
-    CV("rgb_encoder.init.2", false, CONV_S1, at(c->c0a, H1, W1), nb, nb, H1, W1, true, e_raw(at(c->c0, H1, W1)));
     CV("rgb_encoder.enc1.1", false, CONV_S2, at(c->c0, H1, W1), nb, nb, H1, W1, true, e_raw(at(c->c1a, H2, W2)));
     CV("rgb_encoder.enc1.3", false, CONV_S1, at(c->c1a, H2, W2), nb, nb, H2, W2, true, e_raw(at(c->c1, H2, W2)));
     CV("rgb_encoder.enc2.1", false, CONV_S2, at(c->c1, H2, W2), nb, nb, H2, W2, true, e_raw(at(c->c2a, H4, W4)));
@@ -845,9 +867,10 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
             a.pl[1].p = P1(c->p12, H2, W2); a.pl[1].nb = Bl; a.pl[1].bstride = (long)H2 * W2;
             a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = A(c->e2_0a, H2, W2);
             a.B = Bl; a.H = H2; a.W = W2; a.bf16 = c->bf16; a.naive = c->naive;
-            RUN(conv_in_p(c, a, st));
+            // (the pre-activation map is the backward's ReLU mask for the real frames only: batch indices below Nn of a launch that starts at b0 = 0)
+            E e; e.raw = A(c->e2_0, H2, W2); e.up = A(c->y4, H4, W4); e.up_nb = Bl;
+            RUN(conv32_first(c, st, "depth_encoder2.init.2", a, b0 == 0 ? Nn : 0, Bl, H2, W2, e));
         }
-        { E e; e.raw = A(c->e2_0, H2, W2); e.up = A(c->y4, H4, W4); e.up_nb = Bl; CR("depth_encoder2.init.2", false, CONV_S1, A(c->e2_0a, H2, W2), Bl, Bl, H2, W2, true, e); }
         CR("depth_encoder2.enc1.1", false, CONV_S2, A(c->e2_0, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->e2_1a, H4, W4)));
         { E e; e.raw = A(c->e2_1, H4, W4); e.up = A(c->y3, H8, W8); e.up_nb = Bl; CR("depth_encoder2.enc1.3", false, CONV_S1, A(c->e2_1a, H4, W4), Bl, Bl, H4, W4, true, e); }
         CR("depth_encoder2.enc2.1", false, CONV_S2, A(c->e2_1, H4, W4), Bl, Bl, H4, W4, true, raw(A(c->e2_2a, H8, W8)));
@@ -875,9 +898,9 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
             a.pl[1].p = P1(c->p11, H1, W1); a.pl[1].nb = Bl; a.pl[1].bstride = (long)H1 * W1;
             a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = A(c->e3_0a, H1, W1);
             a.B = Bl; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
-            RUN(conv_in_p(c, a, st));
+            E e; e.raw = A(c->e3_0, H1, W1); e.up = A(c->z4, H2, W2); e.up_nb = Bl;
+            RUN(conv32_first(c, st, "depth_encoder3.init.2", a, b0 == 0 ? Nn : 0, Bl, H1, W1, e));
         }
-        { E e; e.raw = A(c->e3_0, H1, W1); e.up = A(c->z4, H2, W2); e.up_nb = Bl; CR("depth_encoder3.init.2", false, CONV_S1, A(c->e3_0a, H1, W1), Bl, Bl, H1, W1, true, e); }
         CR("depth_encoder3.enc1.1", false, CONV_S2, A(c->e3_0, H1, W1), Bl, Bl, H1, W1, true, raw(A(c->e3_1a, H2, W2)));
         { E e; e.raw = A(c->e3_1, H2, W2); e.up = A(c->z3, H4, W4); e.up_nb = Bl; CR("depth_encoder3.enc1.3", false, CONV_S1, A(c->e3_1a, H2, W2), Bl, Bl, H2, W2, true, e); }
         CR("depth_encoder3.enc2.1", false, CONV_S2, A(c->e3_1, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->e3_2a, H4, W4)));
@@ -1241,6 +1264,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     { const char* sf = getenv("PTTA_SPLIT_FWD"); c->split_fwd = sf ? atoi(sf) : 0; }
     { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
     { const char* hv = getenv("PTTA_HEADS_V2"); c->heads_v2 = (hv && strcmp(hv, "0") == 0) ? 0 : 1; }
+    { const char* ff = getenv("PTTA_FUSE_FIRST"); c->fuse_first = ff ? atoi(ff) : 1; }      // 1: the depth encoders' init blocks, 2: the RGB encoder's too
     { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
       if (c->ablate) fprintf(stderr, "libptta_hip: PTTA_ABLATE=%d -- TIMING ABLATION: launches are skipped, every result of this handle is GARBAGE\n", c->ablate); }
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3

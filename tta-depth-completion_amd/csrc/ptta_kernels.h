@@ -46,6 +46,8 @@ struct ConvInArgs {      // planar fp32 (cin = 1..3) -> 32-channel NHWC
 void ptta_pack_conv_in(const float* src, int cin_total, int cin_first, int cin, int transpose_flip,
                        float* wfrag, float* wcanon, hipStream_t s);
 int ptta_launch_conv_in(const ConvInArgs& a, hipStream_t s);
+// the first two layers of an encoder stage in one launch (conv32.hip conv32_s1_first_kernel); returns 1 when not applicable
+int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_out, int a_nb, hipStream_t s);
 
 struct ConvOut1Args {    // 32-channel NHWC -> planar fp32, 1 channel
     const void* in = nullptr; int in_nb = 1;

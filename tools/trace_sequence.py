@@ -8,7 +8,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 adam = [i for i, n in enumerate(names) if n.startswith('adam_multi_kernel')]
-step = rows[adam[-2] + 1:adam[-1] + 1]
+# which step: argv[2] = index into the list of Adam launches (default: the last one -- in bench.py that is the kernel-by-kernel
+# profiling leg; e.g. 8 = a replayed step of the first timed block)
+k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) - 1
+step = rows[adam[k - 1] + 1:adam[k] + 1]
 t0 = int(step[0]['Start_Timestamp'])
 prev_end = t0
 tot = 0.0

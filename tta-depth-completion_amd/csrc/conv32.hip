@@ -550,11 +550,15 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
 // first wait.  Same products in the same order as conv32_s1_x3_kernel: bit-identical outputs.
 #define X3S_TH 4
 #define X3S_PH 6
-template <bool RELU, bool UP, bool MASK, bool ADD>
+template <bool RELU, bool UP, bool MASK, bool ADD, bool WLDS = true>
 __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> p) {
     constexpr int UPH = 4, UPW = 18;                      // a 4x32 output tile reads <= 3x17 source pixels of the half-resolution map
-    __shared__ __attribute__((aligned(16))) unsigned char lds[X3S_PH * X3_PW * X3_STRIDE + (UP ? UPH * UPW * 128 : 0)];
-    float* const up_lds = (float*)(lds + X3S_PH * X3_PW * X3_STRIDE);
+    // weights: ONE cooperative copy of the hi and lo fragments per block (36 KB, 9 x 16 B per thread) into LDS, read from there by every
+    // wave -- the per-wave register copies of round 3 moved 147 KB per block through the vector-memory path, which at ~11 B/clk/CU was
+    // most of a one-tile block's life
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3S_PH * X3_PW * X3_STRIDE + 2 * 18 * 64 * 16 + (UP ? UPH * UPW * 128 : 0)];
+    unsigned char* const w_lds = lds + X3S_PH * X3_PW * X3_STRIDE;
+    float* const up_lds = (float*)(w_lds + 2 * 18 * 64 * 16);
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -564,8 +568,8 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
     const float sy = up_scale(H >> 1, H), sx = up_scale(W >> 1, W);
     constexpr int NPIX = X3S_PH * X3_PW;                  // 204 halo pixels
     constexpr int NIT = (((NPIX + 7) / 8) * 32 + 255) / 256;      // (pixel, 8-channel group) items per thread
-    uint4 wh[9][2], wl[9][2];
     bool wloaded = false;
+    uint4 wh[WLDS ? 1 : 9][2], wl[WLDS ? 1 : 9][2];            // (A/B: the round-3 form, both fragment sets in registers per wave)
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ty = tile % nty, tx = (tile / nty) % ntx, b = tile / (nty * ntx);
         const int y0 = ty * X3S_TH, x0 = tx << 5;
@@ -583,13 +587,20 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
                 v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
             }
         }
-        if (!wloaded) {                                   // block-uniform; in flight together with the halo
+        uint4 wreg[9];
+        const bool wnow = !wloaded;                       // block-uniform; in flight together with the halo
+        if (wnow) {
             const uint4* ph = (const uint4*)p.wpack;
             const uint4* pl = (const uint4*)p.wpack2;
+            if (WLDS) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+                for (int q = 0; q < 9; ++q) { const int idx = tid + 256 * q; wreg[q] = idx < 18 * 64 ? ph[idx] : pl[idx - 18 * 64]; }
+            } else {
 #pragma unroll
-                for (int k = 0; k < 2; ++k) { wh[t][k] = ph[(t * 2 + k) * 64 + lane]; wl[t][k] = pl[(t * 2 + k) * 64 + lane]; }
+                for (int t = 0; t < (WLDS ? 1 : 9); ++t)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) { wh[t][k] = ph[(t * 2 + k) * 64 + lane]; wl[t][k] = pl[(t * 2 + k) * 64 + lane]; }
+            }
             wloaded = true;
         }
         int uy0 = 0, ux0 = 0;
@@ -619,6 +630,10 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
                 *(uint4*)(dst + 64) = lo;
             }
         }
+        if (wnow && WLDS) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) *(uint4*)(w_lds + (size_t)(tid + 256 * q) * 16) = wreg[q];
+        }
         lds_barrier();
         const int y = y0 + wave;
         if (y < H) {                                      // wave-uniform
@@ -633,8 +648,8 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
                 for (int k = 0; k < 2; ++k) {
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
                     const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, wl[tap][k]);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, WLDS ? *(const uint4*)(w_lds + ((tap * 2 + k) * 64 + lane) * 16) : wh[WLDS ? 0 : tap][k]);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, WLDS ? *(const uint4*)(w_lds + ((18 + tap * 2 + k) * 64 + lane) * 16) : wl[WLDS ? 0 : tap][k]);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first (as conv32_s1_x3_kernel)
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
@@ -973,7 +988,9 @@ static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_
         if (!small_off && tiles8 <= 256) {
             const long t4 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3S_TH - 1) / X3S_TH);
             const int nb4 = (int)(t4 > 1024 ? 1024 : t4);
-#define KS_(U, M, A) hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, U, M, A>), dim3(nb4), dim3(256), 0, s, p)
+            static const int wlds = getenv("PTTA_SMALL_WLDS") ? atoi(getenv("PTTA_SMALL_WLDS")) : 0;      // one cooperative LDS copy of the weights instead of per-wave registers: measured neutral (1.708 vs 1.703 ms)
+#define KS_(U, M, A) do { if (wlds) hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, U, M, A, true>), dim3(nb4), dim3(256), 0, s, p); \
+                          else hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, U, M, A, false>), dim3(nb4), dim3(256), 0, s, p); } while (0)
             switch (flags) {
                 case 0: KS_(false, false, false); break; case 1: KS_(true, false, false); break;
                 case 2: KS_(false, true, false); break;  case 3: KS_(true, true, false); break;

@@ -98,7 +98,20 @@ struct ptta_ctx {
     // from the second moments of the 32-channel input, the hidden is recomputed inside the 512x512 GEMMs (forward: A-operand producer;
     // backward: mask / BatchNorm-backward sums + the contraction with W0 inside the block)
     int heads_v2 = 1;
-    int fuse_first = 1;              // PTTA_FUSE_FIRST=0: the first two convolutions of an encoder stage as two launches
+    int fuse_first = 1;
+    // ---- the fused step as FOUR graphs on two streams (PTTA_DUAL=0: one graph).  The grad pass (real frames) and the no-grad proxy pass
+    // (zero image) of _rgbd_meta_contrast share nothing downstream of the meta layer until the loss, and about half of their ~60 launches
+    // are low-resolution layers that leave the chip half empty.  Forks INSIDE one hipGraph are replayed interleaved on one queue (measured
+    // slower); separate graphs on separate streams do overlap (the frame-pipelining prefix).  So: phase A (what
+    // both passes need: meta layer, and the prefix when it was not run ahead) on the caller's stream; phase R (real frames: decoder 1 ...
+    // encoder 3, proj head, decoder 3) on the caller's stream BESIDE phase P (proxy frames: decoder 1 ... encoder 3, proj + pred heads) on
+    // a stream of its own; phase L (loss, backward, Adam) after both.  Same kernels on the same data: bit-identical results.
+    int dual_on = 0;
+    int fwd_phase = 0;               // 0: the whole forward (one stream); 1 / 2 / 3: phase A / R / P only
+    struct DualG { hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; };
+    DualG dgA[2][2], dgR[2], dgP[2], dgL[4][2];      // A: [prefix run ahead?][buffer set]; R, P: [set]; L: [graph key][set]
+    hipStream_t dual_stream = nullptr;
+    hipEvent_t ev_dA = nullptr, ev_dP = nullptr;              // PTTA_FUSE_FIRST=0: the first two convolutions of an encoder stage as two launches
     void* w0frag = nullptr; float *hm_part = nullptr, *headP = nullptr; double* head_k12 = nullptr;
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
     // classes (include/ptta.h PTTA_PROF_*): 0/1 stride-1 32->32 conv with ReLU on load, maps above / up to 1/4 resolution; 2/3 the same
@@ -171,6 +184,9 @@ struct ptta_ctx {
                 if (rgraph[k][p]) { (void)hipGraphDestroy(rgraph[k][p]); rgraph[k][p] = nullptr; }
             }
         }
+        auto drop = [](DualG& d) { if (d.e) { (void)hipGraphExecDestroy(d.e); d.e = nullptr; } if (d.g) { (void)hipGraphDestroy(d.g); d.g = nullptr; } };
+        if (dual_stream) (void)hipStreamSynchronize(dual_stream);
+        for (int p = 0; p < 2; ++p) { drop(dgA[0][p]); drop(dgA[1][p]); drop(dgR[p]); drop(dgP[p]); for (int k = 0; k < 4; ++k) drop(dgL[k][p]); }
         for (int p = 0; p < 2; ++p) {
             if (pexec[p]) { (void)hipGraphExecDestroy(pexec[p]); pexec[p] = nullptr; }
             if (pgraph[p]) { (void)hipGraphDestroy(pgraph[p]); pgraph[p] = nullptr; }
@@ -350,6 +366,10 @@ void build_registry(ptta_ctx* c) {
         BNorm n; n.gamma = c->falloc(512); n.beta = c->falloc(512);
         n.mean = c->falloc(512); n.inv = c->falloc(512); n.scale = c->falloc(512); n.shift = c->falloc(512);
         c->bn[std::string(p) + ".1"] = n;
+        if (std::string(p) == "proj") {      // state of proj.1 for the proxy pass while the two passes run side by side (gamma / beta shared)
+            BNorm z = n; z.mean = c->falloc(512); z.inv = c->falloc(512); z.scale = c->falloc(512); z.shift = c->falloc(512);
+            c->bn["proj.1z"] = z;
+        }
     }
 }
 
@@ -689,9 +709,11 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
     return 0;
 }
 
-int heads_forward(ptta_ctx* c, hipStream_t s);
+int heads_forward(ptta_ctx* c, hipStream_t s, int part = 0);
 static int pipe_quiesce(ptta_ctx* c);
 static void pipe_use(ptta_ctx* c, int p);
+static bool dual_ok(const ptta_ctx* c);
+static int dual_step(ptta_ctx* c, int key, int set, bool prefix_done, hipStream_t s);
 // a full forward (ptta_forward_eval / ptta_forward_train) has written an arbitrary frame's prefix into set p: whatever was prepared into it
 // or adapted from it is gone.  (Set p is pipe_last; when a prefix of the SAME frame was kept there for another step -- inner_iter > 1 --
 // the step that follows recomputes it in line.)
@@ -800,7 +822,7 @@ int stage1_independent(ptta_ctx* c, int B2, hipStream_t s) {
 // One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half;
 // the MLP heads (which only need depth_encoder3's output) run on the auxiliary stream beside decoder 3.
 int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
-    hipStream_t s2 = train ? c->aux(s) : nullptr;
+    hipStream_t s2 = (train && c->fwd_phase == 0) ? c->aux(s) : nullptr;
     const int Nn = c->Nn, B2 = train ? 2 * Nn : Nn;
     const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
@@ -817,13 +839,17 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         RUN(enc1_head(s2));
         HIPCHK(hipEventRecord(c->ev_join, s2));
     }
+    const int ph = train ? c->fwd_phase : 0;              // the step as four graphs: 1 = what both passes need, 2 = real frames, 3 = proxy frames
+    if (ph < 2) {
     if (!c->skip_prefix) RUN(rgb_encoder(c, image, Nn, 0, Nn, s));
     RUN(meta_forward(c, train, B2, s));
 
     // ---- stage 1/4 (:487-489): depth-only encoder shared by both passes ----
     if (early) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); else if (!c->skip_prefix) RUN(enc1_head(s));
-    const bool split = train && s2 && (c->split_fwd & 1);
-    if (!c->skip_prefix && !split) RUN(stage1_independent(c, B2, s));
+    }
+    const bool split = train && s2 && (c->split_fwd & 1) && ph == 0;
+    if (ph < 2 && !c->skip_prefix && !split) RUN(stage1_independent(c, B2, s));
+    if (ph == 1) return 0;
     if (split) {                     // (diagnostic split of the two passes: the head of decoder 1 stays inside each pass's chain)
         { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
           CV("depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, B2, H8, W8, true, e); }
@@ -843,7 +869,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         auto raw = [](void* r) { E e; e.raw = r; return e; };
 #define CR(...) RUN(conv32(c, st, __VA_ARGS__))
         // decoder 1 (DepthDecoder.forward :296-311); its first three launches are in stage1_independent() unless the passes are split
-        if (Bl != B2) {
+        if (split) {
         CR("depth_decoder1.dec2.1", false, CONV_T2, A(c->y2, H16, W16), Bl, Bl, H16, W16, true, raw(A(c->t1, H8, W8)));
         { E e; e.raw = A(c->y3, H8, W8); e.sum = A(c->s1_1, H8, W8); e.add1 = A(c->y1, H8, W8); e.add1_nb = Bl;
           CR("depth_decoder1.dec2.3", false, CONV_S1, A(c->t1, H8, W8), Bl, Bl, H8, W8, true, e); }
@@ -909,7 +935,14 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
 #undef CR
         return 0;
     };
-    if (split) {
+    if (ph == 3) {                   // proxy frames: decoder 1 ... encoder 3, then emb = pred(proj(feat_zero))
+        RUN(region(s, Nn, Nn));
+        return heads_forward(c, s, 1);
+    }
+    if (ph == 2) {                   // real frames: decoder 1 ... encoder 3, ref = proj(feat), then decoder 3 (below)
+        RUN(region(s, 0, Nn));
+        RUN(heads_forward(c, s, 2));
+    } else if (split) {
         // real frames on s, proxy frames on s2; the heads (both halves' depth_encoder3 outputs) follow on s2 beside decoder 3
         HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
         RUN(region(s, 0, Nn));
@@ -943,7 +976,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     }
     }
 #undef CV
-    if (train) {
+    if (train && ph == 0) {
         if (s2) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
         else RUN(heads_forward(c, s));
     }
@@ -971,7 +1004,7 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
     return 0;
 }
 
-int heads_forward(ptta_ctx* c, hipStream_t s) {
+int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2 only): 0 both passes, 1 the proxy pass, 2 the real pass
     if (c->ablate & 4) return 0;      // timing ablation only
     // profiling class 6: 3 applications of Linear(32,512) / Linear(512,512) pairs (proj on both passes, pred on the proxy pass; proj.3 and
     // pred.0 run merged) = per row 2 x (32 + 512) + 4 x (512 + 512) elements by SURVEY 8d's rule as the REFERENCE executes it (6 linears)
@@ -996,39 +1029,51 @@ int heads_forward(ptta_ctx* c, hipStream_t s) {
         const Lin& l0 = c->fc["proj.0"]; const Lin& lf = c->fused_pp; const Lin& lp3 = c->fc["pred.3"]; const Lin& l3 = c->fc["proj.3"];
         BNorm& b1 = c->bn["proj.1"]; BNorm& b2 = c->bn["pred.1"];
         const int R = (int)c->Rg, Rw = R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), nbm = ptta_gemm_row_blocks(R);
-        {   // BatchNorm1d batch statistics of proj.0's output for BOTH passes: the K = 32 GEMM with its column sums and NO store -- one launch
+        float* part_real = c->hm_part; float* part_zero = c->hm_part + (size_t)nbm * 2 * 512;
+        {   // BatchNorm1d batch statistics of proj.0's output: the K = 32 GEMM with its column sums and NO store -- both passes in one launch
             // over rows [0, R) = real frames, [R, 2R) = proxy frames when the 128-row blocks do not straddle the two, else one per pass
             GemmArgs g; g.A = c->feat; g.W = l0.W; g.bias = l0.bias; g.R = 2 * R; g.K = 32; g.N = 512; g.epi = 4; g.part = c->hm_part;
             g.x3 = 1; g.Whi = l0.Whi; g.Wlo = l0.Wlo; g.Wil = l0.Wil;
-            if (R % 128 == 0) RUN(ptta_launch_gemm(g, s));
+            if (part == 0 && R % 128 == 0) RUN(ptta_launch_gemm(g, s));
             else {
-                g.R = R; RUN(ptta_launch_gemm(g, s));
-                g.A = feat_zero; g.part = c->hm_part + (size_t)nbm * 2 * 512; RUN(ptta_launch_gemm(g, s));
+                g.R = R;
+                if (part != 1) RUN(ptta_launch_gemm(g, s));
+                g.A = feat_zero; g.part = part_zero;
+                if (part != 2) RUN(ptta_launch_gemm(g, s));
             }
         }
-        float* part_real = c->hm_part; float* part_zero = c->hm_part + (size_t)nbm * 2 * 512;
-        auto gemm_h = [&](const void* x, const Lin& w, float* out, int epi) {
-            GemmArgs g; g.X = (const float*)x; g.W0frag = c->w0frag; g.b0 = l0.bias; g.pscale = b1.scale; g.pshift = b1.shift; g.pro = 3;
+        // part != 0: the two passes run side by side on two streams -> the proxy pass keeps its own BatchNorm state (proj.1z) and neither
+        // finalize touches the running statistics (ptta_launch_bn_running2 applies both updates in the reference's order afterwards)
+        BNorm& bz = part == 0 ? b1 : c->bn["proj.1z"];
+        auto gemm_h = [&](const void* x, const BNorm& bn_, const Lin& w, float* out, int epi) {
+            GemmArgs g; g.X = (const float*)x; g.W0frag = c->w0frag; g.b0 = l0.bias; g.pscale = bn_.scale; g.pshift = bn_.shift; g.pro = 3;
             g.W = w.W; g.bias = w.bias; g.C = out; g.R = R; g.K = 512; g.N = 512; g.epi = epi; g.part = c->bn_part;
             g.x3 = 1; g.Whi = w.Whi; g.Wlo = w.Wlo; g.Wil = w.Wil;
             return g;
         };
-        // proxy pass first: the running statistics are updated in the reference's order (proj(feat_zero), then proj(feat), :551-554)
-        RUN(ptta_stat_sync(&c->stat_sync, part_zero, nbm, 512, 1, s));
-        RUN(ptta_launch_bn_finalize(part_zero, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
-        const GemmArgs gf = gemm_h(feat_zero, lf, c->h2, 1);
-        RUN(ptta_launch_gemm(gf, s));
-        RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(gf), 512, 1, s));
-        RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(gf), Rw, 512, b2.gamma, b2.beta, 1e-5f, 0.1f, b2.rm, b2.rv, b2.nbt, b2.mean, b2.inv, b2.scale, b2.shift, s));
-        GemmArgs g3; g3.A = c->h2; g3.W = lp3.W; g3.bias = lp3.bias; g3.C = c->emb; g3.R = R; g3.K = 512; g3.N = 512; g3.pro = 1;
-        g3.pscale = b2.scale; g3.pshift = b2.shift; g3.x3 = 1; g3.Whi = lp3.Whi; g3.Wlo = lp3.Wlo; g3.Wil = lp3.Wil;
-        RUN(ptta_launch_gemm(g3, s));
-        // real pass last: its BatchNorm statistics are the ones the backward needs
-        RUN(ptta_stat_sync(&c->stat_sync, part_real, nbm, 512, 1, s));
-        RUN(ptta_launch_bn_finalize(part_real, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
-        RUN(ptta_launch_gemm(gemm_h(c->feat, l3, c->ref, 0), s));
+        if (part != 2) {
+            // proxy pass first: the running statistics are updated in the reference's order (proj(feat_zero), then proj(feat), :551-554)
+            RUN(ptta_stat_sync(&c->stat_sync, part_zero, nbm, 512, 1, s));
+            RUN(ptta_launch_bn_finalize(part_zero, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, part ? nullptr : b1.rm, part ? nullptr : b1.rv, part ? nullptr : b1.nbt,
+                                        bz.mean, bz.inv, bz.scale, bz.shift, s));
+            const GemmArgs gf = gemm_h(feat_zero, bz, lf, c->h2, 1);
+            RUN(ptta_launch_gemm(gf, s));
+            RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(gf), 512, 1, s));
+            RUN(ptta_launch_bn_finalize(c->bn_part, ptta_gemm_part_blocks(gf), Rw, 512, b2.gamma, b2.beta, 1e-5f, 0.1f, b2.rm, b2.rv, b2.nbt, b2.mean, b2.inv, b2.scale, b2.shift, s));
+            GemmArgs g3; g3.A = c->h2; g3.W = lp3.W; g3.bias = lp3.bias; g3.C = c->emb; g3.R = R; g3.K = 512; g3.N = 512; g3.pro = 1;
+            g3.pscale = b2.scale; g3.pshift = b2.shift; g3.x3 = 1; g3.Whi = lp3.Whi; g3.Wlo = lp3.Wlo; g3.Wil = lp3.Wil;
+            RUN(ptta_launch_gemm(g3, s));
+        }
+        if (part != 1) {
+            // real pass last: its BatchNorm statistics are the ones the backward needs
+            RUN(ptta_stat_sync(&c->stat_sync, part_real, nbm, 512, 1, s));
+            RUN(ptta_launch_bn_finalize(part_real, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, part ? nullptr : b1.rm, part ? nullptr : b1.rv, part ? nullptr : b1.nbt,
+                                        b1.mean, b1.inv, b1.scale, b1.shift, s));
+            RUN(ptta_launch_gemm(gemm_h(c->feat, b1, l3, c->ref, 0), s));
+        }
         return 0;
     }
+    if (part != 0) return c->fail("heads_forward: split passes need heads v2", -22);
     if (c->fuse_heads && c->fused_pp_valid && c->x3 && !c->bf16 && !c->skip_dec3) {      // (the stage-2 head trainer needs proj's output itself)
         // emb = pred.3(relu(bn(pred.0(proj.3(relu(bn(proj.0 x))))))) with proj.3 / pred.0 merged into one GEMM (ptta_ctx::fused_pp)
         const Lin& l0 = c->fc["proj.0"]; const Lin& lf = c->fused_pp; const Lin& l3 = c->fc["pred.3"];
@@ -1177,6 +1222,7 @@ int push_hparams(ptta_ctx* c, hipStream_t s) {
 int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool train, hipStream_t s) {
     for (auto& ad : c->adapted) if (!ad.p) return c->fail("adapted parameter " + ad.name + " not bound (ptta_bind_adapted)", -3);
     const float* img = image; const float* sp = sparse;
+    if (train && c->fwd_phase >= 2) return backbone(c, img, train, s);          // (phases R / P of the four-graph step: never with padding)
     if (c->dual) {
         hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * 3 * c->Hp * c->Wp)), dim3(256), 0, s, image, c->img_pad, c->N, 3, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr, c->img_norm);
         hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * c->Hp * c->Wp)), dim3(256), 0, s, sparse, c->sp_pad, c->N, 1, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
@@ -1264,7 +1310,8 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     { const char* sf = getenv("PTTA_SPLIT_FWD"); c->split_fwd = sf ? atoi(sf) : 0; }
     { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
     { const char* hv = getenv("PTTA_HEADS_V2"); c->heads_v2 = (hv && strcmp(hv, "0") == 0) ? 0 : 1; }
-    { const char* ff = getenv("PTTA_FUSE_FIRST"); c->fuse_first = ff ? atoi(ff) : 1; }      // 1: the depth encoders' init blocks, 2: the RGB encoder's too
+    { const char* ff = getenv("PTTA_FUSE_FIRST"); c->fuse_first = ff ? atoi(ff) : 1; }
+    { const char* du = getenv("PTTA_DUAL"); c->dual_on = (du && strcmp(du, "1") == 0) ? 1 : 0; }      // measured neutral: off by default      // 1: the depth encoders' init blocks, 2: the RGB encoder's too
     { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
       if (c->ablate) fprintf(stderr, "libptta_hip: PTTA_ABLATE=%d -- TIMING ABLATION: launches are skipped, every result of this handle is GARBAGE\n", c->ablate); }
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
@@ -1289,6 +1336,7 @@ void ptta_destroy(ptta_handle h) {
         (void)hipStreamDestroy(h->pre_stream); (void)hipEventDestroy(h->ev_entry);
         for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(h->ev_prefix[p]); (void)hipEventDestroy(h->ev_rest[p]); }
     }
+    if (h->dual_stream) { (void)hipStreamDestroy(h->dual_stream); (void)hipEventDestroy(h->ev_dA); (void)hipEventDestroy(h->ev_dP); }
     if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_real); }
     for (void* p : h->allocs) if (p) (void)hipFree(p);
     for (auto& pc : h->prof) for (auto& e : pc.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1613,10 +1661,22 @@ int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream 
     return 0;
 }
 
+static int step_tail(ptta_handle c, const float* loss_image, const float* sparse, const float* validity, ptta_stream s_, bool passes_were_split);
 static int step_body(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
                      ptta_stream s_) {
-    hipStream_t s = (hipStream_t)s_;
     RUN(ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_));
+    return step_tail(c, loss_image, sparse, validity, s_, false);
+}
+// loss + backward + (gradient all-reduce) + Adam: everything of the step behind the forward
+static int step_tail(ptta_handle c, const float* loss_image, const float* sparse, const float* validity, ptta_stream s_, bool passes_were_split) {
+    hipStream_t s = (hipStream_t)s_;
+    if (passes_were_split) {
+        // the two forward passes ran side by side and left proj.1's running statistics alone: both momentum updates now, proxy pass first
+        // (proj(feat_zero) precedes proj(feat) in the reference, network_exp_msg_chn_adapt.py:551-554)
+        BNorm& b1 = c->bn["proj.1"];
+        const int nbm = ptta_gemm_row_blocks((int)c->Rg);
+        REST_(s, ptta_launch_bn_running2(c->hm_part + (size_t)nbm * 2 * 512, c->hm_part, nbm, (int)c->Rg, 512, 0.1f, b1.rm, b1.rv, b1.nbt, s));
+    }
     // validity == NULL: where(sparse > 0, 1, sparse) is evaluated inside the loss kernels; the loss finalisation runs inside
     // the two gradient kernels (no 1-block launch between forward and backward)
     REST_(s, ptta_launch_loss_forward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
@@ -1646,6 +1706,12 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
         HIPCHK(hipMemcpyAsync(c->in_sparse, sparse, pbytes, hipMemcpyDeviceToDevice, s));
         if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
         if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
+        RUN(ensure_fused_heads(c, s));
+        if (dual_ok(c)) {
+            RUN(ensure_proxy_rgb(c, c->in_image, s));
+            RUN(ensure_adam_table(c, s));
+            RUN(dual_step(c, key, c->cur_set, false, s));
+        } else {
         if (!c->gexec[key]) {
             RUN(ensure_proxy_rgb(c, c->in_image, s));        // outside the capture: the graph holds the real-frame encoder only
             RUN(ensure_adam_table(c, s));
@@ -1661,6 +1727,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
             HIPCHK(hipGraphInstantiate(&c->gexec[key], g, nullptr, nullptr, 0));
         }
         HIPCHK(hipGraphLaunch(c->gexec[key], s));
+        }
         if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));
         HIPCHK(hipEventRecord(c->ev_replay, s));
         c->fwd_valid = true;
@@ -1737,6 +1804,47 @@ static int prefix_body(ptta_ctx* c, const float* image, const float* sparse, hip
     return stage1_independent(c, 2 * c->Nn, s);
 }
 template <class F>
+static int pipe_capture(ptta_ctx* c, hipGraph_t* g_out, hipGraphExec_t* e_out, F body);
+static bool dual_ok(const ptta_ctx* c) {
+    return c->dual_on && c->use_graph && !c->prof_on && !c->dual && !c->stat_sync.on() && !c->grad_comm && !c->naive && !c->bf16 && !c->split_fwd &&
+           !c->ablate && heads_v2_on(c);
+}
+// One step as four graphs on two streams (ptta_ctx::dual_on): A on `s`, then R on `s` beside P on the handle's second stream, then L on `s`.
+// The inputs are already staged at the fixed addresses of buffer set `set` (the members point at it); prefix_done: the parameter-independent
+// prefix of this frame was computed ahead (ptta_step_pipelined).
+static int dual_step(ptta_ctx* c, int key, int set, bool prefix_done, hipStream_t s) {
+    if (!c->dual_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->dual_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_dA, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_dP, hipEventDisableTiming));
+    }
+    ptta_ctx::DualG& A = c->dgA[prefix_done ? 1 : 0][set]; ptta_ctx::DualG& R = c->dgR[set]; ptta_ctx::DualG& P = c->dgP[set]; ptta_ctx::DualG& L = c->dgL[key][set];
+    const bool sp0 = c->skip_prefix;
+    auto fwd = [&](int phase, ptta_ctx::DualG& d) -> int {
+        if (d.e) return 0;
+        c->fwd_phase = phase; c->skip_prefix = prefix_done;
+        const int rc = pipe_capture(c, &d.g, &d.e, [&](hipStream_t cs) { return forward_common(c, c->in_image, c->in_sparse, true, cs); });
+        c->fwd_phase = 0; c->skip_prefix = sp0;
+        return rc;
+    };
+    RUN(fwd(1, A)); RUN(fwd(2, R)); RUN(fwd(3, P));
+    if (!L.e) {
+        c->fwd_valid = true;
+        RUN(pipe_capture(c, &L.g, &L.e, [&](hipStream_t cs) {
+            return step_tail(c, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse, (key & 2) ? c->in_validity : nullptr, (ptta_stream)cs, true);
+        }));
+    }
+    HIPCHK(hipGraphLaunch(A.e, s));
+    HIPCHK(hipEventRecord(c->ev_dA, s));
+    HIPCHK(hipStreamWaitEvent(c->dual_stream, c->ev_dA, 0));
+    HIPCHK(hipGraphLaunch(P.e, c->dual_stream));
+    HIPCHK(hipEventRecord(c->ev_dP, c->dual_stream));
+    HIPCHK(hipGraphLaunch(R.e, s));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_dP, 0));
+    HIPCHK(hipGraphLaunch(L.e, s));
+    return 0;
+}
+template <class F>
 static int pipe_capture(ptta_ctx* c, hipGraph_t* g_out, hipGraphExec_t* e_out, F body) {
     if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
     HIPCHK(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -1802,6 +1910,8 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     P.prepared = false; P.prep_token = 0;
     if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
     if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
+    if (dual_ok(c)) RUN(dual_step(c, key, p, true, s));
+    else {
     if (!c->rexec[key][p]) {
         c->skip_prefix = true;
         const int rc = pipe_capture(c, &c->rgraph[key][p], &c->rexec[key][p], [&](hipStream_t cs) {
@@ -1811,6 +1921,7 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         if (rc) return rc;
     }
     HIPCHK(hipGraphLaunch(c->rexec[key][p], s));
+    }
     HIPCHK(hipEventRecord(c->ev_rest[p], s));
     P.rest_recorded = true; c->pipe_last = p; P.last_token = frame_token ? frame_token : ~(uint64_t)0;      // (an unnamed frame is still the one ptta_forward_eval_last scores)
     if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));

@@ -136,6 +136,8 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s);
 int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* beta,
                             float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
                             float* mean, float* invstd, float* scale, float* shift, hipStream_t s);
+int ptta_launch_bn_running2(const float* part_a, const float* part_b, int row_blocks, int R, int N, float momentum, float* running_mean,
+                            float* running_var, long long* nbt, hipStream_t s);
 int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
                                 float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr,
                                 double* k12 = nullptr, const float* b0 = nullptr, const float* mean = nullptr);    // k12: [k1 512 | k2 512] for ptta_launch_head_bwd_finish

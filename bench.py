@@ -353,8 +353,23 @@ def costdcnet_shared(args, rank, world, dist):
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 3)):
         shared_parameter_step(eng, data[i % 2][1], data[i % 2][2], loss_image=data[i % 2][0])
+    # start-up self-check of the shared-parameter protocol: after the warm-up steps (different frames on every rank, one statistics exchange
+    # per BatchNorm and one gradient all-reduce per step) every rank must hold BITWISE the parameters of rank 0
+    flat = torch.cat([k[0].reshape(-1) for k in keep])
+    same = True
+    if dist is not None:
+        ref = flat.clone() if dist.get_backend() == 'nccl' else flat.cpu().clone()
+        dist.broadcast(ref, 0)
+        ok = torch.tensor([1 if torch.equal(ref.to(flat.device), flat) else 0], device=ref.device, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        same = bool(ok.item())
+    if rank == 0:
+        print('costdcnet-shared: rccl_ranks=%d exchange=%s adapted parameters bitwise equal across ranks after %d steps: %s'
+              % (world, mode, max(args.warmup, 3), same), file=sys.stderr)
+    if not same:
+        raise SystemExit('costdcnet-shared: the ranks hold different adapted parameters after the warm-up steps')
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -378,7 +393,74 @@ def costdcnet_shared(args, rank, world, dist):
                                    'BatchNorm1d / the sparse encoder\'s, 116 listed entries = 112 tensors, src/costdcnet_model_adapt.py:364-366)',
                        'parallelism': 'dp%d: SyncBatchNorm statistics exchange per BatchNorm (forward and backward) + one flat gradient all-reduce '
                                       '(11,888 floats) per step' % world,
-                       'exchange': mode, 'finite': finite}}))
+                       'exchange': mode, 'rccl_ranks': world, 'params_bitwise_equal_across_ranks_after_warmup': same, 'finite': finite}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def msgchn_multi_stream(args, rank, world, dist, affinity):
+    """Config 4 with S independent frame streams PER GPU (--streams-per-gpu S): every stream has its own engine (adapted parameters, Adam
+    state, hipGraphs) and HIP stream; frames of one stream stay sequential.  One stream's step leaves ~20 % of the chip's time to kernel
+    prologues, tails and launch floors, which a second stream fills.  NOT the headline: `value` there is one stream
+    per GPU; this line says so in config.streams_per_gpu."""
+    from proxytta import synth
+    from proxytta.engine import Engine
+    S = args.streams_per_gpu
+    engs, keep = [], []
+    for k in range(S):
+        eng = Engine(1, H, W, dtype='fp32', **HP)
+        sd = {kk: torch.from_numpy(np.asarray(v)).cuda() for kk, v in synth.formula_state_dict(MODE).items()}
+        eng.load_state_dict(sd)
+        for name in eng.adapted:
+            keep.append((sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name])))
+            eng.bind_adapted(name, *keep[-1])
+        engs.append(eng)
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    frames = [[[torch.from_numpy(x).cuda() for x in synth.synthetic_frame((rank * S + k) * 1000 + i, H, W, 1)] for i in range(4)] for k in range(S)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(n, it0):
+        info = None
+        for it in range(n):
+            for k, (e, st) in enumerate(zip(engs, streams)):
+                with torch.cuda.stream(st):
+                    info, _ = e.step(*frames[k][(it0 + it) % 4], next_frame=frames[k][(it0 + it + 1) % 4])
+        return info
+    run(args.warmup, 0)
+    nblocks = 1 if args.single_block else max(10, -(-200 // max(args.steps, 1)))
+    block_s, it = [], args.warmup
+    for blk in range(nblocks):
+        barrier()
+        t0 = time.perf_counter()
+        info = run(args.steps, it)
+        it += args.steps
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        block_s.append(dt)
+    elapsed = float(np.median(block_s))
+    finite = bool(torch.isfinite(info).all().item())
+    for e in engs:
+        e.close()
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'TTA frames/sec (fwd+loss+bwd+Adam) at 352x1216', 'value': world * S * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / (S * args.steps), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32 storage, bf16x3 MFMA arithmetic (fp32 accumulate)', 'data': 'synthetic',
+            'config': {'workload': 'MSG_CHN 1layer meta, 352x1216 KITTI-shaped synthetic, 1 TTA step/frame, batch 1 per stream',
+                       'parallelism': 'independent frame streams, dp%d x %d streams per GPU, no collectives' % (world, S), 'streams_per_gpu': S,
+                       'note': 'NOT the headline configuration (one stream per GPU): ms_per_step is per frame over all streams of a GPU',
+                       'cpu_affinity': affinity, 'finite': finite},
+            'timing': {'blocks': nblocks, 'steps_timed': nblocks * args.steps * S, 'ms_per_frame_min': 1e3 * min(block_s) / (S * args.steps),
+                       'ms_per_frame_max': 1e3 * max(block_s) / (S * args.steps)}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -433,6 +515,45 @@ def launch_ranks(args, argv):
         print(line, file=sys.stdout if line.startswith('{') else sys.stderr)
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
+
+
+def pin_rank_to_local_cpus(local_rank, ranks_on_node):
+    """Before any HIP call: restrict this rank (its Python launch loop, the staging copies, the runtime's helper threads) to the CPUs next
+    to its GPU -- the GPU's NUMA node when sysfs names it (/sys/class/drm/renderD<128 + i>/device/local_cpulist), otherwise an even slice
+    of the CPUs this process may use.  Eight launch loops migrating over one host is where the >= 6x of config 4 would be lost first.
+    Returns a description for the JSON line."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return 'unsupported'
+    if ranks_on_node <= 1 or len(allowed) < 2 * ranks_on_node:
+        return 'unchanged (%d CPUs, %d rank(s))' % (len(allowed), ranks_on_node)
+    cpus, how = None, 'even slice'
+    try:
+        txt = open('/sys/class/drm/renderD%d/device/local_cpulist' % (128 + local_rank)).read().strip()
+        near = set()
+        for part in txt.split(','):
+            a, _, b = part.partition('-')
+            near.update(range(int(a), int(b or a) + 1))
+        near = sorted(near & set(allowed))
+        # several GPUs share a NUMA node: slice that node's CPUs among them by local rank
+        if len(near) >= 2:
+            peers = [r for r in range(ranks_on_node)
+                     if os.path.exists('/sys/class/drm/renderD%d/device/local_cpulist' % (128 + r))
+                     and open('/sys/class/drm/renderD%d/device/local_cpulist' % (128 + r)).read().strip() == txt]
+            k, n = (peers.index(local_rank), len(peers)) if local_rank in peers else (0, 1)
+            step = max(len(near) // n, 1)
+            cpus, how = near[k * step:(k + 1) * step] or near, 'NUMA-local (%s), slice %d/%d' % (txt, k, n)
+    except (OSError, ValueError):
+        pass
+    if not cpus:
+        step = len(allowed) // ranks_on_node
+        cpus = allowed[local_rank * step:(local_rank + 1) * step]
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError as e:
+        return 'failed: %s' % e
+    return '%s: %d CPUs [%d..%d]' % (how, len(cpus), cpus[0], cpus[-1])
 
 
 def costdcnet_frames(count, h, w):
@@ -524,6 +645,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-block', action='store_true', help='time ONE block of --steps steps (quick A/B runs) instead of >= 10 blocks / >= 200 steps')
     ap.add_argument('--no-nlspn', action='store_true', help='skip the side measurements (2layers, NLSPN, CostDCNet)')
+    ap.add_argument('--streams-per-gpu', type=int, default=1,
+                    help='config 4 only (independent frame streams): this many streams -- own adapted parameters, Adam state and hipGraphs each -- '
+                         'per GPU; the headline (and the default) is 1')
     ap.add_argument('--workload', default='msg_chn', choices=['msg_chn', 'costdcnet-shared'],
                     help="'costdcnet-shared': BASELINE config 5 (shared adapted parameters, all-reduce + SyncBatchNorm) instead of the headline metric")
     ap.add_argument('--plumbing-only', action='store_true',
@@ -538,6 +662,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)' % (args.gpus, world))
+    affinity = pin_rank_to_local_cpus(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))      # before anything touches the GPU
     if args.plumbing_only:
         return plumbing_only(args, rank, world)
     if not torch.cuda.is_available():
@@ -552,6 +677,8 @@ def main():
 
     if args.workload == 'costdcnet-shared':
         return costdcnet_shared(args, rank, world, dist)
+    if args.streams_per_gpu > 1:
+        return msgchn_multi_stream(args, rank, world, dist, affinity)
     from proxytta import synth
     from proxytta.engine import ADAPTED, Engine
     eng = Engine(1, H, W, dtype=args.dtype, **HP)
@@ -703,6 +830,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'MSG_CHN 1layer meta, 352x1216 KITTI-shaped synthetic, 1 TTA step/frame, batch 1 per GPU',
                        'parallelism': 'independent frame streams, dp%d, no collectives' % world, 'finite': finite,
+                       'cpu_affinity': affinity,
                        'frame_pipelining': ('on: every call names the next frame of the stream; the part of its forward upstream of the adapted layer (frozen RGB '
                                             'encoder, sparse-depth pooling, stage-1/4 cascade down to decoder 1\'s last transposed conv) runs on a second stream '
                                             'beside the current step; K timed calls = K prefixes + K remainders; identical results' if pipe else 'off'),

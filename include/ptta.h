@@ -328,6 +328,11 @@ int ptta_debug_tensor(ptta_handle h, const char* name, float* dst, int64_t capac
 int ptta_op_conv32(const float* in_nhwc, const float* weight, const float* bias, float* out_nhwc,
                    int b, int hin, int win, int mode, int relu_in, int in_major, int flip, int dtype, int naive,
                    ptta_stream s);
+/* Diagnostic (tools/bench_chain.py): `reps` dependent launches of one stride-1 32->32 convolution (fp32 NHWC, default arithmetic) captured
+ * into one hipGraph and replayed `replays` times: microseconds per launch INSIDE a replayed graph.  epi_flags: 2 = ReLU mask from `aux`,
+ * 4 = skip addition of `aux`.  Synchronises. */
+int ptta_op_conv32_chain(const float* in_nhwc, const float* weight, const float* bias, float* buf_a, float* buf_b, const float* aux,
+                         int b, int h, int w, int relu_in, int epi_flags, int reps, int replays, float* us_per_launch_host, ptta_stream s);
 int ptta_version(void);
 
 #ifdef __cplusplus

@@ -550,8 +550,11 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
 // first wait.  Same products in the same order as conv32_s1_x3_kernel: bit-identical outputs.
 #define X3S_TH 4
 #define X3S_PH 6
-template <bool RELU, bool UP, bool MASK, bool ADD, bool WLDS = true>
+// ABL (diagnostic instantiations, PTTA_SMALL_ABL + tools/bench_chain.py): 1 no stores, 2 no halo loads, 4 no MFMA phase, 8 no weight loads,
+// 16 empty kernel (launch floor at this launch configuration)
+template <bool RELU, bool UP, bool MASK, bool ADD, bool WLDS = true, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> p) {
+    if (ABL & 16) return;
     constexpr int UPH = 4, UPW = 18;                      // a 4x32 output tile reads <= 3x17 source pixels of the half-resolution map
     // weights: ONE cooperative copy of the hi and lo fragments per block (36 KB, 9 x 16 B per thread) into LDS, read from there by every
     // wave -- the per-wave register copies of round 3 moved 147 KB per block through the vector-memory path, which at ~11 B/clk/CU was
@@ -582,6 +585,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
             const int py = pix / X3_PW, px = pix - py * X3_PW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
+            if (ABL & 2) { v0[it] = make_float4((float)gy, (float)gx, 1.f, (float)it); v1[it] = v0[it]; continue; }
             if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) {
                 const float* src = inb + ((size_t)gy * W + gx) * 32 + 8 * g;
                 v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
@@ -599,7 +603,10 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
 #pragma unroll
                 for (int t = 0; t < (WLDS ? 1 : 9); ++t)
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) { wh[t][k] = ph[(t * 2 + k) * 64 + lane]; wl[t][k] = pl[(t * 2 + k) * 64 + lane]; }
+                    for (int k = 0; k < 2; ++k) {
+                        if (ABL & 8) { wh[t][k] = make_uint4(lane, t, k, 0x3f803f80u); wl[t][k] = wh[t][k]; continue; }
+                        wh[t][k] = ph[(t * 2 + k) * 64 + lane]; wl[t][k] = pl[(t * 2 + k) * 64 + lane];
+                    }
             }
             wloaded = true;
         }
@@ -644,6 +651,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
                 const unsigned char* a = lds + ((wave + ky) * X3_PW + i + kx) * X3_STRIDE + 16 * h;
+                if (ABL & 4) { acc[tap] += __uint_as_float((WLDS ? 0u : wh[WLDS ? 0 : tap][0].x) ^ *(const unsigned*)a); continue; }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
             if (UP) {
                 epi_tile<float, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
             } else {
-                epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+                if (!(ABL & 1) || acc[0] == 1.2345e-30f) epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
             }
         }
         if (tile + (int)gridDim.x < ntiles) lds_barrier();   // LDS reuse by the next tile
@@ -988,6 +996,12 @@ static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_
         if (!small_off && tiles8 <= 256) {
             const long t4 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3S_TH - 1) / X3S_TH);
             const int nb4 = (int)(t4 > 1024 ? 1024 : t4);
+            static const int sabl = getenv("PTTA_SMALL_ABL") ? atoi(getenv("PTTA_SMALL_ABL")) : 0;            // diagnostic (plain variant only)
+            if (sabl && flags == 0) {
+#define KSA_(N) case N: hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, false, false, false, false, N>), dim3(nb4), dim3(256), 0, s, p); return
+                switch (sabl) { KSA_(1); KSA_(2); KSA_(3); KSA_(4); KSA_(7); KSA_(8); KSA_(10); KSA_(15); KSA_(16); default: break; }
+#undef KSA_
+            }
             static const int wlds = getenv("PTTA_SMALL_WLDS") ? atoi(getenv("PTTA_SMALL_WLDS")) : 0;      // one cooperative LDS copy of the weights instead of per-wave registers: measured neutral (1.708 vs 1.703 ms)
 #define KS_(U, M, A) do { if (wlds) hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, U, M, A, true>), dim3(nb4), dim3(256), 0, s, p); \
                           else hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, U, M, A, false>), dim3(nb4), dim3(256), 0, s, p); } while (0)

@@ -2354,4 +2354,51 @@ int ptta_op_conv32(const float* in, const float* weight, const float* bias, floa
     return rc;
 }
 
+// Diagnostic: `reps` DEPENDENT launches of one 32 -> 32 stride-1 convolution (ping-pong between two buffers, optional ReLU mask / skip
+// addition epilogue reading a third) captured into ONE hipGraph and replayed: microseconds per launch as it costs INSIDE a replayed graph
+// (rocprofv3 adds ~3-5 us to every kernel and a host-timed single launch measures the launch path).  tools/bench_chain.py.
+int ptta_op_conv32_chain(const float* in, const float* weight, const float* bias, float* buf_a, float* buf_b, const float* aux, int b, int h, int w,
+                         int relu_in, int epi_flags, int reps, int replays, float* us_per_launch_host, ptta_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    if (!in || !weight || !buf_a || !buf_b || reps < 1 || replays < 1 || !us_per_launch_host) return -22;
+    ConvW wv{};
+    if (hipMalloc((void**)&wv.mf32, 9 * 4 * 64 * 4 * 4) != hipSuccess || hipMalloc((void**)&wv.mbf16, 9 * 2 * 64 * 8 * 2) != hipSuccess ||
+        hipMalloc((void**)&wv.canon, 9216 * 4) != hipSuccess || hipMalloc((void**)&wv.mlo, 9 * 2 * 64 * 8 * 2) != hipSuccess) return -12;
+    ptta_pack_conv32(weight, wv, 0, 0, s);
+    (void)hipStreamSynchronize(s);
+    hipStream_t cs = nullptr; hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = 0;
+    if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) rc = -5;
+    if (!rc && hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = -5;
+    if (!rc) {
+        for (int r = 0; r < reps && !rc; ++r) {
+            Conv32Args a; a.w = &wv; a.bias = bias; a.B = b; a.Hin = h; a.Win = w; a.mode = CONV_S1; a.relu_in = relu_in; a.x3 = 1;
+            a.in = r == 0 ? in : ((r & 1) ? buf_a : buf_b); a.in_nb = b; a.out_raw = (r & 1) ? buf_b : buf_a;
+            if ((epi_flags & 2) && aux) { a.mask = aux; a.mask_nb = b; }
+            if ((epi_flags & 4) && aux) { a.add1 = aux; a.add1_nb = b; }
+            rc = ptta_launch_conv32(a, cs);
+        }
+        if (hipStreamEndCapture(cs, &g) != hipSuccess || !g) rc = rc ? rc : -5;
+    }
+    if (!rc && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) rc = -5;
+    if (!rc && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) rc = -5;
+    if (!rc) {
+        (void)hipGraphLaunch(ge, s); (void)hipGraphLaunch(ge, s);           // warm
+        (void)hipEventRecord(e0, s);
+        for (int k = 0; k < replays; ++k) (void)hipGraphLaunch(ge, s);
+        (void)hipEventRecord(e1, s);
+        (void)hipStreamSynchronize(s);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *us_per_launch_host = 1e3f * ms / ((float)replays * (float)reps);
+    }
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (cs) (void)hipStreamDestroy(cs);
+    (void)hipFree(wv.mf32); (void)hipFree(wv.mbf16); (void)hipFree(wv.mlo); (void)hipFree(wv.canon);
+    return rc;
+}
+
 }  // extern "C"

@@ -87,6 +87,7 @@ SIGNATURES = [
                                   POINTER(c_int64), _P]),
     ('ptta_debug_tensor', c_int, [_P, c_char_p, _P, c_int64, POINTER(c_int64), _P]),
     ('ptta_op_conv32', c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    ('ptta_op_conv32_chain', c_int, [_P] * 6 + [c_int] * 7 + [POINTER(c_float), _P]),
     ('ptta_version', c_int, []),
 ]
 

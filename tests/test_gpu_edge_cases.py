@@ -1,4 +1,6 @@
 """Edge cases and the other BASELINE.json shapes, HIP path vs the oracle (through the C-ABI)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -131,8 +133,17 @@ def test_shared_parameter_step_single_rank_equals_fused_step():
     info2, _ = shared_parameter_step(e2, image, sparse, w=(HP['w_sparse_depth'], HP['w_smoothness'], HP['w_cos']))
     torch.cuda.synchronize()
     assert torch.allclose(info1, info2, rtol=1e-6)
-    for k in ad1:
-        assert torch.equal(ad1[k][0], ad2[k][0])
+    # round 4: the fused step forms d loss_cos / d ref inside the backward GEMM's operand staging, the split calls write it as a tensor first.
+    # The same expression compiled twice may differ in the last bit, and the GEMM's bf16 hi / lo split of its A operand turns a last-bit change
+    # into a 2^-17 step of the represented value: the adapted gradients agree to 2.9e-6 / 2.0e-6 of their mean magnitude (measured, 32x48;
+    # 64x96: 2.3e-6 / 1.3e-6) -- the size of bf16x3's own error -- no longer bit for bit (PTTA_COS_IN_GEMM=0: bit-identical again).  Adam's first
+    # step is lr * sign(g) wherever |g| >> eps, so the parameters are identical except at entries whose gradient is within that noise of zero.
+    for name, k in (('gW', 'conv1_rgb_meta.weight'), ('gB', 'conv1_rgb_meta.bias')):
+        g1, g2 = e1.debug_tensor(name), e2.debug_tensor(name)
+        assert rel_mae(g1, g2) < 6e-6, name
+        clear = (g1.abs() > 1e-3 * g1.abs().max()).view(-1)
+        assert torch.allclose(ad1[k][0].reshape(-1)[clear], ad2[k][0].reshape(-1)[clear], rtol=0, atol=1e-7), k
+        assert clear.float().mean() > 0.97
     e1.close(); e2.close()
 
 
@@ -142,8 +153,14 @@ def test_shared_parameter_step_2layers_meta():
     from proxytta.distributed import shared_parameter_step
     n, h, w = 1, 32, 48
     image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(4, h, w, n)]
-    e1, sd1, ad1 = make_engine(n, h, w, 'fp32', HP, meta='2layers')
-    e2, sd2, ad2 = make_engine(n, h, w, 'fp32', HP, meta='2layers')
+    # (this test is about the plumbing of the general path: with the tensor form of d loss_cos / d ref in the fused step the two are bit-identical;
+    # the in-GEMM form is compared with the split calls in test_shared_parameter_step_single_rank_equals_fused_step)
+    os.environ['PTTA_COS_IN_GEMM'] = '0'
+    try:
+        e1, sd1, ad1 = make_engine(n, h, w, 'fp32', HP, meta='2layers')
+        e2, sd2, ad2 = make_engine(n, h, w, 'fp32', HP, meta='2layers')
+    finally:
+        os.environ.pop('PTTA_COS_IN_GEMM', None)
     assert len(e2.adapted) == 7
     info1, _ = e1.step(image, sparse)
     info2, _ = shared_parameter_step(e2, image, sparse, w=(HP['w_sparse_depth'], HP['w_smoothness'], HP['w_cos']))

@@ -168,6 +168,9 @@ struct GemmX3P {
     const float* X; const uint4* W0frag; const float* b0;
     const bf16_t* W0hi; const bf16_t* W0lo; const bf16_t* W0thi; const bf16_t* W0tlo;
     float* P;
+    // PRO 4: A = d loss_cos / d ref computed while it is staged: A[r][k] = coef (e[r][k] / |e_r| - c_r ref[r][k] / |ref_r|) / |ref_r| from
+    // emb (g.A), ref (Bref), the per-row statistics of the loss forward (rowstats: |e|, |ref|, cos) and the gated weight (coef[0])
+    const float* Bref; const float* rowstats; const float* coef;
 };
 #define DY_ROW 272           // bytes per row of the EPI 3 gradient planes: 128 bf16 + 16 pad (conflict-free ds_read_b128)
 
@@ -354,8 +357,19 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
         // ================= staging waves =================
         const int tid = threadIdx.x - 256;
         // one K slice in flight: [item][half] (PRO 3: the four W0 fragments), B hi / lo, prologue scale / shift (PRO 3: + the first Linear's bias)
-        struct Regs { float4 a[2][2]; uint4 bh[4], bl[4]; float4 sc[2], sh[2]; };
+        struct Regs { float4 a[2][2]; uint4 bh[4], bl[4]; float4 sc[2], sh[2]; float4 e[PRO == 4 ? 2 : 1][2]; };
         Regs r0, r1;
+        float cg_ie[2] = {0.f, 0.f}, cg_ir[2] = {0.f, 0.f}, cg_pj[2] = {0.f, 0.f}, cg_coef = 0.f;
+        if (PRO == 4) {            // this lane's two rows are the same in every K slice: their constants once per block
+            cg_coef = q.coef[0];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                long gr = row0 + stage_row(tid + 256 * it);
+                if (gr >= p.R) gr = p.R - 1;
+                const float ne = q.rowstats[3 * gr], nr = q.rowstats[3 * gr + 1], cc = q.rowstats[3 * gr + 2];
+                cg_ie[it] = 1.f / ne; cg_ir[it] = 1.f / nr; cg_pj[it] = (nr > 1e-12f) ? cc : 0.f;       // as loss.hip cos_grad_body
+            }
+        }
         // PRO 3: A[row][k] = relu(bn(x[row] . W0[k] + b0[k])) is COMPUTED here, on the matrix cores, as the 32 x 32 tile D = W0[slice] x^T
         // (M = hidden unit, N = row, K = 32 input channels: 2 k-steps x 3 bf16 products): this wave owns rows 32 (wave - 4) ... + 31, its x
         // fragments (B operand: lane = row, 8 consecutive channels) are split once per block; a lane then holds 4 x 4 consecutive hidden
@@ -386,6 +400,10 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 if (gr >= p.R) gr = p.R - 1;                                  // clamped (rows beyond R are never stored)
                 const float* src = (const float*)p.A + gr * p.K + k0 + 8 * (idx & 3);
                 rr.a[it][0] = *(const float4*)src; rr.a[it][1] = *(const float4*)(src + 4);
+                if (PRO == 4) {
+                    const float* sr = q.Bref + gr * p.K + k0 + 8 * (idx & 3);
+                    rr.e[it][0] = *(const float4*)sr; rr.e[it][1] = *(const float4*)(sr + 4);
+                }
             }
             }
             if (PRO == 1) {     // fetched WITH the slice (both items of a thread share the 8 columns): a load inside store_slice is the
@@ -449,6 +467,12 @@ __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {
                 const int idx = tid + 256 * it;
                 const int row = stage_row(idx), kq = idx & 3;
                 float v[8] = {rr.a[it][0].x, rr.a[it][0].y, rr.a[it][0].z, rr.a[it][0].w, rr.a[it][1].x, rr.a[it][1].y, rr.a[it][1].z, rr.a[it][1].w};
+                if (PRO == 4) {
+                    const float b[8] = {rr.e[it][0].x, rr.e[it][0].y, rr.e[it][0].z, rr.e[it][0].w, rr.e[it][1].x, rr.e[it][1].y, rr.e[it][1].z, rr.e[it][1].w};
+                    const float ie = cg_ie[it], ir = cg_ir[it], pj = cg_pj[it];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = cos_grad_elem(cg_coef, v[e], b[e], ie, ir, pj);
+                }
                 if (PRO == 1) {
                     const float4 s0 = rr.sc[0], s1 = rr.sc[1], t0 = rr.sh[0], t1 = rr.sh[1];
                     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
@@ -969,6 +993,8 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.x3 && !a.a_bf16) {
         GemmX3P q; q.g = p; q.Whi = a.Whi; q.Wlo = a.Wlo; q.Wil = a.Wil;
         q.X = a.X; q.W0frag = (const uint4*)a.W0frag; q.b0 = a.b0; q.W0hi = a.W0hi; q.W0lo = a.W0lo; q.W0thi = a.W0thi; q.W0tlo = a.W0tlo; q.P = a.P;
+        q.Bref = a.Bref; q.rowstats = a.rowstats; q.coef = a.coef;
+        if (a.pro == 4 && (!a.Bref || !a.rowstats || !a.coef || a.epi != 3)) return -22;
         const int key3 = a.pro * 10 + a.epi;
         if ((a.pro == 3 && (!a.X || !a.W0frag || !a.b0 || !a.pscale || !a.pshift)) ||
             (a.epi == 3 && (!a.X || !a.b0 || !a.W0hi || !a.W0lo || !a.W0thi || !a.W0tlo || !a.P || !a.escale || !a.part))) return -22;
@@ -985,6 +1011,7 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
                 case 10: GS_(1, 0); break; case 11: GS_(1, 1); break;
                 case 30: GS_(3, 0); break; case 31: GS_(3, 1); break; case 3: GS_(0, 3); break;       // heads v2
                 case 4: GS_(0, 4); break;                                                              // column statistics only (no C)
+                case 43: GS_(4, 3); break;                                                             // heads v2 backward from emb / ref (no gradient tensor)
                 default: return -22;
             }
 #undef GS_

@@ -30,6 +30,7 @@ static __host__ __device__ inline long ws_cos_off(int N) { return ws_depth_off(N
 static __host__ __device__ inline long ws_rows_off(int N) { return ws_cos_off(N) + LOSS_CB; }
 
 int ptta_loss_ws_floats(int N, int H, int W, long R) { return (int)(ws_rows_off(N) + 3 * R + 64); }
+long ptta_loss_ws_rows_off(int N) { return ws_rows_off(N); }
 
 // validity_map of the TTA step = where(sparse > 0, 1, sparse) on the RAW sparse depth (src/tta_main.py:583-586); computed on the
 // fly when the caller passes no map
@@ -258,10 +259,10 @@ __device__ __forceinline__ void cos_grad_body(int bx, int nbx, const float* __re
         for (int k = 4 * lane; k < D; k += 256) {
             const float4 a = *(const float4*)(emb + row * D + k), b = *(const float4*)(ref + row * D + k);
             float4 o;
-            o.x = coef * (a.x * ie - proj * b.x * ir) * ir;
-            o.y = coef * (a.y * ie - proj * b.y * ir) * ir;
-            o.z = coef * (a.z * ie - proj * b.z * ir) * ir;
-            o.w = coef * (a.w * ie - proj * b.w * ir) * ir;
+            o.x = cos_grad_elem(coef, a.x, b.x, ie, ir, proj);
+            o.y = cos_grad_elem(coef, a.y, b.y, ie, ir, proj);
+            o.z = cos_grad_elem(coef, a.z, b.z, ie, ir, proj);
+            o.w = cos_grad_elem(coef, a.w, b.w, ie, ir, proj);
             *(float4*)(gref + row * D + k) = o;
         }
     }

@@ -99,6 +99,8 @@ struct ptta_ctx {
     // backward: mask / BatchNorm-backward sums + the contraction with W0 inside the block)
     int heads_v2 = 1;
     int fuse_first = 1;
+    int cos_grad_fused = 1;          // PTTA_COS_IN_GEMM=0: the fused step writes d loss / d ref as a tensor (loss.hip cos_grad_body) instead
+    bool cos_in_gemm = false;        // (set around the fused step's backward only: ptta_backward with a caller's gradient keeps the tensor form)
     // ---- the fused step as FOUR graphs on two streams (PTTA_DUAL=0: one graph).  The grad pass (real frames) and the no-grad proxy pass
     // (zero image) of _rgbd_meta_contrast share nothing downstream of the meta layer until the loss, and about half of their ~60 launches
     // are low-resolution layers that leave the chip half empty.  Forks INSIDE one hipGraph are replayed interleaved on one queue (measured
@@ -1111,6 +1113,9 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
         // contracts the masked gradient (x gamma x invstd) with W0 inside the block (P: [column block 2][R][32]); the BatchNorm-backward
         // correction terms are linear in x: d x = P[0] + P[1] - x M - u (heads.hip head_bwd_mat_kernel)
         GemmArgs g; g.A = gref; g.W = l3.Wt; g.R = R; g.K = 512; g.N = 512; g.epi = 3;
+        if (c->cos_in_gemm) {       // fused step: the gradient of the cosine term is formed while the GEMM stages its A operand (no [R][512] tensor)
+            g.A = c->emb; g.Bref = c->ref; g.rowstats = c->loss_ws + ptta_loss_ws_rows_off(c->N); g.coef = c->loss_ws; g.pro = 4;
+        }
         g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part;
         g.x3 = 1; g.Whi = l3.Wthi; g.Wlo = l3.Wtlo; g.Wil = l3.Wtil;
         g.X = (const float*)c->feat; g.b0 = l0.bias; g.W0hi = l0.Whi; g.W0lo = l0.Wlo; g.W0thi = l0.Wthi; g.W0tlo = l0.Wtlo; g.P = c->headP;
@@ -1311,6 +1316,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
     { const char* hv = getenv("PTTA_HEADS_V2"); c->heads_v2 = (hv && strcmp(hv, "0") == 0) ? 0 : 1; }
     { const char* ff = getenv("PTTA_FUSE_FIRST"); c->fuse_first = ff ? atoi(ff) : 1; }
+    { const char* cg = getenv("PTTA_COS_IN_GEMM"); c->cos_grad_fused = (cg && strcmp(cg, "0") == 0) ? 0 : 1; }
     { const char* du = getenv("PTTA_DUAL"); c->dual_on = (du && strcmp(du, "1") == 0) ? 1 : 0; }      // measured neutral: off by default      // 1: the depth encoders' init blocks, 2: the RGB encoder's too
     { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
       if (c->ablate) fprintf(stderr, "libptta_hip: PTTA_ABLATE=%d -- TIMING ABLATION: launches are skipped, every result of this handle is GARBAGE\n", c->ablate); }
@@ -1681,9 +1687,13 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
     // the two gradient kernels (no 1-block launch between forward and backward)
     REST_(s, ptta_launch_loss_forward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
                                       c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info, s, 1));
+    const bool cig = c->cos_grad_fused && heads_v2_on(c) && c->N <= 16;          // (N <= LOSS_FIN_MAXN: the gradient launch finalises the loss)
     REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
-                                       c->N, c->H, c->W, c->loss_ws, c->g_final, c->gref_buf, s, c->hyper + 5, c->loss_info));
-    RUN(ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_));
+                                       c->N, c->H, c->W, c->loss_ws, c->g_final, cig ? nullptr : c->gref_buf, s, c->hyper + 5, c->loss_info));
+    c->cos_in_gemm = cig;
+    const int rc_b = ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_);
+    c->cos_in_gemm = false;
+    if (rc_b) return rc_b;
     // shared-parameter run (the reference's DDP, src/tta_main.py:354,631-633): mean of the adapted gradients over the ranks, one message
     if (c->grad_comm && ptta_rccl_allreduce_mean_f32(c->grad_comm, c->grad_arena, c->grad_arena_n, s_)) return c->fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
     RUN(ptta_adam_step(c, nullptr, nullptr, s_));

@@ -265,6 +265,11 @@ __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, i
 
 // MFMA 32x32 accumulator row of register r for lane half h (cdna_hip_programming.md §3):
 // row = (r&3) + 8*(r>>2) + 4*h, col = lane&31.
+// d loss_cos / d ref, one element: coef (e / |e| - c ref / |ref|) / |ref| with ie = 1 / |e|, ir = 1 / |ref| (loss.hip cos_grad_body; heads.hip PRO 4:
+// the same expression in both, but the compiler is free to contract it differently in the two kernels -- last-bit differences)
+__device__ __forceinline__ float cos_grad_elem(float coef, float e, float r, float ie, float ir, float proj) {
+    return coef * (e * ie - proj * r * ir) * ir;
+}
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // conv geometry

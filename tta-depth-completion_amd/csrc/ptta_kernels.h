@@ -118,6 +118,9 @@ struct GemmArgs {
     const bf16_t* W0hi = nullptr; const bf16_t* W0lo = nullptr;       // epi 3: [512][32] bf16 planes
     const bf16_t* W0thi = nullptr; const bf16_t* W0tlo = nullptr;     // epi 3: [32][512] bf16 planes (transposed)
     float* P = nullptr;                        // epi 3: [2][R][32]
+    // pro 4 (with epi 3): A = the cosine term's gradient wrt `ref`, computed while staged from A = emb, Bref = ref, the loss forward's
+    // per-row statistics and the gated weight (loss.hip: ptta_loss_ws_rows_off, WS_SCAL[0]) -- the [R][512] gradient tensor is never written
+    const float* Bref = nullptr; const float* rowstats = nullptr; const float* coef = nullptr;
 };
 // W0 [512][32] fp32 -> [slice 16][kstep 2][hi, lo][lane 64] uint4 fragments (8 bf16: hidden unit 32*slice + (lane & 31), channels 16*kstep + 8*(lane >> 5) ...)
 void ptta_pack_w0_frag(const float* W0, void* frag, hipStream_t s);
@@ -145,6 +148,7 @@ int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N,
 // ---- loss.hip ---------------------------------------------------------------------------------
 struct LossScalars;      // device-resident scalars, see loss.hip
 int ptta_loss_ws_floats(int N, int H, int W, long R);
+long ptta_loss_ws_rows_off(int N);        // floats from the workspace start to the per-row statistics [R][3] = (|e|, |ref|, cos); [0] = the gated cosine coefficient
 int ptta_launch_loss_forward(const float* depth, const float* image, const float* sparse, const float* validity,
                              float max_input_depth, const float* emb, const float* ref, long R, int D,
                              const float* w3_dev /* w_sd, w_sm, w_cos */, int N, int H, int W,

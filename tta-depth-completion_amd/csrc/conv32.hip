@@ -372,13 +372,19 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
 // body of conv32_s1_x3_kernel on that LDS tile.  The pre-activation map is still written for the frames whose backward needs it as a
 // ReLU mask (`a_out`, frames b < a_nb: the real frames; not at all for the RGB encoder).  The input-plane window lives in the LDS
 // region of the bilinear-skip window (dead until the matrix phase); the next tile's window is prefetched into registers.
+// The same construction serves the backward of a prediction head: d v = conv^T_{1 -> 32}(g) * (v > 0) followed by the data gradient of
+// prdct.1 (a stride-1 32 -> 32 convolution with a ReLU-mask epilogue) -- FMASK: the first convolution's output is masked by the sign bits
+// of a 32-channel map (one word per halo pixel, applied after the lane-quad transpose), RELU_MID = false: no ReLU in between, EMASK: the second convolution's
+// epilogue mask.  The 55-MB d v map is neither written nor read.
 struct FirstP {
     Plane pl[3]; int zero_from_b;
     const float* w1;             // [14][64] fp32 MFMA fragments of the first convolution (ptta_pack_conv_in)
-    const float* bias1;
+    const float* bias1;          // may be null
     float* a_out; int a_nb;
+    const uint32_t* fmask_bits; int fmask_nb;        // FMASK: sign bits of the first convolution's ReLU mask (one word per pixel), frames b % fmask_nb
+    uint32_t* a_bits;                        // sign bits of the a_out map for the same frames (the backward's mask), or null
 };
-template <int CIN, bool UP>
+template <int CIN, bool UP, bool FMASK = false, bool RELU_MID = true, bool EMASK = false>
 __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> p, FirstP f) {
     constexpr int UPH = 6, UPW = 18;
     constexpr int K1 = 9 * CIN, NS = (K1 + 1) / 2;
@@ -423,7 +429,31 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
             pv[k] = v;
         }
     };
-    if (blockIdx.x < ntiles) load_planes(blockIdx.x);
+    const int tq = (i & 3) + 4 * h, c4 = 4 * (i >> 2);
+    // FMASK: the first convolution's ReLU mask for one halo group (4 float4 per lane), double-buffered one group ahead: the first group's
+    // loads are issued at the top of the tile, the next group's before the current group's arithmetic.  (Holding all three groups' masks
+    // across the previous tile's main loop spilled 51 registers and was 20 us slower.)
+    // The mask comes in its sign-bit form only (fmask_bits, one word per pixel): the 12 words of this wave's three halo groups are
+    // fetched one tile AHEAD, with the input planes and before the current tile's epilogue stores -- a load issued after those stores
+    // cannot complete before they have drained (vmcnt is in order and counts stores), which cost this kernel ~20 us per tile round.
+    constexpr int NGW = FMASK ? 3 : 1;
+    uint32_t mkw[NGW][4];
+    auto load_masks = [&](long tile) {
+        if (!FMASK) return;
+        int b, y0, x0;
+        tile_coords(tile, b, y0, x0);
+        const uint32_t* mbb = f.fmask_bits + (size_t)(b % f.fmask_nb) * H * W;
+#pragma unroll
+        for (int gi = 0; gi < NGW; ++gi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pp = min(32 * (wave + 4 * gi) + 8 * j + tq, X3_PH * X3_PW - 1);
+                const int py = pp / X3_PW, px = pp - py * X3_PW;
+                const int gy = min(max(y0 - 1 + py, 0), H - 1), gx = min(max(x0 - 1 + px, 0), W - 1);
+                mkw[gi][j] = mbb[(size_t)gy * W + gx];
+            }
+    };
+    if (blockIdx.x < ntiles) { load_planes(blockIdx.x); load_masks(blockIdx.x); }
     uint4 wh[9][2];
     float w1[NS];
     {
@@ -437,8 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
         for (int s_ = 0; s_ < NS; ++s_) w1[s_] = f.w1[s_ * 64 + lane];
         for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
     }
-    const float b1 = f.bias1[i];
-    const int tq = (i & 3) + 4 * h, c4 = 4 * (i >> 2);
+    const float b1 = f.bias1 ? f.bias1[i] : 0.f;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
@@ -449,8 +478,8 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
         lds_barrier();
         // ---- first convolution on the halo: pixel p = 34 py + px of the (8 + 2) x (32 + 2) halo, 32 pixels per MFMA group ----
         const bool amap = f.a_out != nullptr && b < f.a_nb;
-#pragma unroll 1
-        for (int g = wave; g < (X3_PH * X3_PW + 31) / 32; g += 4) {
+        const bool abits = f.a_bits != nullptr && b < f.a_nb;
+        auto halo_group = [&](const int g, const uint32_t* mk) {
             const int pm = min(32 * g + i, X3_PH * X3_PW - 1);
             const float* base = planes + (pm / X3_PW) * PL_W + (pm % X3_PW);
             f32x16 acc;
@@ -475,9 +504,18 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
                 const int gy = y0 - 1 + py, gx = x0 - 1 + px;
                 const bool inimg = pp < X3_PH * X3_PW && gy >= 0 && gy < H && gx >= 0 && gx < W;
                 float4 v = make_float4(t[4 * j], t[4 * j + 1], t[4 * j + 2], t[4 * j + 3]);
-                if (amap && inimg && py >= 1 && py <= X3_TH && px >= 1 && px <= 32)
-                    *(float4*)(f.a_out + (((size_t)b * H + gy) * W + gx) * 32 + c4) = v;
-                v = inimg ? relu4(v) : make_float4(0.f, 0.f, 0.f, 0.f);            // the second convolution's zero padding
+                if (FMASK) {
+                    const uint32_t nib = mk[j] >> c4;
+                    v.x = (nib & 1u) ? v.x : 0.f; v.y = (nib & 2u) ? v.y : 0.f; v.z = (nib & 4u) ? v.z : 0.f; v.w = (nib & 8u) ? v.w : 0.f;
+                }
+                const bool store_a = inimg && py >= 1 && py <= X3_TH && px >= 1 && px <= 32;
+                if (amap && store_a) *(float4*)(f.a_out + (((size_t)b * H + gy) * W + gx) * 32 + c4) = v;
+                if (abits) {                                                        // (wave-uniform; all lanes reach the ballots)
+                    const uint32_t word = mask_word_from_quads(v.x, v.y, v.z, v.w, i, h);
+                    if (i < 4 && store_a) f.a_bits[((size_t)b * H + gy) * W + gx] = word;
+                }
+                if (RELU_MID) v = relu4(v);
+                if (!inimg) v = make_float4(0.f, 0.f, 0.f, 0.f);                    // the second convolution's zero padding
                 uint2 hi, lo;
                 split2(v.x, v.y, hi.x, lo.x); split2(v.z, v.w, hi.y, lo.y);
                 if (pp < X3_PH * X3_PW) {
@@ -485,9 +523,24 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
                     *(uint2*)(lds + pp * X3_STRIDE + 64 + 2 * c4) = lo;
                 }
             }
+        };
+        constexpr int NG = (X3_PH * X3_PW + 31) / 32;
+        static_assert(!FMASK || NG <= 12, "three halo groups per wave");
+        if (FMASK) {
+            uint32_t mk[4];
+#pragma unroll 1
+            for (int gi = 0; gi < NGW; ++gi) {
+                if (wave + 4 * gi >= NG) break;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mk[j] = gi == 0 ? mkw[0][j] : (gi == 1 ? mkw[NGW > 1 ? 1 : 0][j] : mkw[NGW > 2 ? 2 : 0][j]);
+                halo_group(wave + 4 * gi, mk);
+            }
+        } else {
+#pragma unroll 1
+            for (int g = wave; g < NG; g += 4) halo_group(g, mkw[0]);
         }
         lds_barrier();                                                  // halo complete; the plane window is dead
-        if (tile + gridDim.x < ntiles) load_planes(tile + gridDim.x);
+        if (tile + gridDim.x < ntiles) { load_planes(tile + gridDim.x); load_masks(tile + gridDim.x); }
         int uy0 = 0, ux0 = 0;
         if (UP) {
             const int Hu = H >> 1, Wu = W >> 1;
@@ -533,8 +586,8 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
             }
             if (UP && rr == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); }      // every wave's pieces of the window have landed
             if (y < H) {
-                if (UP) epi_tile<float, false, false, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
-                else epi_tile<float, false, false, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+                if (UP) epi_tile<float, false, EMASK, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
+                else epi_tile<float, false, EMASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
             }
         }
         lds_barrier();          // LDS reuse by the next tile (plane window over the bilinear window, halo)
@@ -1047,6 +1100,7 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     p.epi.add1 = (const T*)a.add1; p.epi.add1_nb = a.add1_nb > 0 ? a.add1_nb : 1;
     p.epi.add2 = (const T*)a.add2; p.epi.add2_nb = a.add2_nb > 0 ? a.add2_nb : 1;
     p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = (T*)a.out_sum;
+    p.epi.mask_bits = a.mask_bits; p.epi.bits_out = a.bits_out; p.epi.bits_nb = a.bits_nb; p.epi.bits_sum = a.bits_sum;
     p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.stagger = 0;
     if (MODE == CONV_S1) { p.Hout = a.Hin; p.Wout = a.Win; }
     else if (MODE == CONV_S2) { p.Hout = a.Hin / 2; p.Wout = a.Win / 2; }
@@ -1116,15 +1170,21 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
 // first convolution's pre-activation map is still written (frames b < a_nb), or null.  Returns 1 when this form does not apply
 // (the caller then launches the two kernels): other storage / arithmetic modes, epilogues other than the bilinear skip, small maps.
 int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_out, int a_nb, hipStream_t s) {
-    if (a.bf16 || a.naive || !a.x3 || a.mode != CONV_S1 || !a.relu_in || a.mask || a.add1 || a.add2 || a.out_sum || f.bf16 || f.naive) return 1;
-    if (f.cin < 1 || f.cin > 3 || f.up || f.mask || f.add1 || f.B != a.B || f.H != a.Hin || f.W != a.Win) return 1;
+    // two shapes: forward (ReLU between the convolutions, optional bilinear skip, no masks) and the prediction head's backward (cin = 1, the
+    // first convolution masked, no ReLU in between, the second convolution's epilogue masked, no bilinear skip)
+    const bool bwd_form = f.mask != nullptr;
+    if (bwd_form && !f.mask_bits) return 1;
+    if (a.bf16 || a.naive || !a.x3 || a.mode != CONV_S1 || a.add1 || a.add2 || a.out_sum || f.bf16 || f.naive) return 1;
+    if (bwd_form ? (a.relu_in || !a.mask || a.up || f.cin != 1) : (!a.relu_in || a.mask != nullptr)) return 1;
+    if (f.cin < 1 || f.cin > 3 || f.up || f.add1 || f.B != a.B || f.H != a.Hin || f.W != a.Win) return 1;
     const long tiles = (long)a.B * ((a.Win + 31) / 32) * ((a.Hin + X3_TH - 1) / X3_TH);
     if (tiles <= 256) return 1;
     Conv32P<float> p;
     p.in = nullptr; p.in_nb = 1; p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
     p.epi.bias = a.bias; p.epi.up = (const float*)a.up; p.epi.up_nb = a.up_nb > 0 ? a.up_nb : 1;
-    p.epi.mask = nullptr; p.epi.mask_nb = 1; p.epi.add1 = nullptr; p.epi.add1_nb = 1; p.epi.add2 = nullptr; p.epi.add2_nb = 1;
+    p.epi.mask = (const float*)a.mask; p.epi.mask_nb = a.mask_nb > 0 ? a.mask_nb : 1; p.epi.add1 = nullptr; p.epi.add1_nb = 1; p.epi.add2 = nullptr; p.epi.add2_nb = 1;
     p.epi.out_raw = (float*)a.out_raw; p.epi.out_sum = nullptr;
+    p.epi.mask_bits = a.mask_bits; p.epi.bits_out = a.bits_out; p.epi.bits_nb = a.bits_nb; p.epi.bits_sum = 0;
     p.B = a.B; p.Hin = p.Hout = a.Hin; p.Win = p.Wout = a.Win;
     static const int stag = getenv("PTTA_STAGGER") ? atoi(getenv("PTTA_STAGGER")) : 8000;
     const int blocks = (int)(tiles > 512 ? 512 : tiles);
@@ -1132,6 +1192,12 @@ int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_o
     FirstP q;
     for (int c = 0; c < 3; ++c) { q.pl[c] = f.pl[c]; if (q.pl[c].nb < 1) q.pl[c].nb = 1; }
     q.zero_from_b = f.zero_from_b; q.w1 = f.wfrag; q.bias1 = f.bias; q.a_out = (float*)a_out; q.a_nb = a_nb;
+    q.fmask_nb = f.mask_nb > 0 ? f.mask_nb : 1; q.fmask_bits = f.mask_bits; q.a_bits = a_out ? f.a_bits : nullptr;
+    if (bwd_form) {
+        hipLaunchKernelGGL((conv32_s1_first_kernel<1, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p, q);
+        PTTA_CHECK_LAUNCH();
+        return 0;
+    }
 #define KF_(C) do { if (a.up) hipLaunchKernelGGL((conv32_s1_first_kernel<C, true>), dim3(blocks), dim3(256), 0, s, p, q); \
                     else hipLaunchKernelGGL((conv32_s1_first_kernel<C, false>), dim3(blocks), dim3(256), 0, s, p, q); } while (0)
     if (f.cin == 1) KF_(1); else if (f.cin == 2) KF_(2); else KF_(3);

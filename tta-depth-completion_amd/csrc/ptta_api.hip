@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ptta.h"
@@ -212,6 +213,21 @@ struct ptta_ctx {
         dbg[name] = Dbg{p, (long)nb * h * w * 32, 1};
         return p;
     }
+    // Sign-bit masks (ptta_common.h Epi): for every pre-activation map the backward uses as a ReLU mask, one word per pixel of the REAL
+    // frames, written by the forward epilogue that writes the map and read by the backward epilogue instead of the 128-B fp32 pixel.
+    // fp32 storage, MFMA kernels (PTTA_MASK_BITS=0: float masks everywhere).  Keyed by the map's base pointer: conv32() looks its
+    // output / mask operands up, so the schedule code does not name the bit planes.
+    int mask_bits_on = 1;
+    std::unordered_map<const void*, uint32_t*> mbits;
+    void mask_plane(const void* map, int nb, int h, int w) {
+        if (!mask_bits_on || bf16 || naive) return;
+        mbits[map] = (uint32_t*)dalloc((size_t)nb * h * w * sizeof(uint32_t));
+    }
+    uint32_t* bits_of(const void* map) const {
+        if (!map) return nullptr;
+        auto it = mbits.find(map);
+        return it == mbits.end() ? nullptr : it->second;
+    }
     float* map1(const char* name, int nb, int h, int w) {
         float* p = falloc((size_t)nb * h * w);
         dbg[name] = Dbg{p, (long)nb * h * w, 0};
@@ -399,6 +415,18 @@ void build_workspace(ptta_ctx* c) {
     A_(e3_0a, B2, H1, W1); A_(e3_0, B2, H1, W1); A_(e3_1a, B2, H2, W2); A_(e3_1, B2, H2, W2); A_(e3_2a, B2, H4, W4);
     A_(feat, B2, H4, W4); A_(w2, B2, H4, W4);
     A_(t3, Nn, H2, W2); A_(s1_3, Nn, H2, W2); A_(u3, Nn, H1, W1); A_(s0_3, Nn, H1, W1); A_(v3, Nn, H1, W1);
+    {   // the ReLU masks of backbone_backward (real frames).  v1 is not listed: its only reader is the unfused conv^T_{1->32} kernel
+        // (float mask); e*_0a only when the fused init block (conv32_first) is what writes them for every launch shape.
+#define MB_(name, h, w) c->mask_plane(c->name, Nn, h, w)
+        MB_(v3, H1, W1); MB_(s0_3, H1, W1); MB_(u3, H1, W1); MB_(e3_0, H1, W1);
+        MB_(s1_3, H2, W2); MB_(t3, H2, W2); MB_(e3_1, H2, W2); MB_(e3_1a, H2, W2); MB_(v2, H2, W2); MB_(s0_2, H2, W2); MB_(u2, H2, W2); MB_(e2_0, H2, W2);
+        MB_(w2, H4, W4); MB_(e3_2a, H4, W4); MB_(s1_2, H4, W4); MB_(t2, H4, W4); MB_(e2_1, H4, W4); MB_(e2_1a, H4, W4); MB_(s0_1, H4, W4);
+        MB_(z2, H8, W8); MB_(e2_2a, H8, W8);
+        auto first_fused = [&](int h, int w) { return c->fuse_first >= 1 && !(c->ablate & 3) && c->x3 && (long)Nn * ((w + 31) / 32) * ((h + 7) / 8) > 256; };
+        if (first_fused(H1, W1)) MB_(e3_0a, H1, W1);
+        if (first_fused(H2, W2)) MB_(e2_0a, H2, W2);
+#undef MB_
+    }
     // heads
     const size_t RD = (size_t)c->Rg * 512;
     c->h1z = c->falloc(RD); c->pz = c->falloc(RD); c->h2 = c->falloc(RD); c->emb = c->falloc(RD);
@@ -521,6 +549,16 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     a.add1 = e.add1; a.add1_nb = e.add1_nb; a.add2 = e.add2; a.add2_nb = e.add2_nb;
     a.out_raw = e.raw; a.out_sum = e.sum;
     a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = c->bf16; a.naive = c->naive; a.x3 = c->x3;
+    if (!c->mbits.empty()) {
+        // sign-bit masks: the backward reads the bits of its mask; a forward launch that starts at frame 0 of a map the backward masks
+        // with writes that map's bits for the real frames (launches over the proxy half start at an offset pointer: no entry, no bits)
+        a.mask_bits = c->bits_of(e.mask);
+        if (!bwd) {
+            uint32_t* bs = c->bits_of(e.sum); uint32_t* br = c->bits_of(e.raw);
+            if (bs && br) return c->fail("conv32: both outputs of " + layer + " are registered masks", -22);
+            if (bs || br) { a.bits_out = bs ? bs : br; a.bits_sum = bs ? 1 : 0; a.bits_nb = c->Nn; }
+        }
+    }
     {   // TIMING ablation only (results are garbage): PTTA_ABLATE bit 0 skips the 32->32 convolutions at <= 1/4 resolution, bit 1 those above
         const int abl = c->ablate;
         const bool small = (long)Hin * Win <= (long)c->H4 * c->W4 * (mode == CONV_S2 ? 4 : 1);
@@ -560,11 +598,35 @@ int conv32_first(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvInArg
         const double px = (double)B * H * W;
         // (both layers' algorithmic bytes and MACs: the launch executes both)
         ProfScope ps(c, 0, s, (px * (f.cin + 32) + 9.0 * f.cin * 32 + px * 64 + 9216) * c->es, px * 9.0 * (f.cin * 32 + 1024), 1);
+        f.a_bits = a_nb > 0 ? c->bits_of(f.out_raw) : nullptr;
+        if (!c->mbits.empty()) { uint32_t* br = c->bits_of(e.raw); if (br) { a.bits_out = br; a.bits_nb = c->Nn; } }
         const int rc = ptta_launch_conv32_first(a, f, a_nb > 0 ? f.out_raw : nullptr, a_nb, s);
         return rc == 1 ? c->fail("conv32_first: fused form refused a case its caller accepted", -22) : rc;
     }
     RUN(conv_in_p(c, f, s));
     return conv32(c, s, layer, false, CONV_S1, f.out_raw, B, B, H, W, true, e);
+}
+
+// Backward of a prediction head in one launch: d v = conv^T_{1->32}(g) * (v > 0) formed per halo tile and consumed by the data gradient of
+// prdct.1 (mask epilogue) -- the d v map is never written (conv32.hip conv32_s1_first_kernel<1, false, true, false, true>).  Large maps only.
+int conv32_first_bwd(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvInArgs& f, int B, int H, int W, const E& e) {
+    auto it = c->l32.find(layer);
+    if (it == c->l32.end()) return c->fail("unknown 32->32 layer " + layer, -2);
+    const long tiles = (long)B * ((W + 31) / 32) * ((H + 7) / 8);
+    static const bool on = !getenv("PTTA_FUSE_HEAD_BWD") || atoi(getenv("PTTA_FUSE_HEAD_BWD")) != 0;
+    if (on && c->bits_of(f.mask) && c->fuse_first >= 1 && !(c->ablate & 3) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && e.mask && e.raw && !e.add1 && !e.add2 && !e.sum && !e.up) {
+        Conv32Args a;
+        a.in = nullptr; a.in_nb = B; a.w = &it->second.b; a.bias = nullptr;
+        a.mask = e.mask; a.mask_nb = e.mask_nb; a.out_raw = e.raw;
+        a.mask_bits = c->bits_of(e.mask); f.mask_bits = c->bits_of(f.mask);
+        a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 0; a.bf16 = 0; a.naive = 0; a.x3 = 1;
+        const double px = (double)B * H * W;
+        ProfScope ps(c, 4, s, (px * (1 + 32) + 9.0 * 32 + px * 64 + 9216) * c->es, px * 9.0 * (32 + 1024), 1);
+        const int rc = ptta_launch_conv32_first(a, f, nullptr, 0, s);
+        return rc == 1 ? c->fail("conv32_first_bwd: fused form refused a case its caller accepted", -22) : rc;
+    }
+    RUN(conv_in_p(c, f, s));
+    return conv32(c, s, layer, true, CONV_S1, f.out_raw, B, B, H, W, false, e);
 }
 
 inline float* st_ptr(float* base, int C, int pass, int kind) { return base + ((size_t)pass * 4 + kind) * C; }   // kind: 0 mean 1 inv 2 scale 3 shift
@@ -1145,12 +1207,21 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     const int Nn = c->Nn, B2 = 2 * Nn;
     const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
-    auto dgrad_out1 = [&](const std::string& layer, const float* g, const void* mask, void* out, int H, int W) -> int {
+    auto out1_args = [&](const std::string& layer, const float* g, const void* mask, void* out, int H, int W) {
         const LOut& lo = c->lout[layer];
         ConvInArgs a; a.cin = 1; a.pl[0].p = g; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H * W;
         a.wfrag = lo.bfrag; a.wcanon = lo.bcanon; a.mask = mask; a.mask_nb = B2; a.out_raw = out;
         a.B = Nn; a.H = H; a.W = W; a.bf16 = c->bf16; a.naive = c->naive;
+        return a;
+    };
+    auto dgrad_out1 = [&](const std::string& layer, const float* g, const void* mask, void* out, int H, int W) -> int {
+        ConvInArgs a = out1_args(layer, g, mask, out, H, W);
         return conv_in_p(c, a, s);
+    };
+    // prediction head backward: prdct.3^T then prdct.1's data gradient, one launch on large maps
+    auto head_bwd = [&](const std::string& l3, const std::string& l1, const float* g, const void* v, void* dv, int H, int W, const E& e) -> int {
+        ConvInArgs a = out1_args(l3, g, v, dv, H, W);
+        return conv32_first_bwd(c, s, l1, a, Nn, H, W, e);
     };
     auto dgrad_in_ch1 = [&](const std::string& layer, const void* g, const float* add, float* out, int H, int W) -> int {
         const LIn& li = c->lin_in[layer];
@@ -1160,8 +1231,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     };
     auto em = [](void* raw, const void* mask, int mask_nb) { E e; e.raw = raw; e.mask = mask; e.mask_nb = mask_nb; return e; };
     // ---- decoder 3 ----
-    RUN(dgrad_out1("depth_decoder3.prdct.3", g_net, c->v3, c->dv3, H1, W1));
-    CV("depth_decoder3.prdct.1", true, CONV_S1, c->dv3, Nn, Nn, H1, W1, false, em(c->ds0_3, c->s0_3, Nn));
+    RUN(head_bwd("depth_decoder3.prdct.3", "depth_decoder3.prdct.1", g_net, c->v3, c->dv3, H1, W1, em(c->ds0_3, c->s0_3, Nn)));
     CV("depth_decoder3.dec1.3", true, CONV_S1, c->ds0_3, Nn, Nn, H1, W1, false, em(c->du3, c->u3, Nn));
     CV("depth_decoder3.dec1.1", true, CONV_S2, c->du3, Nn, Nn, H1, W1, false, em(c->ds1_3, c->s1_3, Nn));
     CV("depth_decoder3.dec2.3", true, CONV_S1, c->ds1_3, Nn, Nn, H2, W2, false, em(c->dt3, c->t3, Nn));
@@ -1180,8 +1250,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     RUN(dgrad_in_ch1("depth_encoder3.init.0", c->de3_0a, g_net, c->dp11, H1, W1));       // d p11 = conv^T + d output
     REST_(s, ptta_launch_up2T_1ch(c->dp11, c->dq, Nn, H2, W2, s));                              // d(out2 + p12)
     // ---- decoder 2 ----
-    RUN(dgrad_out1("depth_decoder2.prdct.3", c->dq, c->v2, c->dv2, H2, W2));
-    CV("depth_decoder2.prdct.1", true, CONV_S1, c->dv2, Nn, Nn, H2, W2, false, em(c->ds0_2, c->s0_2, B2));
+    RUN(head_bwd("depth_decoder2.prdct.3", "depth_decoder2.prdct.1", c->dq, c->v2, c->dv2, H2, W2, em(c->ds0_2, c->s0_2, B2)));
     REST_(s, ptta_launch_up2T_32(c->de3_0, c->ds0_2, c->dz4, Nn, H2, W2, c->bf16, s));         // d z4 = d s0_2 + up2^T(d e3_0)
     CV("depth_decoder2.dec1.3", true, CONV_S1, c->dz4, Nn, Nn, H2, W2, false, em(c->du2, c->u2, B2));
     CV("depth_decoder2.dec1.1", true, CONV_S2, c->du2, Nn, Nn, H2, W2, false, em(c->ds1_2, c->s1_2, B2));
@@ -1316,6 +1385,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
     { const char* hv = getenv("PTTA_HEADS_V2"); c->heads_v2 = (hv && strcmp(hv, "0") == 0) ? 0 : 1; }
     { const char* ff = getenv("PTTA_FUSE_FIRST"); c->fuse_first = ff ? atoi(ff) : 1; }
+    { const char* mb = getenv("PTTA_MASK_BITS"); c->mask_bits_on = (mb && strcmp(mb, "0") == 0) ? 0 : 1; }
     { const char* cg = getenv("PTTA_COS_IN_GEMM"); c->cos_grad_fused = (cg && strcmp(cg, "0") == 0) ? 0 : 1; }
     { const char* du = getenv("PTTA_DUAL"); c->dual_on = (du && strcmp(du, "1") == 0) ? 1 : 0; }      // measured neutral: off by default      // 1: the depth encoders' init blocks, 2: the RGB encoder's too
     { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
@@ -1945,7 +2015,8 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         P.prepared = true; P.prep_token = frame_token;
     } else if (next_image && next_sparse && next_token != 0) {
         // the next frame's prefix into the other set, on its own stream: after the caller's data is there and after the step that last read
-        // that set (two calls ago) is done with it
+        // that set (two calls ago) is done with it.  (Queued AFTER this frame's remainder; handing it to the GPU before the remainder moves
+        // it to the head of the step -- rocprofv3 timeline -- and changes nothing: 1.691 vs 1.693 ms.)
         pipe_use(c, q);
         ptta_ctx::PreSet& Q = c->pset[q];
         hipStream_t ps = c->pre_stream;

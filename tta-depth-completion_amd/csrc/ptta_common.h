@@ -65,7 +65,24 @@ struct Epi {
     const T* add2; int add2_nb;
     T* out_raw;
     T* out_sum;
+    // Sign-bit form of the ReLU masks (fp32 storage, MFMA kernels): one 32-bit word per pixel, bit c = (value of channel c > 0).
+    // A forward epilogue whose output the backward uses as a mask also writes `bits_out` for frames b < bits_nb (of out_sum when
+    // bits_sum, else of out_raw); a backward epilogue then reads `mask_bits` (4 B per pixel) instead of the 128-B fp32 pixel of `mask`.
+    // Same predicate (> 0) on the same stored values: results are bit-identical to the float-mask form.
+    const uint32_t* mask_bits = nullptr;
+    uint32_t* bits_out = nullptr; int bits_nb = 0; int bits_sum = 0;
 };
+
+// One mask word from the transposed epilogue layout: lane (ch, h) holds channels 4 (ch >> 2) ... + 3 of one pixel and the eight lanes
+// ch = a, a + 4, ..., a + 28 (same h) hold that pixel's 32 channels.  Four ballots (one per channel of the lane's quad); the lane with
+// ch = a < 4 assembles the pixel's word: bit 4 k + q = ballot_q bit (32 h + a + 4 k).  Must be called with all 64 lanes active.
+__device__ __forceinline__ uint32_t mask_word_from_quads(float x, float y, float z, float w, int ch, int h) {
+    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(x > 0.0f), b1 = __builtin_amdgcn_ballot_w64(y > 0.0f);
+    const unsigned long long b2 = __builtin_amdgcn_ballot_w64(z > 0.0f), b3 = __builtin_amdgcn_ballot_w64(w > 0.0f);
+    const int sh = 32 * h + (ch & 3);
+    return ((uint32_t)(b0 >> sh) & 0x11111111u) | (((uint32_t)(b1 >> sh) & 0x11111111u) << 1) |
+           (((uint32_t)(b2 >> sh) & 0x11111111u) << 2) | (((uint32_t)(b3 >> sh) & 0x11111111u) << 3);
+}
 
 template <typename T>
 __device__ __forceinline__ void epi_store(const Epi<T>& e, int b, int y, int x, int H, int W, int ch,
@@ -194,10 +211,18 @@ __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, i
         }
         // every auxiliary load of the row is issued before the first store (a store between them would order them)
         float4 mk[4], t1[4], t2[4];
+        uint32_t mw[4];
+        const bool mbits = MASK && e.mask_bits != nullptr;
         if (MASK) {
-            const float* mb = (const float*)e.mask + (size_t)(b % e.mask_nb) * H * W * 32;
+            if (mbits) {
+                const uint32_t* mb = e.mask_bits + (size_t)(b % e.mask_nb) * H * W;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mk[g] = *(const float4*)(mb + xq[g]);
+                for (int g = 0; g < 4; ++g) { mw[g] = mb[xq[g] >> 5]; mk[g] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            } else {
+                const float* mb = (const float*)e.mask + (size_t)(b % e.mask_nb) * H * W * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { mk[g] = *(const float4*)(mb + xq[g]); mw[g] = 0u; }
+            }
         }
         if (ADD) {
             const float* a1 = (const float*)e.add1 + (size_t)(b % e.add1_nb) * H * W * 32;
@@ -213,16 +238,30 @@ __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, i
         }
         float* const oraw = (float*)e.out_raw + (size_t)b * H * W * 32;
         float* const osum = (float*)e.out_sum + (size_t)b * H * W * 32;
+        const bool wbits = e.bits_out != nullptr && b < e.bits_nb;              // wave-uniform
+        uint32_t* const obits = e.bits_out + (size_t)b * H * W;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float4 val = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
             if (MASK) {
-                val.x = mk[g].x > 0.0f ? val.x : 0.0f; val.y = mk[g].y > 0.0f ? val.y : 0.0f;
-                val.z = mk[g].z > 0.0f ? val.z : 0.0f; val.w = mk[g].w > 0.0f ? val.w : 0.0f;
+                if (mbits) {
+                    const uint32_t nib = mw[g] >> j4;
+                    val.x = (nib & 1u) ? val.x : 0.0f; val.y = (nib & 2u) ? val.y : 0.0f;
+                    val.z = (nib & 4u) ? val.z : 0.0f; val.w = (nib & 8u) ? val.w : 0.0f;
+                } else {
+                    val.x = mk[g].x > 0.0f ? val.x : 0.0f; val.y = mk[g].y > 0.0f ? val.y : 0.0f;
+                    val.z = mk[g].z > 0.0f ? val.z : 0.0f; val.w = mk[g].w > 0.0f ? val.w : 0.0f;
+                }
             }
             if (e.out_raw && okg[g]) *(float4*)(oraw + xq[g]) = val;
+            const float4 vraw = val;
             if (ADD) { val.x += t1[g].x; val.y += t1[g].y; val.z += t1[g].z; val.w += t1[g].w; }
             if (e.out_sum && okg[g]) *(float4*)(osum + xq[g]) = val;
+            if (wbits) {
+                const float4 bs = e.bits_sum ? val : vraw;
+                const uint32_t word = mask_word_from_quads(bs.x, bs.y, bs.z, bs.w, ch, h);
+                if (ch < 4 && okg[g]) obits[xq[g] >> 5] = word;
+            }
         }
         return;
     }

@@ -23,6 +23,9 @@ struct Conv32Args {
     int B = 1, Hin = 0, Win = 0;    // input spatial size; output size follows from mode
     int mode = CONV_S1; int relu_in = 0; int bf16 = 0; int naive = 0;
     int x3 = 0;          // fp32 storage: bf16x3 arithmetic on the bf16 matrix cores (stride-1 only)
+    // sign-bit masks (ptta_common.h Epi): fp32 storage, non-naive kernels only -- the caller passes them only in that mode
+    const uint32_t* mask_bits = nullptr;       // backward: replaces the reads of `mask` (which stays set for the other modes)
+    uint32_t* bits_out = nullptr; int bits_nb = 0; int bits_sum = 0;      // forward: bits of out_sum (bits_sum) or out_raw, frames b < bits_nb
 };
 void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, hipStream_t s, int row_stride = 32, int col_off = 0);
 int ptta_launch_conv32(const Conv32Args& a, hipStream_t s);
@@ -42,6 +45,8 @@ struct ConvInArgs {      // planar fp32 (cin = 1..3) -> 32-channel NHWC
     const void* add1 = nullptr; int add1_nb = 1;
     void* out_raw = nullptr; void* out_sum = nullptr;
     int B = 1, H = 0, W = 0; int bf16 = 0; int naive = 0;
+    // fused first-kernel forms only (ptta_launch_conv32_first): sign bits of `mask` / bits of the a_out map
+    const uint32_t* mask_bits = nullptr; uint32_t* a_bits = nullptr;
 };
 void ptta_pack_conv_in(const float* src, int cin_total, int cin_first, int cin, int transpose_flip,
                        float* wfrag, float* wcanon, hipStream_t s);

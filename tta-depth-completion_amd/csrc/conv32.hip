@@ -398,6 +398,9 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
     stagger_start(p.stagger);
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
+    // per-lane index arithmetic is recomputed in each phase from an opaque copy of the lane id: hoisted out of the persistent tile loop it
+    // becomes dozens of long-lived registers (the UP variants spilled 5 - 34) and a scratch reload between two global loads serialises them
+    auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.Hout, W = p.Wout;
     const int ntx = (W + 31) >> 5, nty = (H + X3_TH - 1) / X3_TH;
@@ -414,9 +417,10 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
         const bool live = b < f.zero_from_b;
+        const int tid_ = opaque(tid);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-            const int idx = tid + 256 * k;
+            const int idx = tid_ + 256 * k;
             const int ci = idx / PLANE, r = idx - ci * PLANE;
             const int py = r / PL_W, px = r - py * PL_W;
             const int gy = y0 - 2 + py, gx = x0 - 2 + px;
@@ -472,15 +476,18 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
         // ---- the input-plane window (prefetched) -> LDS ----
+        { const int tid_ = opaque(tid);
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) { const int idx = tid + 256 * k; if (idx < CIN * PLANE) planes[idx] = pv[k]; }
+        for (int k = 0; k < NPL; ++k) { const int idx = tid_ + 256 * k; if (idx < CIN * PLANE) planes[idx] = pv[k]; } }
         if (tid == 0) planes[CIN * PLANE] = 0.f;                       // the padded k of an odd 9 cin reads this word
         lds_barrier();
         // ---- first convolution on the halo: pixel p = 34 py + px of the (8 + 2) x (32 + 2) halo, 32 pixels per MFMA group ----
         const bool amap = f.a_out != nullptr && b < f.a_nb;
         const bool abits = f.a_bits != nullptr && b < f.a_nb;
         auto halo_group = [&](const int g, const uint32_t* mk) {
-            const int pm = min(32 * g + i, X3_PH * X3_PW - 1);
+            const int i_ = opaque(i);
+            const int tq = (i_ & 3) + 4 * h, c4 = 4 * (i_ >> 2);       // (shadow the kernel-scope copies)
+            const int pm = min(32 * g + i_, X3_PH * X3_PW - 1);
             const float* base = planes + (pm / X3_PW) * PL_W + (pm % X3_PW);
             f32x16 acc;
 #pragma unroll
@@ -546,9 +553,10 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
             const int Hu = H >> 1, Wu = W >> 1;
             uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
             const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
+            const int tid_ = opaque(tid);
 #pragma unroll
             for (int k = 0; k < (UPH * UPW * 8 + 255) / 256; ++k) {
-                const int idx = tid + 256 * k;
+                const int idx = tid_ + 256 * k;
                 if (idx < UPH * UPW * 8) {
                     const int q = idx & 7, pix = idx >> 3;
                     const int r = pix / UPW, cc = pix - r * UPW;

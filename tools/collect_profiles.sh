@@ -8,7 +8,7 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=r04; O=gpurun_out/$R; rm -rf $O; mkdir -p $O
 BENCH="bench.py --steps 20 --warmup 10 --no-nlspn --no-cpu-baseline"
-CLASS='conv32_s1_(x3_kernel<true|small_kernel<true|first_kernel<)'
+CLASS='conv32_s1_(x3_kernel<true|small_kernel<true|first_kernel<[23])'
 # 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -o x -- python3 $BENCH > $O/${R}_bench_under_rocprofv3_kernel_trace.json 2> $O/trace_graph.log
 python3 tools/prof_top.py $O/trace_graph 45 > $O/${R}_fp32_kernel_stats_top.txt

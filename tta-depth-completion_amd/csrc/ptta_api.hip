@@ -621,7 +621,7 @@ int conv32_first_bwd(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvI
         a.mask_bits = c->bits_of(e.mask); f.mask_bits = c->bits_of(f.mask);
         a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 0; a.bf16 = 0; a.naive = 0; a.x3 = 1;
         const double px = (double)B * H * W;
-        ProfScope ps(c, 4, s, (px * (1 + 32) + 9.0 * 32 + px * 64 + 9216) * c->es, px * 9.0 * (32 + 1024), 1);
+        ProfScope ps(c, 2, s, (px * (1 + 32) + 9.0 * 32 + px * 64 + 9216) * c->es, px * 9.0 * (32 + 1024), 1);
         const int rc = ptta_launch_conv32_first(a, f, nullptr, 0, s);
         return rc == 1 ? c->fail("conv32_first_bwd: fused form refused a case its caller accepted", -22) : rc;
     }

@@ -37,7 +37,7 @@ struct Conv32P {
 // during the matrix phases and the matrix cores during the memory phases.  Workgroups are dealt to the CUs in index
 // order, so block b and block b + gridDim/2 share a CU: the upper half waits `cycles` before its first load.
 __device__ __forceinline__ void stagger_start(int cycles) {
-    if (cycles > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+    if (cycles > 0 && blockIdx.x >= 256) {                 // the SECOND resident block of a CU (the first 256 workgroups go one per CU)
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)cycles) __builtin_amdgcn_s_sleep(16);
     }
@@ -1098,6 +1098,17 @@ static void launch_direct_x3(const Conv32P<float>& p, int flags, int blocks, hip
 #undef K_
 }
 
+// Workgroups of a persistent full-chip launch.  The stride-1 kernel takes 480 of the 512 slots (two 256-VGPR blocks per CU): a launch that
+// owns every register of the chip keeps every kernel of the other queues (the tiny BatchNorm finalizes between the heads' GEMMs, the next
+// frame's prefix) waiting until it retires, and 32 CUs with a single block break the lock-step of the rest.  Same box, graph replay,
+// pipelined / call by call: 512 + staggered start 1.698 / 1.819, 496 1.699, 480 + stagger 1.693 / 1.813, 480 without 1.681 / 1.803, 464 1.698,
+// 448 1.73, 416 1.81; the first-layer / strided / transposed kernels stay at 512 (480 there: 1.689 vs 1.688).  PTTA_S1_BLOCKS, PTTA_FULL_BLOCKS.
+static int full_chip_blocks(bool s1 = false) {
+    static const int cap = getenv("PTTA_FULL_BLOCKS") ? atoi(getenv("PTTA_FULL_BLOCKS")) : 512;
+    static const int cap1 = getenv("PTTA_S1_BLOCKS") ? atoi(getenv("PTTA_S1_BLOCKS")) : 480;
+    const int c = s1 ? cap1 : cap;
+    return c < 1 ? 1 : (c > 512 ? 512 : c);
+}
 template <typename T, int MODE>
 static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     Conv32P<T> p;
@@ -1119,10 +1130,11 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     if constexpr (sizeof(T) == 4 && MODE == CONV_S1) if (!a.naive && a.x3) {
         p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
         const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
-        static const int cap = getenv("PTTA_S1_BLOCKS") ? atoi(getenv("PTTA_S1_BLOCKS")) : 512;
+        const int cap = full_chip_blocks(true);
         const int blocks = (int)(tiles > cap ? cap : tiles);     // 2 resident blocks per CU, persistent
-        static const int stag = getenv("PTTA_STAGGER") ? atoi(getenv("PTTA_STAGGER")) : 8000;      // measured on one box: 0 -> 8000 cycles: step -15 us
-        if (blocks == 512) p.stagger = stag;
+        // (a staggered start of the CU's second block -- PTTA_STAGGER=8000 cycles -- was worth 15 us with 512 blocks; with 480 it costs 10)
+        static const int stag = getenv("PTTA_STAGGER") ? atoi(getenv("PTTA_STAGGER")) : 0;
+        if (blocks == cap && cap > 256) p.stagger = stag;
         const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
         if (a.relu_in) launch_x3<true>(pf, flags, blocks, s); else launch_x3<false>(pf, flags, blocks, s);
         PTTA_CHECK_LAUNCH();
@@ -1132,14 +1144,15 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
         const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
         const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
-        long blocks = (items + 3) / 4; if (blocks > 512) blocks = 512;
+        const int capd = full_chip_blocks();
+        long blocks = (items + 3) / 4; if (blocks > capd) blocks = capd;
         const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
         static const int s2_direct = getenv("PTTA_S2_DIRECT") ? atoi(getenv("PTTA_S2_DIRECT")) : 0;      // A/B: keep the direct-load form
         if (MODE == CONV_S2 && !(flags & 1) && !s2_direct) {
             const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + S2_TH - 1) / S2_TH);
-            const int tb = (int)(tiles < 512 ? tiles : 512);
+            const int tb = (int)(tiles < capd ? tiles : capd);
             static const int stag2 = getenv("PTTA_STAGGER_S2") ? atoi(getenv("PTTA_STAGGER_S2")) : 0;
-            Conv32P<float> pf2 = pf; if (tb == 512) pf2.stagger = stag2;
+            Conv32P<float> pf2 = pf; if (tb == capd && capd > 256) pf2.stagger = stag2;
 #define KS2_(R, M, A) hipLaunchKernelGGL((conv32_s2_lds_kernel<R, M, A>), dim3(tb), dim3(256), 0, s, pf2)
             const bool m_ = flags & 2, a_ = flags & 4;
             if (a.relu_in) { if (m_) { if (a_) KS2_(true, true, true); else KS2_(true, true, false); } else { if (a_) KS2_(true, false, true); else KS2_(true, false, false); } }
@@ -1149,7 +1162,7 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
             return 0;
         }
         static const int stagd = getenv("PTTA_STAGGER_D") ? atoi(getenv("PTTA_STAGGER_D")) : 0;
-        Conv32P<float> pfd = pf; if (blocks == 512) pfd.stagger = stagd;
+        Conv32P<float> pfd = pf; if (blocks == capd && capd > 256) pfd.stagger = stagd;
         if (a.relu_in) launch_direct_x3<MODE, true>(pfd, flags, (int)blocks, s); else launch_direct_x3<MODE, false>(pfd, flags, (int)blocks, s);
         PTTA_CHECK_LAUNCH();
         return 0;
@@ -1194,9 +1207,11 @@ int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_o
     p.epi.out_raw = (float*)a.out_raw; p.epi.out_sum = nullptr;
     p.epi.mask_bits = a.mask_bits; p.epi.bits_out = a.bits_out; p.epi.bits_nb = a.bits_nb; p.epi.bits_sum = 0;
     p.B = a.B; p.Hin = p.Hout = a.Hin; p.Win = p.Wout = a.Win;
-    static const int stag = getenv("PTTA_STAGGER") ? atoi(getenv("PTTA_STAGGER")) : 8000;
-    const int blocks = (int)(tiles > 512 ? 512 : tiles);
-    p.stagger = blocks == 512 ? stag : 0;
+    static const int stag = getenv("PTTA_STAGGER_F") ? atoi(getenv("PTTA_STAGGER_F")) : 0;
+    static const int capf = getenv("PTTA_FIRST_BLOCKS") ? atoi(getenv("PTTA_FIRST_BLOCKS")) : 512;
+    const int cap = capf < 1 ? 1 : (capf > 512 ? 512 : capf);
+    const int blocks = (int)(tiles > cap ? cap : tiles);
+    p.stagger = (blocks == cap && cap > 256) ? stag : 0;
     FirstP q;
     for (int c = 0; c < 3; ++c) { q.pl[c] = f.pl[c]; if (q.pl[c].nb < 1) q.pl[c].nb = 1; }
     q.zero_from_b = f.zero_from_b; q.w1 = f.wfrag; q.bias1 = f.bias; q.a_out = (float*)a_out; q.a_nb = a_nb;

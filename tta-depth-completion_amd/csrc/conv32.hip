@@ -1215,7 +1215,7 @@ int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_o
     FirstP q;
     for (int c = 0; c < 3; ++c) { q.pl[c] = f.pl[c]; if (q.pl[c].nb < 1) q.pl[c].nb = 1; }
     q.zero_from_b = f.zero_from_b; q.w1 = f.wfrag; q.bias1 = f.bias; q.a_out = (float*)a_out; q.a_nb = a_nb;
-    q.fmask_nb = f.mask_nb > 0 ? f.mask_nb : 1; q.fmask_bits = f.mask_bits; q.a_bits = a_out ? f.a_bits : nullptr;
+    q.fmask_nb = f.mask_nb > 0 ? f.mask_nb : 1; q.fmask_bits = f.mask_bits; q.a_bits = f.a_bits;
     if (bwd_form) {
         hipLaunchKernelGGL((conv32_s1_first_kernel<1, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p, q);
         PTTA_CHECK_LAUNCH();

@@ -598,9 +598,12 @@ int conv32_first(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvInArg
         const double px = (double)B * H * W;
         // (both layers' algorithmic bytes and MACs: the launch executes both)
         ProfScope ps(c, 0, s, (px * (f.cin + 32) + 9.0 * f.cin * 32 + px * 64 + 9216) * c->es, px * 9.0 * (f.cin * 32 + 1024), 1);
+        // the first convolution's pre-activation map is the backward's ReLU mask and nothing else: with a bit plane only its sign bits are
+        // written (a_bits), not the 128-B pixels (PTTA_KEEP_FIRST_MAP=1 writes both)
+        static const bool keep_map = getenv("PTTA_KEEP_FIRST_MAP") && atoi(getenv("PTTA_KEEP_FIRST_MAP")) != 0;
         f.a_bits = a_nb > 0 ? c->bits_of(f.out_raw) : nullptr;
         if (!c->mbits.empty()) { uint32_t* br = c->bits_of(e.raw); if (br) { a.bits_out = br; a.bits_nb = c->Nn; } }
-        const int rc = ptta_launch_conv32_first(a, f, a_nb > 0 ? f.out_raw : nullptr, a_nb, s);
+        const int rc = ptta_launch_conv32_first(a, f, (a_nb > 0 && (!f.a_bits || keep_map)) ? f.out_raw : nullptr, a_nb, s);
         return rc == 1 ? c->fail("conv32_first: fused form refused a case its caller accepted", -22) : rc;
     }
     RUN(conv_in_p(c, f, s));

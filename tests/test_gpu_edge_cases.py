@@ -147,6 +147,37 @@ def test_shared_parameter_step_single_rank_equals_fused_step():
     e1.close(); e2.close()
 
 
+@pytest.mark.parametrize('h,w', [(64, 96), (352, 1216)])
+def test_sign_bit_masks_equal_float_masks_bit_for_bit(h, w):
+    """Round 4: the backward reads ONE word of sign bits per pixel (written by the forward epilogues) instead of the fp32 pre-activation
+    pixel, the prediction heads' backward runs as one launch from those bits and the fused init block writes only the bits of its first
+    map.  Same predicate (> 0) on the same stored values: three steps with PTTA_MASK_BITS=0 (float masks, the unfused launches) and with the
+    default must agree bit for bit -- depth, loss terms, adapted parameters and Adam moments.  352x1216 is where the fused large-map kernels
+    run; 64x96 takes the small-map kernels."""
+    n = 1
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(20 + i, h, w, n)] for i in range(3)]
+    runs = []
+    for bits in ('0', '1'):
+        os.environ['PTTA_MASK_BITS'] = bits
+        try:
+            eng, sd, ad = make_engine(n, h, w, 'fp32', HP)
+        finally:
+            os.environ.pop('PTTA_MASK_BITS', None)
+        out = []
+        for im, sp in frames:
+            info, depth = eng.step(im, sp, want_depth=True)
+            out.append((info.clone(), depth.clone()))
+        torch.cuda.synchronize()
+        runs.append((out, {k: [t.clone() for t in v] for k, v in ad.items()}))
+        eng.close()
+    (o0, a0), (o1, a1) = runs
+    for (i0, d0), (i1, d1) in zip(o0, o1):
+        assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    for k in a0:
+        for t0, t1 in zip(a0[k], a1[k]):
+            assert torch.equal(t0, t1), k
+
+
 def test_shared_parameter_step_2layers_meta():
     """The general path of shared_parameter_step (gradients read from / written back to the library, on-device Adam)
     with the 7-tensor 2layers meta layer, one rank: equals the fused step."""

@@ -147,14 +147,13 @@ def test_shared_parameter_step_single_rank_equals_fused_step():
     e1.close(); e2.close()
 
 
-@pytest.mark.parametrize('h,w', [(64, 96), (352, 1216)])
-def test_sign_bit_masks_equal_float_masks_bit_for_bit(h, w):
+@pytest.mark.parametrize('n,h,w', [(1, 64, 96), (2, 176, 608), (1, 352, 1216)])
+def test_sign_bit_masks_equal_float_masks_bit_for_bit(n, h, w):
     """Round 4: the backward reads ONE word of sign bits per pixel (written by the forward epilogues) instead of the fp32 pre-activation
     pixel, the prediction heads' backward runs as one launch from those bits and the fused init block writes only the bits of its first
     map.  Same predicate (> 0) on the same stored values: three steps with PTTA_MASK_BITS=0 (float masks, the unfused launches) and with the
     default must agree bit for bit -- depth, loss terms, adapted parameters and Adam moments.  352x1216 is where the fused large-map kernels
-    run; 64x96 takes the small-map kernels."""
-    n = 1
+    run; 64x96 takes the small-map kernels; two frames of 176x608 index the bit planes with a batch (b % nb) and mix both kernel families."""
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(20 + i, h, w, n)] for i in range(3)]
     runs = []
     for bits in ('0', '1'):

@@ -424,7 +424,9 @@ def test_graph_replay_equals_kernel_by_kernel_launches():
     for k in a[3]:
         d = (a[3][k] - b[3][k]).abs()
         tot += d.numel(); same += int((d < 1e-4).sum())          # lr = 1e-3: an entry that took the opposite Adam step would differ by 2e-3
-    assert same >= 0.99 * tot, (same, tot)                     # measured 0.995 (two kernel-by-kernel runs: 0.998)
+    # measured 0.995 typically (two kernel-by-kernel runs: 0.998), 0.988 once in ~6 runs: the atomics' order decides the sign of gradients
+    # that are zero up to rounding, and three Adam steps at lr = 1e-3 turn a flipped sign into 2e-3.  0.97 = the observed spread doubled.
+    assert same >= 0.97 * tot, (same, tot)
 
 
 def test_eval_forward_fills_holes_like_the_reference(golden_dir):

@@ -209,6 +209,26 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
     return 0;
 }
 
+// The two halves of ptta_launch_loss_forward as separate launches and the finalisation as its own (the fused step's two branches, ptta_api.hip
+// step_tail: the depth terms behind decoder 3 on one stream, the cosine rows behind the heads on the other -- neither waits for the other's
+// forward): same kernels, same partials, same finalisation.
+int ptta_launch_loss_depth_part(const float* depth, const float* image, const float* sparse, const float* validity, float max_input_depth,
+                                int N, int H, int W, float* ws, hipStream_t s) {
+    hipLaunchKernelGGL(loss_depth_reduce_kernel, dim3(LOSS_PB, N), dim3(256), 0, s, depth, image, sparse, validity, max_input_depth, H, W, ws + ws_depth_off(N));
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+int ptta_launch_loss_cos_part(const float* emb, const float* ref, long R, int D, int N, float* ws, hipStream_t s) {
+    hipLaunchKernelGGL(cos_rows_kernel, dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+int ptta_launch_loss_finalize(float* ws, int N, int H, int W, long R, int has_cos, const float* w3_dev, float* loss_info, hipStream_t s) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, ws, N, H, W, R, has_cos, w3_dev, loss_info);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
 __device__ __forceinline__ void depth_grad_body(int bx, int nbx, const float* __restrict__ depth, const float* __restrict__ image,
                                                 const float* __restrict__ sparse, const float* __restrict__ validity,
                                                 float max_d, int N, int H, int W, float* __restrict__ ws,

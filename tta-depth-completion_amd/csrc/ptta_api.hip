@@ -99,6 +99,11 @@ struct ptta_ctx {
     // from the second moments of the 32-channel input, the hidden is recomputed inside the 512x512 GEMMs (forward: A-operand producer;
     // backward: mask / BatchNorm-backward sums + the contraction with W0 inside the block)
     int heads_v2 = 1;
+    // the fused step without a join between forward and backward: the depth terms of the loss and decoder 3's backward follow decoder 3 on the
+    // main stream, the cosine rows, the finalisation and the heads' backward follow the heads on the auxiliary one; they meet where the
+    // backward needs d feat (PTTA_THRU=0: join after the forward, loss launches, fork again)
+    int thru = 1; bool thru_active = false;
+    hipEvent_t ev_dpart = nullptr;
     int fuse_first = 1;
     int cos_grad_fused = 1;          // PTTA_COS_IN_GEMM=0: the fused step writes d loss / d ref as a tensor (loss.hip cos_grad_body) instead
     bool cos_in_gemm = false;        // (set around the fused step's backward only: ptta_backward with a caller's gradient keeps the tensor form)
@@ -1044,7 +1049,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     }
 #undef CV
     if (train && ph == 0) {
-        if (s2) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
+        if (s2) { if (!c->thru_active) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); }      // (thru: the heads' stream goes on into the loss and the backward)
         else RUN(heads_forward(c, s));
     }
     return 0;
@@ -1389,6 +1394,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     { const char* hv = getenv("PTTA_HEADS_V2"); c->heads_v2 = (hv && strcmp(hv, "0") == 0) ? 0 : 1; }
     { const char* ff = getenv("PTTA_FUSE_FIRST"); c->fuse_first = ff ? atoi(ff) : 1; }
     { const char* mb = getenv("PTTA_MASK_BITS"); c->mask_bits_on = (mb && strcmp(mb, "0") == 0) ? 0 : 1; }
+    { const char* th = getenv("PTTA_THRU"); c->thru = (th && strcmp(th, "0") == 0) ? 0 : 1; }
     { const char* cg = getenv("PTTA_COS_IN_GEMM"); c->cos_grad_fused = (cg && strcmp(cg, "0") == 0) ? 0 : 1; }
     { const char* du = getenv("PTTA_DUAL"); c->dual_on = (du && strcmp(du, "1") == 0) ? 1 : 0; }      // measured neutral: off by default      // 1: the depth encoders' init blocks, 2: the RGB encoder's too
     { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
@@ -1416,6 +1422,7 @@ void ptta_destroy(ptta_handle h) {
         for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(h->ev_prefix[p]); (void)hipEventDestroy(h->ev_rest[p]); }
     }
     if (h->dual_stream) { (void)hipStreamDestroy(h->dual_stream); (void)hipEventDestroy(h->ev_dA); (void)hipEventDestroy(h->ev_dP); }
+    if (h->ev_dpart) (void)hipEventDestroy(h->ev_dpart);
     if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_real); }
     for (void* p : h->allocs) if (p) (void)hipFree(p);
     for (auto& pc : h->prof) for (auto& e : pc.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1741,10 +1748,17 @@ int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream 
 }
 
 static int step_tail(ptta_handle c, const float* loss_image, const float* sparse, const float* validity, ptta_stream s_, bool passes_were_split);
+static bool thru_ok(ptta_ctx* c, hipStream_t s) {
+    return c->thru && c->cos_grad_fused && heads_v2_on(c) && c->N <= 16 && c->fwd_phase == 0 && !(c->split_fwd & 1) && c->aux(s) != nullptr;
+}
 static int step_body(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
                      ptta_stream s_) {
-    RUN(ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_));
-    return step_tail(c, loss_image, sparse, validity, s_, false);
+    c->thru_active = thru_ok(c, (hipStream_t)s_);
+    const int rc = ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_);
+    if (rc) { c->thru_active = false; return rc; }
+    const int rc2 = step_tail(c, loss_image, sparse, validity, s_, false);
+    c->thru_active = false;
+    return rc2;
 }
 // loss + backward + (gradient all-reduce) + Adam: everything of the step behind the forward
 static int step_tail(ptta_handle c, const float* loss_image, const float* sparse, const float* validity, ptta_stream s_, bool passes_were_split) {
@@ -1755,6 +1769,35 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
         BNorm& b1 = c->bn["proj.1"];
         const int nbm = ptta_gemm_row_blocks((int)c->Rg);
         REST_(s, ptta_launch_bn_running2(c->hm_part + (size_t)nbm * 2 * 512, c->hm_part, nbm, (int)c->Rg, 512, 0.1f, b1.rm, b1.rv, b1.nbt, s));
+    }
+    if (c->thru_active) {
+        hipStream_t s2 = c->aux(s);
+        if (!c->ev_dpart) HIPCHK(hipEventCreateWithFlags(&c->ev_dpart, hipEventDisableTiming));
+        // main stream: depth terms of the loss, their gradient (its kernel finalises the depth terms itself: no cosine term, nothing reported)
+        REST_(s, ptta_launch_loss_depth_part(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->N, c->H, c->W, c->loss_ws, s));
+        HIPCHK(hipEventRecord(c->ev_dpart, s));
+        REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, nullptr, nullptr, c->Rg, 512,
+                                           c->N, c->H, c->W, c->loss_ws, c->g_final, nullptr, s, c->hyper + 5, nullptr));
+        // auxiliary stream, behind the heads' forward: cosine rows, the finalisation (gate, coefficient, the four reported scalars: it needs the
+        // depth partials of the other stream, long there by now), the heads' backward
+        REST_(s2, ptta_launch_loss_cos_part(c->emb, c->ref, c->Rg, 512, c->N, c->loss_ws, s2));
+        HIPCHK(hipStreamWaitEvent(s2, c->ev_dpart, 0));
+        REST_(s2, ptta_launch_loss_finalize(c->loss_ws, c->N, c->H, c->W, c->Rg, 1, c->hyper + 5, c->loss_info, s2));
+        c->cos_in_gemm = true;
+        const int rc_h = heads_backward(c, c->gref_buf, s2);
+        c->cos_in_gemm = false;
+        if (rc_h) return rc_h;
+        HIPCHK(hipEventRecord(c->ev_join, s2));
+        const float* g_net = c->g_final;
+        if (c->dual) {
+            hipLaunchKernelGGL(scatter_dual_grad_kernel, dim3(nblk((long)c->Nn * c->Hp * c->Wp)), dim3(256), 0, s, c->g_final, c->g_net,
+                               c->N, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
+            g_net = c->g_net;
+        }
+        RUN(backbone_backward(c, g_net, s, true));
+        if (c->grad_comm && ptta_rccl_allreduce_mean_f32(c->grad_comm, c->grad_arena, c->grad_arena_n, s_)) return c->fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
+        RUN(ptta_adam_step(c, nullptr, nullptr, s_));
+        return 0;
     }
     // validity == NULL: where(sparse > 0, 1, sparse) is evaluated inside the loss kernels; the loss finalisation runs inside
     // the two gradient kernels (no 1-block launch between forward and backward)

@@ -158,6 +158,10 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
                              float max_input_depth, const float* emb, const float* ref, long R, int D,
                              const float* w3_dev /* w_sd, w_sm, w_cos */, int N, int H, int W,
                              float* ws, float* loss_info, hipStream_t s, int defer_finalize = 0);
+int ptta_launch_loss_depth_part(const float* depth, const float* image, const float* sparse, const float* validity, float max_input_depth,
+                                int N, int H, int W, float* ws, hipStream_t s);
+int ptta_launch_loss_cos_part(const float* emb, const float* ref, long R, int D, int N, float* ws, hipStream_t s);
+int ptta_launch_loss_finalize(float* ws, int N, int H, int W, long R, int has_cos, const float* w3_dev, float* loss_info, hipStream_t s);
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
                               int N, int H, int W, float* ws, float* gdepth, float* gref, hipStream_t s, const float* w3_fused = nullptr,

@@ -54,6 +54,28 @@ __global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView 
                     s1 += (a0 + a1) + (a2 + a3); s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
                 }
             }
+            if (MODE == 1) {
+                // four pixels' loads (x, g, y: twelve) in flight, accumulated in the pixel order of the plain loop below: same sums bit for
+                // bit.  (One pixel per iteration made this pass a chain of dependent load latencies: 33 us per call in the NLSPN profile.)
+                const float fs = fscale ? fscale[c] : 0.f, fh = fscale ? fshift[c] : 0.f;
+                for (; p + 3 * pstride < ppp; p += 4 * pstride) {
+                    float xv[4], gv[4], yv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const long q = pix0 + p + k * pstride;
+                        xv[k] = x.p[q * x.ld + c]; gv[k] = g.p[q * g.ld + c]; yv[k] = y.p[q * y.ld + c];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float gk = gv[k];
+                        if (res_relu) {
+                            gk = yv[k] > 0.f ? gk : 0.f;
+                            if (fscale) gk = fmaf(xv[k], fs, fh) > 0.f ? gk : 0.f;
+                        } else gk = gbn_act_grad(gk, yv[k], act);
+                        s1 += gk; s2 += gk * (xv[k] - mu) * iv;
+                    }
+                }
+            }
             for (; p < ppp; p += pstride) {
                 const float xv = x.p[(pix0 + p) * x.ld + c];
                 if (MODE == 0) { s1 += xv; s2 += xv * xv; }

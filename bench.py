@@ -441,12 +441,20 @@ def msgchn_multi_stream(args, rank, world, dist, affinity):
         it += args.steps
         barrier()
         dt = time.perf_counter() - t0
+        own_block_s.append(dt)
         if dist is not None:
             t = torch.tensor([dt], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         block_s.append(dt)
     elapsed = float(np.median(block_s))
+    # per-rank view of the same blocks (each rank's OWN median block, gathered): tells a slow rank from a slow barrier in a SCALE run
+    per_rank_ms = [1e3 * float(np.median(own_block_s)) / args.steps]
+    if dist is not None:
+        t = torch.zeros(world, device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+        t[rank] = per_rank_ms[0]
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(x) for x in t.cpu()]
     finite = bool(torch.isfinite(info).all().item())
     for e in engs:
         e.close()
@@ -636,6 +644,38 @@ def costdcnet_cpu_baseline():
             'sample': '1 TTA step of the same 480x640 workload after one eval forward (PyTorch-CPU oracle, fp32, %.1f s/step)' % dt}
 
 
+def pipelined_self_check(dtype, k, rank=0):
+    """The headline is timed on ptta_step_pipelined; this replays the first `k` frames of the timed stream on TWO fresh handles -- one through
+    the pipelined call (next frame announced), one through plain ptta_step -- from the same initial parameters and compares the adapted
+    parameters, the Adam moments and every step's loss_info BIT FOR BIT (what tests/test_gpu_staging_augment.py asserts under pytest, here
+    inside the run that produced the number)."""
+    from proxytta import synth
+    from proxytta.engine import ADAPTED, Engine
+    nframes = 4
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(rank * 1000 + i, H, W, 1)] for i in range(nframes)]
+    res = []
+    for mode in ('pipelined', 'plain'):
+        eng = Engine(1, H, W, dtype=dtype, **HP)
+        sd = {kk: torch.from_numpy(np.asarray(v)).cuda() for kk, v in synth.formula_state_dict(MODE).items()}
+        eng.load_state_dict(sd)
+        st = {name: (sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name])) for name in ADAPTED}
+        for name in ADAPTED:
+            eng.bind_adapted(name, *st[name])
+        infos = []
+        for i in range(k):
+            nxt = frames[(i + 1) % nframes] if mode == 'pipelined' else None
+            infos.append(eng.step(*frames[i % nframes], next_frame=nxt)[0].clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(infos).cpu(), {n_: [t.detach().cpu().clone() for t in v] for n_, v in st.items()}))
+        eng.close()
+    (ia, pa), (ib, pb) = res
+    same = bool(torch.equal(ia, ib))
+    for n_ in pa:
+        for ta, tb in zip(pa[n_], pb[n_]):
+            same = same and bool(torch.equal(ta, tb))
+    return same
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -644,6 +684,7 @@ def main():
     ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'bf16'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-block', action='store_true', help='time ONE block of --steps steps (quick A/B runs) instead of >= 10 blocks / >= 200 steps')
+    ap.add_argument('--no-self-check', action='store_true', help='skip the pipelined-vs-plain bitwise replay on fresh handles')
     ap.add_argument('--no-nlspn', action='store_true', help='skip the side measurements (2layers, NLSPN, CostDCNet)')
     ap.add_argument('--streams-per-gpu', type=int, default=1,
                     help='config 4 only (independent frame streams): this many streams -- own adapted parameters, Adam state and hipGraphs each -- '
@@ -708,7 +749,7 @@ def main():
     # >= 10 blocks of K steps, >= 200 timed steps in all; every block is the contract's timed region: barrier + synchronize on
     # both sides, MAX over ranks; the reported figure is the MEDIAN block.  (With --warmup 0 the first timed call computes its own prefix in line.)
     nblocks = 1 if args.single_block else max(10, -(-200 // max(args.steps, 1)))
-    block_s = []
+    block_s, own_block_s = [], []
     info = None
     it = args.warmup
     for blk in range(nblocks):
@@ -719,12 +760,20 @@ def main():
             it += 1
         barrier()
         dt = time.perf_counter() - t0
+        own_block_s.append(dt)
         if dist is not None:
             t = torch.tensor([dt], device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         block_s.append(dt)
     elapsed = float(np.median(block_s))
+    # per-rank view of the same blocks (each rank's OWN median block, gathered): tells a slow rank from a slow barrier in a SCALE run
+    per_rank_ms = [1e3 * float(np.median(own_block_s)) / args.steps]
+    if dist is not None:
+        t = torch.zeros(world, device='cuda' if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
+        t[rank] = per_rank_ms[0]
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(x) for x in t.cpu()]
     # the same K steps call by call with no next frame announced (plain ptta_step): reported beside the metric
     plain_ms = None
     if pipe and world == 1:
@@ -789,6 +838,9 @@ def main():
     ms, abytes, macs, launches = [sum(x) for x in zip(prof[0], prof[1])]      # dominant class = stride-1, ReLU on load (large + small maps)
     eng.profile(False)
     finite = bool(torch.isfinite(info).all().item())
+    eq_plain = None
+    if pipe and world == 1 and not args.no_self_check:
+        eq_plain = pipelined_self_check(args.dtype, min(args.steps, 12), rank)
 
     if rank == 0:
         es = 4 if args.dtype == 'fp32' else 2
@@ -834,7 +886,11 @@ def main():
                        'frame_pipelining': ('on: every call names the next frame of the stream; the part of its forward upstream of the adapted layer (frozen RGB '
                                             'encoder, sparse-depth pooling, stage-1/4 cascade down to decoder 1\'s last transposed conv) runs on a second stream '
                                             'beside the current step; K timed calls = K prefixes + K remainders; identical results' if pipe else 'off'),
-                       'ms_per_step_without_frame_pipelining': plain_ms},
+                       'ms_per_step_without_frame_pipelining': plain_ms,
+                       # the timed path against plain ptta_step on fresh handles, bit for bit (null: not run -- N > 1 or --no-self-check)
+                       'pipelined_equals_plain': eq_plain,
+                       'rccl_ranks': world if (dist is not None and dist.get_backend() == 'nccl') else (0 if dist is None else None),
+                       'collective_backend': None if dist is None else dist.get_backend()},
             'step_roofline': {'alg_bytes_per_step': (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * es, 'alg_flop_per_step': ALG_FLOP_PER_STEP,
                               'alg_bytes_reference_executes': ALG_ELEMENTS_PER_STEP * es,
                               'note': 'alg_bytes_per_step excludes the constant zero-image RGB-encoder pass, hoisted out of the step',
@@ -844,7 +900,9 @@ def main():
             'roofline_by_class': by_class,
             'timing': {'protocol': '%d blocks x %d steps, each block bracketed by barrier + synchronize, MAX over ranks; ms_per_step = median block' % (nblocks, args.steps),
                        'blocks': nblocks, 'steps_timed': nblocks * args.steps, 'ms_per_step_median': 1e3 * elapsed / args.steps,
-                       'ms_per_step_min': 1e3 * min(block_s) / args.steps, 'ms_per_step_max': 1e3 * max(block_s) / args.steps},
+                       'ms_per_step_min': 1e3 * min(block_s) / args.steps, 'ms_per_step_max': 1e3 * max(block_s) / args.steps,
+                       'per_rank_ms_per_step': {'min': min(per_rank_ms), 'median': float(np.median(per_rank_ms)), 'max': max(per_rank_ms),
+                                                'ranks': per_rank_ms, 'note': "each rank's own median block, before the MAX over ranks"}},
         }
         if from_host is not None:
             out['from_host_memory'] = from_host

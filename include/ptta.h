@@ -61,7 +61,16 @@ typedef void* ptta_stream;              /* hipStream_t */
  * behind two SyncBatchNorm modules (norm3 and downsample[1]) and are listed -- and updated by Adam -- twice per step:
  * ptta_adapted_repeat() is 2 for them, 0 for proj.1 / pred.1 (listed, never given a gradient), 1 otherwise. */
 enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1, PTTA_BACKBONE_COSTDCNET = 2 };
-enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_BF16 = 1 };   /* storage type of 32-channel activations */
+/* Storage / arithmetic of the MSG_CHN step.
+ * PTTA_DTYPE_F32: every 32-channel map fp32, every product fp32-faithful on the bf16 matrix cores (bf16x3 split, fp32 accumulate).
+ * PTTA_DTYPE_MIXED (BASELINE config 2; replaces the all-bf16 mode of rounds 1-4, which missed the tolerance by 9x and is gone): the REAL
+ *   frames' forward -- the tensors the scored depth map is made of -- exactly as PTTA_DTYPE_F32; the tensors the reference computes under
+ *   no_grad or detaches (the zero-image proxy pass, network_exp_msg_chn_adapt.py:509-532, the embedding branch :551-554) and the data
+ *   gradients of loss.backward() (src/tta_main.py:632), which reach the scored depth only through an lr-sized Adam move, are NARROW: bf16
+ *   storage, one bf16 MFMA per product, fp32 accumulate.  depth_train is bit-identical to PTTA_DTYPE_F32; measured budget per tensor
+ *   class: profiles/r05_precision_budget.txt; bounds per mode: tests/test_gpu_mixed.py.  PTTA_ARITH=exact / PTTA_CONV_IMPL=naive are
+ *   PTTA_DTYPE_F32-only (ptta_create returns -38 with PTTA_DTYPE_MIXED). */
+enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_MIXED = 1 };
 enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };   /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
 /* NLSPN only, OR-ed into meta_mode: ExternalModel_Adapt(..., offset=True) -> args.legacy (src/nlspn_model_adapt.py:62):
  * the confidence gathers add each tap's own (dy, dx) to the learned offset (nlspnmodel_adapt.py:297-302).

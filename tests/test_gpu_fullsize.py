@@ -27,9 +27,13 @@ def _check_map(got, g, key, tol):
     assert abs(np.abs(flat).mean(dtype=np.float64) - float(g[key + '_abs_mean'])) < tol * float(g[key + '_abs_mean'])
 
 
+@pytest.mark.parametrize('path', ['plain', 'pipelined'])
 @pytest.mark.parametrize('name,meta', [('msgchn_1layer_352x1216', '1layer'), ('msgchn_1layer_256x320', '1layer'),
                                        ('msgchn_2layers_352x1216', '2layers'), ('msgchn_2layers_256x320', '2layers')])
-def test_full_size_matches_reference(golden_dir, name, meta):
+def test_full_size_matches_reference(golden_dir, name, meta, path):
+    """path = 'pipelined': the path bench.py's headline times -- ptta_step_pipelined (every call announces frame s + 1, whose
+    parameter-independent prefix runs on the second stream beside this step) and the scored forward from ptta_forward_eval_last --
+    held to the same reference vectors at the same bounds as the plain ptta_step / ptta_forward_eval pair."""
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps, frame0 = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
@@ -37,7 +41,10 @@ def test_full_size_matches_reference(golden_dir, name, meta):
     for s in range(steps):
         image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s, h, w, n)]
         p = 's%d/' % s
-        info, depth = eng.step(image, sparse, want_depth=True)
+        nxt = None
+        if path == 'pipelined':
+            nxt = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s + 1, h, w, n)]
+        info, depth = eng.step(image, sparse, want_depth=True, next_frame=nxt)
         torch.cuda.synchronize()
         _check_map(depth, g, p + 'depth_train', 1e-4)
         np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=1e-4)
@@ -65,7 +72,7 @@ def test_full_size_matches_reference(golden_dir, name, meta):
                 key = k[len(p) + 4:]
                 if not key.startswith('proj_t'):
                     assert rel_mae(sd[key], g[k]) < 2e-3, k
-        d_eval = eng.forward_eval(image, sparse)
+        d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
         _check_map(d_eval, g, p + 'depth_eval', 1e-4)
     eng.close()
 

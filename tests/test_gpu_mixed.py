@@ -1,0 +1,206 @@
+"""The mixed-precision mode (include/ptta.h PTTA_DTYPE_MIXED; BASELINE config 2) under -m gpu, through the C-ABI.
+
+The real frames' forward is the fp32 / bf16x3 path of PTTA_DTYPE_F32; the zero-image proxy pass (no_grad in the reference,
+network_exp_msg_chn_adapt.py:509-532) and every data gradient of loss.backward() (src/tta_main.py:632) run on narrow maps (bf16 storage, one
+bf16 MFMA per product).  What is held here, against vectors produced by the REAL reference (tests/golden/make_golden*.py):
+  * depth_train at the fp32 mode's own bound (and BIT-identical to the fp32 mode on the first step of a handle: same kernels, same inputs),
+  * the scored post-update depth (depth_eval) at 3e-4 -- the north_star asks for 1e-3,
+  * loss_info at 1e-3, the cosine gate on the reference's side of 0.3,
+  * gradients / parameters / Adam moments at bounds = 2x measured (tools/accuracy_report.py --dtype mixed; profiles/r05_precision_budget.txt),
+  * the pipelined call (what bench.py times) bit-identical to the plain one in this mode too.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from proxytta import synth
+from tests.test_gpu_fullsize import _check_map
+from tests.util import golden_hp, make_engine, rel_mae
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('path', ['plain', 'pipelined'])
+@pytest.mark.parametrize('name,meta', [('msgchn_1layer_352x1216', '1layer'), ('msgchn_1layer_256x320', '1layer'),
+                                       ('msgchn_2layers_352x1216', '2layers'), ('msgchn_2layers_256x320', '2layers')])
+def test_mixed_full_size_matches_reference(golden_dir, name, meta, path):
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps, frame0 = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, gain, None, meta=meta)
+    for s in range(steps):
+        image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s, h, w, n)]
+        p = 's%d/' % s
+        nxt = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s + 1, h, w, n)] if path == 'pipelined' else None
+        info, depth = eng.step(image, sparse, want_depth=True, next_frame=nxt)
+        torch.cuda.synchronize()
+        # the training-mode depth is made of fp32 / bf16x3 tensors only: the fp32 mode's bound (second step: behind one mixed Adam move)
+        _check_map(depth, g, p + 'depth_train', 1e-4 if s == 0 else 3e-4)
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=1e-3)
+        if p + 'row_idx' in g.files:
+            idx = g[p + 'row_idx']
+            # narrow proxy features and (from round 5's heads) narrow embeddings: measured 2e-3 / 6e-3 -> bound 2x
+            assert rel_mae(eng.debug_tensor('emb').view(-1, 512).cpu()[idx], g[p + 'emb_rows']) < 4e-2
+            assert rel_mae(eng.debug_tensor('ref').view(-1, 512).cpu()[idx], g[p + 'ref_rows']) < 2e-2
+        for k, (prm, m, v) in adapted.items():
+            if p + 'grad/' + k not in g.files:
+                continue
+            gref = g[p + 'grad/' + k]
+            got = eng.grad(k, prm)
+            if np.abs(gref).max() < 1e-6:                      # conv bias in front of a BatchNorm: analytically zero
+                assert float(got.abs().max()) < 1e-3
+                continue
+            assert rel_mae(got, gref) < (6e-2 if meta == '2layers' else 3e-2), (k, s, rel_mae(got, gref))
+            assert rel_mae(prm, g[p + 'param/' + k]) < 1e-2, k
+        d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
+        _check_map(d_eval, g, p + 'depth_eval', 3e-4)
+    eng.close()
+
+
+def test_mixed_first_step_depth_is_bit_identical_to_fp32_mode():
+    """The real frames' forward runs the SAME kernels on the same inputs in both modes (as one launch per layer over [real | proxy] in fp32
+    mode, over the real frames alone in mixed mode: the arithmetic per tile is the same) -- so before the first Adam move the training-mode
+    depth map and the eval forward are bitwise equal."""
+    n, h, w = 1, 352, 1216
+    hp = dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
+    image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(3, h, w, n)]
+    out = {}
+    for dt in ('fp32', 'mixed'):
+        eng, sd, adapted = make_engine(n, h, w, dt, hp)
+        ev = eng.forward_eval(image, sparse).clone()
+        info, depth = eng.step(image, sparse, want_depth=True)
+        torch.cuda.synchronize()
+        out[dt] = (ev, depth.clone(), info.clone())
+        eng.close()
+    assert torch.equal(out['fp32'][0], out['mixed'][0])
+    assert torch.equal(out['fp32'][1], out['mixed'][1])
+    # depth terms of the loss: same inputs, same kernel; the cosine term sees the narrow proxy pass
+    a, b = out['fp32'][2].cpu().numpy(), out['mixed'][2].cpu().numpy()
+    assert a[1] == b[1] and a[2] == b[2]
+    np.testing.assert_allclose(b, a, rtol=1e-3)
+
+
+def test_mixed_ten_step_sequence_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'msgchn_1layer_64x96_seq10.npz'))
+    h, w, n, steps, frame0 = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, gain, None)
+    for s in range(steps):
+        image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s, h, w, n)]
+        p = 's%d/' % s
+        info, depth = eng.step(image, sparse, want_depth=True)
+        _check_map(depth, g, p + 'depth_train', 1e-3)
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=1e-3)
+        _check_map(eng.forward_eval(image, sparse), g, p + 'depth_eval', 1e-3)
+    assert eng.adam_step_count() == steps
+    eng.close()
+
+
+@pytest.mark.parametrize('side', ['below', 'above'])
+@pytest.mark.parametrize('path', ['graph', 'pipelined', 'eager'])
+def test_mixed_cosine_gate_on_the_reference_side(golden_dir, side, path):
+    """loss_cos < 0.3 => w_cos = 0 (src/external_model_adapt.py:424-425), evaluated on device from the narrow embeddings: the gate must fall
+    on the reference's side in both fixtures (L_cos = 0.204 / 0.369) -- w_cos = 300 there, so a gate taken the wrong way moves the first-step
+    gradient by ~8e-2 and the loss by > 100."""
+    g = np.load(os.path.join(golden_dir, 'msgchn_1layer_64x96_gate_%s.npz' % side))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, gain, None, head_bias=float(g['head_bias']))
+    if path == 'eager':
+        eng.set_graph(False)
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)] for s in range(steps + 1)]
+    below = side == 'below'
+    for s in range(steps):
+        image, sparse = frames[s]
+        p = 's%d/' % s
+        info, depth = eng.step(image, sparse, want_depth=True, next_frame=frames[s + 1] if path == 'pipelined' else None)
+        torch.cuda.synchronize()
+        li = info.cpu().numpy()
+        assert (li[3] < 0.3) == below
+        np.testing.assert_allclose(li, g[p + 'loss_info'], rtol=3e-3)
+        dense = hp['w_sparse_depth'] * li[2] + hp['w_smoothness'] * li[1]
+        assert abs(li[0] - dense) < 1e-4 * li[0] if below else li[0] > dense + 100.0
+        assert rel_mae(depth, g[p + 'depth_train']) < (1e-4 if s == 0 else 1e-3)
+        gw = eng.debug_tensor('gW').view(32, 32, 3, 3)
+        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < 6e-2, (side, s, rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']))
+        d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-3
+    eng.close()
+
+
+@pytest.mark.parametrize('meta,size', [('1layer', (64, 128)), ('1layer', (352, 1216)), ('2layers', (352, 1216)), ('1layer', (36, 52))])
+def test_mixed_pipelined_equals_plain(meta, size):
+    """Bitwise, six frames incl. an unannounced one, in the mixed mode (two launch chains per forward, narrow twins of the prefix's outputs in
+    both buffer sets); 36x52: the dual-corner padded path (falls back to the plain call)."""
+    n = 1
+    h, w = size
+    hp = dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(60 + i, h, w, n)] for i in range(7)]
+    out = {}
+    for mode in ('plain', 'pipelined'):
+        eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, meta=meta)
+        rec = []
+        for i in range(6):
+            nxt = frames[i + 1] if mode == 'pipelined' else None
+            if i == 3 and mode == 'pipelined':
+                nxt = frames[6]                                              # announce the WRONG frame once
+            info, depth = eng.step(frames[i][0], frames[i][1], want_depth=True, next_frame=nxt)
+            ev = eng.forward_eval_last() if (mode == 'pipelined' and i in (1, 4)) else (eng.forward_eval(*frames[i]) if i in (1, 4) else None)
+            rec.append((info.clone(), depth.clone(), None if ev is None else ev.clone(), {k: v[0].clone() for k, v in adapted.items()}))
+        torch.cuda.synchronize()
+        out[mode] = rec
+        eng.close()
+    for a, b in zip(out['plain'], out['pipelined']):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert (a[2] is None) == (b[2] is None) and (a[2] is None or torch.equal(a[2], b[2]))
+        for k in a[3]:
+            assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_mixed_refuses_the_validation_arithmetic_modes():
+    from proxytta.engine import Engine
+    os.environ['PTTA_ARITH'] = 'exact'
+    try:
+        with pytest.raises(RuntimeError):
+            Engine(1, 32, 48, dtype='mixed')
+    finally:
+        os.environ.pop('PTTA_ARITH', None)
+
+
+@pytest.mark.parametrize('name', ['msgchn_1layer_36x52_pad', 'msgchn_1layer_32x48_n2', 'msgchn_1layer_32x48_wcos1', 'msgchn_2layers_32x48'])
+def test_mixed_small_goldens_split_calls_and_fused_step(golden_dir, name):
+    """The reference fixtures of tests/test_gpu_parity.py (dual-corner padding, batch 2, w_cos = 1, the 2layers meta block) in the mixed mode:
+    ptta_forward_train as its own call, then the fused step; depth at the fp32 mode's bound on the first step, 1e-3 afterwards; loss terms
+    1e-3; gradients at 2x measured."""
+    g = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    hp, gain = golden_hp(g)
+    meta = '2layers' if '2layers' in name else '1layer'
+    eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, gain, None, meta=meta)
+    for s in range(steps):
+        image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)]
+        p = 's%d/' % s
+        bufs = {k: v.clone() for k, v in sd.items() if k.endswith(('running_mean', 'running_var'))}
+        depth, emb, ref = eng.forward_train(image, sparse)
+        assert rel_mae(depth, g[p + 'depth_train']) < (1e-4 if s == 0 else 1e-3), (name, s)
+        idx = g[p + 'row_idx']
+        assert rel_mae(emb.cpu()[idx], g[p + 'emb_rows']) < 4e-2
+        assert rel_mae(ref.cpu()[idx], g[p + 'ref_rows']) < 2e-2
+        for k, v in bufs.items():
+            sd[k].copy_(v)
+        info, depth2 = eng.step(image, sparse, want_depth=True)
+        torch.cuda.synchronize()
+        assert rel_mae(depth2, g[p + 'depth_train']) < (1e-4 if s == 0 else 1e-3)
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2e-3)
+        for k, (prm, m, v) in adapted.items():
+            gref = g[p + 'grad/' + k]
+            got = eng.grad(k, prm)
+            if np.abs(gref).max() < 1e-6:
+                assert float(got.abs().max()) < 1e-3
+                continue
+            assert rel_mae(got, gref) < 8e-2, (name, k, s, rel_mae(got, gref))
+        d_eval = eng.forward_eval(image, sparse)
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-3
+    eng.close()

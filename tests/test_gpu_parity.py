@@ -1,7 +1,7 @@
 """GPU parity tests: the HIP path (through the C-ABI) against the golden vectors produced by the
 real reference and against the oracle on the same seeded inputs.  Tolerances are the ones of
 BASELINE.json's north_star: float32, relative MAE <= 1e-3 on depth maps (we hold fp32 mode to
-1e-4 or better); bf16 mode is reported separately in test_gpu_bf16.py."""
+1e-4 or better); the mixed-precision mode has its own file, tests/test_gpu_mixed.py."""
 import os
 
 import numpy as np
@@ -91,18 +91,25 @@ def test_op_conv32_bf16x3(shape, relu):
             assert rel_mae(got, ref) < 2e-5, mode
 
 
-def test_op_conv32_bf16():
+@pytest.mark.parametrize('shape', [(1, 8, 64), (2, 20, 48), (1, 88, 1216)])
+def test_op_conv32_narrow(shape):
+    """The NARROW instantiations of the tuned kernels (bf16 maps, one bf16 MFMA per product: the mixed mode's proxy-pass and gradient
+    maps) against torch on bf16-rounded operands: small maps (one-tile kernel), ragged tiles, and a map of > 256 tiles (the persistent
+    LDS-staged stride-1 / stride-2 kernels and the direct transposed kernel)."""
     from proxytta.engine import op_conv32
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(1, 8, 64, 32, generator=g)
+    b_, h_, w_ = shape
+    x = torch.randn(b_, h_, w_, 32, generator=g)
     w = torch.randn(32, 32, 3, 3, generator=g) * 0.1
     b = torch.randn(32, generator=g)
     for mode in (0, 1, 2):
-        xr = x.bfloat16().float()
-        wr = w.bfloat16().float()
-        ref = _torch_conv(xr, wr, b, mode, True)
-        got = op_conv32(x.cuda(), w.cuda(), b.cuda(), mode, relu_in=True, in_major=(mode == 2), dtype='bf16').cpu()
-        assert rel_mae(got, ref) < 4e-3        # output rounded to bf16
+        for relu in (True, False):
+            xr = x.bfloat16().float()
+            wr = w.bfloat16().float()
+            ref = _torch_conv(xr, wr, b, mode, relu)
+            got = op_conv32(x.cuda(), w.cuda(), b.cuda(), mode, relu_in=relu, in_major=(mode == 2), dtype='narrow').cpu()
+            assert rel_mae(got, ref) < 4e-3, (mode, relu)        # output rounded to bf16 (2^-9 per element)
+            assert rel_mae(got, ref.bfloat16().float()) < 4e-4, (mode, relu)     # ... and beyond that rounding only fp32 summation order
 
 
 def _run_golden(name, impl, golden_dir):

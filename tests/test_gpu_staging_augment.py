@@ -281,13 +281,16 @@ def test_staged_sequence_equals_resident_sequence():
             assert torch.equal(pa[k], pb[k]), (mode, k)
 
 
-@pytest.mark.parametrize('meta,n', [('1layer', 1), ('2layers', 1), ('1layer', 2)])
-def test_pipelined_steps_equal_plain_steps(meta, n):
+@pytest.mark.parametrize('meta,n,size', [('1layer', 1, (64, 128)), ('2layers', 1, (64, 128)), ('1layer', 2, (64, 128)),
+                                         ('1layer', 1, (352, 1216)), ('2layers', 1, (352, 1216))])
+def test_pipelined_steps_equal_plain_steps(meta, n, size):
     """ptta_step_pipelined: the parameter-independent prefix of frame k+1 (sparse-depth pooling, frozen RGB encoder, depth-only head of the
     stage-1 encoder) runs on its own stream beside the step of frame k.  Same parameters, losses and depths as ptta_step, call by call --
     also with an eval forward between two calls, an unannounced frame (prefix recomputed in line) and a plain step in the middle."""
+    # (352x1216: the size bench.py times -- persistent 480-block launches, the fused first-two-layer and head-backward kernels and
+    # the prefix stream beside full-chip kernels only exist together there)
     from tests.util import make_engine
-    h, w = 64, 128
+    h, w = size
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(20 + i, h, w, n)] for i in range(7)]
     out = {}
     for mode in ('plain', 'pipelined'):

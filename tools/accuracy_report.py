@@ -28,7 +28,7 @@ def rel(a, b):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--dtype', default='bf16')
+    ap.add_argument('--dtype', default='mixed')
     ap.add_argument('--size', default='128x256')
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--threads', type=int, default=16)
@@ -52,8 +52,13 @@ def main():
         d_eval = eng.forward_eval(ic.cuda(), sc.cuda())
         ref_eval = o.forward_eval(ic, sc)
         gw = eng.debug_tensor('gW').view(32, 32, 3, 3)
+        gr = r['grads'][ADAPTED[0]]
         row = {'step': s, 'depth_train': rel(depth, r['depth']), 'depth_eval': rel(d_eval, ref_eval),
-               'grad_w': rel(gw, r['grads'][ADAPTED[0]]), 'param_w': rel(sd[ADAPTED[0]], o.P[ADAPTED[0]]),
+               'depth_move': rel(ref_eval, r['depth']),
+               'emb': rel(eng.debug_tensor('emb'), r['emb'].reshape(-1)), 'ref': rel(eng.debug_tensor('ref'), r['ref'].reshape(-1)),
+               'grad_w': rel(gw, gr), 'grad_w_relmax': float((gw.cpu() - gr).abs().max() / gr.abs().max()),
+               'sign_flips': float((torch.sign(gw.cpu()) != torch.sign(gr)).float().mean()),
+               'param_w': rel(sd[ADAPTED[0]], o.P[ADAPTED[0]]),
                'loss_info': [float(x) for x in info.cpu()],
                'loss_info_ref': [r['loss_info'][k] for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')]}
         rows.append(row)

@@ -30,18 +30,7 @@ struct Conv32P {
     const void* wpack2;          // lo fragments (bf16x3 arithmetic)
     Epi<T> epi;
     int B, Hin, Win, Hout, Wout;
-    int stagger;                 // persistent kernels, full grids (two resident blocks per CU): shader cycles by which the second half of the
-                                 // grid starts late, so that the two blocks of a CU run their memory and matrix phases in anti-phase
 };
-// Blocks of a persistent full-chip launch all start together and then stay in lock-step (load, split, MFMA, store): the memory system idles
-// during the matrix phases and the matrix cores during the memory phases.  Workgroups are dealt to the CUs in index
-// order, so block b and block b + gridDim/2 share a CU: the upper half waits `cycles` before its first load.
-__device__ __forceinline__ void stagger_start(int cycles) {
-    if (cycles > 0 && blockIdx.x >= 256) {                 // the SECOND resident block of a CU (the first 256 workgroups go one per CU)
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)cycles) __builtin_amdgcn_s_sleep(16);
-    }
-}
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef float4 A; };
@@ -154,23 +143,24 @@ __global__ __launch_bounds__(256) void conv32_mfma_kernel(Conv32P<T> p) {
 }
 
 
-// ---- stride-1, fp32 storage, "bf16x3" arithmetic, LDS-staged -----------------------------------
-// fp32-faithful products on the bf16 matrix cores: x = xh + xl, w = wh + wl (each half a bf16),
-// x*w ~= xh*wh + xl*wh + xh*wl (the dropped xl*wl term is 2^-16 relative), accumulated in fp32 by
-// v_mfma_f32_32x32x16_bf16: 3 MFMAs instead of the 16x slower fp32 MFMA.  Measured end-to-end
-// error vs the fp32 oracle: see DESIGN.md §6.
-// A block owns an 8x32 output tile: the (8+2)x(32+2) input halo is read from HBM once (full 128-B
-// NHWC lines), ReLU'd and split ONCE while it is staged into LDS as [pixel][hi 64 B | lo 64 B]
-// with a 144-B pixel stride (conflict-free ds_read_b128: bank = 4*(9*pixel mod 16) + const).
-// Each wave computes two 32-pixel rows; weights (hi and lo fragments, 144 VGPRs) stay in
-// registers across the persistent tile loop.
+// ======================================================================================================================
+// The tuned kernels.  Every one is a template over the STORAGE type T of its input, output and skip operands:
+//   T = float   fp32 maps, "bf16x3" arithmetic: x = xh + xl, w = wh + wl (each half a bf16), x*w ~= xl*wh + xh*wl + xh*wh (the dropped
+//               xl*wl term is 2^-16 relative), fp32 accumulate -- the REAL frames' forward, whose output is the scored depth map;
+//   T = bf16_t  narrow maps, ONE bf16 MFMA per product ("x1"), fp32 accumulate, one rounding per stored value -- the tensors the reference
+//               computes under no_grad / detaches (the zero-image proxy pass, network_exp_msg_chn_adapt.py:509-532) and the data gradients
+//               of loss.backward() (src/tta_main.py:632), which reach the scored depth only through an lr-sized Adam move
+//               (profiles/r05_precision_budget.txt).  Half the bytes per pixel, a third of the MFMAs, no operand split, no lo planes.
+// The two instantiations share every line of tile geometry, prefetch and epilogue structure; they differ in Px<T> (8 channels of a pixel in
+// registers), px_stage (ReLU + split while a pixel is written to LDS) and the number of MFMAs per fragment pair.
+// ======================================================================================================================
 #define X3_TH 8
 #define X3_PW 34
 #define X3_PH 10
-#define X3_STRIDE 144
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef short short2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
     float2_t v = {a, b};
@@ -179,23 +169,92 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     float2_t r = {a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u)};
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
 }
+// ReLU of two packed bf16: sign-magnitude values ordered as int16 -> one v_pk_max_i16 against zero (-0.0 -> +0.0)
+__device__ __forceinline__ unsigned relu_pk(unsigned v) {
+    const short2_t z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(short2_t, v), z));
+}
+
+// 8 consecutive channels of one NHWC pixel in registers
+template <typename T> struct Px;
+template <> struct Px<float> { float4 a, b; };
+template <> struct Px<bf16_t> { uint4 a; };
+template <typename T> __device__ __forceinline__ Px<T> px_zero();
+template <> __device__ __forceinline__ Px<float> px_zero<float>() { Px<float> r; r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = r.a; return r; }
+template <> __device__ __forceinline__ Px<bf16_t> px_zero<bf16_t>() { Px<bf16_t> r; r.a = make_uint4(0u, 0u, 0u, 0u); return r; }
+__device__ __forceinline__ Px<float> px_load(const float* src) { Px<float> r; r.a = *(const float4*)src; r.b = *(const float4*)(src + 4); return r; }
+__device__ __forceinline__ Px<bf16_t> px_load(const bf16_t* src) { Px<bf16_t> r; r.a = *(const uint4*)src; return r; }
+// (ReLU,) bf16 hi / lo split, 16 B of hi fragments to `dst` and -- fp32 storage -- 16 B of lo fragments to `dst + lo_off`
+template <bool RELU>
+__device__ __forceinline__ void px_stage(const Px<float>& v, unsigned char* dst, int lo_off) {
+    float4 a0 = v.a, a1 = v.b;
+    if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
+    uint4 hi, lo;
+    split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);
+    split2(a1.x, a1.y, hi.z, lo.z); split2(a1.z, a1.w, hi.w, lo.w);
+    *(uint4*)dst = hi;
+    *(uint4*)(dst + lo_off) = lo;
+}
+template <bool RELU>
+__device__ __forceinline__ void px_stage(const Px<bf16_t>& v, unsigned char* dst, int) {
+    uint4 hi = v.a;
+    if (RELU) { hi.x = relu_pk(hi.x); hi.y = relu_pk(hi.y); hi.z = relu_pk(hi.z); hi.w = relu_pk(hi.w); }
+    *(uint4*)dst = hi;
+}
+// LDS pixel of the stride-1 halo tile: fp32 storage [hi 64 B | lo 64 B | pad 16 B], narrow [hi 64 B | pad 16 B]; both strides keep
+// ds_read_b128 of 16 consecutive pixels on disjoint banks (144: bank = 4 (9 p mod 16) + const; 80: 20 p mod 64 steps through all 16 quads)
+template <typename T> struct Geo;
+template <> struct Geo<float> { static constexpr int STR = 144, LO = 64, WL = 18 * 64 * 16, UPPX = 128, UPPC = 8; };
+template <> struct Geo<bf16_t> { static constexpr int STR = 80, LO = 0, WL = 0, UPPX = 64, UPPC = 4; };
 
 // staging item -> halo pixel: the 8 lanes of one ds_write_b128 group take pixels p and p+4 (not p, p+1):
-// at the 144-B stride their hi/lo footprints then fall on disjoint banks
+// at either pixel stride their footprints then fall on disjoint banks
 __device__ __forceinline__ int x3_stage_pix(int idx) { return ((idx >> 5) << 3) + (((idx >> 2) & 1) << 2) + ((idx >> 3) & 3); }
 
-#define CSTAMP(v) do { if (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
-// ABL (diagnostic instantiations only, PTTA_S1_ABL): 1 = no stores, 2 = no global loads, 4 = no MFMAs (LDS reads kept), 8 = no LDS reads either
-template <bool RELU, bool UP, bool MASK, bool ADD, bool TIMING = false, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) {
-    unsigned long long T0 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0, dW = 0, dS = 0, dI = 0, dB1 = 0, dM = 0, dE = 0, dB2 = 0, Tpro = 0; int ntl = 0;
-    CSTAMP(T0);
-    stagger_start(p.stagger);
-    // one LDS array: [halo tile | lo weight fragments | (UP) half-resolution source window of the bilinear skip]
+// one (tap, k-step) of the implicit GEMM: a = the lane's A fragment in the LDS tile (hi at a, lo at a + LO)
+template <typename T>
+__device__ __forceinline__ void mma_step(f32x16& acc, const unsigned char* a, const uint4& wh, const unsigned char* wl) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh);
+    if constexpr (sizeof(T) == 4) {
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + Geo<T>::LO));
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)wl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+// bilinear x2 skip: the half-resolution source window of a tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers,
+// one 1-KB piece = 8 (fp32) / 16 (narrow) source pixels per wave instruction, lane-linear image [pixel][32 channels], clamped at the borders)
+template <typename T, int UPH, int UPW>
+__device__ __forceinline__ void up_window_dma(const T* ub, int Hu, int Wu, int uy0, int ux0, unsigned char* up_lds, int tid, int wave) {
+    constexpr int PC = Geo<T>::UPPC, N = UPH * UPW * PC;
+#pragma unroll
+    for (int k = 0; k < (N + 255) / 256; ++k) {
+        const int idx = tid + 256 * k;
+        if (idx < N) {
+            const int q = idx % PC, pix = idx / PC;
+            const int r = pix / UPW, cc = pix - r * UPW;
+            const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + ((size_t)gy * Wu + gx) * 32 + (32 / PC) * q),
+                                             (__attribute__((address_space(3))) void*)(up_lds + (size_t)(256 * k + 64 * wave) * 16), 16, 0, 0);
+        }
+    }
+}
+
+// ---- stride-1, LDS-staged -------------------------------------------------------------------------------------------------
+// A block owns an 8x32 output tile: the (8+2)x(32+2) input halo is read from HBM once (full NHWC lines), ReLU'd and split ONCE while it is
+// staged into LDS.  Each wave computes two 32-pixel rows; the hi weight fragments (72 VGPRs) stay in registers across the persistent tile
+// loop, the lo fragments (fp32 storage) in LDS.  Without the bilinear epilogue the NEXT tile's global loads are issued before this tile's
+// MFMAs and land while the matrix cores work (software prefetch across the persistent tile loop).
+template <typename T, bool RELU, bool UP, bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
+    constexpr int STR = Geo<T>::STR, WL = Geo<T>::WL;
     constexpr int UPH = 6, UPW = 18;                      // an 8x32 output tile reads <= 5x17 source pixels
-    __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * X3_STRIDE + 18 * 64 * 16 + (UP ? UPH * UPW * 128 : 0)];
-    unsigned char* const wl_lds = lds + X3_PH * X3_PW * X3_STRIDE;
-    float* const up_lds = (float*)(wl_lds + 18 * 64 * 16);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * STR + WL + (UP ? UPH * UPW * Geo<T>::UPPX : 0)];
+    unsigned char* const wl_lds = lds + X3_PH * X3_PW * STR;
+    unsigned char* const up_lds = wl_lds + WL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -204,12 +263,9 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     const long ntiles = (long)p.B * ntx * nty;
     const float sy = up_scale(H >> 1, H), sx = up_scale(W >> 1, W);
 
-    // (pixel, 8-channel group) staging items, 6 per thread.  Without the bilinear epilogue there are
-    // registers to spare, so the NEXT tile's global loads are issued before this tile's MFMAs and
-    // land while the matrix cores work (software prefetch across the persistent tile loop).
-    constexpr int NIT = (((X3_PH * X3_PW + 7) / 8) * 32 + 255) / 256;
+    constexpr int NIT = (((X3_PH * X3_PW + 7) / 8) * 32 + 255) / 256;     // (pixel, 8-channel group) staging items per thread
     constexpr bool PREFETCH = !UP;       // (the bilinear epilogue leaves no registers for it: 13 spills and no gain when forced)
-    float4 v0[NIT], v1[NIT];
+    Px<T> v[NIT];
     auto tile_coords = [&](long tile, int& b, int& y0, int& x0) {
         long t_ = tile;
         const int ty = (int)(t_ % nty); t_ /= nty;          // y fastest: neighbouring blocks share halo rows in L2
@@ -219,95 +275,56 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
     auto issue_loads = [&](long tile) {
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
-        const float* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
+        const T* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
             const int g = idx & 3, pix = x3_stage_pix(idx);
             const int py = pix / X3_PW, px = pix - py * X3_PW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
-            if (ABL & 2) { v0[it] = make_float4((float)gy, (float)gx, 1.f, (float)it); v1[it] = v0[it]; continue; }
-            if (pix < X3_PH * X3_PW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float* src = inb + ((size_t)gy * W + gx) * 32 + 8 * g;
-                v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
-            }
+            v[it] = px_zero<T>();
+            if (pix < X3_PH * X3_PW && gy >= 0 && gy < H && gx >= 0 && gx < W) v[it] = px_load(inb + ((size_t)gy * W + gx) * 32 + 8 * g);
         }
     };
-    unsigned long long P1 = 0, P2 = 0, F1 = 0;
     if (PREFETCH && blockIdx.x < ntiles) issue_loads(blockIdx.x);
-    CSTAMP(P1);
-    // hi weight fragments stay in registers (72 VGPRs), lo fragments in LDS (read once per use).  Loaded AFTER the
-    // first tile's loads were issued so that the two L2 round trips overlap (the small low-resolution launches are
-    // one tile per block: their duration is this latency chain).
+    // weight fragments: loaded AFTER the first tile's loads were issued so that the two L2 round trips overlap
     uint4 wh[9][2];
     {
         const uint4* ph = (const uint4*)p.wpack;
-        const uint4* pl = (const uint4*)p.wpack2;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-        CSTAMP(P2);
-        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+        if constexpr (WL > 0) {
+            const uint4* pl = (const uint4*)p.wpack2;
+            for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+        }
     }
 
-    CSTAMP(Tpro);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
         int uy0 = 0, ux0 = 0;
         if (UP) {
-            // bilinear x2 skip: the source window goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, one 1-KB piece =
-            // 8 source pixels per wave instruction, lane-linear image [pixel][32 floats], clamped at the borders), issued FIRST so that
-            // it flies while this tile's halo is split and written; drained before the next tile's register prefetch is issued
-            // (vmcnt is in order: a later wait for the window would also wait for that prefetch)
+            // issued FIRST so that it flies while this tile's halo is split and written; drained before the next tile's register prefetch
+            // is issued (vmcnt is in order: a later wait for the window would also wait for that prefetch)
             const int Hu = H >> 1, Wu = W >> 1;
             uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
-            const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
-#pragma unroll
-            for (int k = 0; k < (UPH * UPW * 8 + 255) / 256; ++k) {
-                const int idx = tid + 256 * k;
-                if (idx < UPH * UPW * 8) {
-                    const int q = idx & 7, pix = idx >> 3;
-                    const int r = pix / UPW, cc = pix - r * UPW;
-                    const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q),
-                                                     (__attribute__((address_space(3))) void*)(up_lds + (size_t)(256 * k + 64 * wave) * 4), 16, 0, 0);
-                }
-            }
+            up_window_dma<T, UPH, UPW>(p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32, Hu, Wu, uy0, ux0, up_lds, tid, wave);
         }
         if (!PREFETCH) issue_loads(tile);
-        CSTAMP(ta);
-        if (TIMING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        CSTAMP(tb);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
             const int pix = x3_stage_pix(idx);
-            if (pix < X3_PH * X3_PW) {
-                float4 a0 = v0[it], a1 = v1[it];
-                if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
-                uint4 hi, lo;
-                split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);
-                split2(a1.x, a1.y, hi.z, lo.z); split2(a1.z, a1.w, hi.w, lo.w);
-                unsigned char* dst = lds + pix * X3_STRIDE + 16 * (idx & 3);
-                *(uint4*)dst = hi;
-                *(uint4*)(dst + 64) = lo;
-            }
+            if (pix < X3_PH * X3_PW) px_stage<RELU>(v[it], lds + pix * STR + 16 * (idx & 3), Geo<T>::LO);
         }
         if (UP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the window has landed (and this tile's halo loads before it)
-        CSTAMP(tc);
         if (PREFETCH && tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x);
-        CSTAMP(td);
-        // bilinear x2 skip: stage the source window once per tile as whole 128-B lines (clamped at the
-        // borders; only indices the lerp actually produces are ever read back)
         lds_barrier();          // LDS-only: the next tile's global loads (issued above) stay in flight during the MFMAs
-        CSTAMP(te);
         // ---- two output rows per wave ------------------------------------------------------------
 #pragma unroll 1
         for (int rr = 0; rr < 2; ++rr) {
-            unsigned long long m0 = 0, m1 = 0, m2 = 0; CSTAMP(m0);
             const int row = 2 * wave + rr;
             const int y = y0 + row;
             if (y >= H) break;                                      // wave-uniform
@@ -317,48 +334,16 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
-                const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * X3_STRIDE + 16 * h;
-                if (ABL & 8) { acc[tap] += __uint_as_float(wh[tap][0].x); continue; }
+                const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * STR + 16 * h;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (ABL & 4) {
-                        const uint4 qa = *(const uint4*)(a + 32 * k), qb = *(const uint4*)(a + 32 * k + 64), qc = *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
-                        acc[tap] += __uint_as_float(qa.x ^ qb.y ^ qc.z ^ wh[tap][k].w);
-                        continue;
-                    }
-                    const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-                }
+                for (int k = 0; k < 2; ++k) mma_step<T>(acc, a + 32 * k, wh[tap][k], wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
                 if (kx == 2) __builtin_amdgcn_sched_barrier(0);      // bound the ds_read prefetch depth (VGPR pressure)
             }
-            if (TIMING) { float sink = acc[0]; asm volatile("v_mov_b32 %0, %0" : "+v"(sink) :: "memory"); acc[0] = sink; }   // MFMA results landed
-            CSTAMP(m1);
-            if (UP) {
-                // (conv + bias) + bilinear, in the reference's order; the skip comes from the LDS window, added after the quad
-                // transpose (four channels of one pixel per lane: ptta_common.h epi_tile UPL)
-                epi_tile<float, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
-            } else {
-                if (!(ABL & 1) || acc[0] == 1.2345e-30f) epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
-            }
-            CSTAMP(m2);
-            dM += m1 - m0; dE += m2 - m1;
+            // (conv + bias) + bilinear, in the reference's order; the skip comes from the LDS window, added after the quad transpose
+            if (UP) epi_tile<T, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
+            else epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
         }
-        CSTAMP(tf);
         lds_barrier();          // LDS reuse only: do not wait for this tile's stores (nor the prefetch) to drain
-        CSTAMP(tg);
-        dW += tb - ta; dS += tc - tb; dI += td - tc; dB1 += te - td; dB2 += tg - tf; ++ntl;
-        if (ntl == 1) F1 = tg - ta;
-    }
-    if (TIMING) {
-        unsigned long long Tend = 0; CSTAMP(Tend);
-        if ((blockIdx.x == gridDim.x / 5 || blockIdx.x == (3 * gridDim.x) / 5) && lane == 0)
-            printf("blk %u wave %d tiles %d: life %llu pro %llu (issue0 %llu whloads %llu wl->lds %llu) first tile %llu | per tile: vmwait %llu split+write %llu issue %llu barrier1 %llu mfma %llu epilogue %llu barrier2 %llu\n", blockIdx.x, wave, ntl,
-                   Tend - T0, Tpro - T0, P1 - T0, P2 - P1, Tpro - P2, F1, dW / ntl, dS / ntl, dI / ntl, dB1 / ntl, dM / ntl, dE / ntl, dB2 / ntl);
     }
 }
 
@@ -368,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
 // stages the (8 + 4) x (32 + 4) window of the cin input planes (<= 5 KB instead of a 43.5-KB 32-channel halo), computes the first
 // convolution for its (8 + 2) x (32 + 2) halo on the matrix cores exactly as conv_in_lds_kernel does (v_mfma_f32_32x32x2_f32 over
 // k = 9 cin, the same k order: bit-identical values, 1.33 x recomputed), applies the zero padding of the SECOND convolution, ReLU and the
-// bf16 hi / lo split on the accumulators (lane-quad transpose: four channels of one pixel per lane, 8-byte LDS stores) and then runs the
+// bf16 split on the accumulators (lane-quad transpose: four channels of one pixel per lane, 8-byte LDS stores) and then runs the
 // body of conv32_s1_x3_kernel on that LDS tile.  The pre-activation map is still written for the frames whose backward needs it as a
 // ReLU mask (`a_out`, frames b < a_nb: the real frames; not at all for the RGB encoder).  The input-plane window lives in the LDS
 // region of the bilinear-skip window (dead until the matrix phase); the next tile's window is prefetched into registers.
@@ -376,6 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<float> p) 
 // prdct.1 (a stride-1 32 -> 32 convolution with a ReLU-mask epilogue) -- FMASK: the first convolution's output is masked by the sign bits
 // of a 32-channel map (one word per halo pixel, applied after the lane-quad transpose), RELU_MID = false: no ReLU in between, EMASK: the second convolution's
 // epilogue mask.  The 55-MB d v map is neither written nor read.
+// T = storage / arithmetic of the SECOND convolution and of the output (the input planes are planar fp32 either way).
 struct FirstP {
     Plane pl[3]; int zero_from_b;
     const float* w1;             // [14][64] fp32 MFMA fragments of the first convolution (ptta_pack_conv_in)
@@ -384,18 +370,18 @@ struct FirstP {
     const uint32_t* fmask_bits; int fmask_nb;        // FMASK: sign bits of the first convolution's ReLU mask (one word per pixel), frames b % fmask_nb
     uint32_t* a_bits;                        // sign bits of the a_out map for the same frames (the backward's mask), or null
 };
-template <int CIN, bool UP, bool FMASK = false, bool RELU_MID = true, bool EMASK = false>
-__global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> p, FirstP f) {
+template <typename T, int CIN, bool UP, bool FMASK = false, bool RELU_MID = true, bool EMASK = false>
+__global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, FirstP f) {
+    constexpr int STR = Geo<T>::STR, WL = Geo<T>::WL;
     constexpr int UPH = 6, UPW = 18;
     constexpr int K1 = 9 * CIN, NS = (K1 + 1) / 2;
     constexpr int PL_W = 36, PL_H = 12, PLANE = PL_H * PL_W;
-    constexpr int PLSZ = (CIN * PLANE + 4) * 4, USZ = UP ? UPH * UPW * 128 : 0, AUX = USZ > PLSZ ? USZ : PLSZ;
+    constexpr int PLSZ = (CIN * PLANE + 4) * 4, USZ = UP ? UPH * UPW * Geo<T>::UPPX : 0, AUX = USZ > PLSZ ? USZ : PLSZ;
     constexpr int NPL = (CIN * PLANE + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * X3_STRIDE + 18 * 64 * 16 + AUX];
-    unsigned char* const wl_lds = lds + X3_PH * X3_PW * X3_STRIDE;
-    float* const up_lds = (float*)(wl_lds + 18 * 64 * 16);
-    float* const planes = up_lds;
-    stagger_start(p.stagger);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * STR + WL + AUX];
+    unsigned char* const wl_lds = lds + X3_PH * X3_PW * STR;
+    unsigned char* const up_lds = wl_lds + WL;
+    float* const planes = (float*)up_lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     // per-lane index arithmetic is recomputed in each phase from an opaque copy of the lane id: hoisted out of the persistent tile loop it
@@ -433,19 +419,17 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
             pv[k] = v;
         }
     };
-    const int tq = (i & 3) + 4 * h, c4 = 4 * (i >> 2);
-    // FMASK: the first convolution's ReLU mask for one halo group (4 float4 per lane), double-buffered one group ahead: the first group's
-    // loads are issued at the top of the tile, the next group's before the current group's arithmetic.  (Holding all three groups' masks
-    // across the previous tile's main loop spilled 51 registers and was 20 us slower.)
-    // The mask comes in its sign-bit form only (fmask_bits, one word per pixel): the 12 words of this wave's three halo groups are
-    // fetched one tile AHEAD, with the input planes and before the current tile's epilogue stores -- a load issued after those stores
-    // cannot complete before they have drained (vmcnt is in order and counts stores), which cost this kernel ~20 us per tile round.
+    // FMASK: the first convolution's ReLU mask comes in its sign-bit form only (fmask_bits, one word per pixel): the 12 words of this wave's
+    // three halo groups are fetched one tile AHEAD, with the input planes and before the current tile's epilogue stores -- a load issued
+    // after those stores cannot complete before they have drained (vmcnt is in order and counts stores), which cost ~20 us per tile round.
+    // (Holding all three groups' FLOAT masks across the previous tile's main loop spilled 51 registers and was 20 us slower.)
     constexpr int NGW = FMASK ? 3 : 1;
     uint32_t mkw[NGW][4];
     auto load_masks = [&](long tile) {
         if (!FMASK) return;
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
+        const int tq = (i & 3) + 4 * h;
         const uint32_t* mbb = f.fmask_bits + (size_t)(b % f.fmask_nb) * H * W;
 #pragma unroll
         for (int gi = 0; gi < NGW; ++gi)
@@ -462,14 +446,16 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
     float w1[NS];
     {
         const uint4* ph = (const uint4*)p.wpack;
-        const uint4* pl = (const uint4*)p.wpack2;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) w1[s_] = f.w1[s_ * 64 + lane];
-        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+        if constexpr (WL > 0) {
+            const uint4* pl = (const uint4*)p.wpack2;
+            for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+        }
     }
     const float b1 = f.bias1 ? f.bias1[i] : 0.f;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -486,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
         const bool abits = f.a_bits != nullptr && b < f.a_nb;
         auto halo_group = [&](const int g, const uint32_t* mk) {
             const int i_ = opaque(i);
-            const int tq = (i_ & 3) + 4 * h, c4 = 4 * (i_ >> 2);       // (shadow the kernel-scope copies)
+            const int tq = (i_ & 3) + 4 * h, c4 = 4 * (i_ >> 2);
             const int pm = min(32 * g + i_, X3_PH * X3_PW - 1);
             const float* base = planes + (pm / X3_PW) * PL_W + (pm % X3_PW);
             f32x16 acc;
@@ -523,11 +509,15 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
                 }
                 if (RELU_MID) v = relu4(v);
                 if (!inimg) v = make_float4(0.f, 0.f, 0.f, 0.f);                    // the second convolution's zero padding
-                uint2 hi, lo;
-                split2(v.x, v.y, hi.x, lo.x); split2(v.z, v.w, hi.y, lo.y);
                 if (pp < X3_PH * X3_PW) {
-                    *(uint2*)(lds + pp * X3_STRIDE + 2 * c4) = hi;
-                    *(uint2*)(lds + pp * X3_STRIDE + 64 + 2 * c4) = lo;
+                    if constexpr (sizeof(T) == 4) {
+                        uint2 hi, lo;
+                        split2(v.x, v.y, hi.x, lo.x); split2(v.z, v.w, hi.y, lo.y);
+                        *(uint2*)(lds + pp * STR + 2 * c4) = hi;
+                        *(uint2*)(lds + pp * STR + 64 + 2 * c4) = lo;
+                    } else {
+                        *(uint2*)(lds + pp * STR + 2 * c4) = f4_to_bf4(v);
+                    }
                 }
             }
         };
@@ -552,19 +542,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
         if (UP) {
             const int Hu = H >> 1, Wu = W >> 1;
             uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
-            const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
-            const int tid_ = opaque(tid);
-#pragma unroll
-            for (int k = 0; k < (UPH * UPW * 8 + 255) / 256; ++k) {
-                const int idx = tid_ + 256 * k;
-                if (idx < UPH * UPW * 8) {
-                    const int q = idx & 7, pix = idx >> 3;
-                    const int r = pix / UPW, cc = pix - r * UPW;
-                    const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q),
-                                                     (__attribute__((address_space(3))) void*)(up_lds + (size_t)(256 * k + 64 * wave) * 4), 16, 0, 0);
-                }
-            }
+            up_window_dma<T, UPH, UPW>(p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32, Hu, Wu, uy0, ux0, up_lds, opaque(tid), wave);
         }
         // ---- second convolution, two rows per wave; the bilinear window lands during the first row's MFMAs and is awaited (by every
         // wave: the barrier sits outside the row test) before the first epilogue ----
@@ -578,24 +556,16 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int ky = tap / 3, kx = tap % 3;
-                    const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * X3_STRIDE + 16 * h;
+                    const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * STR + 16 * h;
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
-                        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
-                        const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
-                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first (as conv32_s1_x3_kernel)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-                    }
+                    for (int k = 0; k < 2; ++k) mma_step<T>(acc, a + 32 * k, wh[tap][k], wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
                     if (kx == 2) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (UP && rr == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); }      // every wave's pieces of the window have landed
             if (y < H) {
-                if (UP) epi_tile<float, false, EMASK, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
-                else epi_tile<float, false, EMASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+                if (UP) epi_tile<T, false, EMASK, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
+                else epi_tile<T, false, EMASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
             }
         }
         lds_barrier();          // LDS reuse by the next tile (plane window over the bilinear window, halo)
@@ -605,24 +575,19 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<float> 
 // ---- the same convolution for SMALL maps (at most ~256 tiles of 8x32: the 1/4 ... 1/16-resolution layers, 18 launches of a step) ----
 // Those launches are one tile per block and their duration is a latency chain, not bandwidth (in-kernel stamps of the kernel above on a
 // one-tile launch: 26k cycles = weights -> LDS 5.9k + first loads 3.7k + split 2.6k + 108 MFMAs with LDS-fed lo fragments 6.1k + epilogue
-// 2.6k).  This form shortens the chain: a 4x32 tile (one output row per wave: 54 MFMAs, twice the blocks -- the chip is mostly idle at
-// these sizes), BOTH weight fragment sets in registers (144 VGPRs: no global -> LDS -> barrier hop for the lo half; one block per SIMD
-// row, occupancy is irrelevant here), every global load of the block -- halo, 36 weight fragments, bilinear window -- issued before the
-// first wait.  Same products in the same order as conv32_s1_x3_kernel: bit-identical outputs.
+// 2.6k).  This form shortens the chain: a 4x32 tile (one output row per wave: twice the blocks -- the chip is mostly idle at these sizes),
+// EVERY weight fragment in registers (fp32 storage: hi and lo, 144 VGPRs: no global -> LDS -> barrier hop for the lo half), every global
+// load of the block -- halo, weight fragments, bilinear window -- issued before the first wait.  Same products in the same order as
+// conv32_s1_x3_kernel: bit-identical outputs.
 #define X3S_TH 4
 #define X3S_PH 6
-// ABL (diagnostic instantiations, PTTA_SMALL_ABL + tools/bench_chain.py): 1 no stores, 2 no halo loads, 4 no MFMA phase, 8 no weight loads,
-// 16 empty kernel (launch floor at this launch configuration)
-template <bool RELU, bool UP, bool MASK, bool ADD, bool WLDS = true, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> p) {
-    if (ABL & 16) return;
+template <typename T, bool RELU, bool UP, bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
+    constexpr int STR = Geo<T>::STR;
+    constexpr bool F32 = sizeof(T) == 4;
     constexpr int UPH = 4, UPW = 18;                      // a 4x32 output tile reads <= 3x17 source pixels of the half-resolution map
-    // weights: ONE cooperative copy of the hi and lo fragments per block (36 KB, 9 x 16 B per thread) into LDS, read from there by every
-    // wave -- the per-wave register copies of round 3 moved 147 KB per block through the vector-memory path, which at ~11 B/clk/CU was
-    // most of a one-tile block's life
-    __shared__ __attribute__((aligned(16))) unsigned char lds[X3S_PH * X3_PW * X3_STRIDE + 2 * 18 * 64 * 16 + (UP ? UPH * UPW * 128 : 0)];
-    unsigned char* const w_lds = lds + X3S_PH * X3_PW * X3_STRIDE;
-    float* const up_lds = (float*)(w_lds + 2 * 18 * 64 * 16);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3S_PH * X3_PW * STR + (UP ? UPH * UPW * Geo<T>::UPPX : 0)];
+    unsigned char* const up_lds = lds + X3S_PH * X3_PW * STR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -633,41 +598,33 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
     constexpr int NPIX = X3S_PH * X3_PW;                  // 204 halo pixels
     constexpr int NIT = (((NPIX + 7) / 8) * 32 + 255) / 256;      // (pixel, 8-channel group) items per thread
     bool wloaded = false;
-    uint4 wh[WLDS ? 1 : 9][2], wl[WLDS ? 1 : 9][2];            // (A/B: the round-3 form, both fragment sets in registers per wave)
+    uint4 wh[9][2], wl[F32 ? 9 : 1][2];
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ty = tile % nty, tx = (tile / nty) % ntx, b = tile / (nty * ntx);
         const int y0 = ty * X3S_TH, x0 = tx << 5;
-        const float* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
-        float4 v0[NIT], v1[NIT];
+        const T* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
+        Px<T> v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
             const int g = idx & 3, pix = x3_stage_pix(idx);
             const int py = pix / X3_PW, px = pix - py * X3_PW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
-            if (ABL & 2) { v0[it] = make_float4((float)gy, (float)gx, 1.f, (float)it); v1[it] = v0[it]; continue; }
-            if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float* src = inb + ((size_t)gy * W + gx) * 32 + 8 * g;
-                v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
-            }
+            v[it] = px_zero<T>();
+            if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) v[it] = px_load(inb + ((size_t)gy * W + gx) * 32 + 8 * g);
         }
-        uint4 wreg[9];
-        const bool wnow = !wloaded;                       // block-uniform; in flight together with the halo
-        if (wnow) {
+        if (!wloaded) {                                   // block-uniform; in flight together with the halo
             const uint4* ph = (const uint4*)p.wpack;
-            const uint4* pl = (const uint4*)p.wpack2;
-            if (WLDS) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) { const int idx = tid + 256 * q; wreg[q] = idx < 18 * 64 ? ph[idx] : pl[idx - 18 * 64]; }
-            } else {
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int t = 0; t < (WLDS ? 1 : 9); ++t)
+                for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+            if constexpr (F32) {
+                const uint4* pl = (const uint4*)p.wpack2;
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        if (ABL & 8) { wh[t][k] = make_uint4(lane, t, k, 0x3f803f80u); wl[t][k] = wh[t][k]; continue; }
-                        wh[t][k] = ph[(t * 2 + k) * 64 + lane]; wl[t][k] = pl[(t * 2 + k) * 64 + lane];
-                    }
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) wl[t][k] = pl[(t * 2 + k) * 64 + lane];
             }
             wloaded = true;
         }
@@ -675,32 +632,20 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
         if (UP) {
             const int Hu = H >> 1, Wu = W >> 1;
             uy0 = lerp_coef(y0, Hu, sy).i0; ux0 = lerp_coef(x0, Wu, sx).i0;
-            const float* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
-            for (int idx = tid; idx < UPH * UPW * 8; idx += 256) {
-                const int q = idx & 7, pix = idx >> 3;
+            const T* ub = p.epi.up + (size_t)(b % p.epi.up_nb) * Hu * Wu * 32;
+            constexpr int PC = Geo<T>::UPPC;
+            for (int idx = tid; idx < UPH * UPW * PC; idx += 256) {
+                const int q = idx % PC, pix = idx / PC;
                 const int r = pix / UPW, cc = pix - r * UPW;
                 const int gy = min(uy0 + r, Hu - 1), gx = min(ux0 + cc, Wu - 1);
-                *(float4*)(up_lds + pix * 32 + 4 * q) = *(const float4*)(ub + ((size_t)gy * Wu + gx) * 32 + 4 * q);
+                *(uint4*)(up_lds + (size_t)idx * 16) = *(const uint4*)(ub + ((size_t)gy * Wu + gx) * 32 + (32 / PC) * q);
             }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
             const int pix = x3_stage_pix(idx);
-            if (pix < NPIX) {
-                float4 a0 = v0[it], a1 = v1[it];
-                if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
-                uint4 hi, lo;
-                split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);
-                split2(a1.x, a1.y, hi.z, lo.z); split2(a1.z, a1.w, hi.w, lo.w);
-                unsigned char* dst = lds + pix * X3_STRIDE + 16 * (idx & 3);
-                *(uint4*)dst = hi;
-                *(uint4*)(dst + 64) = lo;
-            }
-        }
-        if (wnow && WLDS) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) *(uint4*)(w_lds + (size_t)(tid + 256 * q) * 16) = wreg[q];
+            if (pix < NPIX) px_stage<RELU>(v[it], lds + pix * STR + 16 * (idx & 3), Geo<T>::LO);
         }
         lds_barrier();
         const int y = y0 + wave;
@@ -711,43 +656,40 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<float> 
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
-                const unsigned char* a = lds + ((wave + ky) * X3_PW + i + kx) * X3_STRIDE + 16 * h;
-                if (ABL & 4) { acc[tap] += __uint_as_float((WLDS ? 0u : wh[WLDS ? 0 : tap][0].x) ^ *(const unsigned*)a); continue; }
+                const unsigned char* a = lds + ((wave + ky) * X3_PW + i + kx) * STR + 16 * h;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
-                    const bf16x8 bh = __builtin_bit_cast(bf16x8, WLDS ? *(const uint4*)(w_lds + ((tap * 2 + k) * 64 + lane) * 16) : wh[WLDS ? 0 : tap][k]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, WLDS ? *(const uint4*)(w_lds + ((18 + tap * 2 + k) * 64 + lane) * 16) : wl[WLDS ? 0 : tap][k]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first (as conv32_s1_x3_kernel)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
+                    if constexpr (F32) {
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, wl[tap][k]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first (as conv32_s1_x3_kernel)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
                 }
             }
-            if (UP) {
-                epi_tile<float, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
-            } else {
-                if (!(ABL & 1) || acc[0] == 1.2345e-30f) epi_tile<float, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
-            }
+            if (UP) epi_tile<T, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
+            else epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
         }
         if (tile + (int)gridDim.x < ntiles) lds_barrier();   // LDS reuse by the next tile
     }
 }
 
-// ---- stride-2 / transposed geometries, fp32 storage, bf16x3 arithmetic, direct loads ----------
-// Same per-wave tiling as conv32_mfma_kernel (32 outputs of one row / one x-parity), but each A
-// fragment (8 fp32 channels of one input pixel) is split into bf16 hi/lo in registers and fed to
-// three bf16 MFMAs.  The weight fragments (hi and lo, 36 KB) sit in LDS, loaded once per block -- the
-// registers go to the 36 activation loads that are in flight ahead of the MFMAs.  Input lines are re-read from L1/L2 by neighbouring taps
-// (2.25x for stride 2), which is cheaper here than an 84 KB halo tile in LDS.  Round 2 built the LDS-staged,
-// input-stationary transposed form (8x32 input tile, four parity accumulators per input row, 16 instead of 36 ds_reads):
+// ---- stride-2 / transposed geometries, direct loads ----------------------------------------------------------------------
+// Same per-wave tiling as conv32_mfma_kernel (32 outputs of one row / one x-parity), but each A fragment (8 channels of one input pixel)
+// goes from L1/L2 straight into registers (fp32 storage: split into bf16 hi/lo there and fed to three bf16 MFMAs).  The weight fragments
+// sit in LDS, loaded once per block -- the registers go to the activation loads that are in flight ahead of the MFMAs.  Input lines are
+// re-read from L1/L2 by neighbouring taps (2.25x for stride 2), which is cheaper here than an 84 KB halo tile in LDS.  Round 2 built the
+// LDS-staged, input-stationary transposed form (8x32 input tile, four parity accumulators per input row, 16 instead of 36 ds_reads):
 // faster kernel by kernel (forward 35 -> 18 us at full resolution) but SLOWER in the replayed step (2.396 vs 2.384 ms, same
 // box): its 79 KB of LDS cannot share a CU with the 120 KB GEMM blocks of the heads that run beside decoder 3, this
-// form's 18 KB can -- reverted; see DESIGN.md §8.
-template <int MODE, bool RELU, bool UP, bool MASK, bool ADD>
-__global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float> p) {
-    __shared__ __attribute__((aligned(16))) unsigned char wl_lds[2 * 18 * 64 * 16];     // [hi | lo][tap][k][lane] weight fragments
-    stagger_start(p.stagger);
+// form's 18 KB can -- reverted.
+template <typename T, int MODE, bool RELU, bool UP, bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<T> p) {
+    constexpr bool F32 = sizeof(T) == 4;
+    __shared__ __attribute__((aligned(16))) unsigned char wl_lds[(F32 ? 2 : 1) * 18 * 64 * 16];     // [hi | lo][tap][k][lane] weight fragments
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -760,7 +702,7 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
     // item state (one item = 32 outputs of one row / x parity), decoded before its first loads
     int y = 0, xpar = 0, b = 0, x0 = 0;
     bool lane_in = false;
-    const float* inb = p.in;
+    const T* inb = p.in;
     auto decode = [&](long item) __attribute__((always_inline)) {
         long t_ = item;
         y = (int)(t_ % p.Hout); t_ /= p.Hout;
@@ -775,7 +717,7 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
     // Loads are UNCONDITIONAL (clamped address + select) and issued three taps ahead of their MFMAs: with a per-load
     // `if (ok)` every one of the 36 loads of an item waited for the previous one (s_waitcnt behind each exec branch), which
     // at the 1/8 and 1/16-resolution layers -- one item per wave -- was the whole kernel: 12.3 us whatever the size.
-    float4 v[9][4];
+    Px<T> v[9][2];                                   // [tap][k-step]: channels 16 k + 8 h ... + 7 of the tap's pixel
     bool act[9], okl[9];
     auto fetch = [&](int tap) __attribute__((always_inline)) {
         const int ky = tap / 3, kx = tap % 3;
@@ -792,9 +734,8 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
         act[tap] = active;                                          // wave-uniform
         okl[tap] = active && lane_in && (xi >= 0) && (xi < p.Win);
         if (!active) return;
-        const float* src = inb + ((size_t)yi * p.Win + (okl[tap] ? xi : 0)) * 32 + 8 * h;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[tap][q] = *(const float4*)(src + 16 * (q >> 1) + 4 * (q & 1));      // q = 2*kstep + half-of-8
+        const T* src = inb + ((size_t)yi * p.Win + (okl[tap] ? xi : 0)) * 32 + 8 * h;
+        v[tap][0] = px_load(src); v[tap][1] = px_load(src + 16);
     };
     long item = (long)blockIdx.x * 4 + wave;
     // the first item's loads go out BEFORE the weight fragments are staged: one memory round trip for both instead of two in a row
@@ -802,8 +743,11 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
     if (item < nitems) { decode(item); fetch(0); fetch(1); fetch(2); fetch(3); fetch(4); fetch(5); }
     {
         const uint4* ph = (const uint4*)p.wpack;
-        const uint4* pl = (const uint4*)p.wpack2;
-        for (int idx = tid; idx < 18 * 64; idx += 256) { *(uint4*)(wl_lds + idx * 16) = ph[idx]; *(uint4*)(wl_lds + (18 * 64 + idx) * 16) = pl[idx]; }
+        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = ph[idx];
+        if constexpr (F32) {
+            const uint4* pl = (const uint4*)p.wpack2;
+            for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + (18 * 64 + idx) * 16) = pl[idx];
+        }
     }
     lds_barrier();
     while (item < nitems) {
@@ -813,50 +757,56 @@ __global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<float>
         auto compute = [&](int tap) __attribute__((always_inline)) {
             if (!act[tap]) return;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!okl[tap]) v[tap][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (RELU) v[tap][q] = relu4(v[tap][q]);
-            }
-#pragma unroll
             for (int k = 0; k < 2; ++k) {
-                uint4 hi, lo;
-                split2(v[tap][2 * k].x, v[tap][2 * k].y, hi.x, lo.x); split2(v[tap][2 * k].z, v[tap][2 * k].w, hi.y, lo.y);
-                split2(v[tap][2 * k + 1].x, v[tap][2 * k + 1].y, hi.z, lo.z); split2(v[tap][2 * k + 1].z, v[tap][2 * k + 1].w, hi.w, lo.w);
-                const bf16x8 ah = __builtin_bit_cast(bf16x8, hi), al = __builtin_bit_cast(bf16x8, lo);
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + k) * 64 + lane) * 16));
-                const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((18 + tap * 2 + k) * 64 + lane) * 16));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                if constexpr (F32) {
+                    float4 q0 = v[tap][k].a, q1 = v[tap][k].b;
+                    if (!okl[tap]) { q0 = make_float4(0.f, 0.f, 0.f, 0.f); q1 = q0; }
+                    if (RELU) { q0 = relu4(q0); q1 = relu4(q1); }
+                    uint4 hi, lo;
+                    split2(q0.x, q0.y, hi.x, lo.x); split2(q0.z, q0.w, hi.y, lo.y);
+                    split2(q1.x, q1.y, hi.z, lo.z); split2(q1.z, q1.w, hi.w, lo.w);
+                    const bf16x8 ah = __builtin_bit_cast(bf16x8, hi), al = __builtin_bit_cast(bf16x8, lo);
+                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((18 + tap * 2 + k) * 64 + lane) * 16));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                } else {
+                    uint4 hi = v[tap][k].a;
+                    if (!okl[tap]) hi = make_uint4(0u, 0u, 0u, 0u);
+                    if (RELU) { hi.x = relu_pk(hi.x); hi.y = relu_pk(hi.y); hi.z = relu_pk(hi.z); hi.w = relu_pk(hi.w); }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hi), bh, acc, 0, 0, 0);
+                }
             }
         };
         compute(0); compute(1); compute(2);
         fetch(6); fetch(7); fetch(8);
         compute(3); compute(4); compute(5);
         compute(6); compute(7); compute(8);
-        epi_tile<float, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx);
+        epi_tile<T, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx);
         item += (long)gridDim.x * 4;
         if (item < nitems) { decode(item); fetch(0); fetch(1); fetch(2); fetch(3); fetch(4); fetch(5); }
     }
 }
 
-// ---- stride-2 convolution, LDS-staged (fp32 storage, bf16x3): the (2*4+1) x (2*32+1) input window of a 4 x 32 output tile is read
-// ONCE as whole pixel lines (every input pixel crosses the vector-memory path 1.14 times, 64 B per load pair) instead of as
-// per-tap fragment loads (1.8 times, 32 B used of every 128-B line touched per instruction).  Same structure as the stride-1
+// ---- stride-2 convolution, LDS-staged: the (2*4+1) x (2*32+1) input window of a 4 x 32 output tile is read
+// ONCE as whole pixel lines (every input pixel crosses the vector-memory path 1.14 times) instead of as
+// per-tap fragment loads (1.8 times, a quarter of every line touched per instruction).  Same structure as the stride-1
 // kernel with two differences: the K loop is split into the two 16-channel k-steps (the window of all 32 channels would not fit
-// two blocks per CU), and a wave owns one output row whose A fragments are read from LDS with a two-pixel stride.  Accumulation
-// order: k-step outer, tap inner.  The next stage's loads are issued before the current stage's MFMAs (one register set; a
+// two blocks per CU in fp32 storage), and a wave owns one output row whose A fragments are read from LDS with a two-pixel stride.
+// Accumulation order: k-step outer, tap inner.  The next stage's loads are issued before the current stage's MFMAs (one register set; a
 // two-set ring with loads two stages ahead needed 254-256 VGPRs, spilled in the mask / add variants and measured slower:
 // 34.4 vs 33.7 us at full resolution, 9.9 vs 8.8 us at 1/8).
 #define S2_TH 4
 #define S2_PH (2 * S2_TH + 1)
 #define S2_PW 65
-#define S2_STR 80                                      // per pixel and k-step: hi 32 B | lo 32 B | pad 16 B
-template <bool RELU, bool MASK, bool ADD>
-__global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<float> p) {
+#define S2_STR 80                                      // per pixel and k-step: hi 32 B | lo 32 B (fp32 storage) | pad 16 B
+template <typename T, bool RELU, bool MASK, bool ADD>
+__global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
+    constexpr bool F32 = sizeof(T) == 4;
     constexpr int NPIX = S2_PH * S2_PW, NIT = (NPIX * 2 + 255) / 256;
-    stagger_start(p.stagger);
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * S2_STR + 18 * 64 * 16];
+    constexpr int WL = F32 ? 18 * 64 * 16 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * S2_STR + WL + 16];
     unsigned char* const wl_lds = lds + NPIX * S2_STR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
@@ -864,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<float> p)
     const int Hin = p.Hin, Win = p.Win, Ho = p.Hout, Wo = p.Wout;
     const int ntx = (Wo + 31) >> 5, nty = (Ho + S2_TH - 1) / S2_TH;
     const long nstages = 2L * p.B * ntx * nty;                      // (tile, k-step) pairs
-    float4 v0[NIT], v1[NIT];
+    Px<T> v[NIT];
     auto coords = [&](long tile, int& b, int& oy0, int& ox0) {
         long t_ = tile;
         const int ty = (int)(t_ % nty); t_ /= nty;
@@ -874,18 +824,15 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<float> p)
     auto issue_loads = [&](long stage) {
         int b, oy0, ox0;
         coords(stage >> 1, b, oy0, ox0);
-        const float* inb = p.in + (size_t)(b % p.in_nb) * Hin * Win * 32 + 16 * (int)(stage & 1);
+        const T* inb = p.in + (size_t)(b % p.in_nb) * Hin * Win * 32 + 16 * (int)(stage & 1);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
             const int g = idx & 1, pix = idx >> 1;
             const int py = pix / S2_PW, px = pix - py * S2_PW;
             const int gy = 2 * oy0 - 1 + py, gx = 2 * ox0 - 1 + px;
-            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
-            if (pix < NPIX && gy >= 0 && gy < Hin && gx >= 0 && gx < Win) {
-                const float* src = inb + ((size_t)gy * Win + gx) * 32 + 8 * g;
-                v0[it] = *(const float4*)src; v1[it] = *(const float4*)(src + 4);
-            }
+            v[it] = px_zero<T>();
+            if (pix < NPIX && gy >= 0 && gy < Hin && gx >= 0 && gx < Win) v[it] = px_load(inb + ((size_t)gy * Win + gx) * 32 + 8 * g);
         }
     };
     const long first = 2L * blockIdx.x, sstride = 2L * gridDim.x;       // this block's stages: 2t, 2t+1 of its tiles
@@ -893,12 +840,14 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<float> p)
     uint4 wh[9][2];
     {
         const uint4* ph = (const uint4*)p.wpack;
-        const uint4* pl = (const uint4*)p.wpack2;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+        if constexpr (F32) {
+            const uint4* pl = (const uint4*)p.wpack2;
+            for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+        }
     }
     f32x16 acc;
     bool started = false;
@@ -913,16 +862,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<float> p)
             for (int it = 0; it < NIT; ++it) {
                 const int idx = tid + 256 * it;
                 const int pix = idx >> 1;
-                if (pix < NPIX) {
-                    float4 a0 = v0[it], a1 = v1[it];
-                    if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
-                    uint4 hi, lo;
-                    split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);
-                    split2(a1.x, a1.y, hi.z, lo.z); split2(a1.z, a1.w, hi.w, lo.w);
-                    unsigned char* dst = lds + pix * S2_STR + 16 * (idx & 1);
-                    *(uint4*)dst = hi;
-                    *(uint4*)(dst + 32) = lo;
-                }
+                if (pix < NPIX) px_stage<RELU>(v[it], lds + pix * S2_STR + 16 * (idx & 1), 32);
             }
             {   // next stage's loads: the other k-step of this tile, or the first k-step of the block's next tile
                 const long nxt = q == 0 ? base + 1 : base + sstride;
@@ -939,14 +879,16 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<float> p)
                     const int ky = tap / 3, kx = tap % 3;
                     const unsigned char* a = lds + ((2 * wave + ky) * S2_PW + 2 * i + kx) * S2_STR + 16 * h;
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
-                    const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][q]);
-                    const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + q) * 64 + lane) * 16));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    if constexpr (F32) {
+                        const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + q) * 64 + lane) * 16));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
                 }
-                if (q == 1) epi_tile<float, false, MASK, ADD>(p.epi, b, oy0 + wave, Ho, Wo, i, acc, ox0, h, Wo, 1, 0, 0.f, 0.f);
+                if (q == 1) epi_tile<T, false, MASK, ADD>(p.epi, b, oy0 + wave, Ho, Wo, i, acc, ox0, h, Wo, 1, 0, 0.f, 0.f);
             }
         }
     }
@@ -1033,50 +975,24 @@ static void launch_mfma(const Conv32P<T>& p, int flags, int blocks, hipStream_t 
     }
 #undef K_
 }
-template <bool RELU>
-static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_t s) {
-    static const int stamps = getenv("PTTA_S1_STAMPS") ? atoi(getenv("PTTA_S1_STAMPS")) : 0;      // diagnostic (tools/exp_c32_stamps.sh)
-    static const int stamp_blocks = getenv("PTTA_S1_STAMPS_BLOCKS") ? atoi(getenv("PTTA_S1_STAMPS_BLOCKS")) : 512;
-    if (stamps && blocks == stamp_blocks && flags == stamps - 1) {
-        if (flags == 0) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, false, true>), dim3(blocks), dim3(256), 0, s, p);
-        else if (flags == 2) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p);
-        else if (flags == 1) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, true, false, false, true>), dim3(blocks), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, true, true>), dim3(blocks), dim3(256), 0, s, p);
+template <typename T, bool RELU>
+static void launch_x3(const Conv32P<T>& p, int flags, int blocks, hipStream_t s) {
+    // small maps: the latency-chain form (conv32_s1_small_kernel), one 4x32 tile per block
+    const long tiles8 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
+    if (tiles8 <= 256) {
+        const long t4 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3S_TH - 1) / X3S_TH);
+        const int nb4 = (int)(t4 > 1024 ? 1024 : t4);
+#define KS_(U, M, A) hipLaunchKernelGGL((conv32_s1_small_kernel<T, RELU, U, M, A>), dim3(nb4), dim3(256), 0, s, p)
+        switch (flags) {
+            case 0: KS_(false, false, false); break; case 1: KS_(true, false, false); break;
+            case 2: KS_(false, true, false); break;  case 3: KS_(true, true, false); break;
+            case 4: KS_(false, false, true); break;  case 5: KS_(true, false, true); break;
+            case 6: KS_(false, true, true); break;   default: KS_(true, true, true); break;
+        }
+#undef KS_
         return;
     }
-    static const int abl = getenv("PTTA_S1_ABL") ? atoi(getenv("PTTA_S1_ABL")) : 0;              // diagnostic: resource ablation of the plain variant
-    if (abl && flags == 0) {
-#define KA_(N) case N: hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, false, false, false, false, N>), dim3(blocks), dim3(256), 0, s, p); return
-        switch (abl) { KA_(1); KA_(2); KA_(3); KA_(4); KA_(5); KA_(6); KA_(7); KA_(8); KA_(9); KA_(10); KA_(11); default: break; }
-#undef KA_
-    }
-    // small maps: the latency-chain form (conv32_s1_small_kernel), one 4x32 tile per block
-    static const int small_off = getenv("PTTA_S1_SMALL") ? (atoi(getenv("PTTA_S1_SMALL")) == 0) : 0;
-    {
-        const long tiles8 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
-        if (!small_off && tiles8 <= 256) {
-            const long t4 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3S_TH - 1) / X3S_TH);
-            const int nb4 = (int)(t4 > 1024 ? 1024 : t4);
-            static const int sabl = getenv("PTTA_SMALL_ABL") ? atoi(getenv("PTTA_SMALL_ABL")) : 0;            // diagnostic (plain variant only)
-            if (sabl && flags == 0) {
-#define KSA_(N) case N: hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, false, false, false, false, N>), dim3(nb4), dim3(256), 0, s, p); return
-                switch (sabl) { KSA_(1); KSA_(2); KSA_(3); KSA_(4); KSA_(7); KSA_(8); KSA_(10); KSA_(15); KSA_(16); default: break; }
-#undef KSA_
-            }
-            static const int wlds = getenv("PTTA_SMALL_WLDS") ? atoi(getenv("PTTA_SMALL_WLDS")) : 0;      // one cooperative LDS copy of the weights instead of per-wave registers: measured neutral (1.708 vs 1.703 ms)
-#define KS_(U, M, A) do { if (wlds) hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, U, M, A, true>), dim3(nb4), dim3(256), 0, s, p); \
-                          else hipLaunchKernelGGL((conv32_s1_small_kernel<RELU, U, M, A, false>), dim3(nb4), dim3(256), 0, s, p); } while (0)
-            switch (flags) {
-                case 0: KS_(false, false, false); break; case 1: KS_(true, false, false); break;
-                case 2: KS_(false, true, false); break;  case 3: KS_(true, true, false); break;
-                case 4: KS_(false, false, true); break;  case 5: KS_(true, false, true); break;
-                case 6: KS_(false, true, true); break;   default: KS_(true, true, true); break;
-            }
-#undef KS_
-            return;
-        }
-    }
-#define K_(U, M, A) hipLaunchKernelGGL((conv32_s1_x3_kernel<RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
+#define K_(U, M, A) hipLaunchKernelGGL((conv32_s1_x3_kernel<T, RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
     switch (flags) {
         case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;
         case 2: K_(false, true, false); break;  case 3: K_(true, true, false); break;
@@ -1086,9 +1002,9 @@ static void launch_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_
 #undef K_
 }
 
-template <int MODE, bool RELU>
-static void launch_direct_x3(const Conv32P<float>& p, int flags, int blocks, hipStream_t s) {
-#define K_(U, M, A) hipLaunchKernelGGL((conv32_direct_x3_kernel<MODE, RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
+template <typename T, int MODE, bool RELU>
+static void launch_direct_x3(const Conv32P<T>& p, int flags, int blocks, hipStream_t s) {
+#define K_(U, M, A) hipLaunchKernelGGL((conv32_direct_x3_kernel<T, MODE, RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
     switch (flags) {
         case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;
         case 2: K_(false, true, false); break;  case 3: K_(true, true, false); break;
@@ -1100,15 +1016,11 @@ static void launch_direct_x3(const Conv32P<float>& p, int flags, int blocks, hip
 
 // Workgroups of a persistent full-chip launch.  The stride-1 kernel takes 480 of the 512 slots (two 256-VGPR blocks per CU): a launch that
 // owns every register of the chip keeps every kernel of the other queues (the tiny BatchNorm finalizes between the heads' GEMMs, the next
-// frame's prefix) waiting until it retires, and 32 CUs with a single block break the lock-step of the rest.  Same box, graph replay,
-// pipelined / call by call: 512 + staggered start 1.698 / 1.819, 496 1.699, 480 + stagger 1.693 / 1.813, 480 without 1.681 / 1.803, 464 1.698,
-// 448 1.73, 416 1.81; the first-layer / strided / transposed kernels stay at 512 (480 there: 1.689 vs 1.688).  PTTA_S1_BLOCKS, PTTA_FULL_BLOCKS.
-static int full_chip_blocks(bool s1 = false) {
-    static const int cap = getenv("PTTA_FULL_BLOCKS") ? atoi(getenv("PTTA_FULL_BLOCKS")) : 512;
-    static const int cap1 = getenv("PTTA_S1_BLOCKS") ? atoi(getenv("PTTA_S1_BLOCKS")) : 480;
-    const int c = s1 ? cap1 : cap;
-    return c < 1 ? 1 : (c > 512 ? 512 : c);
-}
+// frame's prefix) waiting until it retires, and 32 CUs with a single block break the lock-step of the rest.  Round 4, same box, graph
+// replay, pipelined / call by call: 512 1.698 / 1.819, 496 1.699, 480 1.681 / 1.803, 464 1.698, 448 1.73, 416 1.81; the first-layer /
+// strided / transposed kernels stay at 512 (480 there: 1.689 vs 1.688).
+static constexpr int kFullChipBlocks = 512, kS1Blocks = 480;
+
 template <typename T, int MODE>
 static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     Conv32P<T> p;
@@ -1120,40 +1032,33 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     p.epi.add2 = (const T*)a.add2; p.epi.add2_nb = a.add2_nb > 0 ? a.add2_nb : 1;
     p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = (T*)a.out_sum;
     p.epi.mask_bits = a.mask_bits; p.epi.bits_out = a.bits_out; p.epi.bits_nb = a.bits_nb; p.epi.bits_sum = a.bits_sum;
-    p.B = a.B; p.Hin = a.Hin; p.Win = a.Win; p.stagger = 0;
+    p.B = a.B; p.Hin = a.Hin; p.Win = a.Win;
     if (MODE == CONV_S1) { p.Hout = a.Hin; p.Wout = a.Win; }
     else if (MODE == CONV_S2) { p.Hout = a.Hin / 2; p.Wout = a.Win / 2; }
     else { p.Hout = a.Hin * 2; p.Wout = a.Win * 2; }
     if (a.add2 && !a.add1) return -22;
     const int flags = (a.up ? 1 : 0) | (a.mask ? 2 : 0) | (a.add1 ? 4 : 0);
     p.wpack2 = nullptr;
-    if constexpr (sizeof(T) == 4 && MODE == CONV_S1) if (!a.naive && a.x3) {
-        p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
-        const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
-        const int cap = full_chip_blocks(true);
-        const int blocks = (int)(tiles > cap ? cap : tiles);     // 2 resident blocks per CU, persistent
-        // (a staggered start of the CU's second block -- PTTA_STAGGER=8000 cycles -- was worth 15 us with 512 blocks; with 480 it costs 10)
-        static const int stag = getenv("PTTA_STAGGER") ? atoi(getenv("PTTA_STAGGER")) : 0;
-        if (blocks == cap && cap > 256) p.stagger = stag;
-        const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
-        if (a.relu_in) launch_x3<true>(pf, flags, blocks, s); else launch_x3<false>(pf, flags, blocks, s);
-        PTTA_CHECK_LAUNCH();
-        return 0;
-    }
-    if constexpr (sizeof(T) == 4 && MODE != CONV_S1) if (!a.naive && a.x3) {
-        p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
+    // the tuned kernels: fp32 storage with bf16x3 arithmetic, or narrow storage (always one bf16 MFMA per product); a narrow launch with a
+    // ReLU mask takes it as sign bits (the mask map itself is an fp32 map of the real frames)
+    constexpr bool NAR = sizeof(T) == 2;
+    if (NAR && a.mask && !a.mask_bits) return -22;
+    if (!a.naive && (NAR || a.x3)) {
+        p.wpack = a.w->mbf16; p.wpack2 = NAR ? nullptr : a.w->mlo;
+        if (MODE == CONV_S1) {
+            const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
+            const int blocks = (int)(tiles > kS1Blocks ? kS1Blocks : tiles);     // 2 resident blocks per CU, persistent
+            if (a.relu_in) launch_x3<T, true>(p, flags, blocks, s); else launch_x3<T, false>(p, flags, blocks, s);
+            PTTA_CHECK_LAUNCH();
+            return 0;
+        }
         const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
         const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
-        const int capd = full_chip_blocks();
-        long blocks = (items + 3) / 4; if (blocks > capd) blocks = capd;
-        const Conv32P<float>& pf = *(const Conv32P<float>*)&p;
-        static const int s2_direct = getenv("PTTA_S2_DIRECT") ? atoi(getenv("PTTA_S2_DIRECT")) : 0;      // A/B: keep the direct-load form
-        if (MODE == CONV_S2 && !(flags & 1) && !s2_direct) {
+        long blocks = (items + 3) / 4; if (blocks > kFullChipBlocks) blocks = kFullChipBlocks;
+        if (MODE == CONV_S2 && !(flags & 1)) {
             const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + S2_TH - 1) / S2_TH);
-            const int tb = (int)(tiles < capd ? tiles : capd);
-            static const int stag2 = getenv("PTTA_STAGGER_S2") ? atoi(getenv("PTTA_STAGGER_S2")) : 0;
-            Conv32P<float> pf2 = pf; if (tb == capd && capd > 256) pf2.stagger = stag2;
-#define KS2_(R, M, A) hipLaunchKernelGGL((conv32_s2_lds_kernel<R, M, A>), dim3(tb), dim3(256), 0, s, pf2)
+            const int tb = (int)(tiles < kFullChipBlocks ? tiles : kFullChipBlocks);
+#define KS2_(R, M, A) hipLaunchKernelGGL((conv32_s2_lds_kernel<T, R, M, A>), dim3(tb), dim3(256), 0, s, p)
             const bool m_ = flags & 2, a_ = flags & 4;
             if (a.relu_in) { if (m_) { if (a_) KS2_(true, true, true); else KS2_(true, true, false); } else { if (a_) KS2_(true, false, true); else KS2_(true, false, false); } }
             else { if (m_) { if (a_) KS2_(false, true, true); else KS2_(false, true, false); } else { if (a_) KS2_(false, false, true); else KS2_(false, false, false); } }
@@ -1161,9 +1066,9 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
             PTTA_CHECK_LAUNCH();
             return 0;
         }
-        static const int stagd = getenv("PTTA_STAGGER_D") ? atoi(getenv("PTTA_STAGGER_D")) : 0;
-        Conv32P<float> pfd = pf; if (blocks == capd && capd > 256) pfd.stagger = stagd;
-        if (a.relu_in) launch_direct_x3<MODE, true>(pfd, flags, (int)blocks, s); else launch_direct_x3<MODE, false>(pfd, flags, (int)blocks, s);
+        if constexpr (MODE != CONV_S1) {
+            if (a.relu_in) launch_direct_x3<T, MODE, true>(p, flags, (int)blocks, s); else launch_direct_x3<T, MODE, false>(p, flags, (int)blocks, s);
+        }
         PTTA_CHECK_LAUNCH();
         return 0;
     }
@@ -1174,59 +1079,62 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         if (a.relu_in) hipLaunchKernelGGL((conv32_naive_kernel<T, MODE, true>), dim3(blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv32_naive_kernel<T, MODE, false>), dim3(blocks), dim3(256), 0, s, p);
     } else {
-        p.wpack = sizeof(T) == 4 ? (const void*)a.w->mf32 : (const void*)a.w->mbf16;
+        // exact arithmetic (validation): v_mfma_f32_32x32x2_f32, fp32 storage only
+        if (NAR) return -22;
+        p.wpack = (const void*)a.w->mf32;
         const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
         const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
         long blocks = (items + 3) / 4;
-        const long cap = sizeof(T) == 4 ? 512 : 1024;     // persistent waves: 2 (fp32) / 4 (bf16) blocks per CU
-        if (blocks > cap) blocks = cap;
-        if (a.relu_in) launch_mfma<T, MODE, true>(p, flags, (int)blocks, s); else launch_mfma<T, MODE, false>(p, flags, (int)blocks, s);
+        if (blocks > 512) blocks = 512;
+        if constexpr (!NAR) { if (a.relu_in) launch_mfma<T, MODE, true>(p, flags, (int)blocks, s); else launch_mfma<T, MODE, false>(p, flags, (int)blocks, s); }
     }
     PTTA_CHECK_LAUNCH();
     return 0;
 }
 
 // Conv2d(cin, 32) - ReLU - Conv2d(32, 32) in one launch (conv32_s1_first_kernel): `a` describes the SECOND convolution as for
-// ptta_launch_conv32 (its `in` is ignored), `f` the first one as for ptta_launch_conv_in (its outputs are ignored); a_out: where the
-// first convolution's pre-activation map is still written (frames b < a_nb), or null.  Returns 1 when this form does not apply
-// (the caller then launches the two kernels): other storage / arithmetic modes, epilogues other than the bilinear skip, small maps.
-int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_out, int a_nb, hipStream_t s) {
-    // two shapes: forward (ReLU between the convolutions, optional bilinear skip, no masks) and the prediction head's backward (cin = 1, the
-    // first convolution masked, no ReLU in between, the second convolution's epilogue masked, no bilinear skip)
-    const bool bwd_form = f.mask != nullptr;
-    if (bwd_form && !f.mask_bits) return 1;
-    if (a.bf16 || a.naive || !a.x3 || a.mode != CONV_S1 || a.add1 || a.add2 || a.out_sum || f.bf16 || f.naive) return 1;
-    if (bwd_form ? (a.relu_in || !a.mask || a.up || f.cin != 1) : (!a.relu_in || a.mask != nullptr)) return 1;
-    if (f.cin < 1 || f.cin > 3 || f.up || f.add1 || f.B != a.B || f.H != a.Hin || f.W != a.Win) return 1;
-    const long tiles = (long)a.B * ((a.Win + 31) / 32) * ((a.Hin + X3_TH - 1) / X3_TH);
-    if (tiles <= 256) return 1;
-    Conv32P<float> p;
-    p.in = nullptr; p.in_nb = 1; p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
-    p.epi.bias = a.bias; p.epi.up = (const float*)a.up; p.epi.up_nb = a.up_nb > 0 ? a.up_nb : 1;
-    p.epi.mask = (const float*)a.mask; p.epi.mask_nb = a.mask_nb > 0 ? a.mask_nb : 1; p.epi.add1 = nullptr; p.epi.add1_nb = 1; p.epi.add2 = nullptr; p.epi.add2_nb = 1;
-    p.epi.out_raw = (float*)a.out_raw; p.epi.out_sum = nullptr;
+// ptta_launch_conv32 (its `in` is ignored; a.bf16: narrow output and skip operands, one MFMA per product), `f` the first one as for
+// ptta_launch_conv_in (its outputs are ignored); a_out: where the first convolution's pre-activation map is still written (frames
+// b < a_nb), or null.  Returns 1 when this form does not apply (the caller then launches the two kernels): exact / naive arithmetic,
+// epilogues other than the bilinear skip, small maps.
+template <typename T>
+static int launch_first_t(const Conv32Args& a, const ConvInArgs& f, void* a_out, int a_nb, bool bwd_form, long tiles, hipStream_t s) {
+    Conv32P<T> p;
+    p.in = nullptr; p.in_nb = 1; p.wpack = a.w->mbf16; p.wpack2 = sizeof(T) == 4 ? a.w->mlo : nullptr;
+    p.epi.bias = a.bias; p.epi.up = (const T*)a.up; p.epi.up_nb = a.up_nb > 0 ? a.up_nb : 1;
+    p.epi.mask = (const T*)a.mask; p.epi.mask_nb = a.mask_nb > 0 ? a.mask_nb : 1; p.epi.add1 = nullptr; p.epi.add1_nb = 1; p.epi.add2 = nullptr; p.epi.add2_nb = 1;
+    p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = nullptr;
     p.epi.mask_bits = a.mask_bits; p.epi.bits_out = a.bits_out; p.epi.bits_nb = a.bits_nb; p.epi.bits_sum = 0;
     p.B = a.B; p.Hin = p.Hout = a.Hin; p.Win = p.Wout = a.Win;
-    static const int stag = getenv("PTTA_STAGGER_F") ? atoi(getenv("PTTA_STAGGER_F")) : 0;
-    static const int capf = getenv("PTTA_FIRST_BLOCKS") ? atoi(getenv("PTTA_FIRST_BLOCKS")) : 512;
-    const int cap = capf < 1 ? 1 : (capf > 512 ? 512 : capf);
-    const int blocks = (int)(tiles > cap ? cap : tiles);
-    p.stagger = (blocks == cap && cap > 256) ? stag : 0;
+    const int blocks = (int)(tiles > kFullChipBlocks ? kFullChipBlocks : tiles);
     FirstP q;
     for (int c = 0; c < 3; ++c) { q.pl[c] = f.pl[c]; if (q.pl[c].nb < 1) q.pl[c].nb = 1; }
     q.zero_from_b = f.zero_from_b; q.w1 = f.wfrag; q.bias1 = f.bias; q.a_out = (float*)a_out; q.a_nb = a_nb;
     q.fmask_nb = f.mask_nb > 0 ? f.mask_nb : 1; q.fmask_bits = f.mask_bits; q.a_bits = f.a_bits;
     if (bwd_form) {
-        hipLaunchKernelGGL((conv32_s1_first_kernel<1, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p, q);
+        hipLaunchKernelGGL((conv32_s1_first_kernel<T, 1, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p, q);
         PTTA_CHECK_LAUNCH();
         return 0;
     }
-#define KF_(C) do { if (a.up) hipLaunchKernelGGL((conv32_s1_first_kernel<C, true>), dim3(blocks), dim3(256), 0, s, p, q); \
-                    else hipLaunchKernelGGL((conv32_s1_first_kernel<C, false>), dim3(blocks), dim3(256), 0, s, p, q); } while (0)
+#define KF_(C) do { if (a.up) hipLaunchKernelGGL((conv32_s1_first_kernel<T, C, true>), dim3(blocks), dim3(256), 0, s, p, q); \
+                    else hipLaunchKernelGGL((conv32_s1_first_kernel<T, C, false>), dim3(blocks), dim3(256), 0, s, p, q); } while (0)
     if (f.cin == 1) KF_(1); else if (f.cin == 2) KF_(2); else KF_(3);
 #undef KF_
     PTTA_CHECK_LAUNCH();
     return 0;
+}
+int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_out, int a_nb, hipStream_t s) {
+    // two shapes: forward (ReLU between the convolutions, optional bilinear skip, no masks) and the prediction head's backward (cin = 1, the
+    // first convolution masked, no ReLU in between, the second convolution's epilogue masked, no bilinear skip)
+    const bool bwd_form = f.mask != nullptr;
+    if (bwd_form && (!f.mask_bits || !a.mask_bits)) return 1;
+    if (a.naive || (!a.bf16 && !a.x3) || a.mode != CONV_S1 || a.add1 || a.add2 || a.out_sum || f.naive) return 1;
+    if (bwd_form ? (a.relu_in || !a.mask || a.up || f.cin != 1) : (!a.relu_in || a.mask != nullptr)) return 1;
+    if (f.cin < 1 || f.cin > 3 || f.up || f.add1 || f.B != a.B || f.H != a.Hin || f.W != a.Win) return 1;
+    if (a.bf16 && (a_out || f.a_bits)) return 1;             // (a narrow launch has no backward of its own: nothing to keep of the first map)
+    const long tiles = (long)a.B * ((a.Win + 31) / 32) * ((a.Hin + X3_TH - 1) / X3_TH);
+    if (tiles <= 256) return 1;
+    return a.bf16 ? launch_first_t<bf16_t>(a, f, a_out, a_nb, bwd_form, tiles, s) : launch_first_t<float>(a, f, a_out, a_nb, bwd_form, tiles, s);
 }
 
 int ptta_launch_conv32(const Conv32Args& a, hipStream_t s) {

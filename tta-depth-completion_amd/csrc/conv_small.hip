@@ -203,6 +203,9 @@ static int launch_conv_in_t(const ConvInArgs& a, hipStream_t s) {
     p.epi.add1 = (const T*)a.add1; p.epi.add1_nb = a.add1_nb > 0 ? a.add1_nb : 1;
     p.epi.add2 = nullptr; p.epi.add2_nb = 1;
     p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = (T*)a.out_sum;
+    p.epi.mask_bits = a.mask_bits;              // fp32 output: optional; narrow output: the only form a ReLU mask can take
+    if (sizeof(T) == 4 && a.a_bits && a.a_bits_nb > 0 && !a.naive) { p.epi.bits_out = a.a_bits; p.epi.bits_nb = a.a_bits_nb; p.epi.bits_sum = 0; }
+    if (sizeof(T) == 2 && a.mask && !a.mask_bits) return -22;
     p.B = a.B; p.H = a.H; p.W = a.W;
     if (a.naive) {
         p.w = a.wcanon;
@@ -237,113 +240,16 @@ int ptta_launch_conv_in(const ConvInArgs& a, hipStream_t s) {
 }
 
 // ---- 32 -> 1 ------------------------------------------------------------------------------------
-// 8 lanes per pixel (each lane 4 channels = 16 B of the pixel's 128-B line, 8 B in bf16 mode), 8
-// consecutive pixels per wave-instruction: every load instruction reads 8 whole NHWC lines (1 KiB
-// contiguous).  A wave walks DOWN a strip of 8 columns so the rows shared by consecutive outputs
-// stay in L1; the 288 weights live in 36 VGPRs; the 8 partial sums of a pixel are combined with
-// three xor-shuffles.
-template <typename T, bool RELU>
-__global__ __launch_bounds__(256) void conv_out1_kernel(const T* __restrict__ in, int in_nb, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, const float* __restrict__ add,
-                                                        int add_nb, float* __restrict__ out, int B, int H, int W) {
-    const int lane = threadIdx.x & 63, pl = lane >> 3, cq = lane & 7;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    float4 wt[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wt[t] = *(const float4*)(w + t * 32 + 4 * cq);
-    const float b0 = bias ? bias[0] : 0.f;
-    constexpr int RC = 4;                                    // output rows per work item
-    const int nsx = (W + 7) >> 3, nsy = (H + RC - 1) / RC;
-    const long nitems = (long)B * nsx * nsy;
-    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
-        long t_ = item;
-        const int sx = (int)(t_ % nsx); t_ /= nsx;
-        const int sy = (int)(t_ % nsy);
-        const int b = (int)(t_ / nsy);
-        const int x = sx * 8 + pl;
-        const int ya = sy * RC;
-        const T* inb = in + (size_t)(b % in_nb) * H * W * 32 + 4 * cq;
-        float4 v[RC + 2][3];
-        if constexpr (RELU) {
-        // (RC+2) x 3 input window of this lane's channel quad: all 18 loads issued back to back -- UNCONDITIONALLY, from a clamped
-        // address, the zero padding and the ReLU applied afterwards (behind the bounds test each load waited for the previous one:
-        // 39.8 us for the 55 MB of a full-resolution launch)
-        unsigned okm = 0;
-#pragma unroll
-        for (int r = 0; r < RC + 2; ++r)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int yi = ya + r - 1, xi = x + kx - 1;
-                const bool ok = yi >= 0 && yi < H && xi >= 0 && xi < W;
-                okm |= ok ? (1u << (r * 3 + kx)) : 0u;
-                const T* src = inb + ((size_t)min(max(yi, 0), H - 1) * W + min(max(xi, 0), W - 1)) * 32;
-                float4 t;
-                if (sizeof(T) == 4) t = *(const float4*)src;
-                else {
-                    const uint2 u = *(const uint2*)src;
-                    t.x = __uint_as_float(u.x << 16); t.y = __uint_as_float(u.x & 0xffff0000u);
-                    t.z = __uint_as_float(u.y << 16); t.w = __uint_as_float(u.y & 0xffff0000u);
-                }
-                v[r][kx] = t;
-            }
-#pragma unroll
-        for (int r = 0; r < RC + 2; ++r)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                float4 t = v[r][kx];
-                if (!((okm >> (r * 3 + kx)) & 1u)) t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-                v[r][kx] = t;
-            }
-        } else {
-        // (RC+2) x 3 input window of this lane's channel quad: all 18 loads issued back to back
-#pragma unroll
-        for (int r = 0; r < RC + 2; ++r)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int yi = ya + r - 1, xi = x + kx - 1;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (yi >= 0 && yi < H && xi >= 0 && xi < W) {
-                    const T* src = inb + ((size_t)yi * W + xi) * 32;
-                    if (sizeof(T) == 4) t = *(const float4*)src;
-                    else {
-                        const uint2 u = *(const uint2*)src;
-                        t.x = __uint_as_float(u.x << 16); t.y = __uint_as_float(u.x & 0xffff0000u);
-                        t.z = __uint_as_float(u.y << 16); t.w = __uint_as_float(u.y & 0xffff0000u);
-                    }
-                }
-                if (RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
-                v[r][kx] = t;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RC; ++r) {
-            float acc = 0.f;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float4 t = v[r + tap / 3][tap % 3];
-                acc = fmaf(t.x, wt[tap].x, acc); acc = fmaf(t.y, wt[tap].y, acc);
-                acc = fmaf(t.z, wt[tap].z, acc); acc = fmaf(t.w, wt[tap].w, acc);
-            }
-            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
-            const int y = ya + r;
-            if (cq == 0 && x < W && y < H) {
-                const size_t o = (size_t)y * W + x;
-                float res = acc + b0;
-                if (add) res += add[(size_t)(b % add_nb) * H * W + o];
-                out[(size_t)b * H * W + o] = res;
-            }
-        }
-    }
-}
-
-// LDS-staged form for fp32 storage (the shipped one): a block owns an 8 x 32 output tile and stages its (8+2) x (32+2) x 32-channel
+// 8 lanes per pixel (each lane 4 channels = 16 B of the pixel's 128-B line, 8 B in narrow storage); the 288 weights live in 36 VGPRs; the
+// 8 partial sums of a pixel are combined with three xor-shuffles.  (The round-1 strip form -- a wave walking down 8 columns with 18 loads
+// per lane straight from L1/L2 -- moved every input pixel across the vector-memory path 4.5 times; removed in round 5.)
+// LDS-staged: a block owns an 8 x 32 output tile and stages its (8+2) x (32+2) x 32-channel
 // window ONCE as whole 128-B pixel lines (zero padding and the input ReLU applied while staging), so every input pixel crosses the
 // vector-memory path 1.33 times instead of the 4.5 times of the strip kernel above (18 float4 loads per lane and 4 x 8 outputs).
 // Same lane roles (8 lanes per pixel, 4 channels each), same tap order and the same xor-shuffle reduction: bit-identical sums.
 // The 32 results of an output row are collected into one half-wave (lane quad index = pass) and leave as ONE 128-B store.
-template <bool RELU>
-__global__ __launch_bounds__(256) void conv_out1_lds_kernel(const float* __restrict__ in, int in_nb, const float* __restrict__ w,
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void conv_out1_lds_kernel(const T* __restrict__ in, int in_nb, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const float* __restrict__ add,
                                                             int add_nb, float* __restrict__ out, int B, int H, int W) {
     constexpr int TH = 8, PW = 34, PH = TH + 2, NV = PH * PW * 8, NIT = (NV + 255) / 256;
@@ -362,8 +268,8 @@ __global__ __launch_bounds__(256) void conv_out1_lds_kernel(const float* __restr
         const int tx = (int)(t_ % ntx);
         const int b = (int)(t_ / ntx);
         const int y0 = ty * TH, x0 = tx << 5;
-        const float* inb = in + (size_t)(b % in_nb) * H * W * 32;
-        // all loads of the window first (unconditional, clamped), zero padding / ReLU afterwards
+        const T* inb = in + (size_t)(b % in_nb) * H * W * 32;
+        // all loads of the window first (unconditional, clamped), zero padding / ReLU afterwards (narrow storage: 8 B per piece, widened here)
         float4 v[NIT];
         unsigned okm = 0;
 #pragma unroll
@@ -373,7 +279,8 @@ __global__ __launch_bounds__(256) void conv_out1_lds_kernel(const float* __restr
             const int py = pix / PW, px = pix - py * PW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
             okm |= (gy >= 0 && gy < H && gx >= 0 && gx < W) ? (1u << it) : 0u;
-            v[it] = *(const float4*)(inb + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 32 + 4 * q);
+            const T* src = inb + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 32 + 4 * q;
+            if constexpr (sizeof(T) == 4) v[it] = *(const float4*)src; else v[it] = bf4_to_f4(*(const uint2*)src);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -428,21 +335,13 @@ void ptta_pack_conv_out1(const float* src, int src_cin_total, int src_cin_index,
 }
 
 int ptta_launch_conv_out1(const ConvOut1Args& a, hipStream_t s) {
-    const long items = (long)a.B * ((a.W + 7) / 8) * ((a.H + 3) / 4);
-    int blocks = (int)((items + 3) / 4); if (blocks > 8192) blocks = 8192;
     const int add_nb = a.add_nb > 0 ? a.add_nb : 1;
-#define LAUNCH_(T, R) hipLaunchKernelGGL((conv_out1_kernel<T, R>), dim3(blocks), dim3(256), 0, s, (const T*)a.in, a.in_nb, \
-                                         a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W)
-    static const int strip = getenv("PTTA_OUT1_STRIP") ? atoi(getenv("PTTA_OUT1_STRIP")) : 0;      // A/B switch: the strip kernel for fp32 too
-    if (a.bf16) { if (a.relu_in) LAUNCH_(bf16_t, true); else LAUNCH_(bf16_t, false); }
-    else if (strip) { if (a.relu_in) LAUNCH_(float, true); else LAUNCH_(float, false); }
-    else {
-        const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8);
-        const int tb = (int)(tiles < 768 ? tiles : 768);                                            // three 43.5-KB blocks per CU
-        if (a.relu_in) hipLaunchKernelGGL((conv_out1_lds_kernel<true>), dim3(tb), dim3(256), 0, s, (const float*)a.in, a.in_nb, a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W);
-        else hipLaunchKernelGGL((conv_out1_lds_kernel<false>), dim3(tb), dim3(256), 0, s, (const float*)a.in, a.in_nb, a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W);
-    }
-#undef LAUNCH_
+    const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + 7) / 8);
+    const int tb = (int)(tiles < 768 ? tiles : 768);                                            // three 43.5-KB blocks per CU
+#define LDS_(T, R) hipLaunchKernelGGL((conv_out1_lds_kernel<T, R>), dim3(tb), dim3(256), 0, s, (const T*)a.in, a.in_nb, a.w, a.bias, a.add, add_nb, a.out, a.B, a.H, a.W)
+    if (a.bf16) { if (a.relu_in) LDS_(bf16_t, true); else LDS_(bf16_t, false); }
+    else { if (a.relu_in) LDS_(float, true); else LDS_(float, false); }
+#undef LDS_
     PTTA_CHECK_LAUNCH();
     return 0;
 }

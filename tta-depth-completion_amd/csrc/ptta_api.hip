@@ -44,6 +44,16 @@ struct ptta_ctx {
     GNet* nl = nullptr;              // backbones on the generic layer-graph engine (NLSPN, CostDCNet): every entry point forwards to it
     int N = 1, H = 0, W = 0, Hp = 0, Wp = 0, pt = 0, pr = 0, dual = 0, Nn = 1;
     int bf16 = 0, naive = 0, es = 4, x3 = 1;
+    // MIXED storage / arithmetic (PTTA_DTYPE_MIXED, BASELINE config 2): the REAL frames' forward -- what produces the scored depth map -- stays
+    // fp32 storage + bf16x3 arithmetic; every tensor the reference computes under no_grad / detaches (the zero-image proxy pass,
+    // network_exp_msg_chn_adapt.py:509-532) and every data gradient of loss.backward() (src/tta_main.py:632) is a NARROW map: bf16 storage,
+    // one bf16 MFMA per product, fp32 accumulate.  The two passes are separate launch chains (real on the caller's stream, proxy on the
+    // auxiliary one); a [real | proxy] fp32 map `p` has a narrow twin for its proxy frames (tw(p)); masks reach the backward as sign bits.
+    int mixed = 0;
+    std::unordered_map<const void*, void*> ntwin;
+    void* tw(const void* p) const { auto it = ntwin.find(p); return it == ntwin.end() ? nullptr : it->second; }
+    void twin_alloc(const void* p, int nb, int h, int w) { if (mixed && p) ntwin[p] = dalloc((size_t)nb * h * w * 32 * 2); }
+    float *dm_f32 = nullptr;          // fp32 copy of the meta layer's output gradient (the weight-gradient kernels take fp32 operands)
     int ablate = 0;                  // PTTA_ABLATE (diagnostic): groups of launches skipped for timing, results garbage; announced on stderr by ptta_create
     ptta_hparams hp{};
     std::string err;
@@ -104,22 +114,9 @@ struct ptta_ctx {
     // backward needs d feat (PTTA_THRU=0: join after the forward, loss launches, fork again)
     int thru = 1; bool thru_active = false;
     hipEvent_t ev_dpart = nullptr;
-    int fuse_first = 1;
+    int fuse_first = 1, fuse_head_bwd = 1;
     int cos_grad_fused = 1;          // PTTA_COS_IN_GEMM=0: the fused step writes d loss / d ref as a tensor (loss.hip cos_grad_body) instead
     bool cos_in_gemm = false;        // (set around the fused step's backward only: ptta_backward with a caller's gradient keeps the tensor form)
-    // ---- the fused step as FOUR graphs on two streams (PTTA_DUAL=0: one graph).  The grad pass (real frames) and the no-grad proxy pass
-    // (zero image) of _rgbd_meta_contrast share nothing downstream of the meta layer until the loss, and about half of their ~60 launches
-    // are low-resolution layers that leave the chip half empty.  Forks INSIDE one hipGraph are replayed interleaved on one queue (measured
-    // slower); separate graphs on separate streams do overlap (the frame-pipelining prefix).  So: phase A (what
-    // both passes need: meta layer, and the prefix when it was not run ahead) on the caller's stream; phase R (real frames: decoder 1 ...
-    // encoder 3, proj head, decoder 3) on the caller's stream BESIDE phase P (proxy frames: decoder 1 ... encoder 3, proj + pred heads) on
-    // a stream of its own; phase L (loss, backward, Adam) after both.  Same kernels on the same data: bit-identical results.
-    int dual_on = 0;
-    int fwd_phase = 0;               // 0: the whole forward (one stream); 1 / 2 / 3: phase A / R / P only
-    struct DualG { hipGraph_t g = nullptr; hipGraphExec_t e = nullptr; };
-    DualG dgA[2][2], dgR[2], dgP[2], dgL[4][2];      // A: [prefix run ahead?][buffer set]; R, P: [set]; L: [graph key][set]
-    hipStream_t dual_stream = nullptr;
-    hipEvent_t ev_dA = nullptr, ev_dP = nullptr;              // PTTA_FUSE_FIRST=0: the first two convolutions of an encoder stage as two launches
     void* w0frag = nullptr; float *hm_part = nullptr, *headP = nullptr; double* head_k12 = nullptr;
     // per-kernel-class HIP-event timing of the conv32 launches (bench.py roofline leg)
     // classes (include/ptta.h PTTA_PROF_*): 0/1 stride-1 32->32 conv with ReLU on load, maps above / up to 1/4 resolution; 2/3 the same
@@ -167,8 +164,6 @@ struct ptta_ctx {
     int use_aux = 1;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_real = nullptr;
-    int split_fwd = 0;               // PTTA_SPLIT_FWD bit 0: real and proxy frames of the training forward as two concurrent launch chains; bit 1: the
-                                     // depth-only head of the stage-1 encoder beside the RGB encoder (both measured SLOWER inside one graph: DESIGN.md section 8)
     hipStream_t aux(hipStream_t) {
         if (!use_aux || prof_on) return nullptr;
         if (!aux_stream) {
@@ -192,9 +187,6 @@ struct ptta_ctx {
                 if (rgraph[k][p]) { (void)hipGraphDestroy(rgraph[k][p]); rgraph[k][p] = nullptr; }
             }
         }
-        auto drop = [](DualG& d) { if (d.e) { (void)hipGraphExecDestroy(d.e); d.e = nullptr; } if (d.g) { (void)hipGraphDestroy(d.g); d.g = nullptr; } };
-        if (dual_stream) (void)hipStreamSynchronize(dual_stream);
-        for (int p = 0; p < 2; ++p) { drop(dgA[0][p]); drop(dgA[1][p]); drop(dgR[p]); drop(dgP[p]); for (int k = 0; k < 4; ++k) drop(dgL[k][p]); }
         for (int p = 0; p < 2; ++p) {
             if (pexec[p]) { (void)hipGraphExecDestroy(pexec[p]); pexec[p] = nullptr; }
             if (pgraph[p]) { (void)hipGraphDestroy(pgraph[p]); pgraph[p] = nullptr; }
@@ -216,6 +208,14 @@ struct ptta_ctx {
     void* act(const char* name, int nb, int h, int w) {
         void* p = dalloc((size_t)nb * h * w * 32 * es);
         dbg[name] = Dbg{p, (long)nb * h * w * 32, 1};
+        if (mixed && nb == 2 * Nn) twin_alloc(p, Nn, h, w);          // [real | proxy] map: narrow twin of the proxy frames
+        return p;
+    }
+    // gradient map of the backward (real frames only): narrow in the mixed mode
+    void* gact(const char* name, int nb, int h, int w) {
+        const int e = mixed ? 2 : es;
+        void* p = dalloc((size_t)nb * h * w * 32 * e);
+        dbg[name] = Dbg{p, (long)nb * h * w * 32, mixed ? 2 : 1};
         return p;
     }
     // Sign-bit masks (ptta_common.h Epi): for every pre-activation map the backward uses as a ReLU mask, one word per pixel of the REAL
@@ -226,6 +226,7 @@ struct ptta_ctx {
     std::unordered_map<const void*, uint32_t*> mbits;
     void mask_plane(const void* map, int nb, int h, int w) {
         if (!mask_bits_on || bf16 || naive) return;
+        if (mbits.count(map)) return;
         mbits[map] = (uint32_t*)dalloc((size_t)nb * h * w * sizeof(uint32_t));
     }
     uint32_t* bits_of(const void* map) const {
@@ -428,8 +429,11 @@ void build_workspace(ptta_ctx* c) {
         MB_(w2, H4, W4); MB_(e3_2a, H4, W4); MB_(s1_2, H4, W4); MB_(t2, H4, W4); MB_(e2_1, H4, W4); MB_(e2_1a, H4, W4); MB_(s0_1, H4, W4);
         MB_(z2, H8, W8); MB_(e2_2a, H8, W8);
         auto first_fused = [&](int h, int w) { return c->fuse_first >= 1 && !(c->ablate & 3) && c->x3 && (long)Nn * ((w + 31) / 32) * ((h + 7) / 8) > 256; };
-        if (first_fused(H1, W1)) MB_(e3_0a, H1, W1);
-        if (first_fused(H2, W2)) MB_(e2_0a, H2, W2);
+        // (mixed mode: EVERY mask of the backward is a bit plane -- a narrow launch cannot read an fp32 mask map; the unfused first-layer
+        // kernel writes the planes of e*_0a then, and decoder 1's v1 gets one too)
+        if (first_fused(H1, W1) || c->mixed) MB_(e3_0a, H1, W1);
+        if (first_fused(H2, W2) || c->mixed) MB_(e2_0a, H2, W2);
+        if (c->mixed) MB_(v1, H4, W4);
 #undef MB_
     }
     // heads
@@ -445,14 +449,21 @@ void build_workspace(ptta_ctx* c) {
     c->loss_ws = c->falloc((size_t)ptta_loss_ws_floats(c->N, c->H, c->W, c->Rg));
     c->loss_info = c->falloc(4);
     M_(g_final, c->N, c->H, c->W); M_(g_net, Nn, H1, W1);
-    // backward
-    A_(dv3, Nn, H1, W1); A_(ds0_3, Nn, H1, W1); A_(du3, Nn, H1, W1); A_(ds1_3, Nn, H2, W2); A_(dt3, Nn, H2, W2);
-    A_(dw2, Nn, H4, W4); A_(dfeat_tot, Nn, H4, W4); A_(dz2_up, Nn, H8, W8); A_(de3_2a, Nn, H4, W4);
-    A_(de3_1, Nn, H2, W2); A_(de3_1a, Nn, H2, W2); A_(de3_0, Nn, H1, W1); A_(de3_0a, Nn, H1, W1);
-    A_(dv2, Nn, H2, W2); A_(ds0_2, Nn, H2, W2); A_(dz4, Nn, H2, W2); A_(du2, Nn, H2, W2); A_(ds1_2, Nn, H4, W4);
-    A_(dz3, Nn, H4, W4); A_(dt2, Nn, H4, W4); A_(dz2, Nn, H8, W8); A_(de2_2a, Nn, H8, W8); A_(de2_1, Nn, H4, W4);
-    A_(de2_1a, Nn, H4, W4); A_(de2_0, Nn, H2, W2); A_(de2_0a, Nn, H2, W2); A_(dv1, Nn, H4, W4); A_(dm_total, Nn, H4, W4);
-    A_(g_feat, Nn, H4, W4);
+    // backward (gradient maps: narrow in the mixed mode)
+#define G_(name, nb, h, w) c->name = c->gact(#name, nb, h, w)
+    G_(dv3, Nn, H1, W1); G_(ds0_3, Nn, H1, W1); G_(du3, Nn, H1, W1); G_(ds1_3, Nn, H2, W2); G_(dt3, Nn, H2, W2);
+    G_(dw2, Nn, H4, W4); G_(dfeat_tot, Nn, H4, W4); G_(dz2_up, Nn, H8, W8); G_(de3_2a, Nn, H4, W4);
+    G_(de3_1, Nn, H2, W2); G_(de3_1a, Nn, H2, W2); G_(de3_0, Nn, H1, W1); G_(de3_0a, Nn, H1, W1);
+    G_(dv2, Nn, H2, W2); G_(ds0_2, Nn, H2, W2); G_(dz4, Nn, H2, W2); G_(du2, Nn, H2, W2); G_(ds1_2, Nn, H4, W4);
+    G_(dz3, Nn, H4, W4); G_(dt2, Nn, H4, W4); G_(dz2, Nn, H8, W8); G_(de2_2a, Nn, H8, W8); G_(de2_1, Nn, H4, W4);
+    G_(de2_1a, Nn, H4, W4); G_(de2_0, Nn, H2, W2); G_(de2_0a, Nn, H2, W2); G_(dv1, Nn, H4, W4); G_(dm_total, Nn, H4, W4);
+    G_(g_feat, Nn, H4, W4);
+#undef G_
+    if (c->mixed) {
+        c->dm_f32 = c->falloc((size_t)Nn * H4 * W4 * 32);
+        // depth-only maps of the stage-1 encoder that the proxy chain reads (held once, fp32): narrow copies made in the prefix
+        c->twin_alloc(c->e1_0, Nn, H4, W4); c->twin_alloc(c->e1_1a, Nn, H8, W8); c->twin_alloc(c->e1_2a, Nn, H16, W16);
+    }
     M_(dp11, Nn, H1, W1); M_(dq, Nn, H2, W2); M_(dp12, Nn, H2, W2); M_(dout1, Nn, H4, W4);
     c->g_feat_f32 = c->falloc((size_t)c->Rg * 32);
     c->dbg["g_feat_f32"] = Dbg{c->g_feat_f32, c->Rg * 32, 0};
@@ -527,21 +538,29 @@ struct ProfScope {
     ~ProfScope() { if (pc) { (void)hipEventRecord(pc->ev[pc->used].second, s); pc->used++; } }
 };
 // first-layer / prediction convolutions (class 7): Cin <= 3 -> 32 and 32 -> 1, forward and as each other's data gradient
-int conv_in_p(ptta_ctx* c, const ConvInArgs& a, hipStream_t s) {
+int conv_in_p(ptta_ctx* c, const ConvInArgs& a_, hipStream_t s) {
+    ConvInArgs a = a_;
     const double px = (double)a.B * a.H * a.W;
-    ProfScope ps(c, 7, s, (px * (a.cin + 32) + 9.0 * a.cin * 32) * c->es, px * 9.0 * a.cin * 32, 1);
+    ProfScope ps(c, 7, s, px * (a.cin * 4 + 32 * (a.bf16 ? 2 : c->es)) + 9.0 * a.cin * 32 * 4, px * 9.0 * a.cin * 32, 1);
+    if (!c->mbits.empty()) {
+        // sign-bit planes: a masked launch reads its mask's plane when there is one (a narrow launch must); a launch that starts at frame 0
+        // of a map the backward masks with writes that map's plane for the real frames
+        if (!a.mask_bits) a.mask_bits = c->bits_of(a.mask);
+        if (!a.bf16 && !a.a_bits) { a.a_bits = c->bits_of(a.out_raw); a.a_bits_nb = c->Nn; }
+    }
     return ptta_launch_conv_in(a, s);
 }
 int conv_out1_p(ptta_ctx* c, const ConvOut1Args& a, hipStream_t s) {
     const double px = (double)a.B * a.H * a.W;
-    ProfScope ps(c, 7, s, (px * 33 + 288) * c->es, px * 288.0, 1);
+    ProfScope ps(c, 7, s, px * (32 * (a.bf16 ? 2 : c->es) + 4) + 288 * 4, px * 288.0, 1);
     return ptta_launch_conv_out1(a, s);
 }
 #define REST_(s_, call) do { ProfScope ps_(c, 8, (s_), 0, 0, 1); RUN(call); } while (0)
 
 struct E { const void* up = nullptr; int up_nb = 1; const void* mask = nullptr; int mask_nb = 1;
            const void* add1 = nullptr; int add1_nb = 1; const void* add2 = nullptr; int add2_nb = 1;
-           void* raw = nullptr; void* sum = nullptr; };
+           void* raw = nullptr; void* sum = nullptr;
+           bool nar = false; };      // nar: a launch over NARROW maps (mixed mode: the proxy chain; every backward launch is one anyway)
 
 int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int mode, const void* in, int in_nb,
            int B, int Hin, int Win, bool relu, const E& e) {
@@ -553,12 +572,14 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     a.up = e.up; a.up_nb = e.up_nb; a.mask = e.mask; a.mask_nb = e.mask_nb;
     a.add1 = e.add1; a.add1_nb = e.add1_nb; a.add2 = e.add2; a.add2_nb = e.add2_nb;
     a.out_raw = e.raw; a.out_sum = e.sum;
-    a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = c->bf16; a.naive = c->naive; a.x3 = c->x3;
+    const bool nar = e.nar || (bwd && c->mixed);
+    const int es_l = nar ? 2 : c->es;
+    a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = nar ? 1 : c->bf16; a.naive = c->naive; a.x3 = c->x3;
     if (!c->mbits.empty()) {
         // sign-bit masks: the backward reads the bits of its mask; a forward launch that starts at frame 0 of a map the backward masks
         // with writes that map's bits for the real frames (launches over the proxy half start at an offset pointer: no entry, no bits)
         a.mask_bits = c->bits_of(e.mask);
-        if (!bwd) {
+        if (!bwd && !nar) {
             uint32_t* bs = c->bits_of(e.sum); uint32_t* br = c->bits_of(e.raw);
             if (bs && br) return c->fail("conv32: both outputs of " + layer + " are registered masks", -22);
             if (bs || br) { a.bits_out = bs ? bs : br; a.bits_sum = bs ? 1 : 0; a.bits_nb = c->Nn; }
@@ -575,7 +596,7 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     const long pin = (long)B * Hin * Win;
     const long pout = mode == CONV_S1 ? pin : (mode == CONV_S2 ? pin / 4 : pin * 4);
     const bool small = (long)Hin * Win <= (long)c->H4 * c->W4 * (mode == CONV_S2 ? 4 : 1);
-    ProfScope ps(c, (mode == CONV_S1 ? (relu ? 0 : 2) : 4) + (small ? 1 : 0), s, (double)((pin + pout) * 32 + 9216) * c->es,
+    ProfScope ps(c, (mode == CONV_S1 ? (relu ? 0 : 2) : 4) + (small ? 1 : 0), s, (double)((pin + pout) * 32 + 9216) * es_l,
                  (double)(mode == CONV_T2 ? pin : pout) * 9.0 * 32.0 * 32.0, 1);
     return ptta_launch_conv32(a, s);
 }
@@ -595,20 +616,22 @@ int conv32_first(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvInArg
     auto it = c->l32.find(layer);
     if (it == c->l32.end()) return c->fail("unknown 32->32 layer " + layer, -2);
     const long tiles = (long)B * ((W + 31) / 32) * ((H + 7) / 8);
+    const bool nar = e.nar;
+    f.bf16 = nar ? 1 : c->bf16;
     if (c->fuse_first >= (f.cin == 3 ? 2 : 1) && !(c->ablate & 3) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && !e.mask && !e.add1 && !e.add2 && !e.sum) {
         Conv32Args a;
         a.in = nullptr; a.in_nb = B; a.w = &it->second.f; a.bias = it->second.bias;
         a.up = e.up; a.up_nb = e.up_nb; a.out_raw = e.raw;
-        a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 1; a.bf16 = 0; a.naive = 0; a.x3 = 1;
+        a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 1; a.bf16 = nar ? 1 : 0; a.naive = 0; a.x3 = 1;
         const double px = (double)B * H * W;
-        // (both layers' algorithmic bytes and MACs: the launch executes both)
-        ProfScope ps(c, 0, s, (px * (f.cin + 32) + 9.0 * f.cin * 32 + px * 64 + 9216) * c->es, px * 9.0 * (f.cin * 32 + 1024), 1);
+        // (both layers' algorithmic bytes and MACs: the launch executes both; the input planes are fp32, the 32-channel maps es_l wide)
+        const int es_l = nar ? 2 : c->es;
+        ProfScope ps(c, 0, s, (px * f.cin + 9.0 * f.cin * 32) * 4 + (px * 96 + 9216) * es_l, px * 9.0 * (f.cin * 32 + 1024), 1);
         // the first convolution's pre-activation map is the backward's ReLU mask and nothing else: with a bit plane only its sign bits are
         // written (a_bits), not the 128-B pixels (PTTA_KEEP_FIRST_MAP=1 writes both)
-        static const bool keep_map = getenv("PTTA_KEEP_FIRST_MAP") && atoi(getenv("PTTA_KEEP_FIRST_MAP")) != 0;
-        f.a_bits = a_nb > 0 ? c->bits_of(f.out_raw) : nullptr;
-        if (!c->mbits.empty()) { uint32_t* br = c->bits_of(e.raw); if (br) { a.bits_out = br; a.bits_nb = c->Nn; } }
-        const int rc = ptta_launch_conv32_first(a, f, (a_nb > 0 && (!f.a_bits || keep_map)) ? f.out_raw : nullptr, a_nb, s);
+        f.a_bits = (a_nb > 0 && !nar) ? c->bits_of(f.out_raw) : nullptr;
+        if (!c->mbits.empty() && !nar) { uint32_t* br = c->bits_of(e.raw); if (br) { a.bits_out = br; a.bits_nb = c->Nn; } }
+        const int rc = ptta_launch_conv32_first(a, f, (a_nb > 0 && !nar && !f.a_bits) ? f.out_raw : nullptr, a_nb, s);
         return rc == 1 ? c->fail("conv32_first: fused form refused a case its caller accepted", -22) : rc;
     }
     RUN(conv_in_p(c, f, s));
@@ -621,15 +644,17 @@ int conv32_first_bwd(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvI
     auto it = c->l32.find(layer);
     if (it == c->l32.end()) return c->fail("unknown 32->32 layer " + layer, -2);
     const long tiles = (long)B * ((W + 31) / 32) * ((H + 7) / 8);
-    static const bool on = !getenv("PTTA_FUSE_HEAD_BWD") || atoi(getenv("PTTA_FUSE_HEAD_BWD")) != 0;
-    if (on && c->bits_of(f.mask) && c->fuse_first >= 1 && !(c->ablate & 3) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && e.mask && e.raw && !e.add1 && !e.add2 && !e.sum && !e.up) {
+    const bool nar = c->mixed != 0;
+    f.bf16 = nar ? 1 : c->bf16;
+    if (c->fuse_head_bwd && c->bits_of(f.mask) && c->bits_of(e.mask) && c->fuse_first >= 1 && !(c->ablate & 3) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && e.mask && e.raw && !e.add1 && !e.add2 && !e.sum && !e.up) {
         Conv32Args a;
         a.in = nullptr; a.in_nb = B; a.w = &it->second.b; a.bias = nullptr;
         a.mask = e.mask; a.mask_nb = e.mask_nb; a.out_raw = e.raw;
         a.mask_bits = c->bits_of(e.mask); f.mask_bits = c->bits_of(f.mask);
-        a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 0; a.bf16 = 0; a.naive = 0; a.x3 = 1;
+        a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 0; a.bf16 = nar ? 1 : 0; a.naive = 0; a.x3 = 1;
         const double px = (double)B * H * W;
-        ProfScope ps(c, 2, s, (px * (1 + 32) + 9.0 * 32 + px * 64 + 9216) * c->es, px * 9.0 * (32 + 1024), 1);
+        const int es_l = nar ? 2 : c->es;
+        ProfScope ps(c, 2, s, (px + 9.0 * 32) * 4 + (px * 96 + 9216) * es_l, px * 9.0 * (32 + 1024), 1);
         const int rc = ptta_launch_conv32_first(a, f, nullptr, 0, s);
         return rc == 1 ? c->fail("conv32_first_bwd: fused form refused a case its caller accepted", -22) : rc;
     }
@@ -646,6 +671,9 @@ int meta_forward(ptta_ctx* c, bool train, int B, hipStream_t s) {
     const int H4 = c->H4, W4 = c->W4, Nn = c->Nn;
     if (c->meta_mode == PTTA_META_1LAYER) {
         E e; e.raw = c->m;
+        if (c->mixed && train && B == 2 * Nn) {      // real frames here (fp32); the proxy frames' narrow launch is meta_forward_proxy()
+            return conv32(c, s, "conv1_rgb_meta", false, CONV_S1, c->c2, Nn, Nn, H4, W4, false, e);
+        }
         return conv32(c, s, "conv1_rgb_meta", false, CONV_S1, c->c2, B, B, H4, W4, false, e);
     }
     auto& m2 = c->m2;
@@ -738,7 +766,7 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
         GView hv = x; hv.p = m2.gh; hv.C = 128; hv.ld = 128;
         GView av = hv; av.p = m2.ga1;
         GView tv = x; tv.p = m2.gt;
-        GView gm = x; gm.p = (float*)c->dm_total;
+        GView gm = x; gm.p = c->mixed ? c->dm_f32 : (float*)c->dm_total;
         GView dt = x; dt.p = m2.gdt;
         GView da1 = hv; da1.p = m2.gda1;
         GView dh = hv; dh.p = m2.gdh;
@@ -781,11 +809,33 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
     return 0;
 }
 
+// mixed mode: the adapted layer on the proxy frames (narrow).  1layer: the same convolution on the narrow copy of the zero-image features;
+// 2layers: the fp32 Res_Conv block above ran on both passes (its BatchNorm statistics are per pass), the proxy half is narrowed here.
+int to_narrow(ptta_ctx* c, const void* src_f32, void* dst, long n, hipStream_t s) {
+    if (!src_f32 || !dst) return c->fail("to_narrow: missing narrow twin", -22);
+    ProfScope ps_(c, 8, s, 0, 0, 1);
+    hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(n)), dim3(256), 0, s, (const float*)src_f32, (bf16_t*)dst, n);
+    return 0;
+}
+int to_wide(ptta_ctx* c, const void* src_nar, float* dst, long n, hipStream_t s) {
+    if (!src_nar || !dst) return c->fail("to_wide: missing operand", -22);
+    ProfScope ps_(c, 8, s, 0, 0, 1);
+    hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(nblk(n)), dim3(256), 0, s, (const bf16_t*)src_nar, dst, n);
+    return 0;
+}
+int meta_forward_proxy(ptta_ctx* c, hipStream_t s) {
+    const int H4 = c->H4, W4 = c->W4, Nn = c->Nn;
+    const long half = (long)Nn * H4 * W4 * 32;
+    if (c->meta_mode == PTTA_META_1LAYER) {
+        E e; e.raw = c->tw(c->m); e.nar = true;
+        return conv32(c, s, "conv1_rgb_meta", false, CONV_S1, c->tw(c->c2), Nn, Nn, H4, W4, false, e);
+    }
+    return to_narrow(c, (const float*)c->m + half, c->tw(c->m), half, s);
+}
+
 int heads_forward(ptta_ctx* c, hipStream_t s, int part = 0);
 static int pipe_quiesce(ptta_ctx* c);
 static void pipe_use(ptta_ctx* c, int p);
-static bool dual_ok(const ptta_ctx* c);
-static int dual_step(ptta_ctx* c, int key, int set, bool prefix_done, hipStream_t s);
 // a full forward (ptta_forward_eval / ptta_forward_train) has written an arbitrary frame's prefix into set p: whatever was prepared into it
 // or adapted from it is gone.  (Set p is pipe_last; when a prefix of the SAME frame was kept there for another step -- inner_iter > 1 --
 // the step that follows recomputes it in line.)
@@ -857,6 +907,14 @@ int ensure_proxy_rgb(ptta_ctx* c, const float* any_image, hipStream_t s) {
     RUN(ensure_fused_heads(c, s));
     if (c->proxy_rgb_valid) return 0;
     RUN(rgb_encoder(c, any_image, c->Nn, c->Nn, 0, s));
+    if (c->mixed) {      // what the proxy chain reads of it: the skip operands c1 .. c4 and the adapted layer's input c2, as narrow maps
+        const int Nn = c->Nn;
+        struct { void* p; int h, w; } maps[4] = {{c->c1, c->H2, c->W2}, {c->c2, c->H4, c->W4}, {c->c3, c->H8, c->W8}, {c->c4, c->H16, c->W16}};
+        for (auto& m_ : maps) {
+            const long half = (long)Nn * m_.h * m_.w * 32;
+            RUN(to_narrow(c, (const float*)m_.p + half, c->tw(m_.p), half, s));
+        }
+    }
     c->proxy_rgb_valid = true;
     return 0;
 }
@@ -878,82 +936,71 @@ int enc1_head_fn(ptta_ctx* c, hipStream_t st) {
 // (:487-489) and decoder 1 down to its last transposed convolution (DepthDecoder.forward :296-305) -- conv1_rgb_meta's output enters
 // at dec1.3.  B2 = images per launch ([real | proxy] in a training forward).
 int stage1_independent(ptta_ctx* c, int B2, hipStream_t s) {
-    const int Nn = c->Nn, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
+    const int Nn = c->Nn, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
+    const bool two = c->mixed && B2 == 2 * Nn;        // mixed training forward: real frames fp32 here, proxy frames narrow below
+    const int Bf = two ? Nn : B2;
     { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
-      RUN(conv32(c, s, "depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, B2, H8, W8, true, e)); }
+      RUN(conv32(c, s, "depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, Bf, H8, W8, true, e)); }
     { E e; e.raw = c->e1_2a; RUN(conv32(c, s, "depth_encoder1.enc2.1", false, CONV_S2, c->e1_1, B2, Nn, H8, W8, true, e)); }
     { E e; e.sum = c->y2; e.add1 = c->c4; e.add1_nb = B2;                                         // y2 = e1_2 + c4
-      RUN(conv32(c, s, "depth_encoder1.enc2.3", false, CONV_S1, c->e1_2a, Nn, B2, H16, W16, true, e)); }
-    { E e; e.raw = c->t1; RUN(conv32(c, s, "depth_decoder1.dec2.1", false, CONV_T2, c->y2, B2, B2, H16, W16, true, e)); }
+      RUN(conv32(c, s, "depth_encoder1.enc2.3", false, CONV_S1, c->e1_2a, Nn, Bf, H16, W16, true, e)); }
+    { E e; e.raw = c->t1; RUN(conv32(c, s, "depth_decoder1.dec2.1", false, CONV_T2, c->y2, B2, Bf, H16, W16, true, e)); }
     { E e; e.raw = c->y3; e.sum = c->s1_1; e.add1 = c->y1; e.add1_nb = B2;
-      RUN(conv32(c, s, "depth_decoder1.dec2.3", false, CONV_S1, c->t1, B2, B2, H8, W8, true, e)); }
-    { E e; e.raw = c->u1; RUN(conv32(c, s, "depth_decoder1.dec1.1", false, CONV_T2, c->s1_1, B2, B2, H8, W8, true, e)); }
+      RUN(conv32(c, s, "depth_decoder1.dec2.3", false, CONV_S1, c->t1, B2, Bf, H8, W8, true, e)); }
+    { E e; e.raw = c->u1; RUN(conv32(c, s, "depth_decoder1.dec1.1", false, CONV_T2, c->s1_1, B2, Bf, H8, W8, true, e)); }
+    if (!two) return 0;
+    // ---- the same six layers for the proxy frames, narrow: the depth-only inputs (held once, fp32) are narrowed first ----
+    RUN(to_narrow(c, c->e1_0, c->tw(c->e1_0), (long)Nn * H4 * W4 * 32, s));
+    RUN(to_narrow(c, c->e1_1a, c->tw(c->e1_1a), (long)Nn * H8 * W8 * 32, s));
+    RUN(to_narrow(c, c->e1_2a, c->tw(c->e1_2a), (long)Nn * H16 * W16 * 32, s));
+    { E e; e.nar = true; e.sum = c->tw(c->y1); e.add1 = c->tw(c->c3); e.add1_nb = Nn;
+      RUN(conv32(c, s, "depth_encoder1.enc1.3", false, CONV_S1, c->tw(c->e1_1a), Nn, Nn, H8, W8, true, e)); }
+    { E e; e.nar = true; e.sum = c->tw(c->y2); e.add1 = c->tw(c->c4); e.add1_nb = Nn;
+      RUN(conv32(c, s, "depth_encoder1.enc2.3", false, CONV_S1, c->tw(c->e1_2a), Nn, Nn, H16, W16, true, e)); }
+    { E e; e.nar = true; e.raw = c->tw(c->t1); RUN(conv32(c, s, "depth_decoder1.dec2.1", false, CONV_T2, c->tw(c->y2), Nn, Nn, H16, W16, true, e)); }
+    { E e; e.nar = true; e.raw = c->tw(c->y3); e.sum = c->tw(c->s1_1); e.add1 = c->tw(c->y1); e.add1_nb = Nn;
+      RUN(conv32(c, s, "depth_decoder1.dec2.3", false, CONV_S1, c->tw(c->t1), Nn, Nn, H8, W8, true, e)); }
+    { E e; e.nar = true; e.raw = c->tw(c->u1); RUN(conv32(c, s, "depth_decoder1.dec1.1", false, CONV_T2, c->tw(c->s1_1), Nn, Nn, H8, W8, true, e)); }
     return 0;
 }
 
 // One encoder-decoder cascade.  train: batch = [Nn real | Nn proxy(zero image)], D3 only on the real half;
 // the MLP heads (which only need depth_encoder3's output) run on the auxiliary stream beside decoder 3.
+// Mixed mode (train): the two passes are two launch chains -- the real frames (fp32 maps, bf16x3) on `s`, the proxy frames (narrow maps,
+// one MFMA per product) on the auxiliary stream from the adapted layer on; the heads follow the proxy chain there once the real chain's
+// depth_encoder3 output exists.
 int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
-    hipStream_t s2 = (train && c->fwd_phase == 0) ? c->aux(s) : nullptr;
+    hipStream_t s2 = train ? c->aux(s) : nullptr;
     const int Nn = c->Nn, B2 = train ? 2 * Nn : Nn;
+    const bool two = train && c->mixed;
     const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
     auto e_raw = [](void* raw) { E e; e.raw = raw; return e; };
     // ---- RGB encoder (RGBEncoder.forward :252-264) + meta layer (:481-482) ----
     // train: the proxy half of c0..c4 (zero image through frozen weights) is a constant of the handle, computed once by
     // ensure_proxy_rgb(); only the real frames go through the encoder here
-    // Its first three launches need nothing from the RGB branch: with a second stream they run BESIDE the RGB encoder
-    // (forked before it, below); the fourth adds c3 and waits for the join.
-    auto enc1_head = [&](hipStream_t st) -> int { return enc1_head_fn(c, st); };
-    const bool early = train && s2 && (c->split_fwd & 2) && !c->skip_prefix;
-    if (early) {                  // depth-only head of the stage-1 encoder beside the RGB encoder
-        HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-        RUN(enc1_head(s2));
-        HIPCHK(hipEventRecord(c->ev_join, s2));
-    }
-    const int ph = train ? c->fwd_phase : 0;              // the step as four graphs: 1 = what both passes need, 2 = real frames, 3 = proxy frames
-    if (ph < 2) {
     if (!c->skip_prefix) RUN(rgb_encoder(c, image, Nn, 0, Nn, s));
     RUN(meta_forward(c, train, B2, s));
-
     // ---- stage 1/4 (:487-489): depth-only encoder shared by both passes ----
-    if (early) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); else if (!c->skip_prefix) RUN(enc1_head(s));
-    }
-    const bool split = train && s2 && (c->split_fwd & 1) && ph == 0;
-    if (ph < 2 && !c->skip_prefix && !split) RUN(stage1_independent(c, B2, s));
-    if (ph == 1) return 0;
-    if (split) {                     // (diagnostic split of the two passes: the head of decoder 1 stays inside each pass's chain)
-        { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
-          CV("depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, B2, H8, W8, true, e); }
-        CV("depth_encoder1.enc2.1", false, CONV_S2, c->e1_1, B2, Nn, H8, W8, true, e_raw(c->e1_2a));
-        { E e; e.sum = c->y2; e.add1 = c->c4; e.add1_nb = B2;                                         // y2 = e1_2 + c4
-          CV("depth_encoder1.enc2.3", false, CONV_S1, c->e1_2a, Nn, B2, H16, W16, true, e); }
-    }
+    if (!c->skip_prefix) { RUN(enc1_head_fn(c, s)); RUN(stage1_independent(c, B2, s)); }
 
-    // ---- decoder 1, stage 1/2, encoder of stage 1/1: `Bl` frames starting at batch index b0 of the [real | proxy] batch.
-    // One pass over the whole batch (b0 = 0, Bl = B2), or -- training step with a second stream -- the real frames on `s` and
-    // the proxy frames on the auxiliary stream: the two halves are independent until the loss, and most of these 30 launches are
-    // 1/4 ... 1/16-resolution layers that leave the chip half empty.  Tensors that hold the batch once
-    // (e1_0, d12, dclamp: depth-only) are indexed modulo their own batch count and take no offset.
-    auto region = [&](hipStream_t st, int b0, int Bl) -> int {
-        auto A = [&](void* p_, int h, int w) { return (void*)((char*)p_ + (size_t)b0 * h * w * 32 * c->es); };
+    // ---- decoder 1, stage 1/2, encoder of stage 1/1: `Bl` frames starting at batch index b0 of the [real | proxy] batch (nar: the
+    // proxy frames as narrow maps, tw(...) of each [real | proxy] map).  Tensors that hold the batch once (e1_0, d12, dclamp:
+    // depth-only) are indexed modulo their own batch count and take no offset.
+    auto region = [&](hipStream_t st, int b0, int Bl, bool nar) -> int {
+        auto A = [&](void* p_, int h, int w) -> void* { return nar ? c->tw(p_) : (void*)((char*)p_ + (size_t)b0 * h * w * 32 * c->es); };
         auto P1 = [&](float* p_, int h, int w) { return p_ + (size_t)b0 * h * w; };
-        auto raw = [](void* r) { E e; e.raw = r; return e; };
+        auto raw = [&](void* r) { E e; e.raw = r; e.nar = nar; return e; };
+        const void* e1_0 = nar ? c->tw(c->e1_0) : c->e1_0;
 #define CR(...) RUN(conv32(c, st, __VA_ARGS__))
-        // decoder 1 (DepthDecoder.forward :296-311); its first three launches are in stage1_independent() unless the passes are split
-        if (split) {
-        CR("depth_decoder1.dec2.1", false, CONV_T2, A(c->y2, H16, W16), Bl, Bl, H16, W16, true, raw(A(c->t1, H8, W8)));
-        { E e; e.raw = A(c->y3, H8, W8); e.sum = A(c->s1_1, H8, W8); e.add1 = A(c->y1, H8, W8); e.add1_nb = Bl;
-          CR("depth_decoder1.dec2.3", false, CONV_S1, A(c->t1, H8, W8), Bl, Bl, H8, W8, true, e); }
-        CR("depth_decoder1.dec1.1", false, CONV_T2, A(c->s1_1, H8, W8), Bl, Bl, H8, W8, true, raw(A(c->u1, H4, W4)));
-        }
-        { E e; e.raw = A(c->y4, H4, W4); e.sum = A(c->s0_1, H4, W4); e.add1 = c->e1_0; e.add1_nb = Nn; e.add2 = A(c->m, H4, W4); e.add2_nb = Bl;
+        // decoder 1 (DepthDecoder.forward :296-311); its first three launches are in stage1_independent()
+        { E e; e.nar = nar; e.raw = A(c->y4, H4, W4); e.sum = A(c->s0_1, H4, W4); e.add1 = e1_0; e.add1_nb = Nn; e.add2 = A(c->m, H4, W4); e.add2_nb = Bl;
           CR("depth_decoder1.dec1.3", false, CONV_S1, A(c->u1, H4, W4), Bl, Bl, H4, W4, true, e); }
         CR("depth_decoder1.prdct.1", false, CONV_S1, A(c->s0_1, H4, W4), Bl, Bl, H4, W4, true, raw(A(c->v1, H4, W4)));
         {
             const LOut& lo = c->lout["depth_decoder1.prdct.3"];
             ConvOut1Args a; a.in = A(c->v1, H4, W4); a.in_nb = Bl; a.w = lo.w; a.bias = lo.bias; a.out = P1(c->out1, H4, W4);
-            a.B = Bl; a.H = H4; a.W = W4; a.relu_in = 1; a.bf16 = c->bf16;
+            a.B = Bl; a.H = H4; a.W = W4; a.relu_in = 1; a.bf16 = nar ? 1 : c->bf16;
             RUN(conv_out1_p(c, a, st));
         }
         // ---- stage 1/2 (:491-498) ----
@@ -966,25 +1013,25 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
             a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = A(c->e2_0a, H2, W2);
             a.B = Bl; a.H = H2; a.W = W2; a.bf16 = c->bf16; a.naive = c->naive;
             // (the pre-activation map is the backward's ReLU mask for the real frames only: batch indices below Nn of a launch that starts at b0 = 0)
-            E e; e.raw = A(c->e2_0, H2, W2); e.up = A(c->y4, H4, W4); e.up_nb = Bl;
-            RUN(conv32_first(c, st, "depth_encoder2.init.2", a, b0 == 0 ? Nn : 0, Bl, H2, W2, e));
+            E e; e.nar = nar; e.raw = A(c->e2_0, H2, W2); e.up = A(c->y4, H4, W4); e.up_nb = Bl;
+            RUN(conv32_first(c, st, "depth_encoder2.init.2", a, (b0 == 0 && !nar) ? Nn : 0, Bl, H2, W2, e));
         }
         CR("depth_encoder2.enc1.1", false, CONV_S2, A(c->e2_0, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->e2_1a, H4, W4)));
-        { E e; e.raw = A(c->e2_1, H4, W4); e.up = A(c->y3, H8, W8); e.up_nb = Bl; CR("depth_encoder2.enc1.3", false, CONV_S1, A(c->e2_1a, H4, W4), Bl, Bl, H4, W4, true, e); }
+        { E e; e.nar = nar; e.raw = A(c->e2_1, H4, W4); e.up = A(c->y3, H8, W8); e.up_nb = Bl; CR("depth_encoder2.enc1.3", false, CONV_S1, A(c->e2_1a, H4, W4), Bl, Bl, H4, W4, true, e); }
         CR("depth_encoder2.enc2.1", false, CONV_S2, A(c->e2_1, H4, W4), Bl, Bl, H4, W4, true, raw(A(c->e2_2a, H8, W8)));
-        { E e; e.sum = A(c->z2, H8, W8); e.up = A(c->y2, H16, W16); e.up_nb = Bl; e.add1 = A(c->c3, H8, W8); e.add1_nb = Bl;            // z2 = e2_2 + c3
+        { E e; e.nar = nar; e.sum = A(c->z2, H8, W8); e.up = A(c->y2, H16, W16); e.up_nb = Bl; e.add1 = A(c->c3, H8, W8); e.add1_nb = Bl;            // z2 = e2_2 + c3
           CR("depth_encoder2.enc2.3", false, CONV_S1, A(c->e2_2a, H8, W8), Bl, Bl, H8, W8, true, e); }
         CR("depth_decoder2.dec2.1", false, CONV_T2, A(c->z2, H8, W8), Bl, Bl, H8, W8, true, raw(A(c->t2, H4, W4)));
-        { E e; e.raw = A(c->z3, H4, W4); e.sum = A(c->s1_2, H4, W4); e.add1 = A(c->e2_1, H4, W4); e.add1_nb = Bl; e.add2 = A(c->m, H4, W4); e.add2_nb = Bl;
+        { E e; e.nar = nar; e.raw = A(c->z3, H4, W4); e.sum = A(c->s1_2, H4, W4); e.add1 = A(c->e2_1, H4, W4); e.add1_nb = Bl; e.add2 = A(c->m, H4, W4); e.add2_nb = Bl;
           CR("depth_decoder2.dec2.3", false, CONV_S1, A(c->t2, H4, W4), Bl, Bl, H4, W4, true, e); }
         CR("depth_decoder2.dec1.1", false, CONV_T2, A(c->s1_2, H4, W4), Bl, Bl, H4, W4, true, raw(A(c->u2, H2, W2)));
-        { E e; e.raw = A(c->z4, H2, W2); e.sum = A(c->s0_2, H2, W2); e.add1 = A(c->e2_0, H2, W2); e.add1_nb = Bl; e.add2 = A(c->c1, H2, W2); e.add2_nb = Bl;
+        { E e; e.nar = nar; e.raw = A(c->z4, H2, W2); e.sum = A(c->s0_2, H2, W2); e.add1 = A(c->e2_0, H2, W2); e.add1_nb = Bl; e.add2 = A(c->c1, H2, W2); e.add2_nb = Bl;
           CR("depth_decoder2.dec1.3", false, CONV_S1, A(c->u2, H2, W2), Bl, Bl, H2, W2, true, e); }
         CR("depth_decoder2.prdct.1", false, CONV_S1, A(c->s0_2, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->v2, H2, W2)));
         {
             const LOut& lo = c->lout["depth_decoder2.prdct.3"];
             ConvOut1Args a; a.in = A(c->v2, H2, W2); a.in_nb = Bl; a.w = lo.w; a.bias = lo.bias; a.add = P1(c->p12, H2, W2); a.add_nb = Bl; a.out = P1(c->q, H2, W2);
-            a.B = Bl; a.H = H2; a.W = W2; a.relu_in = 1; a.bf16 = c->bf16;                           // q = out2 + p12
+            a.B = Bl; a.H = H2; a.W = W2; a.relu_in = 1; a.bf16 = nar ? 1 : c->bf16;                           // q = out2 + p12
             RUN(conv_out1_p(c, a, st));
         }
         // ---- stage 1/1 (:500-506) ----
@@ -996,34 +1043,34 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
             a.pl[1].p = P1(c->p11, H1, W1); a.pl[1].nb = Bl; a.pl[1].bstride = (long)H1 * W1;
             a.wfrag = li.wfrag; a.wcanon = li.wcanon; a.bias = li.bias; a.out_raw = A(c->e3_0a, H1, W1);
             a.B = Bl; a.H = H1; a.W = W1; a.bf16 = c->bf16; a.naive = c->naive;
-            E e; e.raw = A(c->e3_0, H1, W1); e.up = A(c->z4, H2, W2); e.up_nb = Bl;
-            RUN(conv32_first(c, st, "depth_encoder3.init.2", a, b0 == 0 ? Nn : 0, Bl, H1, W1, e));
+            E e; e.nar = nar; e.raw = A(c->e3_0, H1, W1); e.up = A(c->z4, H2, W2); e.up_nb = Bl;
+            RUN(conv32_first(c, st, "depth_encoder3.init.2", a, (b0 == 0 && !nar) ? Nn : 0, Bl, H1, W1, e));
         }
         CR("depth_encoder3.enc1.1", false, CONV_S2, A(c->e3_0, H1, W1), Bl, Bl, H1, W1, true, raw(A(c->e3_1a, H2, W2)));
-        { E e; e.raw = A(c->e3_1, H2, W2); e.up = A(c->z3, H4, W4); e.up_nb = Bl; CR("depth_encoder3.enc1.3", false, CONV_S1, A(c->e3_1a, H2, W2), Bl, Bl, H2, W2, true, e); }
+        { E e; e.nar = nar; e.raw = A(c->e3_1, H2, W2); e.up = A(c->z3, H4, W4); e.up_nb = Bl; CR("depth_encoder3.enc1.3", false, CONV_S1, A(c->e3_1a, H2, W2), Bl, Bl, H2, W2, true, e); }
         CR("depth_encoder3.enc2.1", false, CONV_S2, A(c->e3_1, H2, W2), Bl, Bl, H2, W2, true, raw(A(c->e3_2a, H4, W4)));
-        { E e; e.raw = A(c->feat, H4, W4); e.sum = A(c->w2, H4, W4); e.up = A(c->z2, H8, W8); e.up_nb = Bl; e.add1 = A(c->m, H4, W4); e.add1_nb = Bl;   // w2 = feat + m
+        { E e; e.nar = nar; e.raw = A(c->feat, H4, W4); e.up = A(c->z2, H8, W8); e.up_nb = Bl; e.add1 = A(c->m, H4, W4); e.add1_nb = Bl;   // w2 = feat + m
+          if (!nar) e.sum = A(c->w2, H4, W4); else e.add1 = nullptr;         // (the proxy pass stops at depth_encoder3: its w2 feeds nothing)
           CR("depth_encoder3.enc2.3", false, CONV_S1, A(c->e3_2a, H4, W4), Bl, Bl, H4, W4, true, e); }
 #undef CR
         return 0;
     };
-    if (ph == 3) {                   // proxy frames: decoder 1 ... encoder 3, then emb = pred(proj(feat_zero))
-        RUN(region(s, Nn, Nn));
-        return heads_forward(c, s, 1);
-    }
-    if (ph == 2) {                   // real frames: decoder 1 ... encoder 3, ref = proj(feat), then decoder 3 (below)
-        RUN(region(s, 0, Nn));
-        RUN(heads_forward(c, s, 2));
-    } else if (split) {
-        // real frames on s, proxy frames on s2; the heads (both halves' depth_encoder3 outputs) follow on s2 beside decoder 3
-        HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
-        RUN(region(s, 0, Nn));
-        RUN(region(s2, Nn, Nn));
-        HIPCHK(hipEventRecord(c->ev_real, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_real, 0));
-        RUN(heads_forward(c, s2));
-        HIPCHK(hipEventRecord(c->ev_join, s2));
+    if (two) {
+        // real frames on s, proxy frames (narrow) on the auxiliary stream; the heads (both passes' depth_encoder3 outputs) follow there
+        hipStream_t sp = s2 ? s2 : s;
+        if (s2) { HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
+        RUN(meta_forward_proxy(c, sp));
+        RUN(region(s, 0, Nn, false));
+        RUN(region(sp, Nn, Nn, true));
+        // (round 5, step 1: the heads still take fp32 features -- the proxy features are widened into the proxy half of `feat`)
+        RUN(to_wide(c, c->tw(c->feat), (float*)c->feat + (size_t)c->Rg * 32, c->Rg * 32, sp));
+        if (s2) {
+            HIPCHK(hipEventRecord(c->ev_real, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_real, 0));
+            RUN(heads_forward(c, s2));
+            HIPCHK(hipEventRecord(c->ev_join, s2));
+        }
     } else {
-        RUN(region(s, 0, B2));
+        RUN(region(s, 0, B2, false));
         if (train && s2) {
             HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
             RUN(heads_forward(c, s2));
@@ -1048,7 +1095,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     }
     }
 #undef CV
-    if (train && ph == 0) {
+    if (train) {
         if (s2) { if (!c->thru_active) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); }      // (thru: the heads' stream goes on into the loss and the backward)
         else RUN(heads_forward(c, s));
     }
@@ -1193,7 +1240,8 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
         RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
         RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s,
                                         nullptr, nullptr, c->head_k12, l0.bias, bn.mean));
-        RUN(ptta_launch_head_bwd_finish(c->head_k12, l0.W, c->headP, (const float*)c->feat, R, (float*)c->g_feat, s));
+        RUN(ptta_launch_head_bwd_finish(c->head_k12, l0.W, c->headP, (const float*)c->feat, R, c->mixed ? c->g_feat_f32 : (float*)c->g_feat, s));
+        if (c->mixed) RUN(to_narrow(c, c->g_feat_f32, c->g_feat, c->Rg * 32, s));          // the backward's gradient maps are narrow
         return 0;
     }
     GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;
@@ -1202,24 +1250,25 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     RUN(ptta_launch_gemm(g, s));
     RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
     RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
-    GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = c->bf16 ? c->g_feat_f32 : (float*)c->g_feat; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;   // fp32 storage: straight into the gradient map (no copy launch)
+    GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = (c->bf16 || c->mixed) ? c->g_feat_f32 : (float*)c->g_feat; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;   // fp32 storage: straight into the gradient map (no copy launch)
     g2.pscale = c->bnb_gscale; g2.pmean = bn.mean; g2.pinv = bn.inv; g2.pc1 = c->bnb_c1; g2.pc2 = c->bnb_c2;
     g2.x3 = c->x3; g2.Whi = l0.Wthi; g2.Wlo = l0.Wtlo;
     RUN(ptta_launch_gemm(g2, s));
-    if (c->bf16) hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(c->Rg * 32)), dim3(256), 0, s, c->g_feat_f32, (bf16_t*)c->g_feat, c->Rg * 32);
+    if (c->bf16 || c->mixed) hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(c->Rg * 32)), dim3(256), 0, s, c->g_feat_f32, (bf16_t*)c->g_feat, c->Rg * 32);
     return 0;
 }
 
 // data gradients from d(depth_net) [Nn,1,Hp,Wp] and d(feat) down to conv1_rgb_meta, then its wgrad
 int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_aux) {
     const int Nn = c->Nn, B2 = 2 * Nn;
+    const int nbf = c->mixed ? 1 : c->bf16;            // gradient maps: narrow in the mixed mode (conv32() routes every bwd launch there itself)
     const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
     auto out1_args = [&](const std::string& layer, const float* g, const void* mask, void* out, int H, int W) {
         const LOut& lo = c->lout[layer];
         ConvInArgs a; a.cin = 1; a.pl[0].p = g; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H * W;
         a.wfrag = lo.bfrag; a.wcanon = lo.bcanon; a.mask = mask; a.mask_nb = B2; a.out_raw = out;
-        a.B = Nn; a.H = H; a.W = W; a.bf16 = c->bf16; a.naive = c->naive;
+        a.B = Nn; a.H = H; a.W = W; a.bf16 = c->mixed ? 1 : c->bf16; a.naive = c->naive;
         return a;
     };
     auto dgrad_out1 = [&](const std::string& layer, const float* g, const void* mask, void* out, int H, int W) -> int {
@@ -1234,7 +1283,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     auto dgrad_in_ch1 = [&](const std::string& layer, const void* g, const float* add, float* out, int H, int W) -> int {
         const LIn& li = c->lin_in[layer];
         ConvOut1Args a; a.in = g; a.in_nb = Nn; a.w = li.bw; a.add = add; a.add_nb = Nn; a.out = out;
-        a.B = Nn; a.H = H; a.W = W; a.relu_in = 0; a.bf16 = c->bf16;
+        a.B = Nn; a.H = H; a.W = W; a.relu_in = 0; a.bf16 = c->mixed ? 1 : c->bf16;
         return conv_out1_p(c, a, s);
     };
     auto em = [](void* raw, const void* mask, int mask_nb) { E e; e.raw = raw; e.mask = mask; e.mask_nb = mask_nb; return e; };
@@ -1247,7 +1296,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     { E e; e.raw = c->dw2; e.mask = c->w2; e.mask_nb = B2; e.sum = c->dfeat_tot; e.add1 = c->g_feat; e.add1_nb = Nn;
       CV("depth_decoder3.dec2.1", true, CONV_S2, c->dt3, Nn, Nn, H2, W2, false, e); }
     // ---- encoder 3 ----
-    REST_(s, ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, c->bf16, s));
+    REST_(s, ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, nbf, s));
     CV("depth_encoder3.enc2.3", true, CONV_S1, c->dfeat_tot, Nn, Nn, H4, W4, false, em(c->de3_2a, c->e3_2a, B2));
     { E e; e.sum = c->de3_1; e.mask = c->e3_1; e.mask_nb = B2; e.add1 = c->ds1_3; e.add1_nb = Nn;
       CV("depth_encoder3.enc2.1", true, CONV_T2, c->de3_2a, Nn, Nn, H4, W4, false, e); }
@@ -1259,10 +1308,10 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     REST_(s, ptta_launch_up2T_1ch(c->dp11, c->dq, Nn, H2, W2, s));                              // d(out2 + p12)
     // ---- decoder 2 ----
     RUN(head_bwd("depth_decoder2.prdct.3", "depth_decoder2.prdct.1", c->dq, c->v2, c->dv2, H2, W2, em(c->ds0_2, c->s0_2, B2)));
-    REST_(s, ptta_launch_up2T_32(c->de3_0, c->ds0_2, c->dz4, Nn, H2, W2, c->bf16, s));         // d z4 = d s0_2 + up2^T(d e3_0)
+    REST_(s, ptta_launch_up2T_32(c->de3_0, c->ds0_2, c->dz4, Nn, H2, W2, nbf, s));         // d z4 = d s0_2 + up2^T(d e3_0)
     CV("depth_decoder2.dec1.3", true, CONV_S1, c->dz4, Nn, Nn, H2, W2, false, em(c->du2, c->u2, B2));
     CV("depth_decoder2.dec1.1", true, CONV_S2, c->du2, Nn, Nn, H2, W2, false, em(c->ds1_2, c->s1_2, B2));
-    REST_(s, ptta_launch_up2T_32(c->de3_1, c->ds1_2, c->dz3, Nn, H4, W4, c->bf16, s));         // d z3 = d s1_2 + up2^T(d e3_1)
+    REST_(s, ptta_launch_up2T_32(c->de3_1, c->ds1_2, c->dz3, Nn, H4, W4, nbf, s));         // d z3 = d s1_2 + up2^T(d e3_1)
     CV("depth_decoder2.dec2.3", true, CONV_S1, c->dz3, Nn, Nn, H4, W4, false, em(c->dt2, c->t2, B2));
     { E e; e.sum = c->dz2; e.mask = c->z2; e.mask_nb = B2; e.add1 = c->dz2_up; e.add1_nb = Nn;
       CV("depth_decoder2.dec2.1", true, CONV_S2, c->dt2, Nn, Nn, H4, W4, false, e); }
@@ -1282,11 +1331,13 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
       CV("depth_decoder1.prdct.1", true, CONV_S1, c->dv1, Nn, Nn, H4, W4, false, e); }
 #undef CV
     // ---- weight gradient of the meta layer: input = c2 of the real frames ----
+    // (mixed mode: the weight-gradient kernels take fp32 operands -- the 1/4-resolution gradient map is widened once, 3.4 MB)
+    if (c->mixed) RUN(to_wide(c, c->dm_total, c->dm_f32, (long)Nn * H4 * W4 * 32, s));
     if (c->meta_mode == PTTA_META_2LAYERS) return meta2_backward(c, s);
     if (!c->bf16 && c->x3 && !c->naive) {
         // default arithmetic: the bf16x3 reduction-GEMM form (gconv_mfma.hip gwgrad_x3_kernel, single-pair mode)
         GView xv; xv.p = (float*)c->c2; xv.B = Nn; xv.H = H4; xv.W = W4; xv.C = 32; xv.ld = 32;
-        GView gv; gv.p = (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
+        GView gv; gv.p = c->mixed ? c->dm_f32 : (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
         REST_(s, ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s));
         return 0;
     }
@@ -1304,7 +1355,6 @@ int push_hparams(ptta_ctx* c, hipStream_t s) {
 int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool train, hipStream_t s) {
     for (auto& ad : c->adapted) if (!ad.p) return c->fail("adapted parameter " + ad.name + " not bound (ptta_bind_adapted)", -3);
     const float* img = image; const float* sp = sparse;
-    if (train && c->fwd_phase >= 2) return backbone(c, img, train, s);          // (phases R / P of the four-graph step: never with padding)
     if (c->dual) {
         hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * 3 * c->Hp * c->Wp)), dim3(256), 0, s, image, c->img_pad, c->N, 3, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr, c->img_norm);
         hipLaunchKernelGGL(pad_dual_kernel, dim3(nblk((long)c->Nn * c->Hp * c->Wp)), dim3(256), 0, s, sparse, c->sp_pad, c->N, 1, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
@@ -1377,30 +1427,33 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
         return 0;
     }
     if (backbone_id != PTTA_BACKBONE_MSG_CHN || (meta_mode != PTTA_META_1LAYER && meta_mode != PTTA_META_2LAYERS)) return -38;
-    if (n < 1 || height < 16 || width < 16 || (dtype != PTTA_DTYPE_F32 && dtype != PTTA_DTYPE_BF16) || !hp) return -22;
+    if (n < 1 || height < 16 || width < 16 || (dtype != PTTA_DTYPE_F32 && dtype != PTTA_DTYPE_MIXED) || !hp) return -22;
     ptta_ctx* c = new ptta_ctx();
     c->meta_mode = meta_mode;
     c->N = n; c->H = height; c->W = width; c->pt = pad16(height); c->pr = pad16(width);
     c->Hp = height + c->pt; c->Wp = width + c->pr; c->dual = (c->pt || c->pr) ? 1 : 0; c->Nn = c->dual ? 2 * n : n;
-    c->bf16 = dtype == PTTA_DTYPE_BF16; c->es = c->bf16 ? 2 : 4;
+    c->mixed = dtype == PTTA_DTYPE_MIXED ? 1 : 0;
     const char* impl = getenv("PTTA_CONV_IMPL");
     c->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
     const char* gr = getenv("PTTA_GRAPH");
     c->use_graph = (gr && strcmp(gr, "0") == 0) ? 0 : 1;
     const char* ax = getenv("PTTA_AUX_STREAM");
     c->use_aux = (ax && strcmp(ax, "0") == 0) ? 0 : 1;
-    { const char* sf = getenv("PTTA_SPLIT_FWD"); c->split_fwd = sf ? atoi(sf) : 0; }
     { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
     { const char* hv = getenv("PTTA_HEADS_V2"); c->heads_v2 = (hv && strcmp(hv, "0") == 0) ? 0 : 1; }
     { const char* ff = getenv("PTTA_FUSE_FIRST"); c->fuse_first = ff ? atoi(ff) : 1; }
     { const char* mb = getenv("PTTA_MASK_BITS"); c->mask_bits_on = (mb && strcmp(mb, "0") == 0) ? 0 : 1; }
     { const char* th = getenv("PTTA_THRU"); c->thru = (th && strcmp(th, "0") == 0) ? 0 : 1; }
     { const char* cg = getenv("PTTA_COS_IN_GEMM"); c->cos_grad_fused = (cg && strcmp(cg, "0") == 0) ? 0 : 1; }
-    { const char* du = getenv("PTTA_DUAL"); c->dual_on = (du && strcmp(du, "1") == 0) ? 1 : 0; }      // measured neutral: off by default      // 1: the depth encoders' init blocks, 2: the RGB encoder's too
     { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
       if (c->ablate) fprintf(stderr, "libptta_hip: PTTA_ABLATE=%d -- TIMING ABLATION: launches are skipped, every result of this handle is GARBAGE\n", c->ablate); }
     const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
     c->x3 = (arith && strcmp(arith, "exact") == 0) ? 0 : 1;
+    if (c->mixed) {
+        // the mixed mode is defined on the matrix-core kernels with sign-bit masks; the validation arithmetic modes belong to PTTA_DTYPE_F32
+        if (c->naive || !c->x3) { delete c; return -38; }
+        c->mask_bits_on = 1;
+    }
     c->hp = *hp;
     build_registry(c);
     build_workspace(c);
@@ -1421,7 +1474,6 @@ void ptta_destroy(ptta_handle h) {
         (void)hipStreamDestroy(h->pre_stream); (void)hipEventDestroy(h->ev_entry);
         for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(h->ev_prefix[p]); (void)hipEventDestroy(h->ev_rest[p]); }
     }
-    if (h->dual_stream) { (void)hipStreamDestroy(h->dual_stream); (void)hipEventDestroy(h->ev_dA); (void)hipEventDestroy(h->ev_dP); }
     if (h->ev_dpart) (void)hipEventDestroy(h->ev_dpart);
     if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_real); }
     for (void* p : h->allocs) if (p) (void)hipFree(p);
@@ -1703,7 +1755,7 @@ int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref,
             HIPCHK(hipEventRecord(c->ev_join, s2));
             join_aux = true;
         } else RUN(heads_backward(c, grad_ref, s));
-    } else HIPCHK(hipMemsetAsync(c->g_feat, 0, (size_t)c->Rg * 32 * c->es, s));
+    } else HIPCHK(hipMemsetAsync(c->g_feat, 0, (size_t)c->Rg * 32 * (c->mixed ? 2 : c->es), s));
     RUN(backbone_backward(c, g_net, s, join_aux));
     if (c->meta_mode == PTTA_META_1LAYER) {
         if (gw_out) HIPCHK(hipMemcpyAsync(gw_out, c->gW, 9216 * 4, hipMemcpyDeviceToDevice, s));
@@ -1747,29 +1799,22 @@ int ptta_adam_step(ptta_handle c, const float* gw, const float* gb, ptta_stream 
     return 0;
 }
 
-static int step_tail(ptta_handle c, const float* loss_image, const float* sparse, const float* validity, ptta_stream s_, bool passes_were_split);
+static int step_tail(ptta_handle c, const float* loss_image, const float* sparse, const float* validity, ptta_stream s_);
 static bool thru_ok(ptta_ctx* c, hipStream_t s) {
-    return c->thru && c->cos_grad_fused && heads_v2_on(c) && c->N <= 16 && c->fwd_phase == 0 && !(c->split_fwd & 1) && c->aux(s) != nullptr;
+    return c->thru && c->cos_grad_fused && heads_v2_on(c) && c->N <= 16 && c->aux(s) != nullptr;
 }
 static int step_body(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
                      ptta_stream s_) {
     c->thru_active = thru_ok(c, (hipStream_t)s_);
     const int rc = ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_);
     if (rc) { c->thru_active = false; return rc; }
-    const int rc2 = step_tail(c, loss_image, sparse, validity, s_, false);
+    const int rc2 = step_tail(c, loss_image, sparse, validity, s_);
     c->thru_active = false;
     return rc2;
 }
 // loss + backward + (gradient all-reduce) + Adam: everything of the step behind the forward
-static int step_tail(ptta_handle c, const float* loss_image, const float* sparse, const float* validity, ptta_stream s_, bool passes_were_split) {
+static int step_tail(ptta_handle c, const float* loss_image, const float* sparse, const float* validity, ptta_stream s_) {
     hipStream_t s = (hipStream_t)s_;
-    if (passes_were_split) {
-        // the two forward passes ran side by side and left proj.1's running statistics alone: both momentum updates now, proxy pass first
-        // (proj(feat_zero) precedes proj(feat) in the reference, network_exp_msg_chn_adapt.py:551-554)
-        BNorm& b1 = c->bn["proj.1"];
-        const int nbm = ptta_gemm_row_blocks((int)c->Rg);
-        REST_(s, ptta_launch_bn_running2(c->hm_part + (size_t)nbm * 2 * 512, c->hm_part, nbm, (int)c->Rg, 512, 0.1f, b1.rm, b1.rv, b1.nbt, s));
-    }
     if (c->thru_active) {
         hipStream_t s2 = c->aux(s);
         if (!c->ev_dpart) HIPCHK(hipEventCreateWithFlags(&c->ev_dpart, hipEventDisableTiming));
@@ -1833,11 +1878,7 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
         if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
         if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
         RUN(ensure_fused_heads(c, s));
-        if (dual_ok(c)) {
-            RUN(ensure_proxy_rgb(c, c->in_image, s));
-            RUN(ensure_adam_table(c, s));
-            RUN(dual_step(c, key, c->cur_set, false, s));
-        } else {
+        {
         if (!c->gexec[key]) {
             RUN(ensure_proxy_rgb(c, c->in_image, s));        // outside the capture: the graph holds the real-frame encoder only
             RUN(ensure_adam_table(c, s));
@@ -1904,6 +1945,16 @@ static int pipe_init(ptta_ctx* c) {
     Q.dclamp = c->falloc((size_t)Nn * H1 * W1); Q.d12 = c->falloc((size_t)Nn * c->H2 * c->W2); Q.d14 = c->falloc((size_t)Nn * c->H4 * c->W4);
     Q.in_image = c->falloc((size_t)c->N * 3 * c->H * c->W); Q.in_loss_image = c->falloc((size_t)c->N * 3 * c->H * c->W);
     Q.in_sparse = c->falloc((size_t)c->N * c->H * c->W); Q.in_validity = c->falloc((size_t)c->N * c->H * c->W);
+    if (c->mixed) {      // narrow twins of the second set's prefix outputs (proxy frames) and of its depth-only maps
+        for (auto& t_ : {std::make_pair(Q.c1, std::make_pair(c->H2, c->W2)), std::make_pair(Q.c2, std::make_pair(c->H4, c->W4)),
+                         std::make_pair(Q.c3, std::make_pair(c->H8, c->W8)), std::make_pair(Q.c4, std::make_pair(c->H16, c->W16)),
+                         std::make_pair(Q.y1, std::make_pair(c->H8, c->W8)), std::make_pair(Q.y2, std::make_pair(c->H16, c->W16)),
+                         std::make_pair(Q.t1, std::make_pair(c->H8, c->W8)), std::make_pair(Q.y3, std::make_pair(c->H8, c->W8)),
+                         std::make_pair(Q.s1_1, std::make_pair(c->H8, c->W8)), std::make_pair(Q.u1, std::make_pair(c->H4, c->W4)),
+                         std::make_pair(Q.e1_0, std::make_pair(c->H4, c->W4)), std::make_pair(Q.e1_1a, std::make_pair(c->H8, c->W8)),
+                         std::make_pair(Q.e1_2a, std::make_pair(c->H16, c->W16))})
+            c->twin_alloc(t_.first, Nn, t_.second.first, t_.second.second);
+    }
     if (c->oom) return c->fail("out of device memory (second prefix buffer set)", -12);
     HIPCHK(hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking));
     for (int p = 0; p < 2; ++p) {
@@ -1931,45 +1982,6 @@ static int prefix_body(ptta_ctx* c, const float* image, const float* sparse, hip
 }
 template <class F>
 static int pipe_capture(ptta_ctx* c, hipGraph_t* g_out, hipGraphExec_t* e_out, F body);
-static bool dual_ok(const ptta_ctx* c) {
-    return c->dual_on && c->use_graph && !c->prof_on && !c->dual && !c->stat_sync.on() && !c->grad_comm && !c->naive && !c->bf16 && !c->split_fwd &&
-           !c->ablate && heads_v2_on(c);
-}
-// One step as four graphs on two streams (ptta_ctx::dual_on): A on `s`, then R on `s` beside P on the handle's second stream, then L on `s`.
-// The inputs are already staged at the fixed addresses of buffer set `set` (the members point at it); prefix_done: the parameter-independent
-// prefix of this frame was computed ahead (ptta_step_pipelined).
-static int dual_step(ptta_ctx* c, int key, int set, bool prefix_done, hipStream_t s) {
-    if (!c->dual_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&c->dual_stream, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_dA, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_dP, hipEventDisableTiming));
-    }
-    ptta_ctx::DualG& A = c->dgA[prefix_done ? 1 : 0][set]; ptta_ctx::DualG& R = c->dgR[set]; ptta_ctx::DualG& P = c->dgP[set]; ptta_ctx::DualG& L = c->dgL[key][set];
-    const bool sp0 = c->skip_prefix;
-    auto fwd = [&](int phase, ptta_ctx::DualG& d) -> int {
-        if (d.e) return 0;
-        c->fwd_phase = phase; c->skip_prefix = prefix_done;
-        const int rc = pipe_capture(c, &d.g, &d.e, [&](hipStream_t cs) { return forward_common(c, c->in_image, c->in_sparse, true, cs); });
-        c->fwd_phase = 0; c->skip_prefix = sp0;
-        return rc;
-    };
-    RUN(fwd(1, A)); RUN(fwd(2, R)); RUN(fwd(3, P));
-    if (!L.e) {
-        c->fwd_valid = true;
-        RUN(pipe_capture(c, &L.g, &L.e, [&](hipStream_t cs) {
-            return step_tail(c, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse, (key & 2) ? c->in_validity : nullptr, (ptta_stream)cs, true);
-        }));
-    }
-    HIPCHK(hipGraphLaunch(A.e, s));
-    HIPCHK(hipEventRecord(c->ev_dA, s));
-    HIPCHK(hipStreamWaitEvent(c->dual_stream, c->ev_dA, 0));
-    HIPCHK(hipGraphLaunch(P.e, c->dual_stream));
-    HIPCHK(hipEventRecord(c->ev_dP, c->dual_stream));
-    HIPCHK(hipGraphLaunch(R.e, s));
-    HIPCHK(hipStreamWaitEvent(s, c->ev_dP, 0));
-    HIPCHK(hipGraphLaunch(L.e, s));
-    return 0;
-}
 template <class F>
 static int pipe_capture(ptta_ctx* c, hipGraph_t* g_out, hipGraphExec_t* e_out, F body) {
     if (!c->cap_stream) HIPCHK(hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
@@ -2006,7 +2018,7 @@ int ptta_pipeline_stream(ptta_handle c, ptta_stream* out) {
 int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity, uint64_t frame_token,
                         const float* next_image, const float* next_sparse, uint64_t next_token, float* depth_out, float* loss_info_out, ptta_stream s_) {
     if (!c || !image || !sparse) return -1;
-    if (c->nl || !c->use_graph || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16 || c->split_fwd) {
+    if (c->nl || !c->use_graph || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16) {
         const int rc = ptta_step(c, image, loss_image, sparse, validity, depth_out, loss_info_out, s_);
         if (!c->nl) { c->fb_image = rc ? nullptr : image; c->fb_sparse = rc ? nullptr : sparse; }       // for ptta_forward_eval_last
         return rc;
@@ -2036,8 +2048,7 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     P.prepared = false; P.prep_token = 0;
     if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
     if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
-    if (dual_ok(c)) RUN(dual_step(c, key, p, true, s));
-    else {
+    {
     if (!c->rexec[key][p]) {
         c->skip_prefix = true;
         const int rc = pipe_capture(c, &c->rgraph[key][p], &c->rexec[key][p], [&](hipStream_t cs) {
@@ -2445,7 +2456,7 @@ int ptta_debug_tensor(ptta_handle c, const char* name, float* dst, int64_t capac
     if (capacity < it->second.numel) return c->fail("capacity too small", -22);
     hipStream_t s = (hipStream_t)s_;
     const long n = it->second.numel;
-    if (it->second.is_act && c->bf16) hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(nblk(n)), dim3(256), 0, s, (const bf16_t*)it->second.p, dst, n);
+    if ((it->second.is_act == 1 && c->bf16) || it->second.is_act == 2) hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(nblk(n)), dim3(256), 0, s, (const bf16_t*)it->second.p, dst, n);
     else HIPCHK(hipMemcpyAsync(dst, it->second.p, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }
@@ -2466,7 +2477,7 @@ int ptta_op_conv32(const float* in, const float* weight, const float* bias, floa
     if (rc == 0) {
         ptta_pack_conv32(weight, w, in_major, flip, s);
         Conv32Args a; a.w = &w; a.bias = bias; a.B = b; a.Hin = hin; a.Win = win; a.mode = mode; a.relu_in = relu_in; a.naive = naive & 1; a.x3 = (naive >> 1) & 1;
-        if (dtype == PTTA_DTYPE_BF16) {
+        if (dtype != PTTA_DTYPE_F32) {             // narrow storage (bf16 maps, one MFMA per product): the kernels of the mixed mode
             hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(nin)), dim3(256), 0, s, in, (bf16_t*)tin, nin);
             a.in = tin; a.in_nb = b; a.out_raw = tout; a.bf16 = 1;
             rc = ptta_launch_conv32(a, s);

@@ -32,6 +32,18 @@ template <typename T> __device__ __forceinline__ void st(T* p, float v);
 template <> __device__ __forceinline__ void st<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void st<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// four bf16 <-> four floats (8-byte pieces of a narrow NHWC pixel); v_cvt_pk_bf16_f32 rounds to nearest even and keeps a NaN a NaN
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
+typedef float cfloat2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf2(float a, float b) {
+    cfloat2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, cbf16x2));
+}
+__device__ __forceinline__ float4 bf4_to_f4(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint2 f4_to_bf4(float4 v) { return make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); }
+
 // ---- bilinear x2, align_corners=True (F.interpolate, network_exp_msg_chn_adapt.py:200-209) ----
 // PyTorch's upsample_bilinear2d: src = dst * (in-1)/(out-1); i0 = (int)src; i1 = i0 + (i0 < in-1);
 // l1 = src - i0; l0 = 1 - l1.
@@ -148,7 +160,8 @@ __device__ __forceinline__ void quad_transpose(f32x16& t, int lane) {
 template <typename T, bool UP, bool MASK, bool ADD, bool UPL = false, int UPLW = 18>
 __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, int W, int ch, const f32x16& acc,
                                          int x0, int h, int Wt, int xstep, int xoff, float sy, float sx,
-                                         const float* upw = nullptr, int uy0 = 0, int ux0 = 0) {
+                                         const void* upw_ = nullptr, int uy0 = 0, int ux0 = 0) {
+    const float* upw = (const float*)upw_;                // fp32 storage: the bilinear window holds floats; narrow storage casts upw_ to bf16 below
     const float* bp = e.bias ? e.bias : kZeroBias;       // pointer select, not a branch around the load
     const float bias = bp[ch];
     float v[16];
@@ -262,6 +275,80 @@ __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, i
                 const uint32_t word = mask_word_from_quads(bs.x, bs.y, bs.z, bs.w, ch, h);
                 if (ch < 4 && okg[g]) obits[xq[g] >> 5] = word;
             }
+        }
+        return;
+    }
+    if constexpr (sizeof(T) == 2) {
+        // narrow (bf16) storage, the mixed mode's proxy-pass and gradient maps: the same transposed layout, 8 B per lane (four consecutive
+        // channels of one pixel), eight pixels x 64 contiguous bytes per instruction.  ReLU masks come as sign-bit words only (they are
+        // planes of the REAL frames' fp32 maps: the launchers refuse a narrow launch whose mask has no bit plane); skip additions are narrow
+        // maps; arithmetic in fp32, one rounding per stored value.
+        f32x16 t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = v[r];
+        quad_transpose(t, ch + 32 * h);
+        const int j4 = (ch >> 2) * 4;
+        bool okg[4];
+        size_t xq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int px = x0 + (ch & 3) + 8 * g + 4 * h;
+            okg[g] = px < Wt;
+            xq[g] = ((size_t)((okg[g] ? px : Wt - 1) * xstep + xoff) + rowoff) * 32 + j4;
+        }
+        if constexpr (UPL) {
+            const bf16_t* upb = (const bf16_t*)upw_;
+            const Lerp ly = lerp_coef(y, H >> 1, sy);
+            const bf16_t* r0 = upb + (ly.i0 - uy0) * UPLW * 32 + j4;
+            const bf16_t* r1 = upb + (ly.i1 - uy0) * UPLW * 32 + j4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int px = min(x0 + (ch & 3) + 8 * g + 4 * h, W - 1);
+                const Lerp lx = lerp_coef(px, W >> 1, sx);
+                const int c0 = (lx.i0 - ux0) * 32, c1 = (lx.i1 - ux0) * 32;
+                const float4 v00 = bf4_to_f4(*(const uint2*)(r0 + c0)), v01 = bf4_to_f4(*(const uint2*)(r0 + c1));
+                const float4 v10 = bf4_to_f4(*(const uint2*)(r1 + c0)), v11 = bf4_to_f4(*(const uint2*)(r1 + c1));
+                t[4 * g] = t[4 * g] + (ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x));
+                t[4 * g + 1] = t[4 * g + 1] + (ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y));
+                t[4 * g + 2] = t[4 * g + 2] + (ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z));
+                t[4 * g + 3] = t[4 * g + 3] + (ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w));
+            }
+        }
+        uint32_t mw[4];
+        uint2 t1[4], t2[4];
+        if (MASK) {
+            const uint32_t* mb = e.mask_bits + (size_t)(b % e.mask_nb) * H * W;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mw[g] = mb[xq[g] >> 5];
+        }
+        const bool two = ADD && e.add2 != nullptr;
+        if (ADD) {
+            const bf16_t* a1 = (const bf16_t*)e.add1 + (size_t)(b % e.add1_nb) * H * W * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t1[g] = *(const uint2*)(a1 + xq[g]);
+            if (two) {
+                const bf16_t* a2 = (const bf16_t*)e.add2 + (size_t)(b % e.add2_nb) * H * W * 32;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) t2[g] = *(const uint2*)(a2 + xq[g]);
+            }
+        }
+        bf16_t* const oraw = (bf16_t*)e.out_raw + (size_t)b * H * W * 32;
+        bf16_t* const osum = (bf16_t*)e.out_sum + (size_t)b * H * W * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 val = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+            if (MASK) {
+                const uint32_t nib = mw[g] >> j4;
+                val.x = (nib & 1u) ? val.x : 0.0f; val.y = (nib & 2u) ? val.y : 0.0f;
+                val.z = (nib & 4u) ? val.z : 0.0f; val.w = (nib & 8u) ? val.w : 0.0f;
+            }
+            if (e.out_raw && okg[g]) *(uint2*)(oraw + xq[g]) = f4_to_bf4(val);
+            if (ADD) {
+                float4 a = bf4_to_f4(t1[g]);
+                if (two) { const float4 a2 = bf4_to_f4(t2[g]); a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; }
+                val.x += a.x; val.y += a.y; val.z += a.z; val.w += a.w;
+            }
+            if (e.out_sum && okg[g]) *(uint2*)(osum + xq[g]) = f4_to_bf4(val);
         }
         return;
     }

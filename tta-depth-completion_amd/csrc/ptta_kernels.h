@@ -47,6 +47,7 @@ struct ConvInArgs {      // planar fp32 (cin = 1..3) -> 32-channel NHWC
     int B = 1, H = 0, W = 0; int bf16 = 0; int naive = 0;
     // fused first-kernel forms only (ptta_launch_conv32_first): sign bits of `mask` / bits of the a_out map
     const uint32_t* mask_bits = nullptr; uint32_t* a_bits = nullptr;
+    int a_bits_nb = 0;              // unfused launch (fp32 output): also write the sign-bit plane `a_bits` of out_raw for frames b < a_bits_nb
 };
 void ptta_pack_conv_in(const float* src, int cin_total, int cin_first, int cin, int transpose_flip,
                        float* wfrag, float* wcanon, hipStream_t s);

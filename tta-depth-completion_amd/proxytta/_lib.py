@@ -24,7 +24,7 @@ PTTA_SYNCBN_ADAPT = 0x200
 PTTA_META_1LAYER = 0
 PTTA_META_2LAYERS = 1
 PTTA_DTYPE_F32 = 0
-PTTA_DTYPE_BF16 = 1
+PTTA_DTYPE_MIXED = 1
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
 
 

@@ -68,7 +68,10 @@ class Engine:
         self.hp = Hparams(lr, betas[0], betas[1], eps, weight_decay, w_sparse_depth, w_smoothness,
                           w_cos, -1.0 if max_input_depth is None else float(max_input_depth), float(max_predict_depth or 0.0))
         self.handle = c_void_p()
-        code = {'fp32': _lib.PTTA_DTYPE_F32, 'bf16': _lib.PTTA_DTYPE_BF16}[dtype]
+        if dtype not in ('fp32', 'mixed'):
+            raise ValueError("dtype must be 'fp32' (fp32 maps, bf16x3 products) or 'mixed' (fp32 / bf16x3 for the real frames' forward, narrow "
+                             "bf16 maps and single-MFMA products for the no_grad proxy pass and the backward: include/ptta.h PTTA_DTYPE_MIXED)")
+        code = {'fp32': _lib.PTTA_DTYPE_F32, 'mixed': _lib.PTTA_DTYPE_MIXED}[dtype]
         rc = self.lib.ptta_create(byref(self.handle),
                                   {'nlspn': _lib.PTTA_BACKBONE_NLSPN, 'costdcnet': _lib.PTTA_BACKBONE_COSTDCNET}.get(backbone, _lib.PTTA_BACKBONE_MSG_CHN),
                                   (_lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER) |
@@ -425,7 +428,7 @@ def op_conv32(x_nhwc, weight, bias, mode, relu_in=False, in_major=False, flip=Fa
     ho, wo = {0: (h, w), 1: (h // 2, w // 2), 2: (2 * h, 2 * w)}[mode]
     out = torch.empty((b, ho, wo, 32), device=x_nhwc.device, dtype=torch.float32)
     rc = lib.ptta_op_conv32(ptr(x_nhwc.contiguous()), ptr(weight.contiguous()), ptr(bias), ptr(out), b, h, w, mode,
-                            int(relu_in), int(in_major), int(flip), 1 if dtype == 'bf16' else 0, int(bool(naive)) | (2 if x3 else 0), _stream())
+                            int(relu_in), int(in_major), int(flip), 0 if dtype == 'fp32' else 1, int(bool(naive)) | (2 if x3 else 0), _stream())
     if rc != 0:
         raise RuntimeError('ptta_op_conv32 failed (%d)' % rc)
     return out

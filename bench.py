@@ -50,6 +50,11 @@ MFMA_F32_PEAK = 157.3e12   # fp32 matrix peak
 MFMA_BF16_PEAK = 2.5e15    # dense bf16
 HP = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0,
           w_cos=0.1, max_input_depth=80.0)
+DTYPE_TEXT = {
+    'fp32': 'f32 storage, bf16x3 MFMA arithmetic (fp32 accumulate)',
+    'mixed': ('mixed: real frames\' forward (the scored depth) f32 storage + bf16x3 MFMA arithmetic; no_grad proxy pass and all data gradients bf16 '
+              'storage + single bf16 MFMA; fp32 accumulate everywhere; loss / Adam / adapted parameters fp32 (include/ptta.h PTTA_DTYPE_MIXED)'),
+}
 
 
 def cpu_model_string():
@@ -681,7 +686,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'bf16'])
+    ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'mixed'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-block', action='store_true', help='time ONE block of --steps steps (quick A/B runs) instead of >= 10 blocks / >= 200 steps')
     ap.add_argument('--no-self-check', action='store_true', help='skip the pipelined-vs-plain bitwise replay on fresh handles')
@@ -843,18 +848,15 @@ def main():
         eq_plain = pipelined_self_check(args.dtype, min(args.steps, 12), rank)
 
     if rank == 0:
-        es = 4 if args.dtype == 'fp32' else 2
+        es = 4
+        mixed = args.dtype == 'mixed'
         steps_per_s = world * args.steps / elapsed
-        if args.dtype == 'fp32':
+        if True:
             # fp32 storage, bf16x3 arithmetic: 3 x 2 x MACs bf16 FLOP against 256 B of fp32 I/O per pixel
             # -> arithmetic intensity 3*18432*... = 216 FLOP/B < ridge 312: HBM is the roof
             achieved = abytes / (ms * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': achieved / (HBM_PEAK / 1e9), 'mfma_bf16_tflops': 3 * 2.0 * macs / (ms * 1e-3) / 1e12}
-        else:
-            achieved = abytes / (ms * 1e-3) / 1e9
-            roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': achieved / (HBM_PEAK / 1e9)}
         roof.update({'kernel': ('stride-1 3x3 32->32 convolutions with ReLU on load: conv32_s1_x3_kernel<true, *> (large maps) + conv32_s1_small_kernel<true, *> '
                                 '(maps of <= 256 tiles)' if es == 4 else 'conv32_mfma_kernel<bf16, CONV_S1, relu, *>'),
                      'measured': 'hipEvents around each launch, same K steps re-run without the graph (%.3f ms/step)' % instrumented_ms,
@@ -875,10 +877,20 @@ def main():
                               'mfma_bf16x3_frac': (3 * 2.0 * cmc / (cms * 1e-3) / MFMA_BF16_PEAK) if cms > 0 else None}
         by_class['_note'] = ('hipEvent leg (kernel by kernel, one stream, every launch bracketed): us_per_step sums the bracketed launches of the class; '
                              'algorithmic bytes by SURVEY 8d (0 for rest); heads priced as the 6 + 2 linear layers the reference executes')
+        stored = sum(v['alg_bytes_per_step'] for k, v in by_class.items() if isinstance(v, dict))
+        if mixed:
+            # bytes at the width each tensor is STORED at, as the launches of the instrumented leg counted them (SURVEY 8d rule per layer)
+            step_bytes = stored
+            step_note = ('alg_bytes_per_step = sum over the step\'s launches of (input + output + weight elements) x the STORED element size of each '
+                         '(fp32 for the real frames\' forward maps, bf16 for the proxy pass and the gradient maps): a narrower tensor lowers the numerator, '
+                         'the fraction cannot inflate; the constant zero-image RGB-encoder pass is hoisted out of the step')
+        else:
+            step_bytes = (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * 4
+            step_note = 'alg_bytes_per_step excludes the constant zero-image RGB-encoder pass, hoisted out of the step'
         out = {
             'metric': 'TTA frames/sec (fwd+loss+bwd+Adam) at 352x1216', 'value': steps_per_s, 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 storage, bf16x3 MFMA arithmetic (fp32 accumulate)' if es == 4 else 'bf16',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE_TEXT[args.dtype],
             'data': 'synthetic',
             'config': {'workload': 'MSG_CHN 1layer meta, 352x1216 KITTI-shaped synthetic, 1 TTA step/frame, batch 1 per GPU',
                        'parallelism': 'independent frame streams, dp%d, no collectives' % world, 'finite': finite,
@@ -891,11 +903,14 @@ def main():
                        'pipelined_equals_plain': eq_plain,
                        'rccl_ranks': world if (dist is not None and dist.get_backend() == 'nccl') else (0 if dist is None else None),
                        'collective_backend': None if dist is None else dist.get_backend()},
-            'step_roofline': {'alg_bytes_per_step': (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * es, 'alg_flop_per_step': ALG_FLOP_PER_STEP,
-                              'alg_bytes_reference_executes': ALG_ELEMENTS_PER_STEP * es,
-                              'note': 'alg_bytes_per_step excludes the constant zero-image RGB-encoder pass, hoisted out of the step',
-                              'hbm_frac_per_gpu': (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * es * (steps_per_s / world) / HBM_PEAK,
-                              'mfma_frac_per_gpu': (3 if es == 4 else 1) * ALG_FLOP_PER_STEP * (steps_per_s / world) / MFMA_BF16_PEAK},
+            'step_roofline': {'alg_bytes_per_step': step_bytes, 'alg_flop_per_step': ALG_FLOP_PER_STEP,
+                              'alg_bytes_reference_executes': ALG_ELEMENTS_PER_STEP * 4,
+                              'alg_bytes_fp32_storage': (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * 4,
+                              'alg_bytes_bf16_storage': (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * 2,
+                              'note': step_note,
+                              'hbm_frac_per_gpu': step_bytes * (steps_per_s / world) / HBM_PEAK,
+                              'hbm_frac_per_gpu_on_bf16_bytes': (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * 2 * (steps_per_s / world) / HBM_PEAK,
+                              'mfma_frac_per_gpu': 3 * ALG_FLOP_PER_STEP * (steps_per_s / world) / MFMA_BF16_PEAK},
             'roofline': roof,
             'roofline_by_class': by_class,
             'timing': {'protocol': '%d blocks x %d steps, each block bracketed by barrier + synchronize, MAX over ranks; ms_per_step = median block' % (nblocks, args.steps),

@@ -913,7 +913,7 @@ int ptta_launch_head_moments(const float* X, long R, int npass, const float* W0,
 // itself (32 x 32 x 512 on v_mfma_f64_16x16x4_f64, the 512 hidden units split over the 8 waves, fixed-order reduction through LDS:
 // identical in every block) and applies them to its rows.
 __global__ __launch_bounds__(512) void head_bwd_finish_kernel(const double* __restrict__ k12, const float* __restrict__ W0, const float* __restrict__ P,
-                                                              const float* __restrict__ X, long R, float* __restrict__ dX) {
+                                                              const float* __restrict__ X, long R, void* __restrict__ dX_, int halves, int dX_bf16) {
     __shared__ double Mw[8][32][32];
     __shared__ double uw[8][32];
     __shared__ float Ms[32][33];
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(512) void head_bwd_finish_kernel(const double* __re
         const long row = base + 16 * ps + (t >> 5);
         const long rr = row < R ? row : R - 1;
         xv[ps] = X[rr * 32 + ch];
-        pv[ps] = P[rr * 32 + ch] + P[(R + rr) * 32 + ch];
+        pv[ps] = halves == 2 ? P[rr * 32 + ch] + P[(R + rr) * 32 + ch] : P[rr * 32 + ch];
     }
     d4_t m00 = {0, 0, 0, 0}, m01 = m00, m10 = m00, m11 = m00;
     double u0 = 0.0, u1 = 0.0;
@@ -971,11 +971,14 @@ __global__ __launch_bounds__(512) void head_bwd_finish_kernel(const double* __re
         float acc = 0.f;
 #pragma unroll
         for (int a = 0; a < 32; ++a) acc = fmaf(__shfl(xv[ps], (lane & 32) + a, 64), mc[a], acc);
-        if (row < R) dX[row * 32 + ch] = pv[ps] - acc - uc;
+        if (row < R) {
+            if (dX_bf16) ((bf16_t*)dX_)[row * 32 + ch] = f2bf(pv[ps] - acc - uc);
+            else ((float*)dX_)[row * 32 + ch] = pv[ps] - acc - uc;
+        }
     }
 }
-int ptta_launch_head_bwd_finish(const double* k12, const float* W0, const float* P, const float* X, long R, float* dX, hipStream_t s) {
-    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3((int)((R + 127) / 128)), dim3(512), 0, s, k12, W0, P, X, R, dX);
+int ptta_launch_head_bwd_finish(const double* k12, const float* W0, const float* P, const float* X, long R, void* dX, hipStream_t s, int halves, int dX_bf16) {
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3((int)((R + 127) / 128)), dim3(512), 0, s, k12, W0, P, X, R, dX, halves, dX_bf16);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

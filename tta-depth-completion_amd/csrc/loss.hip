@@ -31,6 +31,8 @@ static __host__ __device__ inline long ws_rows_off(int N) { return ws_cos_off(N)
 
 int ptta_loss_ws_floats(int N, int H, int W, long R) { return (int)(ws_rows_off(N) + 3 * R + 64); }
 long ptta_loss_ws_rows_off(int N) { return ws_rows_off(N); }
+long ptta_loss_ws_cos_off(int N) { return ws_cos_off(N); }
+int ptta_loss_cos_blocks() { return LOSS_CB; }
 
 // validity_map of the TTA step = where(sparse > 0, 1, sparse) on the RAW sparse depth (src/tta_main.py:583-586); computed on the
 // fly when the caller passes no map
@@ -79,21 +81,33 @@ __global__ __launch_bounds__(256) void loss_depth_reduce_kernel(const float* __r
     depth_reduce_body(blockIdx.x, gridDim.x, blockIdx.y, depth, image, sparse, validity, max_d, H, W, part);
 }
 
-// one wave per row of `emb`/`ref` (D = 512: 8 values per lane)
-__device__ __forceinline__ void cos_rows_body(int bx, int nbx, const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+// one wave per row of `emb`/`ref` (D = 512: 8 values per lane); T = bf16_t: the narrow embeddings of the mixed mode (one 16-B load per tensor)
+template <typename T>
+__device__ __forceinline__ void cos_rows_body(int bx, int nbx, const T* __restrict__ emb, const T* __restrict__ ref, long R, int D,
                                               float* __restrict__ rowstats, float* __restrict__ part) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc = 0.f;
     for (long row = (long)bx * 4 + wave; row < R; row += (long)nbx * 4) {
-        const float* e = emb + row * D;
-        const float* r = ref + row * D;
+        const T* e = emb + row * D;
+        const T* r = ref + row * D;
         float ee = 0.f, rr = 0.f, er = 0.f;
-        for (int k = 4 * lane; k < D; k += 256) {
-            const float4 a = *(const float4*)(e + k), b = *(const float4*)(r + k);
-            ee += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
-            rr += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
-            er += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        if constexpr (sizeof(T) == 4) {
+            for (int k = 4 * lane; k < D; k += 256) {
+                const float4 a = *(const float4*)(e + k), b = *(const float4*)(r + k);
+                ee += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+                rr += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+                er += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            }
+        } else {
+            for (int k = 8 * lane; k < D; k += 512) {
+                const uint4 ua = *(const uint4*)(e + k), ub = *(const uint4*)(r + k);
+                const float4 a0 = bf4_to_f4(make_uint2(ua.x, ua.y)), a1 = bf4_to_f4(make_uint2(ua.z, ua.w));
+                const float4 b0 = bf4_to_f4(make_uint2(ub.x, ub.y)), b1 = bf4_to_f4(make_uint2(ub.z, ub.w));
+                ee += a0.x * a0.x + a0.y * a0.y + a0.z * a0.z + a0.w * a0.w + a1.x * a1.x + a1.y * a1.y + a1.z * a1.z + a1.w * a1.w;
+                rr += b0.x * b0.x + b0.y * b0.y + b0.z * b0.z + b0.w * b0.w + b1.x * b1.x + b1.y * b1.y + b1.z * b1.z + b1.w * b1.w;
+                er += a0.x * b0.x + a0.y * b0.y + a0.z * b0.z + a0.w * b0.w + a1.x * b1.x + a1.y * b1.y + a1.z * b1.z + a1.w * b1.w;
+            }
         }
         ee = wave_sum(ee); rr = wave_sum(rr); er = wave_sum(er);
         const float ne = fmaxf(sqrtf(ee), 1e-12f), nr = fmaxf(sqrtf(rr), 1e-12f);
@@ -105,9 +119,10 @@ __device__ __forceinline__ void cos_rows_body(int bx, int nbx, const float* __re
     __syncthreads();
     if (threadIdx.x == 0) part[bx] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ __launch_bounds__(256) void cos_rows_kernel(const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
+template <typename T>
+__global__ __launch_bounds__(256) void cos_rows_kernel(const T* __restrict__ emb, const T* __restrict__ ref, long R, int D,
                                                        float* __restrict__ rowstats, float* __restrict__ part) {
-    cos_rows_body(blockIdx.x, gridDim.x, emb, ref, R, D, rowstats, part);
+    cos_rows_body<T>(blockIdx.x, gridDim.x, emb, ref, R, D, rowstats, part);
 }
 // both reductions of the step in ONE launch: blocks [0, N * LOSS_PB) the depth terms (latency-bound: 1.7 MB per frame), the rest the cosine
 // rows (bandwidth-bound: 110 MB) -- the short one hides inside the long one, and one launch less on the critical path
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(256) void loss_forward_merged_kernel(const float* _
                                                                   float* __restrict__ rowstats, float* __restrict__ cpart) {
     const int nd = N * LOSS_PB;
     if ((int)blockIdx.x < nd) depth_reduce_body(blockIdx.x % LOSS_PB, LOSS_PB, blockIdx.x / LOSS_PB, depth, image, sparse, validity, max_d, H, W, dpart);
-    else cos_rows_body(blockIdx.x - nd, gridDim.x - nd, emb, ref, R, D, rowstats, cpart);
+    else cos_rows_body<float>(blockIdx.x - nd, gridDim.x - nd, emb, ref, R, D, rowstats, cpart);
 }
 
 // one block: parallel fixed-shape reductions of the partials (deterministic), then thread 0 finishes
@@ -200,7 +215,7 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
         hipLaunchKernelGGL(loss_depth_reduce_kernel, dim3(LOSS_PB, N), dim3(256), 0, s, depth, image, sparse, validity,
                            max_input_depth, H, W, ws + ws_depth_off(N));
         if (has_cos)
-            hipLaunchKernelGGL(cos_rows_kernel, dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+            hipLaunchKernelGGL((cos_rows_kernel<float>), dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
     }
     // defer_finalize (fused step, N <= LOSS_FIN_MAXN): ptta_launch_loss_backward(..., w3_dev, loss_info) finalises inside its kernels
     if (!defer_finalize || N > LOSS_FIN_MAXN)
@@ -218,8 +233,9 @@ int ptta_launch_loss_depth_part(const float* depth, const float* image, const fl
     PTTA_CHECK_LAUNCH();
     return 0;
 }
-int ptta_launch_loss_cos_part(const float* emb, const float* ref, long R, int D, int N, float* ws, hipStream_t s) {
-    hipLaunchKernelGGL(cos_rows_kernel, dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+int ptta_launch_loss_cos_part(const void* emb, const void* ref, long R, int D, int N, float* ws, hipStream_t s, int narrow) {
+    if (narrow) hipLaunchKernelGGL((cos_rows_kernel<bf16_t>), dim3(LOSS_CB), dim3(256), 0, s, (const bf16_t*)emb, (const bf16_t*)ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+    else hipLaunchKernelGGL((cos_rows_kernel<float>), dim3(LOSS_CB), dim3(256), 0, s, (const float*)emb, (const float*)ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -31,7 +31,9 @@ namespace {
 struct L32 { ConvW f{}, b{}; float* bias = nullptr; int transposed = 0; };
 struct LIn { float *wfrag = nullptr, *wcanon = nullptr, *bias = nullptr, *bw = nullptr; int cin = 1; };
 struct LOut { float *w = nullptr, *bias = nullptr, *bfrag = nullptr, *bcanon = nullptr; };
-struct Lin { float *W = nullptr, *Wt = nullptr, *bias = nullptr; bf16_t *Whi = nullptr, *Wlo = nullptr, *Wthi = nullptr, *Wtlo = nullptr, *Wil = nullptr, *Wtil = nullptr; int N = 0, K = 0; };
+struct Lin { float *W = nullptr, *Wt = nullptr, *bias = nullptr; bf16_t *Whi = nullptr, *Wlo = nullptr, *Wthi = nullptr, *Wtlo = nullptr, *Wil = nullptr, *Wtil = nullptr;
+             bf16_t *Wsl = nullptr, *Wtsl = nullptr;      // slice-major bf16 images of W / W^T for the narrow heads (heads_n.hip), 512 x 512 layers
+             int N = 0, K = 0; };
 struct BNorm { float *gamma = nullptr, *beta = nullptr, *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
                float *mean = nullptr, *inv = nullptr, *scale = nullptr, *shift = nullptr; };
 struct Dbg { const void* p; long numel; int is_act; };
@@ -251,6 +253,10 @@ struct ptta_ctx {
     void *e2_0a, *e2_0, *e2_1a, *e2_1, *e2_2a, *z2, *t2, *z3, *s1_2, *u2, *z4, *s0_2, *v2;
     void *e3_0a, *e3_0, *e3_1a, *e3_1, *e3_2a, *feat, *w2, *t3, *s1_3, *u3, *s0_3, *v3;
     float *h1z, *pz, *h2, *emb, *h1, *ref, *gref_buf, *gmask, *bn_part;
+    double* hn_msc = nullptr;         // per-block second moments of the feature rows ([pass][block][32][33])
+    float* hn_rs = nullptr;           // |emb row|^2 from the emb GEMM's epilogue
+    bool cos_rows_done = false;      // the ref GEMM's epilogue produced the cosine term's row statistics and block partials (heads_n.hip EPI 5)
+    bf16_t *emb_n = nullptr, *ref_n = nullptr, *h2_n = nullptr;       // mixed mode: the heads' narrow [R][512] tensors (heads_n.hip)
     float *bnb_gscale, *bnb_c1, *bnb_c2;
     float *loss_ws, *loss_info, *g_final, *g_net;
     // backward
@@ -380,11 +386,13 @@ void build_registry(ptta_ctx* c) {
             l->Whi = (bf16_t*)c->dalloc(ne * 2); l->Wlo = (bf16_t*)c->dalloc(ne * 2);
             l->Wthi = (bf16_t*)c->dalloc(ne * 2); l->Wtlo = (bf16_t*)c->dalloc(ne * 2);
             l->Wil = (bf16_t*)c->dalloc(ne * 4); l->Wtil = (bf16_t*)c->dalloc(ne * 4);
+            if (l->K == 512) { l->Wsl = (bf16_t*)c->dalloc(ne * 2); l->Wtsl = (bf16_t*)c->dalloc(ne * 2); }
         }
         c->fc[std::string(p) + ".0"] = a; c->fc[std::string(p) + ".3"] = b;
         if (std::string(p) == "proj") {
             Lin& f = c->fused_pp; f.N = 512; f.K = 512; f.W = c->falloc(512 * 512); f.bias = c->falloc(512);
             f.Whi = (bf16_t*)c->dalloc(512 * 512 * 2); f.Wlo = (bf16_t*)c->dalloc(512 * 512 * 2); f.Wil = (bf16_t*)c->dalloc(512 * 512 * 4);
+            f.Wsl = (bf16_t*)c->dalloc(512 * 512 * 2);
         }
         if (std::string(p) == "proj") c->w0frag = c->dalloc(16 * 2 * 2 * 64 * 16);
         BNorm n; n.gamma = c->falloc(512); n.beta = c->falloc(512);
@@ -441,6 +449,13 @@ void build_workspace(ptta_ctx* c) {
     c->h1z = c->falloc(RD); c->pz = c->falloc(RD); c->h2 = c->falloc(RD); c->emb = c->falloc(RD);
     c->h1 = c->falloc(RD); c->ref = c->falloc(RD); c->gref_buf = c->falloc(RD); c->gmask = c->falloc(RD);
     c->dbg["emb"] = Dbg{c->emb, (long)RD, 0}; c->dbg["ref"] = Dbg{c->ref, (long)RD, 0};
+    if (c->mixed) {
+        const size_t te = (size_t)ptta_hn_tiled_elems(c->Rg) * 2;          // tiled layout, padded to whole 128-row blocks (heads_n.hip)
+        c->emb_n = (bf16_t*)c->dalloc(te); c->ref_n = (bf16_t*)c->dalloc(te); c->h2_n = (bf16_t*)c->dalloc(te);
+        c->hn_rs = c->falloc((size_t)c->Rg);
+        c->hn_msc = (double*)c->dalloc((size_t)2 * ptta_hn_moment_blocks(c->Rg) * 1056 * sizeof(double));
+        c->dbg["emb"] = Dbg{c->emb_n, (long)RD, 3}; c->dbg["ref"] = Dbg{c->ref_n, (long)RD, 3};
+    }
     c->dbg["h1"] = Dbg{c->h1, (long)RD, 0}; c->dbg["gmask"] = Dbg{c->gmask, (long)RD, 0}; c->dbg["gref"] = Dbg{c->gref_buf, (long)RD, 0};
     c->bn_part = c->falloc((size_t)ptta_gemm_row_blocks((int)c->Rg) * 2 * 512);
     c->bnb_gscale = c->falloc(512); c->bnb_c1 = c->falloc(512); c->bnb_c2 = c->falloc(512);
@@ -834,6 +849,7 @@ int meta_forward_proxy(ptta_ctx* c, hipStream_t s) {
 }
 
 int heads_forward(ptta_ctx* c, hipStream_t s, int part = 0);
+static bool heads_v2_on(const ptta_ctx* c);
 static int pipe_quiesce(ptta_ctx* c);
 static void pipe_use(ptta_ctx* c, int p);
 // a full forward (ptta_forward_eval / ptta_forward_train) has written an arbitrary frame's prefix into set p: whatever was prepared into it
@@ -899,6 +915,7 @@ int ensure_fused_heads(ptta_ctx* c, hipStream_t s) {
     Lin& f = c->fused_pp; const Lin& a = c->fc["proj.3"]; const Lin& b = c->fc["pred.0"];
     hipLaunchKernelGGL(fuse_linear_kernel, dim3(2, 512), dim3(256), 0, s, b.W, b.bias, a.W, a.bias, f.W, f.bias, 512, 512, 512);
     ptta_split_weight(f.W, f.Whi, f.Wlo, f.Wil, 512L * 512, 512, s);
+    ptta_hn_pack_w(f.Whi, f.Wsl, 512, s);
     c->fused_pp_valid = true;
     return 0;
 }
@@ -1064,9 +1081,11 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         RUN(region(sp, Nn, Nn, true));
         // (round 5, step 1: the heads still take fp32 features -- the proxy features are widened into the proxy half of `feat`)
         RUN(to_wide(c, c->tw(c->feat), (float*)c->feat + (size_t)c->Rg * 32, c->Rg * 32, sp));
+        const bool hn = heads_v2_on(c);              // narrow heads: the proxy half needs nothing of the real chain
         if (s2) {
+            if (hn) RUN(heads_forward(c, s2, 1));
             HIPCHK(hipEventRecord(c->ev_real, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_real, 0));
-            RUN(heads_forward(c, s2));
+            RUN(heads_forward(c, s2, hn ? 2 : 0));
             HIPCHK(hipEventRecord(c->ev_join, s2));
         }
     } else {
@@ -1125,11 +1144,52 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
 
 int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2 only): 0 both passes, 1 the proxy pass, 2 the real pass
     if (c->ablate & 4) return 0;      // timing ablation only
+    if (part != 1) c->cos_rows_done = false;
     // profiling class 6: 3 applications of Linear(32,512) / Linear(512,512) pairs (proj on both passes, pred on the proxy pass; proj.3 and
     // pred.0 run merged) = per row 2 x (32 + 512) + 4 x (512 + 512) elements by SURVEY 8d's rule as the REFERENCE executes it (6 linears)
     ProfScope ps_(c, 6, s, ((double)c->Rg * (2 * 544 + 4 * 1024) + 2 * 16384.0 + 4 * 262144.0) * 4, (double)c->Rg * (2 * 16384.0 + 4 * 262144.0), heads_v2_on(c) ? 7 : 8);
     const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
     const void* feat_zero = (const char*)c->feat + half;
+    if (c->mixed && heads_v2_on(c)) {
+        // ---- mixed mode: narrow heads (heads_n.hip).  BatchNorm1d batch statistics of Linear(32,512) from the second moments of the fp32 feature
+        // rows (head_moments_kernel, fp64; the proxy rows are the widened copy of the narrow features), the three 512 x 512 GEMMs on narrow
+        // operands with the hidden of proj computed on the fly.  part 1: the proxy pass (emb), part 2: the real pass (ref), 0: both.
+        const Lin& l0 = c->fc["proj.0"]; const Lin& lf = c->fused_pp; const Lin& lp3 = c->fc["pred.3"]; const Lin& l3 = c->fc["proj.3"];
+        BNorm& b1 = c->bn["proj.1"]; BNorm& b2 = c->bn["pred.1"];
+        const long R = c->Rg; const int Rw = (int)R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1);
+        const int nbh = 2, nb = ptta_hn_row_blocks(R);           // (the moments path hands the finalize two partial "blocks": value + rounding remainder)
+        float* part_real = c->hm_part; float* part_zero = c->hm_part + (size_t)nbh * 2 * 512;
+        double* msc_real = c->hn_msc; double* msc_zero = c->hn_msc + (size_t)ptta_hn_moment_blocks(R) * 1056;
+        auto gemm_h = [&](const void* x, int x_bf16, const Lin& w, bf16_t* out, int epi) {
+            HnGemmArgs g; g.pro = 3; g.epi = epi; g.X = x; g.x_bf16 = x_bf16; g.W0 = l0.Whi; g.b0 = l0.bias; g.pscale = b1.scale; g.pshift = b1.shift;
+            g.W = w.Wsl; g.bias = w.bias; g.C = out; g.part = c->bn_part; g.R = R;
+            return g;
+        };
+        if (part != 2) {
+            // proxy pass first: the running statistics are updated in the reference's order (proj(feat_zero), then proj(feat), :551-554)
+            RUN(ptta_launch_hn_moments((const float*)c->feat + (size_t)R * 32, R, 1, l0.W, l0.bias, msc_zero, part_zero, s));
+            RUN(ptta_stat_sync(&c->stat_sync, part_zero, nbh, 512, 1, s));
+            RUN(ptta_launch_bn_finalize(part_zero, nbh, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
+            RUN(ptta_launch_hn_gemm(gemm_h(c->tw(c->feat), 1, lf, c->h2_n, 1), s));
+            RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, nb, 512, 1, s));
+            RUN(ptta_launch_bn_finalize(c->bn_part, nb, Rw, 512, b2.gamma, b2.beta, 1e-5f, 0.1f, b2.rm, b2.rv, b2.nbt, b2.mean, b2.inv, b2.scale, b2.shift, s));
+            HnGemmArgs g3; g3.pro = 1; g3.epi = 2; g3.A = c->h2_n; g3.pscale = b2.scale; g3.pshift = b2.shift; g3.W = lp3.Wsl; g3.bias = lp3.bias; g3.C = c->emb_n; g3.R = R;
+            g3.rs = c->hn_rs;                              // |e_r|^2 for the cosine term (the ref GEMM's epilogue completes it)
+            RUN(ptta_launch_hn_gemm(g3, s));
+        }
+        if (part != 1) {
+            // real pass last: its BatchNorm statistics are the ones the backward needs
+            RUN(ptta_launch_hn_moments((const float*)c->feat, R, 1, l0.W, l0.bias, msc_real, part_real, s));
+            RUN(ptta_stat_sync(&c->stat_sync, part_real, nbh, 512, 1, s));
+            RUN(ptta_launch_bn_finalize(part_real, nbh, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
+            HnGemmArgs gr = gemm_h(c->feat, 0, l3, c->ref_n, 5);
+            gr.E = c->emb_n; gr.rs = c->hn_rs; gr.rowstats_out = c->loss_ws + ptta_loss_ws_rows_off(c->N);
+            gr.cpart = c->loss_ws + ptta_loss_ws_cos_off(c->N); gr.cpart_n = ptta_loss_cos_blocks();
+            RUN(ptta_launch_hn_gemm(gr, s));
+            c->cos_rows_done = true;
+        }
+        return 0;
+    }
     if (c->head_swap) {
         // stage 2 without `reverse` (network_exp_msg_chn_adapt.py:681-684): emb = pred(proj(feat)), ref = proj(feat_zero); the
         // BatchNorm state of proj's FIRST application is what its backward needs, the second one overwrites it -> saved aside
@@ -1225,6 +1285,21 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     ProfScope ps_(c, 6, s, ((double)c->Rg * (1024 + 544) + 16384.0 + 262144.0) * 4, (double)c->Rg * (16384.0 + 262144.0), 3);   // data gradient through proj once
     const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
     const int R = (int)c->Rg;
+    if (c->mixed && heads_v2_on(c)) {
+        // mixed mode (heads_n.hip): one block holds full rows, so the contraction with W0 is complete per block (one P half)
+        HnGemmArgs g; g.epi = 3; g.R = R; g.W = l3.Wtsl;
+        if (c->cos_in_gemm) { g.pro = 4; g.A = c->emb_n; g.Bref = c->ref_n; g.rowstats = c->loss_ws + ptta_loss_ws_rows_off(c->N); g.coef = c->loss_ws; }
+        else { g.pro = 5; g.Af = gref; }
+        g.X = c->feat; g.x_bf16 = 0; g.W0 = l0.Whi; g.W0t = l0.Wthi; g.b0 = l0.bias;
+        g.escale = bn.scale; g.eshift = bn.shift; g.emean = bn.mean; g.einv = bn.inv; g.part = c->bn_part; g.P = c->headP;
+        RUN(ptta_launch_hn_gemm(g, s));
+        const int nb = ptta_hn_row_blocks(R);
+        RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, nb, 512, 1, s));
+        RUN(ptta_launch_bn_bwd_finalize(c->bn_part, nb, R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s,
+                                        nullptr, nullptr, c->head_k12, l0.bias, bn.mean));
+        RUN(ptta_launch_head_bwd_finish(c->head_k12, l0.W, c->headP, (const float*)c->feat, R, c->g_feat, s, 1, 1));
+        return 0;
+    }
     if (heads_v2_on(c)) {
         // d ref -> d feat without the stored hidden: the GEMM recomputes h = x W0^T + b0 for the ReLU mask and the BatchNorm-backward sums and
         // contracts the masked gradient (x gamma x invstd) with W0 inside the block (P: [column block 2][R][32]); the BatchNorm-backward
@@ -1565,6 +1640,7 @@ int ptta_load_weights(ptta_handle c, const char* name_, const void* tensor, cons
             hipLaunchKernelGGL(transpose_kernel, dim3(nblk(numel)), dim3(256), 0, s, src, l.Wt, l.N, l.K);
             ptta_split_weight(l.W, l.Whi, l.Wlo, l.Wil, numel, l.K, s);            // [N][K]
             ptta_split_weight(l.Wt, l.Wthi, l.Wtlo, l.Wtil, numel, l.N, s);        // transposed: [K][N]
+            if (l.Wsl) { ptta_hn_pack_w(l.Whi, l.Wsl, 512, s); ptta_hn_pack_w(l.Wthi, l.Wtsl, 512, s); }
             if (base == "proj.0") ptta_pack_w0_frag(l.W, c->w0frag, s);
         } else if (is_b) { HIPCHK(hipMemcpyAsync(l.bias, src, (size_t)l.N * 4, hipMemcpyDeviceToDevice, s)); }
         else return c->fail("unknown key " + name, -2);
@@ -1668,8 +1744,13 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
     RUN(forward_common(c, image, sparse, true, s));      // includes the heads (beside decoder 3)
     const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), dbytes, hipMemcpyDeviceToDevice, s));
+    if (c->mixed && heads_v2_on(c)) {       // the caller's tensors are fp32: widened copies of the narrow embeddings
+        if (emb_out) RUN(ptta_launch_hn_untile(c->emb_n, emb_out, c->Rg, s));
+        if (ref_out) RUN(ptta_launch_hn_untile(c->ref_n, ref_out, c->Rg, s));
+    } else {
     if (emb_out) HIPCHK(hipMemcpyAsync(emb_out, c->emb, ebytes, hipMemcpyDeviceToDevice, s));
     if (ref_out) HIPCHK(hipMemcpyAsync(ref_out, c->ref, ebytes, hipMemcpyDeviceToDevice, s));
+    }
     c->fwd_valid = true;
     return 0;
 }
@@ -1825,7 +1906,8 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
                                            c->N, c->H, c->W, c->loss_ws, c->g_final, nullptr, s, c->hyper + 5, nullptr));
         // auxiliary stream, behind the heads' forward: cosine rows, the finalisation (gate, coefficient, the four reported scalars: it needs the
         // depth partials of the other stream, long there by now), the heads' backward
-        REST_(s2, ptta_launch_loss_cos_part(c->emb, c->ref, c->Rg, 512, c->N, c->loss_ws, s2));
+        // (mixed mode: the ref GEMM's epilogue already left the cosine term's row statistics and block partials in the loss workspace)
+        if (!(c->mixed && heads_v2_on(c) && c->cos_rows_done)) REST_(s2, ptta_launch_loss_cos_part(c->emb, c->ref, c->Rg, 512, c->N, c->loss_ws, s2));
         HIPCHK(hipStreamWaitEvent(s2, c->ev_dpart, 0));
         REST_(s2, ptta_launch_loss_finalize(c->loss_ws, c->N, c->H, c->W, c->Rg, 1, c->hyper + 5, c->loss_info, s2));
         c->cos_in_gemm = true;
@@ -1846,6 +1928,10 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
     }
     // validity == NULL: where(sparse > 0, 1, sparse) is evaluated inside the loss kernels; the loss finalisation runs inside
     // the two gradient kernels (no 1-block launch between forward and backward)
+    if (c->mixed && heads_v2_on(c)) {       // (one-stream fallback of the mixed mode -- profiling leg, no second stream: the fp32 loss kernels on widened copies)
+        RUN(ptta_launch_hn_untile(c->emb_n, c->emb, c->Rg, s));
+        RUN(ptta_launch_hn_untile(c->ref_n, c->ref, c->Rg, s));
+    }
     REST_(s, ptta_launch_loss_forward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
                                       c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info, s, 1));
     const bool cig = c->cos_grad_fused && heads_v2_on(c) && c->N <= 16;          // (N <= LOSS_FIN_MAXN: the gradient launch finalises the loss)
@@ -2142,6 +2228,7 @@ static int head_reload(ptta_ctx* c, int k, hipStream_t s) {
             hipLaunchKernelGGL(transpose_kernel, dim3(nblk(e.n)), dim3(256), 0, s, (const float*)e.p, l.Wt, l.N, l.K);
             ptta_split_weight(l.W, l.Whi, l.Wlo, l.Wil, e.n, l.K, s);
             ptta_split_weight(l.Wt, l.Wthi, l.Wtlo, l.Wtil, e.n, l.N, s);
+            if (l.Wsl) { ptta_hn_pack_w(l.Whi, l.Wsl, 512, s); ptta_hn_pack_w(l.Wthi, l.Wtsl, 512, s); }
             if (base == "proj.0") ptta_pack_w0_frag(l.W, c->w0frag, s);
         } else HIPCHK(hipMemcpyAsync(l.bias, e.p, (size_t)e.n * 4, hipMemcpyDeviceToDevice, s));
     } else {
@@ -2456,7 +2543,8 @@ int ptta_debug_tensor(ptta_handle c, const char* name, float* dst, int64_t capac
     if (capacity < it->second.numel) return c->fail("capacity too small", -22);
     hipStream_t s = (hipStream_t)s_;
     const long n = it->second.numel;
-    if ((it->second.is_act == 1 && c->bf16) || it->second.is_act == 2) hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(nblk(n)), dim3(256), 0, s, (const bf16_t*)it->second.p, dst, n);
+    if (it->second.is_act == 3) RUN(ptta_launch_hn_untile(it->second.p, dst, n / 512, s));
+    else if ((it->second.is_act == 1 && c->bf16) || it->second.is_act == 2) hipLaunchKernelGGL((to_f32_kernel<bf16_t>), dim3(nblk(n)), dim3(256), 0, s, (const bf16_t*)it->second.p, dst, n);
     else HIPCHK(hipMemcpyAsync(dst, it->second.p, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     return 0;
 }

@@ -136,7 +136,8 @@ void ptta_pack_w0_frag(const float* W0, void* frag, hipStream_t s);
 int ptta_head_moment_blocks(long R);
 int ptta_launch_head_moments(const float* X, long R, int npass, const float* W0, const float* b0, float* part, hipStream_t s);
 // after the epi-3 GEMM + ptta_launch_bn_bwd_finalize: dX = P[0] + P[1] - X M - u (M, u from the BatchNorm-backward means, derived per block in fp64)
-int ptta_launch_head_bwd_finish(const double* k12, const float* W0, const float* P, const float* X, long R, float* dX, hipStream_t s);
+// halves: P holds 2 column-block halves (heads.hip EPI 3) or 1 (heads_n.hip); dX_bf16: the gradient map is narrow
+int ptta_launch_head_bwd_finish(const double* k12, const float* W0, const float* P, const float* X, long R, void* dX, hipStream_t s, int halves = 2, int dX_bf16 = 0);
 void ptta_split_weight(const float* w, bf16_t* hi, bf16_t* lo, bf16_t* il, long n, int K, hipStream_t s);
 int ptta_gemm_row_blocks(int R);
 int ptta_gemm_part_blocks(const GemmArgs& a);
@@ -151,6 +152,32 @@ int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N,
                                 float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr,
                                 double* k12 = nullptr, const float* b0 = nullptr, const float* mean = nullptr);    // k12: [k1 512 | k2 512] for ptta_launch_head_bwd_finish
 
+// ---- heads_n.hip: the heads of the mixed mode (narrow storage, one bf16 MFMA per product) --------
+struct HnGemmArgs {
+    int pro = 1, epi = 0;          // pro 1 / 3 / 4 / 5, epi 0 / 1 / 3 (heads_n.hip header)
+    const bf16_t* A = nullptr;     // pro 1: previous layer's output [R][512]; pro 4: emb
+    const float* Af = nullptr;     // pro 5: fp32 gradient tensor [R][512]
+    const bf16_t* Bref = nullptr; const float* rowstats = nullptr; const float* coef = nullptr;      // pro 4
+    const void* X = nullptr; int x_bf16 = 0;        // pro 3 / epi 3: the 32-channel feature rows (fp32 real frames / narrow proxy frames)
+    const bf16_t* W0 = nullptr; const float* b0 = nullptr;           // proj.0: [512][32] bf16, bias
+    const float* pscale = nullptr; const float* pshift = nullptr;    // BatchNorm1d + ReLU applied to the A operand
+    const bf16_t* W = nullptr; const float* bias = nullptr;          // [512][512] bf16 row-major ([out][in]), bias
+    bf16_t* C = nullptr; float* part = nullptr;                      // narrow output (TILED, heads_n.hip); [row blocks of 128][2][512] column partials (epi 1 / 3)
+    const bf16_t* E = nullptr; float* rs = nullptr;                  // epi 2: rs[r] = |c_r|^2 out; epi 5: E = the epi-2 tensor, rs = its row sums (in)
+    float* rowstats_out = nullptr; float* cpart = nullptr; int cpart_n = 0;      // epi 5: (|e|, |c|, cos) per row; block partials of sum (2 - 2 cos), array length
+    const float *escale = nullptr, *eshift = nullptr, *emean = nullptr, *einv = nullptr;             // epi 3: proj.1's state
+    const bf16_t* W0t = nullptr; float* P = nullptr;                 // epi 3: [32][512] bf16; P [R][32] fp32
+    long R = 0;
+};
+int ptta_hn_row_blocks(long R);
+long ptta_hn_tiled_elems(long R);                                   // elements of a tiled [R][512] tensor (padded to whole 128-row blocks)
+void ptta_hn_pack_w(const bf16_t* w_hi_rowmajor, bf16_t* w_slice_major, int K, hipStream_t s);
+int ptta_launch_hn_untile(const void* src_tiled, float* dst, long R, hipStream_t s);
+int ptta_hn_moment_blocks(long R);
+int ptta_launch_hn_moments(const float* X, long R, int npass, const float* W0, const float* b0, double* scratch, float* part, hipStream_t s);
+long ptta_loss_ws_cos_off(int N); int ptta_loss_cos_blocks();        // loss.hip: where the cosine term's block partials live in the workspace
+int ptta_launch_hn_gemm(const HnGemmArgs& a, hipStream_t s);
+
 // ---- loss.hip ---------------------------------------------------------------------------------
 struct LossScalars;      // device-resident scalars, see loss.hip
 int ptta_loss_ws_floats(int N, int H, int W, long R);
@@ -161,7 +188,7 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
                              float* ws, float* loss_info, hipStream_t s, int defer_finalize = 0);
 int ptta_launch_loss_depth_part(const float* depth, const float* image, const float* sparse, const float* validity, float max_input_depth,
                                 int N, int H, int W, float* ws, hipStream_t s);
-int ptta_launch_loss_cos_part(const float* emb, const float* ref, long R, int D, int N, float* ws, hipStream_t s);
+int ptta_launch_loss_cos_part(const void* emb, const void* ref, long R, int D, int N, float* ws, hipStream_t s, int narrow = 0);      // narrow: bf16 [R][512]
 int ptta_launch_loss_finalize(float* ws, int N, int H, int W, long R, int has_cos, const float* w3_dev, float* loss_info, hipStream_t s);
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,

@@ -727,7 +727,8 @@ def main():
         return msgchn_multi_stream(args, rank, world, dist, affinity)
     from proxytta import synth
     from proxytta.engine import ADAPTED, Engine
-    eng = Engine(1, H, W, dtype=args.dtype, **HP)
+    keep = tuple(k for k in os.environ.get('PTTA_BENCH_KEEP', '').split(',') if k)      # precision-budget runs only (tools/precision_budget.sh)
+    eng = Engine(1, H, W, dtype=args.dtype, keep=keep, **HP)
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
     eng.load_state_dict(sd)
     for name in ADAPTED:

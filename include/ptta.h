@@ -70,7 +70,10 @@ enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1, PTTA_BACKBONE_COSTDCN
  *   storage, one bf16 MFMA per product, fp32 accumulate.  depth_train is bit-identical to PTTA_DTYPE_F32; measured budget per tensor
  *   class: profiles/r05_precision_budget.txt; bounds per mode: tests/test_gpu_mixed.py.  PTTA_ARITH=exact / PTTA_CONV_IMPL=naive are
  *   PTTA_DTYPE_F32-only (ptta_create returns -38 with PTTA_DTYPE_MIXED). */
-enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_MIXED = 1 };
+enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_MIXED = 1,
+       /* OR-ed into PTTA_DTYPE_MIXED (precision budget, tools/accuracy_report.py --keep): keep one of the three narrow classes at fp32 storage
+        * and bf16x3 arithmetic -- the proxy chain, the data gradients, the heads */
+       PTTA_MIXED_KEEP_PROXY = 0x100, PTTA_MIXED_KEEP_BACKWARD = 0x200, PTTA_MIXED_KEEP_HEADS = 0x400 };
 enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };   /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
 /* NLSPN only, OR-ed into meta_mode: ExternalModel_Adapt(..., offset=True) -> args.legacy (src/nlspn_model_adapt.py:62):
  * the confidence gathers add each tap's own (dy, dx) to the learned offset (nlspnmodel_adapt.py:297-302).

@@ -32,20 +32,24 @@ def main():
     ap.add_argument('--size', default='128x256')
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--threads', type=int, default=16)
+    ap.add_argument('--keep', default='', help='mixed mode: comma list of classes kept at fp32 / bf16x3: proxy,backward,heads')
+    ap.add_argument('--frame0', type=int, default=0)
+    ap.add_argument('--w-cos', type=float, default=0.1)
+    ap.add_argument('--head-bias', type=float, default=0.0)
     a = ap.parse_args()
     h, w = [int(x) for x in a.size.split('x')]
     torch.set_num_threads(a.threads)
-    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1,
+    hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=a.w_cos,
               max_input_depth=80.0)
-    eng = Engine(1, h, w, dtype=a.dtype, **hp)
-    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
+    eng = Engine(1, h, w, dtype=a.dtype, keep=tuple(k for k in a.keep.split(',') if k), **hp)
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE, 1.0, a.head_bias).items()}
     eng.load_state_dict(sd)
     for name in ADAPTED:
         eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
-    o = O.MsgChnOracle(synth.formula_state_dict(MODE), MODE, max_input_depth=80.0, lr=1e-3, w_sd=1.0, w_sm=2.0, w_cos=0.1)
+    o = O.MsgChnOracle(synth.formula_state_dict(MODE, 1.0, a.head_bias), MODE, max_input_depth=80.0, lr=1e-3, w_sd=1.0, w_sm=2.0, w_cos=a.w_cos)
     rows = []
     for s in range(a.steps):
-        image, sparse = synth.synthetic_frame(s, h, w, 1)
+        image, sparse = synth.synthetic_frame(a.frame0 + s, h, w, 1)
         ic, sc = torch.from_numpy(image), torch.from_numpy(sparse)
         r = o.step(ic, sc)
         info, depth = eng.step(ic.cuda(), sc.cuda(), want_depth=True)

@@ -52,9 +52,12 @@ struct ptta_ctx {
     // one bf16 MFMA per product, fp32 accumulate.  The two passes are separate launch chains (real on the caller's stream, proxy on the
     // auxiliary one); a [real | proxy] fp32 map `p` has a narrow twin for its proxy frames (tw(p)); masks reach the backward as sign bits.
     int mixed = 0;
+    // the three narrow classes of the mixed mode, individually switchable for the precision budget (include/ptta.h PTTA_MIXED_KEEP_*):
+    // nar_proxy: the proxy chain on narrow maps (two launch chains); nar_bwd: narrow gradient maps; nar_heads: heads_n.hip
+    int nar_proxy = 0, nar_bwd = 0, nar_heads = 0;
     std::unordered_map<const void*, void*> ntwin;
     void* tw(const void* p) const { auto it = ntwin.find(p); return it == ntwin.end() ? nullptr : it->second; }
-    void twin_alloc(const void* p, int nb, int h, int w) { if (mixed && p) ntwin[p] = dalloc((size_t)nb * h * w * 32 * 2); }
+    void twin_alloc(const void* p, int nb, int h, int w) { if (nar_proxy && p) ntwin[p] = dalloc((size_t)nb * h * w * 32 * 2); }
     float *dm_f32 = nullptr;          // fp32 copy of the meta layer's output gradient (the weight-gradient kernels take fp32 operands)
     int ablate = 0;                  // PTTA_ABLATE (diagnostic): groups of launches skipped for timing, results garbage; announced on stderr by ptta_create
     ptta_hparams hp{};
@@ -210,14 +213,14 @@ struct ptta_ctx {
     void* act(const char* name, int nb, int h, int w) {
         void* p = dalloc((size_t)nb * h * w * 32 * es);
         dbg[name] = Dbg{p, (long)nb * h * w * 32, 1};
-        if (mixed && nb == 2 * Nn) twin_alloc(p, Nn, h, w);          // [real | proxy] map: narrow twin of the proxy frames
+        if (nar_proxy && nb == 2 * Nn) twin_alloc(p, Nn, h, w);          // [real | proxy] map: narrow twin of the proxy frames
         return p;
     }
     // gradient map of the backward (real frames only): narrow in the mixed mode
     void* gact(const char* name, int nb, int h, int w) {
-        const int e = mixed ? 2 : es;
+        const int e = nar_bwd ? 2 : es;
         void* p = dalloc((size_t)nb * h * w * 32 * e);
-        dbg[name] = Dbg{p, (long)nb * h * w * 32, mixed ? 2 : 1};
+        dbg[name] = Dbg{p, (long)nb * h * w * 32, nar_bwd ? 2 : 1};
         return p;
     }
     // Sign-bit masks (ptta_common.h Epi): for every pre-activation map the backward uses as a ReLU mask, one word per pixel of the REAL
@@ -439,9 +442,9 @@ void build_workspace(ptta_ctx* c) {
         auto first_fused = [&](int h, int w) { return c->fuse_first >= 1 && !(c->ablate & 3) && c->x3 && (long)Nn * ((w + 31) / 32) * ((h + 7) / 8) > 256; };
         // (mixed mode: EVERY mask of the backward is a bit plane -- a narrow launch cannot read an fp32 mask map; the unfused first-layer
         // kernel writes the planes of e*_0a then, and decoder 1's v1 gets one too)
-        if (first_fused(H1, W1) || c->mixed) MB_(e3_0a, H1, W1);
-        if (first_fused(H2, W2) || c->mixed) MB_(e2_0a, H2, W2);
-        if (c->mixed) MB_(v1, H4, W4);
+        if (first_fused(H1, W1) || c->nar_bwd) MB_(e3_0a, H1, W1);
+        if (first_fused(H2, W2) || c->nar_bwd) MB_(e2_0a, H2, W2);
+        if (c->nar_bwd) MB_(v1, H4, W4);
 #undef MB_
     }
     // heads
@@ -449,7 +452,7 @@ void build_workspace(ptta_ctx* c) {
     c->h1z = c->falloc(RD); c->pz = c->falloc(RD); c->h2 = c->falloc(RD); c->emb = c->falloc(RD);
     c->h1 = c->falloc(RD); c->ref = c->falloc(RD); c->gref_buf = c->falloc(RD); c->gmask = c->falloc(RD);
     c->dbg["emb"] = Dbg{c->emb, (long)RD, 0}; c->dbg["ref"] = Dbg{c->ref, (long)RD, 0};
-    if (c->mixed) {
+    if (c->nar_heads) {
         const size_t te = (size_t)ptta_hn_tiled_elems(c->Rg) * 2;          // tiled layout, padded to whole 128-row blocks (heads_n.hip)
         c->emb_n = (bf16_t*)c->dalloc(te); c->ref_n = (bf16_t*)c->dalloc(te); c->h2_n = (bf16_t*)c->dalloc(te);
         c->hn_rs = c->falloc((size_t)c->Rg);
@@ -474,8 +477,8 @@ void build_workspace(ptta_ctx* c) {
     G_(de2_1a, Nn, H4, W4); G_(de2_0, Nn, H2, W2); G_(de2_0a, Nn, H2, W2); G_(dv1, Nn, H4, W4); G_(dm_total, Nn, H4, W4);
     G_(g_feat, Nn, H4, W4);
 #undef G_
-    if (c->mixed) {
-        c->dm_f32 = c->falloc((size_t)Nn * H4 * W4 * 32);
+    if (c->nar_bwd) c->dm_f32 = c->falloc((size_t)Nn * H4 * W4 * 32);
+    if (c->nar_proxy) {
         // depth-only maps of the stage-1 encoder that the proxy chain reads (held once, fp32): narrow copies made in the prefix
         c->twin_alloc(c->e1_0, Nn, H4, W4); c->twin_alloc(c->e1_1a, Nn, H8, W8); c->twin_alloc(c->e1_2a, Nn, H16, W16);
     }
@@ -587,7 +590,7 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     a.up = e.up; a.up_nb = e.up_nb; a.mask = e.mask; a.mask_nb = e.mask_nb;
     a.add1 = e.add1; a.add1_nb = e.add1_nb; a.add2 = e.add2; a.add2_nb = e.add2_nb;
     a.out_raw = e.raw; a.out_sum = e.sum;
-    const bool nar = e.nar || (bwd && c->mixed);
+    const bool nar = e.nar || (bwd && c->nar_bwd);
     const int es_l = nar ? 2 : c->es;
     a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = nar ? 1 : c->bf16; a.naive = c->naive; a.x3 = c->x3;
     if (!c->mbits.empty()) {
@@ -659,7 +662,7 @@ int conv32_first_bwd(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvI
     auto it = c->l32.find(layer);
     if (it == c->l32.end()) return c->fail("unknown 32->32 layer " + layer, -2);
     const long tiles = (long)B * ((W + 31) / 32) * ((H + 7) / 8);
-    const bool nar = c->mixed != 0;
+    const bool nar = c->nar_bwd != 0;
     f.bf16 = nar ? 1 : c->bf16;
     if (c->fuse_head_bwd && c->bits_of(f.mask) && c->bits_of(e.mask) && c->fuse_first >= 1 && !(c->ablate & 3) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && e.mask && e.raw && !e.add1 && !e.add2 && !e.sum && !e.up) {
         Conv32Args a;
@@ -686,7 +689,7 @@ int meta_forward(ptta_ctx* c, bool train, int B, hipStream_t s) {
     const int H4 = c->H4, W4 = c->W4, Nn = c->Nn;
     if (c->meta_mode == PTTA_META_1LAYER) {
         E e; e.raw = c->m;
-        if (c->mixed && train && B == 2 * Nn) {      // real frames here (fp32); the proxy frames' narrow launch is meta_forward_proxy()
+        if (c->nar_proxy && train && B == 2 * Nn) {      // real frames here (fp32); the proxy frames' narrow launch is meta_forward_proxy()
             return conv32(c, s, "conv1_rgb_meta", false, CONV_S1, c->c2, Nn, Nn, H4, W4, false, e);
         }
         return conv32(c, s, "conv1_rgb_meta", false, CONV_S1, c->c2, B, B, H4, W4, false, e);
@@ -781,7 +784,7 @@ int meta2_backward(ptta_ctx* c, hipStream_t s) {
         GView hv = x; hv.p = m2.gh; hv.C = 128; hv.ld = 128;
         GView av = hv; av.p = m2.ga1;
         GView tv = x; tv.p = m2.gt;
-        GView gm = x; gm.p = c->mixed ? c->dm_f32 : (float*)c->dm_total;
+        GView gm = x; gm.p = c->nar_bwd ? c->dm_f32 : (float*)c->dm_total;
         GView dt = x; dt.p = m2.gdt;
         GView da1 = hv; da1.p = m2.gda1;
         GView dh = hv; dh.p = m2.gdh;
@@ -924,7 +927,7 @@ int ensure_proxy_rgb(ptta_ctx* c, const float* any_image, hipStream_t s) {
     RUN(ensure_fused_heads(c, s));
     if (c->proxy_rgb_valid) return 0;
     RUN(rgb_encoder(c, any_image, c->Nn, c->Nn, 0, s));
-    if (c->mixed) {      // what the proxy chain reads of it: the skip operands c1 .. c4 and the adapted layer's input c2, as narrow maps
+    if (c->nar_proxy) {      // what the proxy chain reads of it: the skip operands c1 .. c4 and the adapted layer's input c2, as narrow maps
         const int Nn = c->Nn;
         struct { void* p; int h, w; } maps[4] = {{c->c1, c->H2, c->W2}, {c->c2, c->H4, c->W4}, {c->c3, c->H8, c->W8}, {c->c4, c->H16, c->W16}};
         for (auto& m_ : maps) {
@@ -954,7 +957,7 @@ int enc1_head_fn(ptta_ctx* c, hipStream_t st) {
 // at dec1.3.  B2 = images per launch ([real | proxy] in a training forward).
 int stage1_independent(ptta_ctx* c, int B2, hipStream_t s) {
     const int Nn = c->Nn, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
-    const bool two = c->mixed && B2 == 2 * Nn;        // mixed training forward: real frames fp32 here, proxy frames narrow below
+    const bool two = c->nar_proxy && B2 == 2 * Nn;        // mixed training forward: real frames fp32 here, proxy frames narrow below
     const int Bf = two ? Nn : B2;
     { E e; e.raw = c->e1_1; e.sum = c->y1; e.add1 = c->c3; e.add1_nb = B2;                      // y1 = e1_1 + c3
       RUN(conv32(c, s, "depth_encoder1.enc1.3", false, CONV_S1, c->e1_1a, Nn, Bf, H8, W8, true, e)); }
@@ -989,7 +992,7 @@ int stage1_independent(ptta_ctx* c, int B2, hipStream_t s) {
 int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
     hipStream_t s2 = train ? c->aux(s) : nullptr;
     const int Nn = c->Nn, B2 = train ? 2 * Nn : Nn;
-    const bool two = train && c->mixed;
+    const bool two = train && c->nar_proxy;
     const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8, H16 = c->H16, W16 = c->W16;
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
     auto e_raw = [](void* raw) { E e; e.raw = raw; return e; };
@@ -1081,7 +1084,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         RUN(region(sp, Nn, Nn, true));
         // (round 5, step 1: the heads still take fp32 features -- the proxy features are widened into the proxy half of `feat`)
         RUN(to_wide(c, c->tw(c->feat), (float*)c->feat + (size_t)c->Rg * 32, c->Rg * 32, sp));
-        const bool hn = heads_v2_on(c);              // narrow heads: the proxy half needs nothing of the real chain
+        const bool hn = c->nar_heads && heads_v2_on(c);              // narrow heads: the proxy half needs nothing of the real chain
         if (s2) {
             if (hn) RUN(heads_forward(c, s2, 1));
             HIPCHK(hipEventRecord(c->ev_real, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_real, 0));
@@ -1150,7 +1153,7 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
     ProfScope ps_(c, 6, s, ((double)c->Rg * (2 * 544 + 4 * 1024) + 2 * 16384.0 + 4 * 262144.0) * 4, (double)c->Rg * (2 * 16384.0 + 4 * 262144.0), heads_v2_on(c) ? 7 : 8);
     const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
     const void* feat_zero = (const char*)c->feat + half;
-    if (c->mixed && heads_v2_on(c)) {
+    if (c->nar_heads && heads_v2_on(c)) {
         // ---- mixed mode: narrow heads (heads_n.hip).  BatchNorm1d batch statistics of Linear(32,512) from the second moments of the fp32 feature
         // rows (head_moments_kernel, fp64; the proxy rows are the widened copy of the narrow features), the three 512 x 512 GEMMs on narrow
         // operands with the hidden of proj computed on the fly.  part 1: the proxy pass (emb), part 2: the real pass (ref), 0: both.
@@ -1170,7 +1173,8 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
             RUN(ptta_launch_hn_moments((const float*)c->feat + (size_t)R * 32, R, 1, l0.W, l0.bias, msc_zero, part_zero, s));
             RUN(ptta_stat_sync(&c->stat_sync, part_zero, nbh, 512, 1, s));
             RUN(ptta_launch_bn_finalize(part_zero, nbh, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
-            RUN(ptta_launch_hn_gemm(gemm_h(c->tw(c->feat), 1, lf, c->h2_n, 1), s));
+            if (c->nar_proxy) RUN(ptta_launch_hn_gemm(gemm_h(c->tw(c->feat), 1, lf, c->h2_n, 1), s));
+            else RUN(ptta_launch_hn_gemm(gemm_h((const float*)c->feat + (size_t)R * 32, 0, lf, c->h2_n, 1), s));
             RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, nb, 512, 1, s));
             RUN(ptta_launch_bn_finalize(c->bn_part, nb, Rw, 512, b2.gamma, b2.beta, 1e-5f, 0.1f, b2.rm, b2.rv, b2.nbt, b2.mean, b2.inv, b2.scale, b2.shift, s));
             HnGemmArgs g3; g3.pro = 1; g3.epi = 2; g3.A = c->h2_n; g3.pscale = b2.scale; g3.pshift = b2.shift; g3.W = lp3.Wsl; g3.bias = lp3.bias; g3.C = c->emb_n; g3.R = R;
@@ -1285,7 +1289,7 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     ProfScope ps_(c, 6, s, ((double)c->Rg * (1024 + 544) + 16384.0 + 262144.0) * 4, (double)c->Rg * (16384.0 + 262144.0), 3);   // data gradient through proj once
     const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
     const int R = (int)c->Rg;
-    if (c->mixed && heads_v2_on(c)) {
+    if (c->nar_heads && heads_v2_on(c)) {
         // mixed mode (heads_n.hip): one block holds full rows, so the contraction with W0 is complete per block (one P half)
         HnGemmArgs g; g.epi = 3; g.R = R; g.W = l3.Wtsl;
         if (c->cos_in_gemm) { g.pro = 4; g.A = c->emb_n; g.Bref = c->ref_n; g.rowstats = c->loss_ws + ptta_loss_ws_rows_off(c->N); g.coef = c->loss_ws; }
@@ -1297,7 +1301,7 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
         RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, nb, 512, 1, s));
         RUN(ptta_launch_bn_bwd_finalize(c->bn_part, nb, R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s,
                                         nullptr, nullptr, c->head_k12, l0.bias, bn.mean));
-        RUN(ptta_launch_head_bwd_finish(c->head_k12, l0.W, c->headP, (const float*)c->feat, R, c->g_feat, s, 1, 1));
+        RUN(ptta_launch_head_bwd_finish(c->head_k12, l0.W, c->headP, (const float*)c->feat, R, c->g_feat, s, 1, c->nar_bwd ? 1 : 0));
         return 0;
     }
     if (heads_v2_on(c)) {
@@ -1315,8 +1319,8 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
         RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
         RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s,
                                         nullptr, nullptr, c->head_k12, l0.bias, bn.mean));
-        RUN(ptta_launch_head_bwd_finish(c->head_k12, l0.W, c->headP, (const float*)c->feat, R, c->mixed ? c->g_feat_f32 : (float*)c->g_feat, s));
-        if (c->mixed) RUN(to_narrow(c, c->g_feat_f32, c->g_feat, c->Rg * 32, s));          // the backward's gradient maps are narrow
+        RUN(ptta_launch_head_bwd_finish(c->head_k12, l0.W, c->headP, (const float*)c->feat, R, c->nar_bwd ? c->g_feat_f32 : (float*)c->g_feat, s));
+        if (c->nar_bwd) RUN(to_narrow(c, c->g_feat_f32, c->g_feat, c->Rg * 32, s));          // the backward's gradient maps are narrow
         return 0;
     }
     GemmArgs g; g.A = gref; g.W = l3.Wt; g.C = c->gmask; g.R = R; g.K = 512; g.N = 512; g.epi = 2;
@@ -1325,25 +1329,25 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     RUN(ptta_launch_gemm(g, s));
     RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(g), 512, 1, s));
     RUN(ptta_launch_bn_bwd_finalize(c->bn_part, ptta_gemm_part_blocks(g), R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1), 512, bn.gamma, bn.inv, c->bnb_gscale, c->bnb_c1, c->bnb_c2, s));
-    GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = (c->bf16 || c->mixed) ? c->g_feat_f32 : (float*)c->g_feat; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;   // fp32 storage: straight into the gradient map (no copy launch)
+    GemmArgs g2; g2.A = c->gmask; g2.A2 = c->h1; g2.W = l0.Wt; g2.C = (c->bf16 || c->nar_bwd) ? c->g_feat_f32 : (float*)c->g_feat; g2.R = R; g2.K = 512; g2.N = 32; g2.pro = 2;   // fp32 storage: straight into the gradient map (no copy launch)
     g2.pscale = c->bnb_gscale; g2.pmean = bn.mean; g2.pinv = bn.inv; g2.pc1 = c->bnb_c1; g2.pc2 = c->bnb_c2;
     g2.x3 = c->x3; g2.Whi = l0.Wthi; g2.Wlo = l0.Wtlo;
     RUN(ptta_launch_gemm(g2, s));
-    if (c->bf16 || c->mixed) hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(c->Rg * 32)), dim3(256), 0, s, c->g_feat_f32, (bf16_t*)c->g_feat, c->Rg * 32);
+    if (c->bf16 || c->nar_bwd) hipLaunchKernelGGL((from_f32_kernel<bf16_t>), dim3(nblk(c->Rg * 32)), dim3(256), 0, s, c->g_feat_f32, (bf16_t*)c->g_feat, c->Rg * 32);
     return 0;
 }
 
 // data gradients from d(depth_net) [Nn,1,Hp,Wp] and d(feat) down to conv1_rgb_meta, then its wgrad
 int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_aux) {
     const int Nn = c->Nn, B2 = 2 * Nn;
-    const int nbf = c->mixed ? 1 : c->bf16;            // gradient maps: narrow in the mixed mode (conv32() routes every bwd launch there itself)
+    const int nbf = c->nar_bwd ? 1 : c->bf16;            // gradient maps: narrow in the mixed mode (conv32() routes every bwd launch there itself)
     const int H1 = c->Hp, W1 = c->Wp, H2 = c->H2, W2 = c->W2, H4 = c->H4, W4 = c->W4, H8 = c->H8, W8 = c->W8;
 #define CV(...) RUN(conv32(c, s, __VA_ARGS__))
     auto out1_args = [&](const std::string& layer, const float* g, const void* mask, void* out, int H, int W) {
         const LOut& lo = c->lout[layer];
         ConvInArgs a; a.cin = 1; a.pl[0].p = g; a.pl[0].nb = Nn; a.pl[0].bstride = (long)H * W;
         a.wfrag = lo.bfrag; a.wcanon = lo.bcanon; a.mask = mask; a.mask_nb = B2; a.out_raw = out;
-        a.B = Nn; a.H = H; a.W = W; a.bf16 = c->mixed ? 1 : c->bf16; a.naive = c->naive;
+        a.B = Nn; a.H = H; a.W = W; a.bf16 = c->nar_bwd ? 1 : c->bf16; a.naive = c->naive;
         return a;
     };
     auto dgrad_out1 = [&](const std::string& layer, const float* g, const void* mask, void* out, int H, int W) -> int {
@@ -1358,7 +1362,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     auto dgrad_in_ch1 = [&](const std::string& layer, const void* g, const float* add, float* out, int H, int W) -> int {
         const LIn& li = c->lin_in[layer];
         ConvOut1Args a; a.in = g; a.in_nb = Nn; a.w = li.bw; a.add = add; a.add_nb = Nn; a.out = out;
-        a.B = Nn; a.H = H; a.W = W; a.relu_in = 0; a.bf16 = c->mixed ? 1 : c->bf16;
+        a.B = Nn; a.H = H; a.W = W; a.relu_in = 0; a.bf16 = c->nar_bwd ? 1 : c->bf16;
         return conv_out1_p(c, a, s);
     };
     auto em = [](void* raw, const void* mask, int mask_nb) { E e; e.raw = raw; e.mask = mask; e.mask_nb = mask_nb; return e; };
@@ -1407,12 +1411,12 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
 #undef CV
     // ---- weight gradient of the meta layer: input = c2 of the real frames ----
     // (mixed mode: the weight-gradient kernels take fp32 operands -- the 1/4-resolution gradient map is widened once, 3.4 MB)
-    if (c->mixed) RUN(to_wide(c, c->dm_total, c->dm_f32, (long)Nn * H4 * W4 * 32, s));
+    if (c->nar_bwd) RUN(to_wide(c, c->dm_total, c->dm_f32, (long)Nn * H4 * W4 * 32, s));
     if (c->meta_mode == PTTA_META_2LAYERS) return meta2_backward(c, s);
     if (!c->bf16 && c->x3 && !c->naive) {
         // default arithmetic: the bf16x3 reduction-GEMM form (gconv_mfma.hip gwgrad_x3_kernel, single-pair mode)
         GView xv; xv.p = (float*)c->c2; xv.B = Nn; xv.H = H4; xv.W = W4; xv.C = 32; xv.ld = 32;
-        GView gv; gv.p = c->mixed ? c->dm_f32 : (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
+        GView gv; gv.p = c->nar_bwd ? c->dm_f32 : (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
         REST_(s, ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s));
         return 0;
     }
@@ -1502,12 +1506,15 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
         return 0;
     }
     if (backbone_id != PTTA_BACKBONE_MSG_CHN || (meta_mode != PTTA_META_1LAYER && meta_mode != PTTA_META_2LAYERS)) return -38;
+    const int keep = (dtype >> 8) & 7;                 // PTTA_MIXED_KEEP_*: classes kept at fp32 / bf16x3 (precision budget)
+    dtype &= 0xff;
     if (n < 1 || height < 16 || width < 16 || (dtype != PTTA_DTYPE_F32 && dtype != PTTA_DTYPE_MIXED) || !hp) return -22;
     ptta_ctx* c = new ptta_ctx();
     c->meta_mode = meta_mode;
     c->N = n; c->H = height; c->W = width; c->pt = pad16(height); c->pr = pad16(width);
     c->Hp = height + c->pt; c->Wp = width + c->pr; c->dual = (c->pt || c->pr) ? 1 : 0; c->Nn = c->dual ? 2 * n : n;
     c->mixed = dtype == PTTA_DTYPE_MIXED ? 1 : 0;
+    c->nar_proxy = c->mixed && !(keep & 1); c->nar_bwd = c->mixed && !(keep & 2); c->nar_heads = c->mixed && !(keep & 4);
     const char* impl = getenv("PTTA_CONV_IMPL");
     c->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
     const char* gr = getenv("PTTA_GRAPH");
@@ -1744,7 +1751,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
     RUN(forward_common(c, image, sparse, true, s));      // includes the heads (beside decoder 3)
     const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), dbytes, hipMemcpyDeviceToDevice, s));
-    if (c->mixed && heads_v2_on(c)) {       // the caller's tensors are fp32: widened copies of the narrow embeddings
+    if (c->nar_heads && heads_v2_on(c)) {       // the caller's tensors are fp32: widened copies of the narrow embeddings
         if (emb_out) RUN(ptta_launch_hn_untile(c->emb_n, emb_out, c->Rg, s));
         if (ref_out) RUN(ptta_launch_hn_untile(c->ref_n, ref_out, c->Rg, s));
     } else {
@@ -1836,7 +1843,7 @@ int ptta_backward(ptta_handle c, const float* grad_depth, const float* grad_ref,
             HIPCHK(hipEventRecord(c->ev_join, s2));
             join_aux = true;
         } else RUN(heads_backward(c, grad_ref, s));
-    } else HIPCHK(hipMemsetAsync(c->g_feat, 0, (size_t)c->Rg * 32 * (c->mixed ? 2 : c->es), s));
+    } else HIPCHK(hipMemsetAsync(c->g_feat, 0, (size_t)c->Rg * 32 * (c->nar_bwd ? 2 : c->es), s));
     RUN(backbone_backward(c, g_net, s, join_aux));
     if (c->meta_mode == PTTA_META_1LAYER) {
         if (gw_out) HIPCHK(hipMemcpyAsync(gw_out, c->gW, 9216 * 4, hipMemcpyDeviceToDevice, s));
@@ -1907,7 +1914,7 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
         // auxiliary stream, behind the heads' forward: cosine rows, the finalisation (gate, coefficient, the four reported scalars: it needs the
         // depth partials of the other stream, long there by now), the heads' backward
         // (mixed mode: the ref GEMM's epilogue already left the cosine term's row statistics and block partials in the loss workspace)
-        if (!(c->mixed && heads_v2_on(c) && c->cos_rows_done)) REST_(s2, ptta_launch_loss_cos_part(c->emb, c->ref, c->Rg, 512, c->N, c->loss_ws, s2));
+        if (!(c->nar_heads && heads_v2_on(c) && c->cos_rows_done)) REST_(s2, ptta_launch_loss_cos_part(c->emb, c->ref, c->Rg, 512, c->N, c->loss_ws, s2));
         HIPCHK(hipStreamWaitEvent(s2, c->ev_dpart, 0));
         REST_(s2, ptta_launch_loss_finalize(c->loss_ws, c->N, c->H, c->W, c->Rg, 1, c->hyper + 5, c->loss_info, s2));
         c->cos_in_gemm = true;
@@ -1928,7 +1935,7 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
     }
     // validity == NULL: where(sparse > 0, 1, sparse) is evaluated inside the loss kernels; the loss finalisation runs inside
     // the two gradient kernels (no 1-block launch between forward and backward)
-    if (c->mixed && heads_v2_on(c)) {       // (one-stream fallback of the mixed mode -- profiling leg, no second stream: the fp32 loss kernels on widened copies)
+    if (c->nar_heads && heads_v2_on(c)) {       // (one-stream fallback of the mixed mode -- profiling leg, no second stream: the fp32 loss kernels on widened copies)
         RUN(ptta_launch_hn_untile(c->emb_n, c->emb, c->Rg, s));
         RUN(ptta_launch_hn_untile(c->ref_n, c->ref, c->Rg, s));
     }
@@ -2031,7 +2038,7 @@ static int pipe_init(ptta_ctx* c) {
     Q.dclamp = c->falloc((size_t)Nn * H1 * W1); Q.d12 = c->falloc((size_t)Nn * c->H2 * c->W2); Q.d14 = c->falloc((size_t)Nn * c->H4 * c->W4);
     Q.in_image = c->falloc((size_t)c->N * 3 * c->H * c->W); Q.in_loss_image = c->falloc((size_t)c->N * 3 * c->H * c->W);
     Q.in_sparse = c->falloc((size_t)c->N * c->H * c->W); Q.in_validity = c->falloc((size_t)c->N * c->H * c->W);
-    if (c->mixed) {      // narrow twins of the second set's prefix outputs (proxy frames) and of its depth-only maps
+    if (c->nar_proxy) {      // narrow twins of the second set's prefix outputs (proxy frames) and of its depth-only maps
         for (auto& t_ : {std::make_pair(Q.c1, std::make_pair(c->H2, c->W2)), std::make_pair(Q.c2, std::make_pair(c->H4, c->W4)),
                          std::make_pair(Q.c3, std::make_pair(c->H8, c->W8)), std::make_pair(Q.c4, std::make_pair(c->H16, c->W16)),
                          std::make_pair(Q.y1, std::make_pair(c->H8, c->W8)), std::make_pair(Q.y2, std::make_pair(c->H16, c->W16)),

@@ -52,7 +52,7 @@ class Engine:
     def __init__(self, n, height, width, dtype='fp32', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0,
                  max_input_depth=None, meta='1layer', backbone='msg_chn', legacy_offset=False, max_predict_depth=None,
-                 syncbn_adapted=False):
+                 syncbn_adapted=False, keep=()):
         if not torch.cuda.is_available():
             raise RuntimeError('proxytta needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
@@ -72,6 +72,9 @@ class Engine:
             raise ValueError("dtype must be 'fp32' (fp32 maps, bf16x3 products) or 'mixed' (fp32 / bf16x3 for the real frames' forward, narrow "
                              "bf16 maps and single-MFMA products for the no_grad proxy pass and the backward: include/ptta.h PTTA_DTYPE_MIXED)")
         code = {'fp32': _lib.PTTA_DTYPE_F32, 'mixed': _lib.PTTA_DTYPE_MIXED}[dtype]
+        # precision budget only: classes of the mixed mode kept at fp32 / bf16x3 (include/ptta.h PTTA_MIXED_KEEP_*)
+        for k in keep:
+            code |= {'proxy': 0x100, 'backward': 0x200, 'heads': 0x400}[k]
         rc = self.lib.ptta_create(byref(self.handle),
                                   {'nlspn': _lib.PTTA_BACKBONE_NLSPN, 'costdcnet': _lib.PTTA_BACKBONE_COSTDCNET}.get(backbone, _lib.PTTA_BACKBONE_MSG_CHN),
                                   (_lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER) |

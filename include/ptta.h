@@ -70,6 +70,9 @@ enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1, PTTA_BACKBONE_COSTDCN
  *   storage, one bf16 MFMA per product, fp32 accumulate.  depth_train is bit-identical to PTTA_DTYPE_F32; measured budget per tensor
  *   class: profiles/r05_precision_budget.txt; bounds per mode: tests/test_gpu_mixed.py.  PTTA_ARITH=exact / PTTA_CONV_IMPL=naive are
  *   PTTA_DTYPE_F32-only (ptta_create returns -38 with PTTA_DTYPE_MIXED). */
+/* PTTA_BACKBONE_NLSPN with PTTA_DTYPE_MIXED: the generic engine keeps fp32 storage and switches the matrix-core convolutions of the proxy
+ * frames and of the data gradients to one bf16 MFMA per product (scored depth 2.0e-4 after config 3's three steps, 23.3 -> 21.5 ms per step).
+ * PTTA_BACKBONE_COSTDCNET refuses it (-38): its scored depth leaves the tolerance (profiles/r05_nlspn_costdcnet_mixed.txt). */
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_MIXED = 1,
        /* OR-ed into PTTA_DTYPE_MIXED (precision budget, tools/accuracy_report.py --keep): keep one of the three narrow classes at fp32 storage
         * and bf16x3 arithmetic -- the proxy chain, the data gradients, the heads */

@@ -37,13 +37,16 @@ def test_mixed_full_size_matches_reference(golden_dir, name, meta, path):
         info, depth = eng.step(image, sparse, want_depth=True, next_frame=nxt)
         torch.cuda.synchronize()
         # the training-mode depth is made of fp32 / bf16x3 tensors only: the fp32 mode's bound (second step: behind one mixed Adam move)
-        _check_map(depth, g, p + 'depth_train', 1e-4 if s == 0 else 3e-4)
-        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=1e-3)
+        # (bounds = 2x the worst figure of tools/mixed_report.py on MI355X, round 5; measured: depth_train 1.9e-5 / 3.7e-5 first / second step,
+        # depth_eval <= 8.5e-5, loss terms <= 8.3e-5, emb 1.5e-2, ref 6.3e-3, gradients 4.4e-3 (1layer) / 1.1e-2 (2layers), parameters
+        # 2.8e-4 / 2.5e-3, exp_avg 4.4e-3, exp_avg_sq 2.1e-4, BatchNorm running statistics 4.9e-3)
+        _check_map(depth, g, p + 'depth_train', 1e-4)
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=5e-4)
         if p + 'row_idx' in g.files:
             idx = g[p + 'row_idx']
             # narrow proxy features and (from round 5's heads) narrow embeddings: measured 2e-3 / 6e-3 -> bound 2x
-            assert rel_mae(eng.debug_tensor('emb').view(-1, 512).cpu()[idx], g[p + 'emb_rows']) < 4e-2
-            assert rel_mae(eng.debug_tensor('ref').view(-1, 512).cpu()[idx], g[p + 'ref_rows']) < 2e-2
+            assert rel_mae(eng.debug_tensor('emb').view(-1, 512).cpu()[idx], g[p + 'emb_rows']) < 3e-2
+            assert rel_mae(eng.debug_tensor('ref').view(-1, 512).cpu()[idx], g[p + 'ref_rows']) < 1.3e-2
         for k, (prm, m, v) in adapted.items():
             if p + 'grad/' + k not in g.files:
                 continue
@@ -52,8 +55,14 @@ def test_mixed_full_size_matches_reference(golden_dir, name, meta, path):
             if np.abs(gref).max() < 1e-6:                      # conv bias in front of a BatchNorm: analytically zero
                 assert float(got.abs().max()) < 1e-3
                 continue
-            assert rel_mae(got, gref) < (6e-2 if meta == '2layers' else 3e-2), (k, s, rel_mae(got, gref))
-            assert rel_mae(prm, g[p + 'param/' + k]) < 1e-2, k
+            assert rel_mae(got, gref) < (2.2e-2 if meta == '2layers' else 9e-3), (k, s, rel_mae(got, gref))
+            assert rel_mae(prm, g[p + 'param/' + k]) < (5e-3 if meta == '2layers' else 6e-4), k
+            if p + 'exp_avg/' + k in g.files:
+                assert rel_mae(m, g[p + 'exp_avg/' + k]) < 9e-3
+                assert rel_mae(v, g[p + 'exp_avg_sq/' + k]) < 4.2e-4
+        for k in g.files:
+            if k.startswith(p + 'buf/') and not k[len(p) + 4:].startswith('proj_t'):
+                assert rel_mae(sd[k[len(p) + 4:]], g[k]) < 1e-2, k
         d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
         _check_map(d_eval, g, p + 'depth_eval', 3e-4)
     eng.close()
@@ -91,9 +100,14 @@ def test_mixed_ten_step_sequence_matches_reference(golden_dir):
         image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s, h, w, n)]
         p = 's%d/' % s
         info, depth = eng.step(image, sparse, want_depth=True)
-        _check_map(depth, g, p + 'depth_train', 1e-3)
-        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=1e-3)
-        _check_map(eng.forward_eval(image, sparse), g, p + 'depth_eval', 1e-3)
+        # measured (tools/mixed_report.py): the depth maps drift to 1.75e-4 by the tenth step (fp32 mode: 3.4e-5), loss terms <= 1.1e-4
+        _check_map(depth, g, p + 'depth_train', 3.5e-4)
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=3e-4)
+        _check_map(eng.forward_eval(image, sparse), g, p + 'depth_eval', 3.5e-4)
+    p = 's%d/' % (steps - 1)
+    for k, (prm, m, v) in adapted.items():
+        assert rel_mae(prm, g[p + 'param/' + k]) < 2.2e-3, k           # measured 1.1e-3
+        assert rel_mae(m, g[p + 'exp_avg/' + k]) < 7.4e-3, k           # measured 3.7e-3
     assert eng.adam_step_count() == steps
     eng.close()
 
@@ -119,14 +133,14 @@ def test_mixed_cosine_gate_on_the_reference_side(golden_dir, side, path):
         torch.cuda.synchronize()
         li = info.cpu().numpy()
         assert (li[3] < 0.3) == below
-        np.testing.assert_allclose(li, g[p + 'loss_info'], rtol=3e-3)
+        np.testing.assert_allclose(li, g[p + 'loss_info'], rtol=3e-4)            # measured <= 1.2e-4
         dense = hp['w_sparse_depth'] * li[2] + hp['w_smoothness'] * li[1]
         assert abs(li[0] - dense) < 1e-4 * li[0] if below else li[0] > dense + 100.0
-        assert rel_mae(depth, g[p + 'depth_train']) < (1e-4 if s == 0 else 1e-3)
+        assert rel_mae(depth, g[p + 'depth_train']) < 1e-4                      # measured <= 4.5e-5
         gw = eng.debug_tensor('gW').view(32, 32, 3, 3)
-        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < 6e-2, (side, s, rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']))
+        assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < 3.1e-2, (side, s, rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']))     # measured 1.5e-2
         d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
-        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-3
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1.4e-4                    # measured 6.8e-5
     eng.close()
 
 
@@ -184,23 +198,54 @@ def test_mixed_small_goldens_split_calls_and_fused_step(golden_dir, name):
         p = 's%d/' % s
         bufs = {k: v.clone() for k, v in sd.items() if k.endswith(('running_mean', 'running_var'))}
         depth, emb, ref = eng.forward_train(image, sparse)
-        assert rel_mae(depth, g[p + 'depth_train']) < (1e-4 if s == 0 else 1e-3), (name, s)
+        # measured (tools/mixed_report.py): depth_train <= 7.2e-5, depth_eval <= 1.07e-4 (2layers, second step), loss terms <= 2.4e-4,
+        # gradients <= 1.3e-2 (1layer) / 1.83e-2 (2layers)
+        assert rel_mae(depth, g[p + 'depth_train']) < 1.5e-4, (name, s)
         idx = g[p + 'row_idx']
-        assert rel_mae(emb.cpu()[idx], g[p + 'emb_rows']) < 4e-2
-        assert rel_mae(ref.cpu()[idx], g[p + 'ref_rows']) < 2e-2
+        assert rel_mae(emb.cpu()[idx], g[p + 'emb_rows']) < 3e-2
+        assert rel_mae(ref.cpu()[idx], g[p + 'ref_rows']) < 1.3e-2
         for k, v in bufs.items():
             sd[k].copy_(v)
         info, depth2 = eng.step(image, sparse, want_depth=True)
         torch.cuda.synchronize()
-        assert rel_mae(depth2, g[p + 'depth_train']) < (1e-4 if s == 0 else 1e-3)
-        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2e-3)
+        assert rel_mae(depth2, g[p + 'depth_train']) < 1.5e-4
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=5e-4)
         for k, (prm, m, v) in adapted.items():
             gref = g[p + 'grad/' + k]
             got = eng.grad(k, prm)
             if np.abs(gref).max() < 1e-6:
                 assert float(got.abs().max()) < 1e-3
                 continue
-            assert rel_mae(got, gref) < 8e-2, (name, k, s, rel_mae(got, gref))
+            assert rel_mae(got, gref) < (3.7e-2 if meta == '2layers' else 2.6e-2), (name, k, s, rel_mae(got, gref))
         d_eval = eng.forward_eval(image, sparse)
-        assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-3
+        assert rel_mae(d_eval, g[p + 'depth_eval']) < 2.2e-4
     eng.close()
+
+
+def test_nlspn_mixed_three_steps_on_one_full_size_frame(golden_dir):
+    """BASELINE config 3 (inner_iter = 3 on ONE 352x1216 frame) with the generic engine's mixed mode: fp32 storage, one bf16 MFMA per product
+    for the proxy frames' convolutions and for every data gradient, bf16x3 for the real frames' forward.  Measured on MI355X
+    (tools/generic_mixed_report.py, profiles/r05_nlspn_costdcnet_mixed.txt): training depth 2.6e-6 / 8.1e-5 / 1.5e-4, scored depth
+    8.1e-5 / 1.5e-4 / 2.0e-4 over the three steps, loss terms <= 1.2e-4 -- inside the 3e-4 target; 23.3 -> 21.5 ms per step."""
+    from tests.test_gpu_nlspn import make_nlspn, nlspn_frame
+    g = np.load(os.path.join(golden_dir, 'nlspn_352x1216_legacy_inner3.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
+    hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=mid, dtype='mixed')
+    eng, sd, adapted = make_nlspn(n, h, w, hp, legacy=True)
+    raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(0, h, w, n)]
+    for s in range(steps):
+        p = 's%d/' % s
+        info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+        _check_map(depth, g, p + 'depth_train', 3e-5 if s == 0 else 3e-4)
+        np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=2.5e-4)
+        _check_map(eng.forward_eval(image1, sparse), g, p + 'depth_eval', 3e-4)
+    eng.close()
+
+
+def test_costdcnet_has_no_mixed_mode():
+    """With single-MFMA data gradients CostDCNet's scored depth leaves the north_star's tolerance (2.0e-3 at 480x640: near-zero gradient
+    entries take the opposite first Adam step); the mode is refused, not offered with a loose bound."""
+    from proxytta.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine(1, 64, 96, backbone='costdcnet', max_predict_depth=8.0, dtype='mixed')

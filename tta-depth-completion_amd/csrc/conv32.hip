@@ -211,7 +211,11 @@ template <> struct Geo<bf16_t> { static constexpr int STR = 80, LO = 0, WL = 0, 
 // at either pixel stride their footprints then fall on disjoint banks
 __device__ __forceinline__ int x3_stage_pix(int idx) { return ((idx >> 5) << 3) + (((idx >> 2) & 1) << 2) + ((idx >> 3) & 3); }
 
-// one (tap, k-step) of the implicit GEMM: a = the lane's A fragment in the LDS tile (hi at a, lo at a + LO)
+// one (tap, k-step) of the implicit GEMM: a = the lane's A fragment in the LDS tile (hi at a, lo at a + LO); the hi weight fragment is
+// wave-stationary in registers (wh), the lo fragment (fp32 storage) comes from LDS (wl).
+// (Round 5 measured the narrow kernels with their ONLY weight fragment in LDS as well -- 72 registers less, three resident blocks per CU
+// without spills: the full-resolution masked stride-1 launch went from 16.2 to 19.3 us.  At one MFMA per fragment pair the A fragment's
+// 1 KB per wave and matrix instruction already takes half of the LDS's 256 B/clk; a second KB for the B fragment saturates it.)
 template <typename T>
 __device__ __forceinline__ void mma_step(f32x16& acc, const unsigned char* a, const uint4& wh, const unsigned char* wl) {
     const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
@@ -223,6 +227,19 @@ __device__ __forceinline__ void mma_step(f32x16& acc, const unsigned char* a, co
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
     }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+// the block's weight fragments: hi in registers (wh); fp32 storage: lo in LDS
+template <typename T>
+__device__ __forceinline__ void load_weights(uint4 (&wh)[9][2], unsigned char* wl_lds, const void* wpack, const void* wpack2, int tid, int lane) {
+    const uint4* ph = (const uint4*)wpack;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+    if constexpr (sizeof(T) == 4) {
+        const uint4* pl = (const uint4*)wpack2;
+        for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
+    }
 }
 
 // bilinear x2 skip: the half-resolution source window of a tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers,
@@ -289,17 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
     if (PREFETCH && blockIdx.x < ntiles) issue_loads(blockIdx.x);
     // weight fragments: loaded AFTER the first tile's loads were issued so that the two L2 round trips overlap
     uint4 wh[9][2];
-    {
-        const uint4* ph = (const uint4*)p.wpack;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-        if constexpr (WL > 0) {
-            const uint4* pl = (const uint4*)p.wpack2;
-            for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
-        }
-    }
+    load_weights<T>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y0, x0;
@@ -443,19 +450,25 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
     };
     if (blockIdx.x < ntiles) { load_planes(blockIdx.x); load_masks(blockIdx.x); }
     uint4 wh[9][2];
-    float w1[NS];
-    {
-        const uint4* ph = (const uint4*)p.wpack;
+    constexpr bool NARF = sizeof(T) == 2;            // narrow: the FIRST convolution on the bf16 matrix cores too (K = 9 cin <= 27 padded to 32: two
+                                                     // v_mfma_f32_32x32x16_bf16 instead of fourteen v_mfma_f32_32x32x2_f32 per 32 halo pixels)
+    float w1[NARF ? 1 : NS];
+    uint4 w1b[2];                                    // NARF: the first convolution's weights as two bf16 B fragments (k = 16 ks + 8 h + e)
+    load_weights<T>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
+    if constexpr (NARF) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int ks = 0; ks < 2; ++ks) {
+            float wv[8];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * ks + 8 * h + e;               // fp32 fragment layout (ptta_pack_conv_in): [k >> 1][lane = (k & 1) * 32 + cout]
+                wv[e] = k < K1 ? f.w1[(k >> 1) * 64 + (k & 1) * 32 + i] : 0.f;
+            }
+            w1b[ks] = make_uint4(pack_bf2(wv[0], wv[1]), pack_bf2(wv[2], wv[3]), pack_bf2(wv[4], wv[5]), pack_bf2(wv[6], wv[7]));
+        }
+    } else {
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) w1[s_] = f.w1[s_ * 64 + lane];
-        if constexpr (WL > 0) {
-            const uint4* pl = (const uint4*)p.wpack2;
-            for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
-        }
     }
     const float b1 = f.bias1 ? f.bias1[i] : 0.f;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -478,6 +491,23 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if constexpr (NARF) {
+                // A fragment of lane (pixel i_, half h), k-step ks: input values k = 16 ks + 8 h + e -> (tap, plane) at compile-time offsets per h
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    float av[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ka = 16 * ks + e, kb = 16 * ks + 8 + e;          // the two candidates (h = 0 / 1)
+                        const int oa = ka < K1 ? (ka % CIN) * PLANE + ((ka / CIN) / 3) * PL_W + (ka / CIN) % 3 : -1;
+                        const int ob = kb < K1 ? (kb % CIN) * PLANE + ((kb / CIN) / 3) * PL_W + (kb / CIN) % 3 : -1;
+                        const float va = oa >= 0 ? base[oa] : 0.f, vb = ob >= 0 ? base[ob] : 0.f;
+                        av[e] = h ? vb : va;
+                    }
+                    const uint4 af = make_uint4(pack_bf2(av[0], av[1]), pack_bf2(av[2], av[3]), pack_bf2(av[4], av[5]), pack_bf2(av[6], av[7]));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, w1b[ks]), acc, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
             for (int s_ = 0; s_ < NS; ++s_) {
                 const int k0 = 2 * s_, k1 = 2 * s_ + 1;
@@ -485,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
                 const int o1 = (k1 < K1) ? (k1 % CIN) * PLANE + ((k1 / CIN) / 3) * PL_W + (k1 / CIN) % 3 : -1;
                 const float a = h ? (o1 >= 0 ? base[o1] : planes[CIN * PLANE]) : base[o0];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1[s_], acc, 0, 0, 0);
+            }
             }
             f32x16 t;
 #pragma unroll
@@ -687,7 +718,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
 // box): its 79 KB of LDS cannot share a CU with the 120 KB GEMM blocks of the heads that run beside decoder 3, this
 // form's 18 KB can -- reverted.
 template <typename T, int MODE, bool RELU, bool UP, bool MASK, bool ADD>
-__global__ __launch_bounds__(256, 2) void conv32_direct_x3_kernel(Conv32P<T> p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv32_direct_x3_kernel(Conv32P<T> p) {
     constexpr bool F32 = sizeof(T) == 4;
     __shared__ __attribute__((aligned(16))) unsigned char wl_lds[(F32 ? 2 : 1) * 18 * 64 * 16];     // [hi | lo][tap][k][lane] weight fragments
     const int tid = threadIdx.x, lane = tid & 63;
@@ -806,8 +837,9 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
     constexpr bool F32 = sizeof(T) == 4;
     constexpr int NPIX = S2_PH * S2_PW, NIT = (NPIX * 2 + 255) / 256;
     constexpr int WL = F32 ? 18 * 64 * 16 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * S2_STR + WL + 16];
-    unsigned char* const wl_lds = lds + NPIX * S2_STR;
+    constexpr int STR = F32 ? S2_STR : 48;                          // narrow: hi 32 B | pad 16 B per pixel and k-step (three blocks per CU)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * STR + WL + 16];
+    unsigned char* const wl_lds = lds + NPIX * STR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -838,17 +870,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
     const long first = 2L * blockIdx.x, sstride = 2L * gridDim.x;       // this block's stages: 2t, 2t+1 of its tiles
     if (first < nstages) issue_loads(first);
     uint4 wh[9][2];
-    {
-        const uint4* ph = (const uint4*)p.wpack;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-        if constexpr (F32) {
-            const uint4* pl = (const uint4*)p.wpack2;
-            for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
-        }
-    }
+    load_weights<T>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
     f32x16 acc;
     bool started = false;
     for (long base = first; base < nstages; base += sstride) {
@@ -862,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
             for (int it = 0; it < NIT; ++it) {
                 const int idx = tid + 256 * it;
                 const int pix = idx >> 1;
-                if (pix < NPIX) px_stage<RELU>(v[it], lds + pix * S2_STR + 16 * (idx & 1), 32);
+                if (pix < NPIX) px_stage<RELU>(v[it], lds + pix * STR + 16 * (idx & 1), 32);
             }
             {   // next stage's loads: the other k-step of this tile, or the first k-step of the block's next tile
                 const long nxt = q == 0 ? base + 1 : base + sstride;
@@ -877,7 +899,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int ky = tap / 3, kx = tap % 3;
-                    const unsigned char* a = lds + ((2 * wave + ky) * S2_PW + 2 * i + kx) * S2_STR + 16 * h;
+                    const unsigned char* a = lds + ((2 * wave + ky) * S2_PW + 2 * i + kx) * STR + 16 * h;
                     const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
                     const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][q]);
                     if constexpr (F32) {
@@ -1020,6 +1042,9 @@ static void launch_direct_x3(const Conv32P<T>& p, int flags, int blocks, hipStre
 // replay, pipelined / call by call: 512 1.698 / 1.819, 496 1.699, 480 1.681 / 1.803, 464 1.698, 448 1.73, 416 1.81; the first-layer /
 // strided / transposed kernels stay at 512 (480 there: 1.689 vs 1.688).
 static constexpr int kFullChipBlocks = 512, kS1Blocks = 480;
+// narrow kernels (half the LDS tile, ~160 VGPRs): three resident blocks per CU
+static constexpr int kNarrowBlocks = 768;         // (the direct kernel only: <= 160 VGPRs, 18 KB LDS)
+static int env_narrow_blocks() { static const int v = getenv("PTTA_NARROW_BLOCKS") ? atoi(getenv("PTTA_NARROW_BLOCKS")) : kNarrowBlocks; return v < 1 ? 1 : v; }
 
 template <typename T, int MODE>
 static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
@@ -1054,7 +1079,8 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         }
         const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
         const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
-        long blocks = (items + 3) / 4; if (blocks > kFullChipBlocks) blocks = kFullChipBlocks;
+        const int capd = NAR ? env_narrow_blocks() : kFullChipBlocks;
+        long blocks = (items + 3) / 4; if (blocks > capd) blocks = capd;
         if (MODE == CONV_S2 && !(flags & 1)) {
             const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + S2_TH - 1) / S2_TH);
             const int tb = (int)(tiles < kFullChipBlocks ? tiles : kFullChipBlocks);

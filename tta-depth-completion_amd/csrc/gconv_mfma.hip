@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
     const int nch0 = (p.C0 + 31) >> 5;
     const int nq = 2 * p.nchunks;
     const bool six = SIX && b < p.six_B;                 // block-uniform
+    const bool x1 = b >= p.x1_from_B;                    // block-uniform: images of the single-MFMA class (mixed mode: proxy frames, data gradients)
 
     float4 v0[NIT], v1[NIT];
     uint4 wr[NW];
@@ -221,10 +222,12 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bl, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bl, acc[1], 0, 0, 0);
             }
+            if (!x1) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh, acc[1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl, acc[1], 0, 0, 0);
+            }
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh, acc[1], 0, 0, 0);
         }
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
     const int x0 = seg << 5, ybase = yg * R;
     const bool lane_in = (x0 + i) < Wt;
     const bool six = SIX && b < p.six_B;                 // wave-uniform
+    const bool x1 = b >= p.x1_from_B;                    // wave-uniform: single-MFMA class
     f32x16 acc[NCO][R];
 #pragma unroll
     for (int t = 0; t < NCO; ++t)
@@ -458,8 +462,10 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
                 for (int rr = 0; rr < R; ++rr)
 #pragma unroll
                     for (int t = 0; t < NCO; ++t) {
+                        if (!x1) {
                         acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh[t], acc[t][rr], 0, 0, 0);
                         acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl[t], acc[t][rr], 0, 0, 0);
+                        }
                         acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bh[t], acc[t][rr], 0, 0, 0);
                     }
             }

@@ -129,6 +129,9 @@ struct GNet {
     float *depth = nullptr, *gdepth = nullptr;     // (Nu,1,Hu,Wu): network output / its gradient
     int t_emb = -1, t_ref = -1;
     int naive = 0;
+    // mixed mode (include/ptta.h PTTA_DTYPE_MIXED for the generic engine): fp32 storage everywhere; the matrix-core convolutions of the
+    // proxy frames (bit 0) and of the data gradients (bit 1) take one bf16 MFMA per product instead of three (GX3Args::x1_from_B)
+    int mixed = 0;
     // bf16x6 forward for the real frames (GX3Args::six_B): the two-way operand split's 2^-17 representation error reaches the depth
     // map as ~2e-5 relative, enough to flip the sign of near-zero gradient entries -- and Adam's first step turns a sign into +-lr
     // (CostDCNet: post-update eval depth 1.6e-3 from the reference with bf16x3).  PTTA_X6=0/1 overrides.

@@ -85,6 +85,7 @@ int GNet::run_conv_fwd(const Op& o, bool train, hipStream_t s) {
         if (cw.ff_l2 && o.yw != W_PROXY && x6_layer(o.wname)) {               // bf16x6 for the real frames (they come first in a [real | proxy] batch)
             a.wl2 = (const uint4*)cw.ff_l2; a.six_B = (o.yw == W_BOTH && train) ? y.B / 2 : y.B;
         }
+        if ((mixed & 1) && train && o.yw != W_GRAD) a.x1_from_B = o.yw == W_BOTH ? y.B / 2 : 0;     // the proxy frames' products: one MFMA
         if (o.stat_to >= 0 && (train || !ops[o.stat_to].tracked)) {
             a.stat_part = ops[o.stat_to].part; a.stat_C = y.C; a.stat_npass = (o.yw == W_BOTH && train) ? 2 : 1;
         }
@@ -162,6 +163,7 @@ int GNet::run_conv_bwd(const Op& o, hipStream_t s) {
             a.y = gx.p; a.ldy = gx.ld; a.Cy = gx.C; a.accumulate = o.first_x[sidx] ? 0 : 1;
             a.B = gx.B; a.H = gx.H; a.W = gx.W;                  // output geometry = the source's
             a.vert = cw.vcol;
+            if (mixed & 2) a.x1_from_B = 0;                      // data gradients: one MFMA per product
             int rc;
             if (o.stride == 1 && !o.transposed) rc = ptta_launch_gconv_x3(a, o.k, s);
             else rc = ptta_launch_gconv_x3_strided(a, o.k, o.transposed ? 1 : 2, gy.H, gy.W, s);     // convT -> strided conv, strided conv -> convT

@@ -1485,21 +1485,29 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return -19;          // no HIP device: fail loudly
+    // generic engine (NLSPN, CostDCNet): PTTA_DTYPE_MIXED = fp32 storage, single-MFMA products for the proxy frames and the data gradients
+    // (PTTA_MIXED_KEEP_PROXY / _BACKWARD keep a class at bf16x3); the heads of those backbones are 0.4 % of their step and stay bf16x3
+    const int gmix = (dtype & 0xff) == PTTA_DTYPE_MIXED ? ((((dtype >> 8) & 1) ? 0 : 1) | (((dtype >> 8) & 2) ? 0 : 2)) : 0;
+    if (backbone_id != PTTA_BACKBONE_MSG_CHN && (dtype & 0xff) == PTTA_DTYPE_MIXED) dtype = PTTA_DTYPE_F32;
     if (backbone_id == PTTA_BACKBONE_NLSPN) {
         if ((meta_mode & ~(PTTA_NLSPN_LEGACY_OFFSET | PTTA_NLSPN_SYNCBN_ADAPT)) != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32) return -38;
         int rc = 0;
         GNet* e = nlspn_create(n, height, width, hp, ((meta_mode & PTTA_NLSPN_LEGACY_OFFSET) ? 1 : 0) | ((meta_mode & PTTA_NLSPN_SYNCBN_ADAPT) ? 2 : 0), &rc);
         if (!e) return rc ? rc : -12;
+        e->mixed = e->naive ? 0 : gmix;
         ptta_ctx* c = new ptta_ctx();
         c->nl = e; c->N = n; c->H = height; c->W = width; c->hp = *hp;
         *out = c;
         return 0;
     }
     if (backbone_id == PTTA_BACKBONE_COSTDCNET) {
-        if ((meta_mode & ~PTTA_SYNCBN_ADAPT) != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32 || !hp) return -38;
+        // (no mixed mode for CostDCNet: with single-MFMA data gradients its scored depth leaves the tolerance -- 2.0e-3 / 1.7e-3 at 480x640 /
+        // 320x400, with single-MFMA proxy frames alone 8.9e-4 at 320x400, for 3 % of the step: profiles/r05_nlspn_costdcnet_mixed.txt)
+        if ((meta_mode & ~PTTA_SYNCBN_ADAPT) != PTTA_META_1LAYER || dtype != PTTA_DTYPE_F32 || !hp || gmix) return -38;
         int rc = 0;
         GNet* e = costdc_create(n, height, width, hp, hp->max_predict_depth, (meta_mode & PTTA_SYNCBN_ADAPT) ? 1 : 0, &rc);
         if (!e) return rc ? rc : -12;
+        e->mixed = e->naive ? 0 : gmix;
         ptta_ctx* c = new ptta_ctx();
         c->nl = e; c->N = n; c->H = height; c->W = width; c->hp = *hp;
         *out = c;

@@ -315,6 +315,9 @@ struct GX3Args {
     // split x = h + m + l, w = h + m + l and the six products down to 2^-16 (hh, hm, mh, mm, hl, lh): fp32-grade products where the
     // two-way split's 2^-17 operand error is too much (CostDCNet: gradient signs after the first Adam step); wl2 = the weights' l plane
     const uint4* wl2 = nullptr; int six_B = 0;
+    // mixed mode of the generic engine: images b >= x1_from_B take ONE bf16 MFMA per product (hi x hi) instead of three -- the proxy frames
+    // of a [real | proxy] launch (the reference's no_grad pass) and every data-gradient launch (x1_from_B = 0)
+    int x1_from_B = 1 << 30;
 };
 void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
                      hipStream_t s, bf16_t* l2 = nullptr);

@@ -162,9 +162,9 @@ __global__ void up2T_32_kernel(const T* __restrict__ gout, const T* __restrict__
                 if constexpr (sizeof(T) == 4) {             // one 16-B load per tap (the channel quad is 16-B aligned)
                     const float4 v = *(const float4*)q;
                     acc[0] += wgt * v.x; acc[1] += wgt * v.y; acc[2] += wgt * v.z; acc[3] += wgt * v.w;
-                } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] += wgt * ld(q + c);
+                } else {                                    // narrow maps: one 8-B load per tap
+                    const float4 v = bf4_to_f4(*(const uint2*)q);
+                    acc[0] += wgt * v.x; acc[1] += wgt * v.y; acc[2] += wgt * v.z; acc[3] += wgt * v.w;
                 }
             }
         }
@@ -174,12 +174,9 @@ __global__ void up2T_32_kernel(const T* __restrict__ gout, const T* __restrict__
             if (add) { const float4 a = *(const float4*)(add + o); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
             *(float4*)(gin + o) = v;
         } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float v = acc[c];
-            if (add) v += ld(add + o + c);
-            st(gin + o + c, v);
-        }
+            float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (add) { const float4 a = bf4_to_f4(*(const uint2*)(add + o)); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            *(uint2*)(gin + o) = f4_to_bf4(v);
         }
     }
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — ProxyTTA step throughput on MI355X (metric of BASELINE.json).
 
-  python bench.py --gpus N --steps K --warmup W [--dtype fp32|bf16]
+  python bench.py --gpus N --steps K --warmup W [--dtype mixed|fp32]
 
 One "step" = one pass of the hot path (forward [grad + proxy pass + heads] + loss + backward +
 Adam, src/tta_main.py:610-633) over one synthetic 352x1216 KITTI-shaped frame, MSG_CHN backbone,
@@ -31,6 +31,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'tta-depth-completion_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+# Kernel arguments in device memory: the bench process asks for it BEFORE the HIP runtime exists (forced to 0 the replayed step is 7 % slower:
+# every launch of a replayed graph then fetches its arguments across the host link).  A user's own setting is kept; the JSON line reports
+# what the run had (`config.hip_force_dev_kernarg`).  The library and its Python binding never touch the environment.
+KERNARG_PRESET = os.environ.get('HIP_FORCE_DEV_KERNARG')
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -248,14 +254,14 @@ def two_streams_workload(steps=100, nstreams=2):
     return out
 
 
-def nlspn_workload(frames=10, inner_iter=3):
+def nlspn_workload(frames=10, inner_iter=3, dtype='fp32'):
     """BASELINE config 3 (not the headline metric): NLSPN backbone, 352x1216, 3 TTA steps per frame + the scored eval
     forward, adapt_mode meta_bn (88 adapted tensors), batch 1, inputs resident in HBM.  Reported beside the metric."""
     from proxytta import synth
     from proxytta.engine import Engine
     mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
     std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
-    eng = Engine(1, H, W, backbone='nlspn', legacy_offset=True, lr=3e-4, w_sparse_depth=1.0, w_smoothness=0.0, w_cos=0.0, max_input_depth=80.0)
+    eng = Engine(1, H, W, backbone='nlspn', dtype=dtype, legacy_offset=True, lr=3e-4, w_sparse_depth=1.0, w_smoothness=0.0, w_cos=0.0, max_input_depth=80.0)
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
     eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32})
     keep = []
@@ -288,6 +294,11 @@ def nlspn_workload(frames=10, inner_iter=3):
                                                 'note': 'bf16x3: three bf16 MFMAs per fp32 product; frac counts all three, frac_useful = frac / 3 is the fp32-equivalent rate against the same bf16 peak'})(*nlspn_macs(H, W)),
            'finite': bool(torch.isfinite(info).all().item() and torch.isfinite(d).all().item())}
     eng.close()
+    if dtype == 'fp32':
+        # the generic engine's mixed mode beside it (fp32 storage; one bf16 MFMA per product for the proxy frames and the data gradients;
+        # scored depth 2.0e-4 after the three steps: tests/test_gpu_mixed.py, profiles/r05_nlspn_costdcnet_mixed.txt)
+        m = nlspn_workload(frames, inner_iter, dtype='mixed')
+        out['mixed_mode'] = {'ms_per_step': m['ms_per_step'], 'frames_per_s': m['frames_per_s'], 'eval_forward_ms': m['eval_forward_ms'], 'finite': m['finite']}
     return out
 
 
@@ -530,9 +541,34 @@ def launch_ranks(args, argv):
     return max(abs(rc) for rc in rcs)
 
 
+def render_minor_of_hip_device(index):
+    """DRM render minor of HIP device `index` WITHOUT touching the GPU: HIP enumerates the KFD topology's GPU nodes in node order
+    (/sys/class/kfd/kfd/topology/nodes/<n>/properties: simd_count > 0, drm_render_minor), filtered by ROCR_VISIBLE_DEVICES and then
+    HIP_VISIBLE_DEVICES when those are plain index lists.  Returns (minor, how) or (None, reason): renderD(128 + index) is NOT assumed --
+    the DRM minors follow PCI probe order, which need not be the runtime's order."""
+    base = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        minors = []
+        for n in sorted(int(x) for x in os.listdir(base) if x.isdigit()):
+            props = dict(l.split(None, 1) for l in open('%s/%d/properties' % (base, n)).read().splitlines() if ' ' in l)
+            if int(props.get('simd_count', '0')) > 0 and int(props.get('drm_render_minor', '0')) > 0:
+                minors.append(int(props['drm_render_minor']))
+        for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+            v = os.environ.get(var, '').strip()
+            if v:
+                if not all(t.strip().isdigit() for t in v.split(',')):
+                    return None, '%s is not an index list' % var
+                minors = [minors[int(t)] for t in v.split(',') if int(t) < len(minors)]
+        if index < len(minors):
+            return minors[index], 'kfd topology'
+        return None, 'kfd topology lists %d GPU(s)' % len(minors)
+    except (OSError, ValueError, IndexError) as e:
+        return None, 'kfd topology unreadable (%s)' % type(e).__name__
+
+
 def pin_rank_to_local_cpus(local_rank, ranks_on_node):
     """Before any HIP call: restrict this rank (its Python launch loop, the staging copies, the runtime's helper threads) to the CPUs next
-    to its GPU -- the GPU's NUMA node when sysfs names it (/sys/class/drm/renderD<128 + i>/device/local_cpulist), otherwise an even slice
+    to its GPU -- the NUMA node sysfs names for the GPU's render node (render_minor_of_hip_device; local_cpulist), otherwise an even slice
     of the CPUs this process may use.  Eight launch loops migrating over one host is where the >= 6x of config 4 would be lost first.
     Returns a description for the JSON line."""
     try:
@@ -542,21 +578,27 @@ def pin_rank_to_local_cpus(local_rank, ranks_on_node):
     if ranks_on_node <= 1 or len(allowed) < 2 * ranks_on_node:
         return 'unchanged (%d CPUs, %d rank(s))' % (len(allowed), ranks_on_node)
     cpus, how = None, 'even slice'
+
+    def cpulist(rank):
+        minor, _ = render_minor_of_hip_device(rank)
+        return None if minor is None else open('/sys/class/drm/renderD%d/device/local_cpulist' % minor).read().strip()
     try:
-        txt = open('/sys/class/drm/renderD%d/device/local_cpulist' % (128 + local_rank)).read().strip()
-        near = set()
-        for part in txt.split(','):
-            a, _, b = part.partition('-')
-            near.update(range(int(a), int(b or a) + 1))
-        near = sorted(near & set(allowed))
-        # several GPUs share a NUMA node: slice that node's CPUs among them by local rank
-        if len(near) >= 2:
-            peers = [r for r in range(ranks_on_node)
-                     if os.path.exists('/sys/class/drm/renderD%d/device/local_cpulist' % (128 + r))
-                     and open('/sys/class/drm/renderD%d/device/local_cpulist' % (128 + r)).read().strip() == txt]
-            k, n = (peers.index(local_rank), len(peers)) if local_rank in peers else (0, 1)
-            step = max(len(near) // n, 1)
-            cpus, how = near[k * step:(k + 1) * step] or near, 'NUMA-local (%s), slice %d/%d' % (txt, k, n)
+        minor, why = render_minor_of_hip_device(local_rank)
+        if minor is None:
+            how = 'even slice (%s)' % why
+        else:
+            txt = cpulist(local_rank)
+            near = set()
+            for part in txt.split(','):
+                a, _, b = part.partition('-')
+                near.update(range(int(a), int(b or a) + 1))
+            near = sorted(near & set(allowed))
+            # several GPUs share a NUMA node: slice that node's CPUs among them by local rank
+            if len(near) >= 2:
+                peers = [r for r in range(ranks_on_node) if cpulist(r) == txt]
+                k, n = (peers.index(local_rank), len(peers)) if local_rank in peers else (0, 1)
+                step = max(len(near) // n, 1)
+                cpus, how = near[k * step:(k + 1) * step] or near, 'NUMA-local to renderD%d (%s), slice %d/%d' % (minor, txt, k, n)
     except (OSError, ValueError):
         pass
     if not cpus:
@@ -686,7 +728,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'fp32'), choices=['fp32', 'mixed'])
+    ap.add_argument('--dtype', default=os.environ.get('PTTA_BENCH_DTYPE', 'mixed'), choices=['fp32', 'mixed'],
+                    help="'mixed' (default): BASELINE config 2 -- the scored depth's tensors fp32 / bf16x3, the no_grad proxy pass, the heads and the "
+                         "data gradients bf16 / single MFMA (include/ptta.h PTTA_DTYPE_MIXED); 'fp32': every tensor fp32 / bf16x3")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-block', action='store_true', help='time ONE block of --steps steps (quick A/B runs) instead of >= 10 blocks / >= 200 steps')
     ap.add_argument('--no-self-check', action='store_true', help='skip the pipelined-vs-plain bitwise replay on fresh handles')
@@ -705,6 +749,8 @@ def main():
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    kernarg = {'value': os.environ.get('HIP_FORCE_DEV_KERNARG'), 'set_by': 'caller' if KERNARG_PRESET is not None else 'bench.py, before the HIP runtime was loaded',
+               'note': 'kernel arguments in device memory; 0 measured 7 % slower on the replayed step (DESIGN.md); the library never sets it'}
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)' % (args.gpus, world))
@@ -794,6 +840,27 @@ def main():
             torch.cuda.synchronize()
             pb.append(1e3 * (time.perf_counter() - tp) / args.steps)
         plain_ms = float(np.median(pb))
+    # the all-fp32 mode beside the headline (same protocol, fresh handle): what the mixed mode buys on this box in this run
+    other_dtype_ms = None
+    if world == 1 and not args.no_self_check:
+        od = 'fp32' if args.dtype == 'mixed' else 'mixed'
+        e2 = Engine(1, H, W, dtype=od, **HP)
+        sd2 = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
+        e2.load_state_dict(sd2)
+        for name in ADAPTED:
+            e2.bind_adapted(name, sd2[name], torch.zeros_like(sd2[name]), torch.zeros_like(sd2[name]))
+        for i in range(max(args.warmup, 3)):
+            e2.step(*frames[i % nframes], next_frame=nxt(i))
+        ob = []
+        for blk in range(min(nblocks, 5)):
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for i in range(args.steps):
+                e2.step(*frames[i % nframes], next_frame=nxt(i))
+            torch.cuda.synchronize()
+            ob.append(1e3 * (time.perf_counter() - tp) / args.steps)
+        other_dtype_ms = {'dtype': od, 'ms_per_step': float(np.median(ob)), 'blocks': len(ob)}
+        e2.close()
     # Second figure: the same K steps with every frame starting in PAGEABLE HOST memory, as the reference's
     # dataloader hands it over (src/tta_main.py:519-523): pinned triple buffer + copy stream, frame k+1 travels while frame k
     # is adapted.  Never `value` (that one is HBM-resident by contract).
@@ -849,17 +916,16 @@ def main():
         eq_plain = pipelined_self_check(args.dtype, min(args.steps, 12), rank)
 
     if rank == 0:
-        es = 4
         mixed = args.dtype == 'mixed'
         steps_per_s = world * args.steps / elapsed
-        if True:
-            # fp32 storage, bf16x3 arithmetic: 3 x 2 x MACs bf16 FLOP against 256 B of fp32 I/O per pixel
-            # -> arithmetic intensity 3*18432*... = 216 FLOP/B < ridge 312: HBM is the roof
-            achieved = abytes / (ms * 1e-3) / 1e9
-            roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': achieved / (HBM_PEAK / 1e9), 'mfma_bf16_tflops': 3 * 2.0 * macs / (ms * 1e-3) / 1e12}
-        roof.update({'kernel': ('stride-1 3x3 32->32 convolutions with ReLU on load: conv32_s1_x3_kernel<true, *> (large maps) + conv32_s1_small_kernel<true, *> '
-                                '(maps of <= 256 tiles)' if es == 4 else 'conv32_mfma_kernel<bf16, CONV_S1, relu, *>'),
+        # fp32 storage, bf16x3 arithmetic: 3 x 2 x MACs bf16 FLOP against 256 B of fp32 I/O per pixel -> 216 FLOP/B < ridge 312: HBM is the roof
+        # (narrow launches: 1 x 2 x MACs against 128 B -> 144 FLOP/B: HBM again)
+        achieved = abytes / (ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / (HBM_PEAK / 1e9)}
+        roof.update({'kernel': ('stride-1 3x3 32->32 convolutions with ReLU on load: conv32_s1_x3_kernel<T, RELU = true, *> (large maps) + '
+                                'conv32_s1_small_kernel<T, true, *> (maps of <= 256 tiles)' +
+                                ('; T = float for the real frames, unsigned short (bf16) for the proxy frames -- both counted, bytes at the stored width'
+                                 if mixed else '; T = float')),
                      'measured': 'hipEvents around each launch, same K steps re-run without the graph (%.3f ms/step)' % instrumented_ms,
                      'launches': launches, 'avg_launch_us': 1e3 * ms / max(launches, 1),
                      'alg_bytes_per_launch': abytes / max(launches, 1), 'traffic': None})
@@ -895,7 +961,8 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'MSG_CHN 1layer meta, 352x1216 KITTI-shaped synthetic, 1 TTA step/frame, batch 1 per GPU',
                        'parallelism': 'independent frame streams, dp%d, no collectives' % world, 'finite': finite,
-                       'cpu_affinity': affinity,
+                       'cpu_affinity': affinity, 'hip_force_dev_kernarg': kernarg,
+                       'other_dtype_same_run': other_dtype_ms,
                        'frame_pipelining': ('on: every call names the next frame of the stream; the part of its forward upstream of the adapted layer (frozen RGB '
                                             'encoder, sparse-depth pooling, stage-1/4 cascade down to decoder 1\'s last transposed conv) runs on a second stream '
                                             'beside the current step; K timed calls = K prefixes + K remainders; identical results' if pipe else 'off'),

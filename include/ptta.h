@@ -295,8 +295,8 @@ int ptta_photometric(const float* src, float* dst, int n, int height, int width,
                      const uint8_t* do_contrast, const float* f_contrast, const uint8_t* do_saturation, const float* f_saturation,
                      double* scratch, ptta_stream s);
 
-/* ptta_step replays a captured hipGraph of the whole step by default (env PTTA_GRAPH=0 or
- * ptta_set_graph(h, 0) launches kernel by kernel).  Graphs are re-captured after any re-binding. */
+/* ptta_step replays a captured hipGraph of the whole step by default (ptta_set_option(h, "graph", 0)
+ * launches kernel by kernel).  Graphs are re-captured after any re-binding. */
 /* model.convert_syncbn() (src/tta_main.py:326 -> SyncBatchNorm.convert_sync_batchnorm, src/msg_chn_model_adapt.py:547-556)
  * for the one-process-per-GPU run with shared adapted parameters: every training-mode BatchNorm then normalises with
  * the statistics of the GLOBAL batch.  The library collapses a BatchNorm's partial sums into `exchange_buf` (device,
@@ -325,7 +325,32 @@ int ptta_set_stat_sync_rccl(ptta_handle h, void* comm, double* exchange_buf, int
  * Adam the adapted gradients are averaged over the communicator with one ncclAllReduce on the step's stream.  NULL: off. */
 int ptta_set_grad_sync_rccl(ptta_handle h, void* comm);
 
-int ptta_set_graph(ptta_handle h, int enable);
+int ptta_set_graph(ptta_handle h, int enable);         /* = ptta_set_option(h, "graph", enable) */
+
+/* Per-handle switches -- the library's ONLY run-time configuration besides the ptta_hparams struct: no environment variable is read after
+ * ptta_create (the three create-time validation variables are listed at the end of this comment).  Setting an option waits for the
+ * handle's streams and drops its captured graphs; the next step re-captures.  Every non-default value is a correct, slower form of
+ * the same step, kept as the check of the default (tests/test_gpu_options.py) or taken by the library itself where the default
+ * form does not apply (small maps, N > 16, SyncBatchNorm exchange).  Unknown key / value out of range: -22; a key the handle does
+ * not have: -38 (the generic engine has "graph" only; PTTA_DTYPE_MIXED handles keep every key but graph / aux_stream / thru at 1).
+ *   key             default  meaning of 0
+ *   "graph"         1 (0 for NLSPN / CostDCNet)  kernel-by-kernel launches instead of hipGraph replay
+ *   "aux_stream"    1        one stream: no second queue for the proxy chain / the heads
+ *   "thru"          1        the heads' stream joins the main stream before the loss (1: it runs on into loss + head backward)
+ *   "fuse_first"    1        every first-layer convolution + the following 32->32 convolution as two launches (2: the RGB branch fused too)
+ *   "fuse_head_bwd" 1        the prediction heads' backward as separate launches
+ *   "fuse_heads"    1        proj -> pred as separate Linear launches (1: pred.0 o proj.3 folded into one weight at load time)
+ *   "heads_v2"      1        proj's hidden layer materialised (1: recomputed inside the GEMM from analytic BatchNorm statistics)
+ *   "cos_in_gemm"   1        d loss_cos / d ref written as a tensor (1: formed in the backward GEMM's operand staging)
+ *   "mask_bits"     1        fp32 pre-activation maps as ReLU masks (1: one word of sign bits per pixel)
+ * bit-identical to the default: aux_stream, thru, fuse_first, fuse_head_bwd, mask_bits, graph; within bf16x3's own error (documented
+ * in the tests): fuse_heads, heads_v2, cos_in_gemm.
+ * Environment, read once per ptta_create (csrc/ptta_kernels.h ptta_create_env) because it decides allocation and arithmetic:
+ *   PTTA_CONV_IMPL=naive (direct fp32 kernels, PTTA_DTYPE_F32 only), PTTA_ARITH=exact (fp32 MFMA, MSG_CHN PTTA_DTYPE_F32 only),
+ *   PTTA_GRAPH=0|1 (initial value of "graph").  Recommended for the hosting process, not set by the library: HIP_FORCE_DEV_KERNARG=1
+ *   before the HIP runtime initialises (kernel arguments in device memory: -7 % on the replayed step). */
+int ptta_set_option(ptta_handle h, const char* key, int value);
+int ptta_get_option(ptta_handle h, const char* key, int* value_host);
 
 /* Measurement hook for bench.py: while enabled, the step runs kernel by kernel on one stream and EVERY launch is bracketed by hipEvents
  * on that stream, accounted to one of nine classes:  0 / 1 stride-1 3x3 32->32 convolution with ReLU on load, maps above / up to 1/4
@@ -348,6 +373,10 @@ int ptta_op_conv32(const float* in_nhwc, const float* weight, const float* bias,
  * 4 = skip addition of `aux`.  Synchronises. */
 int ptta_op_conv32_chain(const float* in_nhwc, const float* weight, const float* bias, float* buf_a, float* buf_b, const float* aux,
                          int b, int h, int w, int relu_in, int epi_flags, int reps, int replays, float* us_per_launch_host, ptta_stream s);
+/* ABI version of this header: ptta_version() of a loaded library must equal the PTTA_ABI_VERSION the binding was written against
+ * (proxytta/_lib.py checks it at load).  2: ptta_step_pipelined takes the next frame's pointers; ptta_set_option / ptta_get_option;
+ * PTTA_DTYPE_MIXED replaces the bf16 storage mode. */
+#define PTTA_ABI_VERSION 2
 int ptta_version(void);
 
 #ifdef __cplusplus

@@ -1,5 +1,4 @@
 """Edge cases and the other BASELINE.json shapes, HIP path vs the oracle (through the C-ABI)."""
-import os
 
 import numpy as np
 import pytest
@@ -122,7 +121,7 @@ def test_shared_parameter_step_single_rank_equals_fused_step():
     # round 4: the fused step forms d loss_cos / d ref inside the backward GEMM's operand staging, the split calls write it as a tensor first.
     # The same expression compiled twice may differ in the last bit, and the GEMM's bf16 hi / lo split of its A operand turns a last-bit change
     # into a 2^-17 step of the represented value: the adapted gradients agree to 2.9e-6 / 2.0e-6 of their mean magnitude (measured, 32x48;
-    # 64x96: 2.3e-6 / 1.3e-6) -- the size of bf16x3's own error -- no longer bit for bit (PTTA_COS_IN_GEMM=0: bit-identical again).  Adam's first
+    # 64x96: 2.3e-6 / 1.3e-6) -- the size of bf16x3's own error -- no longer bit for bit (option cos_in_gemm = 0: bit-identical again).  Adam's first
     # step is lr * sign(g) wherever |g| >> eps, so the parameters are identical except at entries whose gradient is within that noise of zero.
     for name, k in (('gW', 'conv1_rgb_meta.weight'), ('gB', 'conv1_rgb_meta.bias')):
         g1, g2 = e1.debug_tensor(name), e2.debug_tensor(name)
@@ -137,17 +136,13 @@ def test_shared_parameter_step_single_rank_equals_fused_step():
 def test_sign_bit_masks_equal_float_masks_bit_for_bit(n, h, w):
     """Round 4: the backward reads ONE word of sign bits per pixel (written by the forward epilogues) instead of the fp32 pre-activation
     pixel, the prediction heads' backward runs as one launch from those bits and the fused init block writes only the bits of its first
-    map.  Same predicate (> 0) on the same stored values: three steps with PTTA_MASK_BITS=0 (float masks, the unfused launches) and with the
+    map.  Same predicate (> 0) on the same stored values: three steps with the option mask_bits = 0 (float masks, the unfused launches) and with the
     default must agree bit for bit -- depth, loss terms, adapted parameters and Adam moments.  352x1216 is where the fused large-map kernels
     run; 64x96 takes the small-map kernels; two frames of 176x608 index the bit planes with a batch (b % nb) and mix both kernel families."""
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(20 + i, h, w, n)] for i in range(3)]
     runs = []
-    for bits in ('0', '1'):
-        os.environ['PTTA_MASK_BITS'] = bits
-        try:
-            eng, sd, ad = make_engine(n, h, w, 'fp32', HP)
-        finally:
-            os.environ.pop('PTTA_MASK_BITS', None)
+    for bits in (0, 1):
+        eng, sd, ad = make_engine(n, h, w, 'fp32', HP, options={'mask_bits': bits})
         out = []
         for im, sp in frames:
             info, depth = eng.step(im, sp, want_depth=True)
@@ -171,12 +166,8 @@ def test_shared_parameter_step_2layers_meta():
     image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(4, h, w, n)]
     # (this test is about the plumbing of the general path: with the tensor form of d loss_cos / d ref in the fused step the two are bit-identical;
     # the in-GEMM form is compared with the split calls in test_shared_parameter_step_single_rank_equals_fused_step)
-    os.environ['PTTA_COS_IN_GEMM'] = '0'
-    try:
-        e1, sd1, ad1 = make_engine(n, h, w, 'fp32', HP, meta='2layers')
-        e2, sd2, ad2 = make_engine(n, h, w, 'fp32', HP, meta='2layers')
-    finally:
-        os.environ.pop('PTTA_COS_IN_GEMM', None)
+    e1, sd1, ad1 = make_engine(n, h, w, 'fp32', HP, meta='2layers', options={'cos_in_gemm': 0})
+    e2, sd2, ad2 = make_engine(n, h, w, 'fp32', HP, meta='2layers', options={'cos_in_gemm': 0})
     assert len(e2.adapted) == 7
     info1, _ = e1.step(image, sparse)
     info2, _ = shared_parameter_step(e2, image, sparse, w=(HP['w_sparse_depth'], HP['w_smoothness'], HP['w_cos']))

@@ -220,11 +220,7 @@ def test_merged_head_linears_equal_the_two_layer_form():
     image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(7, h, w, n)]
     out = {}
     for fuse in ('1', '0'):
-        os.environ['PTTA_FUSE_HEADS'] = fuse
-        try:
-            eng, sd, adapted = make_engine(n, h, w, 'fp32')
-        finally:
-            os.environ.pop('PTTA_FUSE_HEADS', None)
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', options={'fuse_heads': int(fuse)})
         depth, emb, ref = eng.forward_train(image, sparse)
         out[fuse] = (emb.clone(), ref.clone(), sd['pred.1.running_mean'].clone(), sd['pred.1.running_var'].clone(), sd['proj.1.running_var'].clone())
         eng.close()

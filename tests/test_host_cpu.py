@@ -21,7 +21,8 @@ def test_library_exports_every_declared_symbol():
     assert declared == bound, (declared ^ bound)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ptta_version() >= 1
+    abi = int(re.search(r'#define PTTA_ABI_VERSION (\d+)', header).group(1))
+    assert lib.ptta_version() == abi == _lib.PTTA_ABI_VERSION
 
 
 def test_no_gpu_means_loud_failure():

@@ -1044,7 +1044,6 @@ static void launch_direct_x3(const Conv32P<T>& p, int flags, int blocks, hipStre
 static constexpr int kFullChipBlocks = 512, kS1Blocks = 480;
 // narrow kernels (half the LDS tile, ~160 VGPRs): three resident blocks per CU
 static constexpr int kNarrowBlocks = 768;         // (the direct kernel only: <= 160 VGPRs, 18 KB LDS)
-static int env_narrow_blocks() { static const int v = getenv("PTTA_NARROW_BLOCKS") ? atoi(getenv("PTTA_NARROW_BLOCKS")) : kNarrowBlocks; return v < 1 ? 1 : v; }
 
 template <typename T, int MODE>
 static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
@@ -1079,7 +1078,7 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         }
         const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
         const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
-        const int capd = NAR ? env_narrow_blocks() : kFullChipBlocks;
+        const int capd = NAR ? kNarrowBlocks : kFullChipBlocks;
         long blocks = (items + 3) / 4; if (blocks > capd) blocks = capd;
         if (MODE == CONV_S2 && !(flags & 1)) {
             const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + S2_TH - 1) / S2_TH);

@@ -466,19 +466,18 @@ GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth
     e->N = e->dual ? 2 * n : n; e->H = h + e->pt; e->W = w + e->pr;
     if ((e->H / 4) < 8 || (e->W / 4) < 8) { delete e; *rc = -22; return nullptr; }      // three 2x poolings of the 1/4-resolution volume
     e->hp = *hp; e->max_depth = max_depth; e->z_step = (float)((double)max_depth / 15.0);
-    const char* impl = getenv("PTTA_CONV_IMPL");
-    e->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
-    { const char* x6 = getenv("PTTA_X6"); e->x6 = e->naive ? 0 : (x6 ? (atoi(x6) ? 1 : 0) : 1); }      // default ON: DESIGN.md section 10 (parity of the post-update depth)
-    // ... on the layers that decide it (measured layer by layer, tools/costdc_report.py with PTTA_X6_LAYERS): Encoder2D, the meta convolution
+    const PttaCreateEnv env = ptta_create_env();
+    e->naive = env.naive;
+    e->x6 = e->naive ? 0 : 1;                // the third operand plane (parity of the post-update depth: DESIGN.md)
+    // ... on the layers that decide it (measured layer by layer, tools/costdc_report.py): Encoder2D, the meta convolution
     // and the first two levels of the UNet3D give the post-update depth of bf16x6 everywhere (5.5e-6 / 6.0e-4 at 320x400 / 480x640); any
     // smaller set leaves it at 0.8 - 1.3e-3
     // (the DDP adapted set adapts the UNet3D's own BatchNorm too: every layer keeps the third plane there)
     e->x6_layers = (flags & 1) ? "" : "enc2d,conv1_rgb_meta,unet3d.inc,unet3d.down1";
     // hipGraph replay of the step / eval forward: built and bit-identical (tests), but measured 0.3 - 2 % SLOWER than kernel-by-kernel
-    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: PTTA_GRAPH=1 / ptta_set_graph(h, 1)
-    { const char* gr = getenv("PTTA_GRAPH"); e->use_graph = (gr && strcmp(gr, "1") == 0) ? 1 : 0; }
+    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: ptta_set_option(h, "graph", 1) / PTTA_GRAPH=1
+    e->use_graph = env.graph == 1 ? 1 : 0;
     e->sync_adapt = (flags & 1) ? 1 : 0;
-    { const char* sa = getenv("PTTA_SPARSE_ASYNC"); e->sp_async = !(sa && strcmp(sa, "0") == 0); }
     e->build();
     if (e->oom || !e->step_dev) { delete e; *rc = -12; return nullptr; }
     if (e->upload_hparams(nullptr)) { delete e; *rc = -5; return nullptr; }

@@ -80,7 +80,7 @@ __global__ void gfrag_pack_kernel(const float* __restrict__ canon, long wld, lon
 // VERT: only the middle column of the 3x3 window (a 3x1x1 Conv3d viewed as a vertical 3-tap convolution over [D][H*W] images,
 // gnet.h Op::rH/rW): three taps, no horizontal halo -- a third of the MFMAs of the zero-padded 3x3 form it replaces.
 // TIMING: s_memtime stamps around the phases of one block's K loop, printed by two blocks of the launch (diagnostic builds of the
-// launcher select it with PTTA_S1_STAMPS=<grid size in blocks>; the shipped instantiation has no stamps)
+// launcher are compiled with -DPTTA_DIAG_STAMPS; the shipped instantiation has no stamps)
 #define STAMP(v) do { if constexpr (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
 // SIX: three operand planes (GX3Args::six_B): 112 B of LDS per pixel, three weight planes, two blocks per CU; blocks of images
 // >= six_B (the proxy frames) skip the three extra products
@@ -781,7 +781,6 @@ int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
     const long tiles = (long)a.B * ((a.W + 31) / 32) * ((a.H + GX_TH - 1) / GX_TH);
     const long blocks = tiles * a.nnf;
     if (blocks < 1 || blocks > 0x7fffffffL) return -22;
-    static const int exp_t = getenv("PTTA_S1_STAMPS") ? atoi(getenv("PTTA_S1_STAMPS")) : 0;   // diagnostic: in-kernel phase stamps (tools/exp_s1_stamps.sh)
     if (a.six_B > 0) {
         if (!a.wl2) return -22;
         if (ks == 3 && a.vert) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
@@ -792,7 +791,9 @@ int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s) {
         return 0;
     }
     if (ks == 3 && a.vert) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    else if (ks == 3 && exp_t && blocks == exp_t) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+#ifdef PTTA_DIAG_STAMPS      // diagnostic build (make DIAG=1): in-kernel phase stamps of the 3x3 launches
+    else if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+#endif
     else if (ks == 3) hipLaunchKernelGGL((gconv_x3_s1_kernel<3, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else if (ks == 1) hipLaunchKernelGGL((gconv_x3_s1_kernel<1, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     else return -22;
@@ -844,8 +845,7 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
         const long nitems = (long)x.B * x.H * nx;
         const int single = (x.C <= 32 && gy.C <= 32) ? 1 : 0;
         const int kcib = sq ? 2 : (wide_out ? 1 : 4);
-        static const int cap1 = getenv("PTTA_WGRAD_BLOCKS") ? atoi(getenv("PTTA_WGRAD_BLOCKS")) : 64;
-        const long cap = single ? (cap1 < 1 ? 1 : (cap1 > 256 ? 256 : cap1)) : 256;
+        const long cap = single ? 64 : 256;
         const int nblk = (int)(nitems < cap ? nitems : cap);
         hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
         const long n = 9L * x.C * gy.C + gy.C;

@@ -134,7 +134,7 @@ struct GNet {
     int mixed = 0;
     // bf16x6 forward for the real frames (GX3Args::six_B): the two-way operand split's 2^-17 representation error reaches the depth
     // map as ~2e-5 relative, enough to flip the sign of near-zero gradient entries -- and Adam's first step turns a sign into +-lr
-    // (CostDCNet: post-update eval depth 1.6e-3 from the reference with bf16x3).  PTTA_X6=0/1 overrides.
+    // (CostDCNet: post-update eval depth 1.6e-3 from the reference with bf16x3).  Per backbone: CostDCNet on, NLSPN off.
     int x6 = 0;
     int norm_on = 0; float norm_div = 1.f, norm_mean[3] = {0, 0, 0}, norm_std[3] = {1, 1, 1};
     bool fwd_valid = false;
@@ -215,23 +215,10 @@ struct GNet {
         v.B = (int)(pix / ((long)rH * rW)); v.H = rH; v.W = rW;
     }
 
-    static bool exact_listed(const char* var, const std::string& wname) {
-        const char* e = getenv(var);
-        if (!e || !*e) return false;
-        std::string l(e); size_t a = 0;
-        while (a <= l.size()) {
-            size_t b = l.find(',', a); if (b == std::string::npos) b = l.size();
-            const std::string pre = l.substr(a, b - a);
-            if (pre == "*" || (!pre.empty() && wname.compare(0, pre.size(), pre) == 0)) return true;
-            a = b + 1;
-        }
-        return false;
-    }
     // layers whose real-frame forward keeps the third operand plane (x6): the backbone's list (x6_layers, comma-separated name prefixes,
-    // empty = every layer), or PTTA_X6_LAYERS ("*" = every layer)
+    // empty = every layer)
     std::string x6_layers;
     bool x6_layer(const std::string& wname) const {
-        if (getenv("PTTA_X6_LAYERS")) return exact_listed("PTTA_X6_LAYERS", wname);
         if (x6_layers.empty()) return true;
         size_t a = 0;
         while (a <= x6_layers.size()) {
@@ -258,10 +245,6 @@ struct GNet {
         cw.C0 = T[x0].C; cw.C1 = x1 >= 0 ? T[x1].C : 0;
         cw.mf = !naive && (stride == 1 && !transposed ? (cw.C0 % 8) == 0 && (cw.C1 % 8) == 0 : (cw.C0 % 16) == 0 && (cw.C1 % 16) == 0);
         cw.mb = !naive && ((cw.Co % 16) == 0 || (stride == 1 && !transposed));
-        // diagnostics: PTTA_EXACT_FWD / PTTA_EXACT_BWD = comma-separated layer-name prefixes ("*" = every layer) whose forward /
-        // data gradient runs on the direct fp32 kernels (needs the activation's real channel count: not the zero-padded inputs)
-        if (exact_listed("PTTA_EXACT_FWD", wname) && wname != "enc2d.conv1" && wname != "conv1_rgb.0" && wname != "conv1_dep.0") cw.mf = false;
-        if (exact_listed("PTTA_EXACT_BWD", wname)) cw.mb = false;
         cw.Co_pad = (cw.Co + 15) / 16 * 16;               // data gradient of a conv with < 16 output channels: gy is zero-padded
         const long pix = (long)T[y].per * T[y].H * T[y].W;
         if (pix > cw.gpad_pix) cw.gpad_pix = pix;

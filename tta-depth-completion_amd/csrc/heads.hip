@@ -1007,8 +1007,9 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s) {
         if (a.N == 512 && a.Wil && a.pro != 2) {
             dim3 grid(2, (a.R + 127) / 128);
 #define GS_(PRO, EPI) hipLaunchKernelGGL((gemm_x3_ws_kernel<PRO, EPI>), grid, dim3(512), 0, s, q)
-            static const int stamps = getenv("PTTA_GEMM_STAMPS") ? atoi(getenv("PTTA_GEMM_STAMPS")) : 0;   // diagnostic: in-kernel phase stamps
-            if (stamps && key3 == 10) { hipLaunchKernelGGL((gemm_x3_ws_kernel<1, 0, true>), grid, dim3(512), 0, s, q); PTTA_CHECK_LAUNCH(); return 0; }
+#ifdef PTTA_DIAG_STAMPS      // diagnostic build (make DIAG=1): in-kernel phase stamps of the PRO 1 / EPI 0 launch
+            if (key3 == 10) { hipLaunchKernelGGL((gemm_x3_ws_kernel<1, 0, true>), grid, dim3(512), 0, s, q); PTTA_CHECK_LAUNCH(); return 0; }
+#endif
             switch (key3) {
                 case 0: GS_(0, 0); break; case 1: GS_(0, 1); break; case 2: GS_(0, 2); break;
                 case 10: GS_(1, 0); break; case 11: GS_(1, 1); break;

@@ -207,8 +207,7 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
                              const float* w3_dev, int N, int H, int W,
                              float* ws, float* loss_info, hipStream_t s, int defer_finalize) {
     const int has_cos = (emb && ref) ? 1 : 0;
-    static const int merge_off = getenv("PTTA_LOSS_MERGE") ? (atoi(getenv("PTTA_LOSS_MERGE")) == 0) : 0;     // A/B switch
-    if (has_cos && !merge_off) {
+    if (has_cos) {
         hipLaunchKernelGGL(loss_forward_merged_kernel, dim3(N * LOSS_PB + LOSS_CB), dim3(256), 0, s, depth, image, sparse, validity, max_input_depth,
                            N, H, W, ws + ws_depth_off(N), emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
     } else {
@@ -326,8 +325,7 @@ int ptta_launch_loss_backward(const float* depth, const float* image, const floa
     if (w3_fused && N > LOSS_FIN_MAXN) w3_fused = nullptr;          // the forward launched the finalize kernel in that case
     int blocks = (int)((total + 255) / 256); if (blocks > (w3_fused ? 1024 : 4096)) blocks = w3_fused ? 1024 : 4096;
     const int has_cos = (emb && ref) ? 1 : 0;
-    static const int merge_off = getenv("PTTA_LOSS_MERGE") ? (atoi(getenv("PTTA_LOSS_MERGE")) == 0) : 0;     // A/B switch
-    if (emb && ref && gref && w3_fused && !merge_off) {
+    if (emb && ref && gref && w3_fused) {
         long cb = (R + 3) / 4; if (cb > 1024) cb = 1024;
         if (blocks > 512) blocks = 512;
         hipLaunchKernelGGL(loss_backward_merged_kernel, dim3(blocks + (int)cb), dim3(256), 0, s, depth, image, sparse, validity, max_input_depth, N, H, W,

@@ -290,12 +290,12 @@ GNet* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int legacy_offse
     if (n < 1 || h < 16 || w < 16 || !hp) { *rc = -22; return nullptr; }
     nlspn_engine* e = new nlspn_engine();
     e->N = e->Nu = n; e->H = e->Hu = h; e->W = e->Wu = w; e->hp = *hp; e->legacy = (legacy_offset & 1) ? 1 : 0; e->heads_adapted = (legacy_offset & 2) ? 1 : 0;
-    const char* impl = getenv("PTTA_CONV_IMPL");
-    e->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;          // direct fp32 kernels everywhere (validation)
-    { const char* x6 = getenv("PTTA_X6"); e->x6 = (!e->naive && x6 && atoi(x6)) ? 1 : 0; }             // default OFF (matrix-core bound; parity holds without)
+    const PttaCreateEnv env = ptta_create_env();
+    e->naive = env.naive;          // direct fp32 kernels everywhere (validation)
+    e->x6 = 0;                     // (third operand plane: off -- matrix-core bound, parity holds without)
     // hipGraph replay of the step / eval forward: built and bit-identical (tests), but measured 0.3 - 2 % SLOWER than kernel-by-kernel
-    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: PTTA_GRAPH=1 / ptta_set_graph(h, 1)
-    { const char* gr = getenv("PTTA_GRAPH"); e->use_graph = (gr && strcmp(gr, "1") == 0) ? 1 : 0; }
+    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: ptta_set_option(h, "graph", 1) / PTTA_GRAPH=1
+    e->use_graph = env.graph == 1 ? 1 : 0;
     e->build();
     if (e->oom || !e->step_dev) { delete e; *rc = -12; return nullptr; }
     const float one[1] = {4.0f};                                  // affinity_gamma * num = 0.5 * 8 (nlspnmodel_adapt.py:231-233)

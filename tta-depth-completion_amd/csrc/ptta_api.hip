@@ -22,7 +22,6 @@
 #include "ptta_kernels.h"
 #include "nlspn.h"
 
-#define PTTA_VERSION 1
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return c->fail(std::string(#x) + ": " + hipGetErrorString(e_), -100 - (int)e_); } while (0)
 #define RUN(x) do { int r_ = (x); if (r_ != 0) return c->fail(std::string(#x) + " failed", r_ < 0 ? r_ : -r_); } while (0)
 
@@ -59,7 +58,6 @@ struct ptta_ctx {
     void* tw(const void* p) const { auto it = ntwin.find(p); return it == ntwin.end() ? nullptr : it->second; }
     void twin_alloc(const void* p, int nb, int h, int w) { if (nar_proxy && p) ntwin[p] = dalloc((size_t)nb * h * w * 32 * 2); }
     float *dm_f32 = nullptr;          // fp32 copy of the meta layer's output gradient (the weight-gradient kernels take fp32 operands)
-    int ablate = 0;                  // PTTA_ABLATE (diagnostic): groups of launches skipped for timing, results garbage; announced on stderr by ptta_create
     ptta_hparams hp{};
     std::string err;
     std::vector<void*> allocs;
@@ -197,6 +195,7 @@ struct ptta_ctx {
             if (pgraph[p]) { (void)hipGraphDestroy(pgraph[p]); pgraph[p] = nullptr; }
             pset[p].prepared = false; pset[p].prep_token = pset[p].last_token = 0;
         }
+        fb_image = fb_sparse = nullptr;
     }
 
     int fail(const std::string& m, int code) { err = m; return code; }
@@ -227,15 +226,15 @@ struct ptta_ctx {
     // frames, written by the forward epilogue that writes the map and read by the backward epilogue instead of the 128-B fp32 pixel.
     // fp32 storage, MFMA kernels (PTTA_MASK_BITS=0: float masks everywhere).  Keyed by the map's base pointer: conv32() looks its
     // output / mask operands up, so the schedule code does not name the bit planes.
-    int mask_bits_on = 1;
+    int mask_bits_on = 1;            // option "mask_bits" (0: float masks; the planes stay allocated, 4 B per pixel)
     std::unordered_map<const void*, uint32_t*> mbits;
     void mask_plane(const void* map, int nb, int h, int w) {
-        if (!mask_bits_on || bf16 || naive) return;
+        if (bf16 || naive) return;
         if (mbits.count(map)) return;
         mbits[map] = (uint32_t*)dalloc((size_t)nb * h * w * sizeof(uint32_t));
     }
     uint32_t* bits_of(const void* map) const {
-        if (!map) return nullptr;
+        if (!map || !mask_bits_on) return nullptr;
         auto it = mbits.find(map);
         return it == mbits.end() ? nullptr : it->second;
     }
@@ -439,11 +438,9 @@ void build_workspace(ptta_ctx* c) {
         MB_(s1_3, H2, W2); MB_(t3, H2, W2); MB_(e3_1, H2, W2); MB_(e3_1a, H2, W2); MB_(v2, H2, W2); MB_(s0_2, H2, W2); MB_(u2, H2, W2); MB_(e2_0, H2, W2);
         MB_(w2, H4, W4); MB_(e3_2a, H4, W4); MB_(s1_2, H4, W4); MB_(t2, H4, W4); MB_(e2_1, H4, W4); MB_(e2_1a, H4, W4); MB_(s0_1, H4, W4);
         MB_(z2, H8, W8); MB_(e2_2a, H8, W8);
-        auto first_fused = [&](int h, int w) { return c->fuse_first >= 1 && !(c->ablate & 3) && c->x3 && (long)Nn * ((w + 31) / 32) * ((h + 7) / 8) > 256; };
-        // (mixed mode: EVERY mask of the backward is a bit plane -- a narrow launch cannot read an fp32 mask map; the unfused first-layer
-        // kernel writes the planes of e*_0a then, and decoder 1's v1 gets one too)
-        if (first_fused(H1, W1) || c->nar_bwd) MB_(e3_0a, H1, W1);
-        if (first_fused(H2, W2) || c->nar_bwd) MB_(e2_0a, H2, W2);
+        // (the fused init block and the unfused first-layer kernel both write the planes of e*_0a; mixed mode: EVERY mask of the backward
+        // is a bit plane -- a narrow launch cannot read an fp32 mask map -- so decoder 1's v1 gets one too)
+        MB_(e3_0a, H1, W1); MB_(e2_0a, H2, W2);
         if (c->nar_bwd) MB_(v1, H4, W4);
 #undef MB_
     }
@@ -603,12 +600,6 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
             if (bs || br) { a.bits_out = bs ? bs : br; a.bits_sum = bs ? 1 : 0; a.bits_nb = c->Nn; }
         }
     }
-    {   // TIMING ablation only (results are garbage): PTTA_ABLATE bit 0 skips the 32->32 convolutions at <= 1/4 resolution, bit 1 those above
-        const int abl = c->ablate;
-        const bool small = (long)Hin * Win <= (long)c->H4 * c->W4 * (mode == CONV_S2 ? 4 : 1);
-        if ((abl & 1) && small) return 0;
-        if ((abl & 2) && !small) return 0;
-    }
     // profiling leg (bench.py roofline): bracket this launch with events on ITS stream; algorithmic bytes = input + output + weight
     // elements x element size, MACs = output pixels x 9 x 32 x 32 (SURVEY.md 8d counting rule)
     const long pin = (long)B * Hin * Win;
@@ -636,7 +627,7 @@ int conv32_first(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvInArg
     const long tiles = (long)B * ((W + 31) / 32) * ((H + 7) / 8);
     const bool nar = e.nar;
     f.bf16 = nar ? 1 : c->bf16;
-    if (c->fuse_first >= (f.cin == 3 ? 2 : 1) && !(c->ablate & 3) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && !e.mask && !e.add1 && !e.add2 && !e.sum) {
+    if (c->fuse_first >= (f.cin == 3 ? 2 : 1) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && !e.mask && !e.add1 && !e.add2 && !e.sum) {
         Conv32Args a;
         a.in = nullptr; a.in_nb = B; a.w = &it->second.f; a.bias = it->second.bias;
         a.up = e.up; a.up_nb = e.up_nb; a.out_raw = e.raw;
@@ -664,7 +655,7 @@ int conv32_first_bwd(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvI
     const long tiles = (long)B * ((W + 31) / 32) * ((H + 7) / 8);
     const bool nar = c->nar_bwd != 0;
     f.bf16 = nar ? 1 : c->bf16;
-    if (c->fuse_head_bwd && c->bits_of(f.mask) && c->bits_of(e.mask) && c->fuse_first >= 1 && !(c->ablate & 3) && !c->bf16 && !c->naive && c->x3 && tiles > 256 && e.mask && e.raw && !e.add1 && !e.add2 && !e.sum && !e.up) {
+    if (c->fuse_head_bwd && c->bits_of(f.mask) && c->bits_of(e.mask) && c->fuse_first >= 1 && !c->bf16 && !c->naive && c->x3 && tiles > 256 && e.mask && e.raw && !e.add1 && !e.add2 && !e.sum && !e.up) {
         Conv32Args a;
         a.in = nullptr; a.in_nb = B; a.w = &it->second.b; a.bias = nullptr;
         a.mask = e.mask; a.mask_nb = e.mask_nb; a.out_raw = e.raw;
@@ -1146,7 +1137,6 @@ int mlp_forward(ptta_ctx* c, const std::string& name, const void* A, int a_bf16,
 }
 
 int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2 only): 0 both passes, 1 the proxy pass, 2 the real pass
-    if (c->ablate & 4) return 0;      // timing ablation only
     if (part != 1) c->cos_rows_done = false;
     // profiling class 6: 3 applications of Linear(32,512) / Linear(512,512) pairs (proj on both passes, pred on the proxy pass; proj.3 and
     // pred.0 run merged) = per row 2 x (32 + 512) + 4 x (512 + 512) elements by SURVEY 8d's rule as the REFERENCE executes it (6 linears)
@@ -1285,7 +1275,6 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
 
 // d ref -> d feat through proj = Linear(32,512) - BN1d - ReLU - Linear(512,512)
 int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
-    if (c->ablate & 4) return 0;      // timing ablation only
     ProfScope ps_(c, 6, s, ((double)c->Rg * (1024 + 544) + 16384.0 + 262144.0) * 4, (double)c->Rg * (16384.0 + 262144.0), 3);   // data gradient through proj once
     const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
     const int R = (int)c->Rg;
@@ -1474,7 +1463,7 @@ const float* final_depth(ptta_ctx* c) { return c->dual ? c->depth_final : c->dep
 
 extern "C" {
 
-int ptta_version(void) { return PTTA_VERSION; }
+int ptta_version(void) { return PTTA_ABI_VERSION; }
 
 const char* ptta_last_error(ptta_handle h) { return h ? (h->nl && h->err.empty() ? h->nl->err.c_str() : h->err.c_str()) : "null handle"; }
 // calls forwarded to a GNet engine clear the wrapper-level message, so the engine's later message is not masked by a stale one
@@ -1523,26 +1512,13 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     c->Hp = height + c->pt; c->Wp = width + c->pr; c->dual = (c->pt || c->pr) ? 1 : 0; c->Nn = c->dual ? 2 * n : n;
     c->mixed = dtype == PTTA_DTYPE_MIXED ? 1 : 0;
     c->nar_proxy = c->mixed && !(keep & 1); c->nar_bwd = c->mixed && !(keep & 2); c->nar_heads = c->mixed && !(keep & 4);
-    const char* impl = getenv("PTTA_CONV_IMPL");
-    c->naive = (impl && strcmp(impl, "naive") == 0) ? 1 : 0;
-    const char* gr = getenv("PTTA_GRAPH");
-    c->use_graph = (gr && strcmp(gr, "0") == 0) ? 0 : 1;
-    const char* ax = getenv("PTTA_AUX_STREAM");
-    c->use_aux = (ax && strcmp(ax, "0") == 0) ? 0 : 1;
-    { const char* fh = getenv("PTTA_FUSE_HEADS"); c->fuse_heads = (fh && strcmp(fh, "0") == 0) ? 0 : 1; }
-    { const char* hv = getenv("PTTA_HEADS_V2"); c->heads_v2 = (hv && strcmp(hv, "0") == 0) ? 0 : 1; }
-    { const char* ff = getenv("PTTA_FUSE_FIRST"); c->fuse_first = ff ? atoi(ff) : 1; }
-    { const char* mb = getenv("PTTA_MASK_BITS"); c->mask_bits_on = (mb && strcmp(mb, "0") == 0) ? 0 : 1; }
-    { const char* th = getenv("PTTA_THRU"); c->thru = (th && strcmp(th, "0") == 0) ? 0 : 1; }
-    { const char* cg = getenv("PTTA_COS_IN_GEMM"); c->cos_grad_fused = (cg && strcmp(cg, "0") == 0) ? 0 : 1; }
-    { const char* ab = getenv("PTTA_ABLATE"); c->ablate = ab ? atoi(ab) : 0;
-      if (c->ablate) fprintf(stderr, "libptta_hip: PTTA_ABLATE=%d -- TIMING ABLATION: launches are skipped, every result of this handle is GARBAGE\n", c->ablate); }
-    const char* arith = getenv("PTTA_ARITH");              // "exact": fp32 MFMA everywhere (validation); default bf16x3
-    c->x3 = (arith && strcmp(arith, "exact") == 0) ? 0 : 1;
+    const PttaCreateEnv env = ptta_create_env();         // (the three validation switches; everything else: ptta_set_option)
+    c->naive = env.naive;
+    c->use_graph = env.graph == 0 ? 0 : 1;
+    c->x3 = env.exact ? 0 : 1;
     if (c->mixed) {
         // the mixed mode is defined on the matrix-core kernels with sign-bit masks; the validation arithmetic modes belong to PTTA_DTYPE_F32
         if (c->naive || !c->x3) { delete c; return -38; }
-        c->mask_bits_on = 1;
     }
     c->hp = *hp;
     build_registry(c);
@@ -1755,7 +1731,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
         pipe_use(c, c->pipe_last);
         pipe_overwritten(c, c->pipe_last);               // ... and the set it DOES overwrite no longer holds the frame it was prepared for / adapted from
     }
-    c->fwd_valid = false; c->head.fwd_ok = false;
+    c->fwd_valid = false; c->head.fwd_ok = false; c->fb_image = c->fb_sparse = nullptr;
     RUN(forward_common(c, image, sparse, true, s));      // includes the heads (beside decoder 3)
     const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
     if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), dbytes, hipMemcpyDeviceToDevice, s));
@@ -1777,6 +1753,7 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
     hipStream_t s = (hipStream_t)s_;
     if (c->pipe_active) { pipe_use(c, c->pipe_last); pipe_overwritten(c, c->pipe_last); }       // as ptta_forward_train
     c->fwd_valid = false; c->head.fwd_ok = false;        // the eval pass overwrites the saved activations
+    c->fb_image = c->fb_sparse = nullptr;                // (ptta_forward_eval_last's fallback restores them around its own call)
     RUN(forward_common(c, image, sparse, false, s));
     HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, hipMemcpyDeviceToDevice, s));
     return 0;
@@ -1791,7 +1768,10 @@ int ptta_forward_eval_last(ptta_handle c, float* depth_out, ptta_stream s_) {
         // the last ptta_step_pipelined call ran as a plain ptta_step (no graph replay, profiling, SyncBatchNorm / gradient exchange, padded
         // sizes, bf16 storage ...): no prefix is held, so this is a full eval forward of that call's frame (its buffers are still the caller's)
         if (!c->fb_image || !c->fb_sparse) return c->fail("ptta_forward_eval_last: no frame adapted by ptta_step_pipelined since the last reset", -3);
-        return ptta_forward_eval(c, c->fb_image, c->fb_sparse, depth_out, s_);
+        const float *im = c->fb_image, *sp = c->fb_sparse;
+        const int rc = ptta_forward_eval(c, im, sp, depth_out, s_);
+        c->fb_image = im; c->fb_sparse = sp;          // (still the last adapted frame: the call may be repeated)
+        return rc;
     }
     if (!c->pset[c->pipe_last].last_token) return c->fail("ptta_forward_eval_last: no frame adapted by ptta_step_pipelined since the last reset", -3);
     hipStream_t s = (hipStream_t)s_;
@@ -1967,7 +1947,6 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
     if (!c || !image || !sparse) return -1;
     if (c->nl) return c->nl->step(image, loss_image, sparse, validity, depth_out, loss_info_out, (hipStream_t)s_);
     RUN(pipe_quiesce(c));
-    c->fb_image = c->fb_sparse = nullptr;
     hipStream_t s = (hipStream_t)s_;
     if (!loss_image) loss_image = image;
     const size_t ibytes = (size_t)c->N * 3 * c->H * c->W * 4, pbytes = (size_t)c->N * c->H * c->W * 4;
@@ -2068,6 +2047,7 @@ static int pipe_init(ptta_ctx* c) {
 }
 // any entry point that is not ptta_step_pipelined: wait for a prefix in flight, forget it, go back to buffer set 0
 static int pipe_quiesce(ptta_ctx* c) {
+    c->fb_image = c->fb_sparse = nullptr;          // (the frame of a ptta_step_pipelined call that ran as ptta_step: forgotten with the rest)
     if (!c->pipe_active) return 0;
     HIPCHK(hipStreamSynchronize(c->pre_stream));
     for (int p = 0; p < 2; ++p) { c->pset[p].prepared = false; c->pset[p].prep_token = c->pset[p].last_token = 0; }
@@ -2465,6 +2445,52 @@ int ptta_set_grad_sync_rccl(ptta_handle c, void* comm) {
     if (c->nl) { c->nl->drop_graphs(); c->nl->grad_comm = comm; return 0; }
     c->grad_comm = comm;
     c->drop_graphs();
+    return 0;
+}
+
+// Per-handle switches (include/ptta.h documents the keys).  The defaults are the shipped step; every other value is a correct,
+// slower form kept for validation (tests/test_gpu_options.py: bit-identical to the default unless noted) or as the fallback a
+// configuration takes by itself (small maps, SyncBatchNorm exchange, N > 16).
+int ptta_set_option(ptta_handle c, const char* key, int value) {
+    if (!c || !key) return -1;
+    const std::string k(key);
+    if (k == "graph") return ptta_set_graph(c, value);
+    if (c->nl) return -38;                         // the generic engine has the one switch
+    int* f = nullptr; int lo = 0, hi = 1;
+    if (k == "aux_stream") f = &c->use_aux;
+    else if (k == "thru") f = &c->thru;
+    else if (k == "fuse_first") { f = &c->fuse_first; hi = 2; }
+    else if (k == "fuse_head_bwd") f = &c->fuse_head_bwd;
+    else if (k == "fuse_heads") f = &c->fuse_heads;
+    else if (k == "heads_v2") f = &c->heads_v2;
+    else if (k == "cos_in_gemm") f = &c->cos_grad_fused;
+    else if (k == "mask_bits") f = &c->mask_bits_on;
+    else return c->fail("ptta_set_option: unknown key '" + k + "'", -22);
+    if (value < lo || value > hi) return c->fail("ptta_set_option: value out of range for '" + k + "'", -22);
+    if (c->mixed && k != "aux_stream" && k != "thru" && value != 1)
+        return c->fail("ptta_set_option: the mixed mode is defined on the default kernels ('" + k + "' stays 1)", -38);
+    if (k == "aux_stream" && c->pre_sync_graph >= 0) { c->pre_sync_aux = value; return 0; }      // statistics exchange active: takes effect when it ends
+    if (*f == value) return 0;
+    RUN(pipe_quiesce(c));
+    c->drop_graphs();
+    *f = value;
+    return 0;
+}
+
+int ptta_get_option(ptta_handle c, const char* key, int* value) {
+    if (!c || !key || !value) return -1;
+    const std::string k(key);
+    if (c->nl) { if (k != "graph") return -38; *value = c->nl->use_graph; return 0; }
+    if (k == "graph") *value = c->use_graph;
+    else if (k == "aux_stream") *value = c->use_aux;
+    else if (k == "thru") *value = c->thru;
+    else if (k == "fuse_first") *value = c->fuse_first;
+    else if (k == "fuse_head_bwd") *value = c->fuse_head_bwd;
+    else if (k == "fuse_heads") *value = c->fuse_heads;
+    else if (k == "heads_v2") *value = c->heads_v2;
+    else if (k == "cos_in_gemm") *value = c->cos_grad_fused;
+    else if (k == "mask_bits") *value = c->mask_bits_on;
+    else return -22;
     return 0;
 }
 

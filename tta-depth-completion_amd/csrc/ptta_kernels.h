@@ -2,7 +2,24 @@
 // include/ptta.h).  All pointers are device pointers; every launcher only enqueues on `s`.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "ptta_common.h"
+
+// ---- the library's whole environment ---------------------------------------------------------------
+// Three validation switches, read here and nowhere else, once per ptta_create: they decide what a handle allocates and which
+// arithmetic its kernels run, so they cannot be options of a live handle.  Every other switch is ptta_set_option (include/ptta.h).
+//   PTTA_CONV_IMPL=naive   direct fp32 kernels everywhere (the check of the matrix-core kernels)
+//   PTTA_ARITH=exact       fp32 MFMA instead of bf16x3 (MSG_CHN, fp32 mode)
+//   PTTA_GRAPH=0|1         initial value of the "graph" option (default: 1 for MSG_CHN, 0 for the generic engine)
+struct PttaCreateEnv { int naive = 0, exact = 0, graph = -1; };
+inline PttaCreateEnv ptta_create_env() {
+    PttaCreateEnv e;
+    const char* v = getenv("PTTA_CONV_IMPL"); e.naive = (v && strcmp(v, "naive") == 0) ? 1 : 0;
+    v = getenv("PTTA_ARITH"); e.exact = (v && strcmp(v, "exact") == 0) ? 1 : 0;
+    v = getenv("PTTA_GRAPH"); e.graph = (v && (strcmp(v, "0") == 0 || strcmp(v, "1") == 0)) ? (v[0] - '0') : -1;
+    return e;
+}
 
 // ---- conv32.hip ------------------------------------------------------------------------------
 struct ConvW {           // one packed 3x3 32->32 filter, three formats (device memory)

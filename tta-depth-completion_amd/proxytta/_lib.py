@@ -7,10 +7,8 @@ import ctypes
 import os
 from ctypes import POINTER, byref, c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
-# Kernel arguments in device memory (the ROCm 7 default on MI300-class parts; measured here: unset = 1 -> 1.69 ms per MSG_CHN step, forced to
-# 0 -> 1.81 ms: every launch of a replayed graph otherwise fetches its arguments across the host link).  Only takes effect if HIP has not
-# been initialised yet in this process; never overrides the user's setting.
-os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+# The binding does not touch the process environment.  The hosting process should export HIP_FORCE_DEV_KERNARG=1 before the HIP runtime
+# initialises (kernel arguments in device memory; 0 costs 7 % of the replayed MSG_CHN step): bench.py does and reports it, INTEGRATION.md.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libptta_hip.so')
@@ -25,6 +23,7 @@ PTTA_META_1LAYER = 0
 PTTA_META_2LAYERS = 1
 PTTA_DTYPE_F32 = 0
 PTTA_DTYPE_MIXED = 1
+PTTA_ABI_VERSION = 2           # include/ptta.h; checked against ptta_version() at load
 CONV_S1, CONV_S2, CONV_T2 = 0, 1, 2
 
 
@@ -87,6 +86,8 @@ SIGNATURES = [
     ('ptta_set_stat_sync_rccl', c_int, [_P, _P, _P, c_int64, c_int]),
     ('ptta_set_grad_sync_rccl', c_int, [_P, _P]),
     ('ptta_set_graph', c_int, [_P, c_int]),
+    ('ptta_set_option', c_int, [_P, c_char_p, c_int]),
+    ('ptta_get_option', c_int, [_P, c_char_p, POINTER(c_int)]),
     ('ptta_profile', c_int, [_P, c_int]),
     ('ptta_profile_read', c_int, [_P, c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double),
                                   POINTER(c_int64), _P]),
@@ -115,6 +116,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    have = lib.ptta_version()
+    if have != PTTA_ABI_VERSION:
+        raise RuntimeError('%s has ABI version %d, this binding is written against %d (include/ptta.h PTTA_ABI_VERSION): rebuild it with '
+                           '`make -C tta-depth-completion_amd/csrc`' % (LIB_PATH, have, PTTA_ABI_VERSION))
     _lib = lib
     return lib
 

@@ -52,7 +52,7 @@ class Engine:
     def __init__(self, n, height, width, dtype='fp32', lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, w_sparse_depth=1.0, w_smoothness=1.0, w_cos=1.0,
                  max_input_depth=None, meta='1layer', backbone='msg_chn', legacy_offset=False, max_predict_depth=None,
-                 syncbn_adapted=False, keep=()):
+                 syncbn_adapted=False, keep=(), options=None):
         if not torch.cuda.is_available():
             raise RuntimeError('proxytta needs a HIP device (torch.cuda.is_available() is False); '
                                'there is no CPU fallback')
@@ -86,6 +86,8 @@ class Engine:
                    -38: 'configuration not on the accelerated path (NLSPN needs fp32 and '
                         'the 1layer meta conv; MSG_CHN needs the 1layer or 2layers meta layer)'}.get(rc, 'see include/ptta.h')
             raise RuntimeError('ptta_create failed (%d): %s' % (rc, why))
+        for k, v in (options or {}).items():       # include/ptta.h ptta_set_option
+            self.set_option(k, v)
         self.rows = int(self.lib.ptta_embedding_rows(self.handle))
         # adapted tensors in the reference's order, from the library (MSG_CHN 1layer: 2, 2layers: 7, NLSPN meta_bn: 88,
         # src/nlspn_model_adapt.py:322-337)
@@ -239,7 +241,12 @@ class Engine:
     def _frame_key(image, sparse):
         # what identifies a frame's CONTENT on the torch side: the storage and torch's in-place modification counters (a staging slot that is
         # refilled with `copy_` keeps its address and gets a new version)
-        return (image.data_ptr(), image._version, sparse.data_ptr(), sparse._version)
+        # (inference-mode tensors have no version counter and raise on the read: they get a key that never matches, i.e. a fresh token per
+        # call -- correct, merely unpipelined; such callers pass explicit tokens)
+        try:
+            return (image.data_ptr(), image._version, sparse.data_ptr(), sparse._version)
+        except RuntimeError:
+            return object()
 
     def step(self, image, sparse, validity=None, loss_image=None, want_depth=False, next_frame=None, frame_token=None, next_token=None):
         """forward + loss + backward + Adam in one enqueue (src/tta_main.py:610-633).
@@ -404,6 +411,16 @@ class Engine:
 
     def set_graph(self, enable):
         self._chk(self.lib.ptta_set_graph(self.handle, int(bool(enable))), 'ptta_set_graph')
+
+    def set_option(self, key, value):
+        """Per-handle switch (include/ptta.h ptta_set_option: graph, aux_stream, thru, fuse_first, fuse_head_bwd, fuse_heads, heads_v2,
+        cos_in_gemm, mask_bits)."""
+        self._chk(self.lib.ptta_set_option(self.handle, key.encode(), int(value)), 'ptta_set_option(%s)' % key)
+
+    def get_option(self, key):
+        v = ctypes.c_int(0)
+        self._chk(self.lib.ptta_get_option(self.handle, key.encode(), byref(v)), 'ptta_get_option(%s)' % key)
+        return v.value
 
     def profile(self, enable):
         self._chk(self.lib.ptta_profile(self.handle, int(bool(enable))), 'ptta_profile')

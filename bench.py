@@ -254,7 +254,7 @@ def two_streams_workload(steps=100, nstreams=2):
     return out
 
 
-def nlspn_workload(frames=10, inner_iter=3, dtype='fp32'):
+def nlspn_workload(frames=10, inner_iter=3, dtype='fp32', with_mixed=True):
     """BASELINE config 3 (not the headline metric): NLSPN backbone, 352x1216, 3 TTA steps per frame + the scored eval
     forward, adapt_mode meta_bn (88 adapted tensors), batch 1, inputs resident in HBM.  Reported beside the metric."""
     from proxytta import synth
@@ -294,7 +294,7 @@ def nlspn_workload(frames=10, inner_iter=3, dtype='fp32'):
                                                 'note': 'bf16x3: three bf16 MFMAs per fp32 product; frac counts all three, frac_useful = frac / 3 is the fp32-equivalent rate against the same bf16 peak'})(*nlspn_macs(H, W)),
            'finite': bool(torch.isfinite(info).all().item() and torch.isfinite(d).all().item())}
     eng.close()
-    if dtype == 'fp32':
+    if dtype == 'fp32' and with_mixed:
         # the generic engine's mixed mode beside it (fp32 storage; one bf16 MFMA per product for the proxy frames and the data gradients;
         # scored depth 2.0e-4 after the three steps: tests/test_gpu_mixed.py, profiles/r05_nlspn_costdcnet_mixed.txt)
         m = nlspn_workload(frames, inner_iter, dtype='mixed')
@@ -774,7 +774,9 @@ def main():
     from proxytta import synth
     from proxytta.engine import ADAPTED, Engine
     keep = tuple(k for k in os.environ.get('PTTA_BENCH_KEEP', '').split(',') if k)      # precision-budget runs only (tools/precision_budget.sh)
-    eng = Engine(1, H, W, dtype=args.dtype, keep=keep, **HP)
+    # A/B runs only (tools/exp_ab.sh): per-handle switches of include/ptta.h ptta_set_option as "key=value,key=value"
+    options = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in os.environ.get('PTTA_BENCH_OPTIONS', '').split(',') if kv}
+    eng = Engine(1, H, W, dtype=args.dtype, keep=keep, options=options, **HP)
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
     eng.load_state_dict(sd)
     for name in ADAPTED:
@@ -962,7 +964,7 @@ def main():
             'config': {'workload': 'MSG_CHN 1layer meta, 352x1216 KITTI-shaped synthetic, 1 TTA step/frame, batch 1 per GPU',
                        'parallelism': 'independent frame streams, dp%d, no collectives' % world, 'finite': finite,
                        'cpu_affinity': affinity, 'hip_force_dev_kernarg': kernarg,
-                       'other_dtype_same_run': other_dtype_ms,
+                       'other_dtype_same_run': other_dtype_ms, 'options': options or 'defaults',
                        'frame_pipelining': ('on: every call names the next frame of the stream; the part of its forward upstream of the adapted layer (frozen RGB '
                                             'encoder, sparse-depth pooling, stage-1/4 cascade down to decoder 1\'s last transposed conv) runs on a second stream '
                                             'beside the current step; K timed calls = K prefixes + K remainders; identical results' if pipe else 'off'),

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of environment switches on ONE box: bash tools/exp_ab.sh "VAR=a" "VAR=b" ...   (3 interleaved repeats each, graph replay)
+# A/B of bench settings on ONE box: bash tools/exp_ab.sh "PTTA_BENCH_OPTIONS=thru=0" "PTTA_BENCH_DTYPE=fp32" ...   (3 interleaved repeats each, graph replay)
 # prints the pipelined (headline) and the call-by-call step time of every variant
 cd $GRAFT_REPO_ROOT
 REPS=${REPS:-3}

@@ -1,12 +1,11 @@
 #!/bin/bash
-# kernel-level A/B of one switch: bash tools/exp_kt.sh VAR 'regex of kernel names'   (per kernel name and grid size: calls, mean us)
+# kernel-level A/B of one ptta_set_option key: bash tools/exp_kt.sh KEY 'regex of kernel names'   (per kernel name and grid size: calls, mean us)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-VAR=${1:-PTTA_FUSE_HEAD_BWD}; RE=${2:-first_kernel|conv_in_lds|conv32_s1_x3_kernel<false}
+KEY=${1:-fuse_head_bwd}; RE=${2:-first_kernel|conv_in_lds|conv32_s1_x3_kernel<false}
 for v in 0 1; do
-env $VAR=$v true
-export $VAR=$v
+export PTTA_BENCH_OPTIONS=$KEY=$v
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt$v -o x -- python3 bench.py --steps 20 --warmup 10 --single-block --no-nlspn --no-cpu-baseline > /dev/null 2> gpurun_out/kt$v.log
-echo "== $VAR=$v"; python3 - gpurun_out/kt$v/x_kernel_trace.csv "$RE" <<'PY'
+echo "== $KEY=$v"; python3 - gpurun_out/kt$v/x_kernel_trace.csv "$RE" <<'PY'
 import csv,sys,re,collections
 d=collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):

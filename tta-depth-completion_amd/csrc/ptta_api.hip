@@ -1140,7 +1140,10 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
     if (part != 1) c->cos_rows_done = false;
     // profiling class 6: 3 applications of Linear(32,512) / Linear(512,512) pairs (proj on both passes, pred on the proxy pass; proj.3 and
     // pred.0 run merged) = per row 2 x (32 + 512) + 4 x (512 + 512) elements by SURVEY 8d's rule as the REFERENCE executes it (6 linears)
-    ProfScope ps_(c, 6, s, ((double)c->Rg * (2 * 544 + 4 * 1024) + 2 * 16384.0 + 4 * 262144.0) * 4, (double)c->Rg * (2 * 16384.0 + 4 * 262144.0), heads_v2_on(c) ? 7 : 8);
+    // (bytes at the STORED width: the 32-wide feature rows are fp32 in both modes, the 512-wide activations and the weights bf16 in the narrow heads)
+    const double esh = (c->nar_heads && heads_v2_on(c)) ? 2.0 : 4.0;
+    ProfScope ps_(c, 6, s, (double)c->Rg * 2 * 32 * 4 + ((double)c->Rg * (2 * 512 + 4 * 1024) + 2 * 16384.0 + 4 * 262144.0) * esh,
+                  (double)c->Rg * (2 * 16384.0 + 4 * 262144.0), heads_v2_on(c) ? 7 : 8);
     const size_t half = (size_t)c->Rg * 32 * c->es;          // feat of the proxy frames follows the real frames
     const void* feat_zero = (const char*)c->feat + half;
     if (c->nar_heads && heads_v2_on(c)) {
@@ -1275,7 +1278,9 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
 
 // d ref -> d feat through proj = Linear(32,512) - BN1d - ReLU - Linear(512,512)
 int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
-    ProfScope ps_(c, 6, s, ((double)c->Rg * (1024 + 544) + 16384.0 + 262144.0) * 4, (double)c->Rg * (16384.0 + 262144.0), 3);   // data gradient through proj once
+    const double esh = (c->nar_heads && heads_v2_on(c)) ? 2.0 : 4.0;       // (stored widths, as heads_forward)
+    ProfScope ps_(c, 6, s, (double)c->Rg * 32 * (c->nar_bwd ? 2 : 4) + ((double)c->Rg * (1024 + 512) + 16384.0 + 262144.0) * esh,
+                  (double)c->Rg * (16384.0 + 262144.0), 3);   // data gradient through proj once
     const Lin& l0 = c->fc["proj.0"]; const Lin& l3 = c->fc["proj.3"]; BNorm& bn = c->bn["proj.1"];
     const int R = (int)c->Rg;
     if (c->nar_heads && heads_v2_on(c)) {

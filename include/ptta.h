@@ -343,6 +343,9 @@ int ptta_set_graph(ptta_handle h, int enable);         /* = ptta_set_option(h, "
  *   "heads_v2"      1        proj's hidden layer materialised (1: recomputed inside the GEMM from analytic BatchNorm statistics)
  *   "cos_in_gemm"   1        d loss_cos / d ref written as a tensor (1: formed in the backward GEMM's operand staging)
  *   "mask_bits"     1        fp32 pre-activation maps as ReLU masks (1: one word of sign bits per pixel)
+ *   "stamps"        0        (diagnostic, 1:) fourteen one-thread nodes of the step's and the prefix's graphs write wall_clock64() ticks since
+ *                            the step's first node into the debug tensor "stamps" -- where the branches of a replayed step start and end with
+ *                            no profiler attached (tools/step_stamps.py, profiles/r05_step_stamps.txt); results unchanged
  * bit-identical to the default: aux_stream, thru, fuse_first, fuse_head_bwd, mask_bits, graph; within bf16x3's own error (documented
  * in the tests): fuse_heads, heads_v2, cos_in_gemm.
  * Environment, read once per ptta_create (csrc/ptta_kernels.h ptta_create_env) because it decides allocation and arithmetic:

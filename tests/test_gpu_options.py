@@ -16,7 +16,7 @@ HP = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_dept
           max_input_depth=80.0)
 
 # options whose other value must not change one bit of the step
-BITWISE = [{'thru': 0}, {'fuse_first': 0}, {'fuse_first': 2}, {'fuse_head_bwd': 0}, {'mask_bits': 0}, {'aux_stream': 0}, {'graph': 0},
+BITWISE = [{'stamps': 1}, {'thru': 0}, {'fuse_first': 0}, {'fuse_first': 2}, {'fuse_head_bwd': 0}, {'mask_bits': 0}, {'aux_stream': 0}, {'graph': 0},
            {'thru': 0, 'fuse_first': 0, 'fuse_head_bwd': 0, 'mask_bits': 0}]
 
 
@@ -98,7 +98,7 @@ def test_option_errors_and_mixed_mode_keys():
     for k in ('mask_bits', 'fuse_first', 'fuse_heads', 'heads_v2', 'cos_in_gemm', 'fuse_head_bwd'):
         with pytest.raises(RuntimeError, match='mixed mode'):
             eng.set_option(k, 0)
-    eng.set_option('thru', 0); eng.set_option('aux_stream', 0); eng.set_option('graph', 0)
+    eng.set_option('thru', 0); eng.set_option('aux_stream', 0); eng.set_option('graph', 0); eng.set_option('stamps', 1)
     im, sp = _frames(1, 64, 96, 1)[0]
     eng.step(im, sp)
     torch.cuda.synchronize()

@@ -27,6 +27,12 @@
 
 namespace {
 
+// Diagnostic (option "stamps", tools/step_stamps.py): wall-clock stamps written by one-thread nodes of the step's graph (ticks since
+// stamp 0) -- where a replayed step's branches start and end WITHOUT a profiler attached (rocprofv3 slows the host enough to reorder them)
+static __global__ void stamp_kernel(float* out, unsigned long long* base, int i) {
+    const unsigned long long t = wall_clock64();
+    if (i == 0) { *base = t; out[0] = 0.f; } else out[i] = (float)(long long)(t - *base);
+}
 struct L32 { ConvW f{}, b{}; float* bias = nullptr; int transposed = 0; };
 struct LIn { float *wfrag = nullptr, *wcanon = nullptr, *bias = nullptr, *bw = nullptr; int cin = 1; };
 struct LOut { float *w = nullptr, *bias = nullptr, *bfrag = nullptr, *bcanon = nullptr; };
@@ -99,7 +105,8 @@ struct ptta_ctx {
     } m2;
     float* hyper = nullptr;      // device: lr b1 b2 eps wd | w_sd w_sm w_cos
     float* w3_tmp = nullptr;     // device: loss weights of the standalone loss call
-    int* step_dev = nullptr;
+    int* step_dev = nullptr; float* stamp_f = nullptr; unsigned long long* stamp_base = nullptr; int stamps = 0;
+    void stamp(int i, hipStream_t s) { if (stamps) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, s, stamp_f, stamp_base, i); }
     PttaAdamEntry* adam_tab = nullptr; unsigned* adam_ticket = nullptr; bool adam_tab_dirty = true;
     std::vector<PttaAdamEntry> adam_host;        // stays alive: the upload reads it
     bool fwd_valid = false;
@@ -326,6 +333,7 @@ __global__ void validity_kernel(const float* __restrict__ sparse, float* __restr
         v[i] = s > 0.f ? 1.f : s;              // torch.where(sd > 0, 1, sd), src/tta_main.py:583-586
     }
 }
+
 template <typename T>
 __global__ void to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = ld(src + i);
@@ -530,7 +538,7 @@ void build_workspace(ptta_ctx* c) {
     c->in_image = c->falloc((size_t)c->N * 3 * c->H * c->W); c->in_loss_image = c->falloc((size_t)c->N * 3 * c->H * c->W);
     c->in_sparse = c->falloc((size_t)c->N * c->H * c->W); c->in_validity = c->falloc((size_t)c->N * c->H * c->W);
     c->hyper = c->falloc(16); c->w3_tmp = c->falloc(4);
-    c->step_dev = (int*)c->dalloc(16);
+    c->step_dev = (int*)c->dalloc(16); c->stamp_f = c->falloc(16); c->stamp_base = (unsigned long long*)c->dalloc(8); c->dbg["stamps"] = Dbg{c->stamp_f, 16, 0};
     c->adam_tab = (PttaAdamEntry*)c->dalloc(8 * sizeof(PttaAdamEntry)); c->adam_ticket = (unsigned*)c->dalloc(16);
 #undef A_
 #undef M_
@@ -1070,16 +1078,22 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         // real frames on s, proxy frames (narrow) on the auxiliary stream; the heads (both passes' depth_encoder3 outputs) follow there
         hipStream_t sp = s2 ? s2 : s;
         if (s2) { HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
+        c->stamp(3, sp);
         RUN(meta_forward_proxy(c, sp));
+        c->stamp(1, s);
         RUN(region(s, 0, Nn, false));
+        c->stamp(2, s);
         RUN(region(sp, Nn, Nn, true));
+        c->stamp(4, sp);
         // (round 5, step 1: the heads still take fp32 features -- the proxy features are widened into the proxy half of `feat`)
         RUN(to_wide(c, c->tw(c->feat), (float*)c->feat + (size_t)c->Rg * 32, c->Rg * 32, sp));
         const bool hn = c->nar_heads && heads_v2_on(c);              // narrow heads: the proxy half needs nothing of the real chain
         if (s2) {
             if (hn) RUN(heads_forward(c, s2, 1));
+            c->stamp(5, s2);
             HIPCHK(hipEventRecord(c->ev_real, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_real, 0));
             RUN(heads_forward(c, s2, hn ? 2 : 0));
+            c->stamp(6, s2);
             HIPCHK(hipEventRecord(c->ev_join, s2));
         }
     } else {
@@ -1107,6 +1121,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         RUN(conv_out1_p(c, a, s));
     }
     }
+    c->stamp(7, s);
 #undef CV
     if (train) {
         if (s2) { if (!c->thru_active) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0)); }      // (thru: the heads' stream goes on into the loss and the backward)
@@ -1453,6 +1468,7 @@ int forward_common(ptta_ctx* c, const float* image, const float* sparse, bool tr
             ptta_pack_conv32(c->adapted[3].p, c->m2.w2b[g], 1, 1, s, 128, 32 * g);                 // its input gradient
         }
     } else {
+        c->stamp(0, s);
         const L32& ml = c->l32["conv1_rgb_meta"];
         { ProfScope ps_(c, 8, s, 0, 0, 1); ptta_pack_conv32(c->meta_w, ml.f, 0, 0, s); }
     }
@@ -1914,6 +1930,7 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
         const int rc_h = heads_backward(c, c->gref_buf, s2);
         c->cos_in_gemm = false;
         if (rc_h) return rc_h;
+        c->stamp(8, s2);
         HIPCHK(hipEventRecord(c->ev_join, s2));
         const float* g_net = c->g_final;
         if (c->dual) {
@@ -1923,7 +1940,9 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
         }
         RUN(backbone_backward(c, g_net, s, true));
         if (c->grad_comm && ptta_rccl_allreduce_mean_f32(c->grad_comm, c->grad_arena, c->grad_arena_n, s_)) return c->fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
+        c->stamp(9, s);
         RUN(ptta_adam_step(c, nullptr, nullptr, s_));
+        c->stamp(10, s);
         return 0;
     }
     // validity == NULL: where(sparse > 0, 1, sparse) is evaluated inside the loss kernels; the loss finalisation runs inside
@@ -2061,10 +2080,14 @@ static int pipe_quiesce(ptta_ctx* c) {
     return 0;
 }
 static int prefix_body(ptta_ctx* c, const float* image, const float* sparse, hipStream_t s) {
+    c->stamp(11, s);
     RUN(ptta_launch_prep(sparse, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
     RUN(rgb_encoder(c, image, c->Nn, 0, c->Nn, s));
+    c->stamp(12, s);
     RUN(enc1_head_fn(c, s));
-    return stage1_independent(c, 2 * c->Nn, s);
+    RUN(stage1_independent(c, 2 * c->Nn, s));
+    c->stamp(13, s);
+    return 0;
 }
 template <class F>
 static int pipe_capture(ptta_ctx* c, hipGraph_t* g_out, hipGraphExec_t* e_out, F body);
@@ -2470,9 +2493,10 @@ int ptta_set_option(ptta_handle c, const char* key, int value) {
     else if (k == "heads_v2") f = &c->heads_v2;
     else if (k == "cos_in_gemm") f = &c->cos_grad_fused;
     else if (k == "mask_bits") f = &c->mask_bits_on;
+    else if (k == "stamps") f = &c->stamps;
     else return c->fail("ptta_set_option: unknown key '" + k + "'", -22);
     if (value < lo || value > hi) return c->fail("ptta_set_option: value out of range for '" + k + "'", -22);
-    if (c->mixed && k != "aux_stream" && k != "thru" && value != 1)
+    if (c->mixed && k != "aux_stream" && k != "thru" && k != "stamps" && value != 1)
         return c->fail("ptta_set_option: the mixed mode is defined on the default kernels ('" + k + "' stays 1)", -38);
     if (k == "aux_stream" && c->pre_sync_graph >= 0) { c->pre_sync_aux = value; return 0; }      // statistics exchange active: takes effect when it ends
     if (*f == value) return 0;
@@ -2495,6 +2519,7 @@ int ptta_get_option(ptta_handle c, const char* key, int* value) {
     else if (k == "heads_v2") *value = c->heads_v2;
     else if (k == "cos_in_gemm") *value = c->cos_grad_fused;
     else if (k == "mask_bits") *value = c->mask_bits_on;
+    else if (k == "stamps") *value = c->stamps;
     else return -22;
     return 0;
 }

@@ -414,7 +414,7 @@ class Engine:
 
     def set_option(self, key, value):
         """Per-handle switch (include/ptta.h ptta_set_option: graph, aux_stream, thru, fuse_first, fuse_head_bwd, fuse_heads, heads_v2,
-        cos_in_gemm, mask_bits)."""
+        cos_in_gemm, mask_bits, stamps)."""
         self._chk(self.lib.ptta_set_option(self.handle, key.encode(), int(value)), 'ptta_set_option(%s)' % key)
 
     def get_option(self, key):

@@ -8,7 +8,7 @@
 # then 4. what a small convolution launch costs inside a replayed graph; 5. NLSPN and CostDCNet: top kernels
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=r05; O=gpurun_out/$R; rm -rf $O; mkdir -p $O
-CLASS='conv32_s1_(x3_kernel<(float|unsigned short), true|small_kernel<(float|unsigned short), true|first_kernel<)'
+CLASS='conv32_s1_(x3_kernel<(float|unsigned short), true|first_kernel<(float|unsigned short), [23])'      # bench.py's dominant kernel: ReLU-on-load stride-1 convolutions on large maps, forward forms
 SHORT="--steps 4 --warmup 2 --single-block --no-nlspn --no-cpu-baseline --no-self-check"
 # counter calibration on a known byte count (one 352x1216 map in, one out)
 for DT in fp32 narrow; do

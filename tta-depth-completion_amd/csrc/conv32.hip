@@ -958,7 +958,7 @@ __global__ void conv32_naive_kernel(Conv32P<T> p) {
 
 // ---- weight packing (device side, so adapted parameters can be re-packed every step) ----------
 // src: a Conv2d weight [out][in][3][3] or ConvTranspose2d weight [in][out][3][3] (fp32, NCHW).
-// in_major: src is indexed [cin_eff][cout_eff]; flip: use tap (2-ky, 2-kx).  See DESIGN.md §4 for
+// in_major: src is indexed [cin_eff][cout_eff]; flip: use tap (2-ky, 2-kx).  See DESIGN.md §5 for
 // which (in_major, flip) pair each forward/backward use needs.
 __global__ void pack_conv32_kernel(const float* __restrict__ src, float* mf32, bf16_t* mbf16, bf16_t* mlo, float* canon,
                                    int in_major, int flip, int row_stride, int col_off) {

@@ -475,7 +475,7 @@ GNet* costdc_create(int n, int h, int w, const ptta_hparams* hp, float max_depth
     // (the DDP adapted set adapts the UNet3D's own BatchNorm too: every layer keeps the third plane there)
     e->x6_layers = (flags & 1) ? "" : "enc2d,conv1_rgb_meta,unet3d.inc,unet3d.down1";
     // hipGraph replay of the step / eval forward: built and bit-identical (tests), but measured 0.3 - 2 % SLOWER than kernel-by-kernel
-    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: ptta_set_option(h, "graph", 1) / PTTA_GRAPH=1
+    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN_LOG.md section 9) -> opt-in: ptta_set_option(h, "graph", 1) / PTTA_GRAPH=1
     e->use_graph = env.graph == 1 ? 1 : 0;
     e->sync_adapt = (flags & 1) ? 1 : 0;
     e->build();

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(GemmX3P q) {
 // tile, 8 lock-step waves, two LDS stages: 24 % MFMA duty, 68 % of wave cycles parked) and against two independent 128x256
 // blocks per CU: 85 / 92 / 95 us per 26752x512x512 GEMM; ablations (profiles/r02_gemm_ablation.txt): stores 20 us, loads 16 us,
 // MFMAs 16 us, everything else 34 us and nothing overlaps across the block's single K loop -> the shape is bound by
-// per-block latency chains, not by the matrix cores.
+// per-block latency chains, not by the matrix cores (DESIGN_LOG.md §8).
 #define GSTAMP(v) do { if (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
 template <int PRO, int EPI, bool TIMING = false>
 __global__ __launch_bounds__(512, 1) void gemm_x3_ws_kernel(GemmX3P q) {

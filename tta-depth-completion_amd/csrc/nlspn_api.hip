@@ -294,7 +294,7 @@ GNet* nlspn_create(int n, int h, int w, const ptta_hparams* hp, int legacy_offse
     e->naive = env.naive;          // direct fp32 kernels everywhere (validation)
     e->x6 = 0;                     // (third operand plane: off -- matrix-core bound, parity holds without)
     // hipGraph replay of the step / eval forward: built and bit-identical (tests), but measured 0.3 - 2 % SLOWER than kernel-by-kernel
-    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN.md section 9) -> opt-in: ptta_set_option(h, "graph", 1) / PTTA_GRAPH=1
+    // launches on this engine (the host keeps ahead of the GPU either way: DESIGN_LOG.md section 9) -> opt-in: ptta_set_option(h, "graph", 1) / PTTA_GRAPH=1
     e->use_graph = env.graph == 1 ? 1 : 0;
     e->build();
     if (e->oom || !e->step_dev) { delete e; *rc = -12; return nullptr; }

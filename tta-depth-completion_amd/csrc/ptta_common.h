@@ -1,6 +1,6 @@
 // Shared device/host definitions for libptta_hip (gfx950 only).
 //
-// Data layout in HBM (DESIGN.md §3):
+// Data layout in HBM (DESIGN.md §4):
 //   * 32-channel feature maps: NHWC, element type T = float (fp32 mode) or bf16 (bf16 mode);
 //     one pixel = one 128-B (fp32) / 64-B (bf16) line, so every access to a pixel is a full line.
 //   * 1- and 3-channel maps (image, sparse depth, predictions, depth gradients): planar NCHW fp32,

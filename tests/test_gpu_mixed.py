@@ -105,9 +105,14 @@ def test_mixed_ten_step_sequence_matches_reference(golden_dir):
         np.testing.assert_allclose(info.cpu().numpy(), g[p + 'loss_info'], rtol=3e-4)
         _check_map(eng.forward_eval(image, sparse), g, p + 'depth_eval', 3.5e-4)
     p = 's%d/' % (steps - 1)
+    # after ten Adam steps (measured, tools/mixed_report.py): weight 3.5e-4, its first moment 4.5e-3; bias 6.0e-3 / 4.0e-3.  The 9,216-entry weight
+    # averages the +-lr noise of near-zero gradient entries; the 32-entry bias does not: ONE entry taking the opposite +-lr step in one of the ten
+    # steps moves its rel. MAE by 2 lr / (32 mean|b|) = 5e-3 (1.1e-3 with round 5's first BatchNorm-statistics kernels, 6.0e-3 = one flip after
+    # their sums were re-associated).  Bounds: 2x measured; the bias at two flips.
     for k, (prm, m, v) in adapted.items():
-        assert rel_mae(prm, g[p + 'param/' + k]) < 2.2e-3, k           # measured 1.1e-3
-        assert rel_mae(m, g[p + 'exp_avg/' + k]) < 7.4e-3, k           # measured 3.7e-3
+        small = prm.numel() <= 32
+        assert rel_mae(prm, g[p + 'param/' + k]) < (1.2e-2 if small else 7e-4), k
+        assert rel_mae(m, g[p + 'exp_avg/' + k]) < (8e-3 if small else 9e-3), k
     assert eng.adam_step_count() == steps
     eng.close()
 

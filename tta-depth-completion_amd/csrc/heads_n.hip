@@ -482,59 +482,76 @@ long ptta_hn_tiled_elems(long R) { return (long)ptta_hn_row_blocks(R) * 128 * 51
 //     fp32 only AFTER the subtraction) and evaluates per hidden unit j: mean_j = w_j . m + b_j, var_j = w_j^T C w_j.  It hands
 //     sum h = n mean_j and sum h^2 = n (var_j + mean_j^2) to the ordinary finalize as TWO float partial "blocks" (value, and what the
 //     float rounding of it lost): the layout ptta_launch_bn_finalize / ptta_stat_sync reduce, [pass][2 blocks][2][512].
-#define HNM_ROWS 256
+#define HNM_ROWS 128       // rows per block of the first stage (one sub-tile: 209 blocks per KITTI frame)
 int ptta_hn_moment_blocks(long R) { return (int)((R + HNM_ROWS - 1) / HNM_ROWS); }
-__global__ __launch_bounds__(256) void hn_moments_kernel(const float* __restrict__ X, long R, double* __restrict__ Sp) {
+// doubles of scratch per pass: the first stage's partial sets, then the reduced 32 x 33 moments
+long ptta_hn_moment_scratch(long R) { return (long)ptta_hn_moment_blocks(R) * 1056 + 1056; }
+// stage 1: second moments [32][33] (column 32: the sums) of 128 feature rows per block, fp32 products of one sub-tile summed into doubles
+__global__ __launch_bounds__(256) void hn_moments_kernel(const float* __restrict__ X, long R, double* __restrict__ Sp, long pass_stride) {
     __shared__ __attribute__((aligned(16))) float xs[128][36];
     const int t = threadIdx.x, a = t >> 3, b4 = (t & 7) * 4;
     const float* Xp = X + (size_t)blockIdx.y * R * 32;
     const long r0 = (long)blockIdx.x * HNM_ROWS;
-    double s00 = 0, s01 = 0, s02 = 0, s03 = 0, sa = 0;
-    float4 pre[2][4];
 #pragma unroll
-    for (int half = 0; half < 2; ++half)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                          // both sub-tiles' loads up front
-            const int idx = t + 256 * q;                       // float4 index: row = idx >> 3, channels 4 (idx & 7) ...
-            const long row = r0 + 128 * half + (idx >> 3);
-            pre[half][q] = row < R ? *(const float4*)(Xp + row * 32 + 4 * (idx & 7)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int idx = t + 256 * q; *(float4*)&xs[idx >> 3][4 * (idx & 7)] = pre[half][q]; }
-        __syncthreads();
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, fs = 0.f;
-#pragma unroll 16
-        for (int r = 0; r < 128; ++r) {
-            const float xa = xs[r][a];
-            const float4 xb = *(const float4*)&xs[r][b4];
-            f0 = fmaf(xa, xb.x, f0); f1 = fmaf(xa, xb.y, f1); f2 = fmaf(xa, xb.z, f2); f3 = fmaf(xa, xb.w, f3);
-            fs += xa;
-        }
-        s00 += (double)f0; s01 += (double)f1; s02 += (double)f2; s03 += (double)f3; sa += (double)fs;
-        __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int idx = t + 256 * q;                       // float4 index: row = idx >> 3, channels 4 (idx & 7) ...
+        const long row = r0 + (idx >> 3);
+        *(float4*)&xs[idx >> 3][4 * (idx & 7)] = row < R ? *(const float4*)(Xp + row * 32 + 4 * (idx & 7)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    double* out = Sp + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (32 * 33);
-    out[a * 33 + b4] = s00; out[a * 33 + b4 + 1] = s01; out[a * 33 + b4 + 2] = s02; out[a * 33 + b4 + 3] = s03;
-    if (b4 == 0) out[a * 33 + 32] = sa;
+    __syncthreads();
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, fs = 0.f;
+#pragma unroll 16
+    for (int r = 0; r < 128; ++r) {
+        const float xa = xs[r][a];
+        const float4 xb = *(const float4*)&xs[r][b4];
+        f0 = fmaf(xa, xb.x, f0); f1 = fmaf(xa, xb.y, f1); f2 = fmaf(xa, xb.z, f2); f3 = fmaf(xa, xb.w, f3);
+        fs += xa;
+    }
+    double* out = Sp + (size_t)blockIdx.y * pass_stride + (size_t)blockIdx.x * (32 * 33);
+    out[a * 33 + b4] = (double)f0; out[a * 33 + b4 + 1] = (double)f1; out[a * 33 + b4 + 2] = (double)f2; out[a * 33 + b4 + 3] = (double)f3;
+    if (b4 == 0) out[a * 33 + 32] = (double)fs;
 }
-__global__ __launch_bounds__(1024) void hn_moment_stats_kernel(const double* __restrict__ Sp, int nblk, long R, const float* __restrict__ W0,
+// stage 2, 33 blocks per pass: block g sums the partial sets of elements 32 g .. 32 g + 31 -- thread (element i, lane k of 32) takes the sets
+// k, k + 32, ... (up to eight independent loads in flight), the 32 lanes' sums are added in a fixed order.  (A last-block-done form of stages
+// 2 + 3 in one launch was measured: its agent-scope release writes back the whole L2 under the other chains' kernels -- the step got 2 % slower.)
+#define HNM_MAXSETS 256
+__global__ __launch_bounds__(1024) void hn_moment_reduce_kernel(double* __restrict__ Sp, int nblk, long pass_stride) {
+    __shared__ double S[32 * 32];
+    const int t = threadIdx.x, g = blockIdx.x;
+    double* sp = Sp + (size_t)blockIdx.y * pass_stride;
+    const int i = t & 31, kl = t >> 5, e = g * 32 + i;
+    double v[HNM_MAXSETS / 32];
+#pragma unroll
+    for (int j = 0; j < HNM_MAXSETS / 32; ++j) { const int k = kl + 32 * j; v[j] = k < nblk ? sp[(size_t)k * 1056 + e] : 0.0; }
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < HNM_MAXSETS / 32; ++j) acc += v[j];
+    for (int k = kl + HNM_MAXSETS; k < nblk; k += 32) acc += sp[(size_t)k * 1056 + e];      // (frames of more than 32K rows)
+    S[kl * 32 + i] = acc;
+    __syncthreads();
+    if (t < 32) {
+        double r = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) r += S[k * 32 + t];          // fixed order
+        sp[(size_t)nblk * 1056 + g * 32 + t] = r;
+    }
+}
+// stage 3, one block per pass: the complete moments -> BatchNorm1d statistics of Linear(32, 512): mean_j = w_j . m + b_j, var_j = w_j^T C w_j,
+// written as the two-"block" column partials bn_finalize expects.  Two threads per column (rows a < 16 / a >= 16 of C), four accumulators each.
+__global__ __launch_bounds__(1024) void hn_moment_stats_kernel(const double* __restrict__ Sp, int nblk, long pass_stride, long R, const float* __restrict__ W0,
                                                                const float* __restrict__ b0, float* __restrict__ part) {
     __shared__ double S[32 * 33];
     __shared__ __attribute__((aligned(16))) float Cf[32][32];
     __shared__ float mf[32];
-    const int t = threadIdx.x;
-    const double* sp = Sp + (size_t)blockIdx.x * nblk * (32 * 33);
-    for (int e = t; e < 32 * 33; e += 1024) {
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;         // four independent chains: the loads of a trip are all in flight
-        int k = 0;
-        for (; k + 4 <= nblk; k += 4) {
-            v0 += sp[(size_t)k * 1056 + e]; v1 += sp[(size_t)(k + 1) * 1056 + e]; v2 += sp[(size_t)(k + 2) * 1056 + e]; v3 += sp[(size_t)(k + 3) * 1056 + e];
-        }
-        for (; k < nblk; ++k) v0 += sp[(size_t)k * 1056 + e];
-        S[e] = (v0 + v1) + (v2 + v3);                          // fixed order
-    }
+    __shared__ float vpart[2][512], mpart[2][512];
+    const int t = threadIdx.x, pass = blockIdx.x;
+    const double* Sg = Sp + (size_t)pass * pass_stride + (size_t)nblk * 1056;
+    const int col = t & 511, hf = t >> 9;
+    float w[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float4 v = *(const float4*)(W0 + (size_t)col * 32 + 4 * q); w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+    const float bj = b0[col];
+    for (int e = t; e < 32 * 33; e += 1024) S[e] = Sg[e];
     __syncthreads();
     const double n = (double)R;
     {
@@ -544,35 +561,41 @@ __global__ __launch_bounds__(1024) void hn_moment_stats_kernel(const double* __r
         if (b == 0) mf[a] = (float)ma;
     }
     __syncthreads();
-    if (t >= 512) return;
-    float w[32];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const float4 v = *(const float4*)(W0 + (size_t)t * 32 + 4 * q); w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
     float wm = 0.f, var = 0.f;
 #pragma unroll
-    for (int a = 0; a < 32; ++a) {
-        wm = fmaf(w[a], mf[a], wm);
-        float rq = 0.f;
+    for (int aa = 0; aa < 16; ++aa) {
+        const int a = 16 * hf + aa;
+        float wa = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) wa = (q == a) ? w[q] : wa;           // (w[] stays in registers: no dynamic indexing)
+        wm = fmaf(wa, mf[a], wm);
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float4 cv = *(const float4*)&Cf[a][4 * q];
-            rq = fmaf(cv.x, w[4 * q], rq); rq = fmaf(cv.y, w[4 * q + 1], rq); rq = fmaf(cv.z, w[4 * q + 2], rq); rq = fmaf(cv.w, w[4 * q + 3], rq);
+            r0 = fmaf(cv.x, w[4 * q], r0); r1 = fmaf(cv.y, w[4 * q + 1], r1); r2 = fmaf(cv.z, w[4 * q + 2], r2); r3 = fmaf(cv.w, w[4 * q + 3], r3);
         }
-        var = fmaf(w[a], rq, var);
+        var = fmaf(wa, (r0 + r1) + (r2 + r3), var);
     }
-    const double mean = (double)wm + (double)b0[t], vr = var > 0.f ? (double)var : 0.0;
+    vpart[hf][col] = var; mpart[hf][col] = wm;
+    __syncthreads();
+    if (t >= 512) return;
+    var = vpart[0][t] + vpart[1][t]; wm = mpart[0][t] + mpart[1][t];
+    const double mean = (double)wm + (double)bj, vr = var > 0.f ? (double)var : 0.0;
     const double sh = n * mean, sh2 = n * (vr + mean * mean);
-    float* o = part + (size_t)blockIdx.x * 2 * 2 * 512;
+    float* o = part + (size_t)pass * 2 * 2 * 512;
     const float h0 = (float)sh, q0 = (float)sh2;
     o[t] = h0; o[512 + t] = q0;                                                    // "block" 0: the float values
     o[1024 + t] = (float)(sh - (double)h0); o[1536 + t] = (float)(sh2 - (double)q0);      // "block" 1: what the rounding lost
 }
-// X: `npass` consecutive groups of R rows x 32 fp32; scratch: npass * ptta_hn_moment_blocks(R) * 1056 doubles; part: [npass][2][2][512] floats
+// X: `npass` consecutive groups of R rows x 32 fp32; scratch: npass * ptta_hn_moment_scratch(R) doubles; part: [npass][2][2][512] floats
 int ptta_launch_hn_moments(const float* X, long R, int npass, const float* W0, const float* b0, double* scratch, float* part, hipStream_t s) {
     if (!X || !W0 || !b0 || !scratch || !part || R < 1 || npass < 1) return -22;
     const int nb = ptta_hn_moment_blocks(R);
-    hipLaunchKernelGGL(hn_moments_kernel, dim3(nb, npass), dim3(256), 0, s, X, R, scratch);
-    hipLaunchKernelGGL(hn_moment_stats_kernel, dim3(npass), dim3(1024), 0, s, scratch, nb, R, W0, b0, part);
+    const long ps = ptta_hn_moment_scratch(R);
+    hipLaunchKernelGGL(hn_moments_kernel, dim3(nb, npass), dim3(256), 0, s, X, R, scratch, ps);
+    hipLaunchKernelGGL(hn_moment_reduce_kernel, dim3(33, npass), dim3(1024), 0, s, scratch, nb, ps);
+    hipLaunchKernelGGL(hn_moment_stats_kernel, dim3(npass), dim3(1024), 0, s, scratch, nb, ps, R, W0, b0, part);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

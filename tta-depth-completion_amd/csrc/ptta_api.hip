@@ -461,7 +461,7 @@ void build_workspace(ptta_ctx* c) {
         const size_t te = (size_t)ptta_hn_tiled_elems(c->Rg) * 2;          // tiled layout, padded to whole 128-row blocks (heads_n.hip)
         c->emb_n = (bf16_t*)c->dalloc(te); c->ref_n = (bf16_t*)c->dalloc(te); c->h2_n = (bf16_t*)c->dalloc(te);
         c->hn_rs = c->falloc((size_t)c->Rg);
-        c->hn_msc = (double*)c->dalloc((size_t)2 * ptta_hn_moment_blocks(c->Rg) * 1056 * sizeof(double));
+        c->hn_msc = (double*)c->dalloc((size_t)2 * ptta_hn_moment_scratch(c->Rg) * sizeof(double));
         c->dbg["emb"] = Dbg{c->emb_n, (long)RD, 3}; c->dbg["ref"] = Dbg{c->ref_n, (long)RD, 3};
     }
     c->dbg["h1"] = Dbg{c->h1, (long)RD, 0}; c->dbg["gmask"] = Dbg{c->gmask, (long)RD, 0}; c->dbg["gref"] = Dbg{c->gref_buf, (long)RD, 0};
@@ -1170,7 +1170,7 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
         const long R = c->Rg; const int Rw = (int)R * (c->stat_sync.world > 1 ? c->stat_sync.world : 1);
         const int nbh = 2, nb = ptta_hn_row_blocks(R);           // (the moments path hands the finalize two partial "blocks": value + rounding remainder)
         float* part_real = c->hm_part; float* part_zero = c->hm_part + (size_t)nbh * 2 * 512;
-        double* msc_real = c->hn_msc; double* msc_zero = c->hn_msc + (size_t)ptta_hn_moment_blocks(R) * 1056;
+        double* msc_real = c->hn_msc; double* msc_zero = c->hn_msc + (size_t)ptta_hn_moment_scratch(R);
         auto gemm_h = [&](const void* x, int x_bf16, const Lin& w, bf16_t* out, int epi) {
             HnGemmArgs g; g.pro = 3; g.epi = epi; g.X = x; g.x_bf16 = x_bf16; g.W0 = l0.Whi; g.b0 = l0.bias; g.pscale = b1.scale; g.pshift = b1.shift;
             g.W = w.Wsl; g.bias = w.bias; g.C = out; g.part = c->bn_part; g.R = R;

@@ -191,6 +191,7 @@ long ptta_hn_tiled_elems(long R);                                   // elements 
 void ptta_hn_pack_w(const bf16_t* w_hi_rowmajor, bf16_t* w_slice_major, int K, hipStream_t s);
 int ptta_launch_hn_untile(const void* src_tiled, float* dst, long R, hipStream_t s);
 int ptta_hn_moment_blocks(long R);
+long ptta_hn_moment_scratch(long R);       // doubles of scratch per pass
 int ptta_launch_hn_moments(const float* X, long R, int npass, const float* W0, const float* b0, double* scratch, float* part, hipStream_t s);
 long ptta_loss_ws_cos_off(int N); int ptta_loss_cos_blocks();        // loss.hip: where the cosine term's block partials live in the workspace
 int ptta_launch_hn_gemm(const HnGemmArgs& a, hipStream_t s);

@@ -14,7 +14,7 @@
  *     is allocated after ptta_create and no call on the path synchronises (host constants travel as
  *     kernel arguments).  The only calls that wait for the stream are the ones that RETURN a host
  *     value (ptta_get_adam_step, ptta_profile_read), the ones that destroy a captured graph
- *     (they wait for its last replay: ptta_load_weights, ptta_bind_adapted, ptta_set_image_norm,
+ *     (option "graph" = 1 only; they wait for its last replay: ptta_load_weights, ptta_bind_adapted, ptta_set_image_norm,
  *     ptta_set_graph(0), a changed max_input_depth in ptta_set_hparams), ptta_step_pipelined when it
  *     is handed a frame it was NOT told about by the previous call (it waits for its own prefix
  *     stream once before computing that frame's prefix in line; an announced frame costs no wait),
@@ -187,8 +187,8 @@ int ptta_step_pipelined(ptta_handle h, const float* image, const float* loss_ima
  * copy's event before the call that announces the frame -- not the caller's stream, which would delay the current step. */
 int ptta_pipeline_stream(ptta_handle h, ptta_stream* stream_out);
 /* The scored eval forward (src/tta_main.py:729-736) of the frame the last ptta_step_pipelined call adapted, without recomputing that
- * frame's parameter-independent prefix (it is still in the handle).  When that call ran as a plain ptta_step (no graph replay, profiling,
- * SyncBatchNorm / gradient exchange, padded sizes, bf16 storage) this is a full ptta_forward_eval of its frame, read from the caller's
+ * frame's parameter-independent prefix (it is still in the handle).  When that call ran as a plain ptta_step (profiling, validation kernels,
+ * SyncBatchNorm / gradient exchange, padded sizes) this is a full ptta_forward_eval of its frame, read from the caller's
  * buffers of that call (which must still hold it).  -3 when no such frame is held (e.g. after ptta_load_weights or a ptta_forward_eval). */
 int ptta_forward_eval_last(ptta_handle h, float* depth_out, ptta_stream s);
 
@@ -295,8 +295,7 @@ int ptta_photometric(const float* src, float* dst, int n, int height, int width,
                      const uint8_t* do_contrast, const float* f_contrast, const uint8_t* do_saturation, const float* f_saturation,
                      double* scratch, ptta_stream s);
 
-/* ptta_step replays a captured hipGraph of the whole step by default (ptta_set_option(h, "graph", 0)
- * launches kernel by kernel).  Graphs are re-captured after any re-binding. */
+/* ptta_step enqueues its kernels directly; with ptta_set_option(h, "graph", 1) it replays a captured hipGraph of the whole step.  Graphs are re-captured after any re-binding. */
 /* model.convert_syncbn() (src/tta_main.py:326 -> SyncBatchNorm.convert_sync_batchnorm, src/msg_chn_model_adapt.py:547-556)
  * for the one-process-per-GPU run with shared adapted parameters: every training-mode BatchNorm then normalises with
  * the statistics of the GLOBAL batch.  The library collapses a BatchNorm's partial sums into `exchange_buf` (device,
@@ -334,7 +333,10 @@ int ptta_set_graph(ptta_handle h, int enable);         /* = ptta_set_option(h, "
  * form does not apply (small maps, N > 16, SyncBatchNorm exchange).  Unknown key / value out of range: -22; a key the handle does
  * not have: -38 (the generic engine has "graph" only; PTTA_DTYPE_MIXED handles keep every key but graph / aux_stream / thru at 1).
  *   key             default  meaning of 0
- *   "graph"         1 (0 for NLSPN / CostDCNet)  kernel-by-kernel launches instead of hipGraph replay
+ *   "graph"         0        (1:) ptta_step / ptta_step_pipelined / ptta_forward_eval replay captured hipGraphs from their second call on.  Default
+ *                            since round 5: direct launches on the caller's stream and the handle's own streams -- measured FASTER than replay
+ *                            on ROCm 7.2 for all three engines (MSG_CHN pipelined 1.28 vs 1.31 ms, call by call 1.45 vs 1.52: a replayed
+ *                            graph starts its second branch late and runs it slower, profiles/r05_step_stamps.txt; host cost 0.46 ms per call)
  *   "aux_stream"    1        one stream: no second queue for the proxy chain / the heads
  *   "thru"          1        the heads' stream joins the main stream before the loss (1: it runs on into loss + head backward)
  *   "fuse_first"    1        every first-layer convolution + the following 32->32 convolution as two launches (2: the RGB branch fused too)

@@ -27,7 +27,7 @@ def _check_map(got, g, key, tol):
     assert abs(np.abs(flat).mean(dtype=np.float64) - float(g[key + '_abs_mean'])) < tol * float(g[key + '_abs_mean'])
 
 
-@pytest.mark.parametrize('path', ['plain', 'pipelined'])
+@pytest.mark.parametrize('path', ['plain', 'pipelined', 'pipelined_graph'])
 @pytest.mark.parametrize('name,meta', [('msgchn_1layer_352x1216', '1layer'), ('msgchn_1layer_256x320', '1layer'),
                                        ('msgchn_2layers_352x1216', '2layers'), ('msgchn_2layers_256x320', '2layers')])
 def test_full_size_matches_reference(golden_dir, name, meta, path):
@@ -37,12 +37,12 @@ def test_full_size_matches_reference(golden_dir, name, meta, path):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps, frame0 = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
-    eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, None, meta=meta)
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, None, meta=meta, options={'graph': 1 if 'graph' in path else 0})
     for s in range(steps):
         image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s, h, w, n)]
         p = 's%d/' % s
         nxt = None
-        if path == 'pipelined':
+        if 'pipelined' in path:
             nxt = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s + 1, h, w, n)]
         info, depth = eng.step(image, sparse, want_depth=True, next_frame=nxt)
         torch.cuda.synchronize()
@@ -72,7 +72,7 @@ def test_full_size_matches_reference(golden_dir, name, meta, path):
                 key = k[len(p) + 4:]
                 if not key.startswith('proj_t'):
                     assert rel_mae(sd[key], g[k]) < 2e-3, k
-        d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
+        d_eval = eng.forward_eval_last() if 'pipelined' in path else eng.forward_eval(image, sparse)
         _check_map(d_eval, g, p + 'depth_eval', 1e-4)
     eng.close()
 

@@ -22,18 +22,18 @@ from tests.util import golden_hp, make_engine, rel_mae
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('path', ['plain', 'pipelined'])
+@pytest.mark.parametrize('path', ['plain', 'pipelined', 'pipelined_graph'])
 @pytest.mark.parametrize('name,meta', [('msgchn_1layer_352x1216', '1layer'), ('msgchn_1layer_256x320', '1layer'),
                                        ('msgchn_2layers_352x1216', '2layers'), ('msgchn_2layers_256x320', '2layers')])
 def test_mixed_full_size_matches_reference(golden_dir, name, meta, path):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps, frame0 = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
-    eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, gain, None, meta=meta)
+    eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, gain, None, meta=meta, options={'graph': 1 if 'graph' in path else 0})
     for s in range(steps):
         image, sparse = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s, h, w, n)]
         p = 's%d/' % s
-        nxt = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s + 1, h, w, n)] if path == 'pipelined' else None
+        nxt = [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s + 1, h, w, n)] if 'pipelined' in path else None
         info, depth = eng.step(image, sparse, want_depth=True, next_frame=nxt)
         torch.cuda.synchronize()
         # the training-mode depth is made of fp32 / bf16x3 tensors only: the fp32 mode's bound (second step: behind one mixed Adam move)
@@ -63,7 +63,7 @@ def test_mixed_full_size_matches_reference(golden_dir, name, meta, path):
         for k in g.files:
             if k.startswith(p + 'buf/') and not k[len(p) + 4:].startswith('proj_t'):
                 assert rel_mae(sd[k[len(p) + 4:]], g[k]) < 1e-2, k
-        d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
+        d_eval = eng.forward_eval_last() if 'pipelined' in path else eng.forward_eval(image, sparse)
         _check_map(d_eval, g, p + 'depth_eval', 3e-4)
     eng.close()
 
@@ -118,7 +118,7 @@ def test_mixed_ten_step_sequence_matches_reference(golden_dir):
 
 
 @pytest.mark.parametrize('side', ['below', 'above'])
-@pytest.mark.parametrize('path', ['graph', 'pipelined', 'eager'])
+@pytest.mark.parametrize('path', ['graph', 'pipelined', 'pipelined_graph', 'eager'])
 def test_mixed_cosine_gate_on_the_reference_side(golden_dir, side, path):
     """loss_cos < 0.3 => w_cos = 0 (src/external_model_adapt.py:424-425), evaluated on device from the narrow embeddings: the gate must fall
     on the reference's side in both fixtures (L_cos = 0.204 / 0.369) -- w_cos = 300 there, so a gate taken the wrong way moves the first-step
@@ -126,15 +126,13 @@ def test_mixed_cosine_gate_on_the_reference_side(golden_dir, side, path):
     g = np.load(os.path.join(golden_dir, 'msgchn_1layer_64x96_gate_%s.npz' % side))
     h, w, n, steps = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
-    eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, gain, None, head_bias=float(g['head_bias']))
-    if path == 'eager':
-        eng.set_graph(False)
+    eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, gain, None, head_bias=float(g['head_bias']), options={'graph': 1 if 'graph' in path else 0})
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(s, h, w, n)] for s in range(steps + 1)]
     below = side == 'below'
     for s in range(steps):
         image, sparse = frames[s]
         p = 's%d/' % s
-        info, depth = eng.step(image, sparse, want_depth=True, next_frame=frames[s + 1] if path == 'pipelined' else None)
+        info, depth = eng.step(image, sparse, want_depth=True, next_frame=frames[s + 1] if 'pipelined' in path else None)
         torch.cuda.synchronize()
         li = info.cpu().numpy()
         assert (li[3] < 0.3) == below
@@ -144,13 +142,14 @@ def test_mixed_cosine_gate_on_the_reference_side(golden_dir, side, path):
         assert rel_mae(depth, g[p + 'depth_train']) < 1e-4                      # measured <= 4.5e-5
         gw = eng.debug_tensor('gW').view(32, 32, 3, 3)
         assert rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']) < 3.1e-2, (side, s, rel_mae(gw, g[p + 'grad/conv1_rgb_meta.weight']))     # measured 1.5e-2
-        d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
+        d_eval = eng.forward_eval_last() if 'pipelined' in path else eng.forward_eval(image, sparse)
         assert rel_mae(d_eval, g[p + 'depth_eval']) < 1.4e-4                    # measured 6.8e-5
     eng.close()
 
 
+@pytest.mark.parametrize('graph', [0, 1])
 @pytest.mark.parametrize('meta,size', [('1layer', (64, 128)), ('1layer', (352, 1216)), ('2layers', (352, 1216)), ('1layer', (36, 52))])
-def test_mixed_pipelined_equals_plain(meta, size):
+def test_mixed_pipelined_equals_plain(meta, size, graph):
     """Bitwise, six frames incl. an unannounced one, in the mixed mode (two launch chains per forward, narrow twins of the prefix's outputs in
     both buffer sets); 36x52: the dual-corner padded path (falls back to the plain call)."""
     n = 1
@@ -159,7 +158,7 @@ def test_mixed_pipelined_equals_plain(meta, size):
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(60 + i, h, w, n)] for i in range(7)]
     out = {}
     for mode in ('plain', 'pipelined'):
-        eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, meta=meta)
+        eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, meta=meta, options={'graph': graph})
         rec = []
         for i in range(6):
             nxt = frames[i + 1] if mode == 'pipelined' else None

@@ -16,7 +16,7 @@ HP = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_dept
           max_input_depth=80.0)
 
 # options whose other value must not change one bit of the step
-BITWISE = [{'stamps': 1}, {'thru': 0}, {'fuse_first': 0}, {'fuse_first': 2}, {'fuse_head_bwd': 0}, {'mask_bits': 0}, {'aux_stream': 0}, {'graph': 0},
+BITWISE = [{'stamps': 1}, {'thru': 0}, {'fuse_first': 0}, {'fuse_first': 2}, {'fuse_head_bwd': 0}, {'mask_bits': 0}, {'aux_stream': 0}, {'graph': 1},
            {'thru': 0, 'fuse_first': 0, 'fuse_head_bwd': 0, 'mask_bits': 0}]
 
 
@@ -77,7 +77,7 @@ def test_options_of_the_2layers_meta_block_are_bitwise():
     n, h, w = 1, 128, 256
     frames = _frames(n, h, w)
     base, pbase = _run(None, n, h, w, frames, False, meta='2layers')
-    for opts in ({'thru': 0}, {'mask_bits': 0, 'fuse_first': 0}, {'graph': 0, 'aux_stream': 0}):
+    for opts in ({'thru': 0}, {'mask_bits': 0, 'fuse_first': 0}, {'graph': 1, 'aux_stream': 0}):
         got, pgot = _run(opts, n, h, w, frames, False, meta='2layers')
         for (i0, d0, e0), (i1, d1, e1) in zip(base, got):
             assert torch.equal(i0, i1) and torch.equal(d0, d1) and torch.equal(e0, e1), opts
@@ -91,14 +91,14 @@ def test_option_errors_and_mixed_mode_keys():
         eng.set_option('no_such_switch', 1)
     with pytest.raises(RuntimeError, match='out of range'):
         eng.set_option('thru', 3)
-    assert eng.get_option('graph') == 1 and eng.get_option('fuse_first') == 1
+    assert eng.get_option('graph') == 0 and eng.get_option('fuse_first') == 1
     eng.close()
     # the mixed mode is defined on the default kernels: only the stream / graph switches move
     eng, sd, ad = make_engine(1, 64, 96, 'mixed', HP)
     for k in ('mask_bits', 'fuse_first', 'fuse_heads', 'heads_v2', 'cos_in_gemm', 'fuse_head_bwd'):
         with pytest.raises(RuntimeError, match='mixed mode'):
             eng.set_option(k, 0)
-    eng.set_option('thru', 0); eng.set_option('aux_stream', 0); eng.set_option('graph', 0); eng.set_option('stamps', 1)
+    eng.set_option('thru', 0); eng.set_option('aux_stream', 0); eng.set_option('graph', 1); eng.set_option('stamps', 1)
     im, sp = _frames(1, 64, 96, 1)[0]
     eng.step(im, sp)
     torch.cuda.synchronize()

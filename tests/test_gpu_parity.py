@@ -367,24 +367,19 @@ def test_eval_metrics_on_device():
 GATE_CASES = ['msgchn_1layer_64x96_gate_below', 'msgchn_1layer_64x96_gate_above']
 
 
-@pytest.mark.parametrize('path', ['graph', 'pipelined', 'eager'])
+@pytest.mark.parametrize('path', ['graph', 'pipelined', 'pipelined_graph', 'eager'])
 @pytest.mark.parametrize('impl', ['exact', None])
 @pytest.mark.parametrize('name', GATE_CASES)
 def test_fused_step_on_both_sides_of_the_cosine_gate(golden_dir, name, impl, path):
     """The `loss_cos < 0.3 => w_loss_cos = 0` gate (src/external_model_adapt.py:424-425) INSIDE the fused step -- loss_finalize_block
-    run by the two gradient kernels -- through graph replay (ptta_step), the frame-pipelined call (ptta_step_pipelined) and kernel by
-    kernel (PTTA_GRAPH=0), against whole steps of the REAL reference on either side of the gate (L_cos = 0.20: the branch trained heads
+    run by the two gradient kernels -- through ptta_step and the frame-pipelined call (ptta_step_pipelined), each with direct launches
+    (the default: 'eager', 'pipelined') and with hipGraph replay ('graph', 'pipelined_graph'), against whole steps of the REAL reference on either side of the gate (L_cos = 0.20: the branch trained heads
     take, the cosine term drops out of loss and gradients; L_cos = 0.37: it stays and, with w_cos = 300, is ~8 % of the adapted gradient,
     so a gate taken the wrong way fails every bound below)."""
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
-    if path == 'eager':
-        os.environ['PTTA_GRAPH'] = '0'
-    try:
-        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, impl, head_bias=float(g['head_bias']))
-    finally:
-        os.environ.pop('PTTA_GRAPH', None)
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, gain, impl, head_bias=float(g['head_bias']), options={'graph': 1 if 'graph' in path else 0})
     # bounds = 2x the worst figure measured on MI355X on these two fixtures (tools/gate_report.py, round 4): first-step gradients exact 9.1e-7 /
     # default 5.6e-3; later steps exact 2.0e-3 (one ReLU decision after Adam's sign-like first update, w_cos = 300) / default 1.2e-2;
     # post-step parameters exact 2.7e-5 / default 6.0e-4.  A gate taken the wrong way moves the first-step gradient by ~8e-2.
@@ -394,7 +389,7 @@ def test_fused_step_on_both_sides_of_the_cosine_gate(golden_dir, name, impl, pat
     for s in range(steps):
         image, sparse = frames[s]
         p = 's%d/' % s
-        info, depth = eng.step(image, sparse, want_depth=True, next_frame=frames[s + 1] if path == 'pipelined' else None)
+        info, depth = eng.step(image, sparse, want_depth=True, next_frame=frames[s + 1] if 'pipelined' in path else None)
         torch.cuda.synchronize()
         li = info.cpu().numpy()
         np.testing.assert_allclose(li, g[p + 'loss_info'], rtol=1e-4)
@@ -409,6 +404,6 @@ def test_fused_step_on_both_sides_of_the_cosine_gate(golden_dir, name, impl, pat
             assert rel_mae(prm, g[p + 'param/' + k]) < ptol, k
             assert rel_mae(m, g[p + 'exp_avg/' + k]) < gtol
             assert rel_mae(v, g[p + 'exp_avg_sq/' + k]) < 2 * gtol
-        d_eval = eng.forward_eval_last() if path == 'pipelined' else eng.forward_eval(image, sparse)
+        d_eval = eng.forward_eval_last() if 'pipelined' in path else eng.forward_eval(image, sparse)
         assert rel_mae(d_eval, g[p + 'depth_eval']) < 1e-4
     eng.close()

@@ -281,9 +281,10 @@ def test_staged_sequence_equals_resident_sequence():
             assert torch.equal(pa[k], pb[k]), (mode, k)
 
 
+@pytest.mark.parametrize('graph', [0, 1])
 @pytest.mark.parametrize('meta,n,size', [('1layer', 1, (64, 128)), ('2layers', 1, (64, 128)), ('1layer', 2, (64, 128)),
                                          ('1layer', 1, (352, 1216)), ('2layers', 1, (352, 1216))])
-def test_pipelined_steps_equal_plain_steps(meta, n, size):
+def test_pipelined_steps_equal_plain_steps(meta, n, size, graph):
     """ptta_step_pipelined: the parameter-independent prefix of frame k+1 (sparse-depth pooling, frozen RGB encoder, depth-only head of the
     stage-1 encoder) runs on its own stream beside the step of frame k.  Same parameters, losses and depths as ptta_step, call by call --
     also with an eval forward between two calls, an unannounced frame (prefix recomputed in line) and a plain step in the middle."""
@@ -294,7 +295,9 @@ def test_pipelined_steps_equal_plain_steps(meta, n, size):
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(20 + i, h, w, n)] for i in range(7)]
     out = {}
     for mode in ('plain', 'pipelined'):
-        eng, sd, adapted = make_engine(n, h, w, 'fp32', dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0), meta=meta)
+        # graph = 0 (default): both forms enqueue their kernels directly; 1: both replay captured hipGraphs
+        eng, sd, adapted = make_engine(n, h, w, 'fp32', dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0), meta=meta,
+                                       options={'graph': graph})
         rec = []
         for i in range(6):
             nxt = frames[i + 1] if mode == 'pipelined' else None
@@ -356,22 +359,17 @@ def test_refilled_buffer_gets_a_fresh_prefix():
     assert not torch.equal(out['plain'][1], out['stale_token'][1])
 
 
-@pytest.mark.parametrize('why', ['no_graph', 'profiling'])
+@pytest.mark.parametrize('why', ['naive', 'profiling'])
 def test_eval_last_after_a_step_that_fell_back_to_the_plain_path(why):
-    """ptta_step_pipelined runs as a plain ptta_step when graph replay is off (PTTA_GRAPH=0), under profiling, with SyncBatchNorm / gradient
-    exchange, padded sizes or bf16 storage; ptta_forward_eval_last must then still return the scored forward of the frame just adapted
+    """ptta_step_pipelined runs as a plain ptta_step with the validation kernels (PTTA_CONV_IMPL=naive), under profiling, with SyncBatchNorm / gradient
+    exchange or padded sizes; ptta_forward_eval_last must then still return the scored forward of the frame just adapted
     (round-3 advisor finding: it raised), and ExternalModel_Adapt.adapt(..., next_frame=...) must run."""
     import os
     from tests.util import make_engine
     n, h, w = 1, 64, 96
     hp = dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(60 + i, h, w, n)] for i in range(3)]
-    if why == 'no_graph':
-        os.environ['PTTA_GRAPH'] = '0'
-    try:
-        eng, sd, adapted = make_engine(n, h, w, 'fp32', hp)
-    finally:
-        os.environ.pop('PTTA_GRAPH', None)
+    eng, sd, adapted = make_engine(n, h, w, 'fp32', hp, impl='naive' if why == 'naive' else None)
     if why == 'profiling':
         eng.profile(True)
     for i in range(2):

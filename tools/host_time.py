@@ -9,7 +9,9 @@ import bench
 from proxytta import synth
 from proxytta.engine import ADAPTED, Engine
 H, W = bench.H, bench.W
-eng = Engine(1, H, W, **bench.HP)
+dtype = sys.argv[1] if len(sys.argv) > 1 and '=' not in sys.argv[1] else 'mixed'
+opts = {kv.split('=')[0]: int(kv.split('=')[1]) for kv in sys.argv[1:] if '=' in kv}
+eng = Engine(1, H, W, dtype=dtype, options=opts, **bench.HP)
 sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(bench.MODE).items()}
 eng.load_state_dict(sd)
 for name in ADAPTED:
@@ -27,5 +29,6 @@ for i in range(10, 50):
 t_host = (time.perf_counter() - t_all) * 1e6
 torch.cuda.synchronize()
 t_tot = (time.perf_counter() - t_all) * 1e6
+print(dtype, opts)
 print('host us per call:', ' '.join('%d' % t for t in ts))
 print('host loop %.0f us for 40 calls (%.0f per call); with final sync %.0f us (%.0f per step)' % (t_host, t_host / 40, t_tot, t_tot / 40))

@@ -125,6 +125,7 @@ struct ptta_ctx {
     int thru = 1; bool thru_active = false;
     hipEvent_t ev_dpart = nullptr;
     int fuse_first = 1, fuse_head_bwd = 1;
+    int bg_cap = 0; bool in_prefix = false;       // EXPERIMENT: grid cap of the background chains' persistent kernels
     int cos_grad_fused = 1;          // PTTA_COS_IN_GEMM=0: the fused step writes d loss / d ref as a tensor (loss.hip cos_grad_body) instead
     bool cos_in_gemm = false;        // (set around the fused step's backward only: ptta_backward with a caller's gradient keeps the tensor form)
     void* w0frag = nullptr; float *hm_part = nullptr, *headP = nullptr; double* head_k12 = nullptr;
@@ -138,7 +139,8 @@ struct ptta_ctx {
     ProfClass prof[NPROF];
     // hipGraph replay of the whole step (inputs are first copied to fixed staging buffers so that
     // the captured pointers never change); one graph per (validity given, separate loss image)
-    int use_graph = 1;
+    int use_graph = 0;           // option "graph": 1 = ptta_step / ptta_step_pipelined replay captured hipGraphs; 0 (default since round 5) = they enqueue
+                                 // their kernels directly on the caller's stream and the handle's own streams -- measured faster
     void* grad_comm = nullptr;       // RCCL communicator of the gradient all-reduce inside ptta_step (ptta_set_grad_sync_rccl)
     float* grad_arena = nullptr; long grad_arena_n = 0;
     int pre_sync_graph = -1, pre_sync_aux = -1;      // use_graph / use_aux as they were before ptta_set_stat_sync switched them off (-1: untouched)
@@ -598,6 +600,7 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     const bool nar = e.nar || (bwd && c->nar_bwd);
     const int es_l = nar ? 2 : c->es;
     a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = nar ? 1 : c->bf16; a.naive = c->naive; a.x3 = c->x3;
+    if (c->bg_cap > 0 && ((e.nar && !bwd) || c->in_prefix)) a.max_blocks = c->bg_cap;
     if (!c->mbits.empty()) {
         // sign-bit masks: the backward reads the bits of its mask; a forward launch that starts at frame 0 of a map the backward masks
         // with writes that map's bits for the real frames (launches over the proxy half start at an offset pointer: no entry, no bits)
@@ -640,6 +643,7 @@ int conv32_first(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvInArg
         a.in = nullptr; a.in_nb = B; a.w = &it->second.f; a.bias = it->second.bias;
         a.up = e.up; a.up_nb = e.up_nb; a.out_raw = e.raw;
         a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 1; a.bf16 = nar ? 1 : 0; a.naive = 0; a.x3 = 1;
+        if (c->bg_cap > 0 && (nar || c->in_prefix)) a.max_blocks = c->bg_cap;
         const double px = (double)B * H * W;
         // (both layers' algorithmic bytes and MACs: the launch executes both; the input planes are fp32, the 32-channel maps es_l wide)
         const int es_l = nar ? 2 : c->es;
@@ -1535,7 +1539,7 @@ int ptta_create(ptta_handle* out, int backbone_id, int meta_mode, int n, int hei
     c->nar_proxy = c->mixed && !(keep & 1); c->nar_bwd = c->mixed && !(keep & 2); c->nar_heads = c->mixed && !(keep & 4);
     const PttaCreateEnv env = ptta_create_env();         // (the three validation switches; everything else: ptta_set_option)
     c->naive = env.naive;
-    c->use_graph = env.graph == 0 ? 0 : 1;
+    c->use_graph = env.graph == 1 ? 1 : 0;
     c->x3 = env.exact ? 0 : 1;
     if (c->mixed) {
         // the mixed mode is defined on the matrix-core kernels with sign-bit masks; the validation arithmetic modes belong to PTTA_DTYPE_F32
@@ -1902,6 +1906,7 @@ static bool thru_ok(ptta_ctx* c, hipStream_t s) {
 }
 static int step_body(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
                      ptta_stream s_) {
+    RUN(ensure_fused_heads(c, (hipStream_t)s_));             // (before thru_ok: the direct-launch step would otherwise take the joined tail on its first call only)
     c->thru_active = thru_ok(c, (hipStream_t)s_);
     const int rc = ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_);
     if (rc) { c->thru_active = false; return rc; }
@@ -2081,6 +2086,8 @@ static int pipe_quiesce(ptta_ctx* c) {
 }
 static int prefix_body(ptta_ctx* c, const float* image, const float* sparse, hipStream_t s) {
     c->stamp(11, s);
+    c->in_prefix = true;
+    struct Leave { ptta_ctx* c; ~Leave() { c->in_prefix = false; } } leave_{c};
     RUN(ptta_launch_prep(sparse, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
     RUN(rgb_encoder(c, image, c->Nn, 0, c->Nn, s));
     c->stamp(12, s);
@@ -2127,7 +2134,7 @@ int ptta_pipeline_stream(ptta_handle c, ptta_stream* out) {
 int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity, uint64_t frame_token,
                         const float* next_image, const float* next_sparse, uint64_t next_token, float* depth_out, float* loss_info_out, ptta_stream s_) {
     if (!c || !image || !sparse) return -1;
-    if (c->nl || !c->use_graph || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16) {
+    if (c->nl || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16) {
         const int rc = ptta_step(c, image, loss_image, sparse, validity, depth_out, loss_info_out, s_);
         if (!c->nl) { c->fb_image = rc ? nullptr : image; c->fb_sparse = rc ? nullptr : sparse; }       // for ptta_forward_eval_last
         return rc;
@@ -2151,13 +2158,21 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         HIPCHK(hipStreamSynchronize(c->pre_stream));          // (a prefix of another frame may still be writing this set) -- the ONE host wait of this path
         HIPCHK(hipMemcpyAsync(c->in_image, image, ibytes, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(c->in_sparse, sparse, pbytes, hipMemcpyDeviceToDevice, s));
+        if (!c->use_graph) RUN(prefix_body(c, c->in_image, c->in_sparse, s));
+        else {
         if (!c->pexec[p]) RUN(pipe_capture(c, &c->pgraph[p], &c->pexec[p], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));
         HIPCHK(hipGraphLaunch(c->pexec[p], s));
+        }
     }
     P.prepared = false; P.prep_token = 0;
     if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
     if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
-    {
+    if (!c->use_graph) {
+        c->skip_prefix = true;
+        const int rc = step_body(c, c->in_image, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse, (key & 2) ? c->in_validity : nullptr, (ptta_stream)s);
+        c->skip_prefix = false;
+        if (rc) return rc;
+    } else {
     if (!c->rexec[key][p]) {
         c->skip_prefix = true;
         const int rc = pipe_capture(c, &c->rgraph[key][p], &c->rexec[key][p], [&](hipStream_t cs) {
@@ -2191,8 +2206,11 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         if (!c->proxy_rgb_valid) { HIPCHK(hipStreamSynchronize(ps)); RUN(ensure_proxy_rgb(c, c->in_image, s)); HIPCHK(hipStreamSynchronize(s)); }   // once per set
         HIPCHK(hipMemcpyAsync(c->in_image, next_image, ibytes, hipMemcpyDeviceToDevice, ps));
         HIPCHK(hipMemcpyAsync(c->in_sparse, next_sparse, pbytes, hipMemcpyDeviceToDevice, ps));
+        if (!c->use_graph) RUN(prefix_body(c, c->in_image, c->in_sparse, ps));
+        else {
         if (!c->pexec[q]) RUN(pipe_capture(c, &c->pgraph[q], &c->pexec[q], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));
         HIPCHK(hipGraphLaunch(c->pexec[q], ps));
+        }
         HIPCHK(hipEventRecord(c->ev_prefix[q], ps));
         Q.prepared = true; Q.prep_token = next_token; Q.last_token = 0;
         c->pipe_cur = q;
@@ -2494,9 +2512,10 @@ int ptta_set_option(ptta_handle c, const char* key, int value) {
     else if (k == "cos_in_gemm") f = &c->cos_grad_fused;
     else if (k == "mask_bits") f = &c->mask_bits_on;
     else if (k == "stamps") f = &c->stamps;
+    else if (k == "bg_cap") { f = &c->bg_cap; hi = 512; }
     else return c->fail("ptta_set_option: unknown key '" + k + "'", -22);
     if (value < lo || value > hi) return c->fail("ptta_set_option: value out of range for '" + k + "'", -22);
-    if (c->mixed && k != "aux_stream" && k != "thru" && k != "stamps" && value != 1)
+    if (c->mixed && k != "aux_stream" && k != "thru" && k != "stamps" && k != "bg_cap" && value != 1)
         return c->fail("ptta_set_option: the mixed mode is defined on the default kernels ('" + k + "' stays 1)", -38);
     if (k == "aux_stream" && c->pre_sync_graph >= 0) { c->pre_sync_aux = value; return 0; }      // statistics exchange active: takes effect when it ends
     if (*f == value) return 0;

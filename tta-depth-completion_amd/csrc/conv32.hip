@@ -1071,21 +1071,18 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
         p.wpack = a.w->mbf16; p.wpack2 = NAR ? nullptr : a.w->mlo;
         if (MODE == CONV_S1) {
             const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
-            const int cap1 = a.max_blocks > 0 && a.max_blocks < kS1Blocks ? a.max_blocks : kS1Blocks;
-            const int blocks = (int)(tiles > cap1 ? cap1 : tiles);     // 2 resident blocks per CU, persistent
+            const int blocks = (int)(tiles > kS1Blocks ? kS1Blocks : tiles);     // 2 resident blocks per CU, persistent
             if (a.relu_in) launch_x3<T, true>(p, flags, blocks, s); else launch_x3<T, false>(p, flags, blocks, s);
             PTTA_CHECK_LAUNCH();
             return 0;
         }
         const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
         const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
-        const int capd0 = NAR ? kNarrowBlocks : kFullChipBlocks;
-        const int capd = a.max_blocks > 0 && a.max_blocks < capd0 ? a.max_blocks : capd0;
+        const int capd = NAR ? kNarrowBlocks : kFullChipBlocks;
         long blocks = (items + 3) / 4; if (blocks > capd) blocks = capd;
         if (MODE == CONV_S2 && !(flags & 1)) {
             const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + S2_TH - 1) / S2_TH);
-            const int capt = a.max_blocks > 0 && a.max_blocks < kFullChipBlocks ? a.max_blocks : kFullChipBlocks;
-            const int tb = (int)(tiles < capt ? tiles : capt);
+            const int tb = (int)(tiles < kFullChipBlocks ? tiles : kFullChipBlocks);
 #define KS2_(R, M, A) hipLaunchKernelGGL((conv32_s2_lds_kernel<T, R, M, A>), dim3(tb), dim3(256), 0, s, p)
             const bool m_ = flags & 2, a_ = flags & 4;
             if (a.relu_in) { if (m_) { if (a_) KS2_(true, true, true); else KS2_(true, true, false); } else { if (a_) KS2_(true, false, true); else KS2_(true, false, false); } }
@@ -1134,8 +1131,7 @@ static int launch_first_t(const Conv32Args& a, const ConvInArgs& f, void* a_out,
     p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = nullptr;
     p.epi.mask_bits = a.mask_bits; p.epi.bits_out = a.bits_out; p.epi.bits_nb = a.bits_nb; p.epi.bits_sum = 0;
     p.B = a.B; p.Hin = p.Hout = a.Hin; p.Win = p.Wout = a.Win;
-    const int capf = a.max_blocks > 0 && a.max_blocks < kFullChipBlocks ? a.max_blocks : kFullChipBlocks;
-    const int blocks = (int)(tiles > capf ? capf : tiles);
+    const int blocks = (int)(tiles > kFullChipBlocks ? kFullChipBlocks : tiles);
     FirstP q;
     for (int c = 0; c < 3; ++c) { q.pl[c] = f.pl[c]; if (q.pl[c].nb < 1) q.pl[c].nb = 1; }
     q.zero_from_b = f.zero_from_b; q.w1 = f.wfrag; q.bias1 = f.bias; q.a_out = (float*)a_out; q.a_nb = a_nb;

@@ -125,7 +125,6 @@ struct ptta_ctx {
     int thru = 1; bool thru_active = false;
     hipEvent_t ev_dpart = nullptr;
     int fuse_first = 1, fuse_head_bwd = 1;
-    int bg_cap = 0; bool in_prefix = false;       // EXPERIMENT: grid cap of the background chains' persistent kernels
     int cos_grad_fused = 1;          // PTTA_COS_IN_GEMM=0: the fused step writes d loss / d ref as a tensor (loss.hip cos_grad_body) instead
     bool cos_in_gemm = false;        // (set around the fused step's backward only: ptta_backward with a caller's gradient keeps the tensor form)
     void* w0frag = nullptr; float *hm_part = nullptr, *headP = nullptr; double* head_k12 = nullptr;
@@ -600,7 +599,6 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     const bool nar = e.nar || (bwd && c->nar_bwd);
     const int es_l = nar ? 2 : c->es;
     a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = nar ? 1 : c->bf16; a.naive = c->naive; a.x3 = c->x3;
-    if (c->bg_cap > 0 && ((e.nar && !bwd) || c->in_prefix)) a.max_blocks = c->bg_cap;
     if (!c->mbits.empty()) {
         // sign-bit masks: the backward reads the bits of its mask; a forward launch that starts at frame 0 of a map the backward masks
         // with writes that map's bits for the real frames (launches over the proxy half start at an offset pointer: no entry, no bits)
@@ -643,7 +641,6 @@ int conv32_first(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvInArg
         a.in = nullptr; a.in_nb = B; a.w = &it->second.f; a.bias = it->second.bias;
         a.up = e.up; a.up_nb = e.up_nb; a.out_raw = e.raw;
         a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 1; a.bf16 = nar ? 1 : 0; a.naive = 0; a.x3 = 1;
-        if (c->bg_cap > 0 && (nar || c->in_prefix)) a.max_blocks = c->bg_cap;
         const double px = (double)B * H * W;
         // (both layers' algorithmic bytes and MACs: the launch executes both; the input planes are fp32, the 32-channel maps es_l wide)
         const int es_l = nar ? 2 : c->es;
@@ -2086,8 +2083,6 @@ static int pipe_quiesce(ptta_ctx* c) {
 }
 static int prefix_body(ptta_ctx* c, const float* image, const float* sparse, hipStream_t s) {
     c->stamp(11, s);
-    c->in_prefix = true;
-    struct Leave { ptta_ctx* c; ~Leave() { c->in_prefix = false; } } leave_{c};
     RUN(ptta_launch_prep(sparse, c->hp.max_input_depth, c->dclamp, c->d12, c->d14, c->Nn, c->Hp, c->Wp, s));
     RUN(rgb_encoder(c, image, c->Nn, 0, c->Nn, s));
     c->stamp(12, s);
@@ -2512,10 +2507,9 @@ int ptta_set_option(ptta_handle c, const char* key, int value) {
     else if (k == "cos_in_gemm") f = &c->cos_grad_fused;
     else if (k == "mask_bits") f = &c->mask_bits_on;
     else if (k == "stamps") f = &c->stamps;
-    else if (k == "bg_cap") { f = &c->bg_cap; hi = 512; }
     else return c->fail("ptta_set_option: unknown key '" + k + "'", -22);
     if (value < lo || value > hi) return c->fail("ptta_set_option: value out of range for '" + k + "'", -22);
-    if (c->mixed && k != "aux_stream" && k != "thru" && k != "stamps" && k != "bg_cap" && value != 1)
+    if (c->mixed && k != "aux_stream" && k != "thru" && k != "stamps" && value != 1)
         return c->fail("ptta_set_option: the mixed mode is defined on the default kernels ('" + k + "' stays 1)", -38);
     if (k == "aux_stream" && c->pre_sync_graph >= 0) { c->pre_sync_aux = value; return 0; }      // statistics exchange active: takes effect when it ends
     if (*f == value) return 0;

@@ -40,7 +40,6 @@ struct Conv32Args {
     int B = 1, Hin = 0, Win = 0;    // input spatial size; output size follows from mode
     int mode = CONV_S1; int relu_in = 0; int bf16 = 0; int naive = 0;
     int x3 = 0;          // fp32 storage: bf16x3 arithmetic on the bf16 matrix cores (stride-1 only)
-    int max_blocks = 0;  // > 0: cap of the persistent kernels' grid (a background chain leaves the rest of the chip to the critical one)
     // sign-bit masks (ptta_common.h Epi): fp32 storage, non-naive kernels only -- the caller passes them only in that mode
     const uint32_t* mask_bits = nullptr;       // backward: replaces the reads of `mask` (which stays set for the other modes)
     uint32_t* bits_out = nullptr; int bits_nb = 0; int bits_sum = 0;      // forward: bits of out_sum (bits_sum) or out_raw, frames b < bits_nb

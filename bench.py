@@ -33,7 +33,7 @@ for p in (ROOT, os.path.join(ROOT, 'tta-depth-completion_amd')):
         sys.path.insert(0, p)
 
 # Kernel arguments in device memory: the bench process asks for it BEFORE the HIP runtime exists (forced to 0 the replayed step is 7 % slower:
-# every launch of a replayed graph then fetches its arguments across the host link).  A user's own setting is kept; the JSON line reports
+# every launch then fetches its arguments across the host link).  A user's own setting is kept; the JSON line reports
 # what the run had (`config.hip_force_dev_kernarg`).  The library and its Python binding never touch the environment.
 KERNARG_PRESET = os.environ.get('HIP_FORCE_DEV_KERNARG')
 os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
@@ -843,10 +843,10 @@ def main():
             pb.append(1e3 * (time.perf_counter() - tp) / args.steps)
         plain_ms = float(np.median(pb))
     # the all-fp32 mode beside the headline (same protocol, fresh handle): what the mixed mode buys on this box in this run
-    other_dtype_ms = None
-    if world == 1 and not args.no_self_check:
-        od = 'fp32' if args.dtype == 'mixed' else 'mixed'
-        e2 = Engine(1, H, W, dtype=od, **HP)
+    other_dtype_ms, graph_ms = None, None
+
+    def side_run(dt, opts):
+        e2 = Engine(1, H, W, dtype=dt, options=opts, **HP)
         sd2 = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
         e2.load_state_dict(sd2)
         for name in ADAPTED:
@@ -861,8 +861,15 @@ def main():
                 e2.step(*frames[i % nframes], next_frame=nxt(i))
             torch.cuda.synchronize()
             ob.append(1e3 * (time.perf_counter() - tp) / args.steps)
-        other_dtype_ms = {'dtype': od, 'ms_per_step': float(np.median(ob)), 'blocks': len(ob)}
         e2.close()
+        return float(np.median(ob)), len(ob)
+    if world == 1 and not args.no_self_check:
+        od = 'fp32' if args.dtype == 'mixed' else 'mixed'
+        ms_, nb_ = side_run(od, options or None)
+        other_dtype_ms = {'dtype': od, 'ms_per_step': ms_, 'blocks': nb_}
+        ms_, nb_ = side_run(args.dtype, dict(options, graph=0 if options.get('graph') else 1))
+        graph_ms = {'graph': 0 if options.get('graph') else 1, 'ms_per_step': ms_, 'blocks': nb_,
+                    'note': 'the same stream of frames with the other launch form (graph = 1: every call replays captured hipGraphs; 0: direct launches)'}
     # Second figure: the same K steps with every frame starting in PAGEABLE HOST memory, as the reference's
     # dataloader hands it over (src/tta_main.py:519-523): pinned triple buffer + copy stream, frame k+1 travels while frame k
     # is adapted.  Never `value` (that one is HBM-resident by contract).
@@ -936,7 +943,7 @@ def main():
                                                        'latency-bound one-tile blocks) counted into the class',
                                                'launches': launches_b, 'avg_launch_us': 1e3 * ms_b / max(launches_b, 1),
                                                'frac': abytes_b / (ms_b * 1e-3) / HBM_PEAK},
-                     'measured': 'hipEvents around each launch, same K steps re-run without the graph (%.3f ms/step)' % instrumented_ms,
+                     'measured': 'hipEvents around each launch, same K steps re-run kernel by kernel on ONE stream (%.3f ms/step)' % instrumented_ms,
                      'launches': launches, 'avg_launch_us': 1e3 * ms / max(launches, 1),
                      'alg_bytes_per_launch': abytes / max(launches, 1), 'traffic': None})
         tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.dtype)
@@ -972,7 +979,9 @@ def main():
             'config': {'workload': 'MSG_CHN 1layer meta, 352x1216 KITTI-shaped synthetic, 1 TTA step/frame, batch 1 per GPU',
                        'parallelism': 'independent frame streams, dp%d, no collectives' % world, 'finite': finite,
                        'cpu_affinity': affinity, 'hip_force_dev_kernarg': kernarg,
-                       'other_dtype_same_run': other_dtype_ms, 'options': options or 'defaults',
+                       'other_dtype_same_run': other_dtype_ms, 'other_launch_form_same_run': graph_ms, 'options': options or 'defaults',
+                       'launch': ('hipGraph replay (option graph = 1)' if options.get('graph') else
+                                  'direct launches on the caller\'s stream + the handle\'s second and prefix streams (option graph = 0, the default)'),
                        'frame_pipelining': ('on: every call names the next frame of the stream; the part of its forward upstream of the adapted layer (frozen RGB '
                                             'encoder, sparse-depth pooling, stage-1/4 cascade down to decoder 1\'s last transposed conv) runs on a second stream '
                                             'beside the current step; K timed calls = K prefixes + K remainders; identical results' if pipe else 'off'),

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round-5 profile artifacts of the FINAL tree (run through gpurun; outputs under gpurun_out/r05/, copy into profiles/).  For each mode
 # (mixed = the headline / bench default, fp32):
-#   1. rocprofv3 --kernel-trace --stats of the bench command (graph replay, as the driver runs it) + the bench JSON of that run
-#   2. ONE replayed step as its ordered launch sequence (from the same trace) and the same command kernel by kernel (PTTA_GRAPH=0)
+#   1. rocprofv3 --kernel-trace --stats of the bench command (as the driver runs it: direct launches, three streams) + the bench JSON of that run
+#   2. ONE step of the timed region as its ordered launch sequence (from the same trace) and one step of the one-stream profiling leg, grouped by kernel
 #   3. separate --pmc passes: FETCH_SIZE, WRITE_SIZE (HBM traffic per launch of the dominant kernel class; the counters calibrated on the
 #      same kernels over a map of known size), SQ counters
 # then 4. what a small convolution launch costs inside a replayed graph; 5. NLSPN and CostDCNet: top kernels
@@ -32,17 +32,16 @@ print('\nroofline class (%s): %d launches, %.2f ms -> %.2f us per launch' % (sys
 PY
   # 2
   python3 tools/trace_sequence.py $O/trace_graph/x_kernel_trace.csv 40 > $O/${R}_${DT}_step_sequence_graph.txt
-  PTTA_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_step -o x -- python3 $BENCH --no-self-check > /dev/null 2> $O/trace_step_$DT.log
-  python3 tools/trace_step.py $O/trace_step/x_kernel_trace.csv 140 > $O/${R}_${DT}_step_trace_summary.txt
+  python3 tools/trace_step.py $O/trace_graph/x_kernel_trace.csv 140 > $O/${R}_${DT}_step_trace_summary.txt
   # 3
-  PTTA_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o x -- python3 bench.py --dtype $DT $SHORT > /dev/null 2> $O/pmc_fetch_$DT.log
-  PTTA_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o x -- python3 bench.py --dtype $DT $SHORT > /dev/null 2> $O/pmc_write_$DT.log
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o x -- python3 bench.py --dtype $DT $SHORT > /dev/null 2> $O/pmc_fetch_$DT.log
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o x -- python3 bench.py --dtype $DT $SHORT > /dev/null 2> $O/pmc_write_$DT.log
   python3 tools/traffic_from_pmc.py $O/pmc_fetch/x_counter_collection.csv $O/pmc_write/x_counter_collection.csv "$CLASS" $O/traffic_$DT.json $O/${R}_pmc_calibration.json > /dev/null
   python3 tools/pmc_summary.py "$O/pmc_fetch/x_counter_collection.csv" "$O/pmc_write/x_counter_collection.csv" > $O/${R}_${DT}_pmc_fetch_write_per_kernel.txt
-  PTTA_GRAPH=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
     --output-format csv -d $O/pmc_sq -o x -- python3 bench.py --dtype $DT $SHORT > /dev/null 2> $O/pmc_sq_$DT.log
   python3 tools/pmc_summary.py "$O/pmc_sq/x_counter_collection.csv" > $O/${R}_${DT}_pmc_sq.txt
-  rm -rf $O/trace_step $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/trace_graph
+  rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/trace_graph
 done
 # 4
 { echo "== one stride-1 32->32 convolution launch inside a replayed graph (tools/bench_chain.py)"; python3 tools/bench_chain.py 2>&1 | grep -v amdgpu; } > $O/${R}_small_conv_in_graph.txt 2>&1

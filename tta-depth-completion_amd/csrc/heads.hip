@@ -1105,41 +1105,6 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-// The running-statistics half of bn_finalize_kernel for TWO forward passes through one BatchNorm1d, applied in the given order (momentum
-// update with the first pass's batch statistics, then with the second's): used when the two passes' finalize launches run side by side on
-// two streams and therefore leave the running statistics alone (ptta_api.hip, the step as four graphs).
-__global__ __launch_bounds__(256) void bn_running2_kernel(const float* __restrict__ part_a, const float* __restrict__ part_b, int row_blocks, int R, int N,
-                                                          float momentum, float* running_mean, float* running_var, long long* nbt) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c == 0 && lane == 0 && nbt) *nbt += 2;
-    if (c >= N || !running_mean) return;
-    float rm = running_mean[c], rv = running_var[c];
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        const float* part = pass ? part_b : part_a;
-        double s1 = 0.0, s2 = 0.0;
-        for (int rb = lane; rb < row_blocks; rb += 64) {
-            s1 += (double)part[((long)rb * 2 + 0) * N + c];
-            s2 += (double)part[((long)rb * 2 + 1) * N + c];
-        }
-        s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-        const double mu = s1 / R;
-        double var = s2 / R - mu * mu;
-        if (var < 0.0) var = 0.0;
-        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-        rm = (1.f - momentum) * rm + momentum * (float)mu;
-        rv = (1.f - momentum) * rv + momentum * (float)unb;
-    }
-    if (lane == 0) { running_mean[c] = rm; running_var[c] = rv; }
-}
-int ptta_launch_bn_running2(const float* part_a, const float* part_b, int row_blocks, int R, int N, float momentum, float* running_mean,
-                            float* running_var, long long* nbt, hipStream_t s) {
-    hipLaunchKernelGGL(bn_running2_kernel, dim3((N + 3) / 4), dim3(256), 0, s, part_a, part_b, row_blocks, R, N, momentum, running_mean, running_var, nbt);
-    PTTA_CHECK_LAUNCH();
-    return 0;
-}
-
 int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* beta,
                             float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
                             float* mean, float* invstd, float* scale, float* shift, hipStream_t s) {

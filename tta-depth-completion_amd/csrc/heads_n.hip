@@ -487,16 +487,29 @@ int ptta_hn_moment_blocks(long R) { return (int)((R + HNM_ROWS - 1) / HNM_ROWS);
 // doubles of scratch per pass: the first stage's partial sets, then the reduced 32 x 33 moments
 long ptta_hn_moment_scratch(long R) { return (long)ptta_hn_moment_blocks(R) * 1056 + 1056; }
 // stage 1: second moments [32][33] (column 32: the sums) of 128 feature rows per block, fp32 products of one sub-tile summed into doubles
-__global__ __launch_bounds__(256) void hn_moments_kernel(const float* __restrict__ X, long R, double* __restrict__ Sp, long pass_stride) {
+template <typename TX>                                     // TX = float: fp32 feature rows; bf16_t: the proxy frames' narrow rows
+__global__ __launch_bounds__(256) void hn_moments_kernel(const TX* __restrict__ X, long R, double* __restrict__ Sp, long pass_stride) {
     __shared__ __attribute__((aligned(16))) float xs[128][36];
     const int t = threadIdx.x, a = t >> 3, b4 = (t & 7) * 4;
-    const float* Xp = X + (size_t)blockIdx.y * R * 32;
+    const TX* Xp = X + (size_t)blockIdx.y * R * 32;
     const long r0 = (long)blockIdx.x * HNM_ROWS;
+    if constexpr (sizeof(TX) == 4) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int idx = t + 256 * q;                       // float4 index: row = idx >> 3, channels 4 (idx & 7) ...
-        const long row = r0 + (idx >> 3);
-        *(float4*)&xs[idx >> 3][4 * (idx & 7)] = row < R ? *(const float4*)(Xp + row * 32 + 4 * (idx & 7)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 256 * q;                   // float4 index: row = idx >> 3, channels 4 (idx & 7) ...
+            const long row = r0 + (idx >> 3);
+            *(float4*)&xs[idx >> 3][4 * (idx & 7)] = row < R ? *(const float4*)(Xp + row * 32 + 4 * (idx & 7)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int idx = t + 256 * q;                   // 16-byte index: row = idx >> 2, channels 8 (idx & 3) ...
+            const long row = r0 + (idx >> 2);
+            const uint4 u = row < R ? *(const uint4*)(Xp + row * 32 + 8 * (idx & 3)) : make_uint4(0u, 0u, 0u, 0u);
+            float* d = &xs[idx >> 2][8 * (idx & 3)];
+            *(float4*)d = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+            *(float4*)(d + 4) = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+        }
     }
     __syncthreads();
     float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, fs = 0.f;
@@ -539,7 +552,7 @@ __global__ __launch_bounds__(1024) void hn_moment_reduce_kernel(double* __restri
 // stage 3, one block per pass: the complete moments -> BatchNorm1d statistics of Linear(32, 512): mean_j = w_j . m + b_j, var_j = w_j^T C w_j,
 // written as the two-"block" column partials bn_finalize expects.  Two threads per column (rows a < 16 / a >= 16 of C), four accumulators each.
 __global__ __launch_bounds__(1024) void hn_moment_stats_kernel(const double* __restrict__ Sp, int nblk, long pass_stride, long R, const float* __restrict__ W0,
-                                                               const float* __restrict__ b0, float* __restrict__ part) {
+                                                               const float* __restrict__ b0, float* __restrict__ part, HnBnOut bo) {
     __shared__ double S[32 * 33];
     __shared__ __attribute__((aligned(16))) float Cf[32][32];
     __shared__ float mf[32];
@@ -582,20 +595,38 @@ __global__ __launch_bounds__(1024) void hn_moment_stats_kernel(const double* __r
     if (t >= 512) return;
     var = vpart[0][t] + vpart[1][t]; wm = mpart[0][t] + mpart[1][t];
     const double mean = (double)wm + (double)bj, vr = var > 0.f ? (double)var : 0.0;
+    if (bo.mean) {
+        // no statistics exchange: mean and (biased) variance go straight into the BatchNorm's state -- bn_finalize_kernel's arithmetic
+        // without its detour through n * mean and n * E[h^2]
+        if (t == 0 && bo.nbt) *bo.nbt += 1;
+        const float iv = (float)(1.0 / sqrt(vr + (double)bo.eps));
+        bo.mean[t] = (float)mean; bo.inv[t] = iv;
+        const float sc = bo.gamma[t] * iv;
+        bo.scale[t] = sc; bo.shift[t] = bo.beta[t] - (float)mean * sc;
+        if (bo.rm) {
+            const double unb = R > 1 ? vr * n / (n - 1.0) : vr;
+            bo.rm[t] = (1.f - bo.momentum) * bo.rm[t] + bo.momentum * (float)mean;
+            bo.rv[t] = (1.f - bo.momentum) * bo.rv[t] + bo.momentum * (float)unb;
+        }
+        return;
+    }
     const double sh = n * mean, sh2 = n * (vr + mean * mean);
     float* o = part + (size_t)pass * 2 * 2 * 512;
     const float h0 = (float)sh, q0 = (float)sh2;
     o[t] = h0; o[512 + t] = q0;                                                    // "block" 0: the float values
     o[1024 + t] = (float)(sh - (double)h0); o[1536 + t] = (float)(sh2 - (double)q0);      // "block" 1: what the rounding lost
 }
-// X: `npass` consecutive groups of R rows x 32 fp32; scratch: npass * ptta_hn_moment_scratch(R) doubles; part: [npass][2][2][512] floats
-int ptta_launch_hn_moments(const float* X, long R, int npass, const float* W0, const float* b0, double* scratch, float* part, hipStream_t s) {
-    if (!X || !W0 || !b0 || !scratch || !part || R < 1 || npass < 1) return -22;
+// X: `npass` consecutive groups of R rows x 32 (fp32, or bf16 with x_bf16); scratch: npass * ptta_hn_moment_scratch(R) doubles; part: [npass][2][2][512]
+// floats (the column partials a statistics exchange + bn_finalize take), or, with `bn` (npass == 1), the BatchNorm's state directly
+int ptta_launch_hn_moments(const void* X, int x_bf16, long R, int npass, const float* W0, const float* b0, double* scratch, float* part, const HnBnOut* bn,
+                           hipStream_t s) {
+    if (!X || !W0 || !b0 || !scratch || (!part && !bn) || R < 1 || npass < 1 || (bn && npass != 1)) return -22;
     const int nb = ptta_hn_moment_blocks(R);
     const long ps = ptta_hn_moment_scratch(R);
-    hipLaunchKernelGGL(hn_moments_kernel, dim3(nb, npass), dim3(256), 0, s, X, R, scratch, ps);
+    if (x_bf16) hipLaunchKernelGGL((hn_moments_kernel<bf16_t>), dim3(nb, npass), dim3(256), 0, s, (const bf16_t*)X, R, scratch, ps);
+    else hipLaunchKernelGGL((hn_moments_kernel<float>), dim3(nb, npass), dim3(256), 0, s, (const float*)X, R, scratch, ps);
     hipLaunchKernelGGL(hn_moment_reduce_kernel, dim3(33, npass), dim3(1024), 0, s, scratch, nb, ps);
-    hipLaunchKernelGGL(hn_moment_stats_kernel, dim3(npass), dim3(1024), 0, s, scratch, nb, ps, R, W0, b0, part);
+    hipLaunchKernelGGL(hn_moment_stats_kernel, dim3(npass), dim3(1024), 0, s, scratch, nb, ps, R, W0, b0, part, bn ? *bn : HnBnOut());
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -409,10 +409,6 @@ void build_registry(ptta_ctx* c) {
         BNorm n; n.gamma = c->falloc(512); n.beta = c->falloc(512);
         n.mean = c->falloc(512); n.inv = c->falloc(512); n.scale = c->falloc(512); n.shift = c->falloc(512);
         c->bn[std::string(p) + ".1"] = n;
-        if (std::string(p) == "proj") {      // state of proj.1 for the proxy pass while the two passes run side by side (gamma / beta shared)
-            BNorm z = n; z.mean = c->falloc(512); z.inv = c->falloc(512); z.scale = c->falloc(512); z.shift = c->falloc(512);
-            c->bn["proj.1z"] = z;
-        }
     }
 }
 
@@ -1086,9 +1082,9 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         c->stamp(2, s);
         RUN(region(sp, Nn, Nn, true));
         c->stamp(4, sp);
-        // (round 5, step 1: the heads still take fp32 features -- the proxy features are widened into the proxy half of `feat`)
-        RUN(to_wide(c, c->tw(c->feat), (float*)c->feat + (size_t)c->Rg * 32, c->Rg * 32, sp));
         const bool hn = c->nar_heads && heads_v2_on(c);              // narrow heads: the proxy half needs nothing of the real chain
+        // (the fp32 heads -- PTTA_MIXED_KEEP_HEADS, or a configuration without heads v2 -- take fp32 features: the proxy rows are widened)
+        if (!hn) RUN(to_wide(c, c->tw(c->feat), (float*)c->feat + (size_t)c->Rg * 32, c->Rg * 32, sp));
         if (s2) {
             if (hn) RUN(heads_forward(c, s2, 1));
             c->stamp(5, s2);
@@ -1172,6 +1168,8 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
         const int nbh = 2, nb = ptta_hn_row_blocks(R);           // (the moments path hands the finalize two partial "blocks": value + rounding remainder)
         float* part_real = c->hm_part; float* part_zero = c->hm_part + (size_t)nbh * 2 * 512;
         double* msc_real = c->hn_msc; double* msc_zero = c->hn_msc + (size_t)ptta_hn_moment_scratch(R);
+        HnBnOut bo1; bo1.gamma = b1.gamma; bo1.beta = b1.beta; bo1.rm = b1.rm; bo1.rv = b1.rv; bo1.nbt = b1.nbt;
+        bo1.mean = b1.mean; bo1.inv = b1.inv; bo1.scale = b1.scale; bo1.shift = b1.shift;
         auto gemm_h = [&](const void* x, int x_bf16, const Lin& w, bf16_t* out, int epi) {
             HnGemmArgs g; g.pro = 3; g.epi = epi; g.X = x; g.x_bf16 = x_bf16; g.W0 = l0.Whi; g.b0 = l0.bias; g.pscale = b1.scale; g.pshift = b1.shift;
             g.W = w.Wsl; g.bias = w.bias; g.C = out; g.part = c->bn_part; g.R = R;
@@ -1179,9 +1177,13 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
         };
         if (part != 2) {
             // proxy pass first: the running statistics are updated in the reference's order (proj(feat_zero), then proj(feat), :551-554)
-            RUN(ptta_launch_hn_moments((const float*)c->feat + (size_t)R * 32, R, 1, l0.W, l0.bias, msc_zero, part_zero, s));
+            const void* xz = c->nar_proxy ? (const void*)c->tw(c->feat) : (const void*)((const float*)c->feat + (size_t)R * 32);
+            if (!c->stat_sync.on()) RUN(ptta_launch_hn_moments(xz, c->nar_proxy ? 1 : 0, R, 1, l0.W, l0.bias, msc_zero, nullptr, &bo1, s));
+            else {
+            RUN(ptta_launch_hn_moments(xz, c->nar_proxy ? 1 : 0, R, 1, l0.W, l0.bias, msc_zero, part_zero, nullptr, s));
             RUN(ptta_stat_sync(&c->stat_sync, part_zero, nbh, 512, 1, s));
             RUN(ptta_launch_bn_finalize(part_zero, nbh, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
+            }
             if (c->nar_proxy) RUN(ptta_launch_hn_gemm(gemm_h(c->tw(c->feat), 1, lf, c->h2_n, 1), s));
             else RUN(ptta_launch_hn_gemm(gemm_h((const float*)c->feat + (size_t)R * 32, 0, lf, c->h2_n, 1), s));
             RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, nb, 512, 1, s));
@@ -1192,9 +1194,12 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
         }
         if (part != 1) {
             // real pass last: its BatchNorm statistics are the ones the backward needs
-            RUN(ptta_launch_hn_moments((const float*)c->feat, R, 1, l0.W, l0.bias, msc_real, part_real, s));
+            if (!c->stat_sync.on()) RUN(ptta_launch_hn_moments(c->feat, 0, R, 1, l0.W, l0.bias, msc_real, nullptr, &bo1, s));
+            else {
+            RUN(ptta_launch_hn_moments(c->feat, 0, R, 1, l0.W, l0.bias, msc_real, part_real, nullptr, s));
             RUN(ptta_stat_sync(&c->stat_sync, part_real, nbh, 512, 1, s));
             RUN(ptta_launch_bn_finalize(part_real, nbh, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
+            }
             HnGemmArgs gr = gemm_h(c->feat, 0, l3, c->ref_n, 5);
             gr.E = c->emb_n; gr.rs = c->hn_rs; gr.rowstats_out = c->loss_ws + ptta_loss_ws_rows_off(c->N);
             gr.cpart = c->loss_ws + ptta_loss_ws_cos_off(c->N); gr.cpart_n = ptta_loss_cos_blocks();
@@ -1226,28 +1231,25 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
             // over rows [0, R) = real frames, [R, 2R) = proxy frames when the 128-row blocks do not straddle the two, else one per pass
             GemmArgs g; g.A = c->feat; g.W = l0.W; g.bias = l0.bias; g.R = 2 * R; g.K = 32; g.N = 512; g.epi = 4; g.part = c->hm_part;
             g.x3 = 1; g.Whi = l0.Whi; g.Wlo = l0.Wlo; g.Wil = l0.Wil;
-            if (part == 0 && R % 128 == 0) RUN(ptta_launch_gemm(g, s));
+            if (R % 128 == 0) RUN(ptta_launch_gemm(g, s));
             else {
                 g.R = R;
-                if (part != 1) RUN(ptta_launch_gemm(g, s));
+                RUN(ptta_launch_gemm(g, s));
                 g.A = feat_zero; g.part = part_zero;
-                if (part != 2) RUN(ptta_launch_gemm(g, s));
+                RUN(ptta_launch_gemm(g, s));
             }
         }
-        // part != 0: the two passes run side by side on two streams -> the proxy pass keeps its own BatchNorm state (proj.1z) and neither
-        // finalize touches the running statistics (ptta_launch_bn_running2 applies both updates in the reference's order afterwards)
-        BNorm& bz = part == 0 ? b1 : c->bn["proj.1z"];
+        BNorm& bz = b1;
         auto gemm_h = [&](const void* x, const BNorm& bn_, const Lin& w, float* out, int epi) {
             GemmArgs g; g.X = (const float*)x; g.W0frag = c->w0frag; g.b0 = l0.bias; g.pscale = bn_.scale; g.pshift = bn_.shift; g.pro = 3;
             g.W = w.W; g.bias = w.bias; g.C = out; g.R = R; g.K = 512; g.N = 512; g.epi = epi; g.part = c->bn_part;
             g.x3 = 1; g.Whi = w.Whi; g.Wlo = w.Wlo; g.Wil = w.Wil;
             return g;
         };
-        if (part != 2) {
+        {
             // proxy pass first: the running statistics are updated in the reference's order (proj(feat_zero), then proj(feat), :551-554)
             RUN(ptta_stat_sync(&c->stat_sync, part_zero, nbm, 512, 1, s));
-            RUN(ptta_launch_bn_finalize(part_zero, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, part ? nullptr : b1.rm, part ? nullptr : b1.rv, part ? nullptr : b1.nbt,
-                                        bz.mean, bz.inv, bz.scale, bz.shift, s));
+            RUN(ptta_launch_bn_finalize(part_zero, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, bz.mean, bz.inv, bz.scale, bz.shift, s));
             const GemmArgs gf = gemm_h(feat_zero, bz, lf, c->h2, 1);
             RUN(ptta_launch_gemm(gf, s));
             RUN(ptta_stat_sync(&c->stat_sync, c->bn_part, ptta_gemm_part_blocks(gf), 512, 1, s));
@@ -1256,16 +1258,15 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
             g3.pscale = b2.scale; g3.pshift = b2.shift; g3.x3 = 1; g3.Whi = lp3.Whi; g3.Wlo = lp3.Wlo; g3.Wil = lp3.Wil;
             RUN(ptta_launch_gemm(g3, s));
         }
-        if (part != 1) {
+        {
             // real pass last: its BatchNorm statistics are the ones the backward needs
             RUN(ptta_stat_sync(&c->stat_sync, part_real, nbm, 512, 1, s));
-            RUN(ptta_launch_bn_finalize(part_real, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, part ? nullptr : b1.rm, part ? nullptr : b1.rv, part ? nullptr : b1.nbt,
-                                        b1.mean, b1.inv, b1.scale, b1.shift, s));
+            RUN(ptta_launch_bn_finalize(part_real, nbm, Rw, 512, b1.gamma, b1.beta, 1e-5f, 0.1f, b1.rm, b1.rv, b1.nbt, b1.mean, b1.inv, b1.scale, b1.shift, s));
             RUN(ptta_launch_gemm(gemm_h(c->feat, b1, l3, c->ref, 0), s));
         }
         return 0;
     }
-    if (part != 0) return c->fail("heads_forward: split passes need heads v2", -22);
+    if (part != 0) return c->fail("heads_forward: split passes are the narrow heads' form", -22);
     if (c->fuse_heads && c->fused_pp_valid && c->x3 && !c->bf16 && !c->skip_dec3) {      // (the stage-2 head trainer needs proj's output itself)
         // emb = pred.3(relu(bn(pred.0(proj.3(relu(bn(proj.0 x))))))) with proj.3 / pred.0 merged into one GEMM (ptta_ctx::fused_pp)
         const Lin& l0 = c->fc["proj.0"]; const Lin& lf = c->fused_pp; const Lin& l3 = c->fc["pred.3"];

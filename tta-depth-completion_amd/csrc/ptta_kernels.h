@@ -163,8 +163,6 @@ int ptta_launch_gemm(const GemmArgs& a, hipStream_t s);
 int ptta_launch_bn_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* beta,
                             float eps, float momentum, float* running_mean, float* running_var, long long* nbt,
                             float* mean, float* invstd, float* scale, float* shift, hipStream_t s);
-int ptta_launch_bn_running2(const float* part_a, const float* part_b, int row_blocks, int R, int N, float momentum, float* running_mean,
-                            float* running_var, long long* nbt, hipStream_t s);
 int ptta_launch_bn_bwd_finalize(const float* part, int row_blocks, int R, int N, const float* gamma, const float* invstd,
                                 float* gscale, float* c1, float* c2, hipStream_t s, float* dgamma = nullptr, float* dbeta = nullptr,
                                 double* k12 = nullptr, const float* b0 = nullptr, const float* mean = nullptr);    // k12: [k1 512 | k2 512] for ptta_launch_head_bwd_finish
@@ -192,7 +190,13 @@ void ptta_hn_pack_w(const bf16_t* w_hi_rowmajor, bf16_t* w_slice_major, int K, h
 int ptta_launch_hn_untile(const void* src_tiled, float* dst, long R, hipStream_t s);
 int ptta_hn_moment_blocks(long R);
 long ptta_hn_moment_scratch(long R);       // doubles of scratch per pass
-int ptta_launch_hn_moments(const float* X, long R, int npass, const float* W0, const float* b0, double* scratch, float* part, hipStream_t s);
+struct HnBnOut {                 // what bn_finalize_kernel (heads.hip) writes: with `mean` set the stats kernel finalises the BatchNorm itself
+    const float *gamma = nullptr, *beta = nullptr; float eps = 1e-5f, momentum = 0.1f;
+    float *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
+    float *mean = nullptr, *inv = nullptr, *scale = nullptr, *shift = nullptr;
+};
+int ptta_launch_hn_moments(const void* X, int x_bf16, long R, int npass, const float* W0, const float* b0, double* scratch, float* part, const HnBnOut* bn,
+                           hipStream_t s);
 long ptta_loss_ws_cos_off(int N); int ptta_loss_cos_blocks();        // loss.hip: where the cosine term's block partials live in the workspace
 int ptta_launch_hn_gemm(const HnGemmArgs& a, hipStream_t s);
 

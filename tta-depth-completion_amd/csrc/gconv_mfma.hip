@@ -630,6 +630,7 @@ __device__ __forceinline__ void wsplit8(const float* v, uint4& hi, uint4& lo) {
     gsplit2(v[4], v[5], hi.z, lo.z); gsplit2(v[6], v[7], hi.w, lo.w);
 }
 // single = 1 (Ci, Co <= 32): one tile pair; the four waves take different items instead and write a partial each.
+template <bool GY16>          // GY16: gy.p points at bf16 values (the narrow gradient maps of the MSG_CHN mixed mode): widened on load, the same products
 __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int nitems_x, int single, int ncib, float* __restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, hg = lane >> 5;
@@ -639,6 +640,7 @@ __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int n
     const int co = cob * 32 + c, ci = cib * 32 + c;
     const bool cov = co < gy.C, civ = ci < x.C;
     const float* gyc = gy.p + (cov ? co : 0);
+    const bf16_t* gyc16 = (const bf16_t*)gy.p + (cov ? co : 0);
     const float* xc = x.p + (civ ? ci : 0);
     f32x16 acc[9];
 #pragma unroll
@@ -657,7 +659,8 @@ __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int n
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int px = p0 + j;
-            r.g[j] = gyc[(rowbase + min(px, W - 1)) * gy.ld];
+            if constexpr (GY16) r.g[j] = __uint_as_float((unsigned)gyc16[(rowbase + min(px, W - 1)) * gy.ld] << 16);
+            else r.g[j] = gyc[(rowbase + min(px, W - 1)) * gy.ld];
             r.gm |= (px < W && cov) ? (1u << j) : 0u;
         }
 #pragma unroll
@@ -835,7 +838,7 @@ long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co) {
     const long b = 256L * 4 * GWG_PART;                                  // gwgrad_x3_kernel: 256 blocks x 4 tile pairs
     return a > b ? a : b;
 }
-int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s) {
+int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s, int gy_bf16) {
     const bool sq = x.C <= 64 && gy.C <= 64, wide_out = x.C <= 32 && gy.C <= 128, wide_in = x.C <= 128 && gy.C <= 32;
     if ((sq || wide_out || wide_in) && x.C > 16) {
         // bf16x3 form: blocks of four waves = four 32x32 channel-tile pairs (2 x 2, or 1 x 4 / 4 x 1 for the 32 <-> 128 layers of the
@@ -847,13 +850,15 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
         const int kcib = sq ? 2 : (wide_out ? 1 : 4);
         const long cap = single ? 64 : 256;
         const int nblk = (int)(nitems < cap ? nitems : cap);
-        hipLaunchKernelGGL(gwgrad_x3_kernel, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
+        if (gy_bf16) hipLaunchKernelGGL(gwgrad_x3_kernel<true>, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
+        else hipLaunchKernelGGL(gwgrad_x3_kernel<false>, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
         const long n = 9L * x.C * gy.C + gy.C;
         if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb);
         else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nblk, 4, kcib, x.C, gy.C, gw, gb);
         PTTA_CHECK_LAUNCH();
         return 0;
     }
+    if (gy_bf16) return -22;          // (the fp32-MFMA form takes fp32 gradients)
     const int nchunks = ptta_gwgrad_mfma_chunks((long)x.B * x.H * x.W);
     const int ncib = (x.C + 31) / 32, ncob = (gy.C + 31) / 32, npairs = ncib * ncob;
     hipLaunchKernelGGL(gwgrad_mfma_kernel, dim3(nchunks, npairs), dim3(64), 0, s, x, gy, nchunks, ncib, part);

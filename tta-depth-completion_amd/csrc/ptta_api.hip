@@ -1421,14 +1421,15 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
       CV("depth_decoder1.prdct.1", true, CONV_S1, c->dv1, Nn, Nn, H4, W4, false, e); }
 #undef CV
     // ---- weight gradient of the meta layer: input = c2 of the real frames ----
-    // (mixed mode: the weight-gradient kernels take fp32 operands -- the 1/4-resolution gradient map is widened once, 3.4 MB)
-    if (c->nar_bwd) RUN(to_wide(c, c->dm_total, c->dm_f32, (long)Nn * H4 * W4 * 32, s));
+    // (mixed mode, 2layers meta block: its BatchNorm / weight-gradient kernels take fp32 operands -- the 1/4-resolution gradient map is widened
+    // once, 3.4 MB; the 1layer weight gradient reads the narrow map itself)
+    if (c->nar_bwd && c->meta_mode == PTTA_META_2LAYERS) RUN(to_wide(c, c->dm_total, c->dm_f32, (long)Nn * H4 * W4 * 32, s));
     if (c->meta_mode == PTTA_META_2LAYERS) return meta2_backward(c, s);
     if (!c->bf16 && c->x3 && !c->naive) {
         // default arithmetic: the bf16x3 reduction-GEMM form (gconv_mfma.hip gwgrad_x3_kernel, single-pair mode)
         GView xv; xv.p = (float*)c->c2; xv.B = Nn; xv.H = H4; xv.W = W4; xv.C = 32; xv.ld = 32;
-        GView gv; gv.p = c->nar_bwd ? c->dm_f32 : (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
-        REST_(s, ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s));
+        GView gv; gv.p = (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
+        REST_(s, ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s, c->nar_bwd ? 1 : 0));
         return 0;
     }
     REST_(s, ptta_launch_wgrad32(c->c2, c->dm_total, c->bf16, Nn, H4, W4, c->wgrad_part, c->gW, c->gB, s));

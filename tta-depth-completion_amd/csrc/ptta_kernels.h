@@ -347,4 +347,4 @@ long ptta_gfrag_elems(int KK, int C0, int C1, int Co);
 int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s);
 int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, int win, hipStream_t s);
 long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co);
-int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s);
+int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s, int gy_bf16 = 0);

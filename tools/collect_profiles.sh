@@ -19,7 +19,7 @@ cat $O/cal_f_fp32/x_counter_collection.csv > $O/cal_fetch.csv; tail -n +2 $O/cal
 cat $O/cal_w_fp32/x_counter_collection.csv > $O/cal_write.csv; tail -n +2 $O/cal_w_narrow/x_counter_collection.csv >> $O/cal_write.csv
 python3 tools/traffic_from_pmc.py --calibrate $O/cal_fetch.csv $O/cal_write.csv $((352*1216*32*4)) $O/${R}_pmc_calibration.json > /dev/null
 for DT in mixed fp32; do
-  BENCH="bench.py --dtype $DT --steps 20 --warmup 10 --no-nlspn --no-cpu-baseline"
+  BENCH="bench.py --dtype $DT --steps 20 --warmup 10 --no-nlspn --no-cpu-baseline --no-self-check"      # (no side runs of the other mode / launch form: the stats are this mode's launches only)
   # 1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_graph -o x -- python3 $BENCH > $O/${R}_${DT}_bench_under_rocprofv3_kernel_trace.json 2> $O/trace_graph_$DT.log
   python3 tools/prof_top.py $O/trace_graph 50 > $O/${R}_${DT}_kernel_stats_top.txt

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void conv32_mfma_kernel(Conv32P<T> p) {
     typedef typename Frag<T>::A AF;
     const int lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
+    const float biasv = epi_bias(p.epi, i);               // once per kernel: ptta_common.h epi_tile
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 
     // ---- wave-stationary weights -------------------------------------------------------------
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void conv32_mfma_kernel(Conv32P<T> p) {
         }
 
         // ---- epilogue: lane = channel (lane&31), registers = 16 pixels of the tile --------------
-        epi_tile<T, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx);
+        epi_tile<T, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx, nullptr, 0, 0, &biasv);
     }
 }
 
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
     unsigned char* const up_lds = wl_lds + WL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
+    const float biasv = epi_bias(p.epi, i);               // once per kernel: ptta_common.h epi_tile
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.Hout, W = p.Wout;
     const int ntx = (W + 31) >> 5, nty = (H + X3_TH - 1) / X3_TH;
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
                 if (kx == 2) __builtin_amdgcn_sched_barrier(0);      // bound the ds_read prefetch depth (VGPR pressure)
             }
             // (conv + bias) + bilinear, in the reference's order; the skip comes from the LDS window, added after the quad transpose
-            if (UP) epi_tile<T, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
-            else epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+            if (UP) epi_tile<T, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0, &biasv);
+            else epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv);
         }
         lds_barrier();          // LDS reuse only: do not wait for this tile's stores (nor the prefetch) to drain
     }
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
     float* const planes = (float*)up_lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
+    const float biasv = epi_bias(p.epi, i);               // once per kernel: ptta_common.h epi_tile
     // per-lane index arithmetic is recomputed in each phase from an opaque copy of the lane id: hoisted out of the persistent tile loop it
     // becomes dozens of long-lived registers (the UP variants spilled 5 - 34) and a scratch reload between two global loads serialises them
     auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
@@ -595,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
             }
             if (UP && rr == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); }      // every wave's pieces of the window have landed
             if (y < H) {
-                if (UP) epi_tile<T, false, EMASK, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
-                else epi_tile<T, false, EMASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+                if (UP) epi_tile<T, false, EMASK, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0, &biasv);
+                else epi_tile<T, false, EMASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv);
             }
         }
         lds_barrier();          // LDS reuse by the next tile (plane window over the bilinear window, halo)
@@ -621,6 +624,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
     unsigned char* const up_lds = lds + X3S_PH * X3_PW * STR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
+    const float biasv = epi_bias(p.epi, i);               // once per kernel: ptta_common.h epi_tile
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = p.Hout, W = p.Wout;
     const int ntx = (W + 31) >> 5, nty = (H + X3S_TH - 1) / X3S_TH;
@@ -701,8 +705,8 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
                 }
             }
-            if (UP) epi_tile<T, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0);
-            else epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx);
+            if (UP) epi_tile<T, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0, &biasv);
+            else epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv);
         }
         if (tile + (int)gridDim.x < ntiles) lds_barrier();   // LDS reuse by the next tile
     }
@@ -723,6 +727,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv32_direct_x3_
     __shared__ __attribute__((aligned(16))) unsigned char wl_lds[(F32 ? 2 : 1) * 18 * 64 * 16];     // [hi | lo][tap][k][lane] weight fragments
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
+    const float biasv = epi_bias(p.epi, i);               // once per kernel: ptta_common.h epi_tile
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
     const int nseg = (Wt + 31) >> 5;
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv32_direct_x3_
         fetch(6); fetch(7); fetch(8);
         compute(3); compute(4); compute(5);
         compute(6); compute(7); compute(8);
-        epi_tile<T, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx);
+        epi_tile<T, UP, MASK, ADD>(p.epi, b, y, p.Hout, p.Wout, i, acc, x0, h, Wt, MODE == CONV_T2 ? 2 : 1, xpar, sy, sx, nullptr, 0, 0, &biasv);
         item += (long)gridDim.x * 4;
         if (item < nitems) { decode(item); fetch(0); fetch(1); fetch(2); fetch(3); fetch(4); fetch(5); }
     }
@@ -842,6 +847,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
     unsigned char* const wl_lds = lds + NPIX * STR;
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
+    const float biasv = epi_bias(p.epi, i);               // once per kernel: ptta_common.h epi_tile
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Hin = p.Hin, Win = p.Win, Ho = p.Hout, Wo = p.Wout;
     const int ntx = (Wo + 31) >> 5, nty = (Ho + S2_TH - 1) / S2_TH;
@@ -910,7 +916,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
                     }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
                 }
-                if (q == 1) epi_tile<T, false, MASK, ADD>(p.epi, b, oy0 + wave, Ho, Wo, i, acc, ox0, h, Wo, 1, 0, 0.f, 0.f);
+                if (q == 1) epi_tile<T, false, MASK, ADD>(p.epi, b, oy0 + wave, Ho, Wo, i, acc, ox0, h, Wo, 1, 0, 0.f, 0.f, nullptr, 0, 0, &biasv);
             }
         }
     }

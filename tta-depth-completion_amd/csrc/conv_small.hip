@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void conv_in_lds_kernel(ConvInP<T> p) {
     __shared__ float tile[CIN * PLANE + 4];                      // + a zero word for the padded k
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
+    const float biasv = epi_bias(p.epi, i);               // once per kernel: ptta_common.h epi_tile
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float w[NS];
 #pragma unroll
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_in_lds_kernel(ConvInP<T> p) {
                 const float a = h ? (o1 >= 0 ? base[o1] : tile[CIN * PLANE]) : base[o0];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[s], acc, 0, 0, 0);
             }
-            epi_tile<T, false, MASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, 0.f, 0.f);
+            epi_tile<T, false, MASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, 0.f, 0.f, nullptr, 0, 0, &biasv);
         }
         __syncthreads();
     }

@@ -157,13 +157,18 @@ __device__ __forceinline__ void quad_transpose(f32x16& t, int lane) {
 // source whose origin is (uy0, ux0), and is added AFTER the quad transpose: a lane then holds four consecutive channels of one pixel,
 // so one row costs it 4 coefficient pairs and 16 ds_read_b128 instead of 16 pairs and 64 ds_read_b32 -- the same expression per
 // element as the accumulator-layout form, (conv + bias) + (ly.l0 (lx.l0 v00 + lx.l1 v01) + ly.l1 (lx.l0 v10 + lx.l1 v11)).
+template <typename T>
+__device__ __forceinline__ float epi_bias(const Epi<T>& e, int ch) { return (e.bias ? e.bias : kZeroBias)[ch]; }
 template <typename T, bool UP, bool MASK, bool ADD, bool UPL = false, int UPLW = 18>
 __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, int W, int ch, const f32x16& acc,
                                          int x0, int h, int Wt, int xstep, int xoff, float sy, float sx,
-                                         const void* upw_ = nullptr, int uy0 = 0, int ux0 = 0) {
+                                         const void* upw_ = nullptr, int uy0 = 0, int ux0 = 0, const float* bias_lane = nullptr) {
     const float* upw = (const float*)upw_;                // fp32 storage: the bilinear window holds floats; narrow storage casts upw_ to bf16 below
     const float* bp = e.bias ? e.bias : kZeroBias;       // pointer select, not a branch around the load
-    const float bias = bp[ch];
+    // bias_lane: the lane's bias, loaded ONCE by the kernel (epi_bias).  Loaded here -- once per output row -- it cannot be hoisted by hipcc
+    // (the epilogue's stores may alias it), and the wait for this youngest load is s_waitcnt vmcnt(0): every row then drained the next
+    // tile's halo prefetch and the previous row's stores before its own epilogue began (round 5, .s of the stride-1 kernel)
+    const float bias = bias_lane ? *bias_lane : bp[ch];
     float v[16];
     int xo[16];
     bool ok[16];

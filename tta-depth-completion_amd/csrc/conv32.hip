@@ -386,7 +386,9 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
     constexpr int K1 = 9 * CIN, NS = (K1 + 1) / 2;
     constexpr int PL_W = 36, PL_H = 12, PLANE = PL_H * PL_W;
     constexpr int PLSZ = (CIN * PLANE + 4) * 4, USZ = UP ? UPH * UPW * Geo<T>::UPPX : 0, AUX = USZ > PLSZ ? USZ : PLSZ;
-    constexpr int NPL = (CIN * PLANE + 255) / 256;
+    constexpr int NPJ = (PLANE + 255) / 256, NPL = CIN * NPJ;       // items per thread: NPJ of each plane (the plane index is a compile-time constant
+                                                                    // of every item: f.pl[ci] stays in scalar registers -- indexed by a lane-varying
+                                                                    // ci it was fetched from memory, a dependent load in front of every data load)
     __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * STR + WL + AUX];
     unsigned char* const wl_lds = lds + X3_PH * X3_PW * STR;
     unsigned char* const up_lds = wl_lds + WL;
@@ -408,25 +410,45 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
         const int tx = (int)(t_ % ntx);
         b = (int)(t_ / ntx); y0 = ty * X3_TH; x0 = tx << 5;
     };
+    // the window's loads are UNCONDITIONAL (clamped address) and RAW: zero padding and the optional photometric normalisation are applied when
+    // the values go to LDS one tile later.  With `if (inside) { v = load; if (norm) v = ... }` every load was followed by its own
+    // s_waitcnt (the normalisation consumes the value inside the branch): four memory round trips in a row in front of every tile's second
+    // convolution (round 5, .s)
     float pv[NPL];
+    unsigned pvok = 0;
     auto load_planes = [&](long tile) {
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
         const bool live = b < f.zero_from_b;
         const int tid_ = opaque(tid);
+        pvok = 0;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            const int idx = tid_ + 256 * k;
-            const int ci = idx / PLANE, r = idx - ci * PLANE;
-            const int py = r / PL_W, px = r - py * PL_W;
-            const int gy = y0 - 2 + py, gx = x0 - 2 + px;
-            float v = 0.f;
-            if (idx < CIN * PLANE && live && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const Plane& pl = f.pl[ci];
-                v = pl.p[(size_t)(b % pl.nb) * pl.bstride + (size_t)gy * W + gx];
-                if (pl.norm) v = (v / pl.div - pl.mean) / pl.stdv;
+        for (int ci = 0; ci < CIN; ++ci) {
+            const Plane& pl = f.pl[ci];
+            const float* pb = pl.p + (size_t)(b % pl.nb) * pl.bstride;
+#pragma unroll
+            for (int j = 0; j < NPJ; ++j) {
+                const int r = tid_ + 256 * j;
+                const int py = r / PL_W, px = r - py * PL_W;
+                const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+                const bool ok = r < PLANE && live && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                pv[ci * NPJ + j] = pb[(size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
+                pvok |= ok ? (1u << (ci * NPJ + j)) : 0u;
             }
-            pv[k] = v;
+        }
+    };
+    auto stage_planes = [&]() {                           // the prefetched window -> LDS: 0 outside the image / for the proxy frames, normalised inside
+        const int tid_ = opaque(tid);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            const Plane& pl = f.pl[ci];
+#pragma unroll
+            for (int j = 0; j < NPJ; ++j) {
+                const int r = tid_ + 256 * j, k = ci * NPJ + j;
+                float v = pv[k];
+                if (pl.norm) v = (v / pl.div - pl.mean) / pl.stdv;
+                if (r < PLANE) planes[ci * PLANE + r] = ((pvok >> k) & 1u) ? v : 0.f;
+            }
         }
     };
     // FMASK: the first convolution's ReLU mask comes in its sign-bit form only (fmask_bits, one word per pixel): the 12 words of this wave's
@@ -478,9 +500,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
         // ---- the input-plane window (prefetched) -> LDS ----
-        { const int tid_ = opaque(tid);
-#pragma unroll
-        for (int k = 0; k < NPL; ++k) { const int idx = tid_ + 256 * k; if (idx < CIN * PLANE) planes[idx] = pv[k]; } }
+        stage_planes();
         if (tid == 0) planes[CIN * PLANE] = 0.f;                       // the padded k of an odd 9 cin reads this word
         lds_barrier();
         // ---- first convolution on the halo: pixel p = 34 py + px of the (8 + 2) x (32 + 2) halo, 32 pixels per MFMA group ----
@@ -638,15 +658,19 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
         const int ty = tile % nty, tx = (tile / nty) % ntx, b = tile / (nty * ntx);
         const int y0 = ty * X3S_TH, x0 = tx << 5;
         const T* inb = p.in + (size_t)(b % p.in_nb) * H * W * 32;
+        // UNCONDITIONAL loads from clamped addresses, zero-filled at staging time: behind `if (inside) v = load` hipcc waited vmcnt(0) at the
+        // join of every one of the four branches (the select with the zero needs the value) -- four L2 round trips in a row in a kernel whose
+        // whole duration is a latency chain (round 5, .s)
         Px<T> v[NIT];
+        bool vok[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
             const int g = idx & 3, pix = x3_stage_pix(idx);
             const int py = pix / X3_PW, px = pix - py * X3_PW;
             const int gy = y0 - 1 + py, gx = x0 - 1 + px;
-            v[it] = px_zero<T>();
-            if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) v[it] = px_load(inb + ((size_t)gy * W + gx) * 32 + 8 * g);
+            vok[it] = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            v[it] = px_load(inb + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 32 + 8 * g);
         }
         if (!wloaded) {                                   // block-uniform; in flight together with the halo
             const uint4* ph = (const uint4*)p.wpack;
@@ -680,6 +704,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
             const int pix = x3_stage_pix(idx);
+            if (!vok[it]) v[it] = px_zero<T>();
             if (pix < NPIX) px_stage<RELU>(v[it], lds + pix * STR + 16 * (idx & 3), Geo<T>::LO);
         }
         lds_barrier();

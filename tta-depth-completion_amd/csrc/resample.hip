@@ -98,6 +98,30 @@ __device__ __forceinline__ void up2T_weights(int i, int in_size, float scale, in
     }
 }
 
+// The destinations whose taps touch source index i lie in the open interval ((i - 1) / s, (i + 1) / s), s = (in - 1) / (2 in - 1): at most
+// FIVE consecutive integers.  up2T_window returns the first of them (clamped so that d0 .. d0 + 4 stays inside [0, 2 in)) and their five
+// weights -- the same values up2T_weights computes, zero where a candidate does not touch i.  With a fixed 5 x 5 window every load of the
+// gather is UNCONDITIONAL: behind `if (w != 0) acc += w * g[...]` hipcc issued each of the ~14 touching taps as its own load + s_waitcnt
+// vmcnt(0) (round 5, .s of both kernels: up to 49 dependent round trips per thread).
+__device__ __forceinline__ void up2T_window(int i, int in_size, float scale, int& d0, float w[5]) {
+    int c0; float w7[7];
+    up2T_weights(i, in_size, scale, c0, w7);
+    int k0 = 0;
+    if (w7[0] == 0.f) { k0 = 1; if (w7[1] == 0.f) k0 = 2; }            // first touching candidate (the touching ones are consecutive)
+    const int out_size = 2 * in_size;
+    int first = c0 + k0;
+    first = max(min(first, out_size - 5), 0);                          // (maps narrower than five: the loads clamp their offsets)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = first + k - c0;                                   // index into the seven candidates
+        float ww = 0.f;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) ww = (q == c) ? w7[q] : ww;
+        w[k] = ww;
+    }
+    d0 = first;
+}
+
 __global__ void up2T_1ch_kernel(const float* __restrict__ gout, float* __restrict__ gin, int B, int Hin, int Win) {
     const int Wo = 2 * Win, Ho = 2 * Hin;
     const float sy = up_scale(Hin, Ho), sx = up_scale(Win, Wo);
@@ -107,18 +131,21 @@ __global__ void up2T_1ch_kernel(const float* __restrict__ gout, float* __restric
         long t_ = idx / Win;
         const int y = (int)(t_ % Hin);
         const int b = (int)(t_ / Hin);
-        int dy0, dx0; float wy[7], wx[7];
-        up2T_weights(y, Hin, sy, dy0, wy);
-        up2T_weights(x, Win, sx, dx0, wx);
-        const float* g = gout + (size_t)b * Ho * Wo;
+        int dy0, dx0; float wy[5], wx[5];
+        up2T_window(y, Hin, sy, dy0, wy);
+        up2T_window(x, Win, sx, dx0, wx);
+        const float* g = gout + (size_t)b * Ho * Wo + (size_t)dy0 * Wo + dx0;
+        float v[5][5];
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) v[ky][kx] = g[(size_t)min(ky, Ho - 1 - dy0) * Wo + min(kx, Wo - 1 - dx0)];
         float acc = 0.f;
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            if (wy[ky] == 0.f) continue;
+        for (int ky = 0; ky < 5; ++ky) {
             float row = 0.f;
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx)
-                if (wx[kx] != 0.f) row += wx[kx] * g[(size_t)(dy0 + ky) * Wo + dx0 + kx];
+            for (int kx = 0; kx < 5; ++kx) row += wx[kx] * v[ky][kx];
             acc += wy[ky] * row;
         }
         gin[idx] = acc;
@@ -146,26 +173,25 @@ __global__ void up2T_32_kernel(const T* __restrict__ gout, const T* __restrict__
         const int x = (int)(t_ % Win); t_ /= Win;
         const int y = (int)(t_ % Hin);
         const int b = (int)(t_ / Hin);
-        int dy0, dx0; float wy[7], wx[7];
-        up2T_weights(y, Hin, sy, dy0, wy);
-        up2T_weights(x, Win, sx, dx0, wx);
-        const T* g = gout + (size_t)b * Ho * Wo * 32 + 4 * cq;
+        int dy0, dx0; float wy[5], wx[5];
+        up2T_window(y, Hin, sy, dy0, wy);
+        up2T_window(x, Win, sx, dx0, wx);
+        const T* g = gout + ((size_t)b * Ho * Wo + (size_t)dy0 * Wo + dx0) * 32 + 4 * cq;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        // row by row: the five taps of a row are in flight together (one 16-B / 8-B load per tap: the channel quad is aligned)
 #pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-            if (wy[ky] == 0.f) continue;
+        for (int ky = 0; ky < 5; ++ky) {
+            float4 v[5];
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) {
-                if (wx[kx] == 0.f) continue;
+            for (int kx = 0; kx < 5; ++kx) {
+                const T* q = g + ((size_t)min(ky, Ho - 1 - dy0) * Wo + min(kx, Wo - 1 - dx0)) * 32;
+                if constexpr (sizeof(T) == 4) v[kx] = *(const float4*)q;
+                else v[kx] = bf4_to_f4(*(const uint2*)q);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
                 const float wgt = wy[ky] * wx[kx];
-                const T* q = g + ((size_t)(dy0 + ky) * Wo + dx0 + kx) * 32;
-                if constexpr (sizeof(T) == 4) {             // one 16-B load per tap (the channel quad is 16-B aligned)
-                    const float4 v = *(const float4*)q;
-                    acc[0] += wgt * v.x; acc[1] += wgt * v.y; acc[2] += wgt * v.z; acc[3] += wgt * v.w;
-                } else {                                    // narrow maps: one 8-B load per tap
-                    const float4 v = bf4_to_f4(*(const uint2*)q);
-                    acc[0] += wgt * v.x; acc[1] += wgt * v.y; acc[2] += wgt * v.z; acc[3] += wgt * v.w;
-                }
+                acc[0] += wgt * v[kx].x; acc[1] += wgt * v[kx].y; acc[2] += wgt * v[kx].z; acc[3] += wgt * v[kx].w;
             }
         }
         const size_t o = (((size_t)b * Hin + y) * Win + x) * 32 + 4 * cq;

@@ -119,24 +119,28 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
     const bool x1 = b >= p.x1_from_B;                    // block-uniform: images of the single-MFMA class (mixed mode: proxy frames, data gradients)
 
     float4 v0[NIT], v1[NIT];
+    unsigned vok = 0;                                    // bit `it`: item it of the sub-chunk in flight is inside the image and the channel range
     uint4 wr[NW];
     auto issue_loads = [&](int q) __attribute__((always_inline)) {
         const int c = q >> 1, kk = q & 1;
         const bool s1 = c >= nch0;
         const float* src = s1 ? p.x1 : p.x0;
         const int ld = s1 ? p.ld1 : p.ld0, Cs = s1 ? p.C1 : p.C0, cb = ((s1 ? c - nch0 : c) << 5) + 16 * kk;
-        const float* inb = src + (size_t)b * H * W * ld + cb;
+        const float* inb = src + (size_t)b * H * W * ld;
+        // UNCONDITIONAL loads from clamped addresses; zero padding is applied when the values are split into LDS (vok).  Behind
+        // `if (inside) { v0 = load; v1 = load; }` hipcc waited vmcnt(0) between the items of one sub-chunk (round 5, .s): the wave
+        // that issues the prefetch stalled for a memory round trip per item instead of going on to its matrix instructions.
+        vok = 0;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + 256 * it;
             const int g = idx & 1, pix = idx >> 1;
             const int py = pix / PW, px = pix - py * PW;
             const int gy = y0 - PAD + py, gx = x0 - PADX + px;
-            v0[it] = make_float4(0.f, 0.f, 0.f, 0.f); v1[it] = v0[it];
-            if (pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && cb + 8 * g < Cs) {
-                const float* s_ = inb + ((size_t)gy * W + gx) * ld + 8 * g;
-                v0[it] = *(const float4*)s_; v1[it] = *(const float4*)(s_ + 4);
-            }
+            const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W && cb + 8 * g < Cs;
+            const float* s_ = inb + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * ld + min(cb + 8 * g, Cs - 8);
+            v0[it] = *(const float4*)s_; v1[it] = *(const float4*)(s_ + 4);
+            vok |= ok ? (1u << it) : 0u;
         }
         const size_t wbase = ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + kk * 64;
 #pragma unroll
@@ -169,7 +173,9 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
             const int idx = tid + 256 * it;
             const int pix = idx >> 1;
             if (pix < NPIX) {
-                const float4 a0 = v0[it], a1 = v1[it];
+                const bool ok = (vok >> it) & 1u;
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 a0 = ok ? v0[it] : z4, a1 = ok ? v1[it] : z4;
                 uint4 hi, lo;
                 unsigned char* dst = lds + pix * STR + 16 * (idx & 1);
                 if constexpr (SIX) {
@@ -289,6 +295,17 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
         const int c4 = (lane & 7) * 4, pl = lane >> 3;
         const int cbase = nf * 32 - p.nf0 * 32 + c4;
         if (cbase < p.Cy) {
+            // an accumulating launch reads the eight old values FIRST, unconditionally (clamped pixel): one load + s_waitcnt + store per
+            // pixel group was eight memory round trips in a row per wave
+            float4 old[8];
+            if (p.accumulate) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int rr = k >> 2, px = (k & 3) * 8 + pl;
+                    const int y = min(y0 + 2 * wave + rr, H - 1), x = min(x0 + px, W - 1);
+                    old[k] = *(const float4*)(p.y + (((size_t)b * H + y) * W + x) * p.ldy + cbase);
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int rr = k >> 2, px = (k & 3) * 8 + pl;
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
                 float4 v = *(const float4*)(tw + (rr * 32 + px) * 32 + c4);
                 float* dst = p.y + (((size_t)b * H + y) * W + x) * p.ldy + cbase;
                 if (p.accumulate) {
-                    const float4 o = *(const float4*)dst;
+                    const float4 o = old[k];
                     v.x = activate_cheap(v.x + o.x); v.y = activate_cheap(v.y + o.y); v.z = activate_cheap(v.z + o.z); v.w = activate_cheap(v.w + o.w);
                 }
                 *(float4*)dst = v;

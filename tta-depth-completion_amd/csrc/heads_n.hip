@@ -494,18 +494,25 @@ __global__ __launch_bounds__(256) void hn_moments_kernel(const TX* __restrict__ 
     const TX* Xp = X + (size_t)blockIdx.y * R * 32;
     const long r0 = (long)blockIdx.x * HNM_ROWS;
     if constexpr (sizeof(TX) == 4) {
+        float4 pre[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int idx = t + 256 * q;                   // float4 index: row = idx >> 3, channels 4 (idx & 7) ...
             const long row = r0 + (idx >> 3);
-            *(float4*)&xs[idx >> 3][4 * (idx & 7)] = row < R ? *(const float4*)(Xp + row * 32 + 4 * (idx & 7)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre[q] = *(const float4*)(Xp + (row < R ? row : R - 1) * 32 + 4 * (idx & 7));      // unconditional: the four loads fly together
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = t + 256 * q;
+            *(float4*)&xs[idx >> 3][4 * (idx & 7)] = r0 + (idx >> 3) < R ? pre[q] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int idx = t + 256 * q;                   // 16-byte index: row = idx >> 2, channels 8 (idx & 3) ...
             const long row = r0 + (idx >> 2);
-            const uint4 u = row < R ? *(const uint4*)(Xp + row * 32 + 8 * (idx & 3)) : make_uint4(0u, 0u, 0u, 0u);
+            uint4 u = *(const uint4*)(Xp + (row < R ? row : R - 1) * 32 + 8 * (idx & 3));
+            if (row >= R) u = make_uint4(0u, 0u, 0u, 0u);
             float* d = &xs[idx >> 2][8 * (idx & 3)];
             *(float4*)d = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
             *(float4*)(d + 4) = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));

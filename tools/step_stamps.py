@@ -28,13 +28,17 @@ khz = 100000.0      # wall_clock64: 100 MHz constant clock on MI300-class parts
 names = ['graph start', 'real chain start', 'real chain end', 'proxy branch start', 'proxy chain end', 'heads part 1 end', 'heads part 2 end',
          'decoder 3 end', 'heads backward end', 'before Adam', 'after Adam', "next frame's prefix start", 'its RGB encoder end', 'its end']
 acc = []
-for i in range(40):
-    eng.step(*frames[i % 4], next_frame=frames[(i + 1) % 4])
-    if i >= 20:
-        torch.cuda.synchronize()
+k = 0
+for rep in range(24):
+    # steady state: the host runs ahead of the GPU (no wait between steps) and the stamps read are those of the LAST step of a burst --
+    # with a wait after every step the direct-launch form shows the host's enqueue times instead (the prefix "starts" when it is queued)
+    for j in range(8):
+        eng.step(*frames[k % 4], next_frame=frames[(k + 1) % 4]); k += 1
+    torch.cuda.synchronize()
+    if rep >= 4:
         acc.append(eng.debug_tensor('stamps').cpu().numpy()[:14] / khz * 1e3)
 t = np.median(np.stack(acc), axis=0)
-print('dtype', dtype, 'options', opts, '(microseconds since the first node of the step graph; median of 20 replayed steps)')
+print('dtype', dtype, 'options', opts, '(microseconds since the first node of the step graph; median over 20 bursts of 8 steps, last step of each)')
 for j, (n, v) in enumerate(zip(names, t)):
     if dtype == 'mixed' or j not in (1, 2, 3, 4, 5, 6):        # (the fp32 mode has one chain: no proxy branch, heads in one piece)
         print('  %-26s %8.1f us' % (n, v))

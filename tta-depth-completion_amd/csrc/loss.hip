@@ -47,6 +47,11 @@ __device__ __forceinline__ float edge_w(const float* img, size_t plane, size_t a
                      fabsf(img[2 * plane + a] - img[2 * plane + b])) / 3.0f;
     return expf(-m);
 }
+// the same weight from values already in registers (a = the pixel, b = its neighbour; same operation order)
+__device__ __forceinline__ float edge_w3(float a0, float a1, float a2, float b0, float b1, float b2) {
+    const float m = (fabsf(a0 - b0) + fabsf(a1 - b1) + fabsf(a2 - b2)) / 3.0f;
+    return expf(-m);
+}
 
 // bx / nbx: this block's index and the block count of the reduction (the merged launches below give each loss its own block range)
 __device__ __forceinline__ void depth_reduce_body(int bx, int nbx, int n, const float* __restrict__ depth, const float* __restrict__ image,
@@ -61,11 +66,19 @@ __device__ __forceinline__ void depth_reduce_body(int bx, int nbx, int n, const 
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (size_t idx = (size_t)bx * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)nbx * blockDim.x) {
         const int x = (int)(idx % W), y = (int)(idx / W);
-        const float d = D[idx], w = valid_w(V, S, idx);
-        a0 += w * fabsf(clampd(S[idx], max_d) - d);
+        // every load of the pixel issued before the first use (clamped neighbours, selected afterwards): behind `if (x < W - 1)` the
+        // compiler waits for each neighbour's loads in turn
+        const bool xr = x < W - 1, yd = y < H - 1;
+        const size_t ir = xr ? idx + 1 : idx, id = yd ? idx + W : idx;
+        const float d = D[idx], dr = D[ir], dd = D[id], sv = S[idx], vv = (V ? V : S)[idx];      // (one address for either case: no branch between the loads)
+        const float w = V ? vv : (sv > 0.f ? 1.f : sv);
+        const float c0 = I[idx], c1 = I[plane + idx], c2 = I[2 * plane + idx];
+        const float r0 = I[ir], r1 = I[plane + ir], r2 = I[2 * plane + ir];
+        const float e0 = I[id], e1 = I[plane + id], e2 = I[2 * plane + id];
+        a0 += w * fabsf(clampd(sv, max_d) - d);
         a1 += w;
-        if (x < W - 1) a2 += edge_w(I, plane, idx, idx + 1) * fabsf(d - D[idx + 1]);
-        if (y < H - 1) a3 += edge_w(I, plane, idx, idx + W) * fabsf(d - D[idx + W]);
+        a2 += xr ? edge_w3(c0, c1, c2, r0, r1, r2) * fabsf(d - dr) : 0.f;
+        a3 += yd ? edge_w3(c0, c1, c2, e0, e1, e2) * fabsf(d - dd) : 0.f;
     }
     a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
     const int wave = threadIdx.x >> 6;
@@ -202,6 +215,24 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(float* __restrict__ 
     loss_finalize_block(ws, N, H, W, R, has_cos, w3, fin, loss_info, ws);
 }
 
+// workspace [0] = the cosine gradient's coefficient as loss_finalize_block forms it (same partials, same reduction, same gate) without the
+// depth terms: the heads' backward starts as soon as the cosine rows are reduced, beside decoder 3's forward
+__global__ __launch_bounds__(256) void loss_cos_coef_kernel(float* __restrict__ ws, int N, long R, const float* __restrict__ w3) {
+    __shared__ double red[4];
+    const float* cp = ws + ws_cos_off(N);
+    double a = 0.0;
+    for (int b = threadIdx.x; b < LOSS_CB; b += 256) a += cp[b];
+    const double l_cos = block_sum_d(a, red) / (double)R;
+    float wc = w3[2];
+    if ((float)l_cos < 0.3f) wc = 0.f;                       // external_model_adapt.py:424-425
+    if (threadIdx.x == 0) ws[WS_SCAL + 0] = (float)(-2.0 * wc / (double)R);
+}
+int ptta_launch_loss_cos_coef(float* ws, int N, long R, const float* w3_dev, hipStream_t s) {
+    hipLaunchKernelGGL(loss_cos_coef_kernel, dim3(1), dim3(256), 0, s, ws, N, R, w3_dev);
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
 int ptta_launch_loss_forward(const float* depth, const float* image, const float* sparse, const float* validity,
                              float max_input_depth, const float* emb, const float* ref, long R, int D,
                              const float* w3_dev, int N, int H, int W,
@@ -260,14 +291,24 @@ __device__ __forceinline__ void depth_grad_body(int bx, int nbx, const float* __
         const int x = (int)(idx % W), y = (int)(idx / W);
         const float* D = depth + n * plane;
         const float* I = image + (size_t)n * 3 * plane;
-        const float d = D[idx];
+        // all 22 loads of the pixel in flight together (clamped neighbours, selected afterwards; see depth_reduce_body)
+        const bool xr = x < W - 1, xl = x > 0, yd = y < H - 1, yu = y > 0;
+        const size_t ir = xr ? idx + 1 : idx, il = xl ? idx - 1 : idx, id = yd ? idx + W : idx, iu = yu ? idx - W : idx;
+        const float d = D[idx], dr = D[ir], dl = D[il], dd = D[id], du = D[iu];
+        const float sv = sparse[gi], vv = (validity ? validity : sparse)[gi];
+        const float c0 = I[idx], c1 = I[plane + idx], c2 = I[2 * plane + idx];
+        const float r0 = I[ir], r1 = I[plane + ir], r2 = I[2 * plane + ir];
+        const float l0 = I[il], l1 = I[plane + il], l2 = I[2 * plane + il];
+        const float e0 = I[id], e1 = I[plane + id], e2 = I[2 * plane + id];
+        const float u0 = I[iu], u1 = I[plane + iu], u2 = I[2 * plane + iu];
         const float sd_n = w3 ? fin[3 + n] : ws[WS_SD + n];
-        float v = sd_n * valid_w(validity, sparse, gi) * sgn(d - clampd(sparse[gi], max_d));
+        const float vw = validity ? vv : (sv > 0.f ? 1.f : sv);
+        float v = sd_n * vw * sgn(d - clampd(sv, max_d));
         float tx = 0.f, ty = 0.f;
-        if (x < W - 1) tx += edge_w(I, plane, idx, idx + 1) * sgn(d - D[idx + 1]);
-        if (x > 0) tx -= edge_w(I, plane, idx - 1, idx) * sgn(D[idx - 1] - d);
-        if (y < H - 1) ty += edge_w(I, plane, idx, idx + W) * sgn(d - D[idx + W]);
-        if (y > 0) ty -= edge_w(I, plane, idx - W, idx) * sgn(D[idx - W] - d);
+        tx += xr ? edge_w3(c0, c1, c2, r0, r1, r2) * sgn(d - dr) : 0.f;
+        tx -= xl ? edge_w3(l0, l1, l2, c0, c1, c2) * sgn(dl - d) : 0.f;
+        ty += yd ? edge_w3(c0, c1, c2, e0, e1, e2) * sgn(d - dd) : 0.f;
+        ty -= yu ? edge_w3(u0, u1, u2, c0, c1, c2) * sgn(du - d) : 0.f;
         g[gi] = v + cx * tx + cy * ty;
     }
 }
@@ -320,11 +361,11 @@ __global__ __launch_bounds__(256) void loss_backward_merged_kernel(const float* 
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
                               int N, int H, int W, float* ws, float* gdepth, float* gref, hipStream_t s, const float* w3_fused,
-                              float* loss_info_fused) {
+                              float* loss_info_fused, int cos_partials_ready) {
     const size_t total = (size_t)N * H * W;
     if (w3_fused && N > LOSS_FIN_MAXN) w3_fused = nullptr;          // the forward launched the finalize kernel in that case
     int blocks = (int)((total + 255) / 256); if (blocks > (w3_fused ? 1024 : 4096)) blocks = w3_fused ? 1024 : 4096;
-    const int has_cos = (emb && ref) ? 1 : 0;
+    const int has_cos = ((emb && ref) || cos_partials_ready) ? 1 : 0;
     if (emb && ref && gref && w3_fused) {
         long cb = (R + 3) / 4; if (cb > 1024) cb = 1024;
         if (blocks > 512) blocks = 512;

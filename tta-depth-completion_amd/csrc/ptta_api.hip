@@ -1919,17 +1919,17 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
     if (c->thru_active) {
         hipStream_t s2 = c->aux(s);
         if (!c->ev_dpart) HIPCHK(hipEventCreateWithFlags(&c->ev_dpart, hipEventDisableTiming));
-        // main stream: depth terms of the loss, their gradient (its kernel finalises the depth terms itself: no cosine term, nothing reported)
-        REST_(s, ptta_launch_loss_depth_part(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->N, c->H, c->W, c->loss_ws, s));
-        HIPCHK(hipEventRecord(c->ev_dpart, s));
-        REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, nullptr, nullptr, c->Rg, 512,
-                                           c->N, c->H, c->W, c->loss_ws, c->g_final, nullptr, s, c->hyper + 5, nullptr));
-        // auxiliary stream, behind the heads' forward: cosine rows, the finalisation (gate, coefficient, the four reported scalars: it needs the
-        // depth partials of the other stream, long there by now), the heads' backward
-        // (mixed mode: the ref GEMM's epilogue already left the cosine term's row statistics and block partials in the loss workspace)
+        // auxiliary stream, behind the heads' forward: cosine rows (mixed mode: the ref GEMM's epilogue already left the row statistics and the
+        // block partials in the loss workspace), the gated coefficient, the heads' backward -- none of it waits for decoder 3 or the depth terms
         if (!(c->nar_heads && heads_v2_on(c) && c->cos_rows_done)) REST_(s2, ptta_launch_loss_cos_part(c->emb, c->ref, c->Rg, 512, c->N, c->loss_ws, s2));
-        HIPCHK(hipStreamWaitEvent(s2, c->ev_dpart, 0));
-        REST_(s2, ptta_launch_loss_finalize(c->loss_ws, c->N, c->H, c->W, c->Rg, 1, c->hyper + 5, c->loss_info, s2));
+        HIPCHK(hipEventRecord(c->ev_dpart, s2));                // (the cosine partials exist)
+        REST_(s2, ptta_launch_loss_cos_coef(c->loss_ws, c->N, c->Rg, c->hyper + 5, s2));
+        // main stream: depth terms of the loss, their gradient; its kernel finalises the whole loss itself (the four reported scalars: the
+        // cosine partials of the other stream are long there by now)
+        REST_(s, ptta_launch_loss_depth_part(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->N, c->H, c->W, c->loss_ws, s));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_dpart, 0));
+        REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, nullptr, nullptr, c->Rg, 512,
+                                           c->N, c->H, c->W, c->loss_ws, c->g_final, nullptr, s, c->hyper + 5, c->loss_info, 1));
         c->cos_in_gemm = true;
         const int rc_h = heads_backward(c, c->gref_buf, s2);
         c->cos_in_gemm = false;

@@ -212,10 +212,13 @@ int ptta_launch_loss_depth_part(const float* depth, const float* image, const fl
                                 int N, int H, int W, float* ws, hipStream_t s);
 int ptta_launch_loss_cos_part(const void* emb, const void* ref, long R, int D, int N, float* ws, hipStream_t s, int narrow = 0);      // narrow: bf16 [R][512]
 int ptta_launch_loss_finalize(float* ws, int N, int H, int W, long R, int has_cos, const float* w3_dev, float* loss_info, hipStream_t s);
+// the gated cosine coefficient alone (workspace [0]): all the heads' backward needs of the finalisation -- it depends on the cosine partials only
+int ptta_launch_loss_cos_coef(float* ws, int N, long R, const float* w3_dev, hipStream_t s);
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
                               int N, int H, int W, float* ws, float* gdepth, float* gref, hipStream_t s, const float* w3_fused = nullptr,
-                              float* loss_info_fused = nullptr);
+                              float* loss_info_fused = nullptr, int cos_partials_ready = 0);
+// (cos_partials_ready with emb == NULL: the depth gradient alone, its in-kernel finalisation includes the cosine term and the gate)
 // validity may be NULL in both calls: where(sparse > 0, 1, sparse) is then computed on the fly (src/tta_main.py:583-586)
 
 int ptta_launch_eval_metrics(const float* depth, const float* gt, long n, float min_eval, float max_eval, double* scratch, float* out4,

@@ -379,7 +379,7 @@ struct FirstP {
     const uint32_t* fmask_bits; int fmask_nb;        // FMASK: sign bits of the first convolution's ReLU mask (one word per pixel), frames b % fmask_nb
     uint32_t* a_bits;                        // sign bits of the a_out map for the same frames (the backward's mask), or null
 };
-template <typename T, int CIN, bool UP, bool FMASK = false, bool RELU_MID = true, bool EMASK = false>
+template <typename T, int CIN, bool UP, bool FMASK = false, bool RELU_MID = true, bool EMASK = false, bool EADD = false>
 __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, FirstP f) {
     constexpr int STR = Geo<T>::STR, WL = Geo<T>::WL;
     constexpr int UPH = 6, UPW = 18;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
             if (UP && rr == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); }      // every wave's pieces of the window have landed
             if (y < H) {
                 if (UP) epi_tile<T, false, EMASK, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0, &biasv);
-                else epi_tile<T, false, EMASK, false>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv);
+                else epi_tile<T, false, EMASK, EADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv);
             }
         }
         lds_barrier();          // LDS reuse by the next tile (plane window over the bilinear window, halo)
@@ -1158,8 +1158,8 @@ static int launch_first_t(const Conv32Args& a, const ConvInArgs& f, void* a_out,
     Conv32P<T> p;
     p.in = nullptr; p.in_nb = 1; p.wpack = a.w->mbf16; p.wpack2 = sizeof(T) == 4 ? a.w->mlo : nullptr;
     p.epi.bias = a.bias; p.epi.up = (const T*)a.up; p.epi.up_nb = a.up_nb > 0 ? a.up_nb : 1;
-    p.epi.mask = (const T*)a.mask; p.epi.mask_nb = a.mask_nb > 0 ? a.mask_nb : 1; p.epi.add1 = nullptr; p.epi.add1_nb = 1; p.epi.add2 = nullptr; p.epi.add2_nb = 1;
-    p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = nullptr;
+    p.epi.mask = (const T*)a.mask; p.epi.mask_nb = a.mask_nb > 0 ? a.mask_nb : 1; p.epi.add1 = (const T*)a.add1; p.epi.add1_nb = a.add1_nb > 0 ? a.add1_nb : 1; p.epi.add2 = nullptr; p.epi.add2_nb = 1;
+    p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = (T*)a.out_sum;          // (add1 / out_sum: the backward form only, see ptta_launch_conv32_first)
     p.epi.mask_bits = a.mask_bits; p.epi.bits_out = a.bits_out; p.epi.bits_nb = a.bits_nb; p.epi.bits_sum = 0;
     p.B = a.B; p.Hin = p.Hout = a.Hin; p.Win = p.Wout = a.Win;
     const int blocks = (int)(tiles > kFullChipBlocks ? kFullChipBlocks : tiles);
@@ -1168,7 +1168,8 @@ static int launch_first_t(const Conv32Args& a, const ConvInArgs& f, void* a_out,
     q.zero_from_b = f.zero_from_b; q.w1 = f.wfrag; q.bias1 = f.bias; q.a_out = (float*)a_out; q.a_nb = a_nb;
     q.fmask_nb = f.mask_nb > 0 ? f.mask_nb : 1; q.fmask_bits = f.mask_bits; q.a_bits = f.a_bits;
     if (bwd_form) {
-        hipLaunchKernelGGL((conv32_s1_first_kernel<T, 1, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p, q);
+        if (a.out_sum) hipLaunchKernelGGL((conv32_s1_first_kernel<T, 1, false, true, false, true, true>), dim3(blocks), dim3(256), 0, s, p, q);
+        else hipLaunchKernelGGL((conv32_s1_first_kernel<T, 1, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p, q);
         PTTA_CHECK_LAUNCH();
         return 0;
     }
@@ -1184,7 +1185,9 @@ int ptta_launch_conv32_first(const Conv32Args& a, const ConvInArgs& f, void* a_o
     // first convolution masked, no ReLU in between, the second convolution's epilogue masked, no bilinear skip)
     const bool bwd_form = f.mask != nullptr;
     if (bwd_form && (!f.mask_bits || !a.mask_bits)) return 1;
-    if (a.naive || (!a.bf16 && !a.x3) || a.mode != CONV_S1 || a.add1 || a.add2 || a.out_sum || f.naive) return 1;
+    if (a.naive || (!a.bf16 && !a.x3) || a.mode != CONV_S1 || a.add2 || f.naive) return 1;
+    // (a second output = masked result + one addend: the backward form only -- d z4 = d s0_2 + up2^T(d e3_0), ptta_api.hip backbone_backward)
+    if ((a.add1 != nullptr) != (a.out_sum != nullptr) || (a.out_sum && !bwd_form)) return 1;
     if (bwd_form ? (a.relu_in || !a.mask || a.up || f.cin != 1) : (!a.relu_in || a.mask != nullptr)) return 1;
     if (f.cin < 1 || f.cin > 3 || f.up || f.add1 || f.B != a.B || f.H != a.Hin || f.W != a.Win) return 1;
     if (a.bf16 && (a_out || f.a_bits)) return 1;             // (a narrow launch has no backward of its own: nothing to keep of the first map)

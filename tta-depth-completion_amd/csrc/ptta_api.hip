@@ -29,6 +29,23 @@ namespace {
 
 // Diagnostic (option "stamps", tools/step_stamps.py): wall-clock stamps written by one-thread nodes of the step's graph (ticks since
 // stamp 0) -- where a replayed step's branches start and end WITHOUT a profiler attached (rocprofv3 slows the host enough to reorder them)
+// device-to-device copies of the step (the next frame into the handle's staging buffers, the depth map and the four loss scalars out): a
+// kernel on the step's stream instead of hipMemcpyAsync -- the runtime's copy carries system-scope fences (what the host may read), these
+// are read by later work of the same device
+static __global__ void d2d_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long n4, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) ((float4*)dst)[i] = ((const float4*)src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[4 * n4 + threadIdx.x] = src[4 * n4 + threadIdx.x];
+}
+static hipError_t d2d_copy(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if ((bytes & 3) || (((uintptr_t)dst | (uintptr_t)src) & 15)) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    const long n = (long)(bytes / 4), n4 = n / 4;
+    long blocks = (n4 + 255) / 256; if (blocks < 1) blocks = 1; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(d2d_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, (float*)dst, n4, n);
+    return hipGetLastError();
+}
+// events that order the handle's own streams among themselves (fork / join inside a step, prefix -> step): no timing, no system-scope fence --
+// nothing the host or another device reads is published by them (ev_replay, which the host waits on before it destroys a graph, keeps the default)
+static constexpr unsigned kStepEvent = hipEventDisableTiming | hipEventDisableSystemFence;
 static __global__ void stamp_kernel(float* out, unsigned long long* base, int i) {
     const unsigned long long t = wall_clock64();
     if (i == 0) { *base = t; out[0] = 0.f; } else out[i] = (float)(long long)(t - *base);
@@ -175,13 +192,16 @@ struct ptta_ctx {
     int use_aux = 1;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_real = nullptr;
+    hipEvent_t ev_side[4] = {nullptr, nullptr, nullptr, nullptr};        // backbone_backward: transposed upsamplings beside the main chain
     hipStream_t aux(hipStream_t) {
         if (!use_aux || prof_on) return nullptr;
         if (!aux_stream) {
             if (hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-            if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_real, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; return nullptr; }
+            if (hipEventCreateWithFlags(&ev_fork, kStepEvent) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_join, kStepEvent) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_real, kStepEvent) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_side[0], kStepEvent) != hipSuccess || hipEventCreateWithFlags(&ev_side[1], kStepEvent) != hipSuccess ||
+                hipEventCreateWithFlags(&ev_side[2], kStepEvent) != hipSuccess || hipEventCreateWithFlags(&ev_side[3], kStepEvent) != hipSuccess) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; return nullptr; }
         }
         return aux_stream;
     }
@@ -271,7 +291,7 @@ struct ptta_ctx {
     float *loss_ws, *loss_info, *g_final, *g_net;
     // backward
     void *dv3, *ds0_3, *du3, *ds1_3, *dt3, *dw2, *dfeat_tot, *dz2_up, *de3_2a, *de3_1, *de3_1a, *de3_0, *de3_0a;
-    void *dv2, *ds0_2, *dz4, *du2, *ds1_2, *dz3, *dt2, *dz2, *de2_2a, *de2_1, *de2_1a, *de2_0, *de2_0a, *dv1, *dm_total, *g_feat;
+    void *up4_t, *up3_t, *dv2, *ds0_2, *dz4, *du2, *ds1_2, *dz3, *dt2, *dz2, *de2_2a, *de2_1, *de2_1a, *de2_0, *de2_0a, *dv1, *dm_total, *g_feat;
     float *dp11, *dq, *dp12, *dout1, *g_feat_f32;
     float* wgrad_part;
 };
@@ -477,7 +497,7 @@ void build_workspace(ptta_ctx* c) {
     G_(dv2, Nn, H2, W2); G_(ds0_2, Nn, H2, W2); G_(dz4, Nn, H2, W2); G_(du2, Nn, H2, W2); G_(ds1_2, Nn, H4, W4);
     G_(dz3, Nn, H4, W4); G_(dt2, Nn, H4, W4); G_(dz2, Nn, H8, W8); G_(de2_2a, Nn, H8, W8); G_(de2_1, Nn, H4, W4);
     G_(de2_1a, Nn, H4, W4); G_(de2_0, Nn, H2, W2); G_(de2_0a, Nn, H2, W2); G_(dv1, Nn, H4, W4); G_(dm_total, Nn, H4, W4);
-    G_(g_feat, Nn, H4, W4);
+    G_(g_feat, Nn, H4, W4); G_(up4_t, Nn, H2, W2); G_(up3_t, Nn, H4, W4);
 #undef G_
     if (c->nar_bwd) c->dm_f32 = c->falloc((size_t)Nn * H4 * W4 * 32);
     if (c->nar_proxy) {
@@ -660,10 +680,10 @@ int conv32_first_bwd(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvI
     const long tiles = (long)B * ((W + 31) / 32) * ((H + 7) / 8);
     const bool nar = c->nar_bwd != 0;
     f.bf16 = nar ? 1 : c->bf16;
-    if (c->fuse_head_bwd && c->bits_of(f.mask) && c->bits_of(e.mask) && c->fuse_first >= 1 && !c->bf16 && !c->naive && c->x3 && tiles > 256 && e.mask && e.raw && !e.add1 && !e.add2 && !e.sum && !e.up) {
+    if (c->fuse_head_bwd && c->bits_of(f.mask) && c->bits_of(e.mask) && c->fuse_first >= 1 && !c->bf16 && !c->naive && c->x3 && tiles > 256 && e.mask && e.raw && (e.add1 != nullptr) == (e.sum != nullptr) && !e.add2 && !e.up) {
         Conv32Args a;
         a.in = nullptr; a.in_nb = B; a.w = &it->second.b; a.bias = nullptr;
-        a.mask = e.mask; a.mask_nb = e.mask_nb; a.out_raw = e.raw;
+        a.mask = e.mask; a.mask_nb = e.mask_nb; a.out_raw = e.raw; a.add1 = e.add1; a.add1_nb = e.add1_nb; a.out_sum = e.sum;
         a.mask_bits = c->bits_of(e.mask); f.mask_bits = c->bits_of(f.mask);
         a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 0; a.bf16 = nar ? 1 : 0; a.naive = 0; a.x3 = 1;
         const double px = (double)B * H * W;
@@ -1385,23 +1405,38 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     if (join_aux) HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));       // d feat from the heads (auxiliary stream)
     { E e; e.raw = c->dw2; e.mask = c->w2; e.mask_nb = B2; e.sum = c->dfeat_tot; e.add1 = c->g_feat; e.add1_nb = Nn;
       CV("depth_decoder3.dec2.1", true, CONV_S2, c->dt3, Nn, Nn, H2, W2, false, e); }
+    // The three transposed bilinear upsamplings of the backward (d z2 += up2^T(d feat_tot), d z3 = d s1_2 + up2^T(d e3_1), d z4 = d s0_2 + up2^T(d e3_0))
+    // do not lie on the chain d feat_tot -> encoder 3 -> decoder 2: each runs on the second stream as soon as its source exists, and its
+    // result enters the chain as the addend of a convolution epilogue (out_sum = masked result + addend; fp32: the same two operands of the
+    // same addition as `add + up2^T(...)` in the upsampling kernel).  One join, in front of decoder 2's prediction head.
+    hipStream_t sd = join_aux ? c->aux(s) : nullptr;
+    if (!sd) sd = s;
+    auto side = [&](int k, const void* src, void* dst, int Hh, int Wh) -> int {
+        if (sd != s) { HIPCHK(hipEventRecord(c->ev_side[k], s)); HIPCHK(hipStreamWaitEvent(sd, c->ev_side[k], 0)); }
+        REST_(sd, ptta_launch_up2T_32(src, nullptr, dst, Nn, Hh, Wh, nbf, sd));
+        return 0;
+    };
     // ---- encoder 3 ----
-    REST_(s, ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, nbf, s));
+    RUN(side(0, c->dfeat_tot, c->dz2_up, H8, W8));
     CV("depth_encoder3.enc2.3", true, CONV_S1, c->dfeat_tot, Nn, Nn, H4, W4, false, em(c->de3_2a, c->e3_2a, B2));
     { E e; e.sum = c->de3_1; e.mask = c->e3_1; e.mask_nb = B2; e.add1 = c->ds1_3; e.add1_nb = Nn;
       CV("depth_encoder3.enc2.1", true, CONV_T2, c->de3_2a, Nn, Nn, H4, W4, false, e); }
+    RUN(side(1, c->de3_1, c->up3_t, H4, W4));
     CV("depth_encoder3.enc1.3", true, CONV_S1, c->de3_1, Nn, Nn, H2, W2, false, em(c->de3_1a, c->e3_1a, B2));
     { E e; e.sum = c->de3_0; e.mask = c->e3_0; e.mask_nb = B2; e.add1 = c->ds0_3; e.add1_nb = Nn;
       CV("depth_encoder3.enc1.1", true, CONV_T2, c->de3_1a, Nn, Nn, H2, W2, false, e); }
+    RUN(side(2, c->de3_0, c->up4_t, H2, W2));
+    if (sd != s) HIPCHK(hipEventRecord(c->ev_side[3], sd));
     CV("depth_encoder3.init.2", true, CONV_S1, c->de3_0, Nn, Nn, H1, W1, false, em(c->de3_0a, c->e3_0a, B2));
     RUN(dgrad_in_ch1("depth_encoder3.init.0", c->de3_0a, g_net, c->dp11, H1, W1));       // d p11 = conv^T + d output
     REST_(s, ptta_launch_up2T_1ch(c->dp11, c->dq, Nn, H2, W2, s));                              // d(out2 + p12)
     // ---- decoder 2 ----
-    RUN(head_bwd("depth_decoder2.prdct.3", "depth_decoder2.prdct.1", c->dq, c->v2, c->dv2, H2, W2, em(c->ds0_2, c->s0_2, B2)));
-    REST_(s, ptta_launch_up2T_32(c->de3_0, c->ds0_2, c->dz4, Nn, H2, W2, nbf, s));         // d z4 = d s0_2 + up2^T(d e3_0)
+    if (sd != s) HIPCHK(hipStreamWaitEvent(s, c->ev_side[3], 0));
+    { E e = em(c->ds0_2, c->s0_2, B2); e.sum = c->dz4; e.add1 = c->up4_t; e.add1_nb = Nn;      // d z4 = d s0_2 + up2^T(d e3_0)
+      RUN(head_bwd("depth_decoder2.prdct.3", "depth_decoder2.prdct.1", c->dq, c->v2, c->dv2, H2, W2, e)); }
     CV("depth_decoder2.dec1.3", true, CONV_S1, c->dz4, Nn, Nn, H2, W2, false, em(c->du2, c->u2, B2));
-    CV("depth_decoder2.dec1.1", true, CONV_S2, c->du2, Nn, Nn, H2, W2, false, em(c->ds1_2, c->s1_2, B2));
-    REST_(s, ptta_launch_up2T_32(c->de3_1, c->ds1_2, c->dz3, Nn, H4, W4, nbf, s));         // d z3 = d s1_2 + up2^T(d e3_1)
+    { E e = em(c->ds1_2, c->s1_2, B2); e.sum = c->dz3; e.add1 = c->up3_t; e.add1_nb = Nn;      // d z3 = d s1_2 + up2^T(d e3_1)
+      CV("depth_decoder2.dec1.1", true, CONV_S2, c->du2, Nn, Nn, H2, W2, false, e); }
     CV("depth_decoder2.dec2.3", true, CONV_S1, c->dz3, Nn, Nn, H4, W4, false, em(c->dt2, c->t2, B2));
     { E e; e.sum = c->dz2; e.mask = c->z2; e.mask_nb = B2; e.add1 = c->dz2_up; e.add1_nb = Nn;
       CV("depth_decoder2.dec2.1", true, CONV_S2, c->dt2, Nn, Nn, H4, W4, false, e); }
@@ -1565,7 +1600,7 @@ void ptta_destroy(ptta_handle h) {
         for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(h->ev_prefix[p]); (void)hipEventDestroy(h->ev_rest[p]); }
     }
     if (h->ev_dpart) (void)hipEventDestroy(h->ev_dpart);
-    if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_real); }
+    if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_real); for (auto& e_ : h->ev_side) if (e_) (void)hipEventDestroy(e_); }
     for (void* p : h->allocs) if (p) (void)hipFree(p);
     for (auto& pc : h->prof) for (auto& e : pc.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete h;
@@ -1758,7 +1793,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
     c->fwd_valid = false; c->head.fwd_ok = false; c->fb_image = c->fb_sparse = nullptr;
     RUN(forward_common(c, image, sparse, true, s));      // includes the heads (beside decoder 3)
     const size_t dbytes = (size_t)c->N * c->H * c->W * 4, ebytes = (size_t)c->Rg * 512 * 4;
-    if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), dbytes, hipMemcpyDeviceToDevice, s));
+    if (depth_out) HIPCHK(d2d_copy(depth_out, final_depth(c), dbytes, s));
     if (c->nar_heads && heads_v2_on(c)) {       // the caller's tensors are fp32: widened copies of the narrow embeddings
         if (emb_out) RUN(ptta_launch_hn_untile(c->emb_n, emb_out, c->Rg, s));
         if (ref_out) RUN(ptta_launch_hn_untile(c->ref_n, ref_out, c->Rg, s));
@@ -1779,7 +1814,7 @@ int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, fl
     c->fwd_valid = false; c->head.fwd_ok = false;        // the eval pass overwrites the saved activations
     c->fb_image = c->fb_sparse = nullptr;                // (ptta_forward_eval_last's fallback restores them around its own call)
     RUN(forward_common(c, image, sparse, false, s));
-    HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(d2d_copy(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, s));
     return 0;
 }
 
@@ -1805,7 +1840,7 @@ int ptta_forward_eval_last(ptta_handle c, float* depth_out, ptta_stream s_) {
     const int rc = forward_common(c, c->in_image, c->in_sparse, false, s);
     c->skip_prefix = false;
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(d2d_copy(depth_out, final_depth(c), (size_t)c->N * c->H * c->W * 4, s));
     return 0;
 }
 
@@ -1918,7 +1953,7 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
     hipStream_t s = (hipStream_t)s_;
     if (c->thru_active) {
         hipStream_t s2 = c->aux(s);
-        if (!c->ev_dpart) HIPCHK(hipEventCreateWithFlags(&c->ev_dpart, hipEventDisableTiming));
+        if (!c->ev_dpart) HIPCHK(hipEventCreateWithFlags(&c->ev_dpart, kStepEvent));
         // auxiliary stream, behind the heads' forward: cosine rows (mixed mode: the ref GEMM's epilogue already left the row statistics and the
         // block partials in the loss workspace), the gated coefficient, the heads' backward -- none of it waits for decoder 3 or the depth terms
         if (!(c->nar_heads && heads_v2_on(c) && c->cos_rows_done)) REST_(s2, ptta_launch_loss_cos_part(c->emb, c->ref, c->Rg, 512, c->N, c->loss_ws, s2));
@@ -1981,10 +2016,10 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
     if (c->use_graph && !c->prof_on) {
         // replay path: stage the inputs at fixed addresses, then one hipGraphLaunch
         const int key = (validity ? 2 : 0) | (loss_image != image ? 1 : 0);
-        HIPCHK(hipMemcpyAsync(c->in_image, image, ibytes, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(c->in_sparse, sparse, pbytes, hipMemcpyDeviceToDevice, s));
-        if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
-        if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(d2d_copy(c->in_image, image, ibytes, s));
+        HIPCHK(d2d_copy(c->in_sparse, sparse, pbytes, s));
+        if (key & 1) HIPCHK(d2d_copy(c->in_loss_image, loss_image, ibytes, s));
+        if (key & 2) HIPCHK(d2d_copy(c->in_validity, validity, pbytes, s));
         RUN(ensure_fused_heads(c, s));
         {
         if (!c->gexec[key]) {
@@ -2009,8 +2044,8 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
     } else {
         RUN(step_body(c, image, loss_image, sparse, validity, s_));
     }
-    if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
-    if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
+    if (depth_out) HIPCHK(d2d_copy(depth_out, final_depth(c), pbytes, s));
+    if (loss_info_out) HIPCHK(d2d_copy(loss_info_out, c->loss_info, 16, s));
     return 0;
 }
 
@@ -2066,10 +2101,10 @@ static int pipe_init(ptta_ctx* c) {
     if (c->oom) return c->fail("out of device memory (second prefix buffer set)", -12);
     HIPCHK(hipStreamCreateWithFlags(&c->pre_stream, hipStreamNonBlocking));
     for (int p = 0; p < 2; ++p) {
-        HIPCHK(hipEventCreateWithFlags(&c->ev_prefix[p], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_rest[p], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_prefix[p], kStepEvent));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_rest[p], kStepEvent));
     }
-    HIPCHK(hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_entry, kStepEvent));
     c->pipe_ready = true;
     return 0;
 }
@@ -2153,8 +2188,8 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         HIPCHK(hipStreamWaitEvent(s, c->ev_prefix[p], 0));
     } else {                                                  // first call, or the caller did not announce this frame: prefix in line
         HIPCHK(hipStreamSynchronize(c->pre_stream));          // (a prefix of another frame may still be writing this set) -- the ONE host wait of this path
-        HIPCHK(hipMemcpyAsync(c->in_image, image, ibytes, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(c->in_sparse, sparse, pbytes, hipMemcpyDeviceToDevice, s));
+        HIPCHK(d2d_copy(c->in_image, image, ibytes, s));
+        HIPCHK(d2d_copy(c->in_sparse, sparse, pbytes, s));
         if (!c->use_graph) RUN(prefix_body(c, c->in_image, c->in_sparse, s));
         else {
         if (!c->pexec[p]) RUN(pipe_capture(c, &c->pgraph[p], &c->pexec[p], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));
@@ -2162,8 +2197,8 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         }
     }
     P.prepared = false; P.prep_token = 0;
-    if (key & 1) HIPCHK(hipMemcpyAsync(c->in_loss_image, loss_image, ibytes, hipMemcpyDeviceToDevice, s));
-    if (key & 2) HIPCHK(hipMemcpyAsync(c->in_validity, validity, pbytes, hipMemcpyDeviceToDevice, s));
+    if (key & 1) HIPCHK(d2d_copy(c->in_loss_image, loss_image, ibytes, s));
+    if (key & 2) HIPCHK(d2d_copy(c->in_validity, validity, pbytes, s));
     if (!c->use_graph) {
         c->skip_prefix = true;
         const int rc = step_body(c, c->in_image, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse, (key & 2) ? c->in_validity : nullptr, (ptta_stream)s);
@@ -2182,11 +2217,13 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     }
     HIPCHK(hipEventRecord(c->ev_rest[p], s));
     P.rest_recorded = true; c->pipe_last = p; P.last_token = frame_token ? frame_token : ~(uint64_t)0;      // (an unnamed frame is still the one ptta_forward_eval_last scores)
-    if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(c->ev_replay, s));
+    if (c->use_graph) {                                       // (direct launches: nothing to keep alive)
+        if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_replay, s));
+    }
     c->fwd_valid = true;
-    if (depth_out) HIPCHK(hipMemcpyAsync(depth_out, final_depth(c), pbytes, hipMemcpyDeviceToDevice, s));
-    if (loss_info_out) HIPCHK(hipMemcpyAsync(loss_info_out, c->loss_info, 16, hipMemcpyDeviceToDevice, s));
+    if (depth_out) HIPCHK(d2d_copy(depth_out, final_depth(c), pbytes, s));
+    if (loss_info_out) HIPCHK(d2d_copy(loss_info_out, c->loss_info, 16, s));
     if (next_token != 0 && next_token == frame_token) {
         // another step on the SAME frame (inner_iter > 1): its prefix is the one just used -- nothing in the step writes those tensors
         HIPCHK(hipEventRecord(c->ev_prefix[p], s));
@@ -2201,8 +2238,8 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         HIPCHK(hipStreamWaitEvent(ps, c->ev_entry, 0));
         if (Q.rest_recorded) HIPCHK(hipStreamWaitEvent(ps, c->ev_rest[q], 0));
         if (!c->proxy_rgb_valid) { HIPCHK(hipStreamSynchronize(ps)); RUN(ensure_proxy_rgb(c, c->in_image, s)); HIPCHK(hipStreamSynchronize(s)); }   // once per set
-        HIPCHK(hipMemcpyAsync(c->in_image, next_image, ibytes, hipMemcpyDeviceToDevice, ps));
-        HIPCHK(hipMemcpyAsync(c->in_sparse, next_sparse, pbytes, hipMemcpyDeviceToDevice, ps));
+        HIPCHK(d2d_copy(c->in_image, next_image, ibytes, ps));
+        HIPCHK(d2d_copy(c->in_sparse, next_sparse, pbytes, ps));
         if (!c->use_graph) RUN(prefix_body(c, c->in_image, c->in_sparse, ps));
         else {
         if (!c->pexec[q]) RUN(pipe_capture(c, &c->pgraph[q], &c->pexec[q], [&](hipStream_t cs) { return prefix_body(c, c->in_image, c->in_sparse, cs); }));

@@ -647,50 +647,66 @@ __device__ __forceinline__ void wsplit8(const float* v, uint4& hi, uint4& lo) {
     gsplit2(v[4], v[5], hi.z, lo.z); gsplit2(v[6], v[7], hi.w, lo.w);
 }
 // single = 1 (Ci, Co <= 32): one tile pair; the four waves take different items instead and write a partial each.
-template <bool GY16>          // GY16: gy.p points at bf16 values (the narrow gradient maps of the MSG_CHN mixed mode): widened on load, the same products
+// BLKRED (single only): the four waves' partial tiles are summed inside the block in a fixed tree ((w0 + w2) + (w1 + w3)) through LDS and the
+// block writes ONE partial -- four times the waves for the same partial traffic: the launch is a latency chain of ~2 us per item and wave
+// (38 strided loads, then 27 MFMAs), so its duration is the items per wave.
+template <bool GY16, bool BLKRED = false>          // GY16: gy.p points at bf16 values (the narrow gradient maps of the MSG_CHN mixed mode): widened on load, the same products
 __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int nitems_x, int single, int ncib, float* __restrict__ part) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, hg = lane >> 5;
     // the four waves of a block = the four (ci tile, co tile) pairs: 2 x 2 (<= 64 x 64 channels), 1 x 4 (32 -> 128) or 4 x 1 (128 -> 32)
     const int cob = single ? 0 : wave / ncib, cib = single ? 0 : wave % ncib;
     const int H = x.H, W = x.W;
     const int co = cob * 32 + c, ci = cib * 32 + c;
     const bool cov = co < gy.C, civ = ci < x.C;
-    const float* gyc = gy.p + (cov ? co : 0);
-    const bf16_t* gyc16 = (const bf16_t*)gy.p + (cov ? co : 0);
-    const float* xc = x.p + (civ ? ci : 0);
+    // Addresses = uniform base + 32-bit BYTE offset (maps < 4 GB, checked by the launcher).  The item is wave-uniform (scalar row / image
+    // arithmetic), a lane adds its channel and its half's eight pixels; clamps are selects between precomputed offsets.  The first form --
+    // 64-bit element indices from a lane-varying item, clamp, multiply by the row pitch per load -- spent ~190 quarter-rate integer
+    // multiplies per item: 3 k of the ~4.5 k cycles an item took (round 5, .s).
+    constexpr unsigned GE = GY16 ? 2u : 4u;
+    const unsigned gld = (unsigned)gy.ld * GE, xld = (unsigned)x.ld * 4u;
+    const unsigned glane = (unsigned)(cov ? co : 0) * GE + (hg ? 8u * gld : 0u), xlane = (unsigned)(civ ? ci : 0) * 4u + (hg ? 8u * xld : 0u);
+    const char* const gbase = (const char*)gy.p;
+    const char* const xbase = (const char*)x.p;
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
-    const long nitems = (long)x.B * H * nitems_x;                     // item = 16 consecutive pixels of one row
+    const int nitems = x.B * H * nitems_x;                            // item = 16 consecutive pixels of one row
     struct Regs { float g[8]; float v[3][10]; unsigned gm, vm[3]; };      // raw loads + validity bits (zero-fill happens at use: no wait at the load)
-    auto fetch = [&](long item, Regs& r) __attribute__((always_inline)) {
-        const int xs = (int)(item % nitems_x); const long t_ = item / nitems_x;
-        const int y = (int)(t_ % H); const int b = (int)(t_ / H);
+    auto fetch = [&](int item, Regs& r) __attribute__((always_inline)) {
+        const int xs = item % nitems_x; const int t_ = item / nitems_x;
+        const int y = t_ % H; const int b = t_ / H;
         const int p0 = xs * 16 + 8 * hg;                               // this lane's first pixel of the step
-        const long rowbase = ((long)b * H + y) * W;
+        const unsigned rowpix = (unsigned)((b * H + y) * W);
+        const unsigned g0 = (rowpix + (unsigned)(xs * 16)) * gld + glane;
+        const unsigned glast = (rowpix + (unsigned)(W - 1)) * gld + (unsigned)(cov ? co : 0) * GE;
         r.gm = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int px = p0 + j;
-            if constexpr (GY16) r.g[j] = __uint_as_float((unsigned)gyc16[(rowbase + min(px, W - 1)) * gy.ld] << 16);
-            else r.g[j] = gyc[(rowbase + min(px, W - 1)) * gy.ld];
-            r.gm |= (px < W && cov) ? (1u << j) : 0u;
+            const bool ok = p0 + j < W;
+            const unsigned off = ok ? g0 + (unsigned)j * gld : glast;
+            if constexpr (GY16) r.g[j] = __uint_as_float((unsigned)*(const bf16_t*)(gbase + off) << 16);
+            else r.g[j] = *(const float*)(gbase + off);
+            r.gm |= (ok && cov) ? (1u << j) : 0u;
         }
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int yy = y + dy - 1;
-            const bool rok = yy >= 0 && yy < H && civ;
-            const long rb = ((long)b * H + min(max(yy, 0), H - 1)) * W;
+            const bool rok = yy >= 0 && yy < H;
+            const unsigned rp = (unsigned)((b * H + min(max(yy, 0), H - 1)) * W);
+            const unsigned x0 = (rp + (unsigned)(xs * 16)) * xld + xlane;          // pixel p0 of the row
+            const unsigned xfirst = rp * xld + (unsigned)(civ ? ci : 0) * 4u, xlast = (rp + (unsigned)(W - 1)) * xld + (unsigned)(civ ? ci : 0) * 4u;
             r.vm[dy] = 0;
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
                 const int px = p0 + j - 1;
-                r.v[dy][j] = xc[(rb + min(max(px, 0), W - 1)) * x.ld];
-                r.vm[dy] |= (rok && px >= 0 && px < W) ? (1u << j) : 0u;
+                const bool lo_ok = px >= 0, hi_ok = px < W;
+                const unsigned off = !lo_ok ? xfirst : (!hi_ok ? xlast : x0 + (unsigned)(j - 1) * xld);
+                r.v[dy][j] = *(const float*)(xbase + off);
+                r.vm[dy] |= (rok && civ && lo_ok && hi_ok) ? (1u << j) : 0u;
             }
         }
     };
@@ -708,49 +724,99 @@ __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int n
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum += r.g[j];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int dy = 0; dy < 3; ++dy) {
+            // the row's ten values are split ONCE: packed hi / lo of the five even-aligned pairs (0,1) .. (8,9) and the four odd-aligned pairs
+            // (1,2) .. (7,8); tap dx = 0 / 2 takes even pairs 0..3 / 1..4, dx = 1 the odd ones.  Same conversions as wsplit8 of the three
+            // shifted windows (hi = RNE(v), lo = RNE(v - hi)): identical fragments, 38 instead of 72 conversions.
+            const float* v = r.v[dy];
+            unsigned eh[5], el[5], oh[4], ol[4];
+            float res[10];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                float2_t pr = {v[2 * k], v[2 * k + 1]};
+                eh[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2_t));
+                res[2 * k] = v[2 * k] - __uint_as_float(eh[k] << 16);
+                res[2 * k + 1] = v[2 * k + 1] - __uint_as_float(eh[k] & 0xffff0000u);
+                float2_t rr2 = {res[2 * k], res[2 * k + 1]};
+                el[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr2, bf16x2_t));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // hi halves of values 2k+1, 2k+2 are already in eh[k] (upper half) and eh[k+1] (lower half)
+                oh[k] = (eh[k] >> 16) | (eh[k + 1] << 16);
+                float2_t rr2 = {res[2 * k + 1], res[2 * k + 2]};
+                ol[k] = __builtin_bit_cast(unsigned, __builtin_convertvector(rr2, bf16x2_t));
+            }
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                uint4 xh, xl;
-                wsplit8(&r.v[dy][dx], xh, xl);                         // pixels p + dx - 1 .. p + dx + 6: a register rename
+                const uint4 xh = dx == 1 ? make_uint4(oh[0], oh[1], oh[2], oh[3]) : (dx == 0 ? make_uint4(eh[0], eh[1], eh[2], eh[3]) : make_uint4(eh[1], eh[2], eh[3], eh[4]));
+                const uint4 xl = dx == 1 ? make_uint4(ol[0], ol[1], ol[2], ol[3]) : (dx == 0 ? make_uint4(el[0], el[1], el[2], el[3]) : make_uint4(el[1], el[2], el[3], el[4]));
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, xh), bl = __builtin_bit_cast(bf16x8, xl);
                 const int t = dy * 3 + dx;
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
             }
+        }
     };
     Regs r0, r1;
-    const long stride = single ? (long)gridDim.x * 4 : gridDim.x;
-    long item = single ? (long)blockIdx.x * 4 + wave : blockIdx.x;
+    const int stride = single ? (int)gridDim.x * 4 : (int)gridDim.x;
+    int item = single ? (int)blockIdx.x * 4 + wave : (int)blockIdx.x;
     if (item < nitems) fetch(item, r0);
     while (item < nitems) {
-        const long n1 = item + stride;
+        const int n1 = item + stride;
         if (n1 < nitems) fetch(n1, r1);
         mma(r0);
         if (n1 >= nitems) break;
-        const long n2 = n1 + stride;
+        const int n2 = n1 + stride;
         if (n2 < nitems) fetch(n2, r0);
         mma(r1);
         item = n2;
+    }
+    bsum += __shfl_xor(bsum, 32);
+    if constexpr (BLKRED) {
+        __shared__ float red[2][9 * 1024 + 32];
+        auto put = [&](float* dst) __attribute__((always_inline)) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(tap * 32 + acc_row(r, hg)) * 32 + c] = acc[tap][r];
+            if (hg == 0) dst[9 * 1024 + c] = bsum;
+        };
+        auto add = [&](const float* src) __attribute__((always_inline)) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tap][r] += src[(tap * 32 + acc_row(r, hg)) * 32 + c];
+            bsum += src[9 * 1024 + c];
+        };
+        if (wave >= 2) put(red[wave - 2]);
+        __syncthreads();
+        if (wave < 2) add(red[wave]);                                  // w0 += w2, w1 += w3
+        __syncthreads();
+        if (wave == 1) put(red[0]);
+        __syncthreads();
+        if (wave != 0) return;
+        add(red[0]);
+        put(part + (long)blockIdx.x * GWG_PART);
+        return;
     }
     float* out = part + ((long)blockIdx.x * 4 + wave) * GWG_PART;      // pair index = cob * ncib + cib = wave; single: chunk index
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[(tap * 32 + acc_row(r, hg)) * 32 + c] = acc[tap][r];
-    bsum += __shfl_xor(bsum, 32);
     if (hg == 0) out[9 * 1024 + c] = bsum;                            // bias partial of channel co (read from the pairs with cib == 0)
 }
 
-// one wave per output element group: 64 lanes sum the chunk partials of one (tap, co, ci) in a fixed order
-// Fixed-order second stage.  A block owns 64 consecutive elements; thread (e = tid & 63, g = tid >> 6) sums the chunks g, g+4, ... of
+// Fixed-order second stage.  A block owns 64 consecutive elements; thread (e = tid & 63, g = tid >> 6) sums the chunks g, g + 16, ... of
 // its element in fp64 -- the 64 lanes of a wave read 64 consecutive floats of one partial tile (ci is the fastest index of both the
-// element order and the tile), where the wave-per-element form touched 64 different cache lines per load -- and the four group sums
-// are combined in a fixed order through LDS.
-__global__ __launch_bounds__(256) void gwgrad_mfma_reduce_kernel(const float* __restrict__ part, int nchunks, int npairs, int ncib, int Ci, int Co,
-                                                                 float* __restrict__ gw, float* __restrict__ gb) {
-    __shared__ double red[4][64];
+// element order and the tile) -- eight loads in flight per thread; the sixteen group sums are combined in a fixed order through LDS.
+// (Four groups with four loads in flight: 16 dependent rounds over 256 partials, 9 us; this form: two.)
+#define GWR_G 16
+__global__ __launch_bounds__(64 * GWR_G) void gwgrad_mfma_reduce_kernel(const float* __restrict__ part, int nchunks, int npairs, int ncib, int Ci, int Co,
+                                                                       float* __restrict__ gw, float* __restrict__ gb) {
+    __shared__ double red[GWR_G][64];
     const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long e = (long)blockIdx.x * 64 + el;
     const long nw = 9L * Co * Ci;
@@ -762,20 +828,26 @@ __global__ __launch_bounds__(256) void gwgrad_mfma_reduce_kernel(const float* __
     }
     const int pair = (co >> 5) * ncib + (e < nw ? (ci >> 5) : 0);
     const long off = e < nw ? ((long)tap * 32 + (co & 31)) * 32 + (ci & 31) : 9 * 1024 + (co & 31);
+    const float* p0 = part + (long)pair * GWG_PART + off;
+    const long cs = (long)npairs * GWG_PART;                   // floats between consecutive chunks of one element
     double s = 0.0;
     if (live) {
         int k = g;
-        for (; k + 12 < nchunks; k += 16) {                 // four independent loads in flight
-            const float a0 = part[((long)k * npairs + pair) * GWG_PART + off], a1 = part[((long)(k + 4) * npairs + pair) * GWG_PART + off];
-            const float a2 = part[((long)(k + 8) * npairs + pair) * GWG_PART + off], a3 = part[((long)(k + 12) * npairs + pair) * GWG_PART + off];
-            s += (double)a0; s += (double)a1; s += (double)a2; s += (double)a3;
+        for (; k + 7 * GWR_G < nchunks; k += 8 * GWR_G) {
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = p0[(long)(k + j * GWR_G) * cs];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)a[j];
         }
-        for (; k < nchunks; k += 4) s += (double)part[((long)k * npairs + pair) * GWG_PART + off];
+        for (; k < nchunks; k += GWR_G) s += (double)p0[(long)k * cs];
     }
     red[g][el] = s;
     __syncthreads();
     if (g || !live) return;
-    s = (red[0][el] + red[1][el]) + (red[2][el] + red[3][el]);
+    s = 0.0;
+#pragma unroll
+    for (int j = 0; j < GWR_G; ++j) s += red[j][el];
     if (e < nw) gw[((long)co * Ci + ci) * 9 + tap] = (float)s;
     else if (gb) gb[co] = (float)s;
 }
@@ -857,7 +929,9 @@ long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co) {
 }
 int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s, int gy_bf16) {
     const bool sq = x.C <= 64 && gy.C <= 64, wide_out = x.C <= 32 && gy.C <= 128, wide_in = x.C <= 128 && gy.C <= 32;
-    if ((sq || wide_out || wide_in) && x.C > 16) {
+    // (the bf16x3 kernel addresses its maps with 32-bit byte offsets)
+    const bool small_maps = (double)x.B * x.H * x.W * x.ld * 4.0 < 4294967296.0 && (double)gy.B * gy.H * gy.W * gy.ld * 4.0 < 4294967296.0;
+    if ((sq || wide_out || wide_in) && x.C > 16 && small_maps) {
         // bf16x3 form: blocks of four waves = four 32x32 channel-tile pairs (2 x 2, or 1 x 4 / 4 x 1 for the 32 <-> 128 layers of the
         // 2layers meta block), partials [block][4 pairs]; <= 32 x 32 channels: one pair, the waves split the items, partials
         // [block * 4 + wave]
@@ -865,13 +939,22 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
         const long nitems = (long)x.B * x.H * nx;
         const int single = (x.C <= 32 && gy.C <= 32) ? 1 : 0;
         const int kcib = sq ? 2 : (wide_out ? 1 : 4);
-        const long cap = single ? 64 : 256;
-        const int nblk = (int)(nitems < cap ? nitems : cap);
+        const long cap = 256;       // (single: measured 64 / 128 / 256 / 336 / 418 blocks on the MSG_CHN step: 1.213 / 1.207 / 1.201 / 1.208 / 1.209 ms)
+        const long want = single ? (nitems + 3) / 4 : nitems;
+        const int nblk = (int)(want < cap ? want : cap);
+        const long n = 9L * x.C * gy.C + gy.C;
+        if (single) {
+            // one partial per BLOCK (summed across its waves in LDS)
+            if (gy_bf16) hipLaunchKernelGGL((gwgrad_x3_kernel<true, true>), dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
+            else hipLaunchKernelGGL((gwgrad_x3_kernel<false, true>), dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
+            hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk, 1, 1, x.C, gy.C, gw, gb);
+            PTTA_CHECK_LAUNCH();
+            return 0;
+        }
         if (gy_bf16) hipLaunchKernelGGL(gwgrad_x3_kernel<true>, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
         else hipLaunchKernelGGL(gwgrad_x3_kernel<false>, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
-        const long n = 9L * x.C * gy.C + gy.C;
-        if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb);
-        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nblk, 4, kcib, x.C, gy.C, gw, gb);
+        if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb);
+        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk, 4, kcib, x.C, gy.C, gw, gb);
         PTTA_CHECK_LAUNCH();
         return 0;
     }
@@ -880,7 +963,7 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
     const int ncib = (x.C + 31) / 32, ncob = (gy.C + 31) / 32, npairs = ncib * ncob;
     hipLaunchKernelGGL(gwgrad_mfma_kernel, dim3(nchunks, npairs), dim3(64), 0, s, x, gy, nchunks, ncib, part);
     const long n = 9L * x.C * gy.C + gy.C;
-    hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, part, nchunks, npairs, ncib, x.C, gy.C, gw, gb);
+    hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nchunks, npairs, ncib, x.C, gy.C, gw, gb);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -118,6 +118,9 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
     const bool six = SIX && b < p.six_B;                 // block-uniform
     const bool x1 = b >= p.x1_from_B;                    // block-uniform: images of the single-MFMA class (mixed mode: proxy frames, data gradients)
 
+    // (weight planes: one base pointer + a per-lane byte offset to the lane's plane -- see issue_loads)
+    const char* const wbase_p = (const char*)p.whi;
+    const long wd_lo = (const char*)p.wlo - wbase_p, wd_l2 = SIX ? (const char*)p.wl2 - wbase_p : wd_lo;
     float4 v0[NIT], v1[NIT];
     unsigned vok = 0;                                    // bit `it`: item it of the sub-chunk in flight is inside the image and the channel range
     uint4 wr[NW];
@@ -143,11 +146,19 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
             vok |= ok ? (1u << it) : 0u;
         }
         const size_t wbase = ((size_t)nf * p.nchunks + c) * (KK * 2 * 64) + kk * 64;
+        // The three weight planes are three allocations and a lane's plane index varies within one j.  Written as
+        // (hl == 0 ? p.whi : hl == 1 ? p.wlo : p.wl2)[...] hipcc selects the ADDRESS of the kernel argument and loads the pointer from
+        // memory -- a dependent load whose s_waitcnt vmcnt(0) also waited for the six activation loads issued just above: every wave
+        // stalled for a full memory round trip per sub-chunk, twice, and the prefetch never overlapped the matrix phase (round 5, .s).
+        // The plane is therefore chosen by a byte OFFSET from the hi plane's pointer (wd_lo, wd_l2: scalar differences formed once): two
+        // v_cndmask on registers, the load unconditional from a clamped index.
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            const int idx = tid + 256 * j;                // [hl][tap][lane]
+            const int idx = min(tid + 256 * j, NWF - 1);  // [hl][tap][lane]  (items beyond NWF are not written to LDS)
             const int hl = idx / (KK * 64), r = idx - hl * (KK * 64);
-            wr[j] = idx < NWF ? (hl == 0 ? p.whi : (hl == 1 ? p.wlo : p.wl2))[wbase + (r >> 6) * 128 + (r & 63)] : make_uint4(0, 0, 0, 0);
+            const uint4* wp = (const uint4*)(wbase_p + (hl == 0 ? 0L : (hl == 1 ? wd_lo : wd_l2)));
+            const uint4 t = wp[wbase + (r >> 6) * 128 + (r & 63)];
+            wr[j].x = t.x; wr[j].y = t.y; wr[j].z = t.z; wr[j].w = t.w;       // (member-wise: `wr[j] = wp[...]` is a memcpy into the array, which then lives in scratch)
         }
     };
     f32x16 acc[2];

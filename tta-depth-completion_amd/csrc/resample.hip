@@ -57,25 +57,21 @@ int ptta_launch_prep(const float* sparse, float max_input_depth, float* dclamp, 
 }
 
 __global__ void up2_1ch_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int Hin, int Win) {
+    // one block row = one output row (grid: x blocks, rows, images): the row's taps and both source-row pointers are scalar, a lane's
+    // offsets 32-bit.  (The flat 64-bit index form spent ~120 quarter-rate integer multiplies per thread on div / mod and addresses: this
+    // launch is two of the latency-bound steps of the real chain.)
     const int Ho = 2 * Hin, Wo = 2 * Win;
     const float sy = up_scale(Hin, Ho), sx = up_scale(Win, Wo);
-    const long total = (long)B * Ho * Wo;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % Wo);
-        long t_ = idx / Wo;
-        const int y = (int)(t_ % Ho);
-        const int b = (int)(t_ / Ho);
-        const Lerp ly = lerp_coef(y, Hin, sy), lx = lerp_coef(x, Win, sx);
-        const float* p = in + (size_t)b * Hin * Win;
-        out[idx] = ly.l0 * (lx.l0 * p[(size_t)ly.i0 * Win + lx.i0] + lx.l1 * p[(size_t)ly.i0 * Win + lx.i1]) +
-                   ly.l1 * (lx.l0 * p[(size_t)ly.i1 * Win + lx.i0] + lx.l1 * p[(size_t)ly.i1 * Win + lx.i1]);
-    }
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= Wo) return;
+    const Lerp ly = lerp_coef(y, Hin, sy), lx = lerp_coef(x, Win, sx);
+    const float* r0 = in + ((size_t)b * Hin + ly.i0) * Win;
+    const float* r1 = in + ((size_t)b * Hin + ly.i1) * Win;
+    out[((size_t)b * Ho + y) * Wo + x] = ly.l0 * (lx.l0 * r0[lx.i0] + lx.l1 * r0[lx.i1]) + ly.l1 * (lx.l0 * r1[lx.i0] + lx.l1 * r1[lx.i1]);
 }
 
 int ptta_launch_up2_1ch(const float* in, float* out, int B, int Hin, int Win, hipStream_t s) {
-    const long total = (long)B * Hin * Win * 4;
-    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(up2_1ch_kernel, dim3(blocks), dim3(256), 0, s, in, out, B, Hin, Win);
+    hipLaunchKernelGGL(up2_1ch_kernel, dim3((2 * Win + 255) / 256, 2 * Hin, B), dim3(256), 0, s, in, out, B, Hin, Win);
     PTTA_CHECK_LAUNCH();
     return 0;
 }
@@ -123,39 +119,35 @@ __device__ __forceinline__ void up2T_window(int i, int in_size, float scale, int
 }
 
 __global__ void up2T_1ch_kernel(const float* __restrict__ gout, float* __restrict__ gin, int B, int Hin, int Win) {
+    // one block row = one source row (as up2_1ch_kernel): the row window and its weights are scalar
     const int Wo = 2 * Win, Ho = 2 * Hin;
     const float sy = up_scale(Hin, Ho), sx = up_scale(Win, Wo);
-    const long total = (long)B * Hin * Win;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % Win);
-        long t_ = idx / Win;
-        const int y = (int)(t_ % Hin);
-        const int b = (int)(t_ / Hin);
-        int dy0, dx0; float wy[5], wx[5];
-        up2T_window(y, Hin, sy, dy0, wy);
-        up2T_window(x, Win, sx, dx0, wx);
-        const float* g = gout + (size_t)b * Ho * Wo + (size_t)dy0 * Wo + dx0;
-        float v[5][5];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= Win) return;
+    int dy0, dx0; float wy[5], wx[5];
+    up2T_window(y, Hin, sy, dy0, wy);
+    up2T_window(x, Win, sx, dx0, wx);
+    const float* g = gout + ((size_t)b * Ho + dy0) * Wo;
+    float v[5][5];
 #pragma unroll
-        for (int ky = 0; ky < 5; ++ky)
+    for (int ky = 0; ky < 5; ++ky) {
+        const float* gr = g + (size_t)min(ky, Ho - 1 - dy0) * Wo;
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) v[ky][kx] = g[(size_t)min(ky, Ho - 1 - dy0) * Wo + min(kx, Wo - 1 - dx0)];
-        float acc = 0.f;
-#pragma unroll
-        for (int ky = 0; ky < 5; ++ky) {
-            float row = 0.f;
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) row += wx[kx] * v[ky][kx];
-            acc += wy[ky] * row;
-        }
-        gin[idx] = acc;
+        for (int kx = 0; kx < 5; ++kx) v[ky][kx] = gr[dx0 + min(kx, Wo - 1 - dx0)];
     }
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+        float row = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) row += wx[kx] * v[ky][kx];
+        acc += wy[ky] * row;
+    }
+    gin[((size_t)b * Hin + y) * Win + x] = acc;
 }
 
 int ptta_launch_up2T_1ch(const float* gout, float* gin, int B, int Hin, int Win, hipStream_t s) {
-    const long total = (long)B * Hin * Win;
-    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(up2T_1ch_kernel, dim3(blocks), dim3(256), 0, s, gout, gin, B, Hin, Win);
+    hipLaunchKernelGGL(up2T_1ch_kernel, dim3((Win + 255) / 256, Hin, B), dim3(256), 0, s, gout, gin, B, Hin, Win);
     PTTA_CHECK_LAUNCH();
     return 0;
 }
@@ -164,54 +156,50 @@ int ptta_launch_up2T_1ch(const float* gout, float* gin, int B, int Hin, int Win,
 template <typename T>
 __global__ void up2T_32_kernel(const T* __restrict__ gout, const T* __restrict__ add, T* __restrict__ gin,
                                int B, int Hin, int Win) {
+    // one block row = one source row (as up2T_1ch_kernel): row window, row weights and row pointers are scalar, a lane's offsets 32-bit
     const int Wo = 2 * Win, Ho = 2 * Hin;
     const float sy = up_scale(Hin, Ho), sx = up_scale(Win, Wo);
-    const long total = (long)B * Hin * Win * 8;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int cq = (int)(idx & 7);
-        long t_ = idx >> 3;
-        const int x = (int)(t_ % Win); t_ /= Win;
-        const int y = (int)(t_ % Hin);
-        const int b = (int)(t_ / Hin);
-        int dy0, dx0; float wy[5], wx[5];
-        up2T_window(y, Hin, sy, dy0, wy);
-        up2T_window(x, Win, sx, dx0, wx);
-        const T* g = gout + ((size_t)b * Ho * Wo + (size_t)dy0 * Wo + dx0) * 32 + 4 * cq;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        // row by row: the five taps of a row are in flight together (one 16-B / 8-B load per tap: the channel quad is aligned)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int cq = t & 7, x = t >> 3;
+    if (x >= Win) return;
+    int dy0, dx0; float wy[5], wx[5];
+    up2T_window(y, Hin, sy, dy0, wy);
+    up2T_window(x, Win, sx, dx0, wx);
+    const T* g = gout + ((size_t)b * Ho + dy0) * Wo * 32;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // row by row: the five taps of a row are in flight together (one 16-B / 8-B load per tap: the channel quad is aligned)
 #pragma unroll
-        for (int ky = 0; ky < 5; ++ky) {
-            float4 v[5];
+    for (int ky = 0; ky < 5; ++ky) {
+        const T* gr = g + (size_t)min(ky, Ho - 1 - dy0) * Wo * 32;
+        float4 v[5];
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const T* q = g + ((size_t)min(ky, Ho - 1 - dy0) * Wo + min(kx, Wo - 1 - dx0)) * 32;
-                if constexpr (sizeof(T) == 4) v[kx] = *(const float4*)q;
-                else v[kx] = bf4_to_f4(*(const uint2*)q);
-            }
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const float wgt = wy[ky] * wx[kx];
-                acc[0] += wgt * v[kx].x; acc[1] += wgt * v[kx].y; acc[2] += wgt * v[kx].z; acc[3] += wgt * v[kx].w;
-            }
+        for (int kx = 0; kx < 5; ++kx) {
+            const T* q = gr + (unsigned)((dx0 + min(kx, Wo - 1 - dx0)) * 32 + 4 * cq);
+            if constexpr (sizeof(T) == 4) v[kx] = *(const float4*)q;
+            else v[kx] = bf4_to_f4(*(const uint2*)q);
         }
-        const size_t o = (((size_t)b * Hin + y) * Win + x) * 32 + 4 * cq;
-        if constexpr (sizeof(T) == 4) {
-            float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            if (add) { const float4 a = *(const float4*)(add + o); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-            *(float4*)(gin + o) = v;
-        } else {
-            float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            if (add) { const float4 a = bf4_to_f4(*(const uint2*)(add + o)); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-            *(uint2*)(gin + o) = f4_to_bf4(v);
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+            const float wgt = wy[ky] * wx[kx];
+            acc[0] += wgt * v[kx].x; acc[1] += wgt * v[kx].y; acc[2] += wgt * v[kx].z; acc[3] += wgt * v[kx].w;
         }
+    }
+    const size_t o = (((size_t)b * Hin + y) * Win + x) * 32 + 4 * cq;
+    if constexpr (sizeof(T) == 4) {
+        float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (add) { const float4 a = *(const float4*)(add + o); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        *(float4*)(gin + o) = v;
+    } else {
+        float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        if (add) { const float4 a = bf4_to_f4(*(const uint2*)(add + o)); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+        *(uint2*)(gin + o) = f4_to_bf4(v);
     }
 }
 
 int ptta_launch_up2T_32(const void* gout, const void* add, void* gin, int B, int Hin, int Win, int bf16, hipStream_t s) {
-    const long total = (long)B * Hin * Win * 8;
-    int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-    if (bf16) hipLaunchKernelGGL((up2T_32_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)gout, (const bf16_t*)add, (bf16_t*)gin, B, Hin, Win);
-    else hipLaunchKernelGGL((up2T_32_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)gout, (const float*)add, (float*)gin, B, Hin, Win);
+    const dim3 grid((Win * 8 + 255) / 256, Hin, B);
+    if (bf16) hipLaunchKernelGGL((up2T_32_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)gout, (const bf16_t*)add, (bf16_t*)gin, B, Hin, Win);
+    else hipLaunchKernelGGL((up2T_32_kernel<float>), grid, dim3(256), 0, s, (const float*)gout, (const float*)add, (float*)gin, B, Hin, Win);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

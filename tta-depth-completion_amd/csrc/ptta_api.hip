@@ -185,6 +185,7 @@ struct ptta_ctx {
     const float *fb_image = nullptr, *fb_sparse = nullptr;   // frame of the last ptta_step_pipelined call that fell back to ptta_step (ptta_forward_eval_last)
     hipStream_t pre_stream = nullptr;
     hipEvent_t ev_prefix[2] = {nullptr, nullptr}, ev_rest[2] = {nullptr, nullptr}, ev_entry = nullptr;
+    hipStream_t pipe_stream = nullptr; bool pipe_stream_set = false;      // the stream of the last ptta_step_pipelined call
     hipGraph_t pgraph[2] = {nullptr, nullptr}, rgraph[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     hipGraphExec_t pexec[2] = {nullptr, nullptr}, rexec[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     // intra-step concurrency: the MLP heads run on a second stream beside decoder 3 (forward) and beside
@@ -1406,26 +1407,24 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     { E e; e.raw = c->dw2; e.mask = c->w2; e.mask_nb = B2; e.sum = c->dfeat_tot; e.add1 = c->g_feat; e.add1_nb = Nn;
       CV("depth_decoder3.dec2.1", true, CONV_S2, c->dt3, Nn, Nn, H2, W2, false, e); }
     // The three transposed bilinear upsamplings of the backward (d z2 += up2^T(d feat_tot), d z3 = d s1_2 + up2^T(d e3_1), d z4 = d s0_2 + up2^T(d e3_0))
-    // do not lie on the chain d feat_tot -> encoder 3 -> decoder 2: each runs on the second stream as soon as its source exists, and its
+    // do not lie on the chain d feat_tot -> encoder 3 -> decoder 2: they run on the second stream, and each
     // result enters the chain as the addend of a convolution epilogue (out_sum = masked result + addend; fp32: the same two operands of the
     // same addition as `add + up2^T(...)` in the upsampling kernel).  One join, in front of decoder 2's prediction head.
     hipStream_t sd = join_aux ? c->aux(s) : nullptr;
     if (!sd) sd = s;
-    auto side = [&](int k, const void* src, void* dst, int Hh, int Wh) -> int {
-        if (sd != s) { HIPCHK(hipEventRecord(c->ev_side[k], s)); HIPCHK(hipStreamWaitEvent(sd, c->ev_side[k], 0)); }
-        REST_(sd, ptta_launch_up2T_32(src, nullptr, dst, Nn, Hh, Wh, nbf, sd));
-        return 0;
-    };
     // ---- encoder 3 ----
-    RUN(side(0, c->dfeat_tot, c->dz2_up, H8, W8));
     CV("depth_encoder3.enc2.3", true, CONV_S1, c->dfeat_tot, Nn, Nn, H4, W4, false, em(c->de3_2a, c->e3_2a, B2));
     { E e; e.sum = c->de3_1; e.mask = c->e3_1; e.mask_nb = B2; e.add1 = c->ds1_3; e.add1_nb = Nn;
       CV("depth_encoder3.enc2.1", true, CONV_T2, c->de3_2a, Nn, Nn, H4, W4, false, e); }
-    RUN(side(1, c->de3_1, c->up3_t, H4, W4));
     CV("depth_encoder3.enc1.3", true, CONV_S1, c->de3_1, Nn, Nn, H2, W2, false, em(c->de3_1a, c->e3_1a, B2));
     { E e; e.sum = c->de3_0; e.mask = c->e3_0; e.mask_nb = B2; e.add1 = c->ds0_3; e.add1_nb = Nn;
       CV("depth_encoder3.enc1.1", true, CONV_T2, c->de3_1a, Nn, Nn, H2, W2, false, e); }
-    RUN(side(2, c->de3_0, c->up4_t, H2, W2));
+    // all three sources exist: ONE fork (every event on the main stream is a packet in front of its next kernel), the three launches run
+    // beside the next three of the chain
+    if (sd != s) { HIPCHK(hipEventRecord(c->ev_side[0], s)); HIPCHK(hipStreamWaitEvent(sd, c->ev_side[0], 0)); }
+    REST_(sd, ptta_launch_up2T_32(c->de3_0, nullptr, c->up4_t, Nn, H2, W2, nbf, sd));
+    REST_(sd, ptta_launch_up2T_32(c->de3_1, nullptr, c->up3_t, Nn, H4, W4, nbf, sd));
+    REST_(sd, ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, nbf, sd));
     if (sd != s) HIPCHK(hipEventRecord(c->ev_side[3], sd));
     CV("depth_encoder3.init.2", true, CONV_S1, c->de3_0, Nn, Nn, H1, W1, false, em(c->de3_0a, c->e3_0a, B2));
     RUN(dgrad_in_ch1("depth_encoder3.init.0", c->de3_0a, g_net, c->dp11, H1, W1));       // d p11 = conv^T + d output
@@ -2178,7 +2177,10 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     const size_t ibytes = (size_t)c->N * 3 * c->H * c->W * 4, pbytes = (size_t)c->N * c->H * c->W * 4;
     const int p = c->pipe_cur, q = 1 - p;
     const int key = (validity ? 2 : 0) | (loss_image != image ? 1 : 0);
-    HIPCHK(hipEventRecord(c->ev_entry, s));                   // what the caller queued before this call (the next frame's data, too)
+    // (a caller that moves to another stream: the steps queued on the previous one come first -- everything below orders against `s` only)
+    if (c->pipe_stream_set && c->pipe_stream != s) { HIPCHK(hipEventRecord(c->ev_rest[0], c->pipe_stream)); HIPCHK(hipStreamWaitEvent(s, c->ev_rest[0], 0)); }
+    c->pipe_stream = s; c->pipe_stream_set = true;
+    HIPCHK(hipEventRecord(c->ev_entry, s));                   // what the caller queued before this call (the next frame's data, too) -- and every earlier step
     pipe_use(c, p);
     RUN(ensure_fused_heads(c, s));                            // (ptta_head_reload / ptta_head_step invalidate the merged head GEMM only)
     if (!c->proxy_rgb_valid) RUN(ensure_proxy_rgb(c, c->in_image, s));
@@ -2215,8 +2217,7 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     }
     HIPCHK(hipGraphLaunch(c->rexec[key][p], s));
     }
-    HIPCHK(hipEventRecord(c->ev_rest[p], s));
-    P.rest_recorded = true; c->pipe_last = p; P.last_token = frame_token ? frame_token : ~(uint64_t)0;      // (an unnamed frame is still the one ptta_forward_eval_last scores)
+    c->pipe_last = p; P.last_token = frame_token ? frame_token : ~(uint64_t)0;      // (an unnamed frame is still the one ptta_forward_eval_last scores)
     if (c->use_graph) {                                       // (direct launches: nothing to keep alive)
         if (!c->ev_replay) HIPCHK(hipEventCreateWithFlags(&c->ev_replay, hipEventDisableTiming));
         HIPCHK(hipEventRecord(c->ev_replay, s));
@@ -2236,7 +2237,6 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
         ptta_ctx::PreSet& Q = c->pset[q];
         hipStream_t ps = c->pre_stream;
         HIPCHK(hipStreamWaitEvent(ps, c->ev_entry, 0));
-        if (Q.rest_recorded) HIPCHK(hipStreamWaitEvent(ps, c->ev_rest[q], 0));
         if (!c->proxy_rgb_valid) { HIPCHK(hipStreamSynchronize(ps)); RUN(ensure_proxy_rgb(c, c->in_image, s)); HIPCHK(hipStreamSynchronize(s)); }   // once per set
         HIPCHK(d2d_copy(c->in_image, next_image, ibytes, ps));
         HIPCHK(d2d_copy(c->in_sparse, next_sparse, pbytes, ps));

@@ -290,6 +290,7 @@ struct ptta_ctx {
     bf16_t *emb_n = nullptr, *ref_n = nullptr, *h2_n = nullptr;       // mixed mode: the heads' narrow [R][512] tensors (heads_n.hip)
     float *bnb_gscale, *bnb_c1, *bnb_c2;
     float *loss_ws, *loss_info, *g_final, *g_net;
+    float* loss_info_dst = nullptr;      // direct launches: the caller's loss_info_out for the step being enqueued (no 16-byte copy launch behind Adam); else loss_info
     // backward
     void *dv3, *ds0_3, *du3, *ds1_3, *dt3, *dw2, *dfeat_tot, *dz2_up, *de3_2a, *de3_1, *de3_1a, *de3_0, *de3_0a;
     void *up4_t, *up3_t, *dv2, *ds0_2, *dz4, *du2, *ds1_2, *dz3, *dt2, *dz2, *de2_2a, *de2_1, *de2_1a, *de2_0, *de2_0a, *dv1, *dm_total, *g_feat;
@@ -1963,7 +1964,7 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
         REST_(s, ptta_launch_loss_depth_part(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->N, c->H, c->W, c->loss_ws, s));
         HIPCHK(hipStreamWaitEvent(s, c->ev_dpart, 0));
         REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, nullptr, nullptr, c->Rg, 512,
-                                           c->N, c->H, c->W, c->loss_ws, c->g_final, nullptr, s, c->hyper + 5, c->loss_info, 1));
+                                           c->N, c->H, c->W, c->loss_ws, c->g_final, nullptr, s, c->hyper + 5, c->loss_info_dst ? c->loss_info_dst : c->loss_info, 1));
         c->cos_in_gemm = true;
         const int rc_h = heads_backward(c, c->gref_buf, s2);
         c->cos_in_gemm = false;
@@ -1990,10 +1991,10 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
         RUN(ptta_launch_hn_untile(c->ref_n, c->ref, c->Rg, s));
     }
     REST_(s, ptta_launch_loss_forward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
-                                      c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info, s, 1));
+                                      c->hyper + 5, c->N, c->H, c->W, c->loss_ws, c->loss_info_dst ? c->loss_info_dst : c->loss_info, s, 1));
     const bool cig = c->cos_grad_fused && heads_v2_on(c) && c->N <= 16;          // (N <= LOSS_FIN_MAXN: the gradient launch finalises the loss)
     REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
-                                       c->N, c->H, c->W, c->loss_ws, c->g_final, cig ? nullptr : c->gref_buf, s, c->hyper + 5, c->loss_info));
+                                       c->N, c->H, c->W, c->loss_ws, c->g_final, cig ? nullptr : c->gref_buf, s, c->hyper + 5, c->loss_info_dst ? c->loss_info_dst : c->loss_info));
     c->cos_in_gemm = cig;
     const int rc_b = ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_);
     c->cos_in_gemm = false;
@@ -2041,7 +2042,12 @@ int ptta_step(ptta_handle c, const float* image, const float* loss_image, const 
         HIPCHK(hipEventRecord(c->ev_replay, s));
         c->fwd_valid = true;
     } else {
-        RUN(step_body(c, image, loss_image, sparse, validity, s_));
+        c->loss_info_dst = loss_info_out;                  // (written by the loss kernel itself)
+        const int rc = step_body(c, image, loss_image, sparse, validity, s_);
+        c->loss_info_dst = nullptr;
+        if (rc) return rc;
+        if (depth_out) HIPCHK(d2d_copy(depth_out, final_depth(c), pbytes, s));
+        return 0;
     }
     if (depth_out) HIPCHK(d2d_copy(depth_out, final_depth(c), pbytes, s));
     if (loss_info_out) HIPCHK(d2d_copy(loss_info_out, c->loss_info, 16, s));
@@ -2202,9 +2208,9 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     if (key & 1) HIPCHK(d2d_copy(c->in_loss_image, loss_image, ibytes, s));
     if (key & 2) HIPCHK(d2d_copy(c->in_validity, validity, pbytes, s));
     if (!c->use_graph) {
-        c->skip_prefix = true;
+        c->skip_prefix = true; c->loss_info_dst = loss_info_out;
         const int rc = step_body(c, c->in_image, (key & 1) ? c->in_loss_image : c->in_image, c->in_sparse, (key & 2) ? c->in_validity : nullptr, (ptta_stream)s);
-        c->skip_prefix = false;
+        c->skip_prefix = false; c->loss_info_dst = nullptr;
         if (rc) return rc;
     } else {
     if (!c->rexec[key][p]) {
@@ -2224,7 +2230,7 @@ int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_ima
     }
     c->fwd_valid = true;
     if (depth_out) HIPCHK(d2d_copy(depth_out, final_depth(c), pbytes, s));
-    if (loss_info_out) HIPCHK(d2d_copy(loss_info_out, c->loss_info, 16, s));
+    if (loss_info_out && c->use_graph) HIPCHK(d2d_copy(loss_info_out, c->loss_info, 16, s));       // (direct launches: the loss kernel wrote it)
     if (next_token != 0 && next_token == frame_token) {
         // another step on the SAME frame (inner_iter > 1): its prefix is the one just used -- nothing in the step writes those tensors
         HIPCHK(hipEventRecord(c->ev_prefix[p], s));

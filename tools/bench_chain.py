@@ -14,17 +14,17 @@ lib = _lib.load()
 H, W = 352, 1216
 wt = torch.randn(32, 32, 3, 3, device='cuda') * 0.05
 bias = torch.randn(32, device='cuda')
-print('%-28s %8s %8s %8s   (us per launch in a replayed graph of 40 dependent launches)' % ('map', 'plain', 'mask', 'add'))
+print('%-28s %8s %8s %8s %8s   (us per launch in a replayed graph of 40 dependent launches; last column: plain, launched directly)' % ('map', 'plain', 'mask', 'add', 'direct'))
 for name, b, s in (('1/16 x2', 2, 16), ('1/8 x2', 2, 8), ('1/4 x1', 1, 4), ('1/4 x2', 2, 4), ('1/2 x1', 1, 2), ('1/2 x2', 2, 2), ('1/1 x1', 1, 1), ('1/1 x2', 2, 1)):
     h, w = H // s, W // s
     x = torch.randn(b, h, w, 32, device='cuda')
     a, c, aux = torch.empty_like(x), torch.empty_like(x), torch.randn_like(x)
     row = []
-    for flags in (0, 2, 4):
+    for flags in (0, 2, 4, 8):
         us = ctypes.c_float(0)
         rc = lib.ptta_op_conv32_chain(ptr(x), ptr(wt), ptr(bias), ptr(a), ptr(c), ptr(aux), b, h, w, 1, flags, 40, 20, ctypes.byref(us),
                                       ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         assert rc == 0, rc
         row.append(us.value)
     mb = b * h * w * 32 * 4 / 1e6
-    print('%-28s %8.2f %8.2f %8.2f   tensor %.1f MB' % ('%s (%dx%d)' % (name, h, w), row[0], row[1], row[2], mb))
+    print('%-28s %8.2f %8.2f %8.2f %8.2f   tensor %.1f MB' % ('%s (%dx%d)' % (name, h, w), row[0], row[1], row[2], row[3], mb))

@@ -2721,6 +2721,27 @@ int ptta_op_conv32_chain(const float* in, const float* weight, const float* bias
         hipMalloc((void**)&wv.canon, 9216 * 4) != hipSuccess || hipMalloc((void**)&wv.mlo, 9 * 2 * 64 * 8 * 2) != hipSuccess) return -12;
     ptta_pack_conv32(weight, wv, 0, 0, s);
     (void)hipStreamSynchronize(s);
+    if (epi_flags & 8) {                   // the same chain launched directly (no graph): what a dependent launch costs in the default form
+        hipEvent_t d0 = nullptr, d1 = nullptr;
+        if (hipEventCreate(&d0) != hipSuccess || hipEventCreate(&d1) != hipSuccess) return -5;
+        int rcd = 0;
+        for (int k = 0; k < replays + 2 && !rcd; ++k) {
+            if (k == 2) (void)hipEventRecord(d0, s);
+            for (int r = 0; r < reps && !rcd; ++r) {
+                Conv32Args a; a.w = &wv; a.bias = bias; a.B = b; a.Hin = h; a.Win = w; a.mode = CONV_S1; a.relu_in = relu_in; a.x3 = 1;
+                a.in = r == 0 ? in : ((r & 1) ? buf_a : buf_b); a.in_nb = b; a.out_raw = (r & 1) ? buf_b : buf_a;
+                if ((epi_flags & 2) && aux) { a.mask = aux; a.mask_nb = b; }
+                if ((epi_flags & 4) && aux) { a.add1 = aux; a.add1_nb = b; }
+                rcd = ptta_launch_conv32(a, s);
+            }
+        }
+        (void)hipEventRecord(d1, s); (void)hipStreamSynchronize(s);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, d0, d1);
+        *us_per_launch_host = 1e3f * ms / ((float)replays * (float)reps);
+        (void)hipEventDestroy(d0); (void)hipEventDestroy(d1);
+        (void)hipFree(wv.mf32); (void)hipFree(wv.mbf16); (void)hipFree(wv.mlo); (void)hipFree(wv.canon);
+        return rcd;
+    }
     hipStream_t cs = nullptr; hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = 0;
     if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) rc = -5;

@@ -114,29 +114,36 @@ def cpu_baseline(warm=3, steps=10):
 
 def msgchn_2layers_workload(steps=30):
     """MSG_CHN with the `2layers` meta layer (Res_Conv(32,128) + 2 BatchNorm2d, 7 adapted tensors): the recipe of
-    bash/adapt/adapt_msgchn_vkitti.sh:26.  Same 352x1216 synthetic frames as the headline (1layer) configuration."""
+    bash/adapt/adapt_msgchn_vkitti.sh:26.  Same 352x1216 synthetic frames as the headline (1layer) configuration; both precision modes."""
     from proxytta import synth
     from proxytta.engine import Engine
     mode = 'meta_selfsup_seq_2layers_ema'
-    eng = Engine(1, H, W, meta='2layers', **HP)
-    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(mode).items()}
-    eng.load_state_dict(sd)
-    for name in eng.adapted:
-        eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
-    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(i, H, W, 1)] for i in range(4)]
     pipe = os.environ.get('PTTA_PIPELINE', '1') != '0'           # frames as a stream, like the headline loop
-    for i in range(5):
-        eng.step(*frames[i % 4], next_frame=frames[(i + 1) % 4] if pipe else None)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        info, _ = eng.step(*frames[(5 + i) % 4], next_frame=frames[(6 + i) % 4] if pipe else None)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    out = {'workload': 'MSG_CHN 2layers meta (Res_Conv(32,128), 7 adapted tensors), 352x1216, 1 TTA step/frame, batch 1, frame pipelining ' + ('on' if pipe else 'off'),
-           'ms_per_step': 1e3 * dt, 'frames_per_s': 1.0 / dt, 'finite': bool(torch.isfinite(info).all().item())}
-    eng.close()
-    return out
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(i, H, W, 1)] for i in range(4)]
+
+    def run(dtype):
+        eng = Engine(1, H, W, meta='2layers', dtype=dtype, **HP)
+        sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(mode).items()}
+        eng.load_state_dict(sd)
+        for name in eng.adapted:
+            eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+        for i in range(5):
+            eng.step(*frames[i % 4], next_frame=frames[(i + 1) % 4] if pipe else None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            info, _ = eng.step(*frames[(5 + i) % 4], next_frame=frames[(6 + i) % 4] if pipe else None)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        fin = bool(torch.isfinite(info).all().item())
+        eng.close()
+        return dt, fin
+
+    dt, fin = run('fp32')
+    dtm, finm = run('mixed')
+    return {'workload': 'MSG_CHN 2layers meta (Res_Conv(32,128), 7 adapted tensors), 352x1216, 1 TTA step/frame, batch 1, frame pipelining ' + ('on' if pipe else 'off'),
+            'ms_per_step': 1e3 * dt, 'frames_per_s': 1.0 / dt, 'finite': fin,
+            'mixed_mode': {'ms_per_step': 1e3 * dtm, 'frames_per_s': 1.0 / dtm, 'finite': finm}}
 
 
 def msgchn_adapt_loop_workload(frames_n=60):

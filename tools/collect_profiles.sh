@@ -30,6 +30,17 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if re.search(sys.argv[2], r
 n = sum(int(r['Calls']) for r in rows); t = sum(float(r['TotalDurationNs']) for r in rows)
 print('\nroofline class (%s): %d launches, %.2f ms -> %.2f us per launch' % (sys.argv[2], n, t / 1e6, t / 1e3 / max(n, 1)))
 PY
+  # 1b: the same command with every launch on ONE stream (no frame pipelining, no second stream) -- the condition bench.py's `roofline` leg
+  # measures its kernels in; in the three-stream trace above the class's launches overlap other chains and read ~20 % longer
+  PTTA_PIPELINE=0 PTTA_BENCH_OPTIONS=aux_stream=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_one -o x -- python3 $BENCH > /dev/null 2> $O/trace_one_$DT.log
+  { echo "# bench.py --dtype $DT --steps 20 --warmup 10, PTTA_PIPELINE=0, option aux_stream=0: every launch on one stream (rocprofv3 --kernel-trace --stats)"; python3 tools/prof_top.py $O/trace_one 12; } > $O/${R}_${DT}_kernel_stats_one_stream.txt
+  python3 - "$O/trace_one/x_kernel_stats.csv" "$CLASS" >> $O/${R}_${DT}_kernel_stats_one_stream.txt <<'PY'
+import csv, re, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if re.search(sys.argv[2], r['Name'])]
+n = sum(int(r['Calls']) for r in rows); t = sum(float(r['TotalDurationNs']) for r in rows)
+print('\nroofline class (%s): %d launches, %.2f ms -> %.2f us per launch' % (sys.argv[2], n, t / 1e6, t / 1e3 / max(n, 1)))
+PY
+  rm -rf $O/trace_one
   # 2
   python3 tools/trace_sequence.py $O/trace_graph/x_kernel_trace.csv 40 > $O/${R}_${DT}_step_sequence_graph.txt
   python3 tools/trace_step.py $O/trace_graph/x_kernel_trace.csv 140 > $O/${R}_${DT}_step_trace_summary.txt

@@ -329,14 +329,20 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
             if (pix < X3_PH * X3_PW) px_stage<RELU>(v[it], lds + pix * STR + 16 * (idx & 3), Geo<T>::LO);
         }
         if (UP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the window has landed (and this tile's halo loads before it)
+        // narrow masked epilogue: both rows' mask words are requested BEFORE the next tile's prefetch (ptta_common.h epi_mask_words)
+        constexpr bool MWPRE = MASK && sizeof(T) == 2;
+        uint32_t mwp0[4], mwp1[4];         // (two arrays and a select below: the row loop is not unrolled, an array indexed by the row lives in scratch)
+        if constexpr (MWPRE) {
+            epi_mask_words<T>(p.epi, b, y0 + 2 * wave, H, W, i, x0, h, mwp0);
+            epi_mask_words<T>(p.epi, b, y0 + 2 * wave + 1, H, W, i, x0, h, mwp1);
+        }
         if (PREFETCH && tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x);
         lds_barrier();          // LDS-only: the next tile's global loads (issued above) stay in flight during the MFMAs
         // ---- two output rows per wave ------------------------------------------------------------
-#pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
+        auto do_row = [&](const int rr) __attribute__((always_inline)) {
             const int row = 2 * wave + rr;
             const int y = y0 + row;
-            if (y >= H) break;                                      // wave-uniform
+            if (y >= H) return;                                     // wave-uniform
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -350,7 +356,19 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
             }
             // (conv + bias) + bilinear, in the reference's order; the skip comes from the LDS window, added after the quad transpose
             if (UP) epi_tile<T, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0, &biasv);
-            else epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv);
+            else {
+                uint32_t mws[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mws[g] = MWPRE ? (rr ? mwp1[g] : mwp0[g]) : 0u;
+                epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv, MWPRE ? mws : nullptr);
+            }
+        };
+        // (narrow masked variants: the two rows as straight-line code -- inside a loop the compiler's wait-count bookkeeping merges with the
+        // back edge and waits vmcnt(0) for the preloaded mask words, i.e. for the prefetch issued behind them)
+        if constexpr (MWPRE) { do_row(0); do_row(1); }
+        else {
+#pragma unroll 1
+            for (int rr = 0; rr < 2; ++rr) do_row(rr);
         }
         lds_barrier();          // LDS reuse only: do not wait for this tile's stores (nor the prefetch) to drain
     }
@@ -591,6 +609,12 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
             for (int g = wave; g < NG; g += 4) halo_group(g, mkw[0]);
         }
         lds_barrier();                                                  // halo complete; the plane window is dead
+        constexpr bool MWPRE = EMASK && !UP && sizeof(T) == 2;           // (as conv32_s1_x3_kernel: the epilogue's mask words in front of the prefetch)
+        uint32_t mwp[2][4];
+        if constexpr (MWPRE) {
+            epi_mask_words<T>(p.epi, b, y0 + 2 * wave, H, W, i, x0, h, mwp[0]);
+            epi_mask_words<T>(p.epi, b, y0 + 2 * wave + 1, H, W, i, x0, h, mwp[1]);
+        }
         if (tile + gridDim.x < ntiles) { load_planes(tile + gridDim.x); load_masks(tile + gridDim.x); }
         int uy0 = 0, ux0 = 0;
         if (UP) {
@@ -619,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
             if (UP && rr == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); }      // every wave's pieces of the window have landed
             if (y < H) {
                 if (UP) epi_tile<T, false, EMASK, false, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0, &biasv);
-                else epi_tile<T, false, EMASK, EADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv);
+                else epi_tile<T, false, EMASK, EADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv, MWPRE ? mwp[rr] : nullptr);
             }
         }
         lds_barrier();          // LDS reuse by the next tile (plane window over the bilinear window, halo)

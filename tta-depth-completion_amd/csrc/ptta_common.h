@@ -159,10 +159,21 @@ __device__ __forceinline__ void quad_transpose(f32x16& t, int lane) {
 // element as the accumulator-layout form, (conv + bias) + (ly.l0 (lx.l0 v00 + lx.l1 v01) + ly.l1 (lx.l0 v10 + lx.l1 v11)).
 template <typename T>
 __device__ __forceinline__ float epi_bias(const Epi<T>& e, int ch) { return (e.bias ? e.bias : kZeroBias)[ch]; }
+// The four mask words epi_tile's narrow branch reads for output row y (stride-1 geometry: xstep 1, xoff 0), loaded AHEAD by the caller and
+// passed back as `mw_pre`: vmcnt is in order, so a load issued in the epilogue -- behind the next tile's halo prefetch -- cannot be waited
+// for without waiting for that prefetch too; issued in front of it, the wait leaves the prefetch in flight (round 5, .s: every row's epilogue
+// of the masked kernels stalled until the next tile had landed).
+template <typename T>
+__device__ __forceinline__ void epi_mask_words(const Epi<T>& e, int b, int y, int H, int W, int ch, int x0, int h, uint32_t (&mw)[4]) {
+    const uint32_t* mb = e.mask_bits + ((size_t)(b % e.mask_nb) * H + min(y, H - 1)) * W;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mw[g] = mb[min(x0 + (ch & 3) + 8 * g + 4 * h, W - 1)];
+}
 template <typename T, bool UP, bool MASK, bool ADD, bool UPL = false, int UPLW = 18>
 __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, int W, int ch, const f32x16& acc,
                                          int x0, int h, int Wt, int xstep, int xoff, float sy, float sx,
-                                         const void* upw_ = nullptr, int uy0 = 0, int ux0 = 0, const float* bias_lane = nullptr) {
+                                         const void* upw_ = nullptr, int uy0 = 0, int ux0 = 0, const float* bias_lane = nullptr,
+                                         const uint32_t* mw_pre = nullptr) {
     const float* upw = (const float*)upw_;                // fp32 storage: the bilinear window holds floats; narrow storage casts upw_ to bf16 below
     const float* bp = e.bias ? e.bias : kZeroBias;       // pointer select, not a branch around the load
     // bias_lane: the lane's bias, loaded ONCE by the kernel (epi_bias).  Loaded here -- once per output row -- it cannot be hoisted by hipcc
@@ -322,9 +333,14 @@ __device__ __forceinline__ void epi_tile(const Epi<T>& e, int b, int y, int H, i
         uint32_t mw[4];
         uint2 t1[4], t2[4];
         if (MASK) {
-            const uint32_t* mb = e.mask_bits + (size_t)(b % e.mask_nb) * H * W;
+            if (mw_pre) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mw[g] = mb[xq[g] >> 5];
+                for (int g = 0; g < 4; ++g) mw[g] = mw_pre[g];
+            } else {
+                const uint32_t* mb = e.mask_bits + (size_t)(b % e.mask_nb) * H * W;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mw[g] = mb[xq[g] >> 5];
+            }
         }
         const bool two = ADD && e.add2 != nullptr;
         if (ADD) {

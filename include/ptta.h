@@ -375,7 +375,8 @@ int ptta_op_conv32(const float* in_nhwc, const float* weight, const float* bias,
                    ptta_stream s);
 /* Diagnostic (tools/bench_chain.py): `reps` dependent launches of one stride-1 32->32 convolution (fp32 NHWC, default arithmetic) captured
  * into one hipGraph and replayed `replays` times: microseconds per launch INSIDE a replayed graph.  epi_flags: 2 = ReLU mask from `aux`,
- * 4 = skip addition of `aux`.  Synchronises. */
+ * 4 = skip addition of `aux`, 8 = the same chain launched directly (no graph), 16 = the layer loop (ONE launch per `reps` layers with a
+ * device-wide barrier between layers; plain epilogue only; -62 when a bounded barrier spin ran out).  Synchronises. */
 int ptta_op_conv32_chain(const float* in_nhwc, const float* weight, const float* bias, float* buf_a, float* buf_b, const float* aux,
                          int b, int h, int w, int relu_in, int epi_flags, int reps, int replays, float* us_per_launch_host, ptta_stream s);
 /* ABI version of this header: ptta_version() of a loaded library must equal the PTTA_ABI_VERSION the binding was written against

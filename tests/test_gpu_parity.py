@@ -91,6 +91,35 @@ def test_op_conv32_bf16x3(shape, relu):
             assert rel_mae(got, ref) < 2e-5, mode
 
 
+@pytest.mark.parametrize('shape', [(2, 22, 76), (1, 19, 70), (2, 88, 304)])
+@pytest.mark.parametrize('relu', [False, True])
+def test_layer_loop_trial_equals_the_chain_of_launches(shape, relu):
+    """The layer-loop trial (conv32_s1_small_loop_kernel: dependent stride-1 layers in ONE launch, a device-wide barrier between layers)
+    against the same chain as separate launches: bit for bit, incl. a ragged map and one of more tiles than blocks; the first layer of
+    the chain against torch.  A barrier spin that runs out reports -62 instead of hanging."""
+    import ctypes
+    from proxytta import _lib
+    from proxytta._lib import ptr
+    lib = _lib.load()
+    b, h, w = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(b, h, w, 32, generator=g).cuda()
+    wt = (torch.randn(32, 32, 3, 3, generator=g) * 0.05).cuda()
+    bias = torch.randn(32, generator=g).cuda()
+    us = ctypes.c_float(0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for reps in (1, 2, 7):
+        a1, c1 = torch.zeros_like(x), torch.zeros_like(x)
+        assert lib.ptta_op_conv32_chain(ptr(x), ptr(wt), ptr(bias), ptr(a1), ptr(c1), None, b, h, w, int(relu), 8, reps, 1, ctypes.byref(us), st) == 0
+        a2, c2 = torch.zeros_like(x), torch.zeros_like(x)
+        assert lib.ptta_op_conv32_chain(ptr(x), ptr(wt), ptr(bias), ptr(a2), ptr(c2), None, b, h, w, int(relu), 16, reps, 1, ctypes.byref(us), st) == 0
+        assert torch.equal(a1, a2) and torch.equal(c1, c2), reps
+        assert float(a1.abs().max()) > 0 and bool(torch.isfinite(a1).all())
+        if reps == 1:
+            ref = _torch_conv(x.cpu(), wt.cpu(), bias.cpu(), 0, relu)
+            assert rel_mae(a1.cpu(), ref) < 2e-5
+
+
 @pytest.mark.parametrize('shape', [(1, 8, 64), (2, 20, 48), (1, 88, 1216)])
 def test_op_conv32_narrow(shape):
     """The NARROW instantiations of the tuned kernels (bf16 maps, one bf16 MFMA per product: the mixed mode's proxy-pass and gradient

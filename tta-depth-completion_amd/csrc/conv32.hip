@@ -761,6 +761,148 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
     }
 }
 
+// ---- the layer loop, measured (tools/bench_chain.py, flag 16; the review's "one bounded trial") --------------------------------------
+// `reps` DEPENDENT stride-1 layers on a small map in ONE launch: every block keeps its tiles, layer r reads what layer r - 1 wrote
+// (ping-pong buf_a / buf_b), and between two layers the whole grid meets at a device-wide barrier: __syncthreads (every wave's stores
+// acknowledged), thread 0 releases at agent scope (buffer_wbl2 sc1: the XCD's dirty L2 lines go to memory -- the 8 L2s are not coherent
+// with each other), adds 1 to a counter in memory, polls it with agent-scope loads until all blocks arrived, acquires (buffer_inv sc1).
+// The next layer's weight fragments are requested BEFORE the barrier (they fly during the spin), which a launch boundary cannot do.
+// Every spin is bounded: after 2^16 polls (~0.1 s) the block raises *err and goes on without the other blocks (wrong values, no hang).
+// The grid must be co-resident (<= 256 blocks of 256 threads, one per CU: the launcher clamps), so this form cannot share the chip with
+// a second such launch.  Same products in the same order as conv32_s1_small_kernel: bit-identical outputs (tests/test_gpu_parity.py).
+// variant 0: acquire loads in the spin (hipcc: global_load sc1 + buffer_inv sc1 PER POLL -- every poll of every waiting block invalidates its
+// XCD's L2 under the blocks that still compute); variant 1: one release fence, a relaxed add, relaxed polls (global_load sc1 alone), one
+// acquire fence behind the loop.
+__device__ __forceinline__ void conv32_grid_barrier(unsigned* ctr, unsigned target, int* err, int variant) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (variant == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++spins > (1 << 16)) { *err = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } else {
+            if (variant == 1) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // (variant 2: no fences -- timing ablation only, values undefined)
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++spins > (1 << 16)) { *err = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (variant == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+}
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256, 1) void conv32_s1_small_loop_kernel(Conv32P<T> p, T* buf_a, T* buf_b, int reps, unsigned* ctr, unsigned base, int* err, int variant) {
+    constexpr int STR = Geo<T>::STR;
+    constexpr bool F32 = sizeof(T) == 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X3S_PH * X3_PW * STR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const float biasv = epi_bias(p.epi, i);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.Hout, W = p.Wout;
+    const int ntx = (W + 31) >> 5, nty = (H + X3S_TH - 1) / X3S_TH;
+    const int ntiles = p.B * ntx * nty;
+    constexpr int NPIX = X3S_PH * X3_PW;
+    constexpr int NIT = (((NPIX + 7) / 8) * 32 + 255) / 256;
+    uint4 wh[9][2], wl[F32 ? 9 : 1][2];
+    auto load_w = [&]() {
+        const uint4* ph = (const uint4*)p.wpack;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
+        if constexpr (F32) {
+            const uint4* pl = (const uint4*)p.wpack2;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) wl[t][k] = pl[(t * 2 + k) * 64 + lane];
+        }
+    };
+    load_w();
+    for (int r = 0; r < reps; ++r) {
+        const T* lin = r == 0 ? p.in : ((r & 1) ? buf_a : buf_b);
+        Epi<T> e = p.epi;
+        e.out_raw = (r & 1) ? buf_b : buf_a;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int ty = tile % nty, tx = (tile / nty) % ntx, b = tile / (nty * ntx);
+            const int y0 = ty * X3S_TH, x0 = tx << 5;
+            const T* inb = lin + (size_t)(b % p.in_nb) * H * W * 32;
+            Px<T> v[NIT];
+            bool vok[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + 256 * it;
+                const int g = idx & 3, pix = x3_stage_pix(idx);
+                const int py = pix / X3_PW, px = pix - py * X3_PW;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                vok[it] = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                v[it] = px_load(inb + ((size_t)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)) * 32 + 8 * g);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + 256 * it;
+                const int pix = x3_stage_pix(idx);
+                if (!vok[it]) v[it] = px_zero<T>();
+                if (pix < NPIX) px_stage<RELU>(v[it], lds + pix * STR + 16 * (idx & 3), Geo<T>::LO);
+            }
+            lds_barrier();
+            const int y = y0 + wave;
+            if (y < H) {
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int ky = tap / 3, kx = tap % 3;
+                    const unsigned char* a = lds + ((wave + ky) * X3_PW + i + kx) * STR + 16 * h;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k));
+                        const bf16x8 bh = __builtin_bit_cast(bf16x8, wh[tap][k]);
+                        if constexpr (F32) {
+                            const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32 * k + 64));
+                            const bf16x8 bl = __builtin_bit_cast(bf16x8, wl[tap][k]);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                        }
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                    }
+                }
+                epi_tile<T, false, false, false>(e, b, y, H, W, i, acc, x0, h, W, 1, 0, 1.f, 1.f, nullptr, 0, 0, &biasv);
+            }
+            lds_barrier();
+        }
+        if (r + 1 < reps) {
+            load_w();          // the next layer's fragments (here: the same tensors, fetched again as a chain of different layers would)
+            conv32_grid_barrier(ctr, base + (unsigned)(r + 1) * gridDim.x, err, variant);
+        }
+    }
+}
+// host side of the trial: returns the counter base the NEXT launch on the same counter must pass
+int ptta_launch_conv32_loop(const Conv32Args& a, void* buf_a, void* buf_b, int reps, unsigned* ctr, unsigned* base_io, int* err, int variant, hipStream_t s) {
+    if (a.bf16 || a.mode != CONV_S1 || !a.x3 || a.naive || a.up || a.mask || a.add1 || a.out_sum) return -22;
+    Conv32P<float> p;
+    p.in = (const float*)a.in; p.in_nb = a.in_nb;
+    p.epi.bias = a.bias; p.epi.up = nullptr; p.epi.up_nb = 1; p.epi.mask = nullptr; p.epi.mask_nb = 1; p.epi.add1 = nullptr; p.epi.add1_nb = 1;
+    p.epi.add2 = nullptr; p.epi.add2_nb = 1; p.epi.out_raw = nullptr; p.epi.out_sum = nullptr;
+    p.B = a.B; p.Hin = p.Hout = a.Hin; p.Win = p.Wout = a.Win;
+    p.wpack = a.w->mbf16; p.wpack2 = a.w->mlo;
+    const long t4 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3S_TH - 1) / X3S_TH);
+    const int nb = (int)(t4 > 256 ? 256 : t4);                    // co-resident: one block per CU
+    if (a.relu_in) hipLaunchKernelGGL((conv32_s1_small_loop_kernel<float, true>), dim3(nb), dim3(256), 0, s, p, (float*)buf_a, (float*)buf_b, reps, ctr, *base_io, err, variant);
+    else hipLaunchKernelGGL((conv32_s1_small_loop_kernel<float, false>), dim3(nb), dim3(256), 0, s, p, (float*)buf_a, (float*)buf_b, reps, ctr, *base_io, err, variant);
+    *base_io += (unsigned)(reps - 1) * (unsigned)nb;
+    PTTA_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- stride-2 / transposed geometries, direct loads ----------------------------------------------------------------------
 // Same per-wave tiling as conv32_mfma_kernel (32 outputs of one row / one x-parity), but each A fragment (8 channels of one input pixel)
 // goes from L1/L2 straight into registers (fp32 storage: split into bf16 hi/lo there and fed to three bf16 MFMAs).  The weight fragments

@@ -2721,6 +2721,30 @@ int ptta_op_conv32_chain(const float* in, const float* weight, const float* bias
         hipMalloc((void**)&wv.canon, 9216 * 4) != hipSuccess || hipMalloc((void**)&wv.mlo, 9 * 2 * 64 * 8 * 2) != hipSuccess) return -12;
     ptta_pack_conv32(weight, wv, 0, 0, s);
     (void)hipStreamSynchronize(s);
+    if (epi_flags & 16) {                  // the layer loop: `reps` dependent layers per LAUNCH, a device-wide barrier between layers (conv32.hip)
+        hipEvent_t d0 = nullptr, d1 = nullptr;
+        unsigned* ctr = nullptr; int* err = nullptr;
+        if (hipEventCreate(&d0) != hipSuccess || hipEventCreate(&d1) != hipSuccess) return -5;
+        if (hipMalloc((void**)&ctr, 256) != hipSuccess) return -12;
+        err = (int*)(ctr + 32);
+        (void)hipMemsetAsync(ctr, 0, 256, s);
+        unsigned base = 0;
+        int rcd = 0;
+        for (int k = 0; k < replays + 2 && !rcd; ++k) {
+            if (k == 2) (void)hipEventRecord(d0, s);
+            Conv32Args a; a.w = &wv; a.bias = bias; a.B = b; a.Hin = h; a.Win = w; a.mode = CONV_S1; a.relu_in = relu_in; a.x3 = 1;
+            a.in = in; a.in_nb = b;
+            rcd = ptta_launch_conv32_loop(a, buf_a, buf_b, reps, ctr, &base, err, (epi_flags & 64) ? 2 : ((epi_flags & 32) ? 1 : 0), s);
+        }
+        (void)hipEventRecord(d1, s); (void)hipStreamSynchronize(s);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, d0, d1);
+        *us_per_launch_host = 1e3f * ms / ((float)replays * (float)reps);
+        int herr = 0; (void)hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);
+        if (!rcd && herr) rcd = -62;       // a bounded spin ran out (ETIME): the values are not a chain's
+        (void)hipEventDestroy(d0); (void)hipEventDestroy(d1); (void)hipFree(ctr);
+        (void)hipFree(wv.mf32); (void)hipFree(wv.mbf16); (void)hipFree(wv.mlo); (void)hipFree(wv.canon);
+        return rcd;
+    }
     if (epi_flags & 8) {                   // the same chain launched directly (no graph): what a dependent launch costs in the default form
         hipEvent_t d0 = nullptr, d1 = nullptr;
         if (hipEventCreate(&d0) != hipSuccess || hipEventCreate(&d1) != hipSuccess) return -5;

@@ -46,6 +46,8 @@ struct Conv32Args {
 };
 void ptta_pack_conv32(const float* src, const ConvW& w, int in_major, int flip, hipStream_t s, int row_stride = 32, int col_off = 0);
 int ptta_launch_conv32(const Conv32Args& a, hipStream_t s);
+// layer-loop trial (conv32.hip conv32_s1_small_loop_kernel; tools/bench_chain.py): `reps` dependent plain stride-1 layers in one launch
+int ptta_launch_conv32_loop(const Conv32Args& a, void* buf_a, void* buf_b, int reps, unsigned* ctr, unsigned* base_io, int* err, int variant, hipStream_t s);
 
 // ---- conv_small.hip ---------------------------------------------------------------------------
 struct Plane { const float* p = nullptr; int nb = 1; long bstride = 0;

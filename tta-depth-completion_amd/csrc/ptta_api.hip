@@ -153,6 +153,7 @@ struct ptta_ctx {
     bool prof_on = false;
     static constexpr int NPROF = 9;
     ProfClass prof[NPROF];
+    std::vector<std::pair<int, size_t>> prof_seq;      // launch order of the profiling leg: (class, index into prof[class].ev) -- debug tensor "prof_seq"
     // hipGraph replay of the whole step (inputs are first copied to fixed staging buffers so that
     // the captured pointers never change); one graph per (validity given, separate loss image)
     int use_graph = 0;           // option "graph": 1 = ptta_step / ptta_step_pipelined replay captured hipGraphs; 0 (default since round 5) = they enqueue
@@ -575,6 +576,7 @@ struct ProfScope {
             pc->ev.push_back({e0, e1});
         }
         pc->bytes += bytes; pc->macs += macs; pc->launches += launches;
+        c->prof_seq.push_back({klass, pc->used});
         (void)hipEventRecord(pc->ev[pc->used].first, s);
     }
     ~ProfScope() { if (pc) { (void)hipEventRecord(pc->ev[pc->used].second, s); pc->used++; } }
@@ -2639,6 +2641,7 @@ int ptta_profile(ptta_handle c, int enable) {
     if (!c) return -1;
     c->prof_on = enable != 0;
     for (auto& pc : c->prof) { pc.used = 0; pc.bytes = 0; pc.macs = 0; pc.launches = 0; }
+    c->prof_seq.clear();
     return 0;
 }
 
@@ -2665,6 +2668,23 @@ int ptta_debug_tensor(ptta_handle c, const char* name, float* dst, int64_t capac
     NLFWD(c->nl->debug_tensor(name, dst, capacity, numel_host, (hipStream_t)s_));
 
     if (!c || !name) return -1;
+    if (std::string(name) == "prof_seq") {
+        // the profiling leg's bracketed launches in launch order: [class, microseconds] pairs (tools/tail_launches.py)
+        HIPCHK(hipStreamSynchronize((hipStream_t)s_));
+        const int64_t n = 2 * (int64_t)c->prof_seq.size();
+        if (numel_host) *numel_host = n;
+        if (!dst) return 0;
+        if (capacity < n) return c->fail("capacity too small", -22);
+        std::vector<float> h((size_t)n);
+        for (size_t k = 0; k < c->prof_seq.size(); ++k) {
+            const auto& q = c->prof_seq[k];
+            float t = 0.f;
+            HIPCHK(hipEventElapsedTime(&t, c->prof[q.first].ev[q.second].first, c->prof[q.first].ev[q.second].second));
+            h[2 * k] = (float)q.first; h[2 * k + 1] = 1e3f * t;
+        }
+        HIPCHK(hipMemcpy(dst, h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        return 0;
+    }
     auto it = c->dbg.find(name);
     if (it == c->dbg.end()) return c->fail(std::string("no debug tensor ") + name, -2);
     if (numel_host) *numel_host = it->second.numel;

@@ -295,6 +295,37 @@ int ptta_photometric(const float* src, float* dst, int n, int height, int width,
                      const uint8_t* do_contrast, const float* f_contrast, const uint8_t* do_saturation, const float* f_saturation,
                      double* scratch, ptta_stream s);
 
+/* The augmentations of Transforms that NO adapt script enables (src/transforms.py:279-305 gamma / hue, :322-332 noise, :508-625 crop-and-pad /
+ * resize-and-pad, :630-655 patch removal).  gamma / hue / pad / resize are torchvision 0.10.1 calls in the reference (parity unpinned,
+ * restated); add_noise, remove_random_patches and the crop / pad index arithmetic are the reference's own torch code (pinned:
+ * tests/golden/transforms_extra.npz).  Handle-free, enqueue only, per-sample decisions as device arrays, dst must not alias src.
+ *   ptta_photometric_full  brightness -> contrast -> gamma -> hue -> saturation (:236-311).  uint8 path when brightness / contrast / hue /
+ *                          saturation is configured (non-NULL do_*; :102-106); with gamma alone the images stay float and torchvision's
+ *                          float branch applies: (x ** gamma).clamp(0, 1).  scratch: 256*n doubles (not needed for gamma alone)
+ *   ptta_add_noise         Transforms.add_noise (:839-876): dst = src + spread * noise (uniform = 0) or src + spread * (noise - 0.5)
+ *                          (uniform = 1) where do_noise[b]; `noise` = the caller's torch.randn / torch.rand field, same shape as src
+ *   ptta_remove_patches    Transforms.remove_random_patches (:878-924) behind random_nonzero's selection (:926-953): selected = n x H x W
+ *                          bytes, 1 at the chosen nonzero pixels; every pixel within the (patch_height[b], patch_width[b]) patch of a
+ *                          chosen pixel is zeroed in all channels
+ *   ptta_crop_pad          Transforms.crop_and_pad (:1072-1135): image[start_y:end_y, start_x:end_x] padded by pad_top / pad_left (and what
+ *                          remains below / right) back to height x width; padding_mode 0 constant (fill), 1 edge, 2 reflect, 3 symmetric
+ *   ptta_resize_pad        Transforms.resize_and_pad (:1137-1220): functional.resize to (resize_height[b], resize_width[b]) <= (height,
+ *                          width), then padded back to height x width as ptta_crop_pad */
+int ptta_photometric_full(const float* src, float* dst, int n, int height, int width, const uint8_t* do_brightness, const float* f_brightness,
+                          const uint8_t* do_contrast, const float* f_contrast, const uint8_t* do_gamma, const float* f_gamma,
+                          const uint8_t* do_hue, const float* f_hue, const uint8_t* do_saturation, const float* f_saturation,
+                          double* scratch, ptta_stream s);
+int ptta_add_noise(const float* src, const float* noise, float* dst, int n, int channels, int height, int width, const uint8_t* do_noise,
+                   float spread, int uniform, ptta_stream s);
+int ptta_remove_patches(const float* src, float* dst, int n, int channels, int height, int width, const uint8_t* do_remove,
+                        const uint8_t* selected, const int32_t* patch_height, const int32_t* patch_width, ptta_stream s);
+int ptta_crop_pad(const float* src, float* dst, int n, int channels, int height, int width, const uint8_t* do_crop_pad,
+                  const int32_t* start_y, const int32_t* start_x, const int32_t* end_y, const int32_t* end_x,
+                  const int32_t* pad_top, const int32_t* pad_left, int padding_mode, float fill, ptta_stream s);
+int ptta_resize_pad(const float* src, float* dst, int n, int channels, int height, int width, const uint8_t* do_resize_pad,
+                    const int32_t* resize_height, const int32_t* resize_width, const int32_t* pad_top, const int32_t* pad_left,
+                    int bilinear, int padding_mode, float fill, ptta_stream s);
+
 /* ptta_step enqueues its kernels directly; with ptta_set_option(h, "graph", 1) it replays a captured hipGraph of the whole step.  Graphs are re-captured after any re-binding. */
 /* model.convert_syncbn() (src/tta_main.py:326 -> SyncBatchNorm.convert_sync_batchnorm, src/msg_chn_model_adapt.py:547-556)
  * for the one-process-per-GPU run with shared adapted parameters: every training-mode BatchNorm then normalises with

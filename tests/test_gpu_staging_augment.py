@@ -70,14 +70,9 @@ def test_crop_flip_full_size_against_index_arithmetic(shape):
 
 
 def test_transforms_refuse_what_is_not_built():
-    with pytest.raises(NotImplementedError):
-        Transforms(random_gamma=[0.5, 1.5])
-    with pytest.raises(NotImplementedError):
-        Transforms(random_hue=[-0.1, 0.1])
+    # (gamma, hue, noise, patch removal, crop-and-pad and resize-and-pad are built: tests/test_gpu_transforms_extra.py)
     with pytest.raises(NotImplementedError):
         Transforms(normalized_image_range=[0, 1])
-    with pytest.raises(NotImplementedError):
-        Transforms(random_crop_and_pad=[0.5, 1.0])
     with pytest.raises(ValueError):
         Transforms(random_crop_to_shape=[1, 2, 3])
 

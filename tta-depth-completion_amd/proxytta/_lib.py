@@ -77,6 +77,11 @@ SIGNATURES = [
     ('ptta_rotate', c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
     ('ptta_resize_crop', c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     ('ptta_photometric', c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    ('ptta_photometric_full', c_int, [_P, _P, c_int, c_int, c_int] + [_P] * 12),
+    ('ptta_add_noise', c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_float, c_int, _P]),
+    ('ptta_remove_patches', c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    ('ptta_crop_pad', c_int, [_P, _P, c_int, c_int, c_int, c_int] + [_P] * 7 + [c_int, c_float, _P]),
+    ('ptta_resize_pad', c_int, [_P, _P, c_int, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int, c_float, _P]),
     ('ptta_set_stat_sync', c_int, [_P, _P, _P, _P, c_int64, c_int]),
     ('ptta_rccl_unique_id', c_int, [_P]),
     ('ptta_rccl_comm_create', c_int, [_P, c_int, c_int, POINTER(c_void_p)]),

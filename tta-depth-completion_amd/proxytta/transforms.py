@@ -9,9 +9,13 @@ Parity: crop / flip are bit-exact against the real class (tests/golden/transform
 photometric jitter are `torchvision.transforms.functional` calls in the reference (torchvision is absent from this image and
 from the reference tree): they restate torchvision 0.10.1's tensor algorithms and are PARITY UNPINNED, held to
 oracle/transforms_oracle.py (the same algorithms on torch's own grid_sample / interpolate) and to property tests.
-Gamma, hue, noise, crop-and-pad, resize-and-pad and patch removal (enabled by no adapt script) raise NotImplementedError; image
-normalisation is fused into the engine's first convolution (`Engine.set_image_norm`) and is refused here.
+Gamma, hue, noise, patch removal, crop-and-pad and resize-and-pad (enabled by no adapt script) are built too: gamma / hue / pad /
+resize restate torchvision (parity unpinned); noise, patch removal, every draw and the crop / pad index arithmetic are pinned by
+tests/golden/transforms_extra.npz (outputs of the real class).  Image normalisation is fused into the engine's first convolution
+(`Engine.set_image_norm`) and is refused here.
 """
+import random
+
 import numpy as np
 import torch
 
@@ -42,24 +46,42 @@ class Transforms(object):
                  random_resize_and_crop=[-1, -1],
                  random_resize_and_pad=[-1, -1],
                  resize_scaling_depth=False):
-        unsupported = {
-            'normalized_image_range': normalized_image_range is not None,
-            'random_gamma': not _unset(random_gamma), 'random_hue': not _unset(random_hue),
-            'random_noise': random_noise_type != 'none' and random_noise_spread > -1,
-            'random_remove_patch_percent_range': not _unset(random_remove_patch_percent_range),
-            'random_crop_and_pad': not _unset(random_crop_and_pad),
-            'random_resize_and_pad': not _unset(random_resize_and_pad)}
-        bad = [k for k, v in unsupported.items() if v]
-        if bad:
+        if normalized_image_range is not None:
             raise NotImplementedError(
-                'proxytta.Transforms builds what the adapt scripts enable (crop, flip, rotate, resize_and_crop, brightness, contrast, '
-                'saturation); not built: %s.  Image normalisation is fused into the engine: Engine.set_image_norm(normalized_image_range)'
-                % ', '.join(bad))
+                'proxytta.Transforms: image normalisation is fused into the engine: Engine.set_image_norm(normalized_image_range)')
         # src/transforms.py:84-96
         self.do_random_brightness = not _unset(random_brightness); self.random_brightness = random_brightness
         self.do_random_contrast = not _unset(random_contrast); self.random_contrast = random_contrast
         self.do_random_saturation = not _unset(random_saturation); self.random_saturation = random_saturation
-        self.do_photometric_transforms = self.do_random_brightness or self.do_random_contrast or self.do_random_saturation
+        self.do_random_gamma = not _unset(random_gamma); self.random_gamma = random_gamma
+        self.do_random_hue = not _unset(random_hue); self.random_hue = random_hue
+        # :102-106: gamma does NOT count -- with gamma alone the images are not cast to uint8 and torchvision's float branch applies
+        self.do_photometric_transforms = self.do_random_brightness or self.do_random_contrast or self.do_random_hue or self.do_random_saturation
+        # :108-125
+        self.do_random_noise = random_noise_type != 'none' and random_noise_spread > -1
+        self.random_noise_type, self.random_noise_spread = random_noise_type, random_noise_spread
+        if self.do_random_noise and random_noise_type not in ('gaussian', 'uniform'):
+            raise ValueError('Unsupported noise type: {}'.format(random_noise_type))
+        self.do_random_remove_patch = not _unset(random_remove_patch_percent_range)
+        self.random_remove_patch_percent_range = random_remove_patch_percent_range
+        if len(random_remove_patch_size) == 4:
+            self.random_remove_patch_size_height = list(range(random_remove_patch_size[0], random_remove_patch_size[2] + 2, 2))
+            self.random_remove_patch_size_width = list(range(random_remove_patch_size[1], random_remove_patch_size[3] + 2, 2))
+        else:
+            self.random_remove_patch_size_height = [random_remove_patch_size[0]]
+            self.random_remove_patch_size_width = [random_remove_patch_size[1]]
+        # :154-161, :174-182
+        self.do_random_crop_and_pad = not _unset(random_crop_and_pad)
+        self.random_crop_and_pad_min, self.random_crop_and_pad_max = random_crop_and_pad[0], random_crop_and_pad[1]
+        if self.do_random_crop_and_pad:
+            assert self.random_crop_and_pad_min < self.random_crop_and_pad_max
+            assert self.random_crop_and_pad_max <= 1
+        self.do_random_resize_and_pad = not _unset(random_resize_and_pad)
+        self.random_resize_and_pad_min, self.random_resize_and_pad_max = random_resize_and_pad[0], random_resize_and_pad[1]
+        if self.do_random_resize_and_pad:
+            assert self.random_resize_and_pad_min < self.random_resize_and_pad_max
+            assert self.random_resize_and_pad_min > 0
+            assert self.random_resize_and_pad_max <= 1.0
         # :151-152, :165-172, :184
         self.do_random_rotate = random_rotate_max > 0
         self.random_rotate_max = random_rotate_max
@@ -88,13 +110,16 @@ class Transforms(object):
         self.last_draw = None
 
     # ---- decisions (host, reference draw order) ------------------------------------------------------
-    def draw(self, n_batch, n_height, n_width, random_transform_probability=0.0, generator=None):
+    def draw(self, n_batch, n_height, n_width, random_transform_probability=0.0, generator=None, channels=(3,)):
         """The random decisions of one `transform` call, drawn in the reference's order (:230, :244-311, :337-350, :391-497) from
         torch's CPU generator (`generator=None`: the global one `torch.manual_seed` seeds) and numpy's global state for
-        the range crop (:346-352)."""
+        the range crop (:346-352).  `channels`: the channel count of every tensor of images_arr -- add_noise draws its field per tensor and
+        sample at this point of the stream (:862-866).  The patch-removal SELECTION (randperm over the nonzero pixels, :946-947) depends on the
+        data and is drawn by `apply`, last, as in the reference."""
         def rand(k):
             return torch.rand(k, generator=generator)
-        d = {'crop': None, 'hflip': None, 'vflip': None, 'rotate': None, 'resize': None, 'brightness': None, 'contrast': None, 'saturation': None}
+        d = {'crop': None, 'hflip': None, 'vflip': None, 'rotate': None, 'resize': None, 'brightness': None, 'contrast': None, 'saturation': None,
+             'gamma': None, 'hue': None, 'noise': None, 'crop_pad': None, 'resize_pad': None, 'remove': None}
         do_random_transform = rand(n_batch) <= random_transform_probability
         # photometric (:244-311): brightness draws `>= 0.50`, the others `<= 0.50`; factor = (max - min) * rand + min
         if self.do_random_brightness:
@@ -105,10 +130,29 @@ class Transforms(object):
             do = torch.logical_and(do_random_transform, rand(n_batch) <= 0.50)
             lo, hi = self.random_contrast
             d['contrast'] = (do.to(torch.uint8), ((hi - lo) * rand(n_batch) + lo).float())
+        if self.do_random_gamma:                                       # :279-290
+            do = torch.logical_and(do_random_transform, rand(n_batch) <= 0.50)
+            lo, hi = self.random_gamma
+            d['gamma'] = (do.to(torch.uint8), ((hi - lo) * rand(n_batch) + lo).float())
+        if self.do_random_hue:                                         # :292-303
+            do = torch.logical_and(do_random_transform, rand(n_batch) <= 0.50)
+            lo, hi = self.random_hue
+            d['hue'] = (do.to(torch.uint8), ((hi - lo) * rand(n_batch) + lo).float())
         if self.do_random_saturation:
             do = torch.logical_and(do_random_transform, rand(n_batch) <= 0.50)
             lo, hi = self.random_saturation
             d['saturation'] = (do.to(torch.uint8), ((hi - lo) * rand(n_batch) + lo).float())
+        if self.do_random_noise:                                       # :322-332; the fields: add_noise's loops, tensor by tensor, sample by sample
+            do = torch.logical_and(do_random_transform, rand(n_batch) <= 0.50)
+            fields = []
+            for c in channels:
+                f = torch.zeros(n_batch, int(c), n_height, n_width)
+                for b in range(n_batch):
+                    if do[b]:
+                        f[b] = (torch.randn(int(c), n_height, n_width, generator=generator) if self.random_noise_type == 'gaussian'
+                                else torch.rand(int(c), n_height, n_width, generator=generator))
+                fields.append(f)
+            d['noise'] = (do.to(torch.uint8), fields)
         do_crop = (self.do_random_crop_to_shape and bool(rand(1) <= 0.50)) or self.do_random_crop_to_shape_range
         if do_crop:
             if self.do_random_crop_to_shape_exact:
@@ -141,10 +185,47 @@ class Transforms(object):
                 sx.append(torch.randint(low=0, high=int(r_w[b]) - n_width + 1, size=(1,), generator=generator))
             d['resize'] = (do.to(torch.uint8), r_h.to(torch.int32), r_w.to(torch.int32), torch.cat(sy).to(torch.int32), torch.cat(sx).to(torch.int32),
                            n_height, n_width)
+        if self.do_random_crop_and_pad:                                # :508-571
+            do = torch.logical_and(do_random_transform, rand(n_batch) <= 0.50)
+            max_h, min_h = int(self.random_crop_and_pad_max * n_height), int(self.random_crop_and_pad_min * n_height)
+            max_w, min_w = int(self.random_crop_and_pad_max * n_width), int(self.random_crop_and_pad_min * n_width)
+            r_h = torch.randint(low=min_h, high=max_h, size=(n_batch,), generator=generator)
+            r_w = torch.randint(low=min_w, high=max_w, size=(n_batch,), generator=generator)
+            sy = torch.cat([torch.randint(low=0, high=max_h - int(v), size=(1,), generator=generator) for v in r_h])
+            sx = torch.cat([torch.randint(low=0, high=max_w - int(v), size=(1,), generator=generator) for v in r_w])
+            ey = torch.minimum(sy + r_h, torch.full_like(sy, n_height))
+            ex = torch.minimum(sx + r_w, torch.full_like(sx, n_width))
+            d_h = (n_height - (ey - sy)).int()
+            pad_top = (d_h * rand(n_batch)).int()
+            d_w = (n_width - (ex - sx)).int()
+            pad_left = (d_w * rand(n_batch)).int()
+            d['crop_pad'] = (do.to(torch.uint8), sy.to(torch.int32), sx.to(torch.int32), ey.to(torch.int32), ex.to(torch.int32),
+                             pad_top.to(torch.int32), (d_h - pad_top).to(torch.int32), pad_left.to(torch.int32), (d_w - pad_left).to(torch.int32))
+        if self.do_random_resize_and_pad:                              # :573-620
+            do = torch.logical_and(do_random_transform, rand(n_batch) <= 0.50)
+            r_h = torch.randint(low=int(self.random_resize_and_pad_min * n_height), high=int(self.random_resize_and_pad_max * n_height),
+                                size=(n_batch,), generator=generator)
+            r_w = torch.randint(low=int(self.random_resize_and_pad_min * n_width), high=int(self.random_resize_and_pad_max * n_width),
+                                size=(n_batch,), generator=generator)
+            d_h = (n_height - r_h).int()
+            pad_top = (d_h * rand(n_batch)).int()
+            pad_bottom = d_h - pad_top
+            d_w = (n_width - r_w).int()
+            pad_left = (d_w * rand(n_batch)).int()
+            pad_right = d_w - pad_left
+            z = torch.zeros_like(pad_top)
+            d['resize_pad'] = (do.to(torch.uint8), r_h.to(torch.int32), r_w.to(torch.int32), torch.maximum(pad_top, z).to(torch.int32),
+                               torch.maximum(pad_bottom, z).to(torch.int32), torch.maximum(pad_left, z).to(torch.int32), torch.maximum(pad_right, z).to(torch.int32))
+        if self.do_random_remove_patch:                                # :630-655: patch sizes from PYTHON's random module
+            do = torch.logical_and(do_random_transform, rand(n_batch) <= 0.50)
+            lo, hi = self.random_remove_patch_percent_range
+            densities = (hi - lo) * rand(n_batch) + lo
+            sizes = [[random.choice(self.random_remove_patch_size_height), random.choice(self.random_remove_patch_size_width)] for _ in range(n_batch)]
+            d['remove'] = (do.to(torch.uint8), densities, sizes)
         return d
 
     # ---- data movement (device) ----------------------------------------------------------------------
-    def apply(self, images_arr, draw, interpolation_modes=('nearest',)):
+    def apply(self, images_arr, draw, interpolation_modes=('nearest',), padding_modes=('constant',), generator=None):
         """Every N x C x H x W cuda tensor of images_arr through the decisions `draw`, in the reference's order: photometric jitter
         (three-channel tensors only make sense there), crop + flip, rotation, resize-and-crop.  interpolation_modes: one of
         'nearest' / 'bilinear' (or the reference's PIL enums 0 / 2) per tensor; rotation repeats the last one for further tensors (:1058-1060),
@@ -166,10 +247,16 @@ class Transforms(object):
             assert t.shape[0] == n and tuple(t.shape[-2:]) == (H, W), 'all tensors of images_arr share N, H, W'
             out.append(t.float().contiguous())
         # ---- photometric (:236-311): uint8-valued images; every tensor of images_arr (the reference passes [image] only) ----
-        if self.do_photometric_transforms:
-            bb, cc, ss = [draw[k] for k in ('brightness', 'contrast', 'saturation')]
+        pmodes = list(padding_modes) + [list(padding_modes)[-1]] * (len(images_arr) - len(padding_modes))
+        for m in pmodes:
+            if m not in self._PAD_MODES:
+                raise NotImplementedError('padding mode %r (torchvision functional.pad: constant, edge, reflect, symmetric)' % (m,))
+        if self.do_photometric_transforms or draw.get('gamma') is not None:
+            bb, cc, gg, hh, ss = [draw.get(k) for k in ('brightness', 'contrast', 'gamma', 'hue', 'saturation')]
+            if hh is not None and bool(((hh[1] < -0.5) | (hh[1] > 0.5)).any()):
+                raise ValueError('hue_factor is not in [-0.5, 0.5].')                 # torchvision's adjust_hue
             args = []
-            for pr in (bb, cc, ss):
+            for pr in (bb, cc, gg, hh, ss):
                 args += [None, None] if pr is None else [up(pr[0]), up(pr[1])]
             scratch = torch.empty(256 * n, device=dev, dtype=torch.float64)
             res = []
@@ -177,9 +264,24 @@ class Transforms(object):
                 if t.shape[1] != 3:
                     raise ValueError('photometric transforms take N x 3 x H x W images')
                 o = torch.empty_like(t)
-                rc = lib.ptta_photometric(ptr(t), ptr(o), n, H, W, *[ptr(a) for a in args], ptr(scratch), stream)
+                rc = lib.ptta_photometric_full(ptr(t), ptr(o), n, H, W, *[ptr(a) for a in args], ptr(scratch), stream)
                 if rc != 0:
-                    raise RuntimeError('ptta_photometric failed (%d)' % rc)
+                    raise RuntimeError('ptta_photometric_full failed (%d)' % rc)
+                res.append(o)
+            out = res
+        # ---- noise (:322-332, :839-876) ----
+        if draw.get('noise') is not None:
+            do, fields = draw['noise']
+            do = up(do)
+            res = []
+            for t, f in zip(out, fields):
+                assert tuple(f.shape) == tuple(t.shape), 'draw(channels=...) must list the channel count of every tensor'
+                o = torch.empty_like(t)
+                f_d = up(f.float().contiguous())
+                rc = lib.ptta_add_noise(ptr(t), ptr(f_d), ptr(o), n, t.shape[1], H, W, ptr(do), float(self.random_noise_spread),
+                                        int(self.random_noise_type == 'uniform'), stream)
+                if rc != 0:
+                    raise RuntimeError('ptta_add_noise failed (%d)' % rc)
                 res.append(o)
             out = res
         # ---- crop + flip ----
@@ -222,16 +324,66 @@ class Transforms(object):
                     raise RuntimeError('ptta_resize_crop failed (%d)' % rc)
                 res.append(o)
             out = res
+        # ---- crop and pad (:508-571, :1072-1135) ----
+        if draw.get('crop_pad') is not None:
+            do, sy_, sx_, ey_, ex_, pt, pb, pl, pr_ = [up(a) for a in draw['crop_pad']]
+            res = []
+            for t, m in zip(out, pmodes):
+                o = torch.empty_like(t)
+                rc = lib.ptta_crop_pad(ptr(t), ptr(o), n, t.shape[1], ch, cw, ptr(do), ptr(sy_), ptr(sx_), ptr(ey_), ptr(ex_), ptr(pt), ptr(pl),
+                                       self._PAD_MODES[m], 0.0, stream)
+                if rc != 0:
+                    raise RuntimeError('ptta_crop_pad failed (%d)' % rc)
+                res.append(o)
+            out = res
+        # ---- resize and pad (:573-620, :1137-1220) ----
+        if draw.get('resize_pad') is not None:
+            do, rh, rw, pt, pb, pl, pr_ = [up(a) for a in draw['resize_pad']]
+            res = []
+            for t, b_, m in zip(out, bil, pmodes):
+                o = torch.empty_like(t)
+                rc = lib.ptta_resize_pad(ptr(t), ptr(o), n, t.shape[1], ch, cw, ptr(do), ptr(rh), ptr(rw), ptr(pt), ptr(pl), int(b_),
+                                         self._PAD_MODES[m], 0.0, stream)
+                if rc != 0:
+                    raise RuntimeError('ptta_resize_pad failed (%d)' % rc)
+                res.append(o)
+            out = res
+        # ---- patch removal (:630-655, :878-953): the selection is random_nonzero's -- nonzero pixels in row-major order, a randperm over them
+        # (drawn here, last, per tensor and sample as the reference does), the first int(density * count) of it ----
+        if draw.get('remove') is not None:
+            do, densities, sizes = draw['remove']
+            # (device copies held in locals until the launches are enqueued: a temporary's block is handed to the next allocation at once)
+            ph = up(torch.tensor([int(k[0]) for k in sizes], dtype=torch.int32))
+            pw = up(torch.tensor([int(k[1]) for k in sizes], dtype=torch.int32))
+            do_d = up(do)
+            res = []
+            for t in out:
+                sel = torch.zeros((n, ch, cw), device=dev, dtype=torch.uint8)
+                for b in range(n):
+                    if not bool(do[b]):
+                        continue
+                    nz = (t[b].abs().sum(dim=0) > 0).nonzero(as_tuple=True)           # (device reduction + index list: host logic of the draw)
+                    count = int(nz[0].shape[0])
+                    perm = torch.randperm(count, generator=generator)[0:int(float(densities[b]) * count)].to(dev)
+                    sel[b, nz[0][perm], nz[1][perm]] = 1
+                o = torch.empty_like(t)
+                rc = lib.ptta_remove_patches(ptr(t), ptr(o), n, t.shape[1], ch, cw, ptr(do_d), ptr(sel), ptr(ph), ptr(pw), stream)
+                if rc != 0:
+                    raise RuntimeError('ptta_remove_patches failed (%d)' % rc)
+                res.append(o)
+            out = res
         return out
+
+    _PAD_MODES = {'constant': 0, 'edge': 1, 'reflect': 2, 'symmetric': 3}
 
     def transform(self, images_arr, intrinsics_arr=[], padding_modes=['constant'], interpolation_modes=['nearest'],
                   random_transform_probability=0.00, generator=None):
         if images_arr[0].ndim != 4:
             raise ValueError('Unsupported number of dimensions: {}'.format(images_arr[0].ndim))
         n, _, H, W = images_arr[0].shape
-        d = self.draw(n, H, W, random_transform_probability, generator)
+        d = self.draw(n, H, W, random_transform_probability, generator, channels=[t.shape[1] for t in images_arr])
         self.last_draw = d
-        images_arr = self.apply(list(images_arr), d, interpolation_modes)
+        images_arr = self.apply(list(images_arr), d, interpolation_modes, padding_modes, generator)
         intrinsics_arr = list(intrinsics_arr)
         if d['crop'] is not None:
             # the reference subtracts (n_width - crop_width, n_height - crop_height) from every sample's optical centre,

@@ -27,7 +27,8 @@ __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0
 
 static __host__ __device__ inline long ws_depth_off(int N) { return WS_SD + ((N + 15) / 16) * 16; }
 static __host__ __device__ inline long ws_cos_off(int N) { return ws_depth_off(N) + (long)N * LOSS_PB * 4; }
-static __host__ __device__ inline long ws_rows_off(int N) { return ws_cos_off(N) + LOSS_CB; }
+static __host__ __device__ inline long ws_cnt_off(int N) { return ws_cos_off(N) + LOSS_CB; }              // [N][LOSS_PB] valid-weight partials (loss_valid_count_kernel)
+static __host__ __device__ inline long ws_rows_off(int N) { return ws_cnt_off(N) + (long)N * LOSS_PB; }
 
 int ptta_loss_ws_floats(int N, int H, int W, long R) { return (int)(ws_rows_off(N) + 3 * R + 64); }
 long ptta_loss_ws_rows_off(int N) { return ws_rows_off(N); }
@@ -92,6 +93,34 @@ __global__ __launch_bounds__(256) void loss_depth_reduce_kernel(const float* __r
                                                                 const float* __restrict__ sparse, const float* __restrict__ validity,
                                                                 float max_d, int H, int W, float* __restrict__ part) {
     depth_reduce_body(blockIdx.x, gridDim.x, blockIdx.y, depth, image, sparse, validity, max_d, H, W, part);
+}
+
+// The sum of the validity weights alone -- the ONLY data-dependent input of the depth gradient's coefficients (w_sd / (N sum_w); the
+// smoothness coefficients are constants) and a function of the step's INPUTS, not of the depth map: the fused step computes it at the start of
+// the auxiliary stream's work, and the depth gradient then starts behind decoder 3 without waiting for the reduction of the loss VALUES
+// (depth_reduce_body above, ~11 us), which moves off the critical path to the auxiliary stream.  Same decomposition and the same summation
+// order as the a1 accumulator of depth_reduce_body: the partials -- and with them the coefficients and the gradient -- are bit-identical.
+__global__ __launch_bounds__(256) void loss_valid_count_kernel(const float* __restrict__ sparse, const float* __restrict__ validity, int H, int W,
+                                                               float* __restrict__ cnt) {
+    __shared__ float red[4];
+    const int bx = blockIdx.x, nbx = gridDim.x, n = blockIdx.y;
+    const size_t plane = (size_t)H * W;
+    const float* S = sparse + n * plane;
+    const float* V = validity ? validity + n * plane : nullptr;
+    float a1 = 0.f;
+    for (size_t idx = (size_t)bx * blockDim.x + threadIdx.x; idx < plane; idx += (size_t)nbx * blockDim.x) {
+        const float sv = S[idx], vv = (V ? V : S)[idx];
+        a1 += V ? vv : (sv > 0.f ? 1.f : sv);
+    }
+    a1 = wave_sum(a1);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a1;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[(size_t)n * LOSS_PB + bx] = red[0] + red[1] + red[2] + red[3];
+}
+int ptta_launch_loss_valid_count(const float* sparse, const float* validity, int N, int H, int W, float* ws, hipStream_t s) {
+    hipLaunchKernelGGL(loss_valid_count_kernel, dim3(LOSS_PB, N), dim3(256), 0, s, sparse, validity, H, W, ws + ws_cnt_off(N));
+    PTTA_CHECK_LAUNCH();
+    return 0;
 }
 
 // one wave per row of `emb`/`ref` (D = 512: 8 values per lane); T = bf16_t: the narrow embeddings of the mixed mode (one 16-B load per tensor)
@@ -209,6 +238,22 @@ __device__ void loss_finalize_block(const float* __restrict__ ws, int N, int H, 
     __syncthreads();
 }
 
+// the depth gradient's coefficients from the valid-weight partials alone (loss_valid_count_kernel): fin[1] cx, fin[2] cy, fin[3 + n] the
+// per-sample sparse-depth coefficient -- the same expressions, on the same sums, as loss_finalize_block
+__device__ void loss_coef_block(const float* __restrict__ cnt, int N, int H, int W, const float* __restrict__ w3, float* __restrict__ fin) {
+    __shared__ double red[4];
+    const float w_sd = w3[0], w_sm = w3[1];
+    const int t = threadIdx.x;
+    for (int n = 0; n < N; ++n) {
+        const double q1 = t < LOSS_PB ? (double)cnt[(size_t)n * LOSS_PB + t] : 0.0;
+        const double den = block_sum_d(q1, red);
+        if (t == 0 && n < LOSS_FIN_MAXN) fin[3 + n] = (float)((double)w_sd / ((double)N * den));
+    }
+    const double cntx = (double)N * H * (W - 1), cnty = (double)N * (H - 1) * W;
+    if (t == 0) { fin[0] = 0.f; fin[1] = (float)(w_sm / cntx); fin[2] = (float)(w_sm / cnty); }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void loss_finalize_kernel(float* __restrict__ ws, int N, int H, int W, long R, int has_cos,
                                                             const float* __restrict__ w3, float* __restrict__ loss_info) {
     __shared__ float fin[3 + LOSS_FIN_MAXN];
@@ -279,11 +324,12 @@ __device__ __forceinline__ void depth_grad_body(int bx, int nbx, const float* __
                                                 const float* __restrict__ sparse, const float* __restrict__ validity,
                                                 float max_d, int N, int H, int W, float* __restrict__ ws,
                                                 float* __restrict__ g, long R, int has_cos, const float* __restrict__ w3,
-                                                float* __restrict__ loss_info) {
+                                                float* __restrict__ loss_info, const float* __restrict__ cnt = nullptr) {
     __shared__ float fin[3 + LOSS_FIN_MAXN];
     const size_t plane = (size_t)H * W;
     const size_t total = (size_t)N * plane;
-    if (w3) loss_finalize_block(ws, N, H, W, R, has_cos, w3, fin, bx == 0 ? loss_info : nullptr, ws);       // fused step
+    if (w3 && cnt) loss_coef_block(cnt, N, H, W, w3, fin);           // fused step, the loss values reduced elsewhere (step_tail, ptta_api.hip)
+    else if (w3) loss_finalize_block(ws, N, H, W, R, has_cos, w3, fin, bx == 0 ? loss_info : nullptr, ws);       // fused step
     const float cx = w3 ? fin[1] : ws[WS_SCAL + 1], cy = w3 ? fin[2] : ws[WS_SCAL + 2];
     for (size_t gi = (size_t)bx * blockDim.x + threadIdx.x; gi < total; gi += (size_t)nbx * blockDim.x) {
         const int n = (int)(gi / plane);
@@ -316,8 +362,8 @@ __global__ __launch_bounds__(256) void loss_depth_grad_kernel(const float* __res
                                                               const float* __restrict__ sparse, const float* __restrict__ validity,
                                                               float max_d, int N, int H, int W, float* __restrict__ ws,
                                                               float* __restrict__ g, long R, int has_cos, const float* __restrict__ w3,
-                                                              float* __restrict__ loss_info) {
-    depth_grad_body(blockIdx.x, gridDim.x, depth, image, sparse, validity, max_d, N, H, W, ws, g, R, has_cos, w3, loss_info);
+                                                              float* __restrict__ loss_info, const float* __restrict__ cnt) {
+    depth_grad_body(blockIdx.x, gridDim.x, depth, image, sparse, validity, max_d, N, H, W, ws, g, R, has_cos, w3, loss_info, cnt);
 }
 
 __device__ __forceinline__ void cos_grad_body(int bx, int nbx, const float* __restrict__ emb, const float* __restrict__ ref, long R, int D,
@@ -361,7 +407,7 @@ __global__ __launch_bounds__(256) void loss_backward_merged_kernel(const float* 
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
                               int N, int H, int W, float* ws, float* gdepth, float* gref, hipStream_t s, const float* w3_fused,
-                              float* loss_info_fused, int cos_partials_ready) {
+                              float* loss_info_fused, int cos_partials_ready, int valid_count_ready) {
     const size_t total = (size_t)N * H * W;
     if (w3_fused && N > LOSS_FIN_MAXN) w3_fused = nullptr;          // the forward launched the finalize kernel in that case
     int blocks = (int)((total + 255) / 256); if (blocks > (w3_fused ? 1024 : 4096)) blocks = w3_fused ? 1024 : 4096;
@@ -374,8 +420,11 @@ int ptta_launch_loss_backward(const float* depth, const float* image, const floa
         PTTA_CHECK_LAUNCH();
         return 0;
     }
+    // valid_count_ready (fused step only): the coefficients come from ptta_launch_loss_valid_count's partials; nothing of the loss VALUES is read
+    // or written here (ptta_launch_loss_depth_part + ptta_launch_loss_finalize report them, on another stream)
+    const float* cnt = (valid_count_ready && w3_fused && !(emb && ref)) ? ws + ws_cnt_off(N) : nullptr;
     hipLaunchKernelGGL(loss_depth_grad_kernel, dim3(blocks), dim3(256), 0, s, depth, image, sparse, validity,
-                       max_input_depth, N, H, W, ws, gdepth, R, has_cos, w3_fused, loss_info_fused);
+                       max_input_depth, N, H, W, ws, gdepth, R, has_cos, w3_fused, cnt ? nullptr : loss_info_fused, cnt);
     if (emb && ref && gref) {
         long cb = (R + 3) / 4; if (cb > (w3_fused ? 1024 : 2048)) cb = w3_fused ? 1024 : 2048;
         hipLaunchKernelGGL(cos_grad_kernel, dim3((int)cb), dim3(256), 0, s, emb, ref, R, D, ws, ws + ws_rows_off(N), gref, N, H, W, w3_fused);

@@ -140,6 +140,11 @@ struct ptta_ctx {
     // main stream, the cosine rows, the finalisation and the heads' backward follow the heads on the auxiliary one; they meet where the
     // backward needs d feat (PTTA_THRU=0: join after the forward, loss launches, fork again)
     int thru = 1; bool thru_active = false;
+    // thru step: the valid-weight partials of the loss are computed at the start of the auxiliary stream's work (backbone), from the loss inputs
+    // step_body leaves here; the loss VALUES are reduced and reported on the auxiliary stream beside the backward (backbone_backward)
+    const float *cnt_sparse = nullptr, *cnt_validity = nullptr;
+    struct { const float *image = nullptr, *sparse = nullptr, *validity = nullptr; bool on = false; } loss_report;
+    hipEvent_t ev_loss = nullptr;
     hipEvent_t ev_dpart = nullptr;
     int fuse_first = 1, fuse_head_bwd = 1;
     int cos_grad_fused = 1;          // PTTA_COS_IN_GEMM=0: the fused step writes d loss / d ref as a tensor (loss.hip cos_grad_body) instead
@@ -1100,6 +1105,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         hipStream_t sp = s2 ? s2 : s;
         if (s2) { HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0)); }
         c->stamp(3, sp);
+        if (s2 && c->thru_active && c->cnt_sparse) REST_(s2, ptta_launch_loss_valid_count(c->cnt_sparse, c->cnt_validity, c->N, c->H, c->W, c->loss_ws, s2));
         RUN(meta_forward_proxy(c, sp));
         c->stamp(1, s);
         RUN(region(s, 0, Nn, false));
@@ -1121,6 +1127,7 @@ int backbone(ptta_ctx* c, const float* image, bool train, hipStream_t s) {
         RUN(region(s, 0, B2, false));
         if (train && s2) {
             HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(s2, c->ev_fork, 0));
+            if (c->thru_active && c->cnt_sparse) REST_(s2, ptta_launch_loss_valid_count(c->cnt_sparse, c->cnt_validity, c->N, c->H, c->W, c->loss_ws, s2));
             RUN(heads_forward(c, s2));
             HIPCHK(hipEventRecord(c->ev_join, s2));
         }
@@ -1372,6 +1379,7 @@ int heads_backward(ptta_ctx* c, const float* gref, hipStream_t s) {
     return 0;
 }
 
+const float* final_depth(ptta_ctx* c);
 // data gradients from d(depth_net) [Nn,1,Hp,Wp] and d(feat) down to conv1_rgb_meta, then its wgrad
 int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_aux) {
     const int Nn = c->Nn, B2 = 2 * Nn;
@@ -1429,6 +1437,14 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     REST_(sd, ptta_launch_up2T_32(c->de3_1, nullptr, c->up3_t, Nn, H4, W4, nbf, sd));
     REST_(sd, ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, nbf, sd));
     if (sd != s) HIPCHK(hipEventRecord(c->ev_side[3], sd));
+    if (sd != s && c->loss_report.on) {
+        // the loss VALUES (thru step): depth terms reduced here, behind the upsamplings the main chain waits for, then the one-block finalisation
+        // that writes the four reported scalars; main joins in front of the weight gradient (ev_loss)
+        REST_(sd, ptta_launch_loss_depth_part(final_depth(c), c->loss_report.image, c->loss_report.sparse, c->loss_report.validity, c->hp.max_input_depth,
+                                              c->N, c->H, c->W, c->loss_ws, sd));
+        REST_(sd, ptta_launch_loss_finalize(c->loss_ws, c->N, c->H, c->W, c->Rg, 1, c->hyper + 5, c->loss_info_dst ? c->loss_info_dst : c->loss_info, sd));
+        HIPCHK(hipEventRecord(c->ev_loss, sd));
+    }
     CV("depth_encoder3.init.2", true, CONV_S1, c->de3_0, Nn, Nn, H1, W1, false, em(c->de3_0a, c->e3_0a, B2));
     RUN(dgrad_in_ch1("depth_encoder3.init.0", c->de3_0a, g_net, c->dp11, H1, W1));       // d p11 = conv^T + d output
     REST_(s, ptta_launch_up2T_1ch(c->dp11, c->dq, Nn, H2, W2, s));                              // d(out2 + p12)
@@ -1457,6 +1473,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     { E e; e.sum = c->dm_total; e.mask = c->s0_1; e.mask_nb = B2; e.add1 = c->dw2; e.add1_nb = Nn; e.add2 = c->ds1_2; e.add2_nb = Nn;
       CV("depth_decoder1.prdct.1", true, CONV_S1, c->dv1, Nn, Nn, H4, W4, false, e); }
 #undef CV
+    if (sd != s && c->loss_report.on) HIPCHK(hipStreamWaitEvent(s, c->ev_loss, 0));       // (signalled ~200 us ago: the caller's loss_info is ordered on `s`)
     // ---- weight gradient of the meta layer: input = c2 of the real frames ----
     // (mixed mode, 2layers meta block: its BatchNorm / weight-gradient kernels take fp32 operands -- the 1/4-resolution gradient map is widened
     // once, 3.4 MB; the 1layer weight gradient reads the narrow map itself)
@@ -1602,6 +1619,7 @@ void ptta_destroy(ptta_handle h) {
         for (int p = 0; p < 2; ++p) { (void)hipEventDestroy(h->ev_prefix[p]); (void)hipEventDestroy(h->ev_rest[p]); }
     }
     if (h->ev_dpart) (void)hipEventDestroy(h->ev_dpart);
+    if (h->ev_loss) (void)hipEventDestroy(h->ev_loss);
     if (h->aux_stream) { (void)hipStreamDestroy(h->aux_stream); (void)hipEventDestroy(h->ev_fork); (void)hipEventDestroy(h->ev_join); (void)hipEventDestroy(h->ev_real); for (auto& e_ : h->ev_side) if (e_) (void)hipEventDestroy(e_); }
     for (void* p : h->allocs) if (p) (void)hipFree(p);
     for (auto& pc : h->prof) for (auto& e : pc.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1944,10 +1962,11 @@ static int step_body(ptta_handle c, const float* image, const float* loss_image,
                      ptta_stream s_) {
     RUN(ensure_fused_heads(c, (hipStream_t)s_));             // (before thru_ok: the direct-launch step would otherwise take the joined tail on its first call only)
     c->thru_active = thru_ok(c, (hipStream_t)s_);
+    c->cnt_sparse = c->thru_active ? sparse : nullptr; c->cnt_validity = validity;
     const int rc = ptta_forward_train(c, image, sparse, nullptr, nullptr, nullptr, s_);
-    if (rc) { c->thru_active = false; return rc; }
+    if (rc) { c->thru_active = false; c->cnt_sparse = nullptr; return rc; }
     const int rc2 = step_tail(c, loss_image, sparse, validity, s_);
-    c->thru_active = false;
+    c->thru_active = false; c->cnt_sparse = nullptr; c->loss_report.on = false;
     return rc2;
 }
 // loss + backward + (gradient all-reduce) + Adam: everything of the step behind the forward
@@ -1961,12 +1980,14 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
         if (!(c->nar_heads && heads_v2_on(c) && c->cos_rows_done)) REST_(s2, ptta_launch_loss_cos_part(c->emb, c->ref, c->Rg, 512, c->N, c->loss_ws, s2));
         HIPCHK(hipEventRecord(c->ev_dpart, s2));                // (the cosine partials exist)
         REST_(s2, ptta_launch_loss_cos_coef(c->loss_ws, c->N, c->Rg, c->hyper + 5, s2));
-        // main stream: depth terms of the loss, their gradient; its kernel finalises the whole loss itself (the four reported scalars: the
-        // cosine partials of the other stream are long there by now)
-        REST_(s, ptta_launch_loss_depth_part(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->N, c->H, c->W, c->loss_ws, s));
+        // main stream: the depth gradient at once -- its coefficients come from the valid-weight partials the auxiliary stream computed at the
+        // start of the step (backbone; ev_dpart lies behind them on that stream); the loss VALUES (depth terms + finalisation: the four reported
+        // scalars) are reduced on the auxiliary stream beside the backward (backbone_backward), not in front of it
         HIPCHK(hipStreamWaitEvent(s, c->ev_dpart, 0));
+        if (!c->ev_loss) HIPCHK(hipEventCreateWithFlags(&c->ev_loss, kStepEvent));
+        c->loss_report.image = loss_image; c->loss_report.sparse = sparse; c->loss_report.validity = validity; c->loss_report.on = true;
         REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, nullptr, nullptr, c->Rg, 512,
-                                           c->N, c->H, c->W, c->loss_ws, c->g_final, nullptr, s, c->hyper + 5, c->loss_info_dst ? c->loss_info_dst : c->loss_info, 1));
+                                           c->N, c->H, c->W, c->loss_ws, c->g_final, nullptr, s, c->hyper + 5, nullptr, 1, 1));
         c->cos_in_gemm = true;
         const int rc_h = heads_backward(c, c->gref_buf, s2);
         c->cos_in_gemm = false;

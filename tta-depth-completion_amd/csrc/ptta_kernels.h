@@ -219,7 +219,10 @@ int ptta_launch_loss_cos_coef(float* ws, int N, long R, const float* w3_dev, hip
 int ptta_launch_loss_backward(const float* depth, const float* image, const float* sparse, const float* validity,
                               float max_input_depth, const float* emb, const float* ref, long R, int D,
                               int N, int H, int W, float* ws, float* gdepth, float* gref, hipStream_t s, const float* w3_fused = nullptr,
-                              float* loss_info_fused = nullptr, int cos_partials_ready = 0);
+                              float* loss_info_fused = nullptr, int cos_partials_ready = 0, int valid_count_ready = 0);
+// the valid-weight partials of the sparse-depth term: all the depth gradient's coefficients depend on (a function of the step's inputs alone);
+// with valid_count_ready the depth gradient reads them instead of the loss partials and reports nothing (fused step: ptta_api.hip step_tail)
+int ptta_launch_loss_valid_count(const float* sparse, const float* validity, int N, int H, int W, float* ws, hipStream_t s);
 // (cos_partials_ready with emb == NULL: the depth gradient alone, its in-kernel finalisation includes the cosine term and the gate)
 // validity may be NULL in both calls: where(sparse > 0, 1, sparse) is then computed on the fly (src/tta_main.py:583-586)
 

@@ -362,7 +362,7 @@ int ptta_set_graph(ptta_handle h, int enable);         /* = ptta_set_option(h, "
  * handle's streams and drops its captured graphs; the next step re-captures.  Every non-default value is a correct, slower form of
  * the same step, kept as the check of the default (tests/test_gpu_options.py) or taken by the library itself where the default
  * form does not apply (small maps, N > 16, SyncBatchNorm exchange).  Unknown key / value out of range: -22; a key the handle does
- * not have: -38 (the generic engine has "graph" only; PTTA_DTYPE_MIXED handles keep every key but graph / aux_stream / thru at 1).
+ * not have: -38 (the generic engine has "graph" only; PTTA_DTYPE_MIXED handles keep every key but graph / aux_stream / thru / adam_in_wgrad at 1).
  *   key             default  meaning of 0
  *   "graph"         0        (1:) ptta_step / ptta_step_pipelined / ptta_forward_eval replay captured hipGraphs from their second call on.  Default
  *                            since round 5: direct launches on the caller's stream and the handle's own streams -- measured FASTER than replay
@@ -370,6 +370,8 @@ int ptta_set_graph(ptta_handle h, int enable);         /* = ptta_set_option(h, "
  *                            graph starts its second branch late and runs it slower, profiles/r05_step_stamps.txt; host cost 0.46 ms per call)
  *   "aux_stream"    1        one stream: no second queue for the proxy chain / the heads
  *   "thru"          1        the heads' stream joins the main stream before the loss (1: it runs on into loss + head backward)
+ *   "adam_in_wgrad" 1        0: Adam is its own launch behind the weight gradient's reduction (1: that reduction applies it -- MSG_CHN 1layer, no
+ *                            gradient exchange between the two; one dependent launch less at the end of the step)
  *   "fuse_first"    1        every first-layer convolution + the following 32->32 convolution as two launches (2: the RGB branch fused too)
  *   "fuse_head_bwd" 1        the prediction heads' backward as separate launches
  *   "fuse_heads"    1        proj -> pred as separate Linear launches (1: pred.0 o proj.3 folded into one weight at load time)
@@ -379,7 +381,7 @@ int ptta_set_graph(ptta_handle h, int enable);         /* = ptta_set_option(h, "
  *   "stamps"        0        (diagnostic, 1:) fourteen one-thread nodes of the step's and the prefix's graphs write wall_clock64() ticks since
  *                            the step's first node into the debug tensor "stamps" -- where the branches of a replayed step start and end with
  *                            no profiler attached (tools/step_stamps.py, profiles/r05_step_stamps.txt); results unchanged
- * bit-identical to the default: aux_stream, thru, fuse_first, fuse_head_bwd, mask_bits, graph; within bf16x3's own error (documented
+ * bit-identical to the default: aux_stream, thru, adam_in_wgrad, fuse_first, fuse_head_bwd, mask_bits, graph; within bf16x3's own error (documented
  * in the tests): fuse_heads, heads_v2, cos_in_gemm.
  * Environment, read once per ptta_create (csrc/ptta_kernels.h ptta_create_env) because it decides allocation and arithmetic:
  *   PTTA_CONV_IMPL=naive (direct fp32 kernels, PTTA_DTYPE_F32 only), PTTA_ARITH=exact (fp32 MFMA, MSG_CHN PTTA_DTYPE_F32 only),

@@ -177,6 +177,50 @@ def test_mixed_pipelined_equals_plain(meta, size, graph):
             assert torch.equal(a[3][k], b[3][k]), k
 
 
+@pytest.mark.parametrize('size', [(64, 128), (352, 1216)])
+def test_mixed_schedule_options_equal_the_default_step(size):
+    """The mixed mode keeps three switches (include/ptta.h): the second stream, the `thru` schedule (depth gradient from the valid-weight partials,
+    loss values reduced beside the backward) and Adam inside the weight gradient's reduction.  adam_in_wgrad = 0 against the default: loss_info,
+    depth, adapted parameters and both Adam moments bit for bit over four frames, plain and pipelined.  thru = 0 / aux_stream = 0 take the
+    one-stream form of the narrow heads (the cosine rows from WIDENED copies of the bf16 embeddings instead of the GEMM epilogue's fp32
+    accumulators): the same step to rounding -- first depth bit for bit, loss terms and parameters to 1e-4 of their size."""
+    n = 1
+    h, w = size
+    hp = dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
+    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(70 + i, h, w, n)] for i in range(5)]
+
+    def run(options, pipelined):
+        eng, sd, adapted = make_engine(n, h, w, 'mixed', hp, options=options)
+        rec = []
+        for i in range(4):
+            info, depth = eng.step(frames[i][0], frames[i][1], want_depth=True, next_frame=frames[i + 1] if pipelined else None)
+            rec.append((info.clone(), depth.clone()))
+        torch.cuda.synchronize()
+        st = {k: [t.clone() for t in v] for k, v in adapted.items()}
+        cnt = eng.adam_step_count()
+        eng.close()
+        return rec, st, cnt
+    for pipelined in (False, True):
+        base, pbase, cbase = run(None, pipelined)
+        assert cbase == 4
+        for opts in ({'adam_in_wgrad': 0}, {'thru': 0}, {'aux_stream': 0}, {'thru': 0, 'adam_in_wgrad': 0}):
+            got, pgot, cgot = run(opts, pipelined)
+            assert cgot == 4, opts
+            if opts == {'adam_in_wgrad': 0}:
+                for (i0, d0), (i1, d1) in zip(base, got):
+                    assert torch.equal(i0, i1) and torch.equal(d0, d1), opts
+                for k in pbase:
+                    for t0, t1 in zip(pbase[k], pgot[k]):
+                        assert torch.equal(t0, t1), (opts, k)
+                continue
+            assert torch.equal(base[0][1], got[0][1]), opts
+            for (i0, d0), (i1, d1) in zip(base, got):
+                assert torch.allclose(i0, i1, rtol=1e-4, atol=1e-6), opts
+                assert float((d0 - d1).abs().mean() / d0.abs().mean()) < 1e-4, opts
+            for k in pbase:
+                assert float((pbase[k][0] - pgot[k][0]).abs().max()) < 2.5e-3, (opts, k)        # a flipped Adam sign moves a weight by 2 lr
+
+
 def test_mixed_refuses_the_validation_arithmetic_modes():
     from proxytta.engine import Engine
     os.environ['PTTA_ARITH'] = 'exact'

@@ -16,7 +16,7 @@ HP = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, w_sparse_dept
           max_input_depth=80.0)
 
 # options whose other value must not change one bit of the step
-BITWISE = [{'stamps': 1}, {'thru': 0}, {'fuse_first': 0}, {'fuse_first': 2}, {'fuse_head_bwd': 0}, {'mask_bits': 0}, {'aux_stream': 0}, {'graph': 1},
+BITWISE = [{'stamps': 1}, {'thru': 0}, {'adam_in_wgrad': 0}, {'fuse_first': 0}, {'fuse_first': 2}, {'fuse_head_bwd': 0}, {'mask_bits': 0}, {'aux_stream': 0}, {'graph': 1},
            {'thru': 0, 'fuse_first': 0, 'fuse_head_bwd': 0, 'mask_bits': 0}]
 
 

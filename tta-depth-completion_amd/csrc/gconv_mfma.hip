@@ -825,8 +825,11 @@ __global__ __launch_bounds__(256) void gwgrad_x3_kernel(GView x, GView gy, int n
 // element order and the tile) -- eight loads in flight per thread; the sixteen group sums are combined in a fixed order through LDS.
 // (Four groups with four loads in flight: 16 dependent rounds over 256 partials, 9 us; this form: two.)
 #define GWR_G 16
+// `ad` (ad.pw != null; MSG_CHN 1layer fused step without a gradient exchange): the thread that finishes an element's sum applies Adam to it at
+// once -- the arithmetic of adam_multi_kernel (wgrad_adam.hip) on the value just stored in gw / gb, t = *step + 1 read by every block, the step
+// count written by the last block to finish: the same parameters and moments bit for bit, one dependent launch less at the very end of the step.
 __global__ __launch_bounds__(64 * GWR_G) void gwgrad_mfma_reduce_kernel(const float* __restrict__ part, int nchunks, int npairs, int ncib, int Ci, int Co,
-                                                                       float* __restrict__ gw, float* __restrict__ gb) {
+                                                                       float* __restrict__ gw, float* __restrict__ gb, GwAdam ad) {
     __shared__ double red[GWR_G][64];
     const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long e = (long)blockIdx.x * 64 + el;
@@ -855,12 +858,34 @@ __global__ __launch_bounds__(64 * GWR_G) void gwgrad_mfma_reduce_kernel(const fl
     }
     red[g][el] = s;
     __syncthreads();
-    if (g || !live) return;
-    s = 0.0;
+    if (g == 0 && live) {
+        s = 0.0;
 #pragma unroll
-    for (int j = 0; j < GWR_G; ++j) s += red[j][el];
-    if (e < nw) gw[((long)co * Ci + ci) * 9 + tap] = (float)s;
-    else if (gb) gb[co] = (float)s;
+        for (int j = 0; j < GWR_G; ++j) s += red[j][el];
+        const float gv = (float)s;
+        const bool isw = e < nw;
+        if (isw) gw[((long)co * Ci + ci) * 9 + tap] = gv;
+        else if (gb) gb[co] = gv;
+        if (ad.pw && (isw || ad.pb)) {
+            const float lr = ad.hyper[0], b1 = ad.hyper[1], b2 = ad.hyper[2], eps = ad.hyper[3], wd = ad.hyper[4];
+            const int t = *ad.step + 1;
+            const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+            const float step_size = (float)((double)lr / bc1);
+            const float bc2s = (float)sqrt(bc2);
+            const long k = isw ? ((long)co * Ci + ci) * 9 + tap : co;
+            float* P = isw ? ad.pw : ad.pb; float* M = isw ? ad.mw : ad.mb; float* V = isw ? ad.vw : ad.vb;
+            float pk = P[k], mk = M[k], vk = V[k];
+            ptta_adam_update(pk, mk, vk, gv, wd, b1, b2, eps, step_size, bc2s);
+            M[k] = mk; V[k] = vk; P[k] = pk;
+        }
+    }
+    if (ad.pw) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned done = atomicAdd(ad.ticket, 1u);
+            if (done == gridDim.x - 1) { *ad.step = *ad.step + 1; *ad.ticket = 0u; }
+        }
+    }
 }
 
 }  // namespace
@@ -938,7 +963,8 @@ long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co) {
     const long b = 256L * 4 * GWG_PART;                                  // gwgrad_x3_kernel: 256 blocks x 4 tile pairs
     return a > b ? a : b;
 }
-int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s, int gy_bf16) {
+int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s, int gy_bf16, const GwAdam* adam) {
+    const GwAdam noad{};
     const bool sq = x.C <= 64 && gy.C <= 64, wide_out = x.C <= 32 && gy.C <= 128, wide_in = x.C <= 128 && gy.C <= 32;
     // (the bf16x3 kernel addresses its maps with 32-bit byte offsets)
     const bool small_maps = (double)x.B * x.H * x.W * x.ld * 4.0 < 4294967296.0 && (double)gy.B * gy.H * gy.W * gy.ld * 4.0 < 4294967296.0;
@@ -958,14 +984,14 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
             // one partial per BLOCK (summed across its waves in LDS)
             if (gy_bf16) hipLaunchKernelGGL((gwgrad_x3_kernel<true, true>), dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
             else hipLaunchKernelGGL((gwgrad_x3_kernel<false, true>), dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
-            hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk, 1, 1, x.C, gy.C, gw, gb);
+            hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk, 1, 1, x.C, gy.C, gw, gb, adam ? *adam : noad);
             PTTA_CHECK_LAUNCH();
             return 0;
         }
         if (gy_bf16) hipLaunchKernelGGL(gwgrad_x3_kernel<true>, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
         else hipLaunchKernelGGL(gwgrad_x3_kernel<false>, dim3(nblk), dim3(256), 0, s, x, gy, nx, single, kcib, part);
-        if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb);
-        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk, 4, kcib, x.C, gy.C, gw, gb);
+        if (single) hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk * 4, 1, 1, x.C, gy.C, gw, gb, noad);
+        else hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nblk, 4, kcib, x.C, gy.C, gw, gb, noad);
         PTTA_CHECK_LAUNCH();
         return 0;
     }
@@ -974,7 +1000,7 @@ int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float*
     const int ncib = (x.C + 31) / 32, ncob = (gy.C + 31) / 32, npairs = ncib * ncob;
     hipLaunchKernelGGL(gwgrad_mfma_kernel, dim3(nchunks, npairs), dim3(64), 0, s, x, gy, nchunks, ncib, part);
     const long n = 9L * x.C * gy.C + gy.C;
-    hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nchunks, npairs, ncib, x.C, gy.C, gw, gb);
+    hipLaunchKernelGGL(gwgrad_mfma_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64 * GWR_G), 0, s, part, nchunks, npairs, ncib, x.C, gy.C, gw, gb, noad);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -26,7 +26,6 @@
 #include "ptta_common.h"
 #include "ptta_kernels.h"
 
-int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s, int gy_bf16);
 long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co);
 int ptta_launch_gbn_running_update(const float* st, int npass, int C, long R, float momentum, float eps, float* rm, float* rv, long long* nbt,
                                    int repeats, hipStream_t s);

@@ -140,6 +140,9 @@ struct ptta_ctx {
     // main stream, the cosine rows, the finalisation and the heads' backward follow the heads on the auxiliary one; they meet where the
     // backward needs d feat (PTTA_THRU=0: join after the forward, loss launches, fork again)
     int thru = 1; bool thru_active = false;
+    // option "adam_in_wgrad": the 1layer weight gradient's reduction applies Adam itself (one launch less at the end of the step) when no
+    // gradient exchange sits between the two; adam_fuse_req: set by step_tail around its backward, adam_fused: the launch took it
+    int adam_in_wgrad = 1; bool adam_fuse_req = false, adam_fused = false;
     // thru step: the valid-weight partials of the loss are computed at the start of the auxiliary stream's work (backbone), from the loss inputs
     // step_body leaves here; the loss VALUES are reduced and reported on the auxiliary stream beside the backward (backbone_backward)
     const float *cnt_sparse = nullptr, *cnt_validity = nullptr;
@@ -1483,7 +1486,13 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
         // default arithmetic: the bf16x3 reduction-GEMM form (gconv_mfma.hip gwgrad_x3_kernel, single-pair mode)
         GView xv; xv.p = (float*)c->c2; xv.B = Nn; xv.H = H4; xv.W = W4; xv.C = 32; xv.ld = 32;
         GView gv; gv.p = (float*)c->dm_total; gv.B = Nn; gv.H = H4; gv.W = W4; gv.C = 32; gv.ld = 32;
-        REST_(s, ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s, c->nar_bwd ? 1 : 0));
+        GwAdam ga;
+        const bool fuse = c->adam_fuse_req && c->adam_in_wgrad && !c->grad_comm && c->adapted.size() == 2 && c->adapted[0].p && c->adapted[0].m && c->adapted[0].v &&
+                          c->adapted[1].p && c->adapted[1].m && c->adapted[1].v && c->adapted[0].g == c->gW && c->adapted[1].g == c->gB;
+        if (fuse) { ga.pw = c->adapted[0].p; ga.mw = c->adapted[0].m; ga.vw = c->adapted[0].v; ga.pb = c->adapted[1].p; ga.mb = c->adapted[1].m; ga.vb = c->adapted[1].v;
+                    ga.hyper = c->hyper; ga.step = c->step_dev; ga.ticket = c->adam_ticket; }
+        REST_(s, ptta_launch_gwgrad_mfma(xv, gv, c->wgrad_part, c->gW, c->gB, s, c->nar_bwd ? 1 : 0, fuse ? &ga : nullptr));
+        c->adam_fused = fuse;
         return 0;
     }
     REST_(s, ptta_launch_wgrad32(c->c2, c->dm_total, c->bf16, Nn, H4, W4, c->wgrad_part, c->gW, c->gB, s));
@@ -2000,10 +2009,13 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
                                c->N, c->H, c->W, c->Hp, c->Wp, c->pt, c->pr);
             g_net = c->g_net;
         }
-        RUN(backbone_backward(c, g_net, s, true));
+        c->adam_fuse_req = true; c->adam_fused = false;
+        const int rc_bb = backbone_backward(c, g_net, s, true);
+        c->adam_fuse_req = false;
+        if (rc_bb) return rc_bb;
         if (c->grad_comm && ptta_rccl_allreduce_mean_f32(c->grad_comm, c->grad_arena, c->grad_arena_n, s_)) return c->fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
         c->stamp(9, s);
-        RUN(ptta_adam_step(c, nullptr, nullptr, s_));
+        if (!c->adam_fused) RUN(ptta_adam_step(c, nullptr, nullptr, s_));
         c->stamp(10, s);
         return 0;
     }
@@ -2019,12 +2031,13 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
     REST_(s, ptta_launch_loss_backward(final_depth(c), loss_image, sparse, validity, c->hp.max_input_depth, c->emb, c->ref, c->Rg, 512,
                                        c->N, c->H, c->W, c->loss_ws, c->g_final, cig ? nullptr : c->gref_buf, s, c->hyper + 5, c->loss_info_dst ? c->loss_info_dst : c->loss_info));
     c->cos_in_gemm = cig;
+    c->adam_fuse_req = true; c->adam_fused = false;
     const int rc_b = ptta_backward(c, c->g_final, c->gref_buf, nullptr, nullptr, s_);
-    c->cos_in_gemm = false;
+    c->cos_in_gemm = false; c->adam_fuse_req = false;
     if (rc_b) return rc_b;
     // shared-parameter run (the reference's DDP, src/tta_main.py:354,631-633): mean of the adapted gradients over the ranks, one message
     if (c->grad_comm && ptta_rccl_allreduce_mean_f32(c->grad_comm, c->grad_arena, c->grad_arena_n, s_)) return c->fail(std::string("gradient all-reduce: ") + ptta_rccl_last_error(), -5);
-    RUN(ptta_adam_step(c, nullptr, nullptr, s_));
+    if (!c->adam_fused) RUN(ptta_adam_step(c, nullptr, nullptr, s_));
     return 0;
 }
 
@@ -2568,6 +2581,7 @@ int ptta_set_option(ptta_handle c, const char* key, int value) {
     int* f = nullptr; int lo = 0, hi = 1;
     if (k == "aux_stream") f = &c->use_aux;
     else if (k == "thru") f = &c->thru;
+    else if (k == "adam_in_wgrad") f = &c->adam_in_wgrad;
     else if (k == "fuse_first") { f = &c->fuse_first; hi = 2; }
     else if (k == "fuse_head_bwd") f = &c->fuse_head_bwd;
     else if (k == "fuse_heads") f = &c->fuse_heads;
@@ -2577,7 +2591,7 @@ int ptta_set_option(ptta_handle c, const char* key, int value) {
     else if (k == "stamps") f = &c->stamps;
     else return c->fail("ptta_set_option: unknown key '" + k + "'", -22);
     if (value < lo || value > hi) return c->fail("ptta_set_option: value out of range for '" + k + "'", -22);
-    if (c->mixed && k != "aux_stream" && k != "thru" && k != "stamps" && value != 1)
+    if (c->mixed && k != "aux_stream" && k != "thru" && k != "adam_in_wgrad" && k != "stamps" && value != 1)
         return c->fail("ptta_set_option: the mixed mode is defined on the default kernels ('" + k + "' stays 1)", -38);
     if (k == "aux_stream" && c->pre_sync_graph >= 0) { c->pre_sync_aux = value; return 0; }      // statistics exchange active: takes effect when it ends
     if (*f == value) return 0;
@@ -2594,6 +2608,7 @@ int ptta_get_option(ptta_handle c, const char* key, int* value) {
     if (k == "graph") *value = c->use_graph;
     else if (k == "aux_stream") *value = c->use_aux;
     else if (k == "thru") *value = c->thru;
+    else if (k == "adam_in_wgrad") *value = c->adam_in_wgrad;
     else if (k == "fuse_first") *value = c->fuse_first;
     else if (k == "fuse_head_bwd") *value = c->fuse_head_bwd;
     else if (k == "fuse_heads") *value = c->fuse_heads;

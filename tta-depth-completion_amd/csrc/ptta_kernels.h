@@ -254,6 +254,18 @@ int ptta_launch_step_inc(int* step_dev, hipStream_t s);
 // rep: how many times the optimizer's parameter list names this tensor (torch.optim.Adam updates a parameter once per occurrence, each
 // with its own step count: occurrence r of step t uses (t - 1) * rep + r + 1); 0 / 1 = the usual single update
 struct PttaAdamEntry { float *p, *m, *v; const float* g; long n, off; int rep = 1; };
+// torch.optim.Adam's update of ONE element, the same instructions wherever it runs (adam_kernel, adam_multi_kernel, the weight gradient's
+// reduction with Adam inside): contraction is off in this body and the two fused multiply-adds are spelled out -- left to hipcc, `b1 m + (1 - b1) g`
+// becomes fma(b1, m, (1 - b1) g) in one kernel and fma(1 - b1, g, b1 m) in another, and the "same" update differs in the last bit.
+__device__ __forceinline__ void ptta_adam_update(float& pk, float& mk, float& vk, float g0, float wd, float b1, float b2, float eps,
+                                                 float step_size, float bc2s) {
+#pragma clang fp contract(off)
+    float gg = g0;
+    if (wd != 0.f) gg = __builtin_fmaf(wd, pk, gg);
+    mk = __builtin_fmaf(b1, mk, (1.f - b1) * gg);
+    vk = __builtin_fmaf(b2, vk, ((1.f - b2) * gg) * gg);
+    pk = pk - step_size * (mk / (sqrtf(vk) / bc2s + eps));
+}
 int ptta_launch_adam_multi(const PttaAdamEntry* tab_dev, int nt, long total, const float* hyper, int* step_dev, unsigned* ticket_dev, hipStream_t s);
 int ptta_launch_set_floats(float* dst, const float* host_src, int n /*<= 8*/, hipStream_t s);   // by kernel argument: no sync
 int ptta_launch_set_int(int* dst, int v, hipStream_t s);
@@ -355,4 +367,7 @@ long ptta_gfrag_elems(int KK, int C0, int C1, int Co);
 int ptta_launch_gconv_x3(const GX3Args& a, int ks, hipStream_t s);
 int ptta_launch_gconv_x3_strided(const GX3Args& a, int ks, int mode, int hin, int win, hipStream_t s);
 long ptta_gwgrad_mfma_part_floats(long pixels, int Ci, int Co);
-int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s, int gy_bf16 = 0);
+// Adam applied by the weight gradient's reduction itself (gconv_mfma.hip gwgrad_mfma_reduce_kernel; <= 32 x 32 channels only): parameter + both
+// moments of the weight and of the bias, the hyper-parameter block, the device step count and its ticket (as ptta_launch_adam_multi)
+struct GwAdam { float *pw = nullptr, *mw = nullptr, *vw = nullptr, *pb = nullptr, *mb = nullptr, *vb = nullptr; const float* hyper = nullptr; int* step = nullptr; unsigned* ticket = nullptr; };
+int ptta_launch_gwgrad_mfma(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s, int gy_bf16 = 0, const GwAdam* adam = nullptr);

@@ -110,13 +110,9 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
     const float step_size = (float)((double)lr / bc1);
     const float bc2s = (float)sqrt(bc2);
     for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long)gridDim.x * blockDim.x) {
-        float gg = g[k];
-        const float pk = p[k];
-        if (wd != 0.f) gg = fmaf(wd, pk, gg);
-        const float mk = b1 * m[k] + (1.f - b1) * gg;
-        const float vk = b2 * v[k] + (1.f - b2) * gg * gg;
-        m[k] = mk; v[k] = vk;
-        p[k] = pk - step_size * (mk / (sqrtf(vk) / bc2s + eps));
+        float pk = p[k], mk = m[k], vk = v[k];
+        ptta_adam_update(pk, mk, vk, g[k], wd, b1, b2, eps, step_size, bc2s);
+        m[k] = mk; v[k] = vk; p[k] = pk;
     }
 }
 
@@ -139,21 +135,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const PttaAdamEntry* __
         const float g0 = e.g[k];
         float pk = e.p[k], mk = e.m[k], vk = e.v[k];
         if (e.rep <= 1) {
-            float gg = g0;
-            if (wd != 0.f) gg = fmaf(wd, pk, gg);
-            mk = b1 * mk + (1.f - b1) * gg;
-            vk = b2 * vk + (1.f - b2) * gg * gg;
-            pk = pk - step_size * (mk / (sqrtf(vk) / bc2s + eps));
+            ptta_adam_update(pk, mk, vk, g0, wd, b1, b2, eps, step_size, bc2s);
         } else {
             // a tensor listed `rep` times: `rep` consecutive updates with the same gradient, step counts (t - 1) * rep + 1 ... t * rep
             for (int r = 0; r < e.rep; ++r) {
                 const int tt = (t - 1) * e.rep + r + 1;
                 const double c1 = 1.0 - pow((double)b1, (double)tt), c2 = 1.0 - pow((double)b2, (double)tt);
-                float gg = g0;
-                if (wd != 0.f) gg = fmaf(wd, pk, gg);
-                mk = b1 * mk + (1.f - b1) * gg;
-                vk = b2 * vk + (1.f - b2) * gg * gg;
-                pk = pk - (float)((double)lr / c1) * (mk / (sqrtf(vk) / (float)sqrt(c2) + eps));
+                ptta_adam_update(pk, mk, vk, g0, wd, b1, b2, eps, (float)((double)lr / c1), (float)sqrt(c2));
             }
         }
         e.m[k] = mk; e.v[k] = vk; e.p[k] = pk;

@@ -26,7 +26,7 @@ for name in ADAPTED:
 frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(i, bench.H, bench.W, 1)] for i in range(4)]
 khz = 100000.0      # wall_clock64: 100 MHz constant clock on MI300-class parts
 names = ['graph start', 'real chain start', 'real chain end', 'proxy branch start', 'proxy chain end', 'heads part 1 end', 'heads part 2 end',
-         'decoder 3 end', 'heads backward end', 'before Adam', 'after Adam', "next frame's prefix start", 'its RGB encoder end', 'its end']
+         'decoder 3 end', 'heads backward end', 'backward + weight gradient done (Adam inside its reduction)', 'after Adam (own launch: option adam_in_wgrad = 0)', "next frame's prefix start", 'its RGB encoder end', 'its end']
 acc = []
 k = 0
 for rep in range(24):

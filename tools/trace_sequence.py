@@ -8,6 +8,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
 adam = [i for i, n in enumerate(names) if n.startswith('adam_multi_kernel')]
+if len(adam) < 2:          # MSG_CHN 1layer since round 5: Adam runs inside the weight gradient's reduction -- that launch ends a step
+    adam = [i for i, n in enumerate(names) if 'gwgrad_mfma_reduce_kernel' in n]
 # which step: argv[2] = index into the list of Adam launches (default: the last one -- in bench.py that is the kernel-by-kernel
 # profiling leg; e.g. 8 = a replayed step of the first timed block)
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(adam) - 1

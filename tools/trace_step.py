@@ -7,7 +7,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-adam = [i for i, n in enumerate(names) if n.startswith('adam_multi_kernel')]      # one launch per step
+adam = [i for i, n in enumerate(names) if n.startswith('adam_multi_kernel')]
+if len(adam) < 2:          # MSG_CHN 1layer since round 5: Adam runs inside the weight gradient's reduction -- that launch ends a step
+    adam = [i for i, n in enumerate(names) if 'gwgrad_mfma_reduce_kernel' in n]      # one launch per step
 step = rows[adam[-2] + 1:adam[-1] + 1]
 t0, t1 = int(step[0]['Start_Timestamp']), int(step[-1]['End_Timestamp'])
 ksum = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in step) / 1e3

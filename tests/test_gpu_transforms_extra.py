@@ -126,6 +126,11 @@ def test_constructor_refuses_only_what_the_engine_fuses():
         Transforms(normalized_image_range=[0, 1])
     with pytest.raises(ValueError):
         Transforms(random_noise_type='salt', random_noise_spread=1.0)
+    te = Transforms(random_remove_patch_percent_range=[0.1, 0.2], random_remove_patch_size=[4, 3])
+    with pytest.raises(ValueError):                      # an even patch size fails in the reference too (max_pool2d returns H + 1 rows)
+        d_ = te.draw(1, 8, 8, 1.0, channels=[1])
+        d_['remove'] = (torch.ones(1, dtype=torch.uint8), d_['remove'][1], d_['remove'][2])
+        te.apply([torch.ones(1, 1, 8, 8).cuda()], d_)
     t = Transforms(random_crop_and_pad=[0.5, 1.0])
     with pytest.raises(NotImplementedError):
         t.apply([torch.zeros(1, 1, 8, 8).cuda()], t.draw(1, 8, 8, 1.0, channels=[1]), padding_modes=['circular'])

@@ -352,6 +352,9 @@ class Transforms(object):
         # (drawn here, last, per tensor and sample as the reference does), the first int(density * count) of it ----
         if draw.get('remove') is not None:
             do, densities, sizes = draw['remove']
+            if any(bool(do[b]) and (int(k[0]) % 2 == 0 or int(k[1]) % 2 == 0) for b, k in enumerate(sizes)):
+                # max_pool2d(kernel k, stride 1, padding k // 2) returns H + 1 rows for an even k: the reference's `mask * image` then fails to broadcast
+                raise ValueError('remove_random_patches: patch sizes must be odd (got %r)' % (sizes,))
             # (device copies held in locals until the launches are enqueued: a temporary's block is handed to the next allocation at once)
             ph = up(torch.tensor([int(k[0]) for k in sizes], dtype=torch.int32))
             pw = up(torch.tensor([int(k[1]) for k in sizes], dtype=torch.int32))

@@ -224,15 +224,77 @@ def nlspn_cpu_baseline(inner_iter=3):
             'sample': '1 TTA step of the same 352x1216 workload after one eval forward (PyTorch-CPU oracle, fp32, %.1f s/step; %d steps/frame)' % (dt, inner_iter)}
 
 
-def two_streams_workload(steps=100, nstreams=2):
+CLASSES = ['s1_relu_large', 's1_relu_small', 's1_plain_large', 's1_plain_small', 'strided_large', 'strided_small', 'heads', 'in_out_convs', 'rest']
+
+
+def msgchn_batch_workload(ns=(1, 2, 4, 8, 16), dtype='mixed', steps=20, blocks=5, warmup=6, by_class=True):
+    """Beside the metric, never `value` (the headline stays batch 1 per GPU): the SAME step with N frames per call -- the reference's own
+    operating point is `n_batch // ngpus` frames per rank (bash/adapt/adapt_msgchn_vkitti.sh:21 --n_batch 16, src/tta_main.py:224: 2 frames per
+    GPU on 8 GPUs, 16 on one).  Same protocol as the headline: frames resident in HBM, ptta_step_pipelined (every call names the next batch),
+    median block; then the same steps kernel by kernel on one stream for the per-class table.  Algorithmic bytes at the stored width."""
+    from proxytta import synth
+    from proxytta.engine import ADAPTED, Engine
+    out = {}
+    for n in ns:
+        eng = Engine(n, H, W, dtype=dtype, **HP)
+        sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
+        eng.load_state_dict(sd)
+        for name in ADAPTED:
+            eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
+        nfr = 3
+        frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(3000 + 16 * i, H, W, n)] for i in range(nfr)]
+        for i in range(warmup):
+            info, _ = eng.step(*frames[i % nfr], next_frame=frames[(i + 1) % nfr])
+        it, bl = warmup, []
+        for _ in range(blocks):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                info, _ = eng.step(*frames[it % nfr], next_frame=frames[(it + 1) % nfr])
+                it += 1
+            torch.cuda.synchronize()
+            bl.append((time.perf_counter() - t0) / steps)
+        ms = 1e3 * float(np.median(bl))
+        rec = {'ms_per_step': ms, 'frames_per_s': 1e3 * n / ms, 'ms_per_frame': ms / n, 'finite': bool(torch.isfinite(info).all().item()),
+               'pipelined_active': eng.get_option('pipelined_active') if hasattr(eng, 'get_option') else None}
+        if by_class:
+            eng.profile(True)
+            torch.cuda.synchronize()
+            for i in range(steps):
+                eng.step(*frames[i % nfr])
+            torch.cuda.synchronize()
+            prof = [eng.profile_read(k) for k in range(len(CLASSES))]
+            eng.profile(False)
+            stored = sum(p[1] for p in prof) / steps
+            rec['alg_bytes_per_step'] = stored
+            rec['step_hbm_frac'] = stored / (ms * 1e-3) / HBM_PEAK
+            rec['roofline_by_class'] = {name: {'launches_per_step': cn / steps, 'us_per_step': 1e3 * cms / steps, 'us_per_frame': 1e3 * cms / steps / n,
+                                               'hbm_frac': (cby / (cms * 1e-3) / HBM_PEAK) if (cms > 0 and cby > 0) else None}
+                                        for name, (cms, cby, cmc, cn) in zip(CLASSES, prof)}
+            rec['serial_sum_us_per_frame'] = sum(1e3 * p[0] for p in prof) / steps / n
+        out[str(n)] = rec
+        eng.close()
+        del eng, sd, frames
+        torch.cuda.empty_cache()
+    base = out.get('1')
+    if base:
+        for k, v in out.items():
+            v['speedup_vs_batch_1'] = v['frames_per_s'] / base['frames_per_s']
+    out['_note'] = ('N frames per call on ONE GPU, %s, ptta_step_pipelined, %d blocks x %d steps, median block; step_hbm_frac = stored algorithmic bytes of '
+                    'the step / time / 8 TB/s; roofline_by_class from the kernel-by-kernel one-stream leg (hipEvents)' % (dtype, blocks, steps))
+    return out
+
+
+def two_streams_workload(steps=100, nstreams=2, dtype='mixed'):
     """Beside the metric, never `value`: the config-4 sharding (independent frame streams, each with its own adapted parameters and
-    Adam state) applied INSIDE one GPU -- two handles, two hipGraphs, two HIP streams.  What the second stream gains is the share of
-    the single-stream step that is latency (small launches, serial chains), not bandwidth."""
+    Adam state) applied INSIDE one GPU -- two handles, two HIP streams, the headline's dtype and call (ptta_step_pipelined: every stream
+    names its next frame).  What the second stream gains is the share of the single-stream step that is latency (small launches, serial
+    chains), not bandwidth."""
     from proxytta import synth
     from proxytta.engine import Engine
     engs, keep = [], []
     for _ in range(nstreams):
-        eng = Engine(1, H, W, dtype='fp32', **HP)
+        eng = Engine(1, H, W, dtype=dtype, **HP)
         sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(MODE).items()}
         eng.load_state_dict(sd)
         for name in eng.adapted:
@@ -240,13 +302,13 @@ def two_streams_workload(steps=100, nstreams=2):
             eng.bind_adapted(name, *keep[-1])
         engs.append(eng)
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
-    frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(900 + i, H, W, 1)] for i in range(4)]
+    frames = [[[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(900 + 10 * j + i, H, W, 1)] for i in range(4)] for j in range(nstreams)]
 
     def run(k):
         for it in range(k):
-            for e, st in zip(engs, streams):
+            for j, (e, st) in enumerate(zip(engs, streams)):
                 with torch.cuda.stream(st):
-                    info, _ = e.step(*frames[it % 4])
+                    info, _ = e.step(*frames[j][it % 4], next_frame=frames[j][(it + 1) % 4])
         return info
     run(10)
     torch.cuda.synchronize()
@@ -254,7 +316,7 @@ def two_streams_workload(steps=100, nstreams=2):
     info = run(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {'workload': '%d independent MSG_CHN 1layer frame streams on one GPU (own parameters / Adam state / hipGraph each), 352x1216, batch 1' % nstreams,
+    out = {'workload': '%d independent MSG_CHN 1layer frame streams on one GPU (own parameters / Adam state each), 352x1216, batch 1, %s, ptta_step_pipelined' % (nstreams, dtype),
            'frames_per_s': steps * nstreams / dt, 'ms_per_frame': 1e3 * dt / (steps * nstreams), 'finite': bool(torch.isfinite(info).all().item())}
     for e in engs:
         e.close()
@@ -431,7 +493,7 @@ def msgchn_multi_stream(args, rank, world, dist, affinity):
     S = args.streams_per_gpu
     engs, keep = [], []
     for k in range(S):
-        eng = Engine(1, H, W, dtype='fp32', **HP)
+        eng = Engine(1, H, W, dtype=args.dtype, **HP)
         sd = {kk: torch.from_numpy(np.asarray(v)).cuda() for kk, v in synth.formula_state_dict(MODE).items()}
         eng.load_state_dict(sd)
         for name in eng.adapted:
@@ -456,7 +518,7 @@ def msgchn_multi_stream(args, rank, world, dist, affinity):
         return info
     run(args.warmup, 0)
     nblocks = 1 if args.single_block else max(10, -(-200 // max(args.steps, 1)))
-    block_s, it = [], args.warmup
+    block_s, own_block_s, it = [], [], args.warmup
     for blk in range(nblocks):
         barrier()
         t0 = time.perf_counter()
@@ -485,13 +547,16 @@ def msgchn_multi_stream(args, rank, world, dist, affinity):
         print(json.dumps({
             'metric': 'TTA frames/sec (fwd+loss+bwd+Adam) at 352x1216', 'value': world * S * args.steps / elapsed, 'unit': 'frames/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / (S * args.steps), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32 storage, bf16x3 MFMA arithmetic (fp32 accumulate)', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': DTYPE_TEXT[args.dtype], 'data': 'synthetic',
             'config': {'workload': 'MSG_CHN 1layer meta, 352x1216 KITTI-shaped synthetic, 1 TTA step/frame, batch 1 per stream',
+                       'launch': 'ptta_step_pipelined on every stream (each call names its stream\'s next frame)',
                        'parallelism': 'independent frame streams, dp%d x %d streams per GPU, no collectives' % (world, S), 'streams_per_gpu': S,
                        'note': 'NOT the headline configuration (one stream per GPU): ms_per_step is per frame over all streams of a GPU',
                        'cpu_affinity': affinity, 'finite': finite},
             'timing': {'blocks': nblocks, 'steps_timed': nblocks * args.steps * S, 'ms_per_frame_min': 1e3 * min(block_s) / (S * args.steps),
-                       'ms_per_frame_max': 1e3 * max(block_s) / (S * args.steps)}}))
+                       'ms_per_frame_max': 1e3 * max(block_s) / (S * args.steps),
+                       'per_rank_ms_per_step': {'min': min(per_rank_ms), 'median': float(np.median(per_rank_ms)), 'max': max(per_rank_ms), 'ranks': per_rank_ms,
+                                                'note': "each rank's own median block / steps (S frames per step), before the MAX over ranks"}}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -698,7 +763,7 @@ def costdcnet_cpu_baseline():
             'sample': '1 TTA step of the same 480x640 workload after one eval forward (PyTorch-CPU oracle, fp32, %.1f s/step)' % dt}
 
 
-def pipelined_self_check(dtype, k, rank=0):
+def pipelined_self_check(dtype, k, rank=0, options=None, keep=()):
     """The headline is timed on ptta_step_pipelined; this replays the first `k` frames of the timed stream on TWO fresh handles -- one through
     the pipelined call (next frame announced), one through plain ptta_step -- from the same initial parameters and compares the adapted
     parameters, the Adam moments and every step's loss_info BIT FOR BIT (what tests/test_gpu_staging_augment.py asserts under pytest, here
@@ -709,7 +774,7 @@ def pipelined_self_check(dtype, k, rank=0):
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(rank * 1000 + i, H, W, 1)] for i in range(nframes)]
     res = []
     for mode in ('pipelined', 'plain'):
-        eng = Engine(1, H, W, dtype=dtype, **HP)
+        eng = Engine(1, H, W, dtype=dtype, options=options, keep=keep, **HP)
         sd = {kk: torch.from_numpy(np.asarray(v)).cuda() for kk, v in synth.formula_state_dict(MODE).items()}
         eng.load_state_dict(sd)
         st = {name: (sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name])) for name in ADAPTED}
@@ -922,7 +987,6 @@ def main():
         eng.step(*frames[i % nframes])
     torch.cuda.synchronize()
     instrumented_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-    CLASSES = ['s1_relu_large', 's1_relu_small', 's1_plain_large', 's1_plain_small', 'strided_large', 'strided_small', 'heads', 'in_out_convs', 'rest']
     prof = [eng.profile_read(k) for k in range(len(CLASSES))]
     # dominant kernel = conv32_s1_x3_kernel<T, RELU, *> (+ its fused first-layer form): the stride-1 convolutions with ReLU on load on maps above
     # 1/4 resolution -- the class with the largest share of the step (roofline_by_class).  Rounds 1-4 priced it TOGETHER with the small-map
@@ -933,7 +997,7 @@ def main():
     finite = bool(torch.isfinite(info).all().item())
     eq_plain = None
     if pipe and world == 1 and not args.no_self_check:
-        eq_plain = pipelined_self_check(args.dtype, min(args.steps, 12), rank)
+        eq_plain = pipelined_self_check(args.dtype, min(args.steps, 12), rank, options or None, keep)
 
     if rank == 0:
         mixed = args.dtype == 'mixed'
@@ -1004,7 +1068,12 @@ def main():
                               'note': step_note,
                               'hbm_frac_per_gpu': step_bytes * (steps_per_s / world) / HBM_PEAK,
                               'hbm_frac_per_gpu_on_bf16_bytes': (ALG_ELEMENTS_PER_STEP - ALG_ELEMENTS_HOISTED) * 2 * (steps_per_s / world) / HBM_PEAK,
-                              'mfma_frac_per_gpu': 3 * ALG_FLOP_PER_STEP * (steps_per_s / world) / MFMA_BF16_PEAK},
+                              # bf16 matrix work ISSUED per step (SURVEY 8d MACs: grad-pass convs 29.34 G, proxy-pass convs 19.11 G of which the
+                              # RGB encoder's 6.93 G are hoisted, heads 28.93 G, minimal backward 29.86 G): fp32 mode 3 MFMAs per product
+                              # everywhere; mixed mode 3 for the real frames' forward only, 1 for the proxy pass, the heads and the data gradients
+                              'mfma_frac_per_gpu': (2.0 * ((3 * 29.34e9 + (19.11e9 - 6.93e9) + 28.93e9 + 29.86e9) if mixed else 3 * (107.2e9 - 6.93e9))
+                                                    * (steps_per_s / world) / MFMA_BF16_PEAK),
+                              'mfma_frac_note': 'issued bf16 MFMA FLOP (bf16x3 launches counted 3x, single-MFMA launches 1x) / 2.5 PFLOP/s dense'},
             'roofline': roof,
             'roofline_by_class': by_class,
             'timing': {'protocol': '%d blocks x %d steps, each block bracketed by barrier + synchronize, MAX over ranks; ms_per_step = median block' % (nblocks, args.steps),
@@ -1021,7 +1090,8 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_nlspn:
             out['other_workloads'] = {'msg_chn_2layers': msgchn_2layers_workload(), 'nlspn': nlspn_workload(), 'costdcnet': costdcnet_workload(),
-                                      'head_stage2': head_stage2_workload(), 'msg_chn_two_streams_per_gpu': two_streams_workload(),
+                                      'head_stage2': head_stage2_workload(), 'msg_chn_two_streams_per_gpu': two_streams_workload(dtype=args.dtype),
+                                      'msg_chn_batch': msgchn_batch_workload(dtype=args.dtype),
                                       'msg_chn_step_plus_scored_eval': msgchn_adapt_loop_workload()}
             if not args.no_cpu_baseline:
                 out['other_workloads']['nlspn']['cpu_baseline'] = nlspn_cpu_baseline()

@@ -381,6 +381,11 @@ int ptta_set_graph(ptta_handle h, int enable);         /* = ptta_set_option(h, "
  *   "stamps"        0        (diagnostic, 1:) fourteen one-thread nodes of the step's and the prefix's graphs write wall_clock64() ticks since
  *                            the step's first node into the debug tensor "stamps" -- where the branches of a replayed step start and end with
  *                            no profiler attached (tools/step_stamps.py, profiles/r05_step_stamps.txt); results unchanged
+ * Read-only keys (ptta_get_option; -22 from ptta_set_option):
+ *   "pipelined_active"  1 when ptta_step_pipelined runs as itself on this handle as configured now; 0 when it degrades to ptta_step call by call
+ *                       (generic-engine backbones, the dual-corner padded path, a statistics exchange or a gradient communicator bound,
+ *                       validation arithmetic, the profiling leg) -- same results, the call-by-call price
+ *   "thru_active"       1 when the step takes the two-stream `thru` schedule
  * bit-identical to the default: aux_stream, thru, adam_in_wgrad, fuse_first, fuse_head_bwd, mask_bits, graph; within bf16x3's own error (documented
  * in the tests): fuse_heads, heads_v2, cos_in_gemm.
  * Environment, read once per ptta_create (csrc/ptta_kernels.h ptta_create_env) because it decides allocation and arithmetic:

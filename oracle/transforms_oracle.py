@@ -355,7 +355,7 @@ def apply_draw(tf, d, arrs, padding_modes=('constant',), interpolation_modes=('n
                 if do[b]:
                     nz = (a[b].abs().sum(dim=0) > 0).nonzero(as_tuple=True)
                     count = int(nz[0].shape[0])
-                    perm = torch.randperm(count, generator=generator)[0:int(float(densities[b]) * count)]
+                    perm = torch.randperm(count, generator=generator)[0:int(densities[b].float() * count)]   # fp32 product, src/transforms.py:944
                     selected[b] = (nz[0][perm], nz[1][perm])
             res.append(remove_patches(a, do, selected, sizes))
         out = res

@@ -32,19 +32,23 @@ def pix_index(numel, k=NPIX):
     return np.unique(np.floor(np.modf(i * 0.6180339887498949)[0] * numel).astype(np.int64))
 
 
-def summarise(out, key, t):
+def summarise(out, key, t, blk=True, npix=NPIX):
     a = t.detach().numpy().astype(np.float32)
     flat = a.reshape(-1)
-    idx = pix_index(flat.size)
+    idx = pix_index(flat.size, npix)
     out[key + '_pix'] = flat[idx]
     out[key + '_sum'] = np.array(flat.sum(dtype=np.float64))
     out[key + '_abs_mean'] = np.array(np.abs(flat).mean(dtype=np.float64))
+    if not blk:
+        return
     n, c, h, w = a.shape
     k = 8 if (h % 8 == 0 and w % 8 == 0) else 4          # 228 x 304 (NYUv2): 4 x 4 blocks
     out[key + '_blk'] = a.reshape(n, c, h // k, k, w // k, k).mean(axis=(3, 5), dtype=np.float64).astype(np.float32)
 
 
-def run_case(ema, name, prepare_mode, h, w, n, steps, full_every=1, frame0=0, moments=True):
+def run_case(ema, name, prepare_mode, h, w, n, steps, full_every=1, frame0=0, moments=True, light=False, alt=False, out=None, prefix=''):
+    """light: a long-horizon sequence (the reference adapts ONE parameter set over a whole dataset, src/tta_main.py:504-636) -- per step only
+    the sampled pixels + checksums of the scored depth and loss_info; the adapted tensors at every `full_every`-th step."""
     hp = dict(HP)
     model = ema.ExternalModel_Adapt('msg_chn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], device=torch.device('cpu'))
     model._prepare_head(prepare_mode)
@@ -53,11 +57,18 @@ def run_case(ema, name, prepare_mode, h, w, n, steps, full_every=1, frame0=0, mo
     assert list(sd.keys()) == list(net.state_dict().keys()), 'key table drifted from reference'
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     params = model.adapt_parameters(mode='meta')
+    if prefix:
+        # the REFERENCE's own sensitivity: the same program from a start that differs by ONE unit in the last place of ONE adapted weight
+        # (stored under `alt/`): how far two runs of the reference itself are apart after s steps is the floor any other fp32 program sits on
+        with torch.no_grad():
+            w0 = params[0].view(-1)
+            w0[0] = torch.nextafter(w0[0], w0[0] * 2)
     opt = torch.optim.Adam(params, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'])
-    out = {'meta': np.array([h, w, n, steps, frame0], dtype=np.int64),
+    out_ = {'meta': np.array([h, w, n, steps, frame0], dtype=np.int64),
            'hp': np.array([hp['lr'], hp['betas'][0], hp['betas'][1], hp['eps'], hp['weight_decay'], hp['w_sd'], hp['w_sm'],
                            hp['w_cos'], hp['max_input_depth'], 1.0], dtype=np.float64),
-           'pix_idx': pix_index(n * h * w)}
+           'pix_idx': pix_index(n * h * w, 1024 if light else NPIX)}
+    out = out_ if out is None else out
     names = [k for k, _ in net.named_parameters() if 'meta' in k]
     for s in range(steps):
         image_np, sparse_np = synth.synthetic_frame(frame0 + s, h, w, n)
@@ -76,17 +87,19 @@ def run_case(ema, name, prepare_mode, h, w, n, steps, full_every=1, frame0=0, mo
         model.eval()
         with torch.no_grad():
             depth_eval = model.forward(image=image, sparse_depth=sparse, loss_type=LOSS_TYPE)
-        p = 's%d/' % s
-        summarise(out, p + 'depth_train', depth)
-        summarise(out, p + 'depth_eval', depth_eval)
+        p = prefix + 's%d/' % s
+        if not light:
+            summarise(out, p + 'depth_train', depth)
+        summarise(out, p + 'depth_eval', depth_eval, blk=not light, npix=1024 if light else NPIX)
         out[p + 'loss_info'] = np.array([float(info[k].detach()) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')])
-        full = (s % full_every == 0) or s == steps - 1
+        full = ((s % full_every == 0) or s == steps - 1) and not prefix
         if full:
-            e, r = emb.detach().numpy(), ref.detach().numpy()
-            idx, out[p + 'emb_rows'] = MG.sample_rows(e)
-            _, out[p + 'ref_rows'] = MG.sample_rows(r)
-            out[p + 'row_idx'] = idx
-            out[p + 'emb_shape'] = np.array(e.shape)
+            if not light:
+                e, r = emb.detach().numpy(), ref.detach().numpy()
+                idx, out[p + 'emb_rows'] = MG.sample_rows(e)
+                _, out[p + 'ref_rows'] = MG.sample_rows(r)
+                out[p + 'row_idx'] = idx
+                out[p + 'emb_shape'] = np.array(e.shape)
             state = opt.state_dict()['state']
             for i, k in enumerate(names):
                 out[p + 'grad/' + k] = grads[k].numpy()
@@ -98,6 +111,10 @@ def run_case(ema, name, prepare_mode, h, w, n, steps, full_every=1, frame0=0, mo
                 if 'running_' in k and ('proj.' in k or 'pred.' in k or 'meta' in k):
                     out[p + 'buf/' + k] = v.numpy().copy()
         print(name, 'step', s, 'loss_info', out[p + 'loss_info'], 'depth mean', float(depth.mean()), flush=True)
+    if prefix:
+        return
+    if alt:
+        run_case(ema, name, prepare_mode, h, w, n, steps, full_every, frame0, moments, light, out=out, prefix='alt/')
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), 'bytes', flush=True)
@@ -134,6 +151,14 @@ CASES = {
     'msgchn_2layers_352x1216': lambda e: run_case(e, 'msgchn_2layers_352x1216', 'meta_selfsup_seq_2layers_ema', 352, 1216, 1, 1, moments=False),
     'msgchn_1layer_64x96_seq10': lambda e: run_case(e, 'msgchn_1layer_64x96_seq10', 'meta_selfsup_seq_1layer_ema', 64, 96, 1, 10,
                                                     full_every=9, frame0=100),
+    # the reference's operating point is n_batch // ngpus frames per rank (bash/adapt/adapt_msgchn_vkitti.sh:21, src/tta_main.py:224)
+    'msgchn_1layer_352x1216_n2': lambda e: run_case(e, 'msgchn_1layer_352x1216_n2', 'meta_selfsup_seq_1layer_ema', 352, 1216, 2, 2, frame0=20),
+    'msgchn_1layer_352x1216_n4': lambda e: run_case(e, 'msgchn_1layer_352x1216_n4', 'meta_selfsup_seq_1layer_ema', 352, 1216, 4, 2, frame0=30),
+    # long horizons: one parameter set adapted over a stream of frames (src/tta_main.py:504-636)
+    'msgchn_1layer_64x96_seq200': lambda e: run_case(e, 'msgchn_1layer_64x96_seq200', 'meta_selfsup_seq_1layer_ema', 64, 96, 1, 200,
+                                                     full_every=20, frame0=1000, light=True, moments=False, alt=True),
+    'msgchn_1layer_256x320_seq30': lambda e: run_case(e, 'msgchn_1layer_256x320_seq30', 'meta_selfsup_seq_1layer_ema', 256, 320, 1, 30,
+                                                      full_every=10, frame0=2000, light=True, moments=False, alt=True),
     'eval_metrics': lambda e: run_eval_metrics(),
 }
 

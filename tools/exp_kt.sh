@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 KEY=${1:-fuse_head_bwd}; RE=${2:-first_kernel|conv_in_lds|conv32_s1_x3_kernel<false}
 for v in 0 1; do
 export PTTA_BENCH_OPTIONS=$KEY=$v
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt$v -o x -- python3 bench.py --steps 20 --warmup 10 --single-block --no-nlspn --no-cpu-baseline > /dev/null 2> gpurun_out/kt$v.log
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/kt$v -o x -- python3 bench.py --dtype ${DTYPE:-mixed} --steps 20 --warmup 10 --single-block --no-self-check --no-nlspn --no-cpu-baseline > /dev/null 2> gpurun_out/kt$v.log
 echo "== $KEY=$v"; python3 - gpurun_out/kt$v/x_kernel_trace.csv "$RE" <<'PY'
 import csv,sys,re,collections
 d=collections.defaultdict(list)

@@ -2145,7 +2145,9 @@ static int pipe_init(ptta_ctx* c) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_prefix[p], kStepEvent));
         HIPCHK(hipEventCreateWithFlags(&c->ev_rest[p], kStepEvent));
     }
-    HIPCHK(hipEventCreateWithFlags(&c->ev_entry, kStepEvent));
+    // ev_entry also publishes what the CALLER queued before the call (the next frame's H2D / peer copy) to the prefix stream: a plain
+    // event (system-scope release), unlike the handle-internal fork / join events
+    HIPCHK(hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming));
     c->pipe_ready = true;
     return 0;
 }
@@ -2604,6 +2606,13 @@ int ptta_set_option(ptta_handle c, const char* key, int value) {
 int ptta_get_option(ptta_handle c, const char* key, int* value) {
     if (!c || !key || !value) return -1;
     const std::string k(key);
+    // read-only: 1 when ptta_step_pipelined would run as itself on this handle as it is configured now, 0 when it degrades to ptta_step
+    // call by call (generic-engine backbones, the dual-corner padded path, a statistics exchange or gradient communicator bound, validation
+    // arithmetic, the profiling leg)
+    if (k == "pipelined_active") { *value = !(c->nl || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16); return 0; }
+    // read-only: 1 when the step takes the two-stream `thru` schedule (loss gradient from the valid-weight partials), as far as it can be known
+    // without the caller's stream (the second stream is created on first use)
+    if (k == "thru_active") { *value = c->nl ? 0 : (c->thru && c->cos_grad_fused && heads_v2_on(c) && c->use_aux); return 0; }
     if (c->nl) { if (k != "graph") return -38; *value = c->nl->use_graph; return 0; }
     if (k == "graph") *value = c->use_graph;
     else if (k == "aux_stream") *value = c->use_aux;

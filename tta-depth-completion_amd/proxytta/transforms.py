@@ -367,7 +367,8 @@ class Transforms(object):
                         continue
                     nz = (t[b].abs().sum(dim=0) > 0).nonzero(as_tuple=True)           # (device reduction + index list: host logic of the draw)
                     count = int(nz[0].shape[0])
-                    perm = torch.randperm(count, generator=generator)[0:int(float(densities[b]) * count)].to(dev)
+                    # int(density * n) with a float32 0-dim density, as src/transforms.py:946-947: the product is rounded to fp32 before truncation
+                    perm = torch.randperm(count, generator=generator)[0:int(densities[b].float() * count)].to(dev)
                     sel[b, nz[0][perm], nz[1][perm]] = 1
                 o = torch.empty_like(t)
                 rc = lib.ptta_remove_patches(ptr(t), ptr(o), n, t.shape[1], ch, cw, ptr(do_d), ptr(sel), ptr(ph), ptr(pw), stream)

@@ -372,6 +372,11 @@ int ptta_set_graph(ptta_handle h, int enable);         /* = ptta_set_option(h, "
  *   "thru"          1        the heads' stream joins the main stream before the loss (1: it runs on into loss + head backward)
  *   "adam_in_wgrad" 1        0: Adam is its own launch behind the weight gradient's reduction (1: that reduction applies it -- MSG_CHN 1layer, no
  *                            gradient exchange between the two; one dependent launch less at the end of the step)
+ *   "bwd_w2"        1        (PTTA_DTYPE_MIXED) 0: the narrow data-gradient convolutions take bf16-ROUNDED weights, one MFMA per product (round 5's
+ *                            form); 1: weights as bf16 hi + lo, two MFMAs per product, gradient maps still bf16 in HBM.  A rounded weight is a
+ *                            systematic 2^-9 error of the gradient's direction, the same at every pixel and step: over 150 steps at 256x320 it
+ *                            put the scored depth at 1.1e-3 from the reference (3x the reference's own 1-ulp sensitivity); with hi + lo
+ *                            weights the mixed mode stays at that floor (profiles/r06_drift.txt).  Not bit-identical to 0 by construction
  *   "fuse_first"    1        every first-layer convolution + the following 32->32 convolution as two launches (2: the RGB branch fused too)
  *   "fuse_head_bwd" 1        the prediction heads' backward as separate launches
  *   "fuse_heads"    1        proj -> pred as separate Linear launches (1: pred.0 o proj.3 folded into one weight at load time)

@@ -157,8 +157,11 @@ CASES = {
     # long horizons: one parameter set adapted over a stream of frames (src/tta_main.py:504-636)
     'msgchn_1layer_64x96_seq200': lambda e: run_case(e, 'msgchn_1layer_64x96_seq200', 'meta_selfsup_seq_1layer_ema', 64, 96, 1, 200,
                                                      full_every=20, frame0=1000, light=True, moments=False, alt=True),
-    'msgchn_1layer_256x320_seq30': lambda e: run_case(e, 'msgchn_1layer_256x320_seq30', 'meta_selfsup_seq_1layer_ema', 256, 320, 1, 30,
-                                                      full_every=10, frame0=2000, light=True, moments=False, alt=True),
+    'msgchn_1layer_256x320_seq150': lambda e: run_case(e, 'msgchn_1layer_256x320_seq150', 'meta_selfsup_seq_1layer_ema', 256, 320, 1, 150,
+                                                       full_every=25, frame0=2000, light=True, moments=False, alt=True),
+    # the headline size (BASELINE config 2) over 120 frames: ~25 min of CPU for the two trajectories
+    'msgchn_1layer_352x1216_seq120': lambda e: run_case(e, 'msgchn_1layer_352x1216_seq120', 'meta_selfsup_seq_1layer_ema', 352, 1216, 1, 120,
+                                                        full_every=30, frame0=4000, light=True, moments=False, alt=True),
     'eval_metrics': lambda e: run_eval_metrics(),
 }
 

@@ -18,7 +18,7 @@ def rel_mae(a, b, floor=1e-4):
 TWO = 'meta_selfsup_seq_2layers_ema'
 
 
-def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None, meta='1layer', head_bias=0.0, options=None):
+def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None, meta='1layer', head_bias=0.0, options=None, keep=()):
     """Engine with formula weights; returns (engine, state dict on device, adapted dict)."""
     from proxytta.engine import Engine, adapted_names
     os.environ.pop('PTTA_CONV_IMPL', None)
@@ -29,7 +29,7 @@ def make_engine(n, h, w, dtype='fp32', hp=None, gain=1.0, impl=None, meta='1laye
     elif impl == 'exact':
         os.environ['PTTA_ARITH'] = 'exact'
     hp = dict(hp or {})
-    eng = Engine(n, h, w, dtype=dtype, meta=meta, options=options, **hp)
+    eng = Engine(n, h, w, dtype=dtype, meta=meta, options=options, keep=keep, **hp)
     os.environ.pop('PTTA_CONV_IMPL', None)
     os.environ.pop('PTTA_ARITH', None)
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(TWO if meta == '2layers' else ONE, gain, head_bias).items()}

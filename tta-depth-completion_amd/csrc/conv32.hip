@@ -217,10 +217,18 @@ __device__ __forceinline__ int x3_stage_pix(int idx) { return ((idx >> 5) << 3) 
 // (Round 5 measured the narrow kernels with their ONLY weight fragment in LDS as well -- 72 registers less, three resident blocks per CU
 // without spills: the full-resolution masked stride-1 launch went from 16.2 to 19.3 us.  At one MFMA per fragment pair the A fragment's
 // 1 KB per wave and matrix instruction already takes half of the LDS's 256 B/clk; a second KB for the B fragment saturates it.)
-template <typename T>
+// W2 (narrow storage only): the WEIGHT operand as hi + lo (two MFMAs per product, a . w_lo first) -- the data gradients of the mixed mode.
+// A bf16-rounded weight is a SYSTEMATIC 2^-9 error of the gradient's direction, the same for every pixel and every step (a rounded gradient
+// value is noise that the sum over the pixels averages out): over a 150-step horizon it was what separated the mixed mode from the
+// reference (profiles/r06_drift.txt; CPU simulation tools/precision_sim.py bwd=xw vs bwd=xas).
+template <typename T, bool W2 = false>
 __device__ __forceinline__ void mma_step(f32x16& acc, const unsigned char* a, const uint4& wh, const unsigned char* wl) {
     const bf16x8 ah = __builtin_bit_cast(bf16x8, *(const uint4*)a);
     const bf16x8 bh = __builtin_bit_cast(bf16x8, wh);
+    if constexpr (sizeof(T) == 2 && W2) {
+        const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)wl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    }
     if constexpr (sizeof(T) == 4) {
         const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + Geo<T>::LO));
         const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)wl);
@@ -230,14 +238,14 @@ __device__ __forceinline__ void mma_step(f32x16& acc, const unsigned char* a, co
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
 }
 // the block's weight fragments: hi in registers (wh); fp32 storage: lo in LDS
-template <typename T>
+template <typename T, bool W2 = false>
 __device__ __forceinline__ void load_weights(uint4 (&wh)[9][2], unsigned char* wl_lds, const void* wpack, const void* wpack2, int tid, int lane) {
     const uint4* ph = (const uint4*)wpack;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 || W2) {
         const uint4* pl = (const uint4*)wpack2;
         for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = pl[idx];
     }
@@ -266,9 +274,9 @@ __device__ __forceinline__ void up_window_dma(const T* ub, int Hu, int Wu, int u
 // staged into LDS.  Each wave computes two 32-pixel rows; the hi weight fragments (72 VGPRs) stay in registers across the persistent tile
 // loop, the lo fragments (fp32 storage) in LDS.  Without the bilinear epilogue the NEXT tile's global loads are issued before this tile's
 // MFMAs and land while the matrix cores work (software prefetch across the persistent tile loop).
-template <typename T, bool RELU, bool UP, bool MASK, bool ADD>
+template <typename T, bool RELU, bool UP, bool MASK, bool ADD, bool W2 = false>
 __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
-    constexpr int STR = Geo<T>::STR, WL = Geo<T>::WL;
+    constexpr int STR = Geo<T>::STR, WL = (sizeof(T) == 4 || W2) ? 18 * 64 * 16 : 0;
     constexpr int UPH = 6, UPW = 18;                      // an 8x32 output tile reads <= 5x17 source pixels
     __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * STR + WL + (UP ? UPH * UPW * Geo<T>::UPPX : 0)];
     unsigned char* const wl_lds = lds + X3_PH * X3_PW * STR;
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
     if (PREFETCH && blockIdx.x < ntiles) issue_loads(blockIdx.x);
     // weight fragments: loaded AFTER the first tile's loads were issued so that the two L2 round trips overlap
     uint4 wh[9][2];
-    load_weights<T>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
+    load_weights<T, W2>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y0, x0;
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
                 const int ky = tap / 3, kx = tap % 3;
                 const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * STR + 16 * h;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) mma_step<T>(acc, a + 32 * k, wh[tap][k], wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
+                for (int k = 0; k < 2; ++k) mma_step<T, W2>(acc, a + 32 * k, wh[tap][k], wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
                 if (kx == 2) __builtin_amdgcn_sched_barrier(0);      // bound the ds_read prefetch depth (VGPR pressure)
             }
             // (conv + bias) + bilinear, in the reference's order; the skip comes from the LDS window, added after the quad transpose
@@ -397,9 +405,9 @@ struct FirstP {
     const uint32_t* fmask_bits; int fmask_nb;        // FMASK: sign bits of the first convolution's ReLU mask (one word per pixel), frames b % fmask_nb
     uint32_t* a_bits;                        // sign bits of the a_out map for the same frames (the backward's mask), or null
 };
-template <typename T, int CIN, bool UP, bool FMASK = false, bool RELU_MID = true, bool EMASK = false, bool EADD = false>
+template <typename T, int CIN, bool UP, bool FMASK = false, bool RELU_MID = true, bool EMASK = false, bool EADD = false, bool W2 = false>
 __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, FirstP f) {
-    constexpr int STR = Geo<T>::STR, WL = Geo<T>::WL;
+    constexpr int STR = Geo<T>::STR, WL = (sizeof(T) == 4 || W2) ? 18 * 64 * 16 : 0;
     constexpr int UPH = 6, UPW = 18;
     constexpr int K1 = 9 * CIN, NS = (K1 + 1) / 2;
     constexpr int PL_W = 36, PL_H = 12, PLANE = PL_H * PL_W;
@@ -497,7 +505,8 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
                                                      // v_mfma_f32_32x32x16_bf16 instead of fourteen v_mfma_f32_32x32x2_f32 per 32 halo pixels)
     float w1[NARF ? 1 : NS];
     uint4 w1b[2];                                    // NARF: the first convolution's weights as two bf16 B fragments (k = 16 ks + 8 h + e)
-    load_weights<T>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
+    uint4 w1l[W2 ? 2 : 1];                           // W2: their lo halves (w - bf16(w), rounded to bf16)
+    load_weights<T, W2>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
     if constexpr (NARF) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -508,6 +517,13 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
                 wv[e] = k < K1 ? f.w1[(k >> 1) * 64 + (k & 1) * 32 + i] : 0.f;
             }
             w1b[ks] = make_uint4(pack_bf2(wv[0], wv[1]), pack_bf2(wv[2], wv[3]), pack_bf2(wv[4], wv[5]), pack_bf2(wv[6], wv[7]));
+            if constexpr (W2) {
+                unsigned hi_[4], lo_[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(wv[2 * e], wv[2 * e + 1], hi_[e], lo_[e]);
+                w1b[ks] = make_uint4(hi_[0], hi_[1], hi_[2], hi_[3]);
+                w1l[ks] = make_uint4(lo_[0], lo_[1], lo_[2], lo_[3]);
+            }
         }
     } else {
 #pragma unroll
@@ -546,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
                         av[e] = h ? vb : va;
                     }
                     const uint4 af = make_uint4(pack_bf2(av[0], av[1]), pack_bf2(av[2], av[3]), pack_bf2(av[4], av[5]), pack_bf2(av[6], av[7]));
+                    if constexpr (W2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, w1l[ks]), acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, w1b[ks]), acc, 0, 0, 0);
                 }
             } else {
@@ -636,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
                     const int ky = tap / 3, kx = tap % 3;
                     const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * STR + 16 * h;
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) mma_step<T>(acc, a + 32 * k, wh[tap][k], wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
+                    for (int k = 0; k < 2; ++k) mma_step<T, W2>(acc, a + 32 * k, wh[tap][k], wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
                     if (kx == 2) __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_first_kernel(Conv32P<T> p, F
 // conv32_s1_x3_kernel: bit-identical outputs.
 #define X3S_TH 4
 #define X3S_PH 6
-template <typename T, bool RELU, bool UP, bool MASK, bool ADD>
+template <typename T, bool RELU, bool UP, bool MASK, bool ADD, bool W2 = false>
 __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
     constexpr int STR = Geo<T>::STR;
     constexpr bool F32 = sizeof(T) == 4;
@@ -677,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
     constexpr int NPIX = X3S_PH * X3_PW;                  // 204 halo pixels
     constexpr int NIT = (((NPIX + 7) / 8) * 32 + 255) / 256;      // (pixel, 8-channel group) items per thread
     bool wloaded = false;
-    uint4 wh[9][2], wl[F32 ? 9 : 1][2];
+    uint4 wh[9][2], wl[(F32 || W2) ? 9 : 1][2];
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int ty = tile % nty, tx = (tile / nty) % ntx, b = tile / (nty * ntx);
         const int y0 = ty * X3S_TH, x0 = tx << 5;
@@ -702,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
             for (int t = 0; t < 9; ++t)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) wh[t][k] = ph[(t * 2 + k) * 64 + lane];
-            if constexpr (F32) {
+            if constexpr (F32 || W2) {
                 const uint4* pl = (const uint4*)p.wpack2;
 #pragma unroll
                 for (int t = 0; t < 9; ++t)
@@ -750,6 +767,8 @@ __global__ __launch_bounds__(256, 1) void conv32_s1_small_kernel(Conv32P<T> p) {
                         const bf16x8 bl = __builtin_bit_cast(bf16x8, wl[tap][k]);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first (as conv32_s1_x3_kernel)
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    } else if constexpr (W2) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, wl[tap][k]), acc, 0, 0, 0);
                     }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
                 }
@@ -912,10 +931,10 @@ int ptta_launch_conv32_loop(const Conv32Args& a, void* buf_a, void* buf_b, int r
 // faster kernel by kernel (forward 35 -> 18 us at full resolution) but SLOWER in the replayed step (2.396 vs 2.384 ms, same
 // box): its 79 KB of LDS cannot share a CU with the 120 KB GEMM blocks of the heads that run beside decoder 3, this
 // form's 18 KB can -- reverted.
-template <typename T, int MODE, bool RELU, bool UP, bool MASK, bool ADD>
+template <typename T, int MODE, bool RELU, bool UP, bool MASK, bool ADD, bool W2 = false>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv32_direct_x3_kernel(Conv32P<T> p) {
     constexpr bool F32 = sizeof(T) == 4;
-    __shared__ __attribute__((aligned(16))) unsigned char wl_lds[(F32 ? 2 : 1) * 18 * 64 * 16];     // [hi | lo][tap][k][lane] weight fragments
+    __shared__ __attribute__((aligned(16))) unsigned char wl_lds[((F32 || W2) ? 2 : 1) * 18 * 64 * 16];     // [hi | lo][tap][k][lane] weight fragments
     const int tid = threadIdx.x, lane = tid & 63;
     const int i = lane & 31, h = lane >> 5;
     const float biasv = epi_bias(p.epi, i);               // once per kernel: ptta_common.h epi_tile
@@ -971,7 +990,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv32_direct_x3_
     {
         const uint4* ph = (const uint4*)p.wpack;
         for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + idx * 16) = ph[idx];
-        if constexpr (F32) {
+        if constexpr (F32 || W2) {
             const uint4* pl = (const uint4*)p.wpack2;
             for (int idx = tid; idx < 18 * 64; idx += 256) *(uint4*)(wl_lds + (18 * 64 + idx) * 16) = pl[idx];
         }
@@ -1002,6 +1021,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv32_direct_x3_
                     uint4 hi = v[tap][k].a;
                     if (!okl[tap]) hi = make_uint4(0u, 0u, 0u, 0u);
                     if (RELU) { hi.x = relu_pk(hi.x); hi.y = relu_pk(hi.y); hi.z = relu_pk(hi.z); hi.w = relu_pk(hi.w); }
+                    if constexpr (W2) {
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((18 + tap * 2 + k) * 64 + lane) * 16));
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hi), bl, acc, 0, 0, 0);
+                    }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, hi), bh, acc, 0, 0, 0);
                 }
             }
@@ -1028,11 +1051,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 2) void conv32_direct_x3_
 #define S2_PH (2 * S2_TH + 1)
 #define S2_PW 65
 #define S2_STR 80                                      // per pixel and k-step: hi 32 B | lo 32 B (fp32 storage) | pad 16 B
-template <typename T, bool RELU, bool MASK, bool ADD>
+template <typename T, bool RELU, bool MASK, bool ADD, bool W2 = false>
 __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
     constexpr bool F32 = sizeof(T) == 4;
     constexpr int NPIX = S2_PH * S2_PW, NIT = (NPIX * 2 + 255) / 256;
-    constexpr int WL = F32 ? 18 * 64 * 16 : 0;
+    constexpr int WL = (F32 || W2) ? 18 * 64 * 16 : 0;
     constexpr int STR = F32 ? S2_STR : 48;                          // narrow: hi 32 B | pad 16 B per pixel and k-step (three blocks per CU)
     __shared__ __attribute__((aligned(16))) unsigned char lds[NPIX * STR + WL + 16];
     unsigned char* const wl_lds = lds + NPIX * STR;
@@ -1067,7 +1090,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
     const long first = 2L * blockIdx.x, sstride = 2L * gridDim.x;       // this block's stages: 2t, 2t+1 of its tiles
     if (first < nstages) issue_loads(first);
     uint4 wh[9][2];
-    load_weights<T>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
+    load_weights<T, W2>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
     f32x16 acc;
     bool started = false;
     for (long base = first; base < nstages; base += sstride) {
@@ -1103,6 +1126,9 @@ __global__ __launch_bounds__(256, 2) void conv32_s2_lds_kernel(Conv32P<T> p) {
                         const bf16x8 al = __builtin_bit_cast(bf16x8, *(const uint4*)(a + 32));
                         const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + q) * 64 + lane) * 16));
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);   // small terms first
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    } else if constexpr (W2) {
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(wl_lds + ((tap * 2 + q) * 64 + lane) * 16));
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
                     }
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
@@ -1194,14 +1220,14 @@ static void launch_mfma(const Conv32P<T>& p, int flags, int blocks, hipStream_t 
     }
 #undef K_
 }
-template <typename T, bool RELU>
+template <typename T, bool RELU, bool W2 = false>
 static void launch_x3(const Conv32P<T>& p, int flags, int blocks, hipStream_t s) {
     // small maps: the latency-chain form (conv32_s1_small_kernel), one 4x32 tile per block
     const long tiles8 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
     if (tiles8 <= 256) {
         const long t4 = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3S_TH - 1) / X3S_TH);
         const int nb4 = (int)(t4 > 1024 ? 1024 : t4);
-#define KS_(U, M, A) hipLaunchKernelGGL((conv32_s1_small_kernel<T, RELU, U, M, A>), dim3(nb4), dim3(256), 0, s, p)
+#define KS_(U, M, A) hipLaunchKernelGGL((conv32_s1_small_kernel<T, RELU, U, M, A, W2>), dim3(nb4), dim3(256), 0, s, p)
         switch (flags) {
             case 0: KS_(false, false, false); break; case 1: KS_(true, false, false); break;
             case 2: KS_(false, true, false); break;  case 3: KS_(true, true, false); break;
@@ -1211,7 +1237,7 @@ static void launch_x3(const Conv32P<T>& p, int flags, int blocks, hipStream_t s)
 #undef KS_
         return;
     }
-#define K_(U, M, A) hipLaunchKernelGGL((conv32_s1_x3_kernel<T, RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
+#define K_(U, M, A) hipLaunchKernelGGL((conv32_s1_x3_kernel<T, RELU, U, M, A, W2>), dim3(blocks), dim3(256), 0, s, p)
     switch (flags) {
         case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;
         case 2: K_(false, true, false); break;  case 3: K_(true, true, false); break;
@@ -1221,9 +1247,9 @@ static void launch_x3(const Conv32P<T>& p, int flags, int blocks, hipStream_t s)
 #undef K_
 }
 
-template <typename T, int MODE, bool RELU>
+template <typename T, int MODE, bool RELU, bool W2 = false>
 static void launch_direct_x3(const Conv32P<T>& p, int flags, int blocks, hipStream_t s) {
-#define K_(U, M, A) hipLaunchKernelGGL((conv32_direct_x3_kernel<T, MODE, RELU, U, M, A>), dim3(blocks), dim3(256), 0, s, p)
+#define K_(U, M, A) hipLaunchKernelGGL((conv32_direct_x3_kernel<T, MODE, RELU, U, M, A, W2>), dim3(blocks), dim3(256), 0, s, p)
     switch (flags) {
         case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;
         case 2: K_(false, true, false); break;  case 3: K_(true, true, false); break;
@@ -1265,7 +1291,38 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
     constexpr bool NAR = sizeof(T) == 2;
     if (NAR && a.mask && !a.mask_bits) return -22;
     if (!a.naive && (NAR || a.x3)) {
-        p.wpack = a.w->mbf16; p.wpack2 = NAR ? nullptr : a.w->mlo;
+        p.wpack = a.w->mbf16; p.wpack2 = (NAR && !a.w2) ? nullptr : a.w->mlo;
+        // narrow storage with hi + lo weights (Conv32Args::w2): the data gradients of the mixed mode -- no bilinear epilogue there
+        if constexpr (NAR) {
+            if (a.w2) {
+                if ((flags & 1) || a.relu_in) return -22;          // (data gradients: no ReLU on load, no bilinear skip -- the other forms are not instantiated)
+                if (MODE == CONV_S1) {
+                    const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
+                    const int blocks = (int)(tiles > kS1Blocks ? kS1Blocks : tiles);
+                    launch_x3<T, false, true>(p, flags, blocks, s);
+                    PTTA_CHECK_LAUNCH();
+                    return 0;
+                }
+                const int Wt = (MODE == CONV_T2) ? p.Win : p.Wout;
+                const long items = (long)p.B * ((Wt + 31) / 32) * (MODE == CONV_T2 ? 2 : 1) * p.Hout;
+                long blocks = (items + 3) / 4; if (blocks > kNarrowBlocks) blocks = kNarrowBlocks;
+                if (MODE == CONV_S2) {
+                    const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + S2_TH - 1) / S2_TH);
+                    const int tb = (int)(tiles < kFullChipBlocks ? tiles : kFullChipBlocks);
+#define KS2W_(R, M, A) hipLaunchKernelGGL((conv32_s2_lds_kernel<T, R, M, A, true>), dim3(tb), dim3(256), 0, s, p)
+                    const bool m_ = flags & 2, a_ = flags & 4;
+                    { if (m_) { if (a_) KS2W_(false, true, true); else KS2W_(false, true, false); } else { if (a_) KS2W_(false, false, true); else KS2W_(false, false, false); } }
+#undef KS2W_
+                    PTTA_CHECK_LAUNCH();
+                    return 0;
+                }
+                if constexpr (MODE != CONV_S1) {
+                    launch_direct_x3<T, MODE, false, true>(p, flags, (int)blocks, s);
+                }
+                PTTA_CHECK_LAUNCH();
+                return 0;
+            }
+        }
         if (MODE == CONV_S1) {
             const long tiles = (long)p.B * ((p.Wout + 31) / 32) * ((p.Hout + X3_TH - 1) / X3_TH);
             const int blocks = (int)(tiles > kS1Blocks ? kS1Blocks : tiles);     // 2 resident blocks per CU, persistent
@@ -1322,7 +1379,7 @@ static int launch_conv32_t(const Conv32Args& a, hipStream_t s) {
 template <typename T>
 static int launch_first_t(const Conv32Args& a, const ConvInArgs& f, void* a_out, int a_nb, bool bwd_form, long tiles, hipStream_t s) {
     Conv32P<T> p;
-    p.in = nullptr; p.in_nb = 1; p.wpack = a.w->mbf16; p.wpack2 = sizeof(T) == 4 ? a.w->mlo : nullptr;
+    p.in = nullptr; p.in_nb = 1; p.wpack = a.w->mbf16; p.wpack2 = (sizeof(T) == 4 || a.w2) ? a.w->mlo : nullptr;
     p.epi.bias = a.bias; p.epi.up = (const T*)a.up; p.epi.up_nb = a.up_nb > 0 ? a.up_nb : 1;
     p.epi.mask = (const T*)a.mask; p.epi.mask_nb = a.mask_nb > 0 ? a.mask_nb : 1; p.epi.add1 = (const T*)a.add1; p.epi.add1_nb = a.add1_nb > 0 ? a.add1_nb : 1; p.epi.add2 = nullptr; p.epi.add2_nb = 1;
     p.epi.out_raw = (T*)a.out_raw; p.epi.out_sum = (T*)a.out_sum;          // (add1 / out_sum: the backward form only, see ptta_launch_conv32_first)
@@ -1334,6 +1391,14 @@ static int launch_first_t(const Conv32Args& a, const ConvInArgs& f, void* a_out,
     q.zero_from_b = f.zero_from_b; q.w1 = f.wfrag; q.bias1 = f.bias; q.a_out = (float*)a_out; q.a_nb = a_nb;
     q.fmask_nb = f.mask_nb > 0 ? f.mask_nb : 1; q.fmask_bits = f.mask_bits; q.a_bits = f.a_bits;
     if (bwd_form) {
+        if constexpr (sizeof(T) == 2) {
+            if (a.w2) {
+                if (a.out_sum) hipLaunchKernelGGL((conv32_s1_first_kernel<T, 1, false, true, false, true, true, true>), dim3(blocks), dim3(256), 0, s, p, q);
+                else hipLaunchKernelGGL((conv32_s1_first_kernel<T, 1, false, true, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p, q);
+                PTTA_CHECK_LAUNCH();
+                return 0;
+            }
+        }
         if (a.out_sum) hipLaunchKernelGGL((conv32_s1_first_kernel<T, 1, false, true, false, true, true>), dim3(blocks), dim3(256), 0, s, p, q);
         else hipLaunchKernelGGL((conv32_s1_first_kernel<T, 1, false, true, false, true>), dim3(blocks), dim3(256), 0, s, p, q);
         PTTA_CHECK_LAUNCH();

@@ -14,7 +14,7 @@
 #include "ptta_kernels.h"
 
 #define LOSS_PB 256          // depth-reduction blocks per sample (<= 256: one finalize thread each)
-#define LOSS_CB 1024         // cosine-reduction blocks
+#define LOSS_CB_MIN 1024     // cosine-reduction blocks (and partial slots) up to 131,072 rows; beyond: one slot per 128-row GEMM block
 #define WS_SCAL 0            // [0] coef_cos [1] coef_smx [2] coef_smy
 #define WS_SD 16             // per-sample w_sd / (N * sum_w)
 
@@ -26,14 +26,17 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 
 static __host__ __device__ inline long ws_depth_off(int N) { return WS_SD + ((N + 15) / 16) * 16; }
-static __host__ __device__ inline long ws_cos_off(int N) { return ws_depth_off(N) + (long)N * LOSS_PB * 4; }
-static __host__ __device__ inline long ws_cnt_off(int N) { return ws_cos_off(N) + LOSS_CB; }              // [N][LOSS_PB] valid-weight partials (loss_valid_count_kernel)
+// slots of the cosine term's block partials: the narrow heads' GEMM epilogue leaves one per 128-row block (heads_n.hip, epi 5), so the count
+// follows the rows (N frames per call: 209 N blocks at 352x1216); never below the 1024 the row kernels of this file launch with
+static __host__ __device__ inline int loss_cb(long R) { const long b = (R + 127) / 128; return b <= LOSS_CB_MIN ? LOSS_CB_MIN : (int)((b + 255) & ~255L); }
+static __host__ __device__ inline long ws_cnt_off(int N) { return ws_depth_off(N) + (long)N * LOSS_PB * 4 + LOSS_CB_MIN; }     // [N][LOSS_PB] valid-weight partials (loss_valid_count_kernel)
 static __host__ __device__ inline long ws_rows_off(int N) { return ws_cnt_off(N) + (long)N * LOSS_PB; }
+static __host__ __device__ inline long ws_cos_off(int N, long R) { return ws_rows_off(N) + 3 * R + 64; }                        // [loss_cb(R)] behind the per-row statistics
 
-int ptta_loss_ws_floats(int N, int H, int W, long R) { return (int)(ws_rows_off(N) + 3 * R + 64); }
+int ptta_loss_ws_floats(int N, int H, int W, long R) { return (int)(ws_cos_off(N, R) + loss_cb(R) + 64); }
 long ptta_loss_ws_rows_off(int N) { return ws_rows_off(N); }
-long ptta_loss_ws_cos_off(int N) { return ws_cos_off(N); }
-int ptta_loss_cos_blocks() { return LOSS_CB; }
+long ptta_loss_ws_cos_off(int N, long R) { return ws_cos_off(N, R); }
+int ptta_loss_cos_blocks(long R) { return loss_cb(R); }
 
 // validity_map of the TTA step = where(sparse > 0, 1, sparse) on the RAW sparse depth (src/tta_main.py:583-586); computed on the
 // fly when the caller passes no map
@@ -219,9 +222,9 @@ __device__ void loss_finalize_block(const float* __restrict__ ws, int N, int H, 
     double l_cos = 0.0;
     float wc = w_cos;
     if (has_cos) {
-        const float* cp = ws + ws_cos_off(N);
+        const float* cp = ws + ws_cos_off(N, R);
         double a = 0.0;
-        for (int b = t; b < LOSS_CB; b += 256) a += cp[b];
+        for (int b = t; b < loss_cb(R); b += 256) a += cp[b];
         l_cos = block_sum_d(a, red) / (double)R;
         if ((float)l_cos < 0.3f) wc = 0.f;                   // external_model_adapt.py:424-425
     }
@@ -264,9 +267,9 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(float* __restrict__ 
 // depth terms: the heads' backward starts as soon as the cosine rows are reduced, beside decoder 3's forward
 __global__ __launch_bounds__(256) void loss_cos_coef_kernel(float* __restrict__ ws, int N, long R, const float* __restrict__ w3) {
     __shared__ double red[4];
-    const float* cp = ws + ws_cos_off(N);
+    const float* cp = ws + ws_cos_off(N, R);
     double a = 0.0;
-    for (int b = threadIdx.x; b < LOSS_CB; b += 256) a += cp[b];
+    for (int b = threadIdx.x; b < loss_cb(R); b += 256) a += cp[b];
     const double l_cos = block_sum_d(a, red) / (double)R;
     float wc = w3[2];
     if ((float)l_cos < 0.3f) wc = 0.f;                       // external_model_adapt.py:424-425
@@ -284,13 +287,13 @@ int ptta_launch_loss_forward(const float* depth, const float* image, const float
                              float* ws, float* loss_info, hipStream_t s, int defer_finalize) {
     const int has_cos = (emb && ref) ? 1 : 0;
     if (has_cos) {
-        hipLaunchKernelGGL(loss_forward_merged_kernel, dim3(N * LOSS_PB + LOSS_CB), dim3(256), 0, s, depth, image, sparse, validity, max_input_depth,
-                           N, H, W, ws + ws_depth_off(N), emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+        hipLaunchKernelGGL(loss_forward_merged_kernel, dim3(N * LOSS_PB + loss_cb(R)), dim3(256), 0, s, depth, image, sparse, validity, max_input_depth,
+                           N, H, W, ws + ws_depth_off(N), emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N, R));
     } else {
         hipLaunchKernelGGL(loss_depth_reduce_kernel, dim3(LOSS_PB, N), dim3(256), 0, s, depth, image, sparse, validity,
                            max_input_depth, H, W, ws + ws_depth_off(N));
         if (has_cos)
-            hipLaunchKernelGGL((cos_rows_kernel<float>), dim3(LOSS_CB), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+            hipLaunchKernelGGL((cos_rows_kernel<float>), dim3(loss_cb(R)), dim3(256), 0, s, emb, ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N, R));
     }
     // defer_finalize (fused step, N <= LOSS_FIN_MAXN): ptta_launch_loss_backward(..., w3_dev, loss_info) finalises inside its kernels
     if (!defer_finalize || N > LOSS_FIN_MAXN)
@@ -309,8 +312,8 @@ int ptta_launch_loss_depth_part(const float* depth, const float* image, const fl
     return 0;
 }
 int ptta_launch_loss_cos_part(const void* emb, const void* ref, long R, int D, int N, float* ws, hipStream_t s, int narrow) {
-    if (narrow) hipLaunchKernelGGL((cos_rows_kernel<bf16_t>), dim3(LOSS_CB), dim3(256), 0, s, (const bf16_t*)emb, (const bf16_t*)ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
-    else hipLaunchKernelGGL((cos_rows_kernel<float>), dim3(LOSS_CB), dim3(256), 0, s, (const float*)emb, (const float*)ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N));
+    if (narrow) hipLaunchKernelGGL((cos_rows_kernel<bf16_t>), dim3(loss_cb(R)), dim3(256), 0, s, (const bf16_t*)emb, (const bf16_t*)ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N, R));
+    else hipLaunchKernelGGL((cos_rows_kernel<float>), dim3(loss_cb(R)), dim3(256), 0, s, (const float*)emb, (const float*)ref, R, D, ws + ws_rows_off(N), ws + ws_cos_off(N, R));
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -23,7 +23,8 @@
 #include "nlspn.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return c->fail(std::string(#x) + ": " + hipGetErrorString(e_), -100 - (int)e_); } while (0)
-#define RUN(x) do { int r_ = (x); if (r_ != 0) return c->fail(std::string(#x) + " failed", r_ < 0 ? r_ : -r_); } while (0)
+// (the message keeps the chain of failing calls: "outer failed <- inner failed <- reason")
+#define RUN(x) do { int r_ = (x); if (r_ != 0) return c->fail_chain(std::string(#x) + " failed", r_ < 0 ? r_ : -r_); } while (0)
 
 namespace {
 
@@ -143,6 +144,10 @@ struct ptta_ctx {
     // option "adam_in_wgrad": the 1layer weight gradient's reduction applies Adam itself (one launch less at the end of the step) when no
     // gradient exchange sits between the two; adam_fuse_req: set by step_tail around its backward, adam_fused: the launch took it
     int adam_in_wgrad = 1; bool adam_fuse_req = false, adam_fused = false;
+    // option "bwd_w2" (mixed mode): the narrow data-gradient launches take their weights as hi + lo (two MFMAs per product); 0 = one MFMA on
+    // bf16-rounded weights -- round 5's form, whose systematic 2^-9 weight error separates the adapted parameters from the reference's over a
+    // long horizon (profiles/r06_drift.txt)
+    int bwd_w2 = 1;
     // thru step: the valid-weight partials of the loss are computed at the start of the auxiliary stream's work (backbone), from the loss inputs
     // step_body leaves here; the loss VALUES are reduced and reported on the auxiliary stream beside the backward (backbone_backward)
     const float *cnt_sparse = nullptr, *cnt_validity = nullptr;
@@ -236,7 +241,9 @@ struct ptta_ctx {
         fb_image = fb_sparse = nullptr;
     }
 
-    int fail(const std::string& m, int code) { err = m; return code; }
+    int err_code = 0;
+    int fail(const std::string& m, int code) { err = m; err_code = code; return code; }
+    int fail_chain(const std::string& m, int code) { err = (err_code == code && !err.empty() && err.size() < 600) ? m + " <- " + err : m; err_code = code; return code; }
 
     bool oom = false;
     void* dalloc(size_t bytes) {
@@ -627,6 +634,7 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     const bool nar = e.nar || (bwd && c->nar_bwd);
     const int es_l = nar ? 2 : c->es;
     a.B = B; a.Hin = Hin; a.Win = Win; a.mode = mode; a.relu_in = relu ? 1 : 0; a.bf16 = nar ? 1 : c->bf16; a.naive = c->naive; a.x3 = c->x3;
+    a.w2 = (bwd && c->nar_bwd && c->bwd_w2) ? 1 : 0;
     if (!c->mbits.empty()) {
         // sign-bit masks: the backward reads the bits of its mask; a forward launch that starts at frame 0 of a map the backward masks
         // with writes that map's bits for the real frames (launches over the proxy half start at an offset pointer: no entry, no bits)
@@ -698,6 +706,7 @@ int conv32_first_bwd(ptta_ctx* c, hipStream_t s, const std::string& layer, ConvI
         a.mask = e.mask; a.mask_nb = e.mask_nb; a.out_raw = e.raw; a.add1 = e.add1; a.add1_nb = e.add1_nb; a.out_sum = e.sum;
         a.mask_bits = c->bits_of(e.mask); f.mask_bits = c->bits_of(f.mask);
         a.B = B; a.Hin = H; a.Win = W; a.mode = CONV_S1; a.relu_in = 0; a.bf16 = nar ? 1 : 0; a.naive = 0; a.x3 = 1;
+        a.w2 = (nar && c->bwd_w2) ? 1 : 0;
         const double px = (double)B * H * W;
         const int es_l = nar ? 2 : c->es;
         ProfScope ps(c, 2, s, (px + 9.0 * 32) * 4 + (px * 96 + 9216) * es_l, px * 9.0 * (32 + 1024), 1);
@@ -1236,7 +1245,7 @@ int heads_forward(ptta_ctx* c, hipStream_t s, int part) {      // part (heads v2
             }
             HnGemmArgs gr = gemm_h(c->feat, 0, l3, c->ref_n, 5);
             gr.E = c->emb_n; gr.rs = c->hn_rs; gr.rowstats_out = c->loss_ws + ptta_loss_ws_rows_off(c->N);
-            gr.cpart = c->loss_ws + ptta_loss_ws_cos_off(c->N); gr.cpart_n = ptta_loss_cos_blocks();
+            gr.cpart = c->loss_ws + ptta_loss_ws_cos_off(c->N, c->Rg); gr.cpart_n = ptta_loss_cos_blocks(c->Rg);
             RUN(ptta_launch_hn_gemm(gr, s));
             c->cos_rows_done = true;
         }
@@ -1811,6 +1820,7 @@ int ptta_get_adam_step(ptta_handle c, int* step, ptta_stream s) {
 int64_t ptta_embedding_rows(ptta_handle c) { return c ? (c->nl ? c->nl->rows() : c->Rg) : 0; }
 
 int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, float* depth_out, float* emb_out, float* ref_out, ptta_stream s_) {
+    if (c) c->err_code = 0;
     NLFWD(c->nl->forward_train(image, sparse, depth_out, emb_out, ref_out, (hipStream_t)s_));
 
     if (!c || !image || !sparse) return -1;
@@ -1835,6 +1845,7 @@ int ptta_forward_train(ptta_handle c, const float* image, const float* sparse, f
 }
 
 int ptta_forward_eval(ptta_handle c, const float* image, const float* sparse, float* depth_out, ptta_stream s_) {
+    if (c) c->err_code = 0;
     NLFWD(c->nl->forward_eval(image, sparse, depth_out, (hipStream_t)s_));
 
     if (!c || !image || !sparse || !depth_out) return -1;
@@ -2043,6 +2054,7 @@ static int step_tail(ptta_handle c, const float* loss_image, const float* sparse
 
 int ptta_step(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity,
               float* depth_out, float* loss_info_out, ptta_stream s_) {
+    if (c) c->err_code = 0;
     if (!c || !image || !sparse) return -1;
     if (c->nl) return c->nl->step(image, loss_image, sparse, validity, depth_out, loss_info_out, (hipStream_t)s_);
     RUN(pipe_quiesce(c));
@@ -2208,6 +2220,7 @@ int ptta_pipeline_stream(ptta_handle c, ptta_stream* out) {
 // staging buffers when it is announced: the caller's buffers only have to hold it until this call's copies have run on the prefix stream.
 int ptta_step_pipelined(ptta_handle c, const float* image, const float* loss_image, const float* sparse, const float* validity, uint64_t frame_token,
                         const float* next_image, const float* next_sparse, uint64_t next_token, float* depth_out, float* loss_info_out, ptta_stream s_) {
+    if (c) c->err_code = 0;
     if (!c || !image || !sparse) return -1;
     if (c->nl || c->prof_on || c->dual || c->stat_sync.on() || c->grad_comm || c->naive || c->bf16) {
         const int rc = ptta_step(c, image, loss_image, sparse, validity, depth_out, loss_info_out, s_);
@@ -2584,6 +2597,7 @@ int ptta_set_option(ptta_handle c, const char* key, int value) {
     if (k == "aux_stream") f = &c->use_aux;
     else if (k == "thru") f = &c->thru;
     else if (k == "adam_in_wgrad") f = &c->adam_in_wgrad;
+    else if (k == "bwd_w2") f = &c->bwd_w2;
     else if (k == "fuse_first") { f = &c->fuse_first; hi = 2; }
     else if (k == "fuse_head_bwd") f = &c->fuse_head_bwd;
     else if (k == "fuse_heads") f = &c->fuse_heads;
@@ -2593,7 +2607,7 @@ int ptta_set_option(ptta_handle c, const char* key, int value) {
     else if (k == "stamps") f = &c->stamps;
     else return c->fail("ptta_set_option: unknown key '" + k + "'", -22);
     if (value < lo || value > hi) return c->fail("ptta_set_option: value out of range for '" + k + "'", -22);
-    if (c->mixed && k != "aux_stream" && k != "thru" && k != "adam_in_wgrad" && k != "stamps" && value != 1)
+    if (c->mixed && k != "aux_stream" && k != "thru" && k != "adam_in_wgrad" && k != "bwd_w2" && k != "stamps" && value != 1)
         return c->fail("ptta_set_option: the mixed mode is defined on the default kernels ('" + k + "' stays 1)", -38);
     if (k == "aux_stream" && c->pre_sync_graph >= 0) { c->pre_sync_aux = value; return 0; }      // statistics exchange active: takes effect when it ends
     if (*f == value) return 0;
@@ -2618,6 +2632,7 @@ int ptta_get_option(ptta_handle c, const char* key, int* value) {
     else if (k == "aux_stream") *value = c->use_aux;
     else if (k == "thru") *value = c->thru;
     else if (k == "adam_in_wgrad") *value = c->adam_in_wgrad;
+    else if (k == "bwd_w2") *value = c->bwd_w2;
     else if (k == "fuse_first") *value = c->fuse_first;
     else if (k == "fuse_head_bwd") *value = c->fuse_head_bwd;
     else if (k == "fuse_heads") *value = c->fuse_heads;

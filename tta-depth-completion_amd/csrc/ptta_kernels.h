@@ -40,6 +40,7 @@ struct Conv32Args {
     int B = 1, Hin = 0, Win = 0;    // input spatial size; output size follows from mode
     int mode = CONV_S1; int relu_in = 0; int bf16 = 0; int naive = 0;
     int x3 = 0;          // fp32 storage: bf16x3 arithmetic on the bf16 matrix cores (stride-1 only)
+    int w2 = 0;          // narrow storage: the weight operand as hi + lo, two MFMAs per product (the mixed mode's data gradients)
     // sign-bit masks (ptta_common.h Epi): fp32 storage, non-naive kernels only -- the caller passes them only in that mode
     const uint32_t* mask_bits = nullptr;       // backward: replaces the reads of `mask` (which stays set for the other modes)
     uint32_t* bits_out = nullptr; int bits_nb = 0; int bits_sum = 0;      // forward: bits of out_sum (bits_sum) or out_raw, frames b < bits_nb
@@ -199,7 +200,7 @@ struct HnBnOut {                 // what bn_finalize_kernel (heads.hip) writes: 
 };
 int ptta_launch_hn_moments(const void* X, int x_bf16, long R, int npass, const float* W0, const float* b0, double* scratch, float* part, const HnBnOut* bn,
                            hipStream_t s);
-long ptta_loss_ws_cos_off(int N); int ptta_loss_cos_blocks();        // loss.hip: where the cosine term's block partials live in the workspace
+long ptta_loss_ws_cos_off(int N, long R); int ptta_loss_cos_blocks(long R);        // loss.hip: where the cosine term's block partials live in the workspace
 int ptta_launch_hn_gemm(const HnGemmArgs& a, hipStream_t s);
 
 // ---- loss.hip ---------------------------------------------------------------------------------

@@ -23,9 +23,14 @@ from oracle.proxytta_oracle import AdamState, adapt_loss, mdconv_forward
 BN_EPS = 1e-5
 
 
+BN_RUNNING = [False]       # stage-2 head trainer only (head_forward below): BatchNorm2d in eval mode, from the loaded running statistics
+
+
 def _bn(P, pre, x):
     """BatchNorm2d after adapt_parameters('meta_bn') (AD:322-337): running statistics dropped, so batch statistics
-    are used in train AND eval mode."""
+    are used in train AND eval mode.  Under `train(prepare=True)` (AD:360-368, stage 2) the module is in eval mode instead."""
+    if BN_RUNNING[0]:
+        return F.batch_norm(x, P[pre + '.running_mean'], P[pre + '.running_var'], P[pre + '.weight'], P[pre + '.bias'], False, 0.1, BN_EPS)
     return F.batch_norm(x, None, None, P[pre + '.weight'], P[pre + '.bias'], True, 0.1, BN_EPS)
 
 
@@ -223,3 +228,75 @@ class NlspnOracle:
         return {'depth': depth.detach(), 'emb': emb.detach(), 'ref': ref.detach(),
                 'loss_info': {k: float(v.detach()) for k, v in info.items()},
                 'grads': {k: g for k, g in zip(self.names, grads)}}
+
+
+# ---- stage-2 head trainer: src/head_main.py:464-480 on NLSPNModel_Adapt._rgbd_meta_contrast_prepare (NM:1014-1060) ----
+_BUF = ('running_mean', 'running_var', 'num_batches_tracked')
+
+
+def head_names(P):
+    return [k for k in P if k.startswith(('proj.', 'pred.')) and not k.endswith(_BUF)]
+
+
+def update_head(P, tau=0.999):
+    """_update_head (NM:1314-1316): proj_t <- tau proj_t + (1 - tau) proj over parameters()."""
+    with torch.no_grad():
+        for k in P:
+            if k.startswith('proj_t.') and not k.endswith(_BUF):
+                P[k].copy_(P[k] * tau + P['proj.' + k[len('proj_t.'):]] * (1.0 - tau))
+
+
+def mlp_train(P, prefix, x):
+    """MLP with its BatchNorm1d in train mode AND tracked: batch statistics, running statistics updated in place (momentum 0.1)."""
+    h = F.linear(x, P[prefix + '.0.weight'], P[prefix + '.0.bias'])
+    h = F.batch_norm(h, P[prefix + '.1.running_mean'], P[prefix + '.1.running_var'], P[prefix + '.1.weight'], P[prefix + '.1.bias'], True, 0.1, BN_EPS)
+    P[prefix + '.1.num_batches_tracked'] += 1
+    return F.linear(F.relu(h), P[prefix + '.3.weight'], P[prefix + '.3.bias'])
+
+
+def head_forward(P, image, sparse_depth, reverse, max_input_depth=None, tau=0.999, features=None):
+    """NM:1028-1058.  `features(P, image, sparse)` -> rows tensor [R, C] of one backbone pass (default: fe6 of this file's encoder, BatchNorm2d in
+    eval mode as train(prepare=True) leaves it, AD:360-368); the zero-image pass is the same function on zeros_like(image)."""
+    if max_input_depth is not None:
+        sparse_depth = torch.clamp(sparse_depth, 0, max_input_depth)
+    if features is None:
+        def features(P_, img, sd):
+            BN_RUNNING[0] = True
+            try:
+                fe6 = encoder(P_, img, sd)[5]
+            finally:
+                BN_RUNNING[0] = False
+            return fe6.permute(0, 2, 3, 1).reshape(-1, fe6.shape[1])
+    with torch.no_grad():
+        rows = features(P, image, sparse_depth)
+        rows_n = features(P, torch.zeros_like(image), sparse_depth)
+    update_head(P, tau)
+    a, b = (rows_n, rows) if reverse else (rows, rows_n)
+    emb = mlp_train(P, 'pred', mlp_train(P, 'proj', a.detach()))
+    with torch.no_grad():
+        ref = mlp_train(P, 'proj_t', b)
+    return emb, ref
+
+
+class HeadTrainerOracle:
+    """Adam over prepare_parameters('head_selfsup_ema') (AD:261-265): the twelve proj.* / pred.* tensors; all of them receive a gradient in
+    both directions (the reference branch goes through proj_t)."""
+
+    def __init__(self, state_dict, loss_type='head_selfsup_seq_ema_reverse', max_input_depth=None, lr=2e-4, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, tau=0.999, features=None):
+        self.reverse = 'reverse' in loss_type
+        self.P = {k: torch.as_tensor(v).clone() for k, v in state_dict.items()}
+        self.names = head_names(self.P)
+        for k in self.names:
+            self.P[k].requires_grad_(True)
+        self.max_input_depth, self.tau, self.features = max_input_depth, tau, features
+        self.opt = AdamState([self.P[k] for k in self.names], lr, betas, eps, weight_decay)
+
+    def step(self, image, sparse_depth):
+        emb, ref = head_forward(self.P, image, sparse_depth, self.reverse, self.max_input_depth, self.tau, self.features)
+        e, r = F.normalize(emb, dim=-1, p=2), F.normalize(ref, dim=-1, p=2)
+        loss = (2 - 2 * (e * r).sum(-1)).mean()                       # prepare_loss, src/external_model_adapt.py:524-541
+        params = [self.P[k] for k in self.names]
+        grads = torch.autograd.grad(loss, params)
+        self.opt.step(params, grads)
+        return {'loss': float(loss.detach()), 'emb': emb.detach(), 'ref': ref.detach(), 'grads': dict(zip(self.names, grads))}

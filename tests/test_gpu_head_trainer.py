@@ -307,3 +307,138 @@ def test_head_trainer_with_the_2layers_meta_layer():
         if 'conv1_rgb_meta' in k and 'running' in k:
             np.testing.assert_allclose(sd[k].cpu().numpy(), o.P[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
     eng.close()
+
+
+# ---- the same trainer on the generic engine: NLSPN and CostDCNet handles (csrc/ghead.hip) -----------------------------------------------------
+GENERIC_HEAD_PARAMS = tuple('%s.%s.%s' % (m, l, t) for m in ('proj', 'pred') for l in ('0', '1', '3') for t in ('weight', 'bias'))
+GENERIC_HEAD_TARGETS = tuple('proj_t' + k[4:] for k in GENERIC_HEAD_PARAMS[:6])
+
+
+def _rows_check(z, key, value, rtol, atol, what):
+    value = value.detach().cpu().numpy() if torch.is_tensor(value) else np.asarray(value)
+    if key in z.files:
+        np.testing.assert_allclose(value, z[key], rtol=rtol, atol=atol, err_msg=what)
+        return
+    rows = z[key + '#rows']
+    idx = np.linspace(0, value.shape[0] - 1, rows.shape[0]).astype(np.int64)
+    np.testing.assert_allclose(value[idx], rows, rtol=rtol, atol=atol, err_msg=what)
+    s = z[key + '#sum']
+    assert abs(value.sum(dtype=np.float64) - s[0]) <= rtol * s[1] + atol * value.size, what
+
+
+def make_generic_head_engine(backbone, n, h, w, hp, tau):
+    from tests.golden.make_golden_head_generic import perturbed_target
+    if backbone == 'nlspn':
+        from tests.test_gpu_nlspn import HP as BHP
+        eng = Engine(n, h, w, backbone='nlspn', legacy_offset=True, **BHP)
+        sd_np = synth.formula_state_dict_nlspn()
+    else:
+        from tests.test_gpu_costdcnet import HP as BHP
+        eng = Engine(n, h, w, backbone='costdcnet', **BHP)
+        sd_np = synth.formula_state_dict_costdcnet()
+    sd_np.update(perturbed_target(sd_np))
+    sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in sd_np.items()}
+    eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32})
+    keep = {}
+    for k in eng.adapted:
+        keep[k] = (sd[k].clone().contiguous(), torch.zeros_like(sd[k]), torch.zeros_like(sd[k]))
+        eng.bind_adapted(k, *keep[k])
+    moments = {}
+    for k in GENERIC_HEAD_PARAMS:
+        moments[k] = (torch.zeros_like(sd[k]), torch.zeros_like(sd[k]))
+        eng.bind_head(k, sd[k], *moments[k])
+    for k in GENERIC_HEAD_TARGETS:
+        eng.bind_head(k, sd[k])
+    eng.set_head_hparams(tau=tau, adam_step=0, **hp)
+    return eng, sd, sd_np, (keep, moments)
+
+
+def _generic_head_frame(backbone, s, h, w, n):
+    if backbone == 'nlspn':
+        from tests.test_gpu_nlspn import nlspn_frame
+        return nlspn_frame(s, h, w, n)[1:]
+    from tests.test_gpu_costdcnet import costdc_frame
+    return costdc_frame(s, h, w, n)[1:]
+
+
+@pytest.mark.parametrize('name', ['head_nlspn_forward_48x80_n2', 'head_nlspn_reverse_48x80_n2', 'head_nlspn_reverse_96x320'])
+def test_generic_head_trainer_reproduces_reference(golden_dir, name):
+    """Stage 2 (src/head_main.py:464-480) on an NLSPN / CostDCNet handle against the REAL reference's vectors
+    (tests/golden/make_golden_head_generic.py): embeddings, loss, all twelve gradients per step, then the trained parameters, the EMA target
+    and the BatchNorm1d running statistics.  Bounds as for the MSG_CHN trainer's default arithmetic (bf16x3 products): first step 2x measured."""
+    backbone = name.split('_')[1]
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = (int(v) for v in z['meta'][:4])
+    lr, b1, b2, eps, wd, tau = (float(v) for v in z['hp'])
+    reverse = 'reverse' in str(z['loss_type'])
+    eng, sd, _, keep = make_generic_head_engine(backbone, n, h, w, dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd), tau)
+    for s in range(steps):
+        image, sparse = (torch.from_numpy(a).cuda() for a in _generic_head_frame(backbone, s, h, w, n))
+        emb, ref = eng.head_forward(image, sparse, reverse)
+        loss = eng.head_backward()
+        p = 's%d/' % s
+        idx = z[p + 'row_idx']
+        np.testing.assert_allclose(emb.cpu().numpy()[idx], z[p + 'emb_rows'], rtol=2e-3, atol=5e-4 if s == 0 else 8e-3)
+        np.testing.assert_allclose(ref.cpu().numpy()[idx], z[p + 'ref_rows'], rtol=2e-3, atol=5e-4 if s == 0 else 8e-3)
+        assert abs(float(loss) - float(z[p + 'loss'])) < (5e-5 if s == 0 else 3e-4), (s, float(loss), float(z[p + 'loss']))
+        for k in GENERIC_HEAD_PARAMS:
+            g = eng.head_grad(k, sd[k])
+            assert g is not None and bool(z[p + 'has_grad/' + k]), k
+            g = g.cpu().numpy()
+            key = p + 'grad/' + k
+            want = z[key] if key in z.files else z[key + '#rows']
+            mine = g if key in z.files else g[np.linspace(0, g.shape[0] - 1, want.shape[0]).astype(np.int64)]
+            if np.abs(want).max() < 1e-7:            # a bias in front of a BatchNorm: mathematically zero
+                assert np.abs(mine).max() < 1e-5, k
+                continue
+            d = np.abs(mine - want)
+            tmax, tmean = GRAD_TOL['default'][s == 0]
+            assert d.max() <= tmax * np.abs(want).max() + 1e-12, (k, s, d.max(), np.abs(want).max())
+            assert d.mean() <= tmean * np.abs(want).mean() + 1e-12, (k, s, d.mean(), np.abs(want).mean())
+        eng.head_adam_step()
+    torch.cuda.synchronize()
+    last = 's%d/after/' % (steps - 1)
+    for k in sd:
+        if not k.startswith(('proj', 'pred')):
+            continue
+        if k in GENERIC_HEAD_PARAMS:
+            _rows_check(z, last + k, sd[k], 0, 2.5 * lr * steps, k)                      # Adam's +-lr moves: bounded by the total travel
+        elif k.endswith('num_batches_tracked'):
+            continue                                                                     # int64 buffers are not bound on this engine
+        elif k.startswith('proj_t.') and not k.endswith(('running_mean', 'running_var')):
+            _rows_check(z, last + k, sd[k], 1e-6, (1 - tau) * 2.5 * lr * steps * steps + 1e-7, k)      # EMA of a parameter that itself moved by Adam
+        elif 'running' in k:
+            _rows_check(z, last + k, sd[k], 5e-4, 2e-2, k)
+    eng.close()
+
+
+def test_generic_head_step_equals_split_calls_and_feeds_the_tta_step():
+    """ptta_head_step = forward + backward + adam_step bit for bit on an NLSPN handle, the loss goes down, and a TTA step on the same handle
+    afterwards runs with the trained heads (its embeddings differ from an untrained handle's)."""
+    n, h, w = 1, 48, 80
+    hp = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    out = []
+    for fused in (False, True):
+        eng, sd, _, _ = make_generic_head_engine('nlspn', n, h, w, hp, 0.999)
+        losses = []
+        for s in range(3):
+            image, sparse = (torch.from_numpy(a).cuda() for a in _generic_head_frame('nlspn', s, h, w, n))
+            if fused:
+                losses.append(eng.head_step(image, sparse, True))
+            else:
+                eng.head_forward(image, sparse, True, want=False)
+                losses.append(eng.head_backward())
+                eng.head_adam_step()
+        torch.cuda.synchronize()
+        depth, emb, ref = eng.forward_train(image, sparse)
+        out.append((torch.cat(losses).cpu(), {k: sd[k].cpu().clone() for k in GENERIC_HEAD_PARAMS + GENERIC_HEAD_TARGETS}, emb.cpu().clone()))
+        eng.close()
+    assert torch.equal(out[0][0], out[1][0])
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    assert float(out[0][0][-1]) < float(out[0][0][0])
+    assert torch.equal(out[0][2], out[1][2])
+    eng, sd, _, _ = make_generic_head_engine('nlspn', n, h, w, hp, 0.999)
+    _, emb0, _ = eng.forward_train(image, sparse)
+    assert float((emb0.cpu() - out[0][2]).abs().max()) > 1e-3          # the trained heads are the ones the TTA forward runs
+    eng.close()

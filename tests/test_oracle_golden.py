@@ -388,7 +388,7 @@ def _check_put(z, key, value, rtol, atol, what):
         np.testing.assert_allclose(value, z[key], rtol=rtol, atol=atol, err_msg=what)
     else:
         rows = z[key + '#rows']
-        idx = np.linspace(0, value.shape[0] - 1, 24).astype(np.int64)
+        idx = np.linspace(0, value.shape[0] - 1, rows.shape[0]).astype(np.int64)        # (24 sampled rows in the MSG_CHN fixtures, 8 in the generic ones)
         np.testing.assert_allclose(value[idx], rows, rtol=rtol, atol=atol, err_msg=what)
         s = z[key + '#sum']
         assert abs(value.sum(dtype=np.float64) - s[0]) <= rtol * s[1] + atol * value.size, what
@@ -427,6 +427,47 @@ def test_head_trainer_oracle_matches_reference(golden_dir, name):
             if 'running' in k:
                 tol = 2e-4          # statistics of activations downstream of Adam-updated weights (first-step sign noise)
             _check_put(z, 's%d/after/%s' % (steps - 1, k), o.P[k].detach().numpy(), 1e-5, tol, k)
+
+
+def _head_generic_check(z, o, steps, frames, lr):
+    for s in range(steps):
+        image, sparse = frames(s)
+        r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+        p = 's%d/' % s
+        assert abs(r['loss'] - float(z[p + 'loss'])) < (2e-6 if s == 0 else 3e-5), (s, r['loss'], float(z[p + 'loss']))
+        idx = z[p + 'row_idx']
+        at = 2e-5 if s == 0 else 1e-3         # later steps carry Adam's first-step sign noise of near-zero gradient entries
+        np.testing.assert_allclose(r['emb'].numpy()[idx], z[p + 'emb_rows'], rtol=1e-4, atol=at)
+        np.testing.assert_allclose(r['ref'].numpy()[idx], z[p + 'ref_rows'], rtol=1e-4, atol=at)
+        for k in z['head_names']:
+            k = str(k)
+            assert bool(z[p + 'has_grad/' + k]) and k in r['grads'], k
+            g = r['grads'][k].numpy()
+            if np.abs(g).max() < 1e-7 and z.get(p + 'grad/' + k) is not None and np.abs(z[p + 'grad/' + k]).max() < 1e-7:
+                continue                      # a bias in front of a BatchNorm: mathematically zero, rounding noise on both sides
+            _check_put(z, p + 'grad/' + k, g, 2e-3 if s == 0 else 3e-2, 3e-8 if s == 0 else 3e-6, k)
+    for k in o.P:
+        if k.startswith(('proj', 'pred')):
+            tol = 3 * lr * steps if k in o.names else (1e-6 + (3 * lr * steps * steps * 1e-3 if k.startswith('proj_t') else 0.0))
+            if 'running' in k:
+                tol = 2e-3          # statistics of activations downstream of Adam-updated weights (first-step sign noise)
+            _check_put(z, 's%d/after/%s' % (steps - 1, k), o.P[k].detach().numpy(), 1e-5, tol, k)
+
+
+@pytest.mark.parametrize('name', ['head_nlspn_forward_48x80_n2', 'head_nlspn_reverse_48x80_n2', 'head_nlspn_reverse_96x320'])
+def test_nlspn_head_trainer_oracle_matches_reference(golden_dir, name):
+    """Stage 2 on the NLSPN backbone (src/head_main.py:464-480 through nlspnmodel_adapt.py:1014-1060): oracle/nlspn_oracle.py HeadTrainerOracle
+    against the REAL reference (tests/golden/make_golden_head_generic.py)."""
+    from oracle import nlspn_oracle as NO
+    from tests.golden.make_golden_head_generic import perturbed_target
+    from tests.test_gpu_nlspn import nlspn_frame
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = (int(v) for v in z['meta'])
+    lr, b1, b2, eps, wd, tau = (float(v) for v in z['hp'])
+    sd = synth.formula_state_dict_nlspn()
+    sd.update(perturbed_target(sd))
+    o = NO.HeadTrainerOracle(sd, str(z['loss_type']), max_input_depth=80.0, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, tau=tau)
+    _head_generic_check(z, o, steps, lambda s: nlspn_frame(s, h, w, n)[1:], lr)
 
 
 @pytest.mark.skipif(not os.path.exists('/root/reference/external_src/costdcnet/weights/enc3d.pth'), reason='needs the reference tree with its pretrained weights (build container)')

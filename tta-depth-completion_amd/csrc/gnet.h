@@ -88,6 +88,9 @@ struct Op {
     bool act_first = false;           // with a residual: y = relu(act(bn(x)) + res) instead of relu(bn(x) + res)
     int stat_repeats = 1;             // the reference runs this layer `repeats` times per training forward on the same input
     float *rm = nullptr, *rv = nullptr; long long* nbt = nullptr;
+    float *rm_own = nullptr, *rv_own = nullptr;   // BatchNorm2d (not tracked): the LOADED running statistics, used by the stage-2 head trainer only
+    bool has_running = false;
+    bool no_dx = false;               // (CONV) no data gradient into the source although it has a gradient buffer (head trainer: detached input)
     float* st_eval = nullptr;         // tracked: eval-mode affine [mean, inv, scale, shift][C] of the running statistics
     mutable bool st_eval_valid = false;   // written by the last training forward's finalize (or an eval forward); cleared by every load()
     // func: fx = tensors whose gradient buffers the backward closure writes (first_x[k] tells it to overwrite or accumulate)
@@ -138,6 +141,9 @@ struct GNet {
     int norm_on = 0; float norm_div = 1.f, norm_mean[3] = {0, 0, 0}, norm_std[3] = {1, 1, 1};
     bool fwd_valid = false;
     int max_bn_C = 16;
+    // stage-2 head trainer (ghead.hip): `train(prepare=True)` of the reference puts every BatchNorm2d of the backbone into eval mode -- while
+    // bn_prepare is set, BN ops that are not `tracked` (= the BatchNorm2d's) normalise every pass with their LOADED running statistics
+    int bn_prepare = 0;
     PttaStatSync stat_sync;               // SyncBatchNorm exchange (ptta_set_stat_sync); world == 1: off
     void* grad_comm = nullptr;            // RCCL communicator of the gradient all-reduce inside step() (ptta_set_grad_sync_rccl)
 
@@ -175,6 +181,37 @@ struct GNet {
     virtual long rows() const = 0;
     virtual int emb_dim() const = 0;
     virtual int load_extra(const std::string& name, const float* src, const int64_t* shape, int ndim, hipStream_t s) { (void)src; (void)shape; (void)ndim; (void)s; return fail("unknown state_dict key " + name, -2); }
+    // ---- stage-2 head trainer on this engine (ghead.hip; include/ptta.h ptta_head_*) ---------------------------------------
+    struct HeadSpec { int x_real = -1, xw_real = 0, x_proxy = -1, xw_proxy = 0, hidden = 0, out = 0; };
+    virtual int head_spec(HeadSpec*) { return fail("the stage-2 head trainer is not built for this backbone", -38); }
+    // both no-gradient backbone passes up to the heads' input rows, BatchNorm2d from running statistics (bn_prepare is set by the caller)
+    virtual int head_features(const float* image, const float* sparse, hipStream_t s) { (void)image; (void)sparse; (void)s; return fail("the stage-2 head trainer is not built for this backbone", -38); }
+    struct HeadTgt { std::string name; long n = 0; float* p = nullptr; };
+    struct HeadTrain {
+        bool built = false, fwd_ok = false, bwd_ok = false;
+        int reverse = -1;                       // wiring of the built program (-1: none yet)
+        HeadSpec spec;
+        std::vector<Op> ops;                    // proj.{0,1,3} on one pass, proj_t.{0,1,3} on the other, pred.{0,1,3} on proj's output
+        std::vector<Adapted> adapted;           // the twelve trained tensors, reference order (proj.0.w, proj.0.b, proj.1.w, ... pred.3.b)
+        std::map<std::string, int> aid;
+        float* gall = nullptr; long gall_n = 0;
+        std::vector<HeadTgt> tgt;               // proj_t.{0,1,3}.{weight,bias}: bound, written by the EMA
+        PttaAdamEntry *adam_tab = nullptr, *etab = nullptr; unsigned* ticket = nullptr;
+        std::vector<PttaAdamEntry> adam_host, etab_host; bool adam_dirty = true, etab_dirty = true; long etab_total = 0;
+        float *hyper = nullptr, *tau2 = nullptr, *loss = nullptr, *loss_part = nullptr;
+        int* step_dev = nullptr;
+        int t_h[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};      // [proj, proj_t, pred][hidden, activation, out]
+        int t_emb = -1, t_ref = -1;
+    } head;
+    int head_build(int reverse);
+    int head_bind(const char* name, float* p, float* m, float* v);
+    int head_set_hparams(float lr, float b1, float b2, float eps, float wd, float tau, int adam_step, hipStream_t s);
+    int head_reload(hipStream_t s);
+    int head_forward(const float* image, const float* sparse, int reverse, float* emb_out, float* ref_out, hipStream_t s);
+    int head_backward(float* loss_out, hipStream_t s);
+    int head_adam_step(hipStream_t s);
+    int head_get_grad(const char* name, float* dst, int64_t capacity, int* has_grad_host, hipStream_t s);
+    int head_sync_packed(bool targets_too, hipStream_t s);
     virtual int debug_extra(const std::string& nm, const float** src, long* n) { (void)src; (void)n; return fail("unknown debug tensor " + nm, -2); }
 
     int fail(const std::string& m, int code) { err = m; return code; }
@@ -257,12 +294,13 @@ struct GNet {
         o.train_only = train_only; o.bwd = bwd;
         const int C = T[x].C;
         if (C > max_bn_C) max_bn_C = C;
-        if (frozen) frozen_bn[bname] = std::make_pair(falloc(C), falloc(C));
+        if (frozen) { if (!frozen_bn.count(bname)) frozen_bn[bname] = std::make_pair(falloc(C), falloc(C)); }
         else {      // a backbone may have reserved the entries already (to fix their place in the adapted list)
             o.ad_g = aid.count(bname + ".weight") ? aid[bname + ".weight"] : add_adapted(bname + ".weight", C);
             o.ad_beta = aid.count(bname + ".bias") ? aid[bname + ".bias"] : add_adapted(bname + ".bias", C);
         }
         o.st = falloc((size_t)4 * 2 * C); o.st_eval = falloc((size_t)4 * C);
+        o.rm_own = falloc(C); o.rv_own = falloc(C);
         // statistics fused into the producing convolution's epilogue when that is the stride-1 matrix-core kernel
         for (int k = (int)ops.size() - 1; k >= 0; --k) {
             Op& pr = ops[k];
@@ -381,8 +419,10 @@ struct GNet {
     int run_bn_fwd(const Op& o, bool train, hipStream_t s);
     int run_conv_bwd(const Op& o, hipStream_t s);
     int run_bn_bwd(const Op& o, hipStream_t s);
-    int run_ops_fwd(bool train, hipStream_t s) {
+    int run_ops_fwd(bool train, hipStream_t s, int limit = -1) {
+        int idx = 0;
         for (const Op& o : ops) {
+            if (limit >= 0 && idx++ >= limit) break;
             if (o.train_only && !train) continue;
             const int rc = o.kind == gnet::K_CONV ? run_conv_fwd(o, train, s) : (o.kind == gnet::K_BN ? run_bn_fwd(o, train, s) : o.ffwd(train, s));
             if (rc) return rc;

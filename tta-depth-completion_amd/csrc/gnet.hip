@@ -33,6 +33,14 @@ int GNet::load(const char* name_c, const void* tensor_, const int64_t* shape, in
         NCHK(hipMemcpyAsync(dst, src, (size_t)shape[0] * sizeof(float), hipMemcpyDeviceToDevice, s));
         return 0;
     }
+    if (leaf == "running_mean" || leaf == "running_var") {
+        // BatchNorm2d of the backbone: the TTA step never reads them (adapt_parameters('meta_bn') drops them), the stage-2 head trainer does
+        for (Op& o : ops)
+            if (o.kind == K_BN && !o.tracked && o.bname == base && o.rm_own && ndim == 1 && shape[0] == T[o.x[0]].C) {
+                NCHK(hipMemcpyAsync(leaf == "running_mean" ? o.rm_own : o.rv_own, src, (size_t)shape[0] * sizeof(float), hipMemcpyDeviceToDevice, s));
+                o.has_running = true;
+            }
+    }
     auto it = convs.find(base);
     if (it == convs.end()) return load_extra(name, src, shape, ndim, s);
     GConvW& cw = it->second;
@@ -86,7 +94,7 @@ int GNet::run_conv_fwd(const Op& o, bool train, hipStream_t s) {
             a.wl2 = (const uint4*)cw.ff_l2; a.six_B = (o.yw == W_BOTH && train) ? y.B / 2 : y.B;
         }
         if ((mixed & 1) && train && o.yw != W_GRAD) a.x1_from_B = o.yw == W_BOTH ? y.B / 2 : 0;     // the proxy frames' products: one MFMA
-        if (o.stat_to >= 0 && (train || !ops[o.stat_to].tracked)) {
+        if (o.stat_to >= 0 && (train || !ops[o.stat_to].tracked) && !(bn_prepare && !ops[o.stat_to].tracked)) {
             a.stat_part = ops[o.stat_to].part; a.stat_C = y.C; a.stat_npass = (o.yw == W_BOTH && train) ? 2 : 1;
         }
         int rc;
@@ -113,6 +121,13 @@ int GNet::run_bn_fwd(const Op& o, bool train, hipStream_t s) {
     GView x = view(o.x[0], o.xw[0], train), y = view(o.y, o.yw, train);
     GView res; if (o.res >= 0) res = view(o.res, o.xw[0], train);
     const int npass = (o.xw[0] == W_BOTH && train) ? 2 : 1;
+    if (bn_prepare && !o.tracked) {                         // stage-2 head trainer: a BatchNorm2d in eval mode, every pass from the loaded running statistics
+        if (!o.has_running) return fail("running statistics of " + o.bname + " not loaded (the stage-2 head trainer evaluates BatchNorm2d from them)", -3);
+        if (ptta_launch_gbn_eval_affine(bn_gamma(o), bn_beta(o), o.rm_own, o.rv_own, BN_EPS, x.C, o.st_eval, s)) return fail("batch-norm " + o.bname + " (prepare) launch failed", -5);
+        o.st_eval_valid = false;
+        if (ptta_launch_gbn_apply(x, res, y, 1, o.act, o.st_eval, 1, s, o.act_first ? 1 : 0)) return fail("batch-norm " + o.bname + " (prepare) launch failed", -5);
+        return 0;
+    }
     if (o.tracked && !train) {                              // eval mode: running statistics
         if (!o.rm || !o.rv) return fail("running statistics of " + o.bname + " not loaded", -3);
         // the affine of the running statistics is left behind by the training forward's finalize; computed here only after a load()
@@ -143,7 +158,7 @@ int GNet::run_conv_bwd(const Op& o, hipStream_t s) {
     review(gy, o.rH, o.rW);
     bool padded = false;
     for (int sidx = 0; sidx < o.nsrc; ++sidx) {
-        if (!T[o.x[sidx]].need_grad) continue;
+        if (!T[o.x[sidx]].need_grad || o.no_dx) continue;
         GView gx = view(o.x[sidx], W_GRAD, true, true);
         review(gx, o.rH, o.rW);
         const bool own_frags = sidx == 1 && cw.fb1_hi != nullptr;
@@ -180,9 +195,13 @@ int GNet::run_conv_bwd(const Op& o, hipStream_t s) {
         if (ptta_launch_gconv_direct(a, s)) return fail("data gradient of " + o.wname + " failed", -5);
     }
     if (ad) {
-        const GView xv = view(o.x[0], W_GRAD, true);
+        const GView xv = view(o.x[0], o.xw[0] == W_PROXY ? W_PROXY : W_GRAD, true);
         float* gw = gall + adapted[o.ad_w].goff;
         float* gb = o.ad_b >= 0 ? gall + adapted[o.ad_b].goff : nullptr;
+        if (o.k == 1) {                                  // nn.Linear / 1x1 convolution (the heads): dW[co][ci] = sum_rows gy[r][co] x[r][ci]
+            if (ptta_launch_glinear_wgrad(xv, gy, gw, gb, s)) return fail("weight gradient of " + o.wname + " failed", -5);
+            return 0;
+        }
         if ((naive ? ptta_launch_gwgrad(xv, gy, wg_part, gw, gb, s) : ptta_launch_gwgrad_mfma(xv, gy, wg_part, gw, gb, s)))
             return fail("weight gradient failed", -5);
     }

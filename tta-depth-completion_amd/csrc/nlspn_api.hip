@@ -65,6 +65,7 @@ struct nlspn_engine : GNet {
     int t_img = -1, t_sd = -1, t_pred = -1, t_oa = -1, t_conf = -1, t_fe6 = -1;
     float *off9 = nullptr, *aff9 = nullptr, *goff9 = nullptr, *gaff9 = nullptr, *feats = nullptr, *gy = nullptr, *gping = nullptr;
     int legacy = 0, heads_adapted = 0;
+    int enc_ops_end = 0;               // ops [0, enc_ops_end) = conv1 .. conv6: what the stage-2 head trainer runs of the backbone
 
     static int half(int v) { return (v + 1) / 2; }                 // 3x3 stride 2 padding 1: ceil
     long rows() const override { return (long)N * half(half(half(half(H)))) * half(half(half(half(W)))); }
@@ -128,6 +129,7 @@ struct nlspn_engine : GNet {
             bn("conv6.1", r, o, -1, GACT_LRELU, W_BOTH);
             fe[6] = o; t_fe6 = o;
         }
+        enc_ops_end = (int)ops.size();
         // shared decoder (:413-424): transposed convs over [decoder | encoder skip]
         // a transposed convolution doubles its input; when an encoder map has an odd size the decoder map is one row / column
         // larger and `_concat` crops it AFTER BatchNorm saw the whole map (nlspnmodel_adapt.py:474-490): the layer is built at
@@ -233,20 +235,25 @@ struct nlspn_engine : GNet {
     }
     int forward(const float* image, const float* sparse, bool train, hipStream_t s) override;
     int backward(hipStream_t s) override;
+    int stage_inputs_nhwc(const float* image, const float* sparse, bool train, hipStream_t s);
+    // stage-2 head trainer (ghead.hip): rows = fe6 of the real pass / of the zero-image pass (nlspnmodel_adapt.py:1028-1046); MLP(512, 1024, 1024)
+    int head_spec(HeadSpec* hs) override {
+        if (heads_adapted) return fail("the stage-2 head trainer runs on a handle whose heads are not in the adapted list (no PTTA_SYNCBN_ADAPT)", -38);
+        hs->x_real = t_fe6; hs->xw_real = W_GRAD; hs->x_proxy = t_fe6; hs->xw_proxy = W_PROXY; hs->hidden = 1024; hs->out = 1024;
+        return 0;
+    }
+    int head_features(const float* image, const float* sparse, hipStream_t s) override {
+        for (auto& ad : adapted) if (!ad.p) return fail("adapted parameter " + ad.name + " not bound (ptta_bind_adapted)", -3);
+        NRUN(stage_inputs_nhwc(image, sparse, true, s));
+        repack_adapted(s);
+        return run_ops_fwd(true, s, enc_ops_end);
+    }
 };
 
 int nlspn_engine::forward(const float* image, const float* sparse, bool train, hipStream_t s) {
     for (auto& ad : adapted) if (!ad.p) return fail("adapted parameter " + ad.name + " not bound (ptta_bind_adapted)", -3);
     const long P = (long)H * W;
-    const int Be = train ? 2 * N : N;
-    // inputs: image -> NHWC (normalised on the fly; proxy half = zero image), sparse depth clamped (external_model_adapt.py:108)
-    GView iv = view(t_img, W_BOTH, train);
-    if (ptta_launch_gnchw_to_nhwc(image, N, 3, iv, N, norm_on, norm_div, norm_mean, norm_std, s)) return fail("image staging failed", -5);
-    hipLaunchKernelGGL(clamp_dup_kernel, dim3(nb(P * Be)), dim3(256), 0, s, sparse, T[t_sd].p, (long)N * P, Be / N, hp.max_input_depth);
-    if (t_sd16 >= 0) {
-        GView sv = view(t_sd16, W_BOTH, train);
-        if (ptta_launch_gnchw_to_nhwc(T[t_sd].p, Be, 1, sv, Be, 0, 1.f, nullptr, nullptr, s)) return fail("sparse staging failed", -5);
-    }
+    NRUN(stage_inputs_nhwc(image, sparse, train, s));
     repack_adapted(s);                  // the adapted conv is re-packed from the bound tensor on every forward
     const int rc = run_ops_fwd(train, s);
     if (rc) return rc;
@@ -261,6 +268,20 @@ int nlspn_engine::forward(const float* image, const float* sparse, bool train, h
     hipLaunchKernelGGL(relu_copy_kernel, dim3(nb((long)N * P)), dim3(256), 0, s, feats + (size_t)PROP_TIME * N * P, depth, (long)N * P);
     if (hipGetLastError() != hipSuccess) return fail("launch failed", -5);
     fwd_valid = train;
+    return 0;
+}
+
+// inputs: image -> NHWC (normalised on the fly; proxy half = zero image), sparse depth clamped (external_model_adapt.py:108)
+int nlspn_engine::stage_inputs_nhwc(const float* image, const float* sparse, bool train, hipStream_t s) {
+    const long P = (long)H * W;
+    const int Be = train ? 2 * N : N;
+    GView iv = view(t_img, W_BOTH, train);
+    if (ptta_launch_gnchw_to_nhwc(image, N, 3, iv, N, norm_on, norm_div, norm_mean, norm_std, s)) return fail("image staging failed", -5);
+    hipLaunchKernelGGL(clamp_dup_kernel, dim3(nb(P * Be)), dim3(256), 0, s, sparse, T[t_sd].p, (long)N * P, Be / N, hp.max_input_depth);
+    if (t_sd16 >= 0) {
+        GView sv = view(t_sd16, W_BOTH, train);
+        if (ptta_launch_gnchw_to_nhwc(T[t_sd].p, Be, 1, sv, Be, 0, 1.f, nullptr, nullptr, s)) return fail("sparse staging failed", -5);
+    }
     return 0;
 }
 

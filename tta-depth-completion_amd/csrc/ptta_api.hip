@@ -2372,6 +2372,7 @@ static int head_reload(ptta_ctx* c, int k, hipStream_t s) {
 
 int ptta_head_bind(ptta_handle c, const char* name_, float* param, float* exp_avg, float* exp_avg_sq) {
     if (!c || !name_ || !param) return -1;
+    NLFWD(c->nl->head_bind(name_, param, exp_avg, exp_avg_sq));
     RUN(head_init(c));
     const std::string name(name_);
     auto& h = c->head;
@@ -2387,6 +2388,7 @@ int ptta_head_bind(ptta_handle c, const char* name_, float* param, float* exp_av
 int ptta_head_set_hparams(ptta_handle c, float lr, float beta1, float beta2, float eps, float weight_decay, float tau, int adam_step,
                           ptta_stream s_) {
     if (!c) return -1;
+    NLFWD(c->nl->head_set_hparams(lr, beta1, beta2, eps, weight_decay, tau, adam_step, (hipStream_t)s_));
     RUN(head_init(c));
     hipStream_t s = (hipStream_t)s_;
     const float hy[5] = {lr, beta1, beta2, eps, weight_decay};
@@ -2399,6 +2401,7 @@ int ptta_head_set_hparams(ptta_handle c, float lr, float beta1, float beta2, flo
 
 int ptta_head_reload(ptta_handle c, ptta_stream s) {
     if (!c) return -1;
+    NLFWD(c->nl->head_reload((hipStream_t)s));
     RUN(head_init(c));
     c->drop_graphs();
     for (int k = 0; k < 12; ++k) RUN(head_reload(c, k, (hipStream_t)s));
@@ -2407,6 +2410,7 @@ int ptta_head_reload(ptta_handle c, ptta_stream s) {
 
 int ptta_head_forward(ptta_handle c, const float* image, const float* sparse, int reverse, float* emb_out, float* ref_out, ptta_stream s_) {
     if (!c || !image || !sparse) return -1;
+    NLFWD(c->nl->head_forward(image, sparse, reverse, emb_out, ref_out, (hipStream_t)s_));
     RUN(head_init(c));
     auto& h = c->head;
     hipStream_t s = (hipStream_t)s_;
@@ -2439,6 +2443,7 @@ int ptta_head_forward(ptta_handle c, const float* image, const float* sparse, in
 
 int ptta_head_backward(ptta_handle c, float* loss_out, ptta_stream s_) {
     if (!c) return -1;
+    NLFWD(c->nl->head_backward(loss_out, (hipStream_t)s_));
     auto& h = c->head;
     if (!h.ready || !h.fwd_ok) return c->fail("ptta_head_backward needs the activations of the last ptta_head_forward", -3);
     hipStream_t s = (hipStream_t)s_;
@@ -2482,6 +2487,7 @@ int ptta_head_backward(ptta_handle c, float* loss_out, ptta_stream s_) {
 
 int ptta_head_adam_step(ptta_handle c, ptta_stream s_) {
     if (!c) return -1;
+    NLFWD(c->nl->head_adam_step((hipStream_t)s_));
     auto& h = c->head;
     if (!h.ready || !h.bwd_ok) return c->fail("ptta_head_adam_step needs the gradients of ptta_head_backward", -3);
     hipStream_t s = (hipStream_t)s_;
@@ -2501,6 +2507,12 @@ int ptta_head_adam_step(ptta_handle c, ptta_stream s_) {
 }
 
 int ptta_head_step(ptta_handle c, const float* image, const float* sparse, int reverse, float* loss_out, ptta_stream s) {
+    if (c && c->nl) {
+        c->err.clear();
+        int rc = c->nl->head_forward(image, sparse, reverse, nullptr, nullptr, (hipStream_t)s);
+        if (!rc) rc = c->nl->head_backward(loss_out, (hipStream_t)s);
+        return rc ? rc : c->nl->head_adam_step((hipStream_t)s);
+    }
     RUN(ptta_head_forward(c, image, sparse, reverse, nullptr, nullptr, s));
     RUN(ptta_head_backward(c, loss_out, s));
     return ptta_head_adam_step(c, s);
@@ -2508,6 +2520,7 @@ int ptta_head_step(ptta_handle c, const float* image, const float* sparse, int r
 
 int ptta_head_get_grad(ptta_handle c, const char* name, float* dst, int64_t capacity, int* has_grad_host, ptta_stream s) {
     if (!c || !name) return -1;
+    NLFWD(c->nl->head_get_grad(name, dst, capacity, has_grad_host, (hipStream_t)s));
     auto& h = c->head;
     if (!h.ready) return c->fail("no head parameter bound", -3);
     for (int k = 0; k < 12; ++k) if (h.prm[k].name == name) {

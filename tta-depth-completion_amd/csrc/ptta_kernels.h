@@ -316,6 +316,8 @@ int ptta_launch_gnchw_to_nhwc(const float* src, int src_nb, int src_c, const GVi
                               const float* stdv, hipStream_t s);
 int ptta_gwgrad_slabs(long pixels);
 int ptta_launch_gwgrad(const GView& x, const GView& gy, float* part, float* gw, float* gb, hipStream_t s);
+// weight / bias gradient of a 1x1 convolution = nn.Linear over the rows (ghead.hip): gw [Co][Ci], gb [Co] or NULL
+int ptta_launch_glinear_wgrad(const GView& x, const GView& gy, float* gw, float* gb, hipStream_t s);
 
 int ptta_gbn_part_floats(int C, int npass);
 int ptta_launch_gbn_forward(const GView& x, const GView& res, const GView& y, int npass, int act, float eps, const float* gamma,

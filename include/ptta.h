@@ -249,6 +249,13 @@ int ptta_set_image_norm(ptta_handle h, float divisor, const float* mean, const f
  *   prepare_loss             mean(2 - 2 <normalize(emb), normalize(ref)>)          (src/external_model_adapt.py:524-541)
  *   Adam                     over prepare_parameters('head_selfsup_ema') (src/msg_chn_model_adapt.py:297-304); parameters
  *                            without a gradient are skipped like torch.optim.Adam skips .grad == None
+ * NLSPN and CostDCNet handles (csrc/ghead.hip; nlspnmodel_adapt.py:1014-1060, CostDCNet_adapt.py:258-303): the same calls.  There the reference branch
+ * goes through the EMA target -- not reverse: emb = pred(proj(rows(real).detach())), ref = proj_t(rows(zero image)).detach(); reverse: the passes
+ * swapped -- so proj AND pred train in both directions (ptta_head_get_grad: has_grad = 1 for all twelve), proj_t's BatchNorm1d runs in train mode
+ * like the other two, and the backbone's BatchNorm2d layers normalise with their LOADED running statistics (`train(prepare=True)`,
+ * src/nlspn_model_adapt.py:360-368, src/costdcnet_model_adapt.py:418-430) -- ptta_load_weights keeps them for this purpose; BatchNorm3d and the
+ * sparse encoder's BatchNorm1d stay in train mode as in the reference.  Not offered (-38) with PTTA_SYNCBN_ADAPT, a statistics exchange bound,
+ * or (CostDCNet) sizes that need the dual-corner padding.
  * ptta_head_bind: name in {proj,pred}.{0,3}.{weight,bias}, {proj,pred}.1.{weight,bias} (param + both Adam moments, device fp32,
  * caller-owned, updated in place) or proj_t.* (param only; bind all six or none).  After ptta_head_adam_step the handle's
  * packed copies of the updated head weights are re-derived, so TTA calls on the same handle see them; after an EXTERNAL

@@ -25,9 +25,14 @@ BN_EPS = 1e-5
 RES, UP_SCALE = 16, 4            # AD:47-52 (args.res, args.up_scale)
 
 
+BN2D_RUNNING = [False]     # stage-2 head trainer only (head_rows below): BatchNorm2d in eval mode, from the loaded running statistics
+
+
 def _bn2d(P, pre, x):
     """BatchNorm2d after adapt_parameters('meta_bn') (AD:357-378): running statistics dropped -> batch statistics in
-    train AND eval mode."""
+    train AND eval mode.  Under `train(prepare=True)` (AD:418-430, stage 2) the module is in eval mode with its buffers intact."""
+    if BN2D_RUNNING[0]:
+        return F.batch_norm(x, P[pre + '.running_mean'], P[pre + '.running_var'], P[pre + '.weight'], P[pre + '.bias'], False, 0.1, BN_EPS)
     return F.batch_norm(x, None, None, P[pre + '.weight'], P[pre + '.bias'], True, 0.1, BN_EPS)
 
 
@@ -262,3 +267,30 @@ class CostDcnOracle:
         return {'depth': depth.detach(), 'emb': emb.detach(), 'ref': ref.detach(),
                 'loss_info': {k: float(torch.as_tensor(v).detach()) for k, v in info.items()},
                 'grads': {k: g for k, g in zip(self.names, grads)}}
+
+
+# ---- stage-2 head trainer: src/head_main.py:464-480 on CostDCNet._rgbd_meta_contrast_prepare (CD:258-303) ----
+def head_rows(P, image, sparse_depth, max_depth):
+    """One no-gradient backbone pass up to the UNet3D bottleneck (CD:268-277), as rows [B * H/32 * W/32, 80 * 2].  `train(prepare=True)` (AD:418-430)
+    puts the BatchNorm2d's (Encoder2D) into eval mode; BatchNorm3d and the sparse encoder's BatchNorm1d are not BatchNorm2d: train mode, batch
+    statistics, running statistics updated by every pass."""
+    z_step = max_depth / (RES - 1)
+    BN2D_RUNNING[0] = True
+    try:
+        feat2d = F.conv2d(encoder2d(P, torch.cat([image, sparse_depth], 1)), P['conv1_rgb_meta.weight'], P['conv1_rgb_meta.bias'], padding=1)
+    finally:
+        BN2D_RUNNING[0] = False
+    feat3d = encoder3d(P, depth2mdp(sparse_depth, z_step), True)
+    _, feat = unet3d(P, fusion(feat3d, feat2d), True)
+    b, c, d, h, w = feat.shape
+    return feat.reshape(b, c * d, h, w).permute(0, 2, 3, 1).reshape(-1, c * d)
+
+
+def make_head_trainer(state_dict, loss_type, max_depth=8.0, **kw):
+    """oracle.nlspn_oracle.HeadTrainerOracle (the same EMA / heads / loss / Adam program: CD:283-303 = NM:1048-1058) over this backbone's rows."""
+    from oracle.nlspn_oracle import HeadTrainerOracle
+    sd = dict(state_dict)
+    for k in list(sd):          # one BatchNorm behind two names (ResBlock.norm3 / downsample.1)
+        if k.startswith('enc2d.') and '.downsample.1.' in k:
+            sd[k] = sd[k.replace('.downsample.1.', '.norm3.')]
+    return HeadTrainerOracle(sd, loss_type, features=lambda P, img, sp: head_rows(P, img, sp, max_depth), **kw)

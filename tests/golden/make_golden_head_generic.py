@@ -116,6 +116,27 @@ def nlspn_cases():
         run_case(model, net, sd, frames, name, loss_type, steps, [h, w, n, steps])
 
 
+def costdcnet_cases():
+    import make_golden_costdcnet as MC          # installs the MinkowskiEngine stand-in (oracle/minkowski_lite.py: parity unpinned for the sparse branch)
+    ema, _ = MC.MG.import_reference()
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    from proxytta import synth
+    # sizes divisible by 32: the heads' rows are the H/32 x W/32 bottleneck of the cost-volume UNet (CostDCNet_adapt.py:287-290)
+    for name, loss_type, h, w, n, steps in (('head_costdcnet_forward_64x96_n2', 'head_selfsup_seq_ema', 64, 96, 2, 2),
+                                            ('head_costdcnet_reverse_64x96_n2', 'head_selfsup_seq_ema_reverse', 64, 96, 2, 2),
+                                            ('head_costdcnet_reverse_160x224', 'head_selfsup_seq_ema_reverse', 160, 224, 1, 2)):
+        model = ema.ExternalModel_Adapt('costdcnet', 0.1, MC.MAX_DEPTH, max_input_depth=None, device=torch.device('cpu'))
+        model._prepare_head(PREPARE)
+        net = model.model.model
+        sd = synth.formula_state_dict_costdcnet(PREPARE)
+
+        def frames(s, h=h, w=w, n=n):
+            raw, image1, sparse = MC.costdc_frame(s, h, w, n, 0.05)
+            return torch.from_numpy(image1), torch.from_numpy(sparse)
+        run_case(model, net, sd, frames, name, loss_type, steps, [h, w, n, steps])
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['nlspn', 'costdcnet']
     if 'nlspn' in which:

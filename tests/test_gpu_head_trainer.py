@@ -326,19 +326,27 @@ def _rows_check(z, key, value, rtol, atol, what):
     assert abs(value.sum(dtype=np.float64) - s[0]) <= rtol * s[1] + atol * value.size, what
 
 
-def make_generic_head_engine(backbone, n, h, w, hp, tau):
+def make_generic_head_engine(backbone, n, h, w, hp, tau, impl='default'):
     from tests.golden.make_golden_head_generic import perturbed_target
+    os.environ.pop('PTTA_CONV_IMPL', None)
+    if impl == 'naive':
+        os.environ['PTTA_CONV_IMPL'] = 'naive'          # direct fp32 kernels everywhere (exact arithmetic)
     if backbone == 'nlspn':
         from tests.test_gpu_nlspn import HP as BHP
         eng = Engine(n, h, w, backbone='nlspn', legacy_offset=True, **BHP)
+        os.environ.pop('PTTA_CONV_IMPL', None)
         sd_np = synth.formula_state_dict_nlspn()
     else:
-        from tests.test_gpu_costdcnet import HP as BHP
-        eng = Engine(n, h, w, backbone='costdcnet', **BHP)
+        from tests.test_gpu_costdcnet import HP as BHP, MAX_DEPTH
+        eng = Engine(n, h, w, backbone='costdcnet', max_predict_depth=MAX_DEPTH, **BHP)
         sd_np = synth.formula_state_dict_costdcnet()
+        os.environ.pop('PTTA_CONV_IMPL', None)
+        for k in list(sd_np):            # one BatchNorm behind two names
+            if k.startswith('enc2d.') and '.downsample.1.' in k:
+                sd_np[k] = sd_np[k.replace('.downsample.1.', '.norm3.')]
     sd_np.update(perturbed_target(sd_np))
     sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in sd_np.items()}
-    eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32})
+    eng.load_state_dict({k: v for k, v in sd.items() if v.dtype == torch.float32} if backbone == 'nlspn' else sd)
     keep = {}
     for k in eng.adapted:
         keep[k] = (sd[k].clone().contiguous(), torch.zeros_like(sd[k]), torch.zeros_like(sd[k]))
@@ -361,8 +369,10 @@ def _generic_head_frame(backbone, s, h, w, n):
     return costdc_frame(s, h, w, n)[1:]
 
 
-@pytest.mark.parametrize('name', ['head_nlspn_forward_48x80_n2', 'head_nlspn_reverse_48x80_n2', 'head_nlspn_reverse_96x320'])
-def test_generic_head_trainer_reproduces_reference(golden_dir, name):
+@pytest.mark.parametrize('name', ['head_nlspn_forward_48x80_n2', 'head_nlspn_reverse_48x80_n2', 'head_nlspn_reverse_96x320',
+                                  'head_costdcnet_forward_64x96_n2', 'head_costdcnet_reverse_64x96_n2', 'head_costdcnet_reverse_160x224'])
+@pytest.mark.parametrize('impl', ['naive', 'default'])
+def test_generic_head_trainer_reproduces_reference(golden_dir, name, impl):
     """Stage 2 (src/head_main.py:464-480) on an NLSPN / CostDCNet handle against the REAL reference's vectors
     (tests/golden/make_golden_head_generic.py): embeddings, loss, all twelve gradients per step, then the trained parameters, the EMA target
     and the BatchNorm1d running statistics.  Bounds as for the MSG_CHN trainer's default arithmetic (bf16x3 products): first step 2x measured."""
@@ -371,7 +381,8 @@ def test_generic_head_trainer_reproduces_reference(golden_dir, name):
     h, w, n, steps = (int(v) for v in z['meta'][:4])
     lr, b1, b2, eps, wd, tau = (float(v) for v in z['hp'])
     reverse = 'reverse' in str(z['loss_type'])
-    eng, sd, _, keep = make_generic_head_engine(backbone, n, h, w, dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd), tau)
+    eng, sd, _, keep = make_generic_head_engine(backbone, n, h, w, dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd), tau, impl)
+    rows = int(z['s0/emb_shape'][0])
     for s in range(steps):
         image, sparse = (torch.from_numpy(a).cuda() for a in _generic_head_frame(backbone, s, h, w, n))
         emb, ref = eng.head_forward(image, sparse, reverse)
@@ -392,7 +403,15 @@ def test_generic_head_trainer_reproduces_reference(golden_dir, name):
                 assert np.abs(mine).max() < 1e-5, k
                 continue
             d = np.abs(mine - want)
-            tmax, tmean = GRAD_TOL['default'][s == 0]
+            tmax, tmean = GRAD_TOL['exact' if impl == 'naive' else 'default'][s == 0]
+            if impl == 'naive':
+                # (different reduction orders of the 512 / 1024-wide layers; later steps: behind Adam's +-lr first move of every weight)
+                tmax, tmean = (2e-4, 5e-5) if s == 0 else (4e-2, 1.5e-2)      # (measured: first step <= 2e-5 / 5e-6; second step 5.1e-3 mean)
+            else:
+                # a hidden pre-activation within 1e-5 of zero changes side under the two-way operand split: with R rows one flipped row moves an
+                # entry of that unit's gradient by up to 1 / R of its magnitude (12 - 120 rows here; 26,752 on the MSG_CHN handle)
+                # -- ONE term of a 12-term sum, which may be several times the mean term: the exact-arithmetic run above is the tight check
+                tmax, tmean = tmax + 4.0 / rows, tmean + 0.5 / rows
             assert d.max() <= tmax * np.abs(want).max() + 1e-12, (k, s, d.max(), np.abs(want).max())
             assert d.mean() <= tmean * np.abs(want).mean() + 1e-12, (k, s, d.mean(), np.abs(want).mean())
         eng.head_adam_step()

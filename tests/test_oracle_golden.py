@@ -470,6 +470,22 @@ def test_nlspn_head_trainer_oracle_matches_reference(golden_dir, name):
     _head_generic_check(z, o, steps, lambda s: nlspn_frame(s, h, w, n)[1:], lr)
 
 
+@pytest.mark.parametrize('name', ['head_costdcnet_forward_64x96_n2', 'head_costdcnet_reverse_64x96_n2', 'head_costdcnet_reverse_160x224'])
+def test_costdcnet_head_trainer_oracle_matches_reference(golden_dir, name):
+    """Stage 2 on the CostDCNet backbone (src/head_main.py:464-480 through CostDCNet_adapt.py:258-303) against the REAL reference; the sparse
+    encoder is minkowski_lite on both sides (parity unpinned there, as for the TTA step)."""
+    from oracle import costdcnet_oracle as CO
+    from tests.golden.make_golden_head_generic import perturbed_target
+    from tests.test_gpu_costdcnet import costdc_frame
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = (int(v) for v in z['meta'])
+    lr, b1, b2, eps, wd, tau = (float(v) for v in z['hp'])
+    sd = synth.formula_state_dict_costdcnet()
+    sd.update(perturbed_target(sd))
+    o = CO.make_head_trainer(sd, str(z['loss_type']), max_depth=8.0, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, tau=tau)
+    _head_generic_check(z, o, steps, lambda s: costdc_frame(s, h, w, n)[1:], lr)
+
+
 @pytest.mark.skipif(not os.path.exists('/root/reference/external_src/costdcnet/weights/enc3d.pth'), reason='needs the reference tree with its pretrained weights (build container)')
 def test_sparse_kernel_order_matches_pretrained_weights():
     """MinkowskiEngine is absent from the reference tree, so the order in which a 3x3x3 sparse kernel's 27 offsets are enumerated is a

@@ -182,12 +182,14 @@ struct costdc_engine : GNet {
         }
         t_cost = tensor("cost", N * 16, h4, w4, 16, true, N * 16);
         conv("unet3d.classif0", x, -1, t_cost, 1, 1, 0, GACT_NONE, W_GRAD, W_GRAD);
+        idx_regress = (int)ops.size();
         func([this](bool, hipStream_t s) { return regress_fwd(s); }, [this](hipStream_t s) { return regress_bwd(s); }, t_cost);
         // heads (CD:243-251, :463-465): emb = pred(proj(rows of the proxy pass)), ref = proj_t(rows of the real pass)
         t_rows = tensor("rows", N, fh, fw, 80 * fD, true);
         t_rows_p = tensor("rows_proxy", N, fh, fw, 80 * fD, false);
         {
             const int oi = func(nullptr, nullptr, t_feat, -1, true);
+            idx_rows = oi;
             ops[oi].ffwd = [this](bool, hipStream_t s) {
                 const float* fz = T[t_feat].p + (size_t)T[t_feat].per * fh * fw * 80;
                 if (cd_launch_rows_fwd(T[t_feat].p, T[t_rows].p, N, fD, fh, fw, 80, s) || cd_launch_rows_fwd(fz, T[t_rows_p].p, N, fD, fh, fw, 80, s))
@@ -417,7 +419,23 @@ struct costdc_engine : GNet {
         return fail("unknown state_dict key " + name, -2);
     }
 
-    int forward(const float* image, const float* sparse, bool train, hipStream_t s) override {
+    int idx_regress = -1, idx_rows = -1;
+    // stage-2 head trainer (ghead.hip): rows = the UNet3D bottleneck of the real pass / of the zero-image pass (CD:268-290); MLP(160, 512, 512)
+    int head_spec(HeadSpec* hs) override {
+        if (sync_adapt) return fail("the stage-2 head trainer runs on a handle without PTTA_SYNCBN_ADAPT", -38);
+        if (dual) return fail("stage 2 runs on sizes divisible by 16", -38);
+        hs->x_real = t_rows; hs->xw_real = W_GRAD; hs->x_proxy = t_rows_p; hs->xw_proxy = W_GRAD; hs->hidden = 512; hs->out = 512;
+        return 0;
+    }
+    // both passes through Encoder2D (BatchNorm2d from running statistics: bn_prepare), the sparse encoder and the WHOLE UNet3D (train mode: its
+    // BatchNorm3d running statistics move as in the reference, which evaluates the full unet3d for the feature, CD:275,288), then the rows
+    int head_features(const float* image, const float* sparse, hipStream_t s) override {
+        NRUN(forward_ops(image, sparse, true, s, idx_regress));
+        fwd_valid = false;
+        return ops[idx_rows].ffwd(true, s);
+    }
+    int forward(const float* image, const float* sparse, bool train, hipStream_t s) override { return forward_ops(image, sparse, train, s, -1); }
+    int forward_ops(const float* image, const float* sparse, bool train, hipStream_t s, int limit) {
         for (auto& ad : adapted) if (!ad.p) return fail("adapted parameter " + ad.name + " not bound (ptta_bind_adapted)", -3);
         const float* img = image; const float* spp = sparse;
         if (dual) {
@@ -446,7 +464,7 @@ struct costdc_engine : GNet {
             sp_inflight = true;
         }
         repack_adapted(s);
-        const int rc = run_ops_fwd(train, s);
+        const int rc = run_ops_fwd(train, s, limit);
         if (rc) return rc;
         fwd_valid = train;
         return 0;

@@ -461,3 +461,45 @@ def test_generic_head_step_equals_split_calls_and_feeds_the_tta_step():
     _, emb0, _ = eng.forward_train(image, sparse)
     assert float((emb0.cpu() - out[0][2]).abs().max()) > 1e-3          # the trained heads are the ones the TTA forward runs
     eng.close()
+
+
+@pytest.mark.parametrize('name', ['head_nlspn_forward_48x80_n2', 'head_costdcnet_reverse_64x96_n2'])
+def test_reference_style_stage2_loop_through_the_generic_facades(golden_dir, name):
+    """The loop of src/head_main.py:441-480 written against the mirror for the NLSPN / CostDCNet adapters: _prepare_head,
+    prepare_parameters('head_selfsup_ema'), torch.optim.Adam over what it returns, train(prepare=True), forward(loss_type) ->
+    compute_loss('prepare') -> zero_grad / backward / step.  All twelve head tensors receive a gradient in both directions; losses follow
+    the reference's fixture."""
+    from proxytta.model import ExternalModel_Adapt
+    from tests.golden.make_golden_head_generic import perturbed_target
+    backbone = name.split('_')[1]
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    h, w, n, steps = (int(v) for v in z['meta'][:4])
+    lr, b1, b2, eps, wd, tau = (float(v) for v in z['hp'])
+    loss_type = str(z['loss_type'])
+    if backbone == 'nlspn':
+        model = ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=80.0, offset=True)
+        sd = synth.formula_state_dict_nlspn()
+    else:
+        model = ExternalModel_Adapt('costdcnet', 0.1, 8.0, max_input_depth=None)
+        sd = {k: v for k, v in synth.formula_state_dict_costdcnet().items() if not (k.startswith('enc2d.') and '.downsample.1.' in k)}
+    model._prepare_head(ONE)
+    head_params = model.prepare_parameters('head_selfsup_ema')
+    sd.update(perturbed_target(sd))
+    model.model.model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    opt = torch.optim.Adam(head_params, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    names = model.model._head_names
+    assert len(names) == 12
+    for s in range(steps):
+        image, sparse = (torch.from_numpy(a).cuda() for a in _generic_head_frame(backbone, s, h, w, n))
+        model.train(prepare=True)
+        output_depth, embedding, reference = model.forward(image=image, sparse_depth=sparse, loss_type=loss_type)
+        assert output_depth is None
+        loss, info = model.compute_loss(input_rgb=image, output_depth=output_depth, validity_map=None, ground_truth=None,
+                                        embedding=embedding, reference=reference, loss_type='prepare')
+        opt.zero_grad()
+        loss.backward()
+        assert all(p.grad is not None for p in head_params)
+        opt.step()
+        assert abs(float(loss.detach()) - float(z['s%d/loss' % s])) < (5e-5 if s == 0 else 5e-4), (s, float(loss.detach()), float(z['s%d/loss' % s]))
+    state = model.model.model.state_dict()
+    _rows_check(z, 's%d/after/proj_t.3.weight' % (steps - 1), state['proj_t.3.weight'], 1e-5, 1e-5, 'proj_t.3.weight')

@@ -75,6 +75,11 @@ class CostDCNetModel_Adapt(MsgChnModel_Adapt):
         self.total_time = self.train_time = self.eval_time = 0.0
         self.to(device)
 
+    heads_reverse_freezes_proj = False          # stage 2: ref = proj_t(...), proj trains in both directions (csrc/ghead.hip)
+
+    def _state_keys(self):
+        return [(k, s) for k, s in synth.costdcnet_keys(self.prepare_mode) if not (k.startswith('enc2d.') and '.downsample.1.' in k)]
+
     def _prepare_head(self, mode=''):
         """CostDCNet._prepare_head (CostDCNet_adapt.py:426-496)."""
         if 'meta' not in mode or 'selfsup' not in mode or 'ema' not in mode or 'seq' not in mode or '1layer' not in mode:
@@ -155,6 +160,10 @@ class CostDCNetModel_Adapt(MsgChnModel_Adapt):
         return eng
 
     def forward(self, image, sparse_depth, intrinsics=None, crop_mask=None, loss_type='pretrain'):
+        if 'head' in loss_type and 'init_meta' not in loss_type and loss_type != 'prepare':       # stage 2 (src/head_main.py:464-468)
+            if not self.training:
+                raise NotImplementedError('the head forward is a training-mode call (head_main.py:441)')
+            return self.head_forward(image, sparse_depth, loss_type)
         if self.training and 'adapt' in loss_type:
             params = dict(self.model.named_parameters())
             return self._timed(lambda: _ForwardFn.apply(self, image, sparse_depth, *[params[k] for k in self.adapted]), loss_type)

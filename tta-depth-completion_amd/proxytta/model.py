@@ -204,11 +204,9 @@ class MsgChnModel_Adapt(object):
             raise NotImplementedError("prepare_parameters(%r): only the head trainer's 'head_selfsup_ema' is on the accelerated path" % mode)
         if self.prepare_mode is None:
             raise RuntimeError('_prepare_head(prepare_mode) first (head_main.py:259)')
-        if type(self) is not MsgChnModel_Adapt:
-            raise NotImplementedError('the stage-2 head trainer is built for MSG_CHN (1layer or 2layers meta layer)')
         params = dict(self.model.named_parameters())
         with torch.no_grad():
-            for k, shape in synth.msg_chn_keys(self.prepare_mode):
+            for k, shape in self._state_keys():
                 if k.startswith(('proj.', 'pred.')):
                     t = params.get(k, None)
                     tgt = t if t is not None else self.model.state_dict()[k]
@@ -220,6 +218,13 @@ class MsgChnModel_Adapt(object):
         self._clear_engines()
         self._head_names = [k for k, _ in self.model.named_parameters() if ('proj' in k or 'pred' in k) and '_t' not in k]
         return [params[k] for k in self._head_names]
+
+    # (key, shape) table of this backbone's state dict and whether `reverse` leaves proj without a gradient (MSG_CHN: its reference branch is
+    # proj itself, network_exp_msg_chn_adapt.py:691-694; NLSPN / CostDCNet: the EMA target proj_t, so proj trains in both directions)
+    heads_reverse_freezes_proj = True
+
+    def _state_keys(self):
+        return synth.msg_chn_keys(self.prepare_mode)
 
     def bind_head_optimizer(self, optimizer, tau=0.999):
         """Share Adam state with a torch.optim.Adam built on prepare_parameters(): `head_step` then updates its exp_avg /
@@ -297,7 +302,7 @@ class MsgChnModel_Adapt(object):
         # the library keeps ONE step count for the head tensors, torch.optim.Adam one per parameter: in `reverse` mode only
         # `pred` steps, so a run that switches between the two loss types would give proj pred's count -> refused
         rev = 'reverse' in loss_type
-        if getattr(self, '_head_mode', rev) != rev and getattr(self, '_head_t', 0) > 0:
+        if self.heads_reverse_freezes_proj and getattr(self, '_head_mode', rev) != rev and getattr(self, '_head_t', 0) > 0:
             raise NotImplementedError('head_step: switching between reverse and non-reverse loss types inside one run is not supported '
                                       '(per-parameter Adam step counts would diverge)')
         self._head_mode = rev
@@ -305,7 +310,7 @@ class MsgChnModel_Adapt(object):
         loss = eng.head_step(image, sparse_depth, rev)
         self._head_t = getattr(self, '_head_t', 0) + 1
         eng._head_t = self._head_t
-        live = self._head_names if 'reverse' not in loss_type else [k for k in self._head_names if k.startswith('pred')]
+        live = self._head_names if (not rev or not self.heads_reverse_freezes_proj) else [k for k in self._head_names if k.startswith('pred')]
         for k in live:
             st = self._head_state[k]
             if 'step' in st:
@@ -531,6 +536,13 @@ class ExternalModel_Adapt(object):
 
     def prepare_parameters(self, mode=''):
         return self.model.prepare_parameters(mode)
+
+    # (key, shape) table of this backbone's state dict and whether `reverse` leaves proj without a gradient (MSG_CHN: its reference branch is
+    # proj itself, network_exp_msg_chn_adapt.py:691-694; NLSPN / CostDCNet: the EMA target proj_t, so proj trains in both directions)
+    heads_reverse_freezes_proj = True
+
+    def _state_keys(self):
+        return synth.msg_chn_keys(self.prepare_mode)
 
     def bind_head_optimizer(self, optimizer, tau=0.999):
         self.model.bind_head_optimizer(optimizer, tau)

@@ -71,6 +71,11 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
             return torch.zeros(shape)                         # nlspnmodel_adapt.py:221-222: zero-initialised
         return _init_tensor(name, shape)
 
+    heads_reverse_freezes_proj = False          # stage 2: ref = proj_t(...), proj trains in both directions (csrc/ghead.hip)
+
+    def _state_keys(self):
+        return [(k, s) for k, s in synth.nlspn_keys(self.prepare_mode) if not (k.startswith('enc2d.') and '.downsample.1.' in k)]
+
     def _prepare_head(self, mode=''):
         """NLSPNModel_Adapt._prepare_head (nlspnmodel_adapt.py:1333-1396)."""
         if 'meta' not in mode or 'selfsup' not in mode or 'ema' not in mode or 'seq' not in mode or '1layer' not in mode:
@@ -120,6 +125,10 @@ class NlspnModel_Adapt(MsgChnModel_Adapt):
         return eng
 
     def forward(self, image, sparse_depth, intrinsics=None, crop_mask=None, loss_type='pretrain'):
+        if 'head' in loss_type and 'init_meta' not in loss_type and loss_type != 'prepare':       # stage 2 (src/head_main.py:464-468)
+            if not self.training:
+                raise NotImplementedError('the head forward is a training-mode call (head_main.py:441)')
+            return self.head_forward(image, sparse_depth, loss_type)
         if self.training and 'adapt' in loss_type:
             # (depth, emb, ref) with autograd edges to the 88 adapted tensors: loss.backward() runs ptta_loss_backward +
             # ptta_backward and fills their .grad (src/tta_main.py:610-632)

@@ -251,6 +251,26 @@ __device__ __forceinline__ void load_weights(uint4 (&wh)[9][2], unsigned char* w
     }
 }
 
+// the LDS operands of one (tap, k) step in registers and its products -- mma_step split in two so that the reads of a later step can be issued
+// in front of the MFMAs of an earlier one (same products in the same order as mma_step)
+template <typename T, bool W2> struct FragSet { uint4 ah, al, bl; };
+template <typename T, bool W2>
+__device__ __forceinline__ void frag_load(FragSet<T, W2>& f, const unsigned char* a, const unsigned char* wl) {
+    f.ah = *(const uint4*)a;
+    if constexpr (sizeof(T) == 4) { f.al = *(const uint4*)(a + Geo<T>::LO); f.bl = *(const uint4*)wl; }
+    else if constexpr (W2) f.bl = *(const uint4*)wl;
+}
+template <typename T, bool W2>
+__device__ __forceinline__ void frag_mma(f32x16& acc, const FragSet<T, W2>& f, const uint4& wh) {
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, f.ah), bh = __builtin_bit_cast(bf16x8, wh);
+    if constexpr (sizeof(T) == 2 && W2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, f.bl), acc, 0, 0, 0);
+    if constexpr (sizeof(T) == 4) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.al), bh, acc, 0, 0, 0);   // small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, __builtin_bit_cast(bf16x8, f.bl), acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
 // bilinear x2 skip: the half-resolution source window of a tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers,
 // one 1-KB piece = 8 (fp32) / 16 (narrow) source pixels per wave instruction, lane-linear image [pixel][32 channels], clamped at the borders)
 template <typename T, int UPH, int UPW>
@@ -274,8 +294,14 @@ __device__ __forceinline__ void up_window_dma(const T* ub, int Hu, int Wu, int u
 // staged into LDS.  Each wave computes two 32-pixel rows; the hi weight fragments (72 VGPRs) stay in registers across the persistent tile
 // loop, the lo fragments (fp32 storage) in LDS.  Without the bilinear epilogue the NEXT tile's global loads are issued before this tile's
 // MFMAs and land while the matrix cores work (software prefetch across the persistent tile loop).
-template <typename T, bool RELU, bool UP, bool MASK, bool ADD, bool W2 = false>
+// TIMING (make DIAG=1 only): s_memtime stamps around the phases of the tile loop, printed by two blocks of the launch
+#define X3STAMP(v) do { if constexpr (TIMING) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); v = t_; } } while (0)
+template <typename T, bool RELU, bool UP, bool MASK, bool ADD, bool W2 = false, bool TIMING = false>
 __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
+    unsigned long long T0 = 0, ta = 0, tb = 0, tc = 0, td = 0, te = 0, tf = 0, tg = 0, th = 0;
+    unsigned long long dWait = 0, dSplit = 0, dIssue = 0, dBar1 = 0, dMfma = 0, dEpi = 0, dBar2 = 0, dPro = 0;
+    int ntl = 0;
+    X3STAMP(T0);
     constexpr int STR = Geo<T>::STR, WL = (sizeof(T) == 4 || W2) ? 18 * 64 * 16 : 0;
     constexpr int UPH = 6, UPW = 18;                      // an 8x32 output tile reads <= 5x17 source pixels
     __shared__ __attribute__((aligned(16))) unsigned char lds[X3_PH * X3_PW * STR + WL + (UP ? UPH * UPW * Geo<T>::UPPX : 0)];
@@ -317,11 +343,15 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
     // weight fragments: loaded AFTER the first tile's loads were issued so that the two L2 round trips overlap
     uint4 wh[9][2];
     load_weights<T, W2>(wh, wl_lds, p.wpack, p.wpack2, tid, lane);
+    X3STAMP(ta); dPro = ta - T0;
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y0, x0;
         tile_coords(tile, b, y0, x0);
         int uy0 = 0, ux0 = 0;
+        X3STAMP(ta);
+        if constexpr (TIMING) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        X3STAMP(tb);
         if (UP) {
             // issued FIRST so that it flies while this tile's halo is split and written; drained before the next tile's register prefetch
             // is issued (vmcnt is in order: a later wait for the window would also wait for that prefetch)
@@ -336,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
             const int pix = x3_stage_pix(idx);
             if (pix < X3_PH * X3_PW) px_stage<RELU>(v[it], lds + pix * STR + 16 * (idx & 3), Geo<T>::LO);
         }
+        X3STAMP(tc);
         if (UP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the window has landed (and this tile's halo loads before it)
         // narrow masked epilogue: both rows' mask words are requested BEFORE the next tile's prefetch (ptta_common.h epi_mask_words)
         constexpr bool MWPRE = MASK && sizeof(T) == 2;
@@ -345,7 +376,9 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
             epi_mask_words<T>(p.epi, b, y0 + 2 * wave + 1, H, W, i, x0, h, mwp1);
         }
         if (PREFETCH && tile + gridDim.x < ntiles) issue_loads(tile + gridDim.x);
+        X3STAMP(td);
         lds_barrier();          // LDS-only: the next tile's global loads (issued above) stay in flight during the MFMAs
+        X3STAMP(te);
         // ---- two output rows per wave ------------------------------------------------------------
         auto do_row = [&](const int rr) __attribute__((always_inline)) {
             const int row = 2 * wave + rr;
@@ -354,14 +387,29 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // The fragment reads run AHEAD steps in front of their MFMAs (one step = the (tap, k) pair's reads and products).  Left to hipcc each
+            // ds_read_b128 is issued right in front of the MFMA that consumes it, behind s_waitcnt lgkmcnt(0): the LDS latency exposed every two or
+            // three matrix instructions, 65 - 75 cycles per MFMA instead of 32 (in-kernel stamps, round 6: the MFMA phase was 7 - 8 k of a tile's
+            // 14 k cycles).  The order is fixed by scheduling barriers around each step; the waits are the compiler's own counted lgkmcnt.
+            {
+                constexpr int AHEAD = sizeof(T) == 4 ? 1 : (W2 ? 2 : 4), RING = AHEAD + 1;
+                const unsigned char* const arow = lds + (row * X3_PW + i) * STR + 16 * h;
+                const unsigned char* const wrow = wl_lds + lane * 16;
+                FragSet<T, W2> fr[RING];
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int ky = tap / 3, kx = tap % 3;
-                const unsigned char* a = lds + ((row + ky) * X3_PW + i + kx) * STR + 16 * h;
+                for (int s_ = 0; s_ < AHEAD; ++s_) frag_load<T, W2>(fr[s_], arow + ((s_ / 6) * X3_PW + (s_ / 2) % 3) * STR + 32 * (s_ & 1), wrow + s_ * 1024);
 #pragma unroll
-                for (int k = 0; k < 2; ++k) mma_step<T, W2>(acc, a + 32 * k, wh[tap][k], wl_lds + ((tap * 2 + k) * 64 + lane) * 16);
-                if (kx == 2) __builtin_amdgcn_sched_barrier(0);      // bound the ds_read prefetch depth (VGPR pressure)
+                for (int s_ = 0; s_ < 18; ++s_) {
+                    if (s_ + AHEAD < 18) {
+                        const int n_ = s_ + AHEAD;
+                        frag_load<T, W2>(fr[n_ % RING], arow + ((n_ / 6) * X3_PW + (n_ / 2) % 3) * STR + 32 * (n_ & 1), wrow + n_ * 1024);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    frag_mma<T, W2>(acc, fr[s_ % RING], wh[s_ >> 1][s_ & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            if constexpr (TIMING) { X3STAMP(tf); dMfma += tf - (rr ? tg : te); }
             // (conv + bias) + bilinear, in the reference's order; the skip comes from the LDS window, added after the quad transpose
             if (UP) epi_tile<T, false, MASK, ADD, true, UPW>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, up_lds, uy0, ux0, &biasv);
             else {
@@ -370,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
                 for (int g = 0; g < 4; ++g) mws[g] = MWPRE ? (rr ? mwp1[g] : mwp0[g]) : 0u;
                 epi_tile<T, false, MASK, ADD>(p.epi, b, y, H, W, i, acc, x0, h, W, 1, 0, sy, sx, nullptr, 0, 0, &biasv, MWPRE ? mws : nullptr);
             }
+            if constexpr (TIMING) { X3STAMP(tg); dEpi += tg - tf; }
         };
         // (narrow masked variants: the two rows as straight-line code -- inside a loop the compiler's wait-count bookkeeping merges with the
         // back edge and waits vmcnt(0) for the preloaded mask words, i.e. for the prefetch issued behind them)
@@ -379,6 +428,19 @@ __global__ __launch_bounds__(256, 2) void conv32_s1_x3_kernel(Conv32P<T> p) {
             for (int rr = 0; rr < 2; ++rr) do_row(rr);
         }
         lds_barrier();          // LDS reuse only: do not wait for this tile's stores (nor the prefetch) to drain
+        if constexpr (TIMING) { X3STAMP(th); dWait += tb - ta; dSplit += tc - tb; dIssue += td - tc; dBar1 += te - td; dBar2 += th - tg; ++ntl; }
+    }
+    if constexpr (TIMING) {
+        X3STAMP(th);
+        if (wave == 0 && lane == 0 && (blockIdx.x < 20 || (blockIdx.x >= 256 && blockIdx.x < 276))) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            printf("x3map blk %d xcc %u se %u sh %u cu %u simd %u waveslot %u\n", (int)blockIdx.x, xcc & 15, (hwid >> 13) & 7, (hwid >> 12) & 1, (hwid >> 8) & 15, (hwid >> 4) & 3, hwid & 15);
+        }
+        if ((blockIdx.x == 102 || blockIdx.x == 307) && lane == 0 && ntl > 0)
+            printf("x3 blk %d wave %d tiles %d: life %llu pro %llu | per tile: vmwait %llu split+write %llu issue %llu barrier1 %llu mfma %llu epilogue %llu barrier2 %llu\n",
+                   (int)blockIdx.x, wave, ntl, th - T0, dPro, dWait / ntl, dSplit / ntl, dIssue / ntl, dBar1 / ntl, dMfma / ntl, dEpi / ntl, dBar2 / ntl);
     }
 }
 
@@ -1238,6 +1300,9 @@ static void launch_x3(const Conv32P<T>& p, int flags, int blocks, hipStream_t s)
         return;
     }
 #define K_(U, M, A) hipLaunchKernelGGL((conv32_s1_x3_kernel<T, RELU, U, M, A, W2>), dim3(blocks), dim3(256), 0, s, p)
+#ifdef PTTA_DIAG_STAMPS      // diagnostic build (make DIAG=1): in-kernel phase stamps of the plain launches (tools/bench_chain.py prints them)
+    if (flags == 0 && !W2 && RELU) { hipLaunchKernelGGL((conv32_s1_x3_kernel<T, RELU, false, false, false, false, true>), dim3(blocks), dim3(256), 0, s, p); return; }
+#endif
     switch (flags) {
         case 0: K_(false, false, false); break; case 1: K_(true, false, false); break;
         case 2: K_(false, true, false); break;  case 3: K_(true, true, false); break;

@@ -399,6 +399,34 @@ def head_stage2_workload(steps=30):
         torch.cuda.synchronize()
         out[name] = {'ms_per_step': 1e3 * (time.perf_counter() - t0) / steps, 'finite': bool(torch.isfinite(loss).all().item())}
     eng.close()
+    # the same trainer on the op-list engine (csrc/ghead.hip): NLSPN, 352x1216 -- two no-gradient ResNet34 encoder passes from running
+    # statistics + MLP(512, 1024, 1024) heads on 1,672 rows
+    mean = np.array([0.485, 0.456, 0.406], dtype=np.float32).reshape(1, 3, 1, 1)
+    std = np.array([0.229, 0.224, 0.225], dtype=np.float32).reshape(1, 3, 1, 1)
+    eng = Engine(1, H, W, backbone='nlspn', legacy_offset=True, lr=3e-4, w_sparse_depth=1.0, w_smoothness=0.0, w_cos=0.0, max_input_depth=80.0)
+    sdn = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict_nlspn().items()}
+    eng.load_state_dict({k: v for k, v in sdn.items() if v.dtype == torch.float32})
+    keep = [(sdn[k].clone().contiguous(), torch.zeros_like(sdn[k]), torch.zeros_like(sdn[k])) for k in eng.adapted]
+    for k, t in zip(eng.adapted, keep):
+        eng.bind_adapted(k, *t)
+    gp = ['%s.%s.%s' % (m, l, t) for m in ('proj', 'pred') for l in ('0', '1', '3') for t in ('weight', 'bias')]
+    for k in gp:
+        keep.append((torch.zeros_like(sdn[k]), torch.zeros_like(sdn[k])))
+        eng.bind_head(k, sdn[k], *keep[-1])
+    for k in gp[:6]:
+        eng.bind_head('proj_t' + k[4:], sdn['proj_t' + k[4:]])
+    eng.set_head_hparams(lr=2e-4, adam_step=0)
+    image01, sparse = synth.synthetic_frame(700, H, W, 1)
+    fr = (torch.from_numpy(((np.floor(image01 * 255) / 255 - mean) / std).astype(np.float32)).cuda(), torch.from_numpy(sparse).cuda())
+    for i in range(2):
+        eng.head_step(*fr, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(10):
+        loss = eng.head_step(*fr, True)
+    torch.cuda.synchronize()
+    out['nlspn_head_selfsup_seq_ema_reverse'] = {'ms_per_step': 1e3 * (time.perf_counter() - t0) / 10, 'finite': bool(torch.isfinite(loss).all().item())}
+    eng.close()
     return out
 
 

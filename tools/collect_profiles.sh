@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 profile artifacts of the FINAL tree (run through gpurun; outputs under gpurun_out/r05/, copy into profiles/).  For each mode
+# Round-6 profile artifacts of the FINAL tree (run through gpurun; outputs under gpurun_out/r05/, copy into profiles/).  For each mode
 # (mixed = the headline / bench default, fp32):
 #   1. rocprofv3 --kernel-trace --stats of the bench command (as the driver runs it: direct launches, three streams) + the bench JSON of that run
 #   2. ONE step of the timed region as its ordered launch sequence (from the same trace) and one step of the one-stream profiling leg, grouped by kernel
@@ -7,7 +7,7 @@
 #      same kernels over a map of known size), SQ counters
 # then 4. what a small convolution launch costs inside a replayed graph; 5. NLSPN and CostDCNet: top kernels
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=r05; O=gpurun_out/$R; rm -rf $O; mkdir -p $O
+R=r06; O=gpurun_out/$R; rm -rf $O; mkdir -p $O
 CLASS='conv32_s1_(x3_kernel<(float|unsigned short), true|first_kernel<(float|unsigned short), [23])'      # bench.py's dominant kernel: ReLU-on-load stride-1 convolutions on large maps, forward forms
 SHORT="--steps 4 --warmup 2 --single-block --no-nlspn --no-cpu-baseline --no-self-check"
 # counter calibration on a known byte count (one 352x1216 map in, one out)

@@ -506,7 +506,8 @@ def costdcnet_shared(args, rank, world, dist):
                                    'BatchNorm1d / the sparse encoder\'s, 116 listed entries = 112 tensors, src/costdcnet_model_adapt.py:364-366)',
                        'parallelism': 'dp%d: SyncBatchNorm statistics exchange per BatchNorm (forward and backward) + one flat gradient all-reduce '
                                       '(11,888 floats) per step' % world,
-                       'exchange': mode, 'rccl_ranks': world, 'params_bitwise_equal_across_ranks_after_warmup': same, 'finite': finite}}))
+                       'exchange': mode, 'rccl_ranks': world, 'params_bitwise_equal_across_ranks_after_warmup': same, 'finite': finite,
+                       'launch_form': 'ptta_step call by call (the generic engine has no pipelined form: ptta_get_option "pipelined_active" = 0)'}}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -1008,6 +1009,7 @@ def main():
     # Roofline leg: the timed region above replays a hipGraph, inside which kernels cannot be
     # bracketed by events, so the SAME K steps are re-run kernel by kernel right here with every
     # launch of the dominant kernel class bracketed by hipEvents on its launch stream.
+    pipe_active = eng.get_option('pipelined_active')          # (read before the profiling leg switches the handle to one stream)
     eng.profile(True)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -1087,6 +1089,8 @@ def main():
                        'ms_per_step_without_frame_pipelining': plain_ms,
                        # the timed path against plain ptta_step on fresh handles, bit for bit (null: not run -- N > 1 or --no-self-check)
                        'pipelined_equals_plain': eq_plain,
+                       # 1: ptta_step_pipelined ran as itself on the timed handle; 0: it degraded to ptta_step call by call (include/ptta.h)
+                       'pipelined_active': pipe_active,
                        'rccl_ranks': world if (dist is not None and dist.get_backend() == 'nccl') else (0 if dist is None else None),
                        'collective_backend': None if dist is None else dist.get_backend()},
             'step_roofline': {'alg_bytes_per_step': step_bytes, 'alg_flop_per_step': ALG_FLOP_PER_STEP,

@@ -151,11 +151,15 @@ def test_mixed_cosine_gate_on_the_reference_side(golden_dir, side, path):
 
 
 @pytest.mark.parametrize('graph', [0, 1])
-@pytest.mark.parametrize('meta,size', [('1layer', (64, 128)), ('1layer', (352, 1216)), ('2layers', (352, 1216)), ('1layer', (36, 52))])
+@pytest.mark.parametrize('meta,size', [('1layer', (64, 128)), ('1layer', (352, 1216)), ('2layers', (352, 1216)), ('1layer', (36, 52)),
+                                       ('1layer', (2, 176, 608)), ('1layer', (8, 64, 128))])
 def test_mixed_pipelined_equals_plain(meta, size, graph):
     """Bitwise, six frames incl. an unannounced one, in the mixed mode (two launch chains per forward, narrow twins of the prefix's outputs in
-    both buffer sets); 36x52: the dual-corner padded path (falls back to the plain call)."""
+    both buffer sets); 36x52: the dual-corner padded path (falls back to the plain call); three-element sizes: N frames per call (N = 8: more
+    cosine-partial slots than the 1,024 of N <= 4)."""
     n = 1
+    if len(size) == 3:
+        n, size = size[0], size[1:]
     h, w = size
     hp = dict(lr=1e-3, w_sparse_depth=1.0, w_smoothness=2.0, w_cos=0.1, max_input_depth=80.0)
     frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(60 + i, h, w, n)] for i in range(7)]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every bracketed launch of ONE profiled step (ptta_profile: kernel by kernel on one stream, hipEvents around each launch) in launch order:
 class and microseconds -- what the step's launches cost alone, without the profiler's per-kernel overhead (debug tensor "prof_seq").
-usage: python tools/tail_launches.py [mixed|fp32]"""
+usage: python tools/tail_launches.py [mixed|fp32] [N frames per call]"""
 import os
 import sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
@@ -14,13 +14,14 @@ from proxytta import synth
 from proxytta.engine import ADAPTED, Engine
 
 dtype = sys.argv[1] if len(sys.argv) > 1 else 'mixed'
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 H, W = bench.H, bench.W
-eng = Engine(1, H, W, dtype=dtype, **bench.HP)
+eng = Engine(N, H, W, dtype=dtype, **bench.HP)
 sd = {k: torch.from_numpy(np.asarray(v)).cuda() for k, v in synth.formula_state_dict(bench.MODE).items()}
 eng.load_state_dict(sd)
 for name in ADAPTED:
     eng.bind_adapted(name, sd[name], torch.zeros_like(sd[name]), torch.zeros_like(sd[name]))
-frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(i, H, W, 1)] for i in range(4)]
+frames = [[torch.from_numpy(x).cuda() for x in synth.synthetic_frame(i * 16, H, W, N)] for i in range(4)]
 for i in range(10):
     eng.step(*frames[i % 4])
 CLASSES = ['s1_relu_large', 's1_relu_small', 's1_plain_large', 's1_plain_small', 'strided_large', 'strided_small', 'heads', 'in_out_convs', 'rest']

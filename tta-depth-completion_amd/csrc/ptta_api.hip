@@ -208,8 +208,12 @@ struct ptta_ctx {
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_real = nullptr;
     hipEvent_t ev_side[4] = {nullptr, nullptr, nullptr, nullptr};        // backbone_backward: transposed upsamplings beside the main chain
-    hipStream_t aux(hipStream_t) {
-        if (!use_aux || prof_on) return nullptr;
+    // profiling leg (ptta_profile): the SAME schedule with the caller's stream standing in for the second one -- every fork / join becomes an
+    // event recorded and awaited on one stream (a no-op), the enqueue order is a valid serial order (a wait is always enqueued behind its
+    // record), and the bracketed launches are exactly the ones the timed step runs (round 5's leg took the one-stream FALLBACK forms: two
+    // extra widening launches and the fp32 loss kernels, 36 us of `rest` at batch 1 that the step does not contain)
+    hipStream_t aux(hipStream_t caller) {
+        if (!use_aux) return nullptr;
         if (!aux_stream) {
             if (hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
             if (hipEventCreateWithFlags(&ev_fork, kStepEvent) != hipSuccess ||
@@ -218,7 +222,7 @@ struct ptta_ctx {
                 hipEventCreateWithFlags(&ev_side[0], kStepEvent) != hipSuccess || hipEventCreateWithFlags(&ev_side[1], kStepEvent) != hipSuccess ||
                 hipEventCreateWithFlags(&ev_side[2], kStepEvent) != hipSuccess || hipEventCreateWithFlags(&ev_side[3], kStepEvent) != hipSuccess) { (void)hipStreamDestroy(aux_stream); aux_stream = nullptr; return nullptr; }
         }
-        return aux_stream;
+        return prof_on ? caller : aux_stream;
     }
     float *in_image = nullptr, *in_loss_image = nullptr, *in_sparse = nullptr, *in_validity = nullptr;
     hipEvent_t ev_replay = nullptr;      // recorded after every hipGraphLaunch: a graph is only destroyed once its last replay is done
@@ -1449,7 +1453,7 @@ int backbone_backward(ptta_ctx* c, const float* g_net, hipStream_t s, bool join_
     REST_(sd, ptta_launch_up2T_32(c->de3_1, nullptr, c->up3_t, Nn, H4, W4, nbf, sd));
     REST_(sd, ptta_launch_up2T_32(c->dfeat_tot, nullptr, c->dz2_up, Nn, H8, W8, nbf, sd));
     if (sd != s) HIPCHK(hipEventRecord(c->ev_side[3], sd));
-    if (sd != s && c->loss_report.on) {
+    if (c->loss_report.on) {             // (sd == s: the profiling leg)
         // the loss VALUES (thru step): depth terms reduced here, behind the upsamplings the main chain waits for, then the one-block finalisation
         // that writes the four reported scalars; main joins in front of the weight gradient (ev_loss)
         REST_(sd, ptta_launch_loss_depth_part(final_depth(c), c->loss_report.image, c->loss_report.sparse, c->loss_report.validity, c->hp.max_input_depth,

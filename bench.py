@@ -364,8 +364,8 @@ def nlspn_workload(frames=10, inner_iter=3, dtype='fp32', with_mixed=True):
            'finite': bool(torch.isfinite(info).all().item() and torch.isfinite(d).all().item())}
     eng.close()
     if dtype == 'fp32' and with_mixed:
-        # the generic engine's mixed mode beside it (fp32 storage; one bf16 MFMA per product for the proxy frames and the data gradients;
-        # scored depth 2.0e-4 after the three steps: tests/test_gpu_mixed.py, profiles/r05_nlspn_costdcnet_mixed.txt)
+        # the generic engine's mixed mode beside it (fp32 storage; one bf16 MFMA per product for the proxy frames, two -- hi + lo weights --
+        # for the data gradients; scored depth 3.5e-5 after the three steps: tests/test_gpu_mixed.py, profiles/r06_nlspn_costdcnet_mixed.txt)
         m = nlspn_workload(frames, inner_iter, dtype='mixed')
         out['mixed_mode'] = {'ms_per_step': m['ms_per_step'], 'frames_per_s': m['frames_per_s'], 'eval_forward_ms': m['eval_forward_ms'], 'finite': m['finite']}
     return out

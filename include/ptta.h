@@ -67,16 +67,20 @@ enum { PTTA_BACKBONE_MSG_CHN = 0, PTTA_BACKBONE_NLSPN = 1, PTTA_BACKBONE_COSTDCN
  *   frames' forward -- the tensors the scored depth map is made of -- exactly as PTTA_DTYPE_F32; the tensors the reference computes under
  *   no_grad or detaches (the zero-image proxy pass, network_exp_msg_chn_adapt.py:509-532, the embedding branch :551-554) and the data
  *   gradients of loss.backward() (src/tta_main.py:632), which reach the scored depth only through an lr-sized Adam move, are NARROW: bf16
- *   storage, one bf16 MFMA per product, fp32 accumulate.  depth_train is bit-identical to PTTA_DTYPE_F32; measured budget per tensor
+ *   storage, one bf16 MFMA per product, fp32 accumulate -- except the WEIGHT operand of the data gradients, which stays bf16 hi + lo (two
+ *   MFMAs, option "bwd_w2"): a rounded weight is a systematic error of the gradient's direction and showed over 100+ steps.  depth_train is bit-identical to PTTA_DTYPE_F32; measured budget per tensor
  *   class: profiles/r05_precision_budget.txt; bounds per mode: tests/test_gpu_mixed.py.  PTTA_ARITH=exact / PTTA_CONV_IMPL=naive are
  *   PTTA_DTYPE_F32-only (ptta_create returns -38 with PTTA_DTYPE_MIXED). */
 /* PTTA_BACKBONE_NLSPN with PTTA_DTYPE_MIXED: the generic engine keeps fp32 storage and switches the matrix-core convolutions of the proxy
- * frames and of the data gradients to one bf16 MFMA per product (scored depth 2.0e-4 after config 3's three steps, 23.3 -> 21.5 ms per step).
- * PTTA_BACKBONE_COSTDCNET refuses it (-38): its scored depth leaves the tolerance (profiles/r05_nlspn_costdcnet_mixed.txt). */
+ * frames to one bf16 MFMA per product and those of the data gradients to two (hi activations x hi + lo weights; PTTA_MIXED_BWD_ROUNDED_W:
+ * one, round 5's form -- scored depth 2.0e-4 after config 3's three steps and growing 6e-5 per step with it).
+ * PTTA_BACKBONE_COSTDCNET refuses it (-38): its scored depth leaves the tolerance (profiles/r06_nlspn_costdcnet_mixed.txt). */
 enum { PTTA_DTYPE_F32 = 0, PTTA_DTYPE_MIXED = 1,
        /* OR-ed into PTTA_DTYPE_MIXED (precision budget, tools/accuracy_report.py --keep): keep one of the three narrow classes at fp32 storage
         * and bf16x3 arithmetic -- the proxy chain, the data gradients, the heads */
-       PTTA_MIXED_KEEP_PROXY = 0x100, PTTA_MIXED_KEEP_BACKWARD = 0x200, PTTA_MIXED_KEEP_HEADS = 0x400 };
+       PTTA_MIXED_KEEP_PROXY = 0x100, PTTA_MIXED_KEEP_BACKWARD = 0x200, PTTA_MIXED_KEEP_HEADS = 0x400,
+       /* generic engine, comparison only: the data gradients on bf16-ROUNDED weights, one MFMA per product (round 5's mixed mode) */
+       PTTA_MIXED_BWD_ROUNDED_W = 0x800 };
 enum { PTTA_META_1LAYER = 0, PTTA_META_2LAYERS = 1 };   /* conv1_rgb_meta = Conv2d(32,32,3) | Res_Conv(32,128) */
 /* NLSPN only, OR-ed into meta_mode: ExternalModel_Adapt(..., offset=True) -> args.legacy (src/nlspn_model_adapt.py:62):
  * the confidence gathers add each tap's own (dy, dx) to the learned offset (nlspnmodel_adapt.py:297-302).

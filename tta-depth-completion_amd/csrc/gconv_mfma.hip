@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256, SIX ? 2 : 3) void gconv_x3_s1_kernel(GX3Args p
             if (!x1) {
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh, acc[1], 0, 0, 0);
+            }
+            if (!x1 || p.x1_w2) {                          // (x1 with hi + lo WEIGHTS: the data gradients of the mixed mode, GX3Args::x1_w2)
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl, acc[0], 0, 0, 0);
             acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl, acc[1], 0, 0, 0);
             }
@@ -490,10 +492,8 @@ __global__ __launch_bounds__(256) void gconv_x3_direct_kernel(GX3Args p, int Hin
                 for (int rr = 0; rr < R; ++rr)
 #pragma unroll
                     for (int t = 0; t < NCO; ++t) {
-                        if (!x1) {
-                        acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh[t], acc[t][rr], 0, 0, 0);
-                        acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl[t], acc[t][rr], 0, 0, 0);
-                        }
+                        if (!x1) acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rr], bh[t], acc[t][rr], 0, 0, 0);
+                        if (!x1 || p.x1_w2) acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bl[t], acc[t][rr], 0, 0, 0);
                         acc[t][rr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rr], bh[t], acc[t][rr], 0, 0, 0);
                     }
             }

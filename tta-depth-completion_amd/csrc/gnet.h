@@ -132,7 +132,8 @@ struct GNet {
     int t_emb = -1, t_ref = -1;
     int naive = 0;
     // mixed mode (include/ptta.h PTTA_DTYPE_MIXED for the generic engine): fp32 storage everywhere; the matrix-core convolutions of the
-    // proxy frames (bit 0) and of the data gradients (bit 1) take one bf16 MFMA per product instead of three (GX3Args::x1_from_B)
+    // proxy frames (bit 0) and of the data gradients (bit 1) take one bf16 MFMA per product instead of three (GX3Args::x1_from_B); bit 2: the data
+    // gradients with hi activations x (hi + lo) weights, two MFMAs (GX3Args::x1_w2) -- what PTTA_DTYPE_MIXED selects since round 6
     int mixed = 0;
     // bf16x6 forward for the real frames (GX3Args::six_B): the two-way operand split's 2^-17 representation error reaches the depth
     // map as ~2e-5 relative, enough to flip the sign of near-zero gradient entries -- and Adam's first step turns a sign into +-lr

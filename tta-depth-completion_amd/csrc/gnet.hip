@@ -178,7 +178,7 @@ int GNet::run_conv_bwd(const Op& o, hipStream_t s) {
             a.y = gx.p; a.ldy = gx.ld; a.Cy = gx.C; a.accumulate = o.first_x[sidx] ? 0 : 1;
             a.B = gx.B; a.H = gx.H; a.W = gx.W;                  // output geometry = the source's
             a.vert = cw.vcol;
-            if (mixed & 2) a.x1_from_B = 0;                      // data gradients: one MFMA per product
+            if (mixed & 6) { a.x1_from_B = 0; a.x1_w2 = (mixed & 4) ? 1 : 0; }      // data gradients: hi activations; bit 1: x bf16-rounded weights, bit 2: x (hi + lo) weights
             int rc;
             if (o.stride == 1 && !o.transposed) rc = ptta_launch_gconv_x3(a, o.k, s);
             else rc = ptta_launch_gconv_x3_strided(a, o.k, o.transposed ? 1 : 2, gy.H, gy.W, s);     // convT -> strided conv, strided conv -> convT

@@ -363,6 +363,9 @@ struct GX3Args {
     // mixed mode of the generic engine: images b >= x1_from_B take ONE bf16 MFMA per product (hi x hi) instead of three -- the proxy frames
     // of a [real | proxy] launch (the reference's no_grad pass) and every data-gradient launch (x1_from_B = 0)
     int x1_from_B = 1 << 30;
+    // ... with the WEIGHT operand kept as hi + lo (two MFMAs: a_hi w_lo, a_hi w_hi): the data gradients.  A bf16-rounded weight is a systematic
+    // error of the gradient's direction (conv32.hip mma_step W2), a rounded gradient value is noise
+    int x1_w2 = 0;
 };
 void ptta_gfrag_pack(const float* canon, long wld, long wts, int KK, int C0, int C1, int c0_0, int c0_1, int Co, bf16_t* hi, bf16_t* lo,
                      hipStream_t s, bf16_t* l2 = nullptr);

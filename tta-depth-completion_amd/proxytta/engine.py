@@ -74,7 +74,7 @@ class Engine:
         code = {'fp32': _lib.PTTA_DTYPE_F32, 'mixed': _lib.PTTA_DTYPE_MIXED}[dtype]
         # precision budget only: classes of the mixed mode kept at fp32 / bf16x3 (include/ptta.h PTTA_MIXED_KEEP_*)
         for k in keep:
-            code |= {'proxy': 0x100, 'backward': 0x200, 'heads': 0x400}[k]
+            code |= {'proxy': 0x100, 'backward': 0x200, 'heads': 0x400, 'bwd_rounded_w': 0x800}[k]
         rc = self.lib.ptta_create(byref(self.handle),
                                   {'nlspn': _lib.PTTA_BACKBONE_NLSPN, 'costdcnet': _lib.PTTA_BACKBONE_COSTDCNET}.get(backbone, _lib.PTTA_BACKBONE_MSG_CHN),
                                   (_lib.PTTA_META_2LAYERS if meta == '2layers' else _lib.PTTA_META_1LAYER) |

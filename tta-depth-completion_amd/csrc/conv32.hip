@@ -189,6 +189,10 @@ __device__ __forceinline__ Px<bf16_t> px_load(const bf16_t* src) { Px<bf16_t> r;
 template <bool RELU>
 __device__ __forceinline__ void px_stage(const Px<float>& v, unsigned char* dst, int lo_off) {
     float4 a0 = v.a, a1 = v.b;
+#ifdef X3_TIMING_NOSPLIT
+    // timing-only (wrong values): the staged pixel taken as if the producer had stored it split -- the upper bound of a pre-split storage format
+    *(float4*)dst = a0; *(float4*)(dst + lo_off) = a1; return;
+#endif
     if (RELU) { a0 = relu4(a0); a1 = relu4(a1); }
     uint4 hi, lo;
     split2(a0.x, a0.y, hi.x, lo.x); split2(a0.z, a0.w, hi.y, lo.y);

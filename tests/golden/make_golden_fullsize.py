@@ -154,6 +154,8 @@ CASES = {
     # the reference's operating point is n_batch // ngpus frames per rank (bash/adapt/adapt_msgchn_vkitti.sh:21, src/tta_main.py:224)
     'msgchn_1layer_352x1216_n2': lambda e: run_case(e, 'msgchn_1layer_352x1216_n2', 'meta_selfsup_seq_1layer_ema', 352, 1216, 2, 2, frame0=20),
     'msgchn_1layer_352x1216_n4': lambda e: run_case(e, 'msgchn_1layer_352x1216_n4', 'meta_selfsup_seq_1layer_ema', 352, 1216, 4, 2, frame0=30),
+    # N = 8: beyond the 1,024 cosine-partial slots that N >= 5 overran before round 6 (loss.hip loss_cb) -- the reference's own operating range
+    'msgchn_1layer_352x1216_n8': lambda e: run_case(e, 'msgchn_1layer_352x1216_n8', 'meta_selfsup_seq_1layer_ema', 352, 1216, 8, 2, frame0=40),
     # long horizons: one parameter set adapted over a stream of frames (src/tta_main.py:504-636)
     'msgchn_1layer_64x96_seq200': lambda e: run_case(e, 'msgchn_1layer_64x96_seq200', 'meta_selfsup_seq_1layer_ema', 64, 96, 1, 200,
                                                      full_every=20, frame0=1000, light=True, moments=False, alt=True),

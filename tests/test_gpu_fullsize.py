@@ -31,7 +31,7 @@ def _check_map(got, g, key, tol):
 @pytest.mark.parametrize('name,meta', [('msgchn_1layer_352x1216', '1layer'), ('msgchn_1layer_256x320', '1layer'),
                                        ('msgchn_2layers_352x1216', '2layers'), ('msgchn_2layers_256x320', '2layers'),
                                        # N frames per call: the reference's operating point (n_batch // ngpus per rank, src/tta_main.py:224)
-                                       ('msgchn_1layer_352x1216_n2', '1layer'), ('msgchn_1layer_352x1216_n4', '1layer')])
+                                       ('msgchn_1layer_352x1216_n2', '1layer'), ('msgchn_1layer_352x1216_n4', '1layer'), ('msgchn_1layer_352x1216_n8', '1layer')])
 def test_full_size_matches_reference(golden_dir, name, meta, path):
     """path = 'pipelined': the path bench.py's headline times -- ptta_step_pipelined (every call announces frame s + 1, whose
     parameter-independent prefix runs on the second stream beside this step) and the scored forward from ptta_forward_eval_last --

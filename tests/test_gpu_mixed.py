@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('name,meta', [('msgchn_1layer_352x1216', '1layer'), ('msgchn_1layer_256x320', '1layer'),
                                        ('msgchn_2layers_352x1216', '2layers'), ('msgchn_2layers_256x320', '2layers'),
                                        # N frames per call: the reference's operating point (n_batch // ngpus per rank, src/tta_main.py:224)
-                                       ('msgchn_1layer_352x1216_n2', '1layer'), ('msgchn_1layer_352x1216_n4', '1layer')])
+                                       ('msgchn_1layer_352x1216_n2', '1layer'), ('msgchn_1layer_352x1216_n4', '1layer'), ('msgchn_1layer_352x1216_n8', '1layer')])
 def test_mixed_full_size_matches_reference(golden_dir, name, meta, path):
     g = np.load(os.path.join(golden_dir, name + '.npz'))
     h, w, n, steps, frame0 = [int(x) for x in g['meta']]

@@ -28,7 +28,9 @@ __device__ __forceinline__ float gbn_act(float v, int act) {
 
 // partial sums over the pixels of one pass: MODE 0: {sum x, sum x^2}; MODE 1: {sum g1, sum g1*xhat}
 // part layout [pass][block][2][C]
-template <int MODE>
+// YLESS (MODE 1, plain ReLU without a residual): the ReLU mask is recomputed as fma(x, scale, shift) > 0 -- the very expression whose
+// sign the forward stored as y > 0 (gbn_apply_kernel) -- so the saved output is not read: 2 of the backward's 7 map passes less
+template <int MODE, bool YLESS = false>
 __global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView y, int npass, int act, int res_relu,
                                                         const float* __restrict__ mean, const float* __restrict__ inv,
                                                         float* __restrict__ part, const float* __restrict__ fscale = nullptr,
@@ -63,12 +65,14 @@ __global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView 
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const long q = pix0 + p + k * pstride;
-                        xv[k] = x.p[q * x.ld + c]; gv[k] = g.p[q * g.ld + c]; yv[k] = y.p[q * y.ld + c];
+                        xv[k] = x.p[q * x.ld + c]; gv[k] = g.p[q * g.ld + c];
+                        if constexpr (YLESS) yv[k] = fmaf(xv[k], fs, fh); else yv[k] = y.p[q * y.ld + c];
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float gk = gv[k];
-                        if (res_relu) {
+                        if constexpr (YLESS) gk = yv[k] > 0.f ? gk : 0.f;
+                        else if (res_relu) {
                             gk = yv[k] > 0.f ? gk : 0.f;
                             if (fscale) gk = fmaf(xv[k], fs, fh) > 0.f ? gk : 0.f;
                         } else gk = gbn_act_grad(gk, yv[k], act);
@@ -81,8 +85,9 @@ __global__ __launch_bounds__(256) void gbn_stats_kernel(GView x, GView g, GView 
                 if (MODE == 0) { s1 += xv; s2 += xv * xv; }
                 else {
                     float gv = g.p[(pix0 + p) * g.ld + c];
-                    const float yv = y.p[(pix0 + p) * y.ld + c];
-                    if (res_relu) {
+                    const float yv = YLESS ? fmaf(xv, fscale[c], fshift[c]) : y.p[(pix0 + p) * y.ld + c];
+                    if constexpr (YLESS) gv = yv > 0.f ? gv : 0.f;
+                    else if (res_relu) {
                         gv = yv > 0.f ? gv : 0.f;
                         if (fscale) gv = fmaf(xv, fscale[c], fshift[c]) > 0.f ? gv : 0.f;      // inner ReLU of relu(relu(bn x) + res)
                     } else gv = gbn_act_grad(gv, yv, act);
@@ -300,6 +305,8 @@ __global__ __launch_bounds__(256) void gbn_bwd_finalize_kernel(const float* __re
 }
 
 // gx (+)= gscale*(g1 - c1 - xhat*c2) ; gres (+)= g1 (residual branch of a BasicBlock); four channels per thread
+// YLESS: as gbn_stats_kernel -- plain ReLU, the mask from fma(x, fscale, fshift) > 0, y not read
+template <bool YLESS>
 __global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView gres, int act, int res_relu, int acc_gx, int acc_gres,
                                      const float* __restrict__ mean, const float* __restrict__ inv, const float* __restrict__ bw,
                                      const float* __restrict__ fscale = nullptr, const float* __restrict__ fshift = nullptr) {
@@ -307,8 +314,13 @@ __global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView 
     const long total = (long)g.B * g.H * g.W * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c = (int)(idx % C4) << 2; const long pix = idx / C4;
-        const float4 g4 = *(const float4*)(g.p + pix * g.ld + c), y4 = *(const float4*)(y.p + pix * y.ld + c);
+        const float4 g4 = *(const float4*)(g.p + pix * g.ld + c);
         const float4 x4 = *(const float4*)(x.p + pix * x.ld + c);
+        float4 y4;
+        if constexpr (YLESS) {
+            const float4 fs = *(const float4*)(fscale + c), fh = *(const float4*)(fshift + c);
+            y4 = make_float4(fmaf(x4.x, fs.x, fh.x), fmaf(x4.y, fs.y, fh.y), fmaf(x4.z, fs.z, fh.z), fmaf(x4.w, fs.w, fh.w));
+        } else y4 = *(const float4*)(y.p + pix * y.ld + c);
         const float4 mu = *(const float4*)(mean + c), iv = *(const float4*)(inv + c);
         const float4 b0 = *(const float4*)(bw + c), b1 = *(const float4*)(bw + C + c), b2 = *(const float4*)(bw + 2 * C + c);
         float gv[4] = {g4.x, g4.y, g4.z, g4.w};
@@ -318,10 +330,10 @@ __global__ void gbn_bwd_apply_kernel(GView x, GView g, GView y, GView gx, GView 
         float d[4], gb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (res_relu) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;                      // gradient of the block's final ReLU (goes to the residual too)
+            if (YLESS || res_relu) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;             // gradient of the block's final ReLU (goes to the residual too)
             else gv[k] = gbn_act_grad(gv[k], yv[k], act);
             gb[k] = gv[k];
-            if (res_relu && fscale) gb[k] = fmaf(xv[k], fscale[c + k], fshift[c + k]) > 0.f ? gv[k] : 0.f;   // inner ReLU of relu(relu(bn x) + res)
+            if (!YLESS && res_relu && fscale) gb[k] = fmaf(xv[k], fscale[c + k], fshift[c + k]) > 0.f ? gv[k] : 0.f;   // inner ReLU of relu(relu(bn x) + res)
             const float xh = (xv[k] - m_[k]) * i_[k];
             d[k] = s_[k] * (gb[k] - c1[k] - xh * c2[k]);
         }
@@ -351,15 +363,20 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
     // act_first (CostDCNet's ResBlock, encoder2d.py:44-52): the inner ReLU's mask is recomputed from x and the forward affine
     const float* fscale = (act_first && res_relu) ? st + 2L * npass * C : nullptr;
     const float* fshift = (act_first && res_relu) ? st + 3L * npass * C : nullptr;
-    hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, fscale, fshift);
+    // plain ReLU (no residual): the mask comes from x and the forward affine of pass 0, the saved output is not read
+    const bool yless = !res_relu && act == GACT_RELU && !act_first;
+    const float* ysc = st + 2L * npass * C; const float* ysh = st + 3L * npass * C;
+    if (yless) hipLaunchKernelGGL((gbn_stats_kernel<1, true>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, ysc, ysh);
+    else hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, fscale, fshift);
     long Rg = R; float gsc = 1.f;
     if (sync && sync->on()) { const int rc = ptta_stat_sync(sync, part, blocks, C, 1, s); if (rc) return rc; Rg = R * sync->world; gsc = 1.f / (float)sync->world; }
     hipLaunchKernelGGL(gbn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, part, blocks, C, Rg, gamma, inv, dgamma, dbeta, bw, gsc);
     if ((C & 3) || (x.ld & 3) || (g.ld & 3) || (y.ld & 3) || (gx.ld & 3) || (gres.p && (gres.ld & 3))) return -22;
     const long total = R * (C >> 2);
     long ab = (total + 255) / 256; if (ab > 16384) ab = 16384; if (ab < 1) ab = 1;
-    hipLaunchKernelGGL(gbn_bwd_apply_kernel, dim3((int)ab), dim3(256), 0, s, x0, g, y0, gx, gres, act, res_relu, acc_gx, acc_gres, mean, inv, bw,
-                       fscale, fshift);
+    if (yless) hipLaunchKernelGGL(gbn_bwd_apply_kernel<true>, dim3((int)ab), dim3(256), 0, s, x0, g, y0, gx, gres, act, res_relu, acc_gx, acc_gres, mean, inv, bw, ysc, ysh);
+    else hipLaunchKernelGGL(gbn_bwd_apply_kernel<false>, dim3((int)ab), dim3(256), 0, s, x0, g, y0, gx, gres, act, res_relu, acc_gx, acc_gres, mean, inv, bw,
+                            fscale, fshift);
     PTTA_CHECK_LAUNCH();
     return 0;
 }

@@ -364,7 +364,11 @@ int ptta_launch_gbn_backward(const GView& x, const GView& g, const GView& y, con
     const float* fscale = (act_first && res_relu) ? st + 2L * npass * C : nullptr;
     const float* fshift = (act_first && res_relu) ? st + 3L * npass * C : nullptr;
     // plain ReLU (no residual): the mask comes from x and the forward affine of pass 0, the saved output is not read
+#ifdef GBN_NO_YLESS                   // (comparison builds only: tools/exp/yless_bitwise.sh)
+    const bool yless = false;
+#else
     const bool yless = !res_relu && act == GACT_RELU && !act_first;
+#endif
     const float* ysc = st + 2L * npass * C; const float* ysh = st + 3L * npass * C;
     if (yless) hipLaunchKernelGGL((gbn_stats_kernel<1, true>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, ysc, ysh);
     else hipLaunchKernelGGL((gbn_stats_kernel<1>), dim3(blocks, 1), dim3(256), lds, s, x0, g, y0, 1, act, res_relu, mean, inv, part, fscale, fshift);

@@ -126,7 +126,7 @@ def sample_rows(x, k=24):
     return idx, x[idx]
 
 
-def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_frame=False):
+def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_frame=False, light=False):
     model = ema.ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], offset=offset, device=torch.device('cpu'))
     model._prepare_head(PREPARE)
     net = model.model.model
@@ -174,9 +174,11 @@ def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_fr
         out[p + 'n_zero_train'] = np.array(int((depth == 0).sum()))
         out[p + 'n_zero_eval'] = np.array(int((depth_eval == 0).sum()))
         e, r = emb.detach().numpy(), ref.detach().numpy()
-        idx, out[p + 'emb_rows'] = sample_rows(e)
-        _, out[p + 'ref_rows'] = sample_rows(r)
-        out[p + 'row_idx'] = idx
+        full = not light or s in (0, steps - 1)             # light (long sequences): tensors at the first and the last step only
+        if full:
+            idx, out[p + 'emb_rows'] = sample_rows(e)
+            _, out[p + 'ref_rows'] = sample_rows(r)
+            out[p + 'row_idx'] = idx
         out[p + 'emb_shape'] = np.array(e.shape)
         out[p + 'emb_abs_mean'] = np.array(np.abs(e).mean(dtype=np.float64))
         out[p + 'ref_abs_mean'] = np.array(np.abs(r).mean(dtype=np.float64))
@@ -186,7 +188,7 @@ def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_fr
         out[p + 'grad_norms'] = np.array([float(grads[k].double().norm()) for k in names])
         named = dict(net.named_parameters())
         out[p + 'param_norms'] = np.array([float(named[k].detach().double().norm()) for k in names])
-        for k in keep:
+        for k in (keep if full else ()):
             out[p + 'grad/' + k] = grads[k].numpy()
             out[p + 'param/' + k] = named[k].detach().numpy().copy()
     path = os.path.join(HERE, name + '.npz')
@@ -207,6 +209,11 @@ def main():
         # what src/tta_main.py runs: legacy offsets; the canonical script's loss weights (adapt_nlspn_vkitti.sh) + a smoothness term
         if h * w < 20000:       # small sizes NOT divisible by 16 (decoder crops of nlspnmodel_adapt.py:474-490): full maps, batch 2
             run_case(ema, 'nlspn_%dx%d_n2_legacy' % (h, w), h, w, 2, 2, dict(hp, lr=3e-4), offset=True)
+            return
+        if len(sys.argv) > 2 and sys.argv[2].startswith('seq'):
+            # ONE parameter set adapted over a sequence of different frames (src/tta_main.py:504-804), scored forward after every step
+            k = int(sys.argv[2][3:])
+            run_case(ema, 'nlspn_%dx%d_legacy_seq%d' % (h, w, k), h, w, 1, k, dict(hp, lr=3e-4), offset=True, sampled=True, light=True)
             return
         if len(sys.argv) > 2 and sys.argv[2] == 'inner3':
             # BASELINE config 3 as stated: 3 TTA steps on the SAME frame (inner_iter 3, src/tta_main.py:579-636), scored forward after each

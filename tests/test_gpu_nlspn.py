@@ -490,3 +490,28 @@ def test_three_steps_on_one_full_size_frame_match_the_reference(golden_dir):
             np.testing.assert_allclose(gn, g[p + 'grad_norms'], rtol=TOL['default']['gnorm'], atol=1e-6)
         _check_map(eng.forward_eval(image1, sparse), g, p + 'depth_eval', 3e-5)          # (north_star bound on the scored tensor: 1e-3)
     eng.close()
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'mixed'])
+def test_one_parameter_set_over_a_sequence_of_frames_follows_the_reference(golden_dir, dtype):
+    """The reference adapts ONE parameter set over a whole dataset (src/tta_main.py:504-804).  24 different 96x320 frames through the REAL
+    reference (tests/golden/make_golden_nlspn.py 96x320 seq24), the scored eval forward after every step: measured on MI355X
+    (tools/exp/nlspn_seq_report.py) the scored depth stays at <= 8.3e-5 in the fp32 mode and <= 1.34e-4 in the mixed mode (both level off after
+    ~10 frames; round 5's mixed mode with bf16-rounded weights in the data gradients: 4.1e-4 and still rising) -- asserted at 2x at EVERY
+    step, far inside the north_star's 1e-3."""
+    g = np.load(os.path.join(golden_dir, 'nlspn_96x320_legacy_seq24.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    assert steps == 24 and int(g['same_frame']) == 0
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
+    hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=mid, dtype=dtype)
+    eng, sd, adapted = make_nlspn(n, h, w, hp, legacy=True)
+    bound, lbound = (1.7e-4, 3e-4) if dtype == 'fp32' else (2.7e-4, 1.6e-3)
+    pix = lambda t: t.detach().float().cpu().numpy().reshape(-1)[g['pix_idx']]
+    for s in range(steps):
+        raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(s, h, w, n)]
+        info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)
+        assert rel_mae(pix(depth), g['s%d/depth_train_pix' % s]) < bound, s
+        np.testing.assert_allclose(info.cpu().numpy(), g['s%d/loss_info' % s], rtol=lbound)
+        assert rel_mae(pix(eng.forward_eval(image1, sparse)), g['s%d/depth_eval_pix' % s]) < bound, s
+    eng.close()
+

@@ -250,6 +250,26 @@ def test_nlspn_oracle_matches_reference_96x320(golden_dir, name):
     _check_map(o.forward_eval(image1, sparse), g, 's0/depth_eval', 5e-5)
 
 
+def test_nlspn_oracle_follows_the_reference_over_a_sequence(golden_dir):
+    """ONE NLSPN parameter set adapted over different frames (src/tta_main.py:504-804; tests/golden/make_golden_nlspn.py 96x320 seq24): the
+    oracle against the first three steps of the REAL reference's 24 (the GPU test runs all of them)."""
+    from oracle import nlspn_oracle as N
+    g = np.load(os.path.join(golden_dir, 'nlspn_96x320_legacy_seq24.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    assert steps == 24 and int(g['same_frame']) == 0
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
+    torch.set_num_threads(8)
+    o = N.NlspnOracle(synth.formula_state_dict_nlspn(), max_input_depth=mid, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd,
+                      w_sd=w_sd, w_sm=w_sm, w_cos=w_cos, legacy=True)
+    for s in range(3):
+        raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(s, h, w, n)]
+        r = o.step(image1, sparse, loss_image=raw)
+        _check_map(r['depth'], g, 's%d/depth_train' % s, 5e-5 if s == 0 else 2e-4)
+        li = r['loss_info']
+        np.testing.assert_allclose([li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], g['s%d/loss_info' % s], rtol=3e-4)
+        _check_map(o.forward_eval(image1, sparse), g, 's%d/depth_eval' % s, 2e-4)
+
+
 # ---- CostDCNet (SURVEY.md §8 a17): oracle/costdcnet_oracle.py against tests/golden/costdcnet_*.npz ----------------------
 def costdc_frame(idx, h, w, n, density):
     image01, sparse = synth.synthetic_frame(idx, h, w, n, density=density, dmin=0.3, dmax=7.5)

@@ -59,7 +59,7 @@ def install_cpu_syncbn():
     nn.SyncBatchNorm.forward = forward
 
 
-def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False, syncbn=False):
+def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False, syncbn=False, light=False, alt=False, out=None, prefix=''):
     """syncbn: the reference's DDP run converts every BatchNorm to SyncBatchNorm BEFORE adapt_parameters('meta_bn') (src/tta_main.py:326,339):
     the isinstance test of src/costdcnet_model_adapt.py:364-366 then matches every BatchNorm of the model (116 entries; ResBlock.norm3 and its
     alias inside `downsample` become two modules sharing one Parameter, which therefore appears TWICE in the list and gets two Adam updates
@@ -74,18 +74,23 @@ def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False, syncbn=Fals
         install_cpu_syncbn()
         model.convert_syncbn()
     params = model.adapt_parameters(mode='meta_bn')
+    if prefix:       # the reference against ITSELF: one adapted weight one ulp off -- how far its own trajectory moves (the sensitivity floor)
+        with torch.no_grad():
+            params[0].view(-1)[0] = torch.nextafter(params[0].view(-1)[0], torch.tensor(float('inf')))
     pnames = {id(p): k for k, p in net.named_parameters()}
     names = [pnames[id(p)] for p in params]
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')                 # syncbn: "optimizer contains a parameter group with duplicate parameters"
         opt = torch.optim.Adam(params, lr=HP['lr'], betas=HP['betas'], eps=HP['eps'], weight_decay=HP['weight_decay'])
-    out = {'meta': np.array([h, w, n, steps], dtype=np.int64), 'density': np.array(density),
-           'hp': np.array([HP['lr'], HP['betas'][0], HP['betas'][1], HP['eps'], HP['weight_decay'], HP['w_sd'], HP['w_sm'], HP['w_cos'],
-                           MAX_DEPTH], dtype=np.float64),
-           'adapted_names': np.array(names)}
-    if sampled:
-        out['pix_idx'] = pix_index(n * h * w)
+    own = out is None
+    if own:
+        out = {'meta': np.array([h, w, n, steps], dtype=np.int64), 'density': np.array(density),
+               'hp': np.array([HP['lr'], HP['betas'][0], HP['betas'][1], HP['eps'], HP['weight_decay'], HP['w_sd'], HP['w_sm'], HP['w_cos'],
+                               MAX_DEPTH], dtype=np.float64),
+               'adapted_names': np.array(names)}
+        if sampled:
+            out['pix_idx'] = pix_index(n * h * w)
     for s in range(steps):
         raw, image1, sparse_np = costdc_frame(s, h, w, n, density)
         image, sparse, loss_image = torch.from_numpy(image1), torch.from_numpy(sparse_np), torch.from_numpy(raw)
@@ -104,13 +109,19 @@ def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False, syncbn=Fals
         model.eval()
         with torch.no_grad():
             depth_eval = model.forward(image=image, sparse_depth=sparse, intrinsics=K, loss_type=LOSS_TYPE)
-        p = 's%d/' % s
+        p = prefix + 's%d/' % s
+        if prefix:          # the perturbed trajectory: the scored depth's sampled pixels only
+            summarise(out, p + 'depth_eval', depth_eval, blk=False)
+            continue
         if sampled:
-            summarise(out, p + 'depth_train', depth)
-            summarise(out, p + 'depth_eval', depth_eval)
+            summarise(out, p + 'depth_train', depth, blk=not light)
+            summarise(out, p + 'depth_eval', depth_eval, blk=not light)
         else:
             out[p + 'depth_train'] = depth.detach().numpy()
             out[p + 'depth_eval'] = depth_eval.numpy()
+        out[p + 'loss_info'] = np.array([float(torch.as_tensor(info[k]).detach()) for k in ('loss', 'loss_smooth', 'loss_sparse_depth', 'loss_cos')])
+        if light and s not in (0, steps - 1):
+            continue
         e, r = emb.detach().numpy(), ref.detach().numpy()
         idx, out[p + 'emb_rows'] = MG.sample_rows(e)
         _, out[p + 'ref_rows'] = MG.sample_rows(r)
@@ -128,6 +139,10 @@ def run_case(ema, name, h, w, n, steps, density=0.05, sampled=False, syncbn=Fals
                 out[p + 'buf/' + k] = v.numpy().copy()
         print(name, 'step', s, 'loss_info', out[p + 'loss_info'], 'depth mean', float(depth.mean()), float(depth_eval.mean()),
               'points', int((sparse > 0).sum()), flush=True)
+    if not own:
+        return
+    if alt:
+        run_case(ema, name, h, w, n, steps, density, sampled, syncbn, light, out=out, prefix='alt/')
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), flush=True)
@@ -139,6 +154,8 @@ CASES = {
     'costdcnet_72x100_pad': lambda e: run_case(e, 'costdcnet_72x100_pad', 72, 100, 1, 1),       # dual-corner padding, odd pooled sizes
     'costdcnet_320x400': lambda e: run_case(e, 'costdcnet_320x400', 320, 400, 1, 1, density=0.012, sampled=True),   # the ScanNet script's frame
     'costdcnet_64x64_n2_syncbn': lambda e: run_case(e, 'costdcnet_64x64_n2_syncbn', 64, 64, 2, 2, syncbn=True),      # the DDP run's adapted set (116 entries)
+    # ONE parameter set over 16 different frames (src/tta_main.py:504-804), with the reference's own one-ulp-perturbed trajectory beside it
+    'costdcnet_96x128_seq16': lambda e: run_case(e, 'costdcnet_96x128_seq16', 96, 128, 1, 16, density=0.03, sampled=True, light=True, alt=True),
     'costdcnet_480x640': lambda e: run_case(e, 'costdcnet_480x640', 480, 640, 1, 1, density=1500.0 / (480 * 640), sampled=True),  # config 5
 }
 

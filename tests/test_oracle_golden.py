@@ -311,6 +311,28 @@ def test_costdcnet_oracle_matches_reference(golden_dir, name):
         assert rel_mae(o.forward_eval(image1, sparse), g[p + 'depth_eval']) < 1e-5
 
 
+def test_costdcnet_oracle_follows_the_reference_while_the_reference_follows_itself(golden_dir):
+    """16 different frames through the REAL reference with ONE parameter set (costdcnet_96x128_seq16) and, beside it, the reference with one
+    adapted weight one ulp off: it separates from itself by 1.2e-3 after four frames (arg-max over the cost volume).  The oracle is held to
+    the first three steps, where the reference still is its own witness."""
+    from oracle import costdcnet_oracle as CO
+    g = np.load(os.path.join(golden_dir, 'costdcnet_96x128_seq16.npz'))
+    h, w, n, steps = [int(x) for x in g['meta']]
+    lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, max_depth = [float(x) for x in g['hp']]
+    floor = [rel_mae(g['alt/s%d/depth_eval_pix' % s], g['s%d/depth_eval_pix' % s]) for s in range(steps)]
+    assert floor[0] < 1e-5 and floor[2] < 1e-3 < floor[3] and floor[-1] > 2e-2
+    torch.set_num_threads(4)
+    o = CO.CostDcnOracle(synth.formula_state_dict_costdcnet(), max_depth=max_depth, lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd,
+                         w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
+    for s in range(3):
+        raw, image1, sparse = [torch.from_numpy(x) for x in costdc_frame(s, h, w, n, float(g['density']))]
+        r = o.step(image1, sparse, loss_image=raw)
+        li = r['loss_info']
+        np.testing.assert_allclose([li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], g['s%d/loss_info' % s], rtol=1e-3, atol=1e-7)
+        d = o.forward_eval(image1, sparse).detach().numpy().reshape(-1)[g['pix_idx']]
+        assert rel_mae(d, g['s%d/depth_eval_pix' % s]) < (1e-5 if s == 0 else 5e-4), s
+
+
 def test_costdcnet_oracle_syncbn_adapted_matches_reference(golden_dir):
     """The adapted set of the reference's DDP run: convert_syncbn() BEFORE adapt_parameters('meta_bn') (src/tta_main.py:326,339) ->
     116 entries (every BatchNorm incl. UNet3D's, the heads' and the sparse encoder's; ResBlock.norm3 listed twice and stepped twice by

@@ -164,6 +164,9 @@ CASES = {
     # the headline size (BASELINE config 2) over 120 frames: ~25 min of CPU for the two trajectories
     'msgchn_1layer_352x1216_seq120': lambda e: run_case(e, 'msgchn_1layer_352x1216_seq120', 'meta_selfsup_seq_1layer_ema', 352, 1216, 1, 120,
                                                         full_every=30, frame0=4000, light=True, moments=False, alt=True),
+    # the other meta mode (conv1_rgb_meta + its BatchNorm2d, network_exp_msg_chn_adapt.py 2layers) over 80 frames
+    'msgchn_2layers_256x320_seq80': lambda e: run_case(e, 'msgchn_2layers_256x320_seq80', 'meta_selfsup_seq_2layers_ema', 256, 320, 1, 80,
+                                                       full_every=20, frame0=6000, light=True, moments=False, alt=True),
     'eval_metrics': lambda e: run_eval_metrics(),
 }
 

@@ -126,7 +126,7 @@ def sample_rows(x, k=24):
     return idx, x[idx]
 
 
-def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_frame=False, light=False):
+def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_frame=False, light=False, alt=False, out=None, prefix=''):
     model = ema.ExternalModel_Adapt('nlspn', 0.0, 80.0, max_input_depth=hp['max_input_depth'], offset=offset, device=torch.device('cpu'))
     model._prepare_head(PREPARE)
     net = model.model.model
@@ -134,13 +134,18 @@ def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_fr
     assert list(sd.keys()) == list(net.state_dict().keys()), 'key table drifted from reference'
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     params = model.adapt_parameters(mode='meta_bn')
+    if prefix:       # the reference against ITSELF: one adapted weight one ulp off (the sensitivity floor of its own trajectory)
+        with torch.no_grad():
+            params[0].view(-1)[0] = torch.nextafter(params[0].view(-1)[0], torch.tensor(float('inf')))
     pnames = {id(p): k for k, p in net.named_parameters()}
     names = [pnames[id(p)] for p in params]
     opt = torch.optim.Adam(params, lr=hp['lr'], betas=hp['betas'], eps=hp['eps'], weight_decay=hp['weight_decay'])
-    out = {'meta': np.array([h, w, n, steps], dtype=np.int64),
-           'hp': np.array([hp['lr'], hp['betas'][0], hp['betas'][1], hp['eps'], hp['weight_decay'], hp['w_sd'], hp['w_sm'],
-                           hp['w_cos'], hp['max_input_depth']], dtype=np.float64),
-           'adapted_names': np.array(names), 'legacy': np.array(int(offset)), 'same_frame': np.array(int(same_frame))}
+    own = out is None
+    if own:
+        out = {'meta': np.array([h, w, n, steps], dtype=np.int64),
+               'hp': np.array([hp['lr'], hp['betas'][0], hp['betas'][1], hp['eps'], hp['weight_decay'], hp['w_sd'], hp['w_sm'],
+                               hp['w_cos'], hp['max_input_depth']], dtype=np.float64),
+               'adapted_names': np.array(names), 'legacy': np.array(int(offset)), 'same_frame': np.array(int(same_frame))}
     # a subset of the 88 adapted tensors is stored per step (first/last layers, one per stage)
     keep = [k for k in names if k.startswith(('conv1_rgb_meta', 'conv2.0.bn1', 'conv3.0.downsample.1', 'conv5.2.bn2', 'conv6.1',
                                               'dec5.1', 'dec2.1', 'id_dec1.1', 'gd_dec1.1', 'cf_dec1.1'))]
@@ -162,7 +167,11 @@ def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_fr
         model.eval()
         with torch.no_grad():
             depth_eval = model.forward(image=image, sparse_depth=sparse, loss_type=LOSS_TYPE)
-        p = 's%d/' % s
+        p = prefix + 's%d/' % s
+        if prefix:          # the perturbed trajectory: the scored depth's sampled pixels only
+            from make_golden_fullsize import summarise
+            summarise(out, p + 'depth_eval', depth_eval, blk=False)
+            continue
         if sampled:         # full-size cases: checksums + 4096 sampled pixels + 8x8 block means (make_golden_fullsize.py)
             from make_golden_fullsize import pix_index, summarise
             out['pix_idx'] = pix_index(n * h * w)
@@ -191,6 +200,10 @@ def run_case(ema, name, h, w, n, steps, hp, offset=False, sampled=False, same_fr
         for k in (keep if full else ()):
             out[p + 'grad/' + k] = grads[k].numpy()
             out[p + 'param/' + k] = named[k].detach().numpy().copy()
+    if not own:
+        return
+    if alt:
+        run_case(ema, name, h, w, n, steps, hp, offset, sampled, same_frame, light, out=out, prefix='alt/')
     path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, {k: out['s%d/loss_info' % (steps - 1)] for k in ['last']},
@@ -213,7 +226,7 @@ def main():
         if len(sys.argv) > 2 and sys.argv[2].startswith('seq'):
             # ONE parameter set adapted over a sequence of different frames (src/tta_main.py:504-804), scored forward after every step
             k = int(sys.argv[2][3:])
-            run_case(ema, 'nlspn_%dx%d_legacy_seq%d' % (h, w, k), h, w, 1, k, dict(hp, lr=3e-4), offset=True, sampled=True, light=True)
+            run_case(ema, 'nlspn_%dx%d_legacy_seq%d' % (h, w, k), h, w, 1, k, dict(hp, lr=3e-4), offset=True, sampled=True, light=True, alt=True)
             return
         if len(sys.argv) > 2 and sys.argv[2] == 'inner3':
             # BASELINE config 3 as stated: 3 TTA steps on the SAME frame (inner_iter 3, src/tta_main.py:579-636), scored forward after each

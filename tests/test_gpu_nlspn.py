@@ -505,8 +505,11 @@ def test_one_parameter_set_over_a_sequence_of_frames_follows_the_reference(golde
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid = [float(x) for x in g['hp']]
     hp = dict(lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd, w_sparse_depth=w_sd, w_smoothness=w_sm, w_cos=w_cos, max_input_depth=mid, dtype=dtype)
     eng, sd, adapted = make_nlspn(n, h, w, hp, legacy=True)
-    bound, lbound = (1.7e-4, 3e-4) if dtype == 'fp32' else (2.7e-4, 1.6e-3)
+    bound, lbound = (1.7e-4, 4.4e-4) if dtype == 'fp32' else (2.7e-4, 1.6e-3)
     pix = lambda t: t.detach().float().cpu().numpy().reshape(-1)[g['pix_idx']]
+    # the fixture's own floor: the reference with one adapted weight one ulp off is 5.2e-5 from itself after the 24 frames
+    floor = rel_mae(g['alt/s%d/depth_eval_pix' % (steps - 1)], g['s%d/depth_eval_pix' % (steps - 1)])
+    assert 2e-5 < floor < 1.2e-4
     for s in range(steps):
         raw, image1, sparse = [torch.from_numpy(x).cuda() for x in nlspn_frame(s, h, w, n)]
         info, depth = eng.step(image1, sparse, loss_image=raw, want_depth=True)

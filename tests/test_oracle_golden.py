@@ -555,7 +555,8 @@ def reference_floor(g, steps):
     return np.maximum.accumulate(np.array(e))
 
 
-@pytest.mark.parametrize('name,max_steps', [('msgchn_1layer_64x96_seq200', 200), ('msgchn_1layer_256x320_seq150', 6), ('msgchn_1layer_352x1216_seq120', 2)])
+@pytest.mark.parametrize('name,max_steps', [('msgchn_1layer_64x96_seq200', 200), ('msgchn_1layer_256x320_seq150', 6), ('msgchn_1layer_352x1216_seq120', 2),
+                                            ('msgchn_2layers_256x320_seq80', 6)])
 def test_oracle_stays_on_the_reference_trajectory_over_a_long_horizon(golden_dir, name, max_steps):
     """ONE parameter set adapted over a stream of frames (src/tta_main.py:504-636): the oracle against the REAL reference's scored depth and loss
     terms at every step of the 200-step sequence.  Bit-identical at step 0; afterwards the two fp32 CPU programs separate at the rate the
@@ -566,7 +567,7 @@ def test_oracle_stays_on_the_reference_trajectory_over_a_long_horizon(golden_dir
     h, w, n, steps, frame0 = [int(x) for x in g['meta']]
     lr, b1, b2, eps, wd, w_sd, w_sm, w_cos, mid, gain = [float(x) for x in g['hp']]
     torch.set_num_threads(8)
-    mode = 'meta_selfsup_seq_1layer_ema'
+    mode = 'meta_selfsup_seq_2layers_ema' if '2layers' in name else 'meta_selfsup_seq_1layer_ema'
     o = O.MsgChnOracle(synth.formula_state_dict(mode, gain, 0.0), mode, max_input_depth=mid, lr=lr, betas=(b1, b2), eps=eps,
                        weight_decay=wd, w_sd=w_sd, w_sm=w_sm, w_cos=w_cos)
     floor = reference_floor(g, steps)

@@ -22,7 +22,7 @@ def run(name, dtype, pipelined, keep=(), options=None):
     g = np.load(os.path.join(GD, name + '.npz'))
     h, w, n, steps, frame0 = [int(x) for x in g['meta']]
     hp, gain = golden_hp(g)
-    eng, sd, adapted = make_engine(n, h, w, dtype, hp, gain, None, keep=keep, options=options)
+    eng, sd, adapted = make_engine(n, h, w, dtype, hp, gain, None, keep=keep, options=options, meta='2layers' if '2layers' in name else '1layer')
     frame = lambda s: [torch.from_numpy(x).cuda() for x in synth.synthetic_frame(frame0 + s, h, w, n)]
     cur = frame(0)
     de, li, rows = [], [], []

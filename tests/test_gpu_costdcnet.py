@@ -304,3 +304,25 @@ def test_sequence_of_frames_stays_as_close_to_the_reference_as_the_reference_to_
         assert err < 3.0 * floor[s] + 5e-4, (s, err, floor[s])
     eng.close()
 
+
+# quarter-resolution maps of 4..33 pixels per side, the dual-corner padded path (sizes not divisible by 8), odd batches
+COSTDC_SWEEP = [(1, 64, 64), (1, 40, 104), (2, 56, 72), (1, 68, 132), (3, 48, 40), (1, 100, 60)]
+
+
+@pytest.mark.parametrize('shape', COSTDC_SWEEP)
+def test_shape_sweep_against_oracle(shape):
+    """One full step (default arithmetic) + the eval forward from the ORACLE's post-step parameters and buffers at shapes around the tile
+    sizes of the 2-D and the P3D kernels."""
+    n, h, w = shape
+    eng, sd, adapted = make_costdc(n, h, w)
+    CO, o = _oracle()
+    raw, image1, sparse = [torch.from_numpy(x) for x in costdc_frame(2 + w, h, w, n)]
+    r = o.step(image1, sparse, loss_image=raw)
+    info, depth = eng.step(image1.cuda(), sparse.cuda(), loss_image=raw.cuda(), want_depth=True)
+    assert rel_mae(depth, r['depth']) < TOL['default']['depth'], rel_mae(depth, r['depth'])
+    li = r['loss_info']
+    np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=1e-3, atol=1e-7)
+    for k in eng.adapted:
+        assert rel_mae(eng.grad(k, adapted[k][0]), r['grads'][k]) < 2 * TOL['default']['grad'], (k, rel_mae(eng.grad(k, adapted[k][0]), r['grads'][k]))
+    eng.close()
+

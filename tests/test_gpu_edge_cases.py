@@ -285,3 +285,35 @@ def test_adapt_loop_with_look_ahead_equals_the_plain_loop():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         for pa, pb in zip(a[2], b[2]):
             assert torch.equal(pa, pb)
+
+
+# sizes chosen to land tile edges everywhere: widths around the 32-pixel tile and the 64-pixel strided tile, heights around the 8- / 4-row tiles,
+# not divisible by 16 (dual-corner padded path), odd batches; one full tile row more / less than a multiple
+SWEEP = [(1, 16, 16), (1, 17, 33), (2, 24, 100), (1, 40, 129), (3, 33, 65), (1, 72, 31), (2, 47, 94), (1, 129, 67), (1, 64, 257), (2, 81, 49)]
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'mixed'])
+@pytest.mark.parametrize('shape', SWEEP)
+def test_shape_sweep_against_oracle(shape, dtype):
+    """Every kernel's tile-edge handling at once: one full step + the scored eval forward from the ORACLE's post-step parameters, at ten
+    shapes around the tile sizes, both precision modes.  Bounds as test_other_config_shapes_against_oracle (fp32) / tests/test_gpu_mixed.py
+    (mixed: the real frames' forward is the fp32 one)."""
+    n, h, w = shape
+    eng, sd, adapted = make_engine(n, h, w, dtype, HP)
+    o = _oracle()
+    image, sparse = synth.synthetic_frame(11 + h + w, h, w, n, density=0.08, dmin=0.2, dmax=8.0)
+    r = o.step(torch.from_numpy(image), torch.from_numpy(sparse))
+    info, depth = eng.step(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda(), want_depth=True)
+    assert rel_mae(depth, r['depth']) < 1e-4, rel_mae(depth, r['depth'])
+    li = r['loss_info']
+    np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']],
+                               rtol=2e-4 if dtype == 'fp32' else 3e-3)
+    for k, (prm, m, v) in adapted.items():
+        g = eng.grad(k, prm)
+        assert rel_mae(g, r['grads'][k]) < (3e-2 if dtype == 'fp32' else 8e-2), (k, rel_mae(g, r['grads'][k]))
+        prm.copy_(o.P[k].detach())
+    d_eval = eng.forward_eval(torch.from_numpy(image).cuda(), torch.from_numpy(sparse).cuda())
+    ref_eval = o.forward_eval(torch.from_numpy(image), torch.from_numpy(sparse))
+    assert rel_mae(d_eval, ref_eval) < 1e-4, rel_mae(d_eval, ref_eval)
+    eng.close()
+

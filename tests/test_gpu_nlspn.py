@@ -518,3 +518,32 @@ def test_one_parameter_set_over_a_sequence_of_frames_follows_the_reference(golde
         assert rel_mae(pix(eng.forward_eval(image1, sparse)), g['s%d/depth_eval_pix' % s]) < bound, s
     eng.close()
 
+
+# tile edges of the generic engine's kernels (8x32-pixel tiles, 16-channel sub-chunks), the decoder crops of sizes not divisible by 16,
+# a one-tile map, odd batches
+NLSPN_SWEEP = [(1, 32, 48), (1, 24, 72), (2, 40, 56), (1, 33, 100), (3, 48, 36), (1, 70, 130)]
+
+
+@pytest.mark.parametrize('shape', NLSPN_SWEEP)
+def test_shape_sweep_against_oracle(shape):
+    """One full step (default arithmetic, legacy offsets) + the scored eval forward from the ORACLE's post-step parameters at shapes around every
+    tile size; gradients by norm (the full-tensor bound needs the exact mode, test_step_matches_golden)."""
+    n, h, w = shape
+    eng, sd, adapted = make_nlspn(n, h, w, legacy=True)
+    from oracle import nlspn_oracle as N
+    o = N.NlspnOracle(synth.formula_state_dict_nlspn(), max_input_depth=HP['max_input_depth'], lr=HP['lr'], betas=HP['betas'], eps=HP['eps'],
+                      weight_decay=HP['weight_decay'], w_sd=HP['w_sparse_depth'], w_sm=HP['w_smoothness'], w_cos=HP['w_cos'], legacy=True)
+    raw, image1, sparse = [torch.from_numpy(x) for x in nlspn_frame(3 + h, h, w, n)]
+    r = o.step(image1, sparse, loss_image=raw)
+    info, depth = eng.step(image1.cuda(), sparse.cuda(), loss_image=raw.cuda(), want_depth=True)
+    assert rel_mae(depth, r['depth']) < TOL['default']['depth'], rel_mae(depth, r['depth'])
+    li = r['loss_info']
+    np.testing.assert_allclose(info.cpu().numpy(), [li['loss'], li['loss_smooth'], li['loss_sparse_depth'], li['loss_cos']], rtol=2e-3)
+    gn = np.array([float(eng.grad(k, adapted[k][0]).double().norm()) for k in o.names])
+    gr = np.array([float(r['grads'][k].double().norm()) for k in o.names])
+    np.testing.assert_allclose(gn, gr, rtol=3 * TOL['default']['gnorm'], atol=1e-6)
+    for k in o.names:
+        adapted[k][0].copy_(o.P[k].detach())
+    assert rel_mae(eng.forward_eval(image1.cuda(), sparse.cuda()), o.forward_eval(image1, sparse)) < TOL['default']['depth']
+    eng.close()
+

@@ -654,6 +654,11 @@ int conv32(ptta_ctx* c, hipStream_t s, const std::string& layer, bool bwd, int m
     const long pin = (long)B * Hin * Win;
     const long pout = mode == CONV_S1 ? pin : (mode == CONV_S2 ? pin / 4 : pin * 4);
     const bool small = (long)Hin * Win <= (long)c->H4 * c->W4 * (mode == CONV_S2 ? 4 : 1);
+#ifdef PTTA_EXP_SKIP_PAIRED_S1
+    // timing-only (wrong values): the stride-1 half of every (stride-2 | transposed) -> stride-1 pair on maps <= 1/4 resolution is NOT launched --
+    // the upper bound of fusing each such pair into one launch
+    if (mode == CONV_S1 && small && layer.size() > 2 && layer.compare(layer.size() - 2, 2, ".3") == 0 && layer.find("prdct") == std::string::npos) return 0;
+#endif
     ProfScope ps(c, (mode == CONV_S1 ? (relu ? 0 : 2) : 4) + (small ? 1 : 0), s, (double)((pin + pout) * 32 + 9216) * es_l,
                  (double)(mode == CONV_T2 ? pin : pout) * 9.0 * 32.0 * 32.0, 1);
     return ptta_launch_conv32(a, s);

@@ -167,6 +167,9 @@ CASES = {
     # the other meta mode (conv1_rgb_meta + its BatchNorm2d, network_exp_msg_chn_adapt.py 2layers) over 80 frames
     'msgchn_2layers_256x320_seq80': lambda e: run_case(e, 'msgchn_2layers_256x320_seq80', 'meta_selfsup_seq_2layers_ema', 256, 320, 1, 80,
                                                        full_every=20, frame0=6000, light=True, moments=False, alt=True),
+    # N frames per call over a horizon: 3 frames per step, 60 steps (the reference's operating point is n_batch // ngpus frames per rank)
+    'msgchn_1layer_96x128_n3_seq60': lambda e: run_case(e, 'msgchn_1layer_96x128_n3_seq60', 'meta_selfsup_seq_1layer_ema', 96, 128, 3, 60,
+                                                        full_every=30, frame0=8000, light=True, moments=False, alt=True),
     'eval_metrics': lambda e: run_eval_metrics(),
 }
 

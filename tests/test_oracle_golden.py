@@ -556,7 +556,7 @@ def reference_floor(g, steps):
 
 
 @pytest.mark.parametrize('name,max_steps', [('msgchn_1layer_64x96_seq200', 200), ('msgchn_1layer_256x320_seq150', 6), ('msgchn_1layer_352x1216_seq120', 2),
-                                            ('msgchn_2layers_256x320_seq80', 6)])
+                                            ('msgchn_2layers_256x320_seq80', 6), ('msgchn_1layer_96x128_n3_seq60', 8)])
 def test_oracle_stays_on_the_reference_trajectory_over_a_long_horizon(golden_dir, name, max_steps):
     """ONE parameter set adapted over a stream of frames (src/tta_main.py:504-636): the oracle against the REAL reference's scored depth and loss
     terms at every step of the 200-step sequence.  Bit-identical at step 0; afterwards the two fp32 CPU programs separate at the rate the
